@@ -1,0 +1,126 @@
+/*
+ * ab_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the AstroBurst reference's pixel-compute hot path
+ * (Rust, src-tauri/src/core + src-tauri/src/math).  Every function cites the
+ * reference file:line it follows.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product library
+ * (astroburst_amd/csrc -> libastroburst_hip.so) never links or calls it.
+ *
+ * PARITY PINNING: the reference is Rust and cannot be built in this image
+ * (no rustc/cargo, un-vendored crates), and it ships no golden vectors -- only
+ * behavioural unit tests with loose tolerances.  The oracle is pinned against
+ * every one of those unit tests for the path (tests/test_oracle_reference_cases.py
+ * transcribes inputs + asserted tolerances).  For functions the reference does
+ * not test at all (stats.rs, channel_blend.rs, masked_stretch.rs, star_mask.rs)
+ * the oracle says "parity unpinned" next to the function.
+ *
+ * Arithmetic types follow the reference exactly (f32 vs f64 as cited).  Build
+ * with -ffp-contract=off: Rust never fuses a*b+c.
+ */
+#ifndef AB_ORACLE_H
+#define AB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- math/median.rs ---------------------------------------------------- */
+/* f32_cmp total order, NaN last (median.rs:4-13): returns <0, 0, >0 */
+int orc_f32_cmp(float a, float b);
+/* slice::select_nth_unstable_by(k, f32_cmp): after the call a[k] is the k-th
+ * order statistic, everything before is <=, everything after is >=.  The
+ * permutation of the rest is unspecified in Rust too. */
+void orc_select_nth_f32(float *a, size_t n, size_t k);
+double orc_exact_median_mut(float *data, size_t n);            /* median.rs:27-44 */
+float orc_median_f32_mut(float *data, size_t n);               /* median.rs:46-63 */
+float orc_exact_mad_mut(float *data, size_t n, float median);  /* median.rs:65-73 */
+/* sigma_clip.rs:4-34; values is compacted in place, *n updated */
+void orc_sigma_clipped_stats(float *values, size_t *n, float kappa, size_t iterations,
+                             double *out_median, double *out_sigma);
+
+/* ---- core/stacking/combine.rs ------------------------------------------ */
+/* Summation-order modes for iterations >= 1 (combine.rs:50-60,90).  The
+ * reference sums the survivors in whatever order select_nth_unstable left
+ * them (unspecified).  ORC_ORDER_SELECT sums in the order our quickselect
+ * leaves; ORC_ORDER_ASCENDING sorts the survivors ascending first -- a
+ * function of the multiset only, which is what the HIP kernel reproduces
+ * bit-for-bit.  Both agree to <= 1 ulp(f64) before the f32 cast. */
+enum { ORC_ORDER_SELECT = 0, ORC_ORDER_ASCENDING = 1 };
+
+/* combine.rs:14-92.  values is scratch (permuted/compacted). */
+float orc_sigma_clip_combine(float *values, size_t n, float sigma_low, float sigma_high,
+                             size_t max_iter, int order_mode, uint32_t *out_rejected);
+
+/* combine.rs:94-193 with config.align == false (crop to min dims, gather
+ * finite values per pixel in frame order, sigma_clip_combine).  planes[i] is
+ * rows[i] x cols[i] row-major.  out is min_rows x min_cols.  Returns 0, or
+ * -1 for "No images to stack" (combine.rs:98-100).  threads<=0 -> all cores. */
+int orc_stack_images_noalign(const float *const *planes, const int64_t *rows, const int64_t *cols,
+                             size_t n_images, float sigma_low, float sigma_high, size_t max_iter,
+                             int order_mode, int threads, float *out, uint64_t *out_rejected,
+                             int64_t *out_rows, int64_t *out_cols);
+
+/* Two-level estimator used by the frame-sharded multi-GPU mode:
+ * per-pixel kept-sum (f64) and kept-count of one shard, same clipping as
+ * sigma_clip_combine.  Not a reference function; restated here so the N>1
+ * path has a CPU checker. */
+void orc_stack_partial_noalign(const float *const *planes, size_t n_images, int64_t npix,
+                               float sigma_low, float sigma_high, size_t max_iter, int threads,
+                               double *out_sum, uint32_t *out_cnt, uint64_t *out_rejected);
+
+/* ---- core/imaging/sampling.rs, boundary.rs ------------------------------ */
+double orc_catmull_rom(double t);                                        /* sampling.rs:4-14 */
+size_t orc_clamp_index(int64_t idx, size_t len);                         /* boundary.rs:9-20 */
+float orc_nearest_sample(const float *s, size_t rows, size_t cols, double y, double x);   /* :16-24 */
+float orc_bilinear_sample(const float *s, size_t rows, size_t cols, double y, double x);  /* :26-49 */
+float orc_bicubic_sample(const float *s, size_t rows, size_t cols, double y, double x);   /* :51-80 */
+
+/* ---- core/stacking/align.rs, core/alignment/affine.rs ------------------- */
+/* align.rs:36-57 */
+void orc_shift_image_subpixel(const float *src, size_t rows, size_t cols, double dy, double dx,
+                              int threads, float *out);
+/* affine.rs:663-690; t = {a,b,tx,c,d,ty} maps OUTPUT (x,y) -> SOURCE (sx,sy) */
+void orc_warp_image(const float *src, size_t src_rows, size_t src_cols, const double t[6],
+                    size_t out_rows, size_t out_cols, int threads, float *out);
+
+/* ---- core/imaging/stats.rs  (reference has NO tests here: parity unpinned,
+ *      the restatement itself is the pin) --------------------------------- */
+typedef struct {
+    double min, max, median, mad, sigma, mean;
+    uint64_t valid_count;
+} orc_image_stats;
+
+void orc_compute_image_stats(const float *data, size_t n, orc_image_stats *out);  /* stats.rs:15-23 */
+void orc_compute_image_stats_exact(const float *data, size_t n, orc_image_stats *out); /* :43-73 */
+void orc_compute_image_stats_hist(const float *data, size_t n, orc_image_stats *out);  /* :75-210 */
+void orc_compute_image_stats_with_known_range(const float *data, size_t n, double known_min,
+                                              double known_max, orc_image_stats *out); /* :25-41 */
+/* stats.rs:378-421 build_histogram; bins out u32[bins]; returns 1 if range<1e-10 (all-zero bins) */
+int orc_build_histogram(const float *data, size_t n, size_t bins, double dmin, double dmax,
+                        uint32_t *out_bins);
+/* intermediate histograms of the >4M path, exposed so the GPU histograms can
+ * be checked bin-for-bin: pass 2 (value hist) for a given min/max */
+void orc_stats_value_hist(const float *data, size_t n, double gmin, double gmax, uint64_t *hist65536,
+                          double *out_sum, uint64_t *out_cnt);
+
+/* ---- core/imaging/stf.rs ------------------------------------------------ */
+typedef struct { double shadow, midtone, highlight; } orc_stf_params;
+void orc_auto_stf(const orc_image_stats *st, double target_bg, double shadow_k, orc_stf_params *out); /* stf.rs:13-39 */
+double orc_mtf(double x, double m);                                     /* stf.rs:50-58 */
+double orc_mtf_balance(double m, double t);                             /* stf.rs:41-47 */
+void orc_apply_stf_u8(const float *data, size_t n, const orc_stf_params *p, const orc_image_stats *st,
+                      int threads, uint8_t *out);                        /* stf.rs:89-102 */
+void orc_apply_stf_f32(const float *data, size_t n, const orc_stf_params *p, const orc_image_stats *st,
+                       int threads, float *out);                         /* stf.rs:104-120,147-155 */
+
+/* utility */
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,338 @@
+"""ctypes binding of the CPU ORACLE (test infrastructure, NOT product code).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It loads oracle/liboracle.so (the plain-C restatement of the
+reference's Rust hot path, see oracle/ab_oracle.h) and exposes numpy-friendly
+wrappers named after the reference functions they restate.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+ORDER_SELECT = 0
+ORDER_ASCENDING = 1
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/*.c into liboracle.so (gcc, see oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+class _Stats(C.Structure):
+    _fields_ = [("min", C.c_double), ("max", C.c_double), ("median", C.c_double), ("mad", C.c_double),
+                ("sigma", C.c_double), ("mean", C.c_double), ("valid_count", C.c_uint64)]
+
+
+class _Stf(C.Structure):
+    _fields_ = [("shadow", C.c_double), ("midtone", C.c_double), ("highlight", C.c_double)]
+
+
+@dataclass
+class ImageStats:  # types/image.rs:2-10
+    min: float = 0.0
+    max: float = 0.0
+    median: float = 0.0
+    mad: float = 0.0
+    sigma: float = 0.0
+    mean: float = 0.0
+    valid_count: int = 0
+
+
+@dataclass
+class StfParams:  # types/image.rs:36-40
+    shadow: float = 0.0
+    midtone: float = 0.5
+    highlight: float = 1.0
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    try:
+        L = C.CDLL(_LIB_PATH)
+    except OSError:
+        build(force=True)
+        L = C.CDLL(_LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    L.orc_f32_cmp.restype = C.c_int
+    L.orc_f32_cmp.argtypes = [C.c_float, C.c_float]
+    L.orc_select_nth_f32.argtypes = [fp, C.c_size_t, C.c_size_t]
+    L.orc_exact_median_mut.restype = C.c_double
+    L.orc_exact_median_mut.argtypes = [fp, C.c_size_t]
+    L.orc_median_f32_mut.restype = C.c_float
+    L.orc_median_f32_mut.argtypes = [fp, C.c_size_t]
+    L.orc_exact_mad_mut.restype = C.c_float
+    L.orc_exact_mad_mut.argtypes = [fp, C.c_size_t, C.c_float]
+    L.orc_sigma_clipped_stats.argtypes = [fp, C.POINTER(C.c_size_t), C.c_float, C.c_size_t,
+                                          C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_sigma_clip_combine.restype = C.c_float
+    L.orc_sigma_clip_combine.argtypes = [fp, C.c_size_t, C.c_float, C.c_float, C.c_size_t, C.c_int,
+                                         C.POINTER(C.c_uint32)]
+    L.orc_stack_images_noalign.restype = C.c_int
+    L.orc_stack_images_noalign.argtypes = [C.POINTER(fp), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                           C.c_size_t, C.c_float, C.c_float, C.c_size_t, C.c_int, C.c_int,
+                                           fp, C.POINTER(C.c_uint64), C.POINTER(C.c_int64),
+                                           C.POINTER(C.c_int64)]
+    L.orc_stack_partial_noalign.argtypes = [C.POINTER(fp), C.c_size_t, C.c_int64, C.c_float, C.c_float,
+                                            C.c_size_t, C.c_int, C.POINTER(C.c_double),
+                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.orc_catmull_rom.restype = C.c_double
+    L.orc_catmull_rom.argtypes = [C.c_double]
+    L.orc_clamp_index.restype = C.c_size_t
+    L.orc_clamp_index.argtypes = [C.c_int64, C.c_size_t]
+    for name in ("orc_nearest_sample", "orc_bilinear_sample", "orc_bicubic_sample"):
+        f = getattr(L, name)
+        f.restype = C.c_float
+        f.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_double, C.c_double]
+    L.orc_shift_image_subpixel.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_int, fp]
+    L.orc_warp_image.argtypes = [fp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.c_size_t, C.c_size_t,
+                                 C.c_int, fp]
+    sp = C.POINTER(_Stats)
+    for name in ("orc_compute_image_stats", "orc_compute_image_stats_exact", "orc_compute_image_stats_hist"):
+        getattr(L, name).argtypes = [fp, C.c_size_t, sp]
+    L.orc_compute_image_stats_with_known_range.argtypes = [fp, C.c_size_t, C.c_double, C.c_double, sp]
+    L.orc_build_histogram.restype = C.c_int
+    L.orc_build_histogram.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_double, C.c_double,
+                                      C.POINTER(C.c_uint32)]
+    L.orc_stats_value_hist.argtypes = [fp, C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.orc_auto_stf.argtypes = [sp, C.c_double, C.c_double, C.POINTER(_Stf)]
+    L.orc_mtf.restype = C.c_double
+    L.orc_mtf.argtypes = [C.c_double, C.c_double]
+    L.orc_mtf_balance.restype = C.c_double
+    L.orc_mtf_balance.argtypes = [C.c_double, C.c_double]
+    L.orc_apply_stf_u8.argtypes = [fp, C.c_size_t, C.POINTER(_Stf), sp, C.c_int, C.POINTER(C.c_uint8)]
+    L.orc_apply_stf_f32.argtypes = [fp, C.c_size_t, C.POINTER(_Stf), sp, C.c_int, fp]
+    L.orc_max_threads.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+# ---- math/median.rs -------------------------------------------------------
+def f32_cmp(a: float, b: float) -> int:
+    return int(lib().orc_f32_cmp(a, b))
+
+
+def select_nth(values, k: int) -> np.ndarray:
+    v = _f32(values).copy()
+    lib().orc_select_nth_f32(_fp(v), v.size, k)
+    return v
+
+
+def exact_median_mut(values) -> float:
+    v = _f32(values).copy()
+    return float(lib().orc_exact_median_mut(_fp(v), v.size))
+
+
+def median_f32_mut(values) -> float:
+    v = _f32(values).copy()
+    return float(lib().orc_median_f32_mut(_fp(v), v.size))
+
+
+def exact_mad_mut(values, median: float) -> float:
+    v = _f32(values).copy()
+    return float(lib().orc_exact_mad_mut(_fp(v), v.size, median))
+
+
+def sigma_clipped_stats(values, kappa: float, iterations: int):
+    v = _f32(values).copy()
+    if v.size == 0:
+        v = np.zeros(1, np.float32)
+        n = C.c_size_t(0)
+    else:
+        n = C.c_size_t(v.size)
+    med, sig = C.c_double(), C.c_double()
+    lib().orc_sigma_clipped_stats(_fp(v), C.byref(n), kappa, iterations, C.byref(med), C.byref(sig))
+    return med.value, sig.value
+
+
+# ---- core/stacking/combine.rs --------------------------------------------
+def sigma_clip_combine(values, sigma_low=3.0, sigma_high=3.0, max_iter=5, order=ORDER_ASCENDING):
+    v = _f32(values).copy()
+    n = v.size
+    if n == 0:
+        v = np.zeros(1, np.float32)
+    rej = C.c_uint32(0)
+    r = lib().orc_sigma_clip_combine(_fp(v), n, sigma_low, sigma_high, max_iter, order, C.byref(rej))
+    return np.float32(r), int(rej.value)
+
+
+def stack_images(images, sigma_low=3.0, sigma_high=3.0, max_iterations=5, order=ORDER_ASCENDING, threads=0):
+    """combine.rs:94-193 with align=false.  Returns (image, rejected_pixels)."""
+    imgs = [_f32(im) for im in images]
+    n = len(imgs)
+    if n == 0:
+        raise ValueError("No images to stack")
+    rows = (C.c_int64 * n)(*[im.shape[0] for im in imgs])
+    cols = (C.c_int64 * n)(*[im.shape[1] for im in imgs])
+    ptrs = (C.POINTER(C.c_float) * n)(*[_fp(im) for im in imgs])
+    r = min(im.shape[0] for im in imgs)
+    c = min(im.shape[1] for im in imgs)
+    out = np.zeros((r, c), np.float32)
+    rej = C.c_uint64(0)
+    orow, ocol = C.c_int64(0), C.c_int64(0)
+    rc = lib().orc_stack_images_noalign(ptrs, rows, cols, n, sigma_low, sigma_high, max_iterations, order,
+                                        threads, _fp(out), C.byref(rej), C.byref(orow), C.byref(ocol))
+    if rc != 0:
+        raise ValueError("No images to stack")
+    return out, int(rej.value)
+
+
+def stack_partial(images, sigma_low=3.0, sigma_high=3.0, max_iterations=5, threads=0):
+    imgs = [_f32(im) for im in images]
+    n = len(imgs)
+    npix = imgs[0].size
+    ptrs = (C.POINTER(C.c_float) * n)(*[_fp(im) for im in imgs])
+    s = np.zeros(imgs[0].shape, np.float64)
+    cnt = np.zeros(imgs[0].shape, np.uint32)
+    rej = C.c_uint64(0)
+    lib().orc_stack_partial_noalign(ptrs, n, npix, sigma_low, sigma_high, max_iterations, threads,
+                                    s.ctypes.data_as(C.POINTER(C.c_double)),
+                                    cnt.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(rej))
+    return s, cnt, int(rej.value)
+
+
+# ---- sampling / warp --------------------------------------------------------
+def catmull_rom(t: float) -> float:
+    return float(lib().orc_catmull_rom(t))
+
+
+def clamp_index(idx: int, length: int) -> int:
+    return int(lib().orc_clamp_index(idx, length))
+
+
+def _sample(fn, data, rows, cols, y, x):
+    d = _f32(data).ravel()
+    if d.size == 0:
+        return float(fn(None, rows, cols, y, x))
+    return float(fn(_fp(d), rows, cols, y, x))
+
+
+def nearest_sample(data, rows, cols, y, x):
+    return _sample(lib().orc_nearest_sample, data, rows, cols, y, x)
+
+
+def bilinear_sample(data, rows, cols, y, x):
+    return _sample(lib().orc_bilinear_sample, data, rows, cols, y, x)
+
+
+def bicubic_sample(data, rows, cols, y, x):
+    return _sample(lib().orc_bicubic_sample, data, rows, cols, y, x)
+
+
+def shift_image_subpixel(image, dy: float, dx: float, threads=0) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros_like(im)
+    lib().orc_shift_image_subpixel(_fp(im), im.shape[0], im.shape[1], dy, dx, threads, _fp(out))
+    return out
+
+
+def warp_image(image, transform, out_rows: int, out_cols: int, threads=0) -> np.ndarray:
+    """transform = (a, b, tx, c, d, ty), maps output (x, y) -> source (sx, sy)."""
+    im = _f32(image)
+    t = (C.c_double * 6)(*[float(v) for v in transform])
+    out = np.zeros((out_rows, out_cols), np.float32)
+    lib().orc_warp_image(_fp(im), im.shape[0], im.shape[1], t, out_rows, out_cols, threads, _fp(out))
+    return out
+
+
+# ---- stats / stf --------------------------------------------------------------
+def _stats_out(s: _Stats) -> ImageStats:
+    return ImageStats(s.min, s.max, s.median, s.mad, s.sigma, s.mean, int(s.valid_count))
+
+
+def _stats_in(st: ImageStats) -> _Stats:
+    return _Stats(st.min, st.max, st.median, st.mad, st.sigma, st.mean, st.valid_count)
+
+
+def compute_image_stats(image, path: str = "auto") -> ImageStats:
+    im = _f32(image).ravel()
+    s = _Stats()
+    fn = {"auto": lib().orc_compute_image_stats, "exact": lib().orc_compute_image_stats_exact,
+          "hist": lib().orc_compute_image_stats_hist}[path]
+    fn(_fp(im), im.size, C.byref(s))
+    return _stats_out(s)
+
+
+def compute_image_stats_with_known_range(image, known_min, known_max) -> ImageStats:
+    im = _f32(image).ravel()
+    s = _Stats()
+    lib().orc_compute_image_stats_with_known_range(_fp(im), im.size, known_min, known_max, C.byref(s))
+    return _stats_out(s)
+
+
+def build_histogram(image, bins: int, dmin: float, dmax: float) -> np.ndarray:
+    im = _f32(image).ravel()
+    out = np.zeros(bins, np.uint32)
+    lib().orc_build_histogram(_fp(im), im.size, bins, dmin, dmax, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    return out
+
+
+def stats_value_hist(image, gmin: float, gmax: float):
+    im = _f32(image).ravel()
+    h = np.zeros(65536, np.uint64)
+    s, c = C.c_double(), C.c_uint64()
+    lib().orc_stats_value_hist(_fp(im), im.size, gmin, gmax, h.ctypes.data_as(C.POINTER(C.c_uint64)),
+                               C.byref(s), C.byref(c))
+    return h, s.value, int(c.value)
+
+
+def auto_stf(stats: ImageStats, target_bg=0.25, shadow_k=-2.8) -> StfParams:
+    s = _stats_in(stats)
+    p = _Stf()
+    lib().orc_auto_stf(C.byref(s), target_bg, shadow_k, C.byref(p))
+    return StfParams(p.shadow, p.midtone, p.highlight)
+
+
+def mtf(x: float, m: float) -> float:
+    return float(lib().orc_mtf(x, m))
+
+
+def mtf_balance(m: float, t: float) -> float:
+    return float(lib().orc_mtf_balance(m, t))
+
+
+def apply_stf(image, params: StfParams, stats: ImageStats, threads=0) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros(im.shape, np.uint8)
+    p = _Stf(params.shadow, params.midtone, params.highlight)
+    s = _stats_in(stats)
+    lib().orc_apply_stf_u8(_fp(im), im.size, C.byref(p), C.byref(s), threads,
+                           out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def apply_stf_f32(image, params: StfParams, stats: ImageStats, threads=0) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros(im.shape, np.float32)
+    p = _Stf(params.shadow, params.midtone, params.highlight)
+    s = _stats_in(stats)
+    lib().orc_apply_stf_f32(_fp(im), im.size, C.byref(p), C.byref(s), threads, _fp(out))
+    return out
