@@ -1,0 +1,121 @@
+"""ctypes binding of libastroburst_hip.so (the C ABI in include/astroburst_hip.h).
+
+The library is the product; this module only loads it and declares prototypes.  There is NO
+CPU fallback: if the shared object is missing or no gfx950 device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libastroburst_hip.so")
+HEADER_PATH = os.path.join(ROOT, "include", "astroburst_hip.h")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class AstroBurstError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[ab_status {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+AB_OK, AB_ERR_INVALID, AB_ERR_HIP, AB_ERR_NO_DEVICE, AB_ERR_UNSUPPORTED, AB_ERR_NOMEM = range(6)
+
+
+class Plane(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("on_device", C.c_int32)]
+
+
+class StackConfig(C.Structure):  # types/stacking.rs:3-20
+    _fields_ = [("sigma_low", C.c_float), ("sigma_high", C.c_float), ("max_iterations", C.c_uint32),
+                ("align", C.c_int32)]
+
+
+class ImageStatsC(C.Structure):  # types/image.rs:2-10
+    _fields_ = [("min", C.c_double), ("max", C.c_double), ("median", C.c_double), ("mad", C.c_double),
+                ("sigma", C.c_double), ("mean", C.c_double), ("valid_count", C.c_uint64)]
+
+
+class StfParamsC(C.Structure):  # types/image.rs:36-40
+    _fields_ = [("shadow", C.c_double), ("midtone", C.c_double), ("highlight", C.c_double)]
+
+
+class AutoStfConfigC(C.Structure):  # types/image.rs:52-65
+    _fields_ = [("target_bg", C.c_double), ("shadow_k", C.c_double)]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 every csrc/*.hip into astroburst_amd/libastroburst_hip.so."""
+    cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise RuntimeError("building libastroburst_hip.so failed")
+    return LIB_PATH
+
+
+def declared_symbols() -> list[str]:
+    """Every entry point include/astroburst_hip.h declares."""
+    text = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"AB_API[^;(]*?\b(ab_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AstroBurstError(AB_ERR_NO_DEVICE,
+                              f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                              " -- there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, pp = C.c_void_p, C.POINTER(Plane)
+    L.ab_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ab_ctx_destroy.argtypes = [vp]
+    L.ab_ctx_destroy.restype = None
+    L.ab_last_error.argtypes = [vp]
+    L.ab_last_error.restype = C.c_char_p
+    L.ab_version.restype = C.c_char_p
+    L.ab_ctx_set_stream.argtypes = [vp, vp]
+    L.ab_ctx_get_stream.argtypes = [vp]
+    L.ab_ctx_get_stream.restype = vp
+    L.ab_ctx_synchronize.argtypes = [vp]
+    L.ab_device_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.ab_device_free.argtypes = [vp, vp]
+    L.ab_upload.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ab_download.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ab_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    L.ab_stack_sigma_clip.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, C.POINTER(C.c_uint64)]
+    L.ab_stack_last_rejected.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ab_stack_images.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_uint64)]
+    L.ab_stack_sigma_clip_partial.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), C.c_int64, C.c_int64,
+                                              vp, vp, C.POINTER(C.c_uint64)]
+    L.ab_stack_finalize_partial.argtypes = [vp, vp, vp, C.c_int64, vp]
+    L.ab_shift_image_subpixel.argtypes = [vp, pp, C.c_double, C.c_double, pp]
+    L.ab_warp_image.argtypes = [vp, pp, C.POINTER(C.c_double), pp]
+    L.ab_compute_image_stats.argtypes = [vp, pp, C.POINTER(ImageStatsC)]
+    L.ab_compute_image_stats_with_known_range.argtypes = [vp, pp, C.c_double, C.c_double, C.POINTER(ImageStatsC)]
+    L.ab_build_histogram.argtypes = [vp, pp, C.c_size_t, C.c_double, C.c_double, vp]
+    L.ab_stats_value_hist.argtypes = [vp, pp, C.c_double, C.c_double, vp, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_uint64)]
+    L.ab_auto_stf.argtypes = [C.POINTER(ImageStatsC), C.POINTER(AutoStfConfigC), C.POINTER(StfParamsC)]
+    L.ab_apply_stf_u8.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32]
+    L.ab_apply_stf_f32.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), pp]
+    L.ab_bench_copy.argtypes = [vp, vp, vp, C.c_size_t]
+    for name in declared_symbols():
+        fn = getattr(L, name)  # AttributeError here = header / library drift
+        if fn.restype is C.c_int and name not in ("ab_last_error", "ab_version", "ab_ctx_get_stream"):
+            fn.restype = C.c_int
+    _lib = L
+    return L

@@ -1,0 +1,306 @@
+"""Host-side mirror of the reference's `core::*` functions for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the reference (src-tauri/src/core/...), so the
+parity tests read like the reference's own unit tests.  Planes may be numpy arrays (host: staged
+through HBM by the library) or torch CUDA tensors (device: used in place on torch's current
+stream).  Every function here ends in a HIP kernel of libastroburst_hip.so; nothing is computed
+in Python or on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import AstroBurstError, AutoStfConfigC, ImageStatsC, Plane, StackConfig, StfParamsC
+
+try:  # torch is plumbing only (device memory, streams, torch.distributed)
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+@dataclass
+class ImageStats:  # types/image.rs:2-10
+    min: float = 0.0
+    max: float = 0.0
+    median: float = 0.0
+    mad: float = 0.0
+    sigma: float = 0.0
+    mean: float = 0.0
+    valid_count: int = 0
+
+
+@dataclass
+class StfParams:  # types/image.rs:36-50
+    shadow: float = 0.0
+    midtone: float = 0.5
+    highlight: float = 1.0
+
+
+@dataclass
+class StackResult:  # types/stacking.rs:22-28
+    image: object
+    frame_count: int
+    rejected_pixels: int
+    offsets: list
+
+
+def _is_torch(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class Context:
+    """One ab_ctx: a device, a stream, a scratch arena.  Not thread-safe; one per caller thread."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.ab_ctx_create(device, C.byref(h))
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "ab_ctx_create failed: no gfx950 (MI355X) device visible"
+                                      if rc == _lib.AB_ERR_NO_DEVICE else "ab_ctx_create failed")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ab_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, self._L.ab_last_error(self._h).decode())
+
+    def use_torch_stream(self):
+        """Launch on torch's current stream so torch.cuda.Event timing brackets our kernels."""
+        self._check(self._L.ab_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def synchronize(self):
+        self._check(self._L.ab_ctx_synchronize(self._h))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu, mem = C.c_int(), C.c_uint64()
+        self._check(self._L.ab_device_info(self._h, name, 256, C.byref(cu), C.byref(mem)))
+        return name.value.decode(), cu.value, mem.value
+
+    # ---- plane marshalling -----------------------------------------------------------------
+    def _plane(self, x, keep):
+        if _is_torch(x):
+            assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous(), \
+                "device planes are contiguous 2-D float32 CUDA tensors"
+            keep.append(x)
+            return Plane(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], 1)
+        a = np.ascontiguousarray(x, dtype=np.float32)
+        assert a.ndim == 2, "planes are 2-D (rows, cols)"
+        keep.append(a)
+        return Plane(C.c_void_p(a.ctypes.data), a.shape[0], a.shape[1], 0)
+
+    def _new_like(self, ref, rows, cols):
+        if _is_torch(ref):
+            return torch.empty((rows, cols), dtype=torch.float32, device=ref.device)
+        return np.empty((rows, cols), np.float32)
+
+    # ---- core/stacking/combine.rs ------------------------------------------------------------
+    def stack_sigma_clip(self, frames, sigma_low=3.0, sigma_high=3.0, max_iterations=5, out=None, want_rejected=True):
+        """Per-pixel sigma_clip_combine over equal-or-larger frames (combine.rs:14-92,160-182).
+        want_rejected=False keeps the call asynchronous (fetch the count with last_rejected())."""
+        if len(frames) == 0:
+            raise AstroBurstError(_lib.AB_ERR_INVALID, "No images to stack")
+        keep = []
+        planes = (Plane * len(frames))(*[self._plane(f, keep) for f in frames])
+        rows = min(p.rows for p in planes)
+        cols = min(p.cols for p in planes)
+        if out is None:
+            out = self._new_like(frames[0], rows, cols)
+        po = self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), rows, cols, 0)
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 0)
+        rej = C.c_uint64(0)
+        self._check(self._L.ab_stack_sigma_clip(self._h, planes, len(frames), C.byref(cfg), C.byref(po),
+                                                C.byref(rej) if want_rejected else None))
+        return out, (int(rej.value) if want_rejected else None)
+
+    def last_rejected(self) -> int:
+        rej = C.c_uint64(0)
+        self._check(self._L.ab_stack_last_rejected(self._h, C.byref(rej)))
+        return int(rej.value)
+
+    def stack_images(self, images, sigma_low=3.0, sigma_high=3.0, max_iterations=5, align=True) -> StackResult:
+        """stack_images(&[Array2<f32>], &StackConfig) (combine.rs:94-193)."""
+        n = len(images)
+        if n == 0:
+            raise AstroBurstError(_lib.AB_ERR_INVALID, "No images to stack")
+        keep = []
+        planes = (Plane * n)(*[self._plane(f, keep) for f in images])
+        rows = min(p.rows for p in planes)
+        cols = min(p.cols for p in planes)
+        out = self._new_like(images[0], rows, cols)
+        po = self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), rows, cols, 0)
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 1 if align else 0)
+        rej = C.c_uint64(0)
+        offs = (C.c_int32 * (2 * n))()
+        self._check(self._L.ab_stack_images(self._h, planes, n, C.byref(cfg), C.byref(po), offs, C.byref(rej)))
+        offsets = [(int(offs[2 * i]), int(offs[2 * i + 1])) for i in range(n)]
+        return StackResult(out, n, int(rej.value), offsets)
+
+    def sigma_clip_combine(self, values, sigma_low=3.0, sigma_high=3.0, max_iter=5):
+        """sigma_clip_combine(values, lo, hi, max_iter) -> (f32, u32) (combine.rs:14-92), run on
+        the GPU as a one-pixel stack of len(values) frames."""
+        vals = np.asarray(values, dtype=np.float32).ravel()
+        if vals.size == 0:
+            return np.float32(0.0), 0  # combine.rs:21-23 (no frames: nothing to launch)
+        frames = [np.full((1, 1), v, np.float32) for v in vals]
+        out, rej = self.stack_sigma_clip(frames, sigma_low, sigma_high, max_iter)
+        return np.float32(out[0, 0]), rej
+
+    def stack_partial(self, frames, sigma_low=3.0, sigma_high=3.0, max_iterations=5):
+        """Frame-sharded partial: per-pixel (f64 sum, u32 count) of this shard's survivors."""
+        assert all(_is_torch(f) for f in frames), "partial stacking takes device frames"
+        keep = []
+        planes = (Plane * len(frames))(*[self._plane(f, keep) for f in frames])
+        rows = min(p.rows for p in planes)
+        cols = min(p.cols for p in planes)
+        dev = frames[0].device
+        s = torch.empty((rows, cols), dtype=torch.float64, device=dev)
+        cnt = torch.empty((rows, cols), dtype=torch.int32, device=dev)
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 0)
+        rej = C.c_uint64(0)
+        self._check(self._L.ab_stack_sigma_clip_partial(self._h, planes, len(frames), C.byref(cfg), rows, cols,
+                                                        C.c_void_p(s.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                        C.byref(rej)))
+        return s, cnt, int(rej.value)
+
+    def stack_partial_into(self, frames, s, cnt, sigma_low=3.0, sigma_high=3.0, max_iterations=5):
+        """stack_partial into caller-owned device buffers, fully asynchronous (no rejected read-back)."""
+        keep = []
+        planes = (Plane * len(frames))(*[self._plane(f, keep) for f in frames])
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 0)
+        self._check(self._L.ab_stack_sigma_clip_partial(self._h, planes, len(frames), C.byref(cfg), s.shape[0],
+                                                        s.shape[1], C.c_void_p(s.data_ptr()),
+                                                        C.c_void_p(cnt.data_ptr()), None))
+        return s, cnt, None
+
+    def stack_finalize_partial_into(self, s, cnt, out):
+        self._check(self._L.ab_stack_finalize_partial(self._h, C.c_void_p(s.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                      s.numel(), C.c_void_p(out.data_ptr())))
+        return out
+
+    def stack_finalize_partial(self, s, cnt):
+        out = torch.empty(s.shape, dtype=torch.float32, device=s.device)
+        self._check(self._L.ab_stack_finalize_partial(self._h, C.c_void_p(s.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                                      s.numel(), C.c_void_p(out.data_ptr())))
+        return out
+
+    # ---- core/stacking/align.rs, core/alignment/affine.rs -------------------------------------
+    def shift_image_subpixel(self, image, dy: float, dx: float, out=None):
+        keep = []
+        pi = self._plane(image, keep)
+        if out is None:
+            out = self._new_like(image, pi.rows, pi.cols)
+        po = self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), pi.rows, pi.cols, 0)
+        self._check(self._L.ab_shift_image_subpixel(self._h, C.byref(pi), dy, dx, C.byref(po)))
+        return out
+
+    def warp_image(self, image, transform, out_rows: int, out_cols: int, out=None):
+        """transform = (a, b, tx, c, d, ty): output (x, y) -> source (sx, sy) (affine.rs:74-80)."""
+        keep = []
+        pi = self._plane(image, keep)
+        if out is None:
+            out = self._new_like(image, out_rows, out_cols)
+        po = self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), out_rows, out_cols, 0)
+        t = (C.c_double * 6)(*[float(v) for v in transform])
+        self._check(self._L.ab_warp_image(self._h, C.byref(pi), t, C.byref(po)))
+        return out
+
+    # ---- core/imaging/stats.rs ------------------------------------------------------------------
+    @staticmethod
+    def _stats_out(s: ImageStatsC) -> ImageStats:
+        return ImageStats(s.min, s.max, s.median, s.mad, s.sigma, s.mean, int(s.valid_count))
+
+    @staticmethod
+    def _stats_in(st: ImageStats) -> ImageStatsC:
+        return ImageStatsC(st.min, st.max, st.median, st.mad, st.sigma, st.mean, st.valid_count)
+
+    def compute_image_stats(self, image) -> ImageStats:
+        keep = []
+        pi = self._plane(image, keep)
+        s = ImageStatsC()
+        self._check(self._L.ab_compute_image_stats(self._h, C.byref(pi), C.byref(s)))
+        return self._stats_out(s)
+
+    def compute_image_stats_with_known_range(self, image, known_min: float, known_max: float) -> ImageStats:
+        keep = []
+        pi = self._plane(image, keep)
+        s = ImageStatsC()
+        self._check(self._L.ab_compute_image_stats_with_known_range(self._h, C.byref(pi), known_min, known_max,
+                                                                    C.byref(s)))
+        return self._stats_out(s)
+
+    def build_histogram(self, image, bins: int, dmin: float, dmax: float) -> np.ndarray:
+        keep = []
+        pi = self._plane(image, keep)
+        out = np.zeros(bins, np.uint32)
+        self._check(self._L.ab_build_histogram(self._h, C.byref(pi), bins, dmin, dmax, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def stats_value_hist(self, image, gmin: float, gmax: float):
+        keep = []
+        pi = self._plane(image, keep)
+        h = np.zeros(65536, np.uint64)
+        s, c = C.c_double(), C.c_uint64()
+        self._check(self._L.ab_stats_value_hist(self._h, C.byref(pi), gmin, gmax, C.c_void_p(h.ctypes.data),
+                                                C.byref(s), C.byref(c)))
+        return h, s.value, int(c.value)
+
+    # ---- core/imaging/stf.rs ---------------------------------------------------------------------
+    def auto_stf(self, stats: ImageStats, target_bg=0.25, shadow_k=-2.8) -> StfParams:
+        s = self._stats_in(stats)
+        cfg = AutoStfConfigC(target_bg, shadow_k)
+        p = StfParamsC()
+        rc = self._L.ab_auto_stf(C.byref(s), C.byref(cfg), C.byref(p))
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "ab_auto_stf: null argument")
+        return StfParams(p.shadow, p.midtone, p.highlight)
+
+    def apply_stf(self, image, params: StfParams, stats: ImageStats, out=None):
+        """apply_stf -> u8 (stf.rs:89-102)."""
+        keep = []
+        pi = self._plane(image, keep)
+        p = StfParamsC(params.shadow, params.midtone, params.highlight)
+        s = self._stats_in(stats)
+        if _is_torch(image):
+            if out is None:
+                out = torch.empty((pi.rows, pi.cols), dtype=torch.uint8, device=image.device)
+            self._check(self._L.ab_apply_stf_u8(self._h, C.byref(pi), C.byref(p), C.byref(s),
+                                                C.c_void_p(out.data_ptr()), 1))
+        else:
+            if out is None:
+                out = np.empty((pi.rows, pi.cols), np.uint8)
+            self._check(self._L.ab_apply_stf_u8(self._h, C.byref(pi), C.byref(p), C.byref(s),
+                                                C.c_void_p(out.ctypes.data), 0))
+        return out
+
+    def apply_stf_f32(self, image, params: StfParams, stats: ImageStats, out=None):
+        """apply_stf_f32 (stf.rs:104-120); pass out=image for apply_stf_inplace (:147-155)."""
+        keep = []
+        pi = self._plane(image, keep)
+        if out is None:
+            out = self._new_like(image, pi.rows, pi.cols)
+        po = self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), pi.rows, pi.cols, 0)
+        p = StfParamsC(params.shadow, params.midtone, params.highlight)
+        s = self._stats_in(stats)
+        self._check(self._L.ab_apply_stf_f32(self._h, C.byref(pi), C.byref(p), C.byref(s), C.byref(po)))
+        return out
+
+    # ---- bench support -----------------------------------------------------------------------------
+    def bench_copy(self, src, dst):
+        self._check(self._L.ab_bench_copy(self._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel()))

@@ -1,0 +1,76 @@
+// Internal shared definitions of libastroburst_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/astroburst_hip.h"
+
+struct ab_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // own_stream or a borrowed one
+    std::string err;
+    // scratch arena in HBM (grown on demand, reused across calls)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // small pinned host buffer for scalar/histogram read-back
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // device-side u64 counters (rejected pixels etc.)
+    unsigned long long *counters = nullptr;  // 16 x u64
+    int cu_count = 0;
+};
+
+int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);
+
+#define AB_HIP(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return ab_set_error((ctx), AB_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                      \
+    } while (0)
+
+#define AB_CHECK(ctx, cond, ...)                                         \
+    do {                                                                 \
+        if (!(cond)) return ab_set_error((ctx), AB_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+#define AB_TRY(expr)              \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != AB_OK) return rc_; \
+    } while (0)
+
+// Scratch arena: returns a device pointer valid until the next ab_scratch() call with a larger size.
+int ab_scratch(ab_ctx *ctx, size_t bytes, void **out);
+int ab_pinned(ab_ctx *ctx, size_t bytes, void **out);
+
+// RAII staging of an input plane: host planes are uploaded to a temporary device buffer.
+struct StagedPlane {
+    const float *dptr = nullptr;
+    int64_t rows = 0, cols = 0;
+    void *owned = nullptr;
+};
+int ab_stage_in(ab_ctx *ctx, const ab_plane *p, StagedPlane *out);
+void ab_stage_release(ab_ctx *ctx, StagedPlane *p);
+
+// Output staging: device planes are written in place; host planes get a temp that is
+// downloaded by ab_stage_out_finish.
+struct StagedOut {
+    float *dptr = nullptr;
+    void *owned = nullptr;
+    float *host = nullptr;
+    size_t bytes = 0;
+};
+int ab_stage_out_begin(ab_ctx *ctx, const ab_plane_mut *p, StagedOut *out);
+int ab_stage_out_finish(ab_ctx *ctx, StagedOut *o);  // downloads (sync) + frees when host
+void ab_stage_out_abort(ab_ctx *ctx, StagedOut *o);
+
+static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

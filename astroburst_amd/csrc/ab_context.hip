@@ -1,0 +1,210 @@
+// Context, error reporting, HBM scratch and host<->device staging.
+#include "ab_common.hpp"
+
+int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" {
+
+const char *ab_version(void) { return "astroburst_hip 0.1.0 (gfx950)"; }
+
+int ab_ctx_create(int device_id, ab_ctx **out) {
+    if (!out) return AB_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return AB_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= count) return AB_ERR_INVALID;
+    ab_ctx *ctx = new (std::nothrow) ab_ctx();
+    if (!ctx) return AB_ERR_NOMEM;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        delete ctx;
+        return AB_ERR_HIP;
+    }
+    ctx->cu_count = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // kernels are built for gfx950 only; refuse loudly instead of failing at first launch
+        delete ctx;
+        return AB_ERR_NO_DEVICE;
+    }
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->counters, 16 * sizeof(unsigned long long)) != hipSuccess) {
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx;
+        return AB_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return AB_OK;
+}
+
+void ab_ctx_destroy(ab_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char *ab_last_error(const ab_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ab_ctx_set_stream(ab_ctx *ctx, void *hip_stream) {
+    if (!ctx) return AB_ERR_INVALID;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return AB_OK;
+}
+
+void *ab_ctx_get_stream(ab_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int ab_ctx_synchronize(ab_ctx *ctx) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AB_OK;
+}
+
+int ab_device_alloc(ab_ctx *ctx, size_t bytes, void **out_dptr) {
+    if (!ctx || !out_dptr) return AB_ERR_INVALID;
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    AB_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 1));
+    return AB_OK;
+}
+
+int ab_device_free(ab_ctx *ctx, void *dptr) {
+    if (!ctx) return AB_ERR_INVALID;
+    if (dptr) AB_HIP(ctx, hipFree(dptr));
+    return AB_OK;
+}
+
+int ab_upload(ab_ctx *ctx, void *dst_device, const void *src_host, size_t bytes) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AB_OK;
+}
+
+int ab_download(ab_ctx *ctx, void *dst_host, const void *src_device, size_t bytes) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AB_OK;
+}
+
+int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint64_t *hbm_bytes) {
+    if (!ctx) return AB_ERR_INVALID;
+    hipDeviceProp_t prop;
+    AB_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return AB_OK;
+}
+
+}  // extern "C"
+
+int ab_scratch(ab_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->scratch) {
+            AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            AB_HIP(ctx, hipFree(ctx->scratch));
+            ctx->scratch = nullptr;
+            ctx->scratch_bytes = 0;
+        }
+        size_t want = bytes + (bytes >> 2);
+        AB_HIP(ctx, hipMalloc(&ctx->scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->scratch;
+    return AB_OK;
+}
+
+int ab_pinned(ab_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->pinned_bytes) {
+        if (ctx->pinned) {
+            AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            AB_HIP(ctx, hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+        }
+        AB_HIP(ctx, hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+        ctx->pinned_bytes = bytes;
+    }
+    *out = ctx->pinned;
+    return AB_OK;
+}
+
+int ab_stage_in(ab_ctx *ctx, const ab_plane *p, StagedPlane *out) {
+    AB_CHECK(ctx, p && p->data && p->rows > 0 && p->cols > 0, "plane is null or has a zero dimension");
+    out->rows = p->rows;
+    out->cols = p->cols;
+    if (p->on_device) {
+        out->dptr = p->data;
+        out->owned = nullptr;
+        return AB_OK;
+    }
+    size_t bytes = (size_t)p->rows * (size_t)p->cols * sizeof(float);
+    void *d = nullptr;
+    AB_HIP(ctx, hipMalloc(&d, bytes));
+    hipError_t e = hipMemcpyAsync(d, p->data, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return ab_set_error(ctx, AB_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e));
+    }
+    out->dptr = (const float *)d;
+    out->owned = d;
+    return AB_OK;
+}
+
+void ab_stage_release(ab_ctx *ctx, StagedPlane *p) {
+    if (p->owned) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(p->owned);
+        p->owned = nullptr;
+    }
+}
+
+int ab_stage_out_begin(ab_ctx *ctx, const ab_plane_mut *p, StagedOut *out) {
+    AB_CHECK(ctx, p && p->data && p->rows > 0 && p->cols > 0, "output plane is null or has a zero dimension");
+    out->bytes = (size_t)p->rows * (size_t)p->cols * sizeof(float);
+    if (p->on_device) {
+        out->dptr = p->data;
+        out->owned = nullptr;
+        out->host = nullptr;
+        return AB_OK;
+    }
+    void *d = nullptr;
+    AB_HIP(ctx, hipMalloc(&d, out->bytes));
+    out->dptr = (float *)d;
+    out->owned = d;
+    out->host = p->data;
+    return AB_OK;
+}
+
+int ab_stage_out_finish(ab_ctx *ctx, StagedOut *o) {
+    if (o->owned) {
+        hipError_t e = hipMemcpyAsync(o->host, o->dptr, o->bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(o->owned);
+        o->owned = nullptr;
+        if (e != hipSuccess) return ab_set_error(ctx, AB_ERR_HIP, "D2H copy failed: %s", hipGetErrorString(e));
+    }
+    return AB_OK;
+}
+
+void ab_stage_out_abort(ab_ctx *ctx, StagedOut *o) {
+    if (o->owned) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(o->owned);
+        o->owned = nullptr;
+    }
+}

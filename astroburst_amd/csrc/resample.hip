@@ -1,0 +1,150 @@
+// Sub-pixel registration resampling on gfx950: bicubic (Catmull-Rom) shift and affine warp.
+//
+// Replaces core/stacking/align.rs:36-57 (shift_image_subpixel),
+// core/alignment/affine.rs:663-690 (warp_image) and the sampler they share,
+// core/imaging/sampling.rs:4-14,51-80 (catmull_rom, bicubic_sample) with
+// core/imaging/boundary.rs:9-20 (clamp_index).
+//
+// One lane per OUTPUT pixel, consecutive lanes on consecutive x: the 4x4 source footprint of
+// neighbouring lanes overlaps almost completely, so the 16 taps are served by L1/L2 and HBM sees
+// each source line about once (4*P read + 4*P written per frame).  Coordinates, weights and the
+// accumulation are f64 in the reference's evaluation order, so results are bit-identical to the
+// CPU restatement; only the final store is f32.
+#include "ab_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ double catmull_rom(double t) {  // sampling.rs:4-14
+    const double abs_t = fabs(t);
+    if (abs_t <= 1.0) return abs_t * abs_t * (1.5 * abs_t - 2.5) + 1.0;
+    if (abs_t <= 2.0) return abs_t * (abs_t * (2.5 - 0.5 * abs_t) - 4.0) + 2.0;
+    return 0.0;
+}
+
+__device__ __forceinline__ int64_t clamp_index(int64_t idx, int64_t len) {  // boundary.rs:9-20
+    return idx < 0 ? 0 : (idx >= len ? len - 1 : idx);
+}
+
+// sampling.rs:51-80
+__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int64_t rows, int64_t cols, double y,
+                                                double x) {
+    const double xf = floor(x), yf = floor(y);
+    const int64_t ix = (int64_t)xf, iy = (int64_t)yf;
+    const double fx = x - xf, fy = y - yf;
+    const double wx0 = catmull_rom(fx + 1.0), wx1 = catmull_rom(fx), wx2 = catmull_rom(fx - 1.0),
+                 wx3 = catmull_rom(fx - 2.0);
+    const int64_t c0 = clamp_index(ix - 1, cols), c1 = clamp_index(ix, cols), c2 = clamp_index(ix + 1, cols),
+                  c3 = clamp_index(ix + 2, cols);
+    double val = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float *row = src + clamp_index(iy + j - 1, rows) * cols;
+        double row_val = 0.0;
+        row_val += (double)row[c0] * wx0;
+        row_val += (double)row[c1] * wx1;
+        row_val += (double)row[c2] * wx2;
+        row_val += (double)row[c3] * wx3;
+        val += row_val * catmull_rom(fy - (double)(j - 1));
+    }
+    return (float)val;
+}
+
+// align.rs:46-55
+__global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ src, int64_t rows, int64_t cols, double dy,
+                                                    double dx, float *__restrict__ out) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= cols) return;
+    const double sy = (double)y + dy;
+    const double sx = (double)x + dx;
+    float r = 0.0f;
+    if (!(sy < -0.5 || sy > (double)rows - 0.5 || sx < -0.5 || sx > (double)cols - 0.5))
+        r = bicubic_sample(src, rows, cols, sy, sx);
+    out[y * cols + x] = r;
+}
+
+// affine.rs:674-687; map() is affine.rs:74-80
+__global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src, int64_t src_rows, int64_t src_cols,
+                                                   double a, double b, double tx, double c, double d, double ty,
+                                                   int64_t out_rows, int64_t out_cols, float *__restrict__ out) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t y = blockIdx.y;
+    if (x >= out_cols) return;
+    const double xf = (double)x, yf = (double)y;
+    const double sx = a * xf + b * yf + tx;
+    const double sy = c * xf + d * yf + ty;
+    float r = 0.0f;
+    if (sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1))
+        r = bicubic_sample(src, src_rows, src_cols, sy, sx);
+    out[y * out_cols + x] = r;
+}
+
+}  // namespace
+
+int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, double dy, double dx, float *out) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    if (fabs(dy) < 1e-12 && fabs(dx) < 1e-12) {  // align.rs:37-39: image.clone()
+        if (src != out)
+            AB_HIP(ctx, hipMemcpyAsync(out, src, (size_t)rows * cols * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return AB_OK;
+    }
+    AB_CHECK(ctx, src != out, "shift_image_subpixel cannot run in place");
+    AB_CHECK(ctx, rows <= 65535 * 1, "image taller than 65535 rows needs a tiled launch (not in this build)");
+    const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
+    hipLaunchKernelGGL(shift_kernel, grid, block, 0, ctx->stream, src, rows, cols, dy, dx, out);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
+                   int64_t out_cols, float *out) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    AB_CHECK(ctx, src != out, "warp_image cannot run in place");
+    AB_CHECK(ctx, out_rows <= 65535, "image taller than 65535 rows needs a tiled launch (not in this build)");
+    const dim3 grid((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block(256);
+    hipLaunchKernelGGL(warp_kernel, grid, block, 0, ctx->stream, src, src_rows, src_cols, t[0], t[1], t[2], t[3], t[4],
+                       t[5], out_rows, out_cols, out);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+extern "C" {
+
+int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, double dx, ab_plane_mut *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, src && out, "null plane");
+    AB_CHECK(ctx, src->rows == out->rows && src->cols == out->cols, "shift_image_subpixel keeps the image dims");
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, src, &in));
+    StagedOut so;
+    int rc = ab_stage_out_begin(ctx, out, &so);
+    if (rc == AB_OK) {
+        rc = ab_shift_device(ctx, in.dptr, in.rows, in.cols, dy, dx, so.dptr);
+        if (rc == AB_OK)
+            rc = ab_stage_out_finish(ctx, &so);
+        else
+            ab_stage_out_abort(ctx, &so);
+    }
+    ab_stage_release(ctx, &in);
+    return rc;
+}
+
+int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, src && out && transform, "null plane or transform");
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, src, &in));
+    StagedOut so;
+    int rc = ab_stage_out_begin(ctx, out, &so);
+    if (rc == AB_OK) {
+        rc = ab_warp_device(ctx, in.dptr, in.rows, in.cols, transform, out->rows, out->cols, so.dptr);
+        if (rc == AB_OK)
+            rc = ab_stage_out_finish(ctx, &so);
+        else
+            ab_stage_out_abort(ctx, &so);
+    }
+    ab_stage_release(ctx, &in);
+    return rc;
+}
+
+}  // extern "C"

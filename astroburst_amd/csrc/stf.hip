@@ -1,0 +1,224 @@
+// Screen transfer function (midtone stretch) on gfx950.
+//
+// Replaces core/imaging/stf.rs: auto_stf (:13-39), mtf_balance (:41-47), mtf (:50-58),
+// StfTransform (:60-87), apply_stf -> u8 (:89-102), apply_stf_f32 (:104-120) and
+// apply_stf_inplace (:147-155).
+//
+// Pure streaming map: 4 B read, 1 B (u8) or 4 B (f32) written per pixel, float4 / uchar4 wide.
+// The per-pixel arithmetic is f64 in the reference's evaluation order, so the u8 output is
+// bit-exact against the CPU restatement.
+#include "ab_common.hpp"
+
+#include <cmath>
+
+namespace {
+
+constexpr float kPaddingThreshold = 1e-7f;  // types/constants.rs:6
+
+struct StfTx {  // stf.rs:60-78
+    double inv_range, dmin, shadow, inv_clip, midtone;
+};
+
+__device__ __forceinline__ bool is_valid_pixel(float v) { return __builtin_isfinite(v) && v > kPaddingThreshold; }
+
+__device__ __forceinline__ double mtf(double x, double m) {  // stf.rs:50-58
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    return (m - 1.0) * x / ((2.0 * m - 1.0) * x - m);
+}
+
+__device__ __forceinline__ double tx_apply(const StfTx &t, double v) {  // stf.rs:80-86
+    const double norm = (v - t.dmin) * t.inv_range;
+    double clipped = (norm - t.shadow) * t.inv_clip;
+    clipped = clipped < 0.0 ? 0.0 : (clipped > 1.0 ? 1.0 : clipped);  // f64::clamp (NaN stays NaN)
+    return mtf(clipped, t.midtone);
+}
+
+__device__ __forceinline__ unsigned char to_u8(float v, const StfTx &t) {  // stf.rs:96-100
+    if (!is_valid_pixel(v)) return 0;
+    double r = round(tx_apply(t, (double)v) * 255.0);
+    r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
+    return (r > 0.0) ? (unsigned char)r : (unsigned char)0;  // `as u8`: NaN -> 0
+}
+
+__device__ __forceinline__ float to_f32(float v, const StfTx &t) {  // stf.rs:112-116
+    return is_valid_pixel(v) ? (float)tx_apply(t, (double)v) : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void stf_u8_kernel(const float *__restrict__ in, int64_t n, StfTx t,
+                                                     unsigned char *__restrict__ out) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    uchar4 *out4 = reinterpret_cast<uchar4 *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = in4[i];
+        uchar4 r;
+        r.x = to_u8(v.x, t);
+        r.y = to_u8(v.y, t);
+        r.z = to_u8(v.z, t);
+        r.w = to_u8(v.w, t);
+        out4[i] = r;
+    }
+    if (blockIdx.x == 0) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        if (i < n) out[i] = to_u8(in[i], t);
+    }
+}
+
+__global__ __launch_bounds__(256) void stf_f32_kernel(const float *in, int64_t n, StfTx t, float *out) {
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    float4 *out4 = reinterpret_cast<float4 *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = in4[i];
+        float4 r;
+        r.x = to_f32(v.x, t);
+        r.y = to_f32(v.y, t);
+        r.z = to_f32(v.z, t);
+        r.w = to_f32(v.w, t);
+        out4[i] = r;
+    }
+    if (blockIdx.x == 0) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        if (i < n) out[i] = to_f32(in[i], t);
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+StfTx make_tx(const ab_stf_params *p, const ab_image_stats *st) {  // stf.rs:69-78
+    StfTx t;
+    const double range = std::fmax(st->max - st->min, 1e-30);
+    const double clip_range = std::fmax(p->highlight - p->shadow, 1e-15);
+    t.inv_range = 1.0 / range;
+    t.dmin = st->min;
+    t.shadow = p->shadow;
+    t.inv_clip = 1.0 / clip_range;
+    t.midtone = p->midtone;
+    return t;
+}
+
+inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+int stream_grid(ab_ctx *ctx, int64_t n4) {
+    const int64_t want = (n4 + 255) / 256;
+    const int64_t cap = (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
+    return (int)std::max<int64_t>(1, std::min(want, cap));
+}
+
+}  // namespace
+
+int ab_stf_u8_device(ab_ctx *ctx, const float *in, int64_t n, const ab_stf_params *p, const ab_image_stats *st,
+                     uint8_t *out) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    AB_CHECK(ctx, ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 3) == 0, "apply_stf: planes must be 16-byte aligned");
+    hipLaunchKernelGGL(stf_u8_kernel, dim3(stream_grid(ctx, n >> 2)), dim3(256), 0, ctx->stream, in, n, make_tx(p, st), out);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+int ab_stf_f32_device(ab_ctx *ctx, const float *in, int64_t n, const ab_stf_params *p, const ab_image_stats *st,
+                      float *out) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    AB_CHECK(ctx, ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "apply_stf: planes must be 16-byte aligned");
+    hipLaunchKernelGGL(stf_f32_kernel, dim3(stream_grid(ctx, n >> 2)), dim3(256), 0, ctx->stream, in, n, make_tx(p, st), out);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+extern "C" {
+
+// stf.rs:13-39 (host scalar maths)
+int ab_auto_stf(const ab_image_stats *stats, const ab_auto_stf_config *cfg, ab_stf_params *out) {
+    if (!stats || !cfg || !out) return AB_ERR_INVALID;
+    if (stats->valid_count == 0) {
+        out->shadow = 0.0;
+        out->midtone = 0.5;
+        out->highlight = 1.0;
+        return AB_OK;
+    }
+    const double range = std::fmax(stats->max - stats->min, 1e-30);
+    const double median_norm = (stats->median - stats->min) / range;
+    const double sigma_norm = stats->sigma / range;
+    const double shadow_norm = clampd(median_norm + cfg->shadow_k * sigma_norm, 0.0, 0.98);
+    const double highlight_norm = 1.0;
+    const double clip_range = std::fmax(highlight_norm - shadow_norm, 1e-15);
+    const double m_clipped = clampd((median_norm - shadow_norm) / clip_range, 0.0, 1.0);
+    double midtone = 0.5;
+    if (!(m_clipped <= 0.0 || m_clipped >= 1.0)) {
+        const double t = cfg->target_bg, m = m_clipped;  // mtf_balance, stf.rs:41-47
+        const double denom = 2.0 * t * m - t - m;
+        midtone = std::fabs(denom) < 1e-15 ? 0.5 : clampd(m * (t - 1.0) / denom, 0.0001, 0.9999);
+    }
+    out->shadow = shadow_norm;
+    out->midtone = midtone;
+    out->highlight = highlight_norm;
+    return AB_OK;
+}
+
+int ab_apply_stf_u8(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st, uint8_t *out,
+                    int32_t out_on_device) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, img && p && st && out, "null argument");
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, img, &in));
+    const int64_t n = in.rows * in.cols;
+    int rc = AB_OK;
+    if (out_on_device) {
+        rc = ab_stf_u8_device(ctx, in.dptr, n, p, st, out);
+    } else {
+        void *d = nullptr;
+        hipError_t e = hipMalloc(&d, (size_t)n);
+        if (e != hipSuccess) {
+            rc = ab_set_error(ctx, AB_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e));
+        } else {
+            rc = ab_stf_u8_device(ctx, in.dptr, n, p, st, (uint8_t *)d);
+            if (rc == AB_OK) {
+                e = hipMemcpyAsync(out, d, (size_t)n, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) rc = ab_set_error(ctx, AB_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+            }
+            (void)hipFree(d);
+        }
+    }
+    ab_stage_release(ctx, &in);
+    return rc;
+}
+
+int ab_apply_stf_f32(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st,
+                     ab_plane_mut *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, img && p && st && out, "null argument");
+    AB_CHECK(ctx, img->rows == out->rows && img->cols == out->cols, "apply_stf_f32 keeps the image dims");
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, img, &in));
+    StagedOut so;
+    int rc = ab_stage_out_begin(ctx, out, &so);
+    if (rc == AB_OK) {
+        rc = ab_stf_f32_device(ctx, in.dptr, in.rows * in.cols, p, st, so.dptr);
+        if (rc == AB_OK)
+            rc = ab_stage_out_finish(ctx, &so);
+        else
+            ab_stage_out_abort(ctx, &so);
+    }
+    ab_stage_release(ctx, &in);
+    return rc;
+}
+
+int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, src_dev && dst_dev && (n_floats % 4) == 0, "copy needs 16-byte multiples");
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n4 = (int64_t)(n_floats / 4);
+    hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(ctx, n4)), dim3(256), 0, ctx->stream, (const float4 *)src_dev,
+                       (float4 *)dst_dev, n4);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+}  // extern "C"

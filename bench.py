@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- the north-star metric on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the hot path over one device-resident synthetic stack of
+64 x 4096 x 4096 f32 frames (BASELINE.json configs[1]):
+   affine-register 63 frames on frame 0 (bicubic warp with known rigid transforms)
+   -> per-pixel kappa-sigma stack (3 sigma / 3 sigma / 5 iterations)
+   -> compute_image_stats -> auto_stf -> apply_stf (u8)
+all through the C ABI of libastroburst_hip.so, inputs already in HBM when the clock starts.
+
+N > 1 (one process per GPU, torch.distributed over RCCL): the frame set is sharded by frame
+(BASELINE.json configs[3]): every rank holds its own 64 frames of the same field, computes the
+per-pixel (sum, count) of its survivors, the partials are all-reduced over xGMI and divided, and
+the stretch runs on the result.  Work per GPU is fixed, so scaling is "weak"; `value` counts the
+frame-pixels all ranks processed.
+
+Prints ONE JSON line (rank 0).  `value` = input MPix/s = frames x pixels / second for the whole
+step; `roofline` prices the stacking kernel alone against HBM; `cpu_baseline` times the CPU
+oracle (a C restatement of the reference's Rust path, "port") on a bounded crop of the same frames.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--rows", type=int, default=4096)
+    ap.add_argument("--cols", type=int, default=4096)
+    ap.add_argument("--no-register", action="store_true", help="skip the warp stage (stack + stretch only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
+    return ap.parse_args()
+
+
+def rigid_transforms(n, seed=7):
+    """known per-frame rigid transforms: shift U(-8, 8) px, rotation U(-0.05, 0.05) deg about the centre"""
+    import random
+    rnd = random.Random(seed)
+    ts = [(1.0, 0.0, 0.0, 0.0, 1.0, 0.0)]
+    for _ in range(1, n):
+        ang = math.radians(rnd.uniform(-0.05, 0.05))
+        ts.append((math.cos(ang), -math.sin(ang), rnd.uniform(-8, 8), math.sin(ang), math.cos(ang), rnd.uniform(-8, 8)))
+    return ts
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import astroburst_amd as ab
+    from astroburst_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ctx = ab.Context(local_rank)
+    ctx.use_torch_stream()
+    name, cus, hbm = ctx.device_info()
+
+    N, R, Cc = args.frames, args.rows, args.cols
+    P = R * Cc
+    # ---- synthetic, device-resident input (each rank: its own N frames, seeds offset by rank) ----
+    n_stars = max(8, int(120.0 * P / 1e6))
+    cat = synth.star_catalog(R, Cc, n_stars)
+    truth = torch.full((R, Cc), 200.0, dtype=torch.float32, device=dev) + synth.render_stars(R, Cc, cat, device=dev)
+    raw = []
+    for k in range(N):
+        border = 16 if k % 10 == 9 else 0
+        raw.append(synth.make_frame(R, Cc, k + N * rank, device=dev, truth=truth, border=border))
+    del truth
+    transforms = rigid_transforms(N)
+    register = not args.no_register
+    warped = [raw[0]] + [torch.empty_like(raw[0]) for _ in range(1, N)] if register else raw
+    stacked = torch.empty((R, Cc), dtype=torch.float32, device=dev)
+    u8 = torch.empty((R, Cc), dtype=torch.uint8, device=dev)
+    if world > 1:
+        psum = torch.empty((R, Cc), dtype=torch.float64, device=dev)
+        pcnt = torch.empty((R, Cc), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    stack_ms = []
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + args.warmup)]
+
+    def step(i):
+        if register:
+            for k in range(1, N):
+                ctx.warp_image(raw[k], transforms[k], R, Cc, out=warped[k])
+        e0, e1 = ev[i]
+        e0.record()
+        if world == 1:
+            ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
+            e1.record()
+        else:
+            s, c, _ = ctx.stack_partial_into(warped, psum, pcnt)
+            e1.record()
+            dist.all_reduce(psum)
+            dist.all_reduce(pcnt)
+            ctx.stack_finalize_partial_into(psum, pcnt, stacked)
+        st = ctx.compute_image_stats(stacked)
+        p = ctx.auto_stf(st)
+        ctx.apply_stf(stacked, p, st, out=u8)
+        return st
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        st = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for i in range(args.warmup, args.warmup + args.steps):
+        stack_ms.append(ev[i][0].elapsed_time(ev[i][1]))
+    rejected = ctx.last_rejected()
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * N * P / 1e6 / (elapsed / args.steps)  # input MPix/s, whole job
+
+    # ---- roofline of the dominant kernel (stack): algorithmic bytes = 4*N*P read + 4*P (or 12*P partial) written
+    stack_avg_ms = sum(stack_ms) / len(stack_ms)
+    out_bytes = 4 * P if world == 1 else 12 * P
+    algo_bytes = 4 * N * P + out_bytes
+    achieved = algo_bytes / (stack_avg_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "stack_sigma_clip_kernel<64>", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes": algo_bytes, "avg_kernel_ms": round(stack_avg_ms, 4), "traffic": None}
+
+    # measured streaming ceiling of this GPU (float4 copy), for context
+    a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    ctx.bench_copy(a, b)
+    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0.record()
+    for _ in range(10):
+        ctx.bench_copy(a, b)
+    c1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 10 * 2 * a.numel() * 4 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+    del a, b
+
+    # ---- CPU baseline: the oracle (C restatement of the reference, OpenMP) on a bounded crop ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle
+        import numpy as np
+        threads = pyoracle.max_threads()
+        probe_rows = 8
+        crop = [w[:probe_rows].cpu().numpy() for w in warped]
+        t1 = time.perf_counter()
+        pyoracle.stack_images(crop, 3.0, 3.0, 5, order=pyoracle.ORDER_SELECT)
+        per_row = (time.perf_counter() - t1) / probe_rows
+        rows_s = int(max(16, min(R, args.cpu_seconds / max(per_row, 1e-9))))
+        crop = [w[:rows_s].cpu().numpy() for w in warped]
+        t1 = time.perf_counter()
+        img, _ = pyoracle.stack_images(crop, 3.0, 3.0, 5, order=pyoracle.ORDER_SELECT)
+        cst = pyoracle.compute_image_stats(img)
+        pyoracle.apply_stf(img, pyoracle.auto_stf(cst), cst)
+        dt = time.perf_counter() - t1
+        cpu = {"value": round(N * rows_s * Cc / 1e6 / dt, 2), "unit": "MPix/s", "cores": threads, "kind": "port",
+               "sample": f"{N}x{rows_s}x{Cc} crop of the same registered frames: kappa-sigma stack + stats + auto-STF "
+                         f"(no warp), oracle/liboracle.so with OpenMP over rows, {dt:.1f} s"}
+        # parity spot check of the timed configuration on that crop
+        got = stacked[:rows_s].cpu().numpy()
+        bad = int((~((got == img) | (np.isnan(got) & np.isnan(img)))).sum())
+        rel = float(np.nanmax(np.abs(got - img) / np.maximum(np.abs(img), 1e-30)))
+        cpu["parity_vs_gpu"] = {"pixels": int(img.size), "bit_mismatches": bad, "max_rel_err": rel}
+
+    if rank == 0:
+        out = {
+            "metric": "MPix/s sigma-clipped stack+stretch, 64x4096x4096 f32",
+            "value": round(value, 1), "unit": "MPix/s (input frame-pixels)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: {N}x{R}x{Cc} f32 synthetic frames per GPU: "
+                                   + ("affine register (bicubic warp, 63 known rigid transforms) + " if register else "")
+                                   + ("kappa-sigma stack (3/3/5)" if world == 1 else
+                                      "per-GPU kappa-sigma partial + RCCL all-reduce(sum f64, count i32) + divide")
+                                   + " + image stats + auto-STF u8",
+                       "frames_per_gpu": N, "rows": R, "cols": Cc, "device": name, "cus": cus,
+                       "output_mpix_per_s": round(world * P / 1e6 / (elapsed / args.steps), 1),
+                       "rejected_pixels": rejected, "median": st.median,
+                       "measured_copy_GBs": round(copy_gbs, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

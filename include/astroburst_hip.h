@@ -1,0 +1,164 @@
+/*
+ * astroburst_hip.h -- C ABI of libastroburst_hip.so, the MI355X (gfx950) implementation of
+ * AstroBurst's pixel-compute hot path.
+ *
+ * The reference (Rust, src-tauri/) has no FFI seam of its own; the replaceable edge is the
+ * internal call `cmd::* -> core::*`.  Every entry point below replaces one
+ * `core::*` function and cites it (paths relative to src-tauri/src/).  INTEGRATION.md shows the
+ * Rust `extern "C"` block and the safe wrappers a maintainer would add.
+ *
+ * Conventions
+ *  - plain C types only; all functions return an ab_status (0 = ok) and never abort/throw
+ *    (the app is built panic="abort", Cargo.toml:64).  ab_last_error(ctx) returns the message,
+ *    worded like the reference's anyhow strings where one exists (e.g. "No images to stack").
+ *  - planes are contiguous row-major f32, dims (rows, cols), exactly ndarray::Array2<f32>'s
+ *    standard layout (`.as_slice().expect("contiguous")`, combine.rs:152-155).
+ *  - an ab_plane may point at HOST memory (on_device = 0: staged through HBM by the library)
+ *    or at DEVICE memory (on_device = 1: used in place, nothing is copied).  Inputs are
+ *    borrowed and never modified; outputs are caller-allocated.
+ *  - a context owns one HIP stream (or borrows the caller's, ab_ctx_set_stream) and a scratch
+ *    arena; it is not shared between threads -- create one per calling thread (the Tauri
+ *    commands run concurrently on tokio blocking threads, cmd/common.rs:345-352).
+ *  - device-plane calls are asynchronous on the context's stream unless they return scalars.
+ */
+#ifndef ASTROBURST_HIP_H
+#define ASTROBURST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AB_API __attribute__((visibility("default")))
+
+typedef enum {
+    AB_OK = 0,
+    AB_ERR_INVALID = 1,     /* bad argument (message says which) */
+    AB_ERR_HIP = 2,         /* HIP runtime error (message carries hipGetErrorString) */
+    AB_ERR_NO_DEVICE = 3,   /* no gfx950 device / wrong architecture */
+    AB_ERR_UNSUPPORTED = 4, /* valid request this build cannot serve yet */
+    AB_ERR_NOMEM = 5
+} ab_status;
+
+typedef struct ab_ctx ab_ctx;
+
+typedef struct {
+    const float *data;
+    int64_t rows, cols;
+    int32_t on_device; /* 0 host, 1 device (HBM) */
+} ab_plane;
+
+typedef struct {
+    float *data;
+    int64_t rows, cols;
+    int32_t on_device;
+} ab_plane_mut;
+
+/* ---- context / memory ------------------------------------------------------------------- */
+AB_API int ab_ctx_create(int device_id, ab_ctx **out);
+AB_API void ab_ctx_destroy(ab_ctx *ctx);
+AB_API const char *ab_last_error(const ab_ctx *ctx);
+AB_API const char *ab_version(void);
+/* borrow an existing hipStream_t (e.g. PyTorch's current stream); NULL restores the own stream */
+AB_API int ab_ctx_set_stream(ab_ctx *ctx, void *hip_stream);
+AB_API void *ab_ctx_get_stream(ab_ctx *ctx);
+AB_API int ab_ctx_synchronize(ab_ctx *ctx);
+AB_API int ab_device_alloc(ab_ctx *ctx, size_t bytes, void **out_dptr);
+AB_API int ab_device_free(ab_ctx *ctx, void *dptr);
+AB_API int ab_upload(ab_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+AB_API int ab_download(ab_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* device properties the bench prints: name, CU count, HBM bytes */
+AB_API int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint64_t *hbm_bytes);
+
+/* ---- a1/a2  core/stacking/combine.rs ------------------------------------------------------ */
+/* StackConfig, types/stacking.rs:3-20 (defaults 3.0, 3.0, 5, align=true) */
+typedef struct {
+    float sigma_low;
+    float sigma_high;
+    uint32_t max_iterations;
+    int32_t align; /* bool */
+} ab_stack_config;
+
+/* The per-pixel kernel of stack_images (combine.rs:160-182 + sigma_clip_combine :14-92):
+ * out[y][x] = sigma_clip_combine({planes[k][y][x] finite}, sigma_low, sigma_high, max_iter).
+ * All planes must be at least out->rows x out->cols; each is read with its own row stride
+ * (= its cols), i.e. the reference's top-left crop to the minimum dims (combine.rs:104-113)
+ * costs nothing.  *out_rejected receives StackResult.rejected_pixels (sum of per-pixel
+ * rejection counts, combine.rs:158,181).  1 <= n <= 64 frames per call in this build.
+ * Floating-point contract: the f64 sums of iterations >= 1 are taken over the survivors in
+ * ascending value order (the reference's order is unspecified, SURVEY.md 7 hard part 2). */
+AB_API int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
+                               ab_plane_mut *out, uint64_t *out_rejected);
+
+/* Passing out_rejected = NULL to ab_stack_sigma_clip keeps the call fully asynchronous on the
+ * context's stream; the count of that last stack can be fetched later (synchronises). */
+AB_API int ab_stack_last_rejected(ab_ctx *ctx, uint64_t *out_rejected);
+
+/* stack_images (combine.rs:94-193): crops to the minimum dims, optionally registers frames
+ * 1..n-1 on frame 0 (PhaseCorrelation, combine.rs:126-138), then sigma-clip combines.
+ * out must be min_rows x min_cols.  offsets (nullable) receives n (dy, dx) pairs rounded to
+ * i32 as the reference reports them (combine.rs:135-137).  Errors: n == 0 -> AB_ERR_INVALID
+ * "No images to stack" (combine.rs:98-100). */
+AB_API int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
+                           ab_plane_mut *out, int32_t *offsets_dy_dx, uint64_t *out_rejected);
+
+/* Frame-sharded partial: per pixel the f64 sum and the u32 count of
+ * the survivors of THIS shard's frames; ranks all-reduce (sum, count) and divide.  This is a
+ * two-level estimator, not the reference's single-level one; its CPU checker is
+ * orc_stack_partial_noalign.  out_sum/out_cnt are device pointers of rows*cols elements. */
+AB_API int ab_stack_sigma_clip_partial(ab_ctx *ctx, const ab_plane *planes, size_t n,
+                                       const ab_stack_config *cfg, int64_t rows, int64_t cols,
+                                       double *out_sum_dev, uint32_t *out_cnt_dev, uint64_t *out_rejected);
+/* out[i] = cnt[i] ? (float)(sum[i] / cnt[i]) : 0  -- the divide after the all-reduce */
+AB_API int ab_stack_finalize_partial(ab_ctx *ctx, const double *sum_dev, const uint32_t *cnt_dev, int64_t n,
+                                     float *out_dev);
+
+/* ---- a3/a5  core/stacking/align.rs:36-57, core/alignment/affine.rs:663-690 ---------------- */
+/* shift_image_subpixel(image, dy, dx): out(y,x) = bicubic(src, y+dy, x+dx), 0.0 where the
+ * sample centre leaves [-0.5, dim-0.5]; |dy|,|dx| < 1e-12 is a copy. */
+AB_API int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, double dx, ab_plane_mut *out);
+/* warp_image(image, &AffineTransform{a,b,tx,c,d,ty}, out_rows, out_cols): the transform maps
+ * OUTPUT (x,y) to SOURCE (sx,sy) (affine.rs:74-80); 0.0 outside 0<=sx<cols-1, 0<=sy<rows-1. */
+AB_API int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out);
+
+/* ---- a9  core/imaging/stats.rs ------------------------------------------------------------- */
+typedef struct { /* ImageStats, types/image.rs:2-10 */
+    double min, max, median, mad, sigma, mean;
+    uint64_t valid_count;
+} ab_image_stats;
+
+/* compute_image_stats (stats.rs:15-23): exact select for <= 4 000 000 px, 65 536-bin
+ * histogram refinement above.  Synchronous (returns scalars). */
+AB_API int ab_compute_image_stats(ab_ctx *ctx, const ab_plane *img, ab_image_stats *out);
+/* compute_image_stats_with_known_range (stats.rs:25-41) */
+AB_API int ab_compute_image_stats_with_known_range(ab_ctx *ctx, const ab_plane *img, double known_min,
+                                                   double known_max, ab_image_stats *out);
+/* build_histogram (stats.rs:378-421): bins u32[bins] on the HOST; range < 1e-10 -> zeros */
+AB_API int ab_build_histogram(ab_ctx *ctx, const ab_plane *img, size_t bins, double dmin, double dmax,
+                              uint32_t *out_bins_host);
+/* pass-2 histogram of the >4M-px path (stats.rs:260-300), exposed for bin-for-bin parity
+ * tests and for the multi-GPU all-reduce of row-band partial histograms. */
+AB_API int ab_stats_value_hist(ab_ctx *ctx, const ab_plane *img, double gmin, double gmax,
+                               uint64_t *hist65536_host, double *out_sum, uint64_t *out_cnt);
+
+/* ---- a10/a11  core/imaging/stf.rs ----------------------------------------------------------- */
+typedef struct { double shadow, midtone, highlight; } ab_stf_params;        /* types/image.rs:36-40 */
+typedef struct { double target_bg, shadow_k; } ab_auto_stf_config;          /* types/image.rs:52-65 */
+/* auto_stf (stf.rs:13-39) -- host scalar maths, kept in the library so callers get one ABI */
+AB_API int ab_auto_stf(const ab_image_stats *stats, const ab_auto_stf_config *cfg, ab_stf_params *out);
+/* apply_stf -> Vec<u8> (stf.rs:89-102) */
+AB_API int ab_apply_stf_u8(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st,
+                           uint8_t *out, int32_t out_on_device);
+/* apply_stf_f32 (stf.rs:104-120); out may alias img.data (apply_stf_inplace, stf.rs:147-155) */
+AB_API int ab_apply_stf_f32(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st,
+                            ab_plane_mut *out);
+
+/* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
+AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASTROBURST_HIP_H */

@@ -18,3 +18,12 @@ def oracle():
     from oracle import pyoracle
     pyoracle.lib()
     return pyoracle
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """The product under test: libastroburst_hip.so through astroburst_amd.Context (gfx950 only)."""
+    import astroburst_amd as ab
+    c = ab.Context(0)          # raises loudly without the .so or without an MI355X
+    yield c
+    c.close()

@@ -1,0 +1,207 @@
+"""GPU parity: per-pixel kappa-sigma stacking (combine.rs) through the C ABI vs the CPU oracle.
+
+Bar: bit-exact against the oracle in ascending-summation mode (the order the kernel documents);
+<= 1e-5 relative against the oracle in the reference-like select-order mode.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def make_frames(rng, n, rows, cols, nan_rate=0.01, cr_rate=0.01, zero_border=True, scale=1.0):
+    base = 1000.0 + 50.0 * rng.standard_normal((rows, cols))
+    frames = []
+    for k in range(n):
+        f = (base + 12.0 * rng.standard_normal((rows, cols))).astype(np.float32) * np.float32(scale)
+        hit = rng.random((rows, cols)) < cr_rate
+        f[hit] *= rng.uniform(20, 50, hit.sum()).astype(np.float32)
+        bad = rng.random((rows, cols)) < nan_rate
+        f[bad] = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), bad.sum())
+        if zero_border and k % 3 == 2:
+            f[:2, :] = 0.0
+            f[:, -3:] = 0.0
+        frames.append(f)
+    return frames
+
+
+def assert_bit_equal(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    if not same.all():
+        idx = np.argwhere(~same)[:5]
+        raise AssertionError(f"{(~same).sum()} of {a.size} differ; first {idx.tolist()}: "
+                             f"{[(a[tuple(i)], b[tuple(i)]) for i in idx]}")
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 8, 9, 10, 16, 17, 31, 32, 33, 48, 63, 64])
+def test_stack_matches_oracle(ctx, oracle, n):
+    rng = np.random.default_rng(100 + n)
+    frames = make_frames(rng, n, 37, 131)
+    got, rej = ctx.stack_sigma_clip(frames, 3.0, 3.0, 5)
+    ref, ref_rej = oracle.stack_images(frames, 3.0, 3.0, 5, order=oracle.ORDER_ASCENDING)
+    assert_bit_equal(got, ref)
+    assert rej == ref_rej
+    # reference-like summation order (post-select permutation): within the north-star tolerance
+    ref2, ref2_rej = oracle.stack_images(frames, 3.0, 3.0, 5, order=oracle.ORDER_SELECT)
+    np.testing.assert_allclose(got, ref2, rtol=1e-5, atol=0)
+    assert rej == ref2_rej
+
+
+@pytest.mark.parametrize("n", [4, 16, 64])
+def test_stack_all_finite_fast_path(ctx, oracle, n):
+    rng = np.random.default_rng(7 + n)
+    frames = make_frames(rng, n, 64, 256, nan_rate=0.0, zero_border=False)
+    got, rej = ctx.stack_sigma_clip(frames)
+    ref, ref_rej = oracle.stack_images(frames, order=oracle.ORDER_ASCENDING)
+    assert_bit_equal(got, ref)
+    assert rej == ref_rej and rej > 0
+
+
+@pytest.mark.parametrize("sl,sh,it", [(3.0, 3.0, 0), (3.0, 3.0, 1), (2.0, 2.0, 5), (1.0, 4.0, 3), (0.5, 0.5, 10),
+                                      (0.0, 0.0, 5), (-1.0, 3.0, 5), (3.0, float("inf"), 5), (float("nan"), 3.0, 2)])
+def test_stack_parameter_sweep(ctx, oracle, sl, sh, it):
+    rng = np.random.default_rng(5)
+    frames = make_frames(rng, 12, 24, 70)
+    got, rej = ctx.stack_sigma_clip(frames, sl, sh, it)
+    ref, ref_rej = oracle.stack_images(frames, sl, sh, it, order=oracle.ORDER_ASCENDING)
+    assert_bit_equal(got, ref)
+    assert rej == ref_rej
+
+
+def test_stack_edge_pixels(ctx, oracle):
+    """hand-built pixels: all non-finite, one finite, two finite, ties, constant, negatives, extremes"""
+    n = 8
+    cols = 12
+    px = np.zeros((n, cols), np.float32)
+    px[:, 0] = np.nan                                           # nothing finite -> 0.0 (combine.rs:21-23)
+    px[:, 1] = np.nan; px[3, 1] = 42.5                          # single finite -> itself (combine.rs:24-26)
+    px[:, 2] = np.inf; px[1, 2] = -7.0; px[6, 2] = 9.0          # two finite
+    px[:, 3] = 5.0                                              # constant: MAD 0 -> sigma floor 1e-10
+    px[:, 4] = 5.0; px[2, 4] = 5.0000005                        # constant + 1 ulp outlier -> rejected
+    px[:, 5] = [1, 1, 1, 1, 2, 2, 2, 2]                         # ties around the median
+    px[:, 6] = [-3e38, 3e38, 1, 2, 3, 4, 5, 6]                  # dev overflows to inf
+    px[:, 7] = [-1, -2, -3, -4, -5, -6, -7, -800]               # negatives + outlier
+    px[:, 8] = [1e-40, 2e-40, 3e-40, 1e-39, 0, -0.0, 1e-45, 5e-41]   # subnormals
+    px[:, 9] = [0, 0, 0, 0, 0, 0, 1000, 1001]                   # zero padding majority
+    px[:, 10] = [100, 101, 99, 100, 5000, 6000, 7000, 100.5]    # many outliers: several iterations
+    px[:, 11] = np.arange(8)
+    frames = [px[k].reshape(1, cols).copy() for k in range(n)]
+    for sl, sh, it in [(3.0, 3.0, 5), (1.0, 1.0, 5), (3.0, 3.0, 1)]:
+        got, rej = ctx.stack_sigma_clip(frames, sl, sh, it)
+        ref, ref_rej = oracle.stack_images(frames, sl, sh, it, order=oracle.ORDER_ASCENDING)
+        assert_bit_equal(got, ref)
+        assert rej == ref_rej
+    assert got[0, 0] == 0.0 and ctx.stack_sigma_clip(frames)[0][0, 1] == np.float32(42.5)
+
+
+def test_stack_ragged_frames_crop_top_left(ctx, oracle):       # combine.rs:104-113
+    rng = np.random.default_rng(11)
+    dims = [(40, 50), (33, 64), (48, 41), (35, 45), (60, 60)]
+    frames = [(1000 + 10 * rng.standard_normal(d)).astype(np.float32) for d in dims]
+    res = ctx.stack_images(frames, align=False)
+    ref, ref_rej = oracle.stack_images(frames, order=oracle.ORDER_ASCENDING)
+    assert res.image.shape == (33, 41) and res.frame_count == 5
+    assert res.offsets == [(0, 0)] * 5
+    assert_bit_equal(res.image, ref)
+    assert res.rejected_pixels == ref_rej
+
+
+def test_single_frame_and_no_frames(ctx, oracle):
+    import astroburst_amd as ab
+    f = np.array([[1.0, np.nan, np.inf, -2.0]], np.float32)
+    got, rej = ctx.stack_sigma_clip([f])
+    ref, _ = oracle.stack_images([f])
+    assert_bit_equal(got, ref)
+    assert rej == 0
+    with pytest.raises(ab.AstroBurstError, match="No images to stack"):     # combine.rs:98-100
+        ctx.stack_images([])
+
+
+def test_too_many_frames_is_loud(ctx):
+    import astroburst_amd as ab
+    frames = [np.ones((2, 2), np.float32)] * 65
+    with pytest.raises(ab.AstroBurstError, match="frames"):
+        ctx.stack_sigma_clip(frames)
+
+
+# ---- the reference's own unit tests, run through the HIP path (combine.rs:199-284) ----------------
+def test_ref_sigma_clip_clean_data(ctx):
+    mean, rej = ctx.sigma_clip_combine([10.0, 10.1, 9.9, 10.0, 10.2], 3.0, 3.0, 5)
+    assert abs(mean - 10.04) < 0.1 and rej == 0
+
+
+def test_ref_sigma_clip_with_outlier(ctx):
+    mean, rej = ctx.sigma_clip_combine([10.0, 10.1, 9.9, 10.0, 500.0], 3.0, 3.0, 5)
+    assert mean < 15.0 and rej > 0
+
+
+def test_ref_sigma_clip_cosmic_ray(ctx):
+    mean, rej = ctx.sigma_clip_combine([100.0, 100.2, 99.8, 100.1, 100.0, 5000.0, 99.9], 2.0, 2.0, 5)
+    assert abs(mean - 100.0) < 1.0 and rej >= 1
+
+
+def test_ref_sigma_clip_empty_and_single(ctx):
+    assert ctx.sigma_clip_combine([], 3.0, 3.0, 5) == (0.0, 0)
+    assert ctx.sigma_clip_combine([42.0], 3.0, 3.0, 5) == (42.0, 0)
+
+
+def test_ref_stack_identical(ctx):
+    img = (np.arange(16, dtype=np.float32) * 10.0).reshape(4, 4)
+    res = ctx.stack_images([img, img, img], align=False)
+    assert res.frame_count == 3
+    assert abs(res.image[0, 0]) < 1e-4 and abs(res.image[1, 1] - 50.0) < 1e-4
+
+
+def test_ref_stack_rejects_outlier(ctx):
+    clean = np.full((4, 4), 100.0, np.float32)
+    noisy = clean.copy()
+    noisy[2, 2] = 50000.0
+    res = ctx.stack_images([clean, clean, clean, noisy, clean], 3.0, 3.0, 5, align=False)
+    assert abs(res.image[2, 2] - 100.0) < 1.0 and res.rejected_pixels > 0
+
+
+# ---- device-resident planes + size-independent properties -------------------------------------------
+def test_device_planes_and_properties(ctx, oracle):
+    import torch
+    from astroburst_amd import synth
+    frames = synth.make_stack(24, 128, 192, device="cpu")
+    dev = [f.cuda() for f in frames]
+    ctx.use_torch_stream()
+    out, rej = ctx.stack_sigma_clip(dev)
+    ref, ref_rej = oracle.stack_images([f.numpy() for f in frames], order=oracle.ORDER_ASCENDING)
+    assert_bit_equal(out.cpu().numpy(), ref)
+    assert rej == ref_rej
+    # frame-order invariance: the kernel sums survivors in value order, so any permutation is bit-identical
+    perm = torch.randperm(24, generator=torch.Generator().manual_seed(1)).tolist()
+    out_p, rej_p = ctx.stack_sigma_clip([dev[i] for i in perm])
+    assert torch.equal(out_p, out) or torch.equal(torch.nan_to_num(out_p), torch.nan_to_num(out))
+    assert rej_p == rej
+    # exact power-of-two scaling: every step of the algorithm commutes with x -> 4x
+    out4, rej4 = ctx.stack_sigma_clip([f * 4.0 for f in dev])
+    assert torch.equal(out4, out * 4.0) and rej4 == rej
+    # stacking copies of one frame returns it (finite pixels) and rejects nothing
+    one = torch.nan_to_num(dev[0], nan=0.0, posinf=0.0, neginf=0.0)
+    same, rej_same = ctx.stack_sigma_clip([one] * 8)
+    assert torch.equal(same, one) and rej_same == 0
+
+
+def test_partial_two_level(ctx, oracle):
+    """frame-sharded estimator: per-shard (sum, count), then divide"""
+    import torch
+    from astroburst_amd import synth
+    frames = synth.make_stack(16, 64, 96, device="cpu")
+    shards = [frames[:8], frames[8:]]
+    tot_s = None
+    for sh in shards:
+        s, c, rej = ctx.stack_partial([f.cuda() for f in sh])
+        rs, rc, rrej = oracle.stack_partial([f.numpy() for f in sh])
+        assert np.array_equal(s.cpu().numpy(), rs) and np.array_equal(c.cpu().numpy().astype(np.uint32), rc)
+        assert rej == rrej
+        tot_s = (s, c) if tot_s is None else (tot_s[0] + s, tot_s[1] + c)
+    out = ctx.stack_finalize_partial(tot_s[0], tot_s[1])
+    s_np, c_np = tot_s[0].cpu().numpy(), tot_s[1].cpu().numpy()
+    want = np.where(c_np > 0, (s_np / np.maximum(c_np, 1)).astype(np.float32), np.float32(0))
+    assert np.array_equal(out.cpu().numpy(), want)
