@@ -87,6 +87,7 @@ def lib() -> C.CDLL:
     L.ab_last_error.restype = C.c_char_p
     L.ab_version.restype = C.c_char_p
     L.ab_ctx_set_stream.argtypes = [vp, vp]
+    L.ab_ctx_reset_stream.argtypes = [vp]
     L.ab_ctx_get_stream.argtypes = [vp]
     L.ab_ctx_get_stream.restype = vp
     L.ab_ctx_synchronize.argtypes = [vp]

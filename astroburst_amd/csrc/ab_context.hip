@@ -49,7 +49,7 @@ int ab_ctx_create(int device_id, ab_ctx **out) {
 void ab_ctx_destroy(ab_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->counters) (void)hipFree(ctx->counters);
@@ -61,7 +61,14 @@ const char *ab_last_error(const ab_ctx *ctx) { return ctx ? ctx->err.c_str() : "
 
 int ab_ctx_set_stream(ab_ctx *ctx, void *hip_stream) {
     if (!ctx) return AB_ERR_INVALID;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    // a NULL handle IS a stream: HIP's legacy default stream (what PyTorch uses by default)
+    ctx->stream = (hipStream_t)hip_stream;
+    return AB_OK;
+}
+
+int ab_ctx_reset_stream(ab_ctx *ctx) {
+    if (!ctx) return AB_ERR_INVALID;
+    ctx->stream = ctx->own_stream;
     return AB_OK;
 }
 

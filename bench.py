@@ -176,12 +176,12 @@ def main():
         from oracle import pyoracle
         import numpy as np
         threads = pyoracle.max_threads()
-        probe_rows = 8
+        probe_rows = 4 * threads if 4 * threads < R else R     # a few rows per thread: a fair rate estimate
         crop = [w[:probe_rows].cpu().numpy() for w in warped]
         t1 = time.perf_counter()
         pyoracle.stack_images(crop, 3.0, 3.0, 5, order=pyoracle.ORDER_SELECT)
         per_row = (time.perf_counter() - t1) / probe_rows
-        rows_s = int(max(16, min(R, args.cpu_seconds / max(per_row, 1e-9))))
+        rows_s = int(max(probe_rows, min(R, args.cpu_seconds / max(per_row, 1e-9))))
         crop = [w[:rows_s].cpu().numpy() for w in warped]
         t1 = time.perf_counter()
         img, _ = pyoracle.stack_images(crop, 3.0, 3.0, 5, order=pyoracle.ORDER_SELECT)

@@ -61,8 +61,11 @@ AB_API int ab_ctx_create(int device_id, ab_ctx **out);
 AB_API void ab_ctx_destroy(ab_ctx *ctx);
 AB_API const char *ab_last_error(const ab_ctx *ctx);
 AB_API const char *ab_version(void);
-/* borrow an existing hipStream_t (e.g. PyTorch's current stream); NULL restores the own stream */
+/* borrow an existing hipStream_t (e.g. PyTorch's current stream).  A NULL handle means HIP's
+ * default stream, which is what PyTorch runs on unless told otherwise. */
 AB_API int ab_ctx_set_stream(ab_ctx *ctx, void *hip_stream);
+/* go back to the context's own (non-blocking) stream */
+AB_API int ab_ctx_reset_stream(ab_ctx *ctx);
 AB_API void *ab_ctx_get_stream(ab_ctx *ctx);
 AB_API int ab_ctx_synchronize(ab_ctx *ctx);
 AB_API int ab_device_alloc(ab_ctx *ctx, size_t bytes, void **out_dptr);
