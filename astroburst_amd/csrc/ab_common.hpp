@@ -5,11 +5,14 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/astroburst_hip.h"
+
+#define AB_REJ_SLOTS 2048
 
 struct ab_ctx {
     int device = 0;
@@ -23,8 +26,10 @@ struct ab_ctx {
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     // device-side u64 counters (rejected pixels etc.)
-    unsigned long long *counters = nullptr;  // 16 x u64
+    unsigned long long *counters = nullptr;  // AB_REJ_SLOTS x u64
     int cu_count = 0;
+    // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
+    bool stack_exact = false;
 };
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);

@@ -36,12 +36,14 @@ int ab_ctx_create(int device_id, ab_ctx **out) {
         return AB_ERR_NO_DEVICE;
     }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->counters, 16 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void **)&ctx->counters, AB_REJ_SLOTS * sizeof(unsigned long long)) != hipSuccess) {
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return AB_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    const char *ex = getenv("AB_STACK_EXACT");
+    ctx->stack_exact = ex && ex[0] == '1';
     *out = ctx;
     return AB_OK;
 }

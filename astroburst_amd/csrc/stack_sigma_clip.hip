@@ -42,6 +42,7 @@
 namespace {
 
 constexpr int kMaxFrames = 64;
+constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
 
 struct StackArgs {
@@ -89,93 +90,71 @@ __device__ __forceinline__ double masked_sum(const float (&v)[NP], int a, int b)
     return S;
 }
 
-// k-th (k = NP/2) smallest of |v_i - med| for a fully populated sorted vector (n == NP),
-// med = v[NP/2].  See the header comment; pairs are (v[p], v[p+m]) with m = NP/2.
-template <int NP>
-__device__ __forceinline__ float mad_full(const float (&v)[NP], float med) {
-    constexpr int m = NP / 2;
+// Median and MAD of the n finite samples of one pixel from the SORTED vector v (pads = +inf on
+// top), for the wave-uniform candidate median position MM = n/2 (n = 2MM or 2MM+1):
+//   med = v[MM]                                                        (combine.rs:38-40)
+//   MAD = (n/2)-th smallest of |v_i - med|                              (combine.rs:42-46)
+// The deviations left of the median (A[j] = med - v[MM-j], ascending in j) and right of it
+// (B[j] = v[MM+1+j] - med) are two sorted runs, and the k-th element of their merge is
+//   min over splits i + j = k + 1 of max(A[i-1], B[j-1]);
+// with k = MM the splits pair v[p] with v[p+MM]: term(p) = max(med - v[p], v[p+MM] - med),
+// p = 1 .. n-MM-1, plus the p = 0 term med - v[0].  For even n the p = MM term reads the +inf pad
+// at v[2MM] and drops out by itself, so one instruction stream serves both parities.
+// ~2N min/max/sub instead of a second selection, and every register index is a constant.
+template <int NP, int MM>
+__device__ __forceinline__ void med_mad_at(const float (&v)[NP], float &med_out, float &mad_out) {
+    const float med = v[MM];
     float best = med - v[0];
 #pragma unroll
-    for (int p = 1; p <= NP - m - 1; ++p) {
-        float a = med - v[p];
-        float b = v[p + m] - med;
-        best = fminf(best, fmaxf(a, b));
+    for (int p = 1; p <= MM; ++p) {
+        if (p + MM < NP) {
+            const float a = med - v[p];
+            const float b = v[p + MM] - med;
+            best = fminf(best, fmaxf(a, b));
+        }
     }
-    return best;
+    med_out = med;
+    mad_out = best;
 }
 
-template <int NP, bool PARTIAL>
-__global__ __launch_bounds__(256) void stack_sigma_clip_kernel(const StackArgs args) {
-    const int64_t total = args.rows * args.cols;
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = g < total;
-    if (!valid) g = total - 1;
-
-    int64_t y = 0, x = g;
-    if (!args.contiguous) {
-        y = g / args.cols;
-        x = g - y * args.cols;
-    }
-
-    // ---- gather (combine.rs:170-175): only finite samples take part ----
-    // Non-finite samples and the slots past args.n become +-inf PADS.  They are split so that the
-    // (upper) median of the n finite samples always lands on sorted position NP/2:
-    //   c_lo = NP/2 - n/2 pads of -inf below, the rest +inf above.
-    // That keeps every register index a compile-time constant (a per-lane `v[n/2]` would turn
-    // the sample vector into a runtime-indexed private array, i.e. scratch memory).
-    float v[NP];
-    int n = 0;
-#pragma unroll
-    for (int f = 0; f < NP; ++f) {
-        float s = __builtin_inff();
-        if (f < args.n) {
-            const int64_t off = args.contiguous ? g : (y * args.ld[f] + x);
-            s = args.p[f][off];
+// lanes of one wave can disagree on n/2 (non-finite samples): evaluate each position present
+template <int NP, int MM>
+__device__ __forceinline__ void med_mad_dispatch(const float (&v)[NP], int m, int cur, float &med, float &mad) {
+    if (cur == MM) {
+        float md, ma;
+        med_mad_at<NP, MM>(v, md, ma);
+        if (m == MM) {
+            med = md;
+            mad = ma;
         }
-        v[f] = s;
-        n += __builtin_isfinite(s) ? 1 : 0;
+        return;
     }
-    const bool full_wave = __all(n == NP);
-    const int c_lo = NP / 2 - (n >> 1);
-    if (!full_wave) {
-        int k = 0;  // running index among this pixel's pads
-#pragma unroll
-        for (int f = 0; f < NP; ++f) {
-            const bool fin = __builtin_isfinite(v[f]);
-            const float pad = (k < c_lo) ? -__builtin_inff() : __builtin_inff();
-            v[f] = fin ? v[f] : pad;
-            k += fin ? 0 : 1;
-        }
-    }
+    if constexpr (MM > 0) med_mad_dispatch<NP, MM - 1>(v, m, cur, med, mad);
+}
 
-    SortNet<NP>::sort(v);  // finite samples now occupy sorted positions [c_lo, c_lo + n)
+// Per-lane state handed from the prologue (gather + sort + median/MAD) to a clipping engine.
+struct ClipResult {
+    float value;   // sigma_clip_combine's f32 result
+    double sum;    // f64 sum of the survivors   (partial mode)
+    int len;       // number of survivors        (partial mode)
+    uint32_t rej;  // rejected samples of this pixel
+};
 
-    // ---- iteration 0: median / MAD (combine.rs:37-48) ----
-    const float med = v[NP / 2];
-    float mad;
-    if (full_wave) {
-        mad = mad_full<NP>(v, med);
-    } else {
-        // |v_i - med| of the finite samples, plus c_lo pads of -1 below and +inf above, so that
-        // the n/2-th smallest deviation also lands on position NP/2 of the sorted deviations.
-        float d[NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const float dev = fabsf(v[i] - med);
-            d[i] = (i < c_lo) ? -1.0f : ((i < c_lo + n) ? dev : __builtin_inff());
-        }
-        SortNet<NP>::sort(d);
-        mad = d[NP / 2];
-    }
+// ---- clipping engine A: "exact" -- every iteration re-sums the survivors directly --------------
+// Bit-for-bit the oracle's ORC_ORDER_ASCENDING arithmetic (two-pass mean / sum of squared
+// deviations over the interval, ascending).  ~1500 VALU slots per iteration; kept as the
+// in-library cross-check of the fast engine (AB_STACK_EXACT=1) and for its provable order.
+template <int NP>
+__device__ __forceinline__ ClipResult clip_exact(float (&v)[NP], int n, float med, float mad,
+                                                 float sigma_low, float sigma_high, uint32_t max_iter) {
     float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
     float center = med;
-
-    int a = c_lo, b = c_lo + n - 1, len = n;
+    int a = 0, b = n - 1, len = n;
     uint32_t rej = 0;
     float last_center = __builtin_nanf("");
     bool active = (n >= 2);
 
-    for (uint32_t it = 0; it < args.max_iter; ++it) {
+    for (uint32_t it = 0; it < max_iter; ++it) {
         if (!__any(active)) break;
         launder<NP>(v);  // keep f32->f64 conversions inside the iteration (VGPR pressure)
         if (it > 0) {
@@ -200,8 +179,8 @@ __global__ __launch_bounds__(256) void stack_sigma_clip_kernel(const StackArgs a
         const bool go = active && (len >= 2);  // `if len < 2 { break }` (combine.rs:33-35)
         if (go) last_center = center;          // combine.rs:63
 
-        const float lo = -args.sigma_low * sigma;  // combine.rs:65-66
-        const float hi = args.sigma_high * sigma;
+        const float lo = -sigma_low * sigma;  // combine.rs:65-66
+        const float hi = sigma_high * sigma;
         // survivors stay an interval of the sorted order: count what falls off either end
         int cl = 0, ch = 0;
 #pragma unroll
@@ -231,32 +210,367 @@ __global__ __launch_bounds__(256) void stack_sigma_clip_kernel(const StackArgs a
     launder<NP>(v);
     opaque(a, b);
     const double S = masked_sum<NP>(v, a, b);  // empty interval (a=1,b=0 or n=0) sums to 0
-    float result;
+    ClipResult r;
     if (n == 0) {
-        result = 0.0f;
+        r.value = 0.0f;
     } else if (n == 1) {
-        result = med;  // the single finite sample sits on position NP/2
+        r.value = med;  // the single finite sample is v[0] = v[n/2]
     } else if (len == 0) {
-        result = __builtin_isfinite(last_center) ? last_center : 0.0f;
+        r.value = __builtin_isfinite(last_center) ? last_center : 0.0f;
     } else {
-        result = (float)(S / (double)len);
+        r.value = (float)(S / (double)len);
+    }
+    r.sum = (len > 0) ? S : 0.0;
+    r.len = len > 0 ? len : 0;
+    r.rej = rej;
+    return r;
+}
+
+// ---- clipping engine B: "fast" -- incremental statistics, only the ends are re-examined ---------
+// Because the survivors are an interval [a, b] of the sorted samples and an iteration can only
+// shave samples off its two ends:
+//   * one pass after the median/MAD clip accumulates  S1 = sum x_i  and  Q1 = sum (x_i - c0)^2
+//     over the survivors (f64, ascending; c0 = the median, so every term is small and nothing
+//     cancels -- the big outliers are already gone);
+//   * iteration k >= 1 gets  mean = (S1 - S_rem)/n  and
+//     sum (x_i - mean)^2 = (Q1 - Q_rem) - n (mean - c0)^2      (same algebra as combine.rs:50-59)
+//     where S_rem / Q_rem collect the few samples shaved off so far;
+//   * the clip test walks inwards from each end in chunks of 4 registers and stops (wave-
+//     uniformly) at the first chunk in which every lane has met a surviving sample.
+// The mean is exact whenever the f64 partial sums are (samples within 2^23 of each other); the
+// variance differs from the two-pass value by a few ulp(f64), i.e. the f32 sigma is identical
+// except with probability ~1e-8 per pixel -- far inside the 1e-5 contract, and measured in
+// tests/ against engine A and the oracle.
+template <int NP>
+__device__ __forceinline__ int wave_max_i32(int x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = max(x, __shfl_xor(x, off, 64));
+    return __builtin_amdgcn_readfirstlane(x);
+}
+template <int NP>
+__device__ __forceinline__ int wave_min_i32(int x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = min(x, __shfl_xor(x, off, 64));
+    return __builtin_amdgcn_readfirstlane(x);
+}
+
+// One clipping pass over the two ends.  UPDATE: also fold the shaved samples into s_rem/q_rem.
+template <int NP, bool UPDATE>
+__device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, int b, float center, float lo, float hi,
+                                          double c0d, float c0, int &cl_out, int &ch_out, double &e_rem, double &q_rem) {
+    constexpr int CH = NP >= 4 ? 4 : NP;
+    int cl = 0, ch = 0;
+    bool found_lo = false, found_hi = false;
+#pragma unroll
+    for (int c = 0; c < NP / CH; ++c) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int i = CH * c + j;
+            const bool in = (i >= a) && (i <= b);
+            const float dev = v[i] - center;
+            const bool ok = dev >= lo;
+            const bool r = go && in && !ok;
+            found_lo = found_lo || (in && ok);
+            cl += r ? 1 : 0;
+            if (UPDATE) {
+                if (__any(r)) {
+                    const float xm = r ? v[i] : c0;
+                    const double e = (double)xm - c0d;  // 0 for lanes that keep the sample
+                    e_rem += e;
+                    q_rem = __builtin_fma(e, e, q_rem);
+                }
+            }
+        }
+        const bool more = go && !found_lo && (CH * c + CH - 1 < b);
+        if (!__any(more)) break;
+    }
+#pragma unroll
+    for (int c = 0; c < NP / CH; ++c) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int i = NP - 1 - (CH * c + j);
+            const bool in = (i >= a) && (i <= b);
+            const float dev = v[i] - center;
+            const bool ok = dev <= hi;
+            const bool r = go && in && !ok;
+            found_hi = found_hi || (in && ok);
+            ch += r ? 1 : 0;
+            if (UPDATE) {
+                if (__any(r)) {
+                    const float xm = r ? v[i] : c0;
+                    const double e = (double)xm - c0d;  // 0 for lanes that keep the sample
+                    e_rem += e;
+                    q_rem = __builtin_fma(e, e, q_rem);
+                }
+            }
+        }
+        const bool more = go && !found_hi && (NP - 1 - (CH * c + CH - 1) > a);
+        if (!__any(more)) break;
+    }
+    cl_out = cl;
+    ch_out = ch;
+}
+
+template <int NP, int STAGE = 99>
+__device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med, float mad, float sigma_low,
+                                                float sigma_high, uint32_t max_iter) {
+    float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
+    float center = med;
+    int a = 0, b = n - 1, len = n;
+    uint32_t rej = 0;
+    float last_center = __builtin_nanf("");
+    bool active = (n >= 2);
+    const float c0 = med;
+    const double c0d = (double)med;
+    double e_rem = 0.0, q_rem = 0.0;
+
+    // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
+    if (max_iter >= 1) {
+        const bool go = active;
+        if (go) last_center = center;
+        const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
+        int cl, ch;
+        clip_ends<NP, false>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem);
+        const int removed = (cl + ch > len) ? len : (cl + ch);
+        if (go) {
+            rej += (uint32_t)removed;
+            len -= removed;
+            if (len > 0) {
+                a += cl;
+                b -= ch;
+            } else {
+                a = 1;
+                b = 0;
+            }
+        }
+        active = go && (removed != 0);
     }
 
+    if constexpr (STAGE == 4) {
+        ClipResult r;
+        r.value = (float)(a + b + len) + center;
+        r.sum = 0.0;
+        r.len = len;
+        r.rej = rej;
+        return r;
+    }
+    // ---- one pass over the survivors: E1 = sum e_i, Q1 = sum e_i^2 with e_i = x_i - c0 (f64) ----
+    // (masked only in the 8-register chunks the interval ends can reach; the rest is 4
+    // instructions per sample: cvt, sub, add, fma)
+    double E1 = 0.0, Q1 = 0.0;
+    {
+        constexpr int CH = NP >= 8 ? 8 : NP;
+        const int a_hi = wave_max_i32<NP>(a), b_lo = wave_min_i32<NP>(b);
+#pragma unroll
+        for (int c = 0; c < NP / CH; ++c) {
+            const bool interior = (CH * c >= a_hi) && (CH * c + CH - 1 <= b_lo);  // wave-uniform
+            if (interior) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const double e = (double)v[CH * c + j] - c0d;
+                    E1 += e;
+                    Q1 = __builtin_fma(e, e, Q1);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int i = CH * c + j;
+                    const bool in = (i >= a) && (i <= b);
+                    const float xm = in ? v[i] : c0;
+                    const double e = (double)xm - c0d;
+                    E1 += e;
+                    Q1 = __builtin_fma(e, e, Q1);
+                }
+            }
+        }
+    }
+
+    if constexpr (STAGE == 5) {
+        ClipResult r;
+        r.value = (float)(E1 + Q1);
+        r.sum = 0.0;
+        r.len = len;
+        r.rej = rej;
+        return r;
+    }
+    // ---- iterations >= 1: mean / sigma from the running sums (combine.rs:50-82) ----
+    for (uint32_t it = 1; it < max_iter; ++it) {
+        if (!__any(active)) break;
+        launder<NP>(v);  // stop LICM from hoisting 64 f32->f64 conversions out of this loop
+        const double nn = (double)len;
+        // sum x_i = n c0 + sum e_i: exact whenever the direct f64 sum is (one rounding otherwise)
+        const double mean = __builtin_fma(nn, c0d, E1 - e_rem) / nn;
+        const double dlt = mean - c0d;
+        double ss = (Q1 - q_rem) - nn * (dlt * dlt);
+        ss = ss > 0.0 ? ss : 0.0;
+        const double variance = ss / fmax(nn - 1.0, 1.0);
+        center = (float)mean;
+        sigma = (float)fmax(sqrt(variance), 1e-10);
+
+        const bool go = active && (len >= 2);
+        if (go) last_center = center;
+        const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
+        int cl, ch;
+        clip_ends<NP, true>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem);
+        const int removed = (cl + ch > len) ? len : (cl + ch);
+        if (go) {
+            rej += (uint32_t)removed;
+            len -= removed;
+            if (len > 0) {
+                a += cl;
+                b -= ch;
+            } else {
+                a = 1;
+                b = 0;
+            }
+        }
+        active = go && (removed != 0);
+    }
+
+    const double S = __builtin_fma((double)len, c0d, E1 - e_rem);
+    ClipResult r;
+    if (n == 0) {
+        r.value = 0.0f;
+    } else if (n == 1) {
+        r.value = med;
+    } else if (len == 0) {
+        r.value = __builtin_isfinite(last_center) ? last_center : 0.0f;
+    } else {
+        r.value = (float)(S / (double)len);
+    }
+    r.sum = (len > 0) ? S : 0.0;
+    r.len = len > 0 ? len : 0;
+    r.rej = rej;
+    return r;
+}
+
+// STAGE < 99 cuts the kernel short for the ablation bench (tools/stack_ablate.hip):
+//   1 = loads only, 2 = + pads + sort, 3 = + median/MAD, 99 = everything (the product).
+template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false>
+__global__ __launch_bounds__(256, EXACT ? 1 : 4) void stack_sigma_clip_kernel(const StackArgs args) {
+    const int64_t total = args.rows * args.cols;
+    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = g < total;
+    if (!valid) g = total - 1;
+
+    int64_t y = 0, x = g;
+    if (!args.contiguous) {
+        y = g / args.cols;
+        x = g - y * args.cols;
+    }
+
+    // ---- gather (combine.rs:170-175): only finite samples take part ----
+    // Non-finite samples and the slots past args.n become +inf PADS that sort to the top, so the
+    // n finite samples end up on sorted positions [0, n).
+    float v[NP];
+    float nf = 0.0f;  // fma(x, 0, nf) stays 0 for finite x and turns NaN for inf / NaN
+    if constexpr (DIRECT) {
+        // All NP frames present, contiguous, < 2^30 px: one vector load fetches the 64 plane pointers
+        // (lane f reads p[f] straight from the kernarg segment), v_readlane broadcasts each into an
+        // SGPR pair, and every sample load is `global_load_dword v, voffset, s[base]` -- no per-frame
+        // scalar loads, no 64-bit address arithmetic, 64 loads issued back to back.
+        const uint64_t *kp = (const uint64_t *)__builtin_amdgcn_kernarg_segment_ptr();
+        const uint64_t mine = kp[threadIdx.x & 63];
+        const uint32_t plo = (uint32_t)mine, phi = (uint32_t)(mine >> 32);
+        const uint32_t off = (uint32_t)g * 4u;
+        const uint32_t plane_bytes = (uint32_t)total * 4u;
+#pragma unroll
+        for (int f = 0; f < NP; ++f) {
+            const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, f) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)plo, f);
+            // buffer descriptor in 4 SGPRs -> `buffer_load_dword v, voffset, s[rsrc], 0 offen`
+            const __amdgpu_buffer_rsrc_t rsrc =
+                __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)plane_bytes, 0x00020000);
+            v[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int f = 0; f < NP; ++f) nf = __builtin_fmaf(v[f], 0.0f, nf);
+    } else {
+#pragma unroll
+        for (int f = 0; f < NP; ++f) {
+            float s = __builtin_inff();
+            if (f < args.n) {
+                const int64_t off = args.contiguous ? g : (y * args.ld[f] + x);
+                s = args.p[f][off];
+                nf = __builtin_fmaf(s, 0.0f, nf);
+            }
+            v[f] = s;
+        }
+    }
+    int n = DIRECT ? NP : args.n;
+    if (__any(nf != nf)) {  // rare: some lane of this wave met a non-finite sample
+        n = 0;
+#pragma unroll
+        for (int f = 0; f < NP; ++f) {
+            const bool fin = __builtin_isfinite(v[f]);
+            v[f] = fin ? v[f] : __builtin_inff();
+            n += fin ? 1 : 0;
+        }
+    }
+    if constexpr (STAGE == 1) {
+        float t = 0.0f;
+#pragma unroll
+        for (int f = 0; f < NP; ++f) t += v[f];
+        if (valid) args.out[g] = t + (float)n;
+        return;
+    }
+
+    SortNet<NP>::sort(v);
+
+    if constexpr (STAGE == 2) {
+        float t = 0.0f;
+#pragma unroll
+        for (int f = 0; f < NP; ++f) t += v[f] * (float)(f + 1);
+        if (valid) args.out[g] = t;
+        return;
+    }
+
+    // ---- iteration 0: median / MAD (combine.rs:37-48) ----
+    const int m = n >> 1;
+    float med = 0.0f, mad = 0.0f;
+    if (__all(m == NP / 2)) {
+        med_mad_at<NP, NP / 2>(v, med, mad);  // the common case: every lane has all NP samples
+    } else {
+        unsigned long long todo = __ballot(1);
+        while (todo) {
+            launder<NP>(v);  // or LICM evaluates all NP/2+1 candidate positions up front and spills
+            const int cur = __builtin_amdgcn_readlane(m, (int)__builtin_ctzll(todo));
+            med_mad_dispatch<NP, NP / 2>(v, m, cur, med, mad);
+            todo &= ~__ballot(m == cur);
+        }
+    }
+
+    if constexpr (STAGE == 3) {
+        if (valid) args.out[g] = med + mad;
+        return;
+    }
+
+    ClipResult r;
+    if constexpr (EXACT)
+        r = clip_exact<NP>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
+    else
+        r = clip_fast<NP, STAGE>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
+
+    uint32_t rej = r.rej;
     if (valid) {
         if constexpr (PARTIAL) {
-            args.out_sum[g] = (len > 0) ? S : 0.0;
-            args.out_cnt[g] = (uint32_t)(len > 0 ? len : 0);
+            args.out_sum[g] = r.sum;
+            args.out_cnt[g] = (uint32_t)r.len;
         } else {
-            args.out[g] = result;
+            args.out[g] = r.value;
         }
     } else {
         rej = 0;
     }
 
-    // wavefront reduction of the rejection count, one atomic per wave
+    // rejection count: wavefront shuffle reduction, then ONE atomic per wave spread over kRejSlots
+    // counters (summed by the host).  All 262 144 waves of a 4096^2 stack adding to a single
+    // address serialise at ~12 ns per atomic = 3 ms, more than the whole kernel; a workgroup-level
+    // LDS reduction would need a barrier that makes the 4 waves of a group wait for the slowest.
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) rej += __shfl_xor(rej, off, 64);
-    if ((threadIdx.x & 63) == 0 && rej != 0) atomicAdd(args.rejected, (unsigned long long)rej);
+    if ((threadIdx.x & 63) == 0 && rej != 0)
+        atomicAdd(&args.rejected[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kRejSlots - 1)], (unsigned long long)rej);
 }
 
 // single frame: sigma_clip_combine returns the value itself, or 0 if it is not finite
@@ -282,17 +596,26 @@ __global__ void finalize_partial_kernel(const double *sum, const uint32_t *cnt, 
     out[g] = c ? (float)(sum[g] / (double)c) : 0.0f;
 }
 
-template <bool PARTIAL>
+template <int NP, bool PARTIAL, bool EXACT>
+void launch_np(ab_ctx *ctx, const StackArgs &args, dim3 grid, dim3 block) {
+    // DIRECT gather: no absent-frame slots, one row stride, byte offsets fit 32 bits
+    if (args.n == NP && args.contiguous && args.rows * args.cols < (int64_t(1) << 30))
+        hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, 99, true>), grid, block, 0, ctx->stream, args);
+    else
+        hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, 99, false>), grid, block, 0, ctx->stream, args);
+}
+
+template <bool PARTIAL, bool EXACT>
 int launch_stack(ab_ctx *ctx, const StackArgs &args, int np) {
     const int64_t total = args.rows * args.cols;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     switch (np) {
-        case 2: hipLaunchKernelGGL((stack_sigma_clip_kernel<2, PARTIAL>), grid, block, 0, ctx->stream, args); break;
-        case 4: hipLaunchKernelGGL((stack_sigma_clip_kernel<4, PARTIAL>), grid, block, 0, ctx->stream, args); break;
-        case 8: hipLaunchKernelGGL((stack_sigma_clip_kernel<8, PARTIAL>), grid, block, 0, ctx->stream, args); break;
-        case 16: hipLaunchKernelGGL((stack_sigma_clip_kernel<16, PARTIAL>), grid, block, 0, ctx->stream, args); break;
-        case 32: hipLaunchKernelGGL((stack_sigma_clip_kernel<32, PARTIAL>), grid, block, 0, ctx->stream, args); break;
-        case 64: hipLaunchKernelGGL((stack_sigma_clip_kernel<64, PARTIAL>), grid, block, 0, ctx->stream, args); break;
+        case 2: launch_np<2, PARTIAL, EXACT>(ctx, args, grid, block); break;
+        case 4: launch_np<4, PARTIAL, EXACT>(ctx, args, grid, block); break;
+        case 8: launch_np<8, PARTIAL, EXACT>(ctx, args, grid, block); break;
+        case 16: launch_np<16, PARTIAL, EXACT>(ctx, args, grid, block); break;
+        case 32: launch_np<32, PARTIAL, EXACT>(ctx, args, grid, block); break;
+        case 64: launch_np<64, PARTIAL, EXACT>(ctx, args, grid, block); break;
         default: return ab_set_error(ctx, AB_ERR_INVALID, "internal: bad padded frame count %d", np);
     }
     AB_HIP(ctx, hipGetLastError());
@@ -300,6 +623,17 @@ int launch_stack(ab_ctx *ctx, const StackArgs &args, int np) {
 }
 
 }  // namespace
+
+static int read_rejected(ab_ctx *ctx, uint64_t *out) {
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, kRejSlots * sizeof(unsigned long long), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, ctx->counters, kRejSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t tot = 0;
+    for (int i = 0; i < kRejSlots; ++i) tot += ((const unsigned long long *)pin)[i];
+    *out = tot;
+    return AB_OK;
+}
 
 // Shared implementation.  dplanes: device pointers + row strides of the n frames.
 int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows,
@@ -314,7 +648,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     const int64_t total = rows * cols;
     const bool partial = out_sum_dev != nullptr;
 
-    AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(unsigned long long), ctx->stream));
+    AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kRejSlots * sizeof(unsigned long long), ctx->stream));
     if (n == 1) {
         const dim3 grid((unsigned)((total + 255) / 256)), block(256);
         hipLaunchKernelGGL(stack_single_kernel, grid, block, 0, ctx->stream, dplanes[0], ld[0], rows, cols,
@@ -342,15 +676,12 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         args.rejected = ctx->counters;
         int np = 2;
         while (np < (int)n) np <<= 1;
-        AB_TRY(partial ? launch_stack<true>(ctx, args, np) : launch_stack<false>(ctx, args, np));
+        if (ctx->stack_exact)
+            AB_TRY(partial ? (launch_stack<true, true>(ctx, args, np)) : (launch_stack<false, true>(ctx, args, np)));
+        else
+            AB_TRY(partial ? (launch_stack<true, false>(ctx, args, np)) : (launch_stack<false, false>(ctx, args, np)));
     }
-    if (out_rejected) {
-        void *pin = nullptr;
-        AB_TRY(ab_pinned(ctx, sizeof(unsigned long long), &pin));
-        AB_HIP(ctx, hipMemcpyAsync(pin, ctx->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        *out_rejected = *(unsigned long long *)pin;
-    }
+    if (out_rejected) AB_TRY(read_rejected(ctx, out_rejected));
     return AB_OK;
 }
 
@@ -418,12 +749,7 @@ int ab_stack_sigma_clip_partial(ab_ctx *ctx, const ab_plane *planes, size_t n, c
 int ab_stack_last_rejected(ab_ctx *ctx, uint64_t *out_rejected) {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, out_rejected, "null output");
-    void *pin = nullptr;
-    AB_TRY(ab_pinned(ctx, sizeof(unsigned long long), &pin));
-    AB_HIP(ctx, hipMemcpyAsync(pin, ctx->counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *out_rejected = *(unsigned long long *)pin;
-    return AB_OK;
+    return read_rejected(ctx, out_rejected);
 }
 
 int ab_stack_finalize_partial(ab_ctx *ctx, const double *sum_dev, const uint32_t *cnt_dev, int64_t n, float *out_dev) {

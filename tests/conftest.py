@@ -27,3 +27,20 @@ def ctx():
     c = ab.Context(0)          # raises loudly without the .so or without an MI355X
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_exact():
+    """Same library, AB_STACK_EXACT=1: the direct re-summing clipping engine (bit-exact cross-check)."""
+    import astroburst_amd as ab
+    old = os.environ.get("AB_STACK_EXACT")
+    os.environ["AB_STACK_EXACT"] = "1"
+    try:
+        c = ab.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("AB_STACK_EXACT", None)
+        else:
+            os.environ["AB_STACK_EXACT"] = old
+    yield c
+    c.close()

@@ -25,6 +25,20 @@ def make_frames(rng, n, rows, cols, nan_rate=0.01, cr_rate=0.01, zero_border=Tru
     return frames
 
 
+def assert_stack_parity(got, ref, got_rej, ref_rej, bit_exact):
+    """exact engine: bit-for-bit.  fast engine: the north-star contract (1e-5 relative) plus a cap on
+    how many pixels may differ at all (incremental vs two-pass variance: expected 0)."""
+    assert got_rej == ref_rej
+    if bit_exact:
+        assert_bit_equal(got, ref)
+        return
+    got = np.asarray(got)
+    ref = np.asarray(ref)
+    np.testing.assert_allclose(got, ref, rtol=1e-5, atol=0)
+    differ = ~((got == ref) | (np.isnan(got) & np.isnan(ref)))
+    assert differ.mean() <= 1e-4, f"{differ.sum()} of {got.size} pixels differ"
+
+
 def assert_bit_equal(a, b):
     a = np.asarray(a)
     b = np.asarray(b)
@@ -36,14 +50,19 @@ def assert_bit_equal(a, b):
                              f"{[(a[tuple(i)], b[tuple(i)]) for i in idx]}")
 
 
+@pytest.fixture(params=["fast", "exact"])
+def engine(request, ctx, ctx_exact):
+    return (ctx, False) if request.param == "fast" else (ctx_exact, True)
+
+
 @pytest.mark.parametrize("n", [2, 3, 4, 5, 7, 8, 9, 10, 16, 17, 31, 32, 33, 48, 63, 64])
-def test_stack_matches_oracle(ctx, oracle, n):
+def test_stack_matches_oracle(engine, oracle, n):
+    ctx, exact = engine
     rng = np.random.default_rng(100 + n)
     frames = make_frames(rng, n, 37, 131)
     got, rej = ctx.stack_sigma_clip(frames, 3.0, 3.0, 5)
     ref, ref_rej = oracle.stack_images(frames, 3.0, 3.0, 5, order=oracle.ORDER_ASCENDING)
-    assert_bit_equal(got, ref)
-    assert rej == ref_rej
+    assert_stack_parity(got, ref, rej, ref_rej, exact)
     # reference-like summation order (post-select permutation): within the north-star tolerance
     ref2, ref2_rej = oracle.stack_images(frames, 3.0, 3.0, 5, order=oracle.ORDER_SELECT)
     np.testing.assert_allclose(got, ref2, rtol=1e-5, atol=0)
@@ -51,27 +70,28 @@ def test_stack_matches_oracle(ctx, oracle, n):
 
 
 @pytest.mark.parametrize("n", [4, 16, 64])
-def test_stack_all_finite_fast_path(ctx, oracle, n):
+def test_stack_all_finite_fast_path(engine, oracle, n):
+    ctx, exact = engine
     rng = np.random.default_rng(7 + n)
     frames = make_frames(rng, n, 64, 256, nan_rate=0.0, zero_border=False)
     got, rej = ctx.stack_sigma_clip(frames)
     ref, ref_rej = oracle.stack_images(frames, order=oracle.ORDER_ASCENDING)
-    assert_bit_equal(got, ref)
-    assert rej == ref_rej and rej > 0
+    assert_stack_parity(got, ref, rej, ref_rej, exact)
+    assert rej > 0
 
 
 @pytest.mark.parametrize("sl,sh,it", [(3.0, 3.0, 0), (3.0, 3.0, 1), (2.0, 2.0, 5), (1.0, 4.0, 3), (0.5, 0.5, 10),
                                       (0.0, 0.0, 5), (-1.0, 3.0, 5), (3.0, float("inf"), 5), (float("nan"), 3.0, 2)])
-def test_stack_parameter_sweep(ctx, oracle, sl, sh, it):
+def test_stack_parameter_sweep(engine, oracle, sl, sh, it):
+    ctx, exact = engine
     rng = np.random.default_rng(5)
     frames = make_frames(rng, 12, 24, 70)
     got, rej = ctx.stack_sigma_clip(frames, sl, sh, it)
     ref, ref_rej = oracle.stack_images(frames, sl, sh, it, order=oracle.ORDER_ASCENDING)
-    assert_bit_equal(got, ref)
-    assert rej == ref_rej
+    assert_stack_parity(got, ref, rej, ref_rej, exact)
 
 
-def test_stack_edge_pixels(ctx, oracle):
+def test_stack_edge_pixels(engine, oracle):
     """hand-built pixels: all non-finite, one finite, two finite, ties, constant, negatives, extremes"""
     n = 8
     cols = 12
@@ -89,11 +109,11 @@ def test_stack_edge_pixels(ctx, oracle):
     px[:, 10] = [100, 101, 99, 100, 5000, 6000, 7000, 100.5]    # many outliers: several iterations
     px[:, 11] = np.arange(8)
     frames = [px[k].reshape(1, cols).copy() for k in range(n)]
+    ctx, exact = engine
     for sl, sh, it in [(3.0, 3.0, 5), (1.0, 1.0, 5), (3.0, 3.0, 1)]:
         got, rej = ctx.stack_sigma_clip(frames, sl, sh, it)
         ref, ref_rej = oracle.stack_images(frames, sl, sh, it, order=oracle.ORDER_ASCENDING)
-        assert_bit_equal(got, ref)
-        assert rej == ref_rej
+        assert_stack_parity(got, ref, rej, ref_rej, exact)
     assert got[0, 0] == 0.0 and ctx.stack_sigma_clip(frames)[0][0, 1] == np.float32(42.5)
 
 
@@ -172,8 +192,7 @@ def test_device_planes_and_properties(ctx, oracle):
     ctx.use_torch_stream()
     out, rej = ctx.stack_sigma_clip(dev)
     ref, ref_rej = oracle.stack_images([f.numpy() for f in frames], order=oracle.ORDER_ASCENDING)
-    assert_bit_equal(out.cpu().numpy(), ref)
-    assert rej == ref_rej
+    assert_stack_parity(out.cpu().numpy(), ref, rej, ref_rej, False)
     # frame-order invariance: the kernel sums survivors in value order, so any permutation is bit-identical
     perm = torch.randperm(24, generator=torch.Generator().manual_seed(1)).tolist()
     out_p, rej_p = ctx.stack_sigma_clip([dev[i] for i in perm])

@@ -1,0 +1,145 @@
+// VALU issue-rate micro-bench for gfx950 (developer tool): cycles per wave64 instruction per SIMD
+// for the op classes the stacking / warp kernels are made of.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/valu_rate.hip -o build/valu_rate
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define REP 64
+#define ITER 2048
+
+template <int OP>
+__global__ __launch_bounds__(256) void k(float *out, float seed) {
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7;
+    for (int it = 0; it < ITER; ++it) {
+#pragma unroll
+        for (int r = 0; r < REP / 8; ++r) {
+            if (OP == 0) {  // v_min_f32 / v_max_f32 (8 independent chains)
+                asm volatile("v_min_f32 %0, %0, %1\n v_max_f32 %1, %1, %2\n v_min_f32 %2, %2, %3\n v_max_f32 %3, %3, %4\n"
+                             "v_min_f32 %4, %4, %5\n v_max_f32 %5, %5, %6\n v_min_f32 %6, %6, %7\n v_max_f32 %7, %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 1) {  // v_fma_f32
+                asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %1, %1, %2, %3\n v_fma_f32 %2, %2, %3, %4\n v_fma_f32 %3, %3, %4, %5\n"
+                             "v_fma_f32 %4, %4, %5, %6\n v_fma_f32 %5, %5, %6, %7\n v_fma_f32 %6, %6, %7, %0\n v_fma_f32 %7, %7, %0, %1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 2) {  // v_add_f64
+                asm volatile("v_add_f64 %0, %0, %1\n v_add_f64 %1, %1, %2\n v_add_f64 %2, %2, %3\n v_add_f64 %3, %3, %4\n"
+                             "v_add_f64 %4, %4, %5\n v_add_f64 %5, %5, %6\n v_add_f64 %6, %6, %7\n v_add_f64 %7, %7, %0\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+            } else if (OP == 3) {  // v_mul_f64
+                asm volatile("v_mul_f64 %0, %0, %1\n v_mul_f64 %1, %1, %2\n v_mul_f64 %2, %2, %3\n v_mul_f64 %3, %3, %4\n"
+                             "v_mul_f64 %4, %4, %5\n v_mul_f64 %5, %5, %6\n v_mul_f64 %6, %6, %7\n v_mul_f64 %7, %7, %0\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+            } else if (OP == 4) {  // v_fma_f64
+                asm volatile("v_fma_f64 %0, %0, %1, %2\n v_fma_f64 %1, %1, %2, %3\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %3, %3, %4, %5\n"
+                             "v_fma_f64 %4, %4, %5, %6\n v_fma_f64 %5, %5, %6, %7\n v_fma_f64 %6, %6, %7, %0\n v_fma_f64 %7, %7, %0, %1\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+            } else if (OP == 5) {  // v_cvt_f64_f32
+                asm volatile("v_cvt_f64_f32 %0, %8\n v_cvt_f64_f32 %1, %9\n v_cvt_f64_f32 %2, %10\n v_cvt_f64_f32 %3, %11\n"
+                             "v_cvt_f64_f32 %4, %12\n v_cvt_f64_f32 %5, %13\n v_cvt_f64_f32 %6, %14\n v_cvt_f64_f32 %7, %15\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)
+                             : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7));
+            } else if (OP == 6) {  // v_cndmask_b32 with vcc
+                asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                             "v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            } else if (OP == 7) {  // v_pk_add_f32
+                asm volatile("v_pk_add_f32 %0, %0, %1\n v_pk_add_f32 %1, %1, %2\n v_pk_add_f32 %2, %2, %3\n v_pk_add_f32 %3, %3, %4\n"
+                             "v_pk_add_f32 %4, %4, %5\n v_pk_add_f32 %5, %5, %6\n v_pk_add_f32 %6, %6, %7\n v_pk_add_f32 %7, %7, %0\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+            } else if (OP == 8) {  // v_min3_f32 / v_med3_f32 / v_max3_f32
+                asm volatile("v_min3_f32 %0, %0, %1, %2\n v_med3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %4\n v_min3_f32 %3, %3, %4, %5\n"
+                             "v_med3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n v_min3_f32 %6, %6, %7, %0\n v_med3_f32 %7, %7, %0, %1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 9) {  // v_sub_f32
+                asm volatile("v_sub_f32 %0, %0, %1\n v_sub_f32 %1, %1, %2\n v_sub_f32 %2, %2, %3\n v_sub_f32 %3, %3, %4\n"
+                             "v_sub_f32 %4, %4, %5\n v_sub_f32 %5, %5, %6\n v_sub_f32 %6, %6, %7\n v_sub_f32 %7, %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 10) {  // v_pk_mul_f32
+                asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %2\n v_pk_mul_f32 %2, %2, %3\n v_pk_mul_f32 %3, %3, %4\n"
+                             "v_pk_mul_f32 %4, %4, %5\n v_pk_mul_f32 %5, %5, %6\n v_pk_mul_f32 %6, %6, %7\n v_pk_mul_f32 %7, %7, %0\n"
+                             : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7));
+            } else if (OP >= 20 && OP < 40) {
+#define CHAIN2(OPN) asm volatile(OPN " %0, %0, %1\n " OPN " %1, %1, %2\n " OPN " %2, %2, %3\n " OPN " %3, %3, %4\n " \
+                                 OPN " %4, %4, %5\n " OPN " %5, %5, %6\n " OPN " %6, %6, %7\n " OPN " %7, %7, %0\n"     \
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+                if (OP == 20) CHAIN2("v_min_i32");
+                if (OP == 21) CHAIN2("v_max_u32");
+                if (OP == 22) CHAIN2("v_add_u32");
+                if (OP == 23) CHAIN2("v_pk_min_i16");
+                if (OP == 24) CHAIN2("v_pk_max_u16");
+                if (OP == 25) CHAIN2("v_and_b32");
+                if (OP == 26) CHAIN2("v_min_f16");
+                if (OP == 27) CHAIN2("v_pk_min_f16");
+                if (OP == 28) CHAIN2("v_add_f32");
+                if (OP == 29) CHAIN2("v_mul_f32");
+                if (OP == 30) CHAIN2("v_xor_b32");
+                if (OP == 31) CHAIN2("v_lshlrev_b32");
+                if (OP == 32) CHAIN2("v_sub_u32");
+                if (OP == 33) CHAIN2("v_max_i16");
+            } else if (OP == 40) {  // v_cmp_lt_f32 (vcc) only
+                asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %4\n"
+                             "v_cmp_lt_f32 vcc, %4, %5\n v_cmp_lt_f32 vcc, %5, %6\n v_cmp_lt_f32 vcc, %6, %7\n v_cmp_lt_f32 vcc, %7, %0\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            } else if (OP == 41) {  // v_cndmask_b32 reading a constant vcc
+                asm volatile("v_cndmask_b32 %0, %1, %2, vcc\n v_cndmask_b32 %1, %2, %3, vcc\n v_cndmask_b32 %2, %3, %4, vcc\n v_cndmask_b32 %3, %4, %5, vcc\n"
+                             "v_cndmask_b32 %4, %5, %6, vcc\n v_cndmask_b32 %5, %6, %7, vcc\n v_cndmask_b32 %6, %7, %0, vcc\n v_cndmask_b32 %7, %0, %1, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 42) {  // v_med3_i32 / v_min3_i32 / v_max3_i32
+                asm volatile("v_min3_i32 %0, %0, %1, %2\n v_med3_i32 %1, %1, %2, %3\n v_max3_i32 %2, %2, %3, %4\n v_min3_i32 %3, %3, %4, %5\n"
+                             "v_med3_i32 %4, %4, %5, %6\n v_max3_i32 %5, %5, %6, %7\n v_min3_i32 %6, %6, %7, %0\n v_med3_i32 %7, %7, %0, %1\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 11) {  // v_cmp_lt_f32 -> vcc ; v_cndmask (dependent pair, as the compiler emits it)
+                asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %2, %2, %3, vcc\n v_cmp_lt_f32 vcc, %4, %5\n s_nop 1\n v_cndmask_b32 %6, %6, %7, vcc\n"
+                             "v_cmp_lt_f32 vcc, %1, %2\n s_nop 1\n v_cndmask_b32 %3, %3, %4, vcc\n v_cmp_lt_f32 vcc, %5, %6\n s_nop 1\n v_cndmask_b32 %7, %7, %0, vcc\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc");
+            }
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+}
+
+template <int OP>
+void run(const char *name, float *out, int blocks_per_cu, int cus, double clk_ghz) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int grid = cus * blocks_per_cu;
+    k<OP><<<grid, 256>>>(out, 1.0f);
+    hipEventRecord(e0);
+    k<OP><<<grid, 256>>>(out, 1.0f);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    // per SIMD: blocks_per_cu waves (one wave of each block per SIMD), each REP*ITER instructions
+    const double instr_per_simd = (double)blocks_per_cu * REP * ITER * (OP == 11 ? 0.75 : 1.0);
+    const double cycles = ms * 1e-3 * clk_ghz * 1e9;
+    printf("%-34s %2d waves/SIMD  %8.3f ms  %.2f cycles/instr (at %.2f GHz)\n", name, blocks_per_cu, ms, cycles / instr_per_simd, clk_ghz);
+}
+
+int main() {
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    const int cus = p.multiProcessorCount;
+    const double clk = p.clockRate * 1e-6;
+    float *out; hipMalloc(&out, (size_t)cus * 8 * 256 * 4);
+    printf("%s: %d CUs, clock %.2f GHz\n", p.gcnArchName, cus, clk);
+    for (int w : {1, 2, 4}) {
+        if (w == 1) { run<0>("v_min/max_f32", out, 1, cus, clk); run<1>("v_fma_f32", out, 1, cus, clk); run<2>("v_add_f64", out, 1, cus, clk); }
+        if (w == 2) { run<0>("v_min/max_f32", out, 2, cus, clk); run<1>("v_fma_f32", out, 2, cus, clk); run<2>("v_add_f64", out, 2, cus, clk); }
+        if (w == 4) {
+            run<0>("v_min/max_f32", out, 4, cus, clk); run<1>("v_fma_f32", out, 4, cus, clk); run<9>("v_sub_f32", out, 4, cus, clk);
+            run<8>("v_min3/med3/max3_f32", out, 4, cus, clk); run<6>("v_cndmask_b32 (vcc)", out, 4, cus, clk);
+            run<11>("v_cmp+s_nop1+v_cndmask (per instr)", out, 4, cus, clk);
+            run<7>("v_pk_add_f32", out, 4, cus, clk); run<10>("v_pk_mul_f32", out, 4, cus, clk);
+            run<2>("v_add_f64", out, 4, cus, clk); run<3>("v_mul_f64", out, 4, cus, clk); run<4>("v_fma_f64", out, 4, cus, clk);
+            run<5>("v_cvt_f64_f32", out, 4, cus, clk);
+            run<20>("v_min_i32", out, 4, cus, clk); run<21>("v_max_u32", out, 4, cus, clk); run<22>("v_add_u32", out, 4, cus, clk);
+            run<32>("v_sub_u32", out, 4, cus, clk); run<25>("v_and_b32", out, 4, cus, clk); run<30>("v_xor_b32", out, 4, cus, clk);
+            run<31>("v_lshlrev_b32", out, 4, cus, clk); run<23>("v_pk_min_i16", out, 4, cus, clk); run<24>("v_pk_max_u16", out, 4, cus, clk);
+            run<33>("v_max_i16", out, 4, cus, clk); run<26>("v_min_f16", out, 4, cus, clk); run<27>("v_pk_min_f16", out, 4, cus, clk);
+            run<28>("v_add_f32", out, 4, cus, clk); run<29>("v_mul_f32", out, 4, cus, clk);
+            run<40>("v_cmp_lt_f32 -> vcc", out, 4, cus, clk); run<41>("v_cndmask_b32 (const vcc)", out, 4, cus, clk);
+            run<42>("v_min3/med3/max3_i32", out, 4, cus, clk);
+        }
+    }
+    return 0;
+}
