@@ -14,61 +14,78 @@
 
 namespace {
 
-__device__ __forceinline__ double catmull_rom(double t) {  // sampling.rs:4-14
-    const double abs_t = fabs(t);
-    if (abs_t <= 1.0) return abs_t * abs_t * (1.5 * abs_t - 2.5) + 1.0;
-    if (abs_t <= 2.0) return abs_t * (abs_t * (2.5 - 0.5 * abs_t) - 4.0) + 2.0;
-    return 0.0;
+// catmull_rom (sampling.rs:4-14) for the four taps of one axis, f in [0, 1]:
+//   w0 = cr(f + 1), w1 = cr(f), w2 = cr(f - 1), w3 = cr(f - 2).
+// |f + 1| and |f - 2| lie in [1, 2], |f| and |f - 1| in [0, 1], so the reference's two branches
+// are known statically; where the two ranges touch (|t| = 1) both polynomials give exactly 0.0,
+// so taking the other branch there is still bit-identical.  Operation order as in the reference.
+__device__ __forceinline__ double cr_inner(double t) { return t * t * (1.5 * t - 2.5) + 1.0; }            // |t| <= 1
+__device__ __forceinline__ double cr_outer(double t) { return t * (t * (2.5 - 0.5 * t) - 4.0) + 2.0; }    // 1 <= |t| <= 2
+
+__device__ __forceinline__ void catmull_weights(double f, double &w0, double &w1, double &w2, double &w3) {
+    w0 = cr_outer(fabs(f + 1.0));
+    w1 = cr_inner(fabs(f));
+    w2 = cr_inner(fabs(f - 1.0));
+    w3 = cr_outer(fabs(f - 2.0));
 }
 
-__device__ __forceinline__ int64_t clamp_index(int64_t idx, int64_t len) {  // boundary.rs:9-20
+__device__ __forceinline__ int clamp_i32(int idx, int len) {  // boundary.rs:9-20
     return idx < 0 ? 0 : (idx >= len ? len - 1 : idx);
 }
 
-// sampling.rs:51-80
-__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int64_t rows, int64_t cols, double y,
-                                                double x) {
-    const double xf = floor(x), yf = floor(y);
-    const int64_t ix = (int64_t)xf, iy = (int64_t)yf;
-    const double fx = x - xf, fy = y - yf;
-    const double wx0 = catmull_rom(fx + 1.0), wx1 = catmull_rom(fx), wx2 = catmull_rom(fx - 1.0),
-                 wx3 = catmull_rom(fx - 2.0);
-    const int64_t c0 = clamp_index(ix - 1, cols), c1 = clamp_index(ix, cols), c2 = clamp_index(ix + 1, cols),
-                  c3 = clamp_index(ix + 2, cols);
+// sampling.rs:51-80 with 32-bit indexing (callers guarantee rows*cols < 2^31 and |x|,|y| sane).
+// `row_val += s*w` starts from 0.0, so the first add is exact and is skipped.
+__device__ __forceinline__ float bicubic_taps(const float *__restrict__ src, int rows, int cols, int ix, int iy,
+                                              double wx0, double wx1, double wx2, double wx3, double wy0, double wy1,
+                                              double wy2, double wy3) {
+    const int c0 = clamp_i32(ix - 1, cols), c1 = clamp_i32(ix, cols), c2 = clamp_i32(ix + 1, cols),
+              c3 = clamp_i32(ix + 2, cols);
+    const int r0 = clamp_i32(iy - 1, rows) * cols, r1 = clamp_i32(iy, rows) * cols, r2 = clamp_i32(iy + 1, rows) * cols,
+              r3 = clamp_i32(iy + 2, rows) * cols;
+    const double wy[4] = {wy0, wy1, wy2, wy3};
+    const int rr[4] = {r0, r1, r2, r3};
     double val = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float *row = src + clamp_index(iy + j - 1, rows) * cols;
-        double row_val = 0.0;
-        row_val += (double)row[c0] * wx0;
+        const float *row = src + rr[j];
+        double row_val = (double)row[c0] * wx0;
         row_val += (double)row[c1] * wx1;
         row_val += (double)row[c2] * wx2;
         row_val += (double)row[c3] * wx3;
-        val += row_val * catmull_rom(fy - (double)(j - 1));
+        const double t = row_val * wy[j];
+        val = (j == 0) ? t : val + t;
     }
     return (float)val;
 }
 
+__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int rows, int cols, double y, double x) {
+    const double xf = floor(x), yf = floor(y);
+    double wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3;
+    catmull_weights(x - xf, wx0, wx1, wx2, wx3);
+    catmull_weights(y - yf, wy0, wy1, wy2, wy3);
+    return bicubic_taps(src, rows, cols, (int)xf, (int)yf, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
+}
+
 // align.rs:46-55
-__global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ src, int64_t rows, int64_t cols, double dy,
-                                                    double dx, float *__restrict__ out) {
-    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t y = blockIdx.y;
+__global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ src, int rows, int cols, double dy, double dx,
+                                                    float *__restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
     if (x >= cols) return;
     const double sy = (double)y + dy;
     const double sx = (double)x + dx;
     float r = 0.0f;
     if (!(sy < -0.5 || sy > (double)rows - 0.5 || sx < -0.5 || sx > (double)cols - 0.5))
         r = bicubic_sample(src, rows, cols, sy, sx);
-    out[y * cols + x] = r;
+    out[(size_t)y * cols + x] = r;
 }
 
 // affine.rs:674-687; map() is affine.rs:74-80
-__global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src, int64_t src_rows, int64_t src_cols,
-                                                   double a, double b, double tx, double c, double d, double ty,
-                                                   int64_t out_rows, int64_t out_cols, float *__restrict__ out) {
-    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t y = blockIdx.y;
+__global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src, int src_rows, int src_cols, double a,
+                                                   double b, double tx, double c, double d, double ty, int out_rows,
+                                                   int out_cols, float *__restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
     if (x >= out_cols) return;
     const double xf = (double)x, yf = (double)y;
     const double sx = a * xf + b * yf + tx;
@@ -76,7 +93,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
     float r = 0.0f;
     if (sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1))
         r = bicubic_sample(src, src_rows, src_cols, sy, sx);
-    out[y * out_cols + x] = r;
+    out[(size_t)y * out_cols + x] = r;
 }
 
 }  // namespace
@@ -89,9 +106,10 @@ int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, d
         return AB_OK;
     }
     AB_CHECK(ctx, src != out, "shift_image_subpixel cannot run in place");
-    AB_CHECK(ctx, rows <= 65535 * 1, "image taller than 65535 rows needs a tiled launch (not in this build)");
+    AB_CHECK(ctx, rows <= 65535 && rows * cols < (int64_t(1) << 31),
+             "image of %lld x %lld needs a tiled launch (not in this build)", (long long)rows, (long long)cols);
     const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
-    hipLaunchKernelGGL(shift_kernel, grid, block, 0, ctx->stream, src, rows, cols, dy, dx, out);
+    hipLaunchKernelGGL(shift_kernel, grid, block, 0, ctx->stream, src, (int)rows, (int)cols, dy, dx, out);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -100,10 +118,11 @@ int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_
                    int64_t out_cols, float *out) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     AB_CHECK(ctx, src != out, "warp_image cannot run in place");
-    AB_CHECK(ctx, out_rows <= 65535, "image taller than 65535 rows needs a tiled launch (not in this build)");
+    AB_CHECK(ctx, out_rows <= 65535 && out_rows * out_cols < (int64_t(1) << 31) && src_rows * src_cols < (int64_t(1) << 31),
+             "image of %lld x %lld needs a tiled launch (not in this build)", (long long)out_rows, (long long)out_cols);
     const dim3 grid((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block(256);
-    hipLaunchKernelGGL(warp_kernel, grid, block, 0, ctx->stream, src, src_rows, src_cols, t[0], t[1], t[2], t[3], t[4],
-                       t[5], out_rows, out_cols, out);
+    hipLaunchKernelGGL(warp_kernel, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
+                       t[4], t[5], (int)out_rows, (int)out_cols, out);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }

@@ -447,7 +447,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
 // STAGE < 99 cuts the kernel short for the ablation bench (tools/stack_ablate.hip):
 //   1 = loads only, 2 = + pads + sort, 3 = + median/MAD, 99 = everything (the product).
 template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false>
-__global__ __launch_bounds__(256, EXACT ? 1 : 4) void stack_sigma_clip_kernel(const StackArgs args) {
+__global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(const StackArgs args) {
     const int64_t total = args.rows * args.cols;
     int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = g < total;

@@ -100,27 +100,30 @@ def main():
         pcnt = torch.empty((R, Cc), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    stack_ms = []
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps + args.warmup)]
+    stack_ms, warp_ms, tail_ms = [], [], []
+    nsteps = args.steps + args.warmup
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nsteps)]
 
     def step(i):
+        e = ev[i]
+        e[0].record()
         if register:
             for k in range(1, N):
                 ctx.warp_image(raw[k], transforms[k], R, Cc, out=warped[k])
-        e0, e1 = ev[i]
-        e0.record()
+        e[1].record()
         if world == 1:
             ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
-            e1.record()
+            e[2].record()
         else:
-            s, c, _ = ctx.stack_partial_into(warped, psum, pcnt)
-            e1.record()
+            ctx.stack_partial_into(warped, psum, pcnt)
+            e[2].record()
             dist.all_reduce(psum)
             dist.all_reduce(pcnt)
             ctx.stack_finalize_partial_into(psum, pcnt, stacked)
         st = ctx.compute_image_stats(stacked)
         p = ctx.auto_stf(st)
         ctx.apply_stf(stacked, p, st, out=u8)
+        e[3].record()
         return st
 
     for i in range(args.warmup):
@@ -142,20 +145,45 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     for i in range(args.warmup, args.warmup + args.steps):
-        stack_ms.append(ev[i][0].elapsed_time(ev[i][1]))
+        warp_ms.append(ev[i][0].elapsed_time(ev[i][1]))
+        stack_ms.append(ev[i][1].elapsed_time(ev[i][2]))
+        tail_ms.append(ev[i][2].elapsed_time(ev[i][3]))
     rejected = ctx.last_rejected()
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * N * P / 1e6 / (elapsed / args.steps)  # input MPix/s, whole job
 
-    # ---- roofline of the dominant kernel (stack): algorithmic bytes = 4*N*P read + 4*P (or 12*P partial) written
+    # ---- roofline of the north-star kernel (stack): algorithmic bytes = 4*N*P read + 4*P (12*P partial) written,
+    # divided by the kernel's average duration between HIP events on the launch stream
     stack_avg_ms = sum(stack_ms) / len(stack_ms)
     out_bytes = 4 * P if world == 1 else 12 * P
     algo_bytes = 4 * N * P + out_bytes
     achieved = algo_bytes / (stack_avg_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes committed with the profile of this same command
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
+    # calibration in profiles/: a loads-only kernel with this access pattern reads exactly 1/2)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "stack_pmc.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("frames") == N and pmc.get("pixels") == P:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "kernel": "stack_sigma_clip_kernel<64>", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes": algo_bytes, "avg_kernel_ms": round(stack_avg_ms, 4), "traffic": None}
+                "algorithmic_bytes": algo_bytes, "avg_kernel_ms": round(stack_avg_ms, 4), "traffic": traffic}
+    warp_avg_ms = (sum(warp_ms) / len(warp_ms)) if register else 0.0
+    stage_ms = {"register_63_warps": round(warp_avg_ms, 4), "stack": round(stack_avg_ms, 4),
+                "stats_stf" + ("_allreduce" if world > 1 else ""): round(sum(tail_ms) / len(tail_ms), 4)}
+    # the warp is f64-VALU bound (the reference's f64 bicubic, ~111 f64 ops per pixel), not HBM bound
+    warp_roofline = None
+    if register:
+        per = warp_avg_ms / (N - 1)
+        warp_roofline = {"bound": "valu_f64", "kernel": "warp_kernel", "avg_kernel_ms": round(per, 4),
+                         "hbm_GBs": round(8 * P / (per * 1e-3) / 1e9, 1),
+                         "f64_ops_per_pixel": 111, "achieved_Gops": round(111 * P / (per * 1e-3) / 1e9, 1),
+                         "peak_Gops": 39300.0, "frac": round(111 * P / (per * 1e-3) / 1e9 / 39300.0, 4)}
 
     # measured streaming ceiling of this GPU (float4 copy), for context
     a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)
@@ -211,8 +239,9 @@ def main():
                        "frames_per_gpu": N, "rows": R, "cols": Cc, "device": name, "cus": cus,
                        "output_mpix_per_s": round(world * P / 1e6 / (elapsed / args.steps), 1),
                        "rejected_pixels": rejected, "median": st.median,
-                       "measured_copy_GBs": round(copy_gbs, 1)},
+                       "measured_copy_GBs": round(copy_gbs, 1), "stage_ms": stage_ms},
             "roofline": roofline,
+            "roofline_warp": warp_roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/{trace,fetch,write}_results.db into the committed summaries:
+  profiles/<tag>_kernel_stats.txt   per-kernel calls / avg / min / max (rocprofv3 --kernel-trace --stats)
+  profiles/<tag>_pmc.txt            per-kernel FETCH_SIZE / WRITE_SIZE (separate --pmc passes)
+  profiles/stack_pmc.json           HBM bytes per launch of the stacking kernel (bench.py's roofline.traffic)
+FETCH_SIZE on gfx950 counts 128-byte reads as 64 (MI355X_MICROARCH.md, HBM section); calibrated on
+this access pattern with the loads-only stage of tools/stack_ablate (4 GiB read -> counter 2 GiB),
+so the read side is doubled.  WRITE_SIZE is exact for dword stores (fill kernel: 64 MiB -> 65536 KiB)."""
+import contextlib
+import io
+import json
+import os
+import sqlite3
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import rocpd_pmc  # noqa: E402
+import rocpd_summary  # noqa: E402
+
+
+def capture(fn, path):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        fn(path)
+    return buf.getvalue()
+
+
+def counter_avg(db, like):
+    con = sqlite3.connect(db)
+    rows = con.execute("select value from counters_collection where kernel_name like ? order by start", (like,)).fetchall()
+    vals = [r[0] for r in rows]
+    return vals
+
+
+def main(tag, outdir=None, frames=64, pixels=4096 * 4096):
+    d = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    pdir = outdir or os.path.join(ROOT, "profiles")
+    os.makedirs(pdir, exist_ok=True)
+    with open(os.path.join(pdir, f"{tag}_kernel_stats.txt"), "w") as f:
+        f.write(capture(rocpd_summary.main, os.path.join(d, "trace_results.db")))
+    txt = capture(rocpd_pmc.main, os.path.join(d, "fetch_results.db")) + capture(rocpd_pmc.main, os.path.join(d, "write_results.db"))
+    with open(os.path.join(pdir, f"{tag}_pmc.txt"), "w") as f:
+        f.write(txt)
+    fetch = counter_avg(os.path.join(d, "fetch_results.db"), "%stack_sigma_clip_kernel<64%")
+    write = counter_avg(os.path.join(d, "write_results.db"), "%stack_sigma_clip_kernel<64%")
+    fk = sum(fetch) / len(fetch)
+    wk = sum(write) / len(write)
+    out = {"source": f"profiles/{tag}_pmc.txt", "frames": frames, "pixels": pixels,
+           "FETCH_SIZE_KiB_avg": fk, "WRITE_SIZE_KiB_avg": wk, "fetch_correction": 2.0,
+           "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
+           "algorithmic_bytes": 4 * frames * pixels + 4 * pixels}
+    out["traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / out["algorithmic_bytes"], 4)
+    with open(os.path.join(pdir, "stack_pmc.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01", sys.argv[2] if len(sys.argv) > 2 else None)
