@@ -65,6 +65,7 @@ def main():
     import torch.distributed as dist
     import astroburst_amd as ab
     from astroburst_amd import synth
+    from astroburst_amd.distributed import sharded_stack
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,11 +116,12 @@ def main():
             ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
             e[2].record()
         else:
-            ctx.stack_partial_into(warped, psum, pcnt)
-            e[2].record()
-            dist.all_reduce(psum)
-            dist.all_reduce(pcnt)
-            ctx.stack_finalize_partial_into(psum, pcnt, stacked)
+            def partial_fn(fr):
+                r = ctx.stack_partial_into(fr, psum, pcnt)
+                e[2].record()
+                return r
+
+            sharded_stack(warped, partial_fn, lambda s_, c_: ctx.stack_finalize_partial_into(s_, c_, stacked))
         st = ctx.compute_image_stats(stacked)
         p = ctx.auto_stf(st)
         ctx.apply_stf(stacked, p, st, out=u8)
