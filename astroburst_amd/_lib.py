@@ -49,6 +49,19 @@ class AutoStfConfigC(C.Structure):  # types/image.rs:52-65
     _fields_ = [("target_bg", C.c_double), ("shadow_k", C.c_double)]
 
 
+class ScnrConfigC(C.Structure):  # types/image.rs:82-100
+    _fields_ = [("method", C.c_int32), ("amount", C.c_float), ("preserve_luminance", C.c_int32)]
+
+
+class BlendWeightC(C.Structure):  # channel_blend.rs:5-11
+    _fields_ = [("channel_idx", C.c_uint64), ("r_weight", C.c_double), ("g_weight", C.c_double),
+                ("b_weight", C.c_double)]
+
+
+class LevelsParamsC(C.Structure):  # curves.rs:4-9
+    _fields_ = [("black", C.c_double), ("gamma", C.c_double), ("white", C.c_double)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into astroburst_amd/libastroburst_hip.so."""
     cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
@@ -114,6 +127,16 @@ def lib() -> C.CDLL:
     L.ab_apply_stf_u8.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32]
     L.ab_apply_stf_f32.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), pp]
     L.ab_bench_copy.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ab_apply_scnr_inplace.argtypes = [vp, pp, pp, pp, C.POINTER(ScnrConfigC)]
+    L.ab_blend_channels.argtypes = [vp, pp, C.c_size_t, C.POINTER(BlendWeightC), C.c_size_t, pp, pp, pp]
+    L.ab_spline_lut_from_points.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_float)]
+    L.ab_apply_curve.argtypes = [vp, pp, C.POINTER(C.c_float), pp]
+    L.ab_apply_levels.argtypes = [vp, pp, C.POINTER(LevelsParamsC), pp]
+    L.ab_arcsinh_stretch_with_stats.argtypes = [vp, pp, C.c_float, C.c_float, C.c_float, C.c_float, pp]
+    L.ab_luminance.argtypes = [vp, pp, pp, pp, pp]
+    L.ab_scale.argtypes = [vp, pp, C.c_float, pp]
+    L.ab_calibrate_image.argtypes = [vp, pp, pp, pp, pp, C.c_float, pp]
+    L.ab_median_combine.argtypes = [vp, pp, C.c_size_t, pp]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift
         if fn.restype is C.c_int and name not in ("ab_last_error", "ab_version", "ab_ctx_get_stream"):

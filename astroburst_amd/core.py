@@ -301,6 +301,107 @@ class Context:
         self._check(self._L.ab_apply_stf_f32(self._h, C.byref(pi), C.byref(p), C.byref(s), C.byref(po)))
         return out
 
+    # ---- colour / tone / calibration maps -----------------------------------------------------------
+    def _out_plane(self, out, keep, rows, cols):
+        return self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), rows, cols, 0)
+
+    def _unary(self, fn, image, out, *mid):
+        keep = []
+        pi = self._plane(image, keep)
+        if out is None:
+            out = self._new_like(image, pi.rows, pi.cols)
+        po = self._out_plane(out, keep, pi.rows, pi.cols)
+        self._check(fn(self._h, C.byref(pi), *mid, C.byref(po)))
+        return out
+
+    def apply_scnr_inplace(self, r, g, b, method="average", amount=1.0, preserve_luminance=False):
+        """apply_scnr_inplace(&mut r, &mut g, &mut b, &ScnrConfig) (scnr.rs:18-53); mutates r, g, b."""
+        keep = []
+        planes = []
+        for x in (r, g, b):
+            if _is_torch(x):
+                planes.append(self._plane(x, keep))
+            else:
+                assert isinstance(x, np.ndarray) and x.dtype == np.float32 and x.flags.c_contiguous, \
+                    "in-place SCNR needs contiguous float32 arrays"
+                planes.append(Plane(C.c_void_p(x.ctypes.data), x.shape[0], x.shape[1], 0))
+        cfg = _lib.ScnrConfigC(0 if method in ("average", "AverageNeutral", 0) else 1, amount,
+                               1 if preserve_luminance else 0)
+        self._check(self._L.ab_apply_scnr_inplace(self._h, C.byref(planes[0]), C.byref(planes[1]),
+                                                  C.byref(planes[2]), C.byref(cfg)))
+
+    def blend_channels(self, channels, weights, rows, cols):
+        """blend_channels(&[&Array2], &[BlendWeight], rows, cols) -> (R, G, B) (channel_blend.rs:13-70).
+        weights: iterable of (channel_idx, r_weight, g_weight, b_weight)."""
+        keep = []
+        chans = (Plane * len(channels))(*[self._plane(c, keep) for c in channels])
+        ws = (_lib.BlendWeightC * max(1, len(weights)))(*[_lib.BlendWeightC(int(w[0]), w[1], w[2], w[3])
+                                                           for w in weights])
+        outs = [self._new_like(channels[0], rows, cols) for _ in range(3)]
+        pos = [self._out_plane(o, keep, rows, cols) for o in outs]
+        self._check(self._L.ab_blend_channels(self._h, chans, len(channels), ws, len(weights), C.byref(pos[0]),
+                                              C.byref(pos[1]), C.byref(pos[2])))
+        return tuple(outs)
+
+    def spline_lut_from_points(self, points) -> np.ndarray:
+        """SplineLut::from_points (curves.rs:69-95) -> 4096 f32 (host scalar maths in the library)."""
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.float64).reshape(-1, 2))
+        lut = np.zeros(4096, np.float32)
+        rc = self._L.ab_spline_lut_from_points(pts.ctypes.data_as(C.POINTER(C.c_double)), pts.shape[0],
+                                               lut.ctypes.data_as(C.POINTER(C.c_float)))
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "ab_spline_lut_from_points: bad arguments")
+        return lut
+
+    def apply_curve(self, image, lut, out=None):
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        assert lut.size == 4096
+        return self._unary(self._L.ab_apply_curve, image, out, lut.ctypes.data_as(C.POINTER(C.c_float)))
+
+    def apply_levels(self, image, black=0.0, gamma=1.0, white=1.0, out=None):
+        p = _lib.LevelsParamsC(black, gamma, white)
+        return self._unary(self._L.ab_apply_levels, image, out, C.byref(p))
+
+    def arcsinh_stretch_with_stats(self, image, dmin, dmax, factor, gamma=1.0, out=None):
+        return self._unary(self._L.ab_arcsinh_stretch_with_stats, image, out, C.c_float(dmin), C.c_float(dmax),
+                           C.c_float(factor), C.c_float(gamma))
+
+    def scale(self, image, factor, out=None):
+        return self._unary(self._L.ab_scale, image, out, C.c_float(factor))
+
+    def luminance(self, r, g, b, out=None):
+        keep = []
+        pr, pg, pb = (self._plane(x, keep) for x in (r, g, b))
+        if out is None:
+            out = self._new_like(r, pr.rows, pr.cols)
+        po = self._out_plane(out, keep, pr.rows, pr.cols)
+        self._check(self._L.ab_luminance(self._h, C.byref(pr), C.byref(pg), C.byref(pb), C.byref(po)))
+        return out
+
+    def calibrate_image(self, raw, master_bias=None, master_dark=None, master_flat=None, dark_exposure_ratio=1.0,
+                        out=None):
+        """calibrate_image(raw, &CalibrationConfig) (calibration.rs:47-82)."""
+        keep = []
+        praw = self._plane(raw, keep)
+        opt = [C.byref(self._plane(x, keep)) if x is not None else None for x in (master_bias, master_dark, master_flat)]
+        if out is None:
+            out = self._new_like(raw, praw.rows, praw.cols)
+        po = self._out_plane(out, keep, praw.rows, praw.cols)
+        self._check(self._L.ab_calibrate_image(self._h, C.byref(praw), opt[0], opt[1], opt[2],
+                                               C.c_float(dark_exposure_ratio), C.byref(po)))
+        return out
+
+    def median_combine(self, frames, out=None):
+        """median_combine_row_major (calibration.rs:84-125): per-pixel upper median of the finite samples."""
+        keep = []
+        planes = (Plane * len(frames))(*[self._plane(f, keep) for f in frames])
+        rows, cols = planes[0].rows, planes[0].cols
+        if out is None:
+            out = self._new_like(frames[0], rows, cols)
+        po = self._out_plane(out, keep, rows, cols)
+        self._check(self._L.ab_median_combine(self._h, planes, len(frames), C.byref(po)))
+        return out
+
     # ---- bench support -----------------------------------------------------------------------------
     def bench_copy(self, src, dst):
         self._check(self._L.ab_bench_copy(self._h, C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), src.numel()))

@@ -4,7 +4,7 @@
 
 int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
                     const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev,
-                    uint64_t *out_rejected);
+                    uint64_t *out_rejected, bool median_only);
 
 extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
                                ab_plane_mut *out, int32_t *offsets_dy_dx, uint64_t *out_rejected) {

@@ -544,6 +544,10 @@ __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(co
         if (valid) args.out[g] = med + mad;
         return;
     }
+    if constexpr (STAGE == 10) {  // median_combine_row_major (calibration.rs:84-125): [len/2] of the finite samples
+        if (valid) args.out[g] = (n == 0) ? 0.0f : med;
+        return;
+    }
 
     ClipResult r;
     if constexpr (EXACT)
@@ -596,26 +600,26 @@ __global__ void finalize_partial_kernel(const double *sum, const uint32_t *cnt, 
     out[g] = c ? (float)(sum[g] / (double)c) : 0.0f;
 }
 
-template <int NP, bool PARTIAL, bool EXACT>
+template <int NP, bool PARTIAL, bool EXACT, int STAGE>
 void launch_np(ab_ctx *ctx, const StackArgs &args, dim3 grid, dim3 block) {
     // DIRECT gather: no absent-frame slots, one row stride, byte offsets fit 32 bits
     if (args.n == NP && args.contiguous && args.rows * args.cols < (int64_t(1) << 30))
-        hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, 99, true>), grid, block, 0, ctx->stream, args);
+        hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, true>), grid, block, 0, ctx->stream, args);
     else
-        hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, 99, false>), grid, block, 0, ctx->stream, args);
+        hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, false>), grid, block, 0, ctx->stream, args);
 }
 
-template <bool PARTIAL, bool EXACT>
+template <bool PARTIAL, bool EXACT, int STAGE = 99>
 int launch_stack(ab_ctx *ctx, const StackArgs &args, int np) {
     const int64_t total = args.rows * args.cols;
     const dim3 grid((unsigned)((total + 255) / 256)), block(256);
     switch (np) {
-        case 2: launch_np<2, PARTIAL, EXACT>(ctx, args, grid, block); break;
-        case 4: launch_np<4, PARTIAL, EXACT>(ctx, args, grid, block); break;
-        case 8: launch_np<8, PARTIAL, EXACT>(ctx, args, grid, block); break;
-        case 16: launch_np<16, PARTIAL, EXACT>(ctx, args, grid, block); break;
-        case 32: launch_np<32, PARTIAL, EXACT>(ctx, args, grid, block); break;
-        case 64: launch_np<64, PARTIAL, EXACT>(ctx, args, grid, block); break;
+        case 2: launch_np<2, PARTIAL, EXACT, STAGE>(ctx, args, grid, block); break;
+        case 4: launch_np<4, PARTIAL, EXACT, STAGE>(ctx, args, grid, block); break;
+        case 8: launch_np<8, PARTIAL, EXACT, STAGE>(ctx, args, grid, block); break;
+        case 16: launch_np<16, PARTIAL, EXACT, STAGE>(ctx, args, grid, block); break;
+        case 32: launch_np<32, PARTIAL, EXACT, STAGE>(ctx, args, grid, block); break;
+        case 64: launch_np<64, PARTIAL, EXACT, STAGE>(ctx, args, grid, block); break;
         default: return ab_set_error(ctx, AB_ERR_INVALID, "internal: bad padded frame count %d", np);
     }
     AB_HIP(ctx, hipGetLastError());
@@ -638,7 +642,7 @@ static int read_rejected(ab_ctx *ctx, uint64_t *out) {
 // Shared implementation.  dplanes: device pointers + row strides of the n frames.
 int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows,
                     int64_t cols, const ab_stack_config *cfg, float *out_dev, double *out_sum_dev,
-                    uint32_t *out_cnt_dev, uint64_t *out_rejected) {
+                    uint32_t *out_cnt_dev, uint64_t *out_rejected, bool median_only) {
     AB_CHECK(ctx, n >= 1, "No images to stack");
     if (n > (size_t)kMaxFrames)
         return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "stack of %zu frames: this build keeps <= %d frames per pixel in registers",
@@ -676,7 +680,9 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         args.rejected = ctx->counters;
         int np = 2;
         while (np < (int)n) np <<= 1;
-        if (ctx->stack_exact)
+        if (median_only)
+            AB_TRY((launch_stack<false, false, 10>(ctx, args, np)));
+        else if (ctx->stack_exact)
             AB_TRY(partial ? (launch_stack<true, true>(ctx, args, np)) : (launch_stack<false, true>(ctx, args, np)));
         else
             AB_TRY(partial ? (launch_stack<true, false>(ctx, args, np)) : (launch_stack<false, false>(ctx, args, np)));
@@ -687,8 +693,8 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
 
 extern "C" {
 
-int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, ab_plane_mut *out,
-                        uint64_t *out_rejected) {
+static int stack_planes(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, ab_plane_mut *out,
+                        uint64_t *out_rejected, bool median_only) {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");
     AB_CHECK(ctx, cfg && out, "null config or output");
@@ -719,7 +725,7 @@ int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_
     uint64_t rejected = 0;
     if (rc == AB_OK)
         rc = ab_stack_device(ctx, dp.data(), ld.data(), n, out->rows, out->cols, cfg, so.dptr, nullptr, nullptr,
-                             out_rejected ? &rejected : nullptr);
+                             out_rejected ? &rejected : nullptr, median_only);
     if (rc == AB_OK) {
         rc = ab_stage_out_finish(ctx, &so);
         so_open = false;
@@ -728,6 +734,17 @@ int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_
     for (size_t i = 0; i < staged; ++i) ab_stage_release(ctx, &st[i]);
     if (rc == AB_OK && out_rejected) *out_rejected = rejected;
     return rc;
+}
+
+int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, ab_plane_mut *out,
+                        uint64_t *out_rejected) {
+    return stack_planes(ctx, planes, n, cfg, out, out_rejected, false);
+}
+
+// median_combine_row_major (calibration.rs:84-125): per-pixel [len/2] order statistic of the finite samples
+int ab_median_combine(ab_ctx *ctx, const ab_plane *planes, size_t n, ab_plane_mut *out) {
+    const ab_stack_config cfg = {3.0f, 3.0f, 0, 0};
+    return stack_planes(ctx, planes, n, &cfg, out, nullptr, true);
 }
 
 int ab_stack_sigma_clip_partial(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, int64_t rows,
@@ -743,7 +760,8 @@ int ab_stack_sigma_clip_partial(ab_ctx *ctx, const ab_plane *planes, size_t n, c
         dp[i] = planes[i].data;
         ld[i] = planes[i].cols;
     }
-    return ab_stack_device(ctx, dp.data(), ld.data(), n, rows, cols, cfg, nullptr, out_sum_dev, out_cnt_dev, out_rejected);
+    return ab_stack_device(ctx, dp.data(), ld.data(), n, rows, cols, cfg, nullptr, out_sum_dev, out_cnt_dev, out_rejected,
+                           false);
 }
 
 int ab_stack_last_rejected(ab_ctx *ctx, uint64_t *out_rejected) {

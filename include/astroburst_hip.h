@@ -158,6 +158,53 @@ AB_API int ab_apply_stf_u8(ab_ctx *ctx, const ab_plane *img, const ab_stf_params
 AB_API int ab_apply_stf_f32(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st,
                             ab_plane_mut *out);
 
+/* ---- a14  core/imaging/scnr.rs ----------------------------------------------------------------- */
+typedef struct { /* ScnrConfig, types/image.rs:82-100 */
+    int32_t method; /* 0 AverageNeutral, 1 MaximumNeutral */
+    float amount;
+    int32_t preserve_luminance;
+} ab_scnr_config;
+/* apply_scnr_inplace (scnr.rs:18-53): mutates the three caller-owned planes; mismatched dims or
+ * amount < 1e-7 is a silent no-op exactly as in the reference. */
+AB_API int ab_apply_scnr_inplace(ab_ctx *ctx, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b,
+                                 const ab_scnr_config *cfg);
+
+/* ---- a16  core/compose/channel_blend.rs ------------------------------------------------------------ */
+typedef struct { /* BlendWeight, channel_blend.rs:5-11 */
+    uint64_t channel_idx;
+    double r_weight, g_weight, b_weight;
+} ab_blend_weight;
+/* blend_channels (channel_blend.rs:13-70): out_c[i] = sum over weights (list order) of ch[idx][i] * w_c,
+ * f32 multiply then add; weights whose channel_idx >= n_channels are skipped. */
+AB_API int ab_blend_channels(ab_ctx *ctx, const ab_plane *channels, size_t n_channels, const ab_blend_weight *weights,
+                             size_t n_weights, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b);
+
+/* ---- a15  core/imaging/curves.rs ----------------------------------------------------------------------- */
+typedef struct { double black, gamma, white; } ab_levels_params; /* LevelsParams, curves.rs:4-9 */
+/* SplineLut::from_points (curves.rs:69-95): Fritsch-Carlson monotone cubic -> 4096-entry LUT (host maths) */
+AB_API int ab_spline_lut_from_points(const double *points_xy, size_t n_points, float *lut4096);
+/* apply_curve (curves.rs:186-197): truncating LUT lookup, non-finite or negative -> 0 */
+AB_API int ab_apply_curve(ab_ctx *ctx, const ab_plane *img, const float *lut4096_host, ab_plane_mut *out);
+/* apply_levels (curves.rs:31-52): clamp((v-black)/(white-black))^(1/gamma) in f64 */
+AB_API int ab_apply_levels(ab_ctx *ctx, const ab_plane *img, const ab_levels_params *p, ab_plane_mut *out);
+
+/* ---- a19  core/imaging/stretch.rs:10-45 ------------------------------------------------------------------ */
+AB_API int ab_arcsinh_stretch_with_stats(ab_ctx *ctx, const ab_plane *img, float dmin, float dmax, float factor,
+                                         float gamma, ab_plane_mut *out);
+
+/* ---- helpers of a13/a17/a18: luminance (masked_stretch.rs:143-154), WB scale (cmd/compose/color.rs:28-40) */
+AB_API int ab_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, ab_plane_mut *out);
+AB_API int ab_scale(ab_ctx *ctx, const ab_plane *img, float factor, ab_plane_mut *out);
+
+/* ---- a20  core/stacking/calibration.rs ---------------------------------------------------------------------- */
+/* calibrate_image (calibration.rs:47-82): (raw - bias - dark*ratio) / flat (flat finite, |f| > 1e-4), clamped
+ * at 0; any of bias/dark/flat may be NULL. */
+AB_API int ab_calibrate_image(ab_ctx *ctx, const ab_plane *raw, const ab_plane *bias, const ab_plane *dark,
+                              const ab_plane *flat, float dark_exposure_ratio, ab_plane_mut *out);
+/* median_combine_row_major (calibration.rs:84-125), the per-pixel combine of create_master_{bias,dark,flat}:
+ * element [len/2] of the finite samples (upper median), 0 if none.  1 <= n <= 64. */
+AB_API int ab_median_combine(ab_ctx *ctx, const ab_plane *planes, size_t n, ab_plane_mut *out);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

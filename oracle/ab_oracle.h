@@ -117,6 +117,23 @@ void orc_apply_stf_u8(const float *data, size_t n, const orc_stf_params *p, cons
 void orc_apply_stf_f32(const float *data, size_t n, const orc_stf_params *p, const orc_image_stats *st,
                        int threads, float *out);                         /* stf.rs:104-120,147-155 */
 
+/* ---- colour / tone / calibration maps (orc_color.c) --------------------------------- */
+/* scnr.rs:18-53; method 0 AverageNeutral, 1 MaximumNeutral */
+void orc_apply_scnr_inplace(float *r, float *g, float *b, size_t n, int method, float amount, int preserve);
+/* channel_blend.rs:13-70; weights = n_weights x {channel_idx, r, g, b} (f64).  parity unpinned */
+void orc_blend_channels(const float *const *channels, size_t n_channels, const double *weights, size_t n_weights,
+                        size_t npix, float *r_out, float *g_out, float *b_out);
+void orc_spline_lut_from_points(const double *points_xy, size_t n, float *lut4096);  /* curves.rs:69-95 */
+void orc_apply_curve(const float *data, size_t n, const float *lut4096, float *out); /* curves.rs:186-197 */
+void orc_apply_levels(const float *data, size_t n, double black, double gamma, double white, float *out); /* :31-52 */
+void orc_arcsinh_stretch_with_stats(const float *data, size_t n, float dmin, float dmax, float factor, float gamma,
+                                    float *out);                                       /* stretch.rs:10-45 */
+void orc_luminance(const float *r, const float *g, const float *b, size_t n, float *out); /* masked_stretch.rs:143-154 */
+void orc_scale(const float *data, size_t n, float factor, float *out);                 /* cmd/compose/color.rs:28-40 */
+void orc_calibrate_image(const float *raw, const float *bias, const float *dark, const float *flat, float dark_ratio,
+                         size_t n, float *out);                                        /* calibration.rs:47-82 */
+void orc_median_combine(const float *const *planes, size_t n_frames, size_t npix, float *out); /* :84-125 */
+
 /* utility */
 int orc_max_threads(void);
 

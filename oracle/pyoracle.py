@@ -119,8 +119,101 @@ def lib():
     L.orc_apply_stf_u8.argtypes = [fp, C.c_size_t, C.POINTER(_Stf), sp, C.c_int, C.POINTER(C.c_uint8)]
     L.orc_apply_stf_f32.argtypes = [fp, C.c_size_t, C.POINTER(_Stf), sp, C.c_int, fp]
     L.orc_max_threads.restype = C.c_int
+    L.orc_apply_scnr_inplace.argtypes = [fp, fp, fp, C.c_size_t, C.c_int, C.c_float, C.c_int]
+    L.orc_blend_channels.argtypes = [C.POINTER(fp), C.c_size_t, C.POINTER(C.c_double), C.c_size_t, C.c_size_t,
+                                     fp, fp, fp]
+    L.orc_spline_lut_from_points.argtypes = [C.POINTER(C.c_double), C.c_size_t, fp]
+    L.orc_apply_curve.argtypes = [fp, C.c_size_t, fp, fp]
+    L.orc_apply_levels.argtypes = [fp, C.c_size_t, C.c_double, C.c_double, C.c_double, fp]
+    L.orc_arcsinh_stretch_with_stats.argtypes = [fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, fp]
+    L.orc_luminance.argtypes = [fp, fp, fp, C.c_size_t, fp]
+    L.orc_scale.argtypes = [fp, C.c_size_t, C.c_float, fp]
+    L.orc_calibrate_image.argtypes = [fp, fp, fp, fp, C.c_float, C.c_size_t, fp]
+    L.orc_median_combine.argtypes = [C.POINTER(fp), C.c_size_t, C.c_size_t, fp]
     _lib = L
     return L
+
+
+# ---- colour / tone / calibration maps (orc_color.c) ------------------------------------------------
+def apply_scnr(r, g, b, method="average", amount=1.0, preserve_luminance=False):
+    """returns new (r, g, b) after apply_scnr_inplace (scnr.rs:18-53)"""
+    r, g, b = _f32(r).copy(), _f32(g).copy(), _f32(b).copy()
+    if r.shape != g.shape or g.shape != b.shape:
+        return r, g, b
+    lib().orc_apply_scnr_inplace(_fp(r), _fp(g), _fp(b), r.size, 0 if method in ("average", 0) else 1, amount,
+                                 1 if preserve_luminance else 0)
+    return r, g, b
+
+
+def blend_channels(channels, weights, rows, cols):
+    chans = [_f32(c) for c in channels]
+    n = len(chans)
+    ptrs = (C.POINTER(C.c_float) * n)(*[_fp(c) for c in chans])
+    w = np.ascontiguousarray(np.asarray([[float(x) for x in ww] for ww in weights], np.float64).reshape(-1, 4))
+    outs = [np.zeros((rows, cols), np.float32) for _ in range(3)]
+    lib().orc_blend_channels(ptrs, n, w.ctypes.data_as(C.POINTER(C.c_double)), w.shape[0], rows * cols,
+                             _fp(outs[0]), _fp(outs[1]), _fp(outs[2]))
+    return tuple(outs)
+
+
+def spline_lut_from_points(points) -> np.ndarray:
+    pts = np.ascontiguousarray(np.asarray(points, np.float64).reshape(-1, 2))
+    lut = np.zeros(4096, np.float32)
+    lib().orc_spline_lut_from_points(pts.ctypes.data_as(C.POINTER(C.c_double)), pts.shape[0], _fp(lut))
+    return lut
+
+
+def apply_curve(image, lut) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros_like(im)
+    lut = _f32(lut)
+    lib().orc_apply_curve(_fp(im), im.size, _fp(lut), _fp(out))
+    return out
+
+
+def apply_levels(image, black=0.0, gamma=1.0, white=1.0) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros_like(im)
+    lib().orc_apply_levels(_fp(im), im.size, black, gamma, white, _fp(out))
+    return out
+
+
+def arcsinh_stretch_with_stats(image, dmin, dmax, factor, gamma=1.0) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros_like(im)
+    lib().orc_arcsinh_stretch_with_stats(_fp(im), im.size, dmin, dmax, factor, gamma, _fp(out))
+    return out
+
+
+def luminance(r, g, b) -> np.ndarray:
+    r, g, b = _f32(r), _f32(g), _f32(b)
+    out = np.zeros_like(r)
+    lib().orc_luminance(_fp(r), _fp(g), _fp(b), r.size, _fp(out))
+    return out
+
+
+def scale(image, factor) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros_like(im)
+    lib().orc_scale(_fp(im), im.size, factor, _fp(out))
+    return out
+
+
+def calibrate_image(raw, master_bias=None, master_dark=None, master_flat=None, dark_exposure_ratio=1.0) -> np.ndarray:
+    raw = _f32(raw)
+    opt = [None if x is None else _f32(x) for x in (master_bias, master_dark, master_flat)]
+    out = np.zeros_like(raw)
+    lib().orc_calibrate_image(_fp(raw), *[None if x is None else _fp(x) for x in opt], dark_exposure_ratio, raw.size,
+                              _fp(out))
+    return out
+
+
+def median_combine(frames) -> np.ndarray:
+    fr = [_f32(f) for f in frames]
+    ptrs = (C.POINTER(C.c_float) * len(fr))(*[_fp(f) for f in fr])
+    out = np.zeros_like(fr[0])
+    lib().orc_median_combine(ptrs, len(fr), fr[0].size, _fp(out))
+    return out
 
 
 def _f32(a) -> np.ndarray:
