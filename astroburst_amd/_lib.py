@@ -49,6 +49,10 @@ class AutoStfConfigC(C.Structure):  # types/image.rs:52-65
     _fields_ = [("target_bg", C.c_double), ("shadow_k", C.c_double)]
 
 
+class PhaseCorrelationResultC(C.Structure):  # phase_correlation.rs:15-20
+    _fields_ = [("dx", C.c_double), ("dy", C.c_double), ("confidence", C.c_double)]
+
+
 class ScnrConfigC(C.Structure):  # types/image.rs:82-100
     _fields_ = [("method", C.c_int32), ("amount", C.c_float), ("preserve_luminance", C.c_int32)]
 
@@ -127,6 +131,8 @@ def lib() -> C.CDLL:
     L.ab_apply_stf_u8.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32]
     L.ab_apply_stf_f32.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), pp]
     L.ab_bench_copy.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ab_phase_correlate.argtypes = [vp, pp, pp, C.POINTER(PhaseCorrelationResultC)]
+    L.ab_correlate_single.argtypes = [vp, pp, pp, C.POINTER(PhaseCorrelationResultC), vp]
     L.ab_apply_scnr_inplace.argtypes = [vp, pp, pp, pp, C.POINTER(ScnrConfigC)]
     L.ab_blend_channels.argtypes = [vp, pp, C.c_size_t, C.POINTER(BlendWeightC), C.c_size_t, pp, pp, pp]
     L.ab_spline_lut_from_points.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_float)]

@@ -301,6 +301,29 @@ class Context:
         self._check(self._L.ab_apply_stf_f32(self._h, C.byref(pi), C.byref(p), C.byref(s), C.byref(po)))
         return out
 
+    # ---- core/alignment/phase_correlation.rs ----------------------------------------------------------
+    def phase_correlate(self, reference, target):
+        """phase_correlate(reference, target) -> (dx, dy, confidence) (phase_correlation.rs:22-89)."""
+        keep = []
+        pr, pt = self._plane(reference, keep), self._plane(target, keep)
+        res = _lib.PhaseCorrelationResultC()
+        self._check(self._L.ab_phase_correlate(self._h, C.byref(pr), C.byref(pt), C.byref(res)))
+        return res.dx, res.dy, res.confidence
+
+    def correlate_single(self, a, b, want_surface=False):
+        """correlate_single (phase_correlation.rs:105-141), dims <= 512; optionally the correlation surface."""
+        keep = []
+        pa, pb = self._plane(a, keep), self._plane(b, keep)
+        res = _lib.PhaseCorrelationResultC()
+        surf = None
+        if want_surface:
+            fr = 1 << max(0, (pa.rows - 1).bit_length())
+            fc = 1 << max(0, (pa.cols - 1).bit_length())
+            surf = np.zeros((fr, fc), np.float64)
+        self._check(self._L.ab_correlate_single(self._h, C.byref(pa), C.byref(pb), C.byref(res),
+                                                C.c_void_p(surf.ctypes.data) if surf is not None else None))
+        return (res.dx, res.dy, res.confidence, surf) if want_surface else (res.dx, res.dy, res.confidence)
+
     # ---- colour / tone / calibration maps -----------------------------------------------------------
     def _out_plane(self, out, keep, rows, cols):
         return self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), rows, cols, 0)

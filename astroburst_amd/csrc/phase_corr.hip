@@ -1,0 +1,493 @@
+// Phase-correlation registration on gfx950.
+//
+// Replaces core/alignment/phase_correlation.rs (phase_correlate :22-89, correlate_single
+// :105-141, is_constant_or_zero :143-160), core/alignment/downsample.rs:6-46 (area_downsample)
+// and the math/ pieces they use: window.rs:3-18, fft.rs:136-167,202-226,271-282,
+// complex.rs:27-44, subpixel.rs:27-100, normalization.rs:128-170.
+//
+// The transform sizes are fixed by the algorithm: everything larger than 512 px is first
+// area-averaged to 512 x 512 and then refined on a centred 512 x 512 crop, so the work per frame is
+// three 512^2 complex-f64 2-D FFTs twice over (4 MiB per buffer, L2 resident).  One workgroup
+// runs one line through an LDS-resident radix-2 decimation-in-time FFT (8 KiB of f64 pairs,
+// one butterfly per thread per stage, twiddles from a host-made table).  Rows first, then columns,
+// exactly the reference's order.  The reference's FFT is rustfft (not reproducible bit for bit,
+// its tests pin the shift to +-1 px); the CPU oracle uses the same butterflies as this kernel, so
+// the correlation surface is bit-identical between the two and the estimated shift agrees to ~1e-12.
+// find_peak's tie-break (schedule dependent in the reference) is the lowest index.
+#include "ab_common.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+constexpr int kCoarseMaxDim = 512;   // phase_correlation.rs:10
+constexpr int kRefineCropSize = 512; // :11
+constexpr double kEpsilon = 1e-15;   // :13
+constexpr int kBlock = 256;
+
+struct MinMaxPartial {
+    float mn, mx;
+    unsigned long long finite;
+};
+
+// phase_correlation.rs:143-160
+__global__ __launch_bounds__(kBlock) void minmax_finite_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
+                                                               MinMaxPartial *__restrict__ partials) {
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    unsigned long long cnt = 0;
+    const int64_t total = (int64_t)rows * cols, stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
+        const int y = (int)(i / cols), x = (int)(i - (int64_t)y * cols);
+        const float v = img[y * ld + x];
+        if (__builtin_isfinite(v)) {
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+            cnt += 1;
+        }
+    }
+    __shared__ float s_mn[kBlock / 64], s_mx[kBlock / 64];
+    __shared__ unsigned long long s_c[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_mn[threadIdx.x >> 6] = mn;
+        s_mx[threadIdx.x >> 6] = mx;
+        s_c[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; ++i) {
+            mn = fminf(mn, s_mn[i]);
+            mx = fmaxf(mx, s_mx[i]);
+            cnt += s_c[i];
+        }
+        partials[blockIdx.x].mn = mn;
+        partials[blockIdx.x].mx = mx;
+        partials[blockIdx.x].finite = cnt;
+    }
+}
+
+// downsample.rs:18-43: box average of the finite samples, f64 sum in row-major order
+__global__ __launch_bounds__(kBlock) void area_downsample_kernel(const float *__restrict__ src, int in_rows, int in_cols,
+                                                                 int64_t ld, int out_rows, int out_cols, double scale_y,
+                                                                 double scale_x, float *__restrict__ out) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= out_rows * out_cols) return;
+    const int oy = idx / out_cols, ox = idx - oy * out_cols;
+    auto clampi = [](long long v, int len) { return v < 0 ? 0 : (v >= len ? len - 1 : (int)v); };
+    const int y0 = clampi((long long)floor((double)oy * scale_y), in_rows);
+    const long long y1r = (long long)ceil((double)(oy + 1) * scale_y);
+    const int y1 = y1r <= 0 ? 0 : (y1r < in_rows ? (int)y1r : in_rows);
+    const int x0 = clampi((long long)floor((double)ox * scale_x), in_cols);
+    const long long x1r = (long long)ceil((double)(ox + 1) * scale_x);
+    const int x1 = x1r <= 0 ? 0 : (x1r < in_cols ? (int)x1r : in_cols);
+    double sum = 0.0;
+    unsigned count = 0;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const float v = src[y * ld + x];
+            if (__builtin_isfinite(v)) {
+                sum += (double)v;
+                count += 1;
+            }
+        }
+    out[idx] = count > 0 ? (float)(sum / (double)count) : 0.0f;
+}
+
+// fft.rs:202-226: v * wy * wx for finite v, zero padded to the power-of-two buffer
+__global__ __launch_bounds__(kBlock) void window_pad_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
+                                                            const double *__restrict__ win_y, const double *__restrict__ win_x,
+                                                            int fft_rows, int fft_cols, double2 *__restrict__ out) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= fft_rows * fft_cols) return;
+    const int y = idx / fft_cols, x = idx - y * fft_cols;
+    double re = 0.0;
+    if (y < rows && x < cols) {
+        const double v = (double)img[y * ld + x];
+        re = __builtin_isfinite(v) ? v * win_y[y] * win_x[x] : 0.0;
+    }
+    out[idx] = make_double2(re, 0.0);
+}
+
+// one line per workgroup, radix-2 DIT in LDS; tw[k] = exp(-2 pi i k / n)
+__global__ __launch_bounds__(kBlock) void fft_lines_kernel(double2 *data, int n, int log2n, int64_t elem_stride,
+                                                           int64_t line_stride, const double2 *__restrict__ tw, int inverse) {
+    __shared__ double2 s[512];
+    double2 *line = data + (int64_t)blockIdx.x * line_stride;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const int r = log2n ? (int)(__brev((unsigned)i) >> (32 - log2n)) : 0;
+        s[r] = line[(int64_t)i * elem_stride];
+    }
+    __syncthreads();
+    for (int m = 2; m <= n; m <<= 1) {
+        const int half = m >> 1, step = n / m;
+        for (int t = threadIdx.x; t < n / 2; t += kBlock) {
+            const int k = (t / half) * m, j = t % half;
+            double2 w = tw[j * step];
+            if (inverse) w.y = -w.y;
+            const double2 x = s[k + j + half];
+            const double tr = w.x * x.x - w.y * x.y;
+            const double ti = w.x * x.y + w.y * x.x;
+            const double2 u = s[k + j];
+            s[k + j] = make_double2(u.x + tr, u.y + ti);
+            s[k + j + half] = make_double2(u.x - tr, u.y - ti);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += kBlock) line[(int64_t)i * elem_stride] = s[i];
+}
+
+// complex.rs:27-44, in place into fa
+__global__ __launch_bounds__(kBlock) void cross_power_kernel(double2 *fa, const double2 *__restrict__ fb, int n, double eps) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double2 a = fa[i], b = fb[i];
+    const double pr = a.x * b.x + a.y * b.y;
+    const double pi = a.y * b.x - a.x * b.y;
+    const double mag = sqrt(pr * pr + pi * pi);
+    fa[i] = mag > eps ? make_double2(pr / mag, pi / mag) : make_double2(0.0, 0.0);
+}
+
+struct PeakPartial {
+    double best;
+    int best_idx;
+    double sum, count;
+};
+
+// inverse_2d's 1/(rows*cols) scaling + extract_real + find_peak + first moment, one pass
+__global__ __launch_bounds__(kBlock) void scale_peak_kernel(const double2 *__restrict__ buf, int n, double norm,
+                                                            double *__restrict__ corr, PeakPartial *__restrict__ partials) {
+    double best = -DBL_MAX, sum = 0.0, count = 0.0;
+    int best_idx = 0x7fffffff;
+    const int stride = gridDim.x * kBlock;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double v = buf[i].x * norm;  // c.re * norm (fft.rs:161-166)
+        corr[i] = v;
+        if (v > best) {  // ascending i per thread: the first maximum is kept
+            best = v;
+            best_idx = i;
+        }
+        if (__builtin_isfinite(v)) {
+            sum += v;
+            count += 1.0;
+        }
+    }
+    __shared__ PeakPartial sh[kBlock];
+    sh[threadIdx.x] = {best, best_idx, sum, count};
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            PeakPartial &a = sh[threadIdx.x];
+            const PeakPartial &b = sh[threadIdx.x + off];
+            // maximum value, lowest index among equals; NaN never wins (v > best is false)
+            if (b.best_idx != 0x7fffffff && (a.best_idx == 0x7fffffff || b.best > a.best || (b.best == a.best && b.best_idx < a.best_idx))) {
+                a.best = b.best;
+                a.best_idx = b.best_idx;
+            }
+            a.sum += b.sum;
+            a.count += b.count;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(kBlock) void var_kernel(const double *__restrict__ corr, int n, double mean, double *__restrict__ partials) {
+    double vs = 0.0;
+    const int stride = gridDim.x * kBlock;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const double v = corr[i];
+        if (__builtin_isfinite(v)) {
+            const double d = v - mean;
+            vs += d * d;
+        }
+    }
+    __shared__ double sh[kBlock];
+    sh[threadIdx.x] = vs;
+    __syncthreads();
+    for (int off = kBlock / 2; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+int ilog2(int n) {
+    int l = 0;
+    while ((1 << l) < n) ++l;
+    return l;
+}
+
+struct View {  // a rows x cols window of a device plane with row stride ld
+    const float *p;
+    int rows, cols;
+    int64_t ld;
+};
+
+constexpr int kPartials = 256;
+
+struct PcScratch {
+    double2 *fa, *fb;      // 512 x 512 each
+    double *corr;          // 512 x 512
+    double *hann_y, *hann_x;
+    double2 *tw_r, *tw_c;  // 256 each
+    float *ds_a, *ds_b;    // 512 x 512 downsampled planes
+    void *partials;        // kPartials x 32 B
+};
+
+int pc_carve(ab_ctx *ctx, PcScratch *s) {
+    const size_t n = 512 * 512;
+    const size_t bytes = 2 * n * sizeof(double2) + n * sizeof(double) + 2 * 512 * sizeof(double) + 2 * 256 * sizeof(double2) +
+                         2 * n * sizeof(float) + kPartials * 32 + 256;
+    void *p = nullptr;
+    AB_TRY(ab_scratch(ctx, bytes, &p));
+    char *c = (char *)p;
+    s->fa = (double2 *)c; c += n * sizeof(double2);
+    s->fb = (double2 *)c; c += n * sizeof(double2);
+    s->corr = (double *)c; c += n * sizeof(double);
+    s->hann_y = (double *)c; c += 512 * sizeof(double);
+    s->hann_x = (double *)c; c += 512 * sizeof(double);
+    s->tw_r = (double2 *)c; c += 256 * sizeof(double2);
+    s->tw_c = (double2 *)c; c += 256 * sizeof(double2);
+    s->ds_a = (float *)c; c += n * sizeof(float);
+    s->ds_b = (float *)c; c += n * sizeof(float);
+    s->partials = (void *)c;
+    return AB_OK;
+}
+
+void hann_periodic(int n, std::vector<double> &w) {  // window.rs:3-18
+    w.resize(n);
+    if (n == 1) {
+        w[0] = 1.0;
+        return;
+    }
+    const double two_pi = 2.0 * 3.14159265358979323846, nf = (double)n;
+    for (int i = 0; i < n; ++i) w[i] = 0.5 * (1.0 - std::cos(two_pi * (double)i / nf));
+}
+
+void twiddles(int n, std::vector<double> &tw) {
+    tw.assign(2 * std::max(1, n / 2), 0.0);
+    for (int k = 0; k < n / 2; ++k) {
+        const double ang = -2.0 * 3.14159265358979323846 * (double)k / (double)n;
+        tw[2 * k] = std::cos(ang);
+        tw[2 * k + 1] = std::sin(ang);
+    }
+}
+
+int fft2d(ab_ctx *ctx, double2 *buf, int fr, int fc, const PcScratch &s, int inverse) {
+    hipLaunchKernelGGL(fft_lines_kernel, dim3(fr), dim3(kBlock), 0, ctx->stream, buf, fc, ilog2(fc), (int64_t)1, (int64_t)fc,
+                       s.tw_c, inverse);  // rows
+    hipLaunchKernelGGL(fft_lines_kernel, dim3(fc), dim3(kBlock), 0, ctx->stream, buf, fr, ilog2(fr), (int64_t)fc, (int64_t)1,
+                       s.tw_r, inverse);  // columns
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+int is_constant_or_zero(ab_ctx *ctx, const View &v, const PcScratch &s, bool *out) {
+    const int grid = std::min<int64_t>(kPartials, ((int64_t)v.rows * v.cols + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(minmax_finite_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, v.p, v.rows, v.cols, v.ld,
+                       (MinMaxPartial *)s.partials);
+    AB_HIP(ctx, hipGetLastError());
+    std::vector<MinMaxPartial> h(grid);
+    AB_HIP(ctx, hipMemcpyAsync(h.data(), s.partials, grid * sizeof(MinMaxPartial), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float mn = INFINITY, mx = -INFINITY;
+    unsigned long long cnt = 0;
+    for (const auto &p : h) {
+        mn = std::fmin(mn, p.mn);
+        mx = std::fmax(mx, p.mx);
+        cnt += p.finite;
+    }
+    *out = cnt < 16 || std::fabs(mx - mn) < 1e-10f;
+    return AB_OK;
+}
+
+// phase_correlation.rs:105-141
+int correlate_single(ab_ctx *ctx, const View &a, const View &b, const PcScratch &s, double *dx, double *dy, double *conf,
+                     double *surface_host) {
+    const int rows = a.rows, cols = a.cols;
+    const int fr = next_pow2(rows), fc = next_pow2(cols), n = fr * fc;
+    std::vector<double> hy, hx, twr, twc;
+    hann_periodic(rows, hy);
+    hann_periodic(cols, hx);
+    twiddles(fr, twr);
+    twiddles(fc, twc);
+    AB_HIP(ctx, hipMemcpyAsync(s.hann_y, hy.data(), rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipMemcpyAsync(s.hann_x, hx.data(), cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipMemcpyAsync(s.tw_r, twr.data(), twr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipMemcpyAsync(s.tw_c, twc.data(), twc.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host tables are locals
+    const int g = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(window_pad_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, a.p, rows, cols, a.ld, s.hann_y, s.hann_x, fr, fc, s.fa);
+    hipLaunchKernelGGL(window_pad_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, b.p, rows, cols, b.ld, s.hann_y, s.hann_x, fr, fc, s.fb);
+    AB_TRY(fft2d(ctx, s.fa, fr, fc, s, 0));
+    AB_TRY(fft2d(ctx, s.fb, fr, fc, s, 0));
+    hipLaunchKernelGGL(cross_power_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, s.fa, s.fb, n, kEpsilon);
+    AB_TRY(fft2d(ctx, s.fa, fr, fc, s, 1));
+    const int pg = std::min(kPartials, g);
+    hipLaunchKernelGGL(scale_peak_kernel, dim3(pg), dim3(kBlock), 0, ctx->stream, s.fa, n, 1.0 / (double)((size_t)fr * fc), s.corr,
+                       (PeakPartial *)s.partials);
+    AB_HIP(ctx, hipGetLastError());
+    std::vector<PeakPartial> pp(pg);
+    AB_HIP(ctx, hipMemcpyAsync(pp.data(), s.partials, pg * sizeof(PeakPartial), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    double best = -DBL_MAX, sum = 0.0, count = 0.0;
+    int best_idx = 0x7fffffff;
+    for (const auto &p : pp) {
+        if (p.best_idx != 0x7fffffff && (best_idx == 0x7fffffff || p.best > best || (p.best == best && p.best_idx < best_idx))) {
+            best = p.best;
+            best_idx = p.best_idx;
+        }
+        sum += p.sum;
+        count += p.count;
+    }
+    if (best_idx == 0x7fffffff) best_idx = 0;
+    double mean = 0.0, sigma = 0.0;  // normalization.rs:128-161
+    if (count >= 1.0) {
+        mean = sum / count;
+        hipLaunchKernelGGL(var_kernel, dim3(pg), dim3(kBlock), 0, ctx->stream, s.corr, n, mean, (double *)s.partials);
+        AB_HIP(ctx, hipGetLastError());
+        std::vector<double> vp(pg);
+        AB_HIP(ctx, hipMemcpyAsync(vp.data(), s.partials, pg * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        double var_sum = 0.0;
+        for (double v : vp) var_sum += v;
+        sigma = std::sqrt(var_sum / (count > 1.0 ? count - 1.0 : 1.0));
+    }
+    const int py = best_idx / fc, px = best_idx % fc;
+    // the 5 surface samples of the 3-point refinements (subpixel.rs:27-62), wrap-around neighbours
+    const int nb[5] = {py * fc + px, (py == 0 ? fr - 1 : py - 1) * fc + px, (py == fr - 1 ? 0 : py + 1) * fc + px,
+                       py * fc + (px == 0 ? fc - 1 : px - 1), py * fc + (px == fc - 1 ? 0 : px + 1)};
+    double sv[5];
+    for (int i = 0; i < 5; ++i)
+        AB_HIP(ctx, hipMemcpyAsync(&sv[i], s.corr + nb[i], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (surface_host) AB_HIP(ctx, hipMemcpyAsync(surface_host, s.corr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto refine = [](double center, double prev, double next) {
+        const double denom = 2.0 * (2.0 * center - prev - next);
+        if (std::fabs(denom) < 1e-15) return 0.0;  // FftFloat::epsilon_val() for f64 is 1e-15 (math/fft.rs)
+        const double r = (prev - next) / denom;
+        return std::fmin(std::fmax(r, -0.5), 0.5);
+    };
+    *conf = std::fabs(sigma) < 1e-15 ? 0.0 : (sv[0] - mean) / sigma;                    // normalization.rs:163-168
+    const double raw_dy = py > fr / 2 ? (double)py - (double)fr : (double)py;           // subpixel.rs:77-83
+    const double raw_dx = px > fc / 2 ? (double)px - (double)fc : (double)px;
+    *dy = raw_dy + refine(sv[0], sv[1], sv[2]);
+    *dx = raw_dx + refine(sv[0], sv[3], sv[4]);
+    return AB_OK;
+}
+
+int64_t f64_to_i64_sat(double v) {
+    if (std::isnan(v)) return 0;
+    if (v >= 9223372036854775807.0) return INT64_MAX;
+    if (v <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)v;
+}
+
+}  // namespace
+
+// phase_correlation.rs:22-89 on device-resident planes (row strides allowed: crops cost nothing)
+int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, int64_t ref_cols, int64_t ref_ld, const float *tgt,
+                              int64_t tgt_rows, int64_t tgt_cols, int64_t tgt_ld, double *dx, double *dy, double *confidence) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t rows = std::min(ref_rows, tgt_rows), cols = std::min(ref_cols, tgt_cols);
+    *dx = 0.0;
+    *dy = 0.0;
+    *confidence = 0.0;
+    AB_CHECK(ctx, rows > 0 && cols > 0 && rows < (1 << 30) && cols < (1 << 30), "phase_correlate: bad dims");
+    PcScratch s;
+    AB_TRY(pc_carve(ctx, &s));
+    const View r{ref, (int)rows, (int)cols, ref_ld}, t{tgt, (int)rows, (int)cols, tgt_ld};
+    bool cr = false, ct = false;
+    AB_TRY(is_constant_or_zero(ctx, r, s, &cr));
+    if (!cr) AB_TRY(is_constant_or_zero(ctx, t, s, &ct));
+    if (cr || ct) return AB_OK;                                                    // :42-48
+    if (rows <= kCoarseMaxDim && cols <= kCoarseMaxDim) return correlate_single(ctx, r, t, s, dx, dy, confidence, nullptr);  // :50-52
+    const double scale_y = (double)rows / (double)kCoarseMaxDim, scale_x = (double)cols / (double)kCoarseMaxDim;
+    const int ds_rows = (int)std::min<int64_t>(kCoarseMaxDim, rows), ds_cols = (int)std::min<int64_t>(kCoarseMaxDim, cols);
+    // area_downsample's own scale (downsample.rs:13-14) is in/out, which differs from scale_y when a dim <= 512
+    const double dsy = (double)rows / (double)ds_rows, dsx = (double)cols / (double)ds_cols;
+    const int g = (ds_rows * ds_cols + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(area_downsample_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, r.p, r.rows, r.cols, r.ld, ds_rows, ds_cols,
+                       dsy, dsx, s.ds_a);
+    hipLaunchKernelGGL(area_downsample_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, t.p, t.rows, t.cols, t.ld, ds_rows, ds_cols,
+                       dsy, dsx, s.ds_b);
+    AB_HIP(ctx, hipGetLastError());
+    double cdx, cdy, cconf;
+    AB_TRY(correlate_single(ctx, View{s.ds_a, ds_rows, ds_cols, ds_cols}, View{s.ds_b, ds_rows, ds_cols, ds_cols}, s, &cdx, &cdy,
+                            &cconf, nullptr));
+    const double coarse_dx = cdx * scale_x, coarse_dy = cdy * scale_y;            // :62-64
+    const int64_t half = kRefineCropSize / 2, ref_cy = rows / 2, ref_cx = cols / 2;
+    const int64_t tgt_cy = std::min(std::max<int64_t>(f64_to_i64_sat(std::round((double)ref_cy + coarse_dy)), 0), rows - 1);
+    const int64_t tgt_cx = std::min(std::max<int64_t>(f64_to_i64_sat(std::round((double)ref_cx + coarse_dx)), 0), cols - 1);
+    auto crop = [&](const View &v, int64_t cy, int64_t cx) {                       // extract_crop, :91-103
+        const int64_t y0 = cy > half ? cy - half : 0, y1 = std::min(cy + half, rows), x0 = cx > half ? cx - half : 0,
+                      x1 = std::min(cx + half, cols);
+        return View{v.p + y0 * v.ld + x0, (int)(y1 - y0), (int)(x1 - x0), v.ld};
+    };
+    const View rc = crop(r, ref_cy, ref_cx), tc = crop(t, tgt_cy, tgt_cx);
+    if (rc.rows != tc.rows || rc.cols != tc.cols) {                               // :74-80
+        *dx = coarse_dx;
+        *dy = coarse_dy;
+        *confidence = cconf;
+        return AB_OK;
+    }
+    double rdx, rdy, rconf;
+    AB_TRY(correlate_single(ctx, rc, tc, s, &rdx, &rdy, &rconf, nullptr));
+    *dx = coarse_dx + rdx;
+    *dy = coarse_dy + rdy;
+    *confidence = rconf;
+    return AB_OK;
+}
+
+extern "C" {
+
+int ab_phase_correlate(ab_ctx *ctx, const ab_plane *reference, const ab_plane *target, ab_phase_correlation_result *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, reference && target && out, "null argument");
+    StagedPlane r, t;
+    AB_TRY(ab_stage_in(ctx, reference, &r));
+    int rc = ab_stage_in(ctx, target, &t);
+    if (rc == AB_OK) {
+        rc = ab_phase_correlate_device(ctx, r.dptr, r.rows, r.cols, r.cols, t.dptr, t.rows, t.cols, t.cols, &out->dx, &out->dy,
+                                       &out->confidence);
+        ab_stage_release(ctx, &t);
+    }
+    ab_stage_release(ctx, &r);
+    return rc;
+}
+
+// test hook: correlate_single's full correlation surface (dims <= 512) for bit-level parity
+int ab_correlate_single(ab_ctx *ctx, const ab_plane *a, const ab_plane *b, ab_phase_correlation_result *out, double *surface_host) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, a && b && out, "null argument");
+    AB_CHECK(ctx, a->rows == b->rows && a->cols == b->cols && a->rows <= kCoarseMaxDim && a->cols <= kCoarseMaxDim,
+             "correlate_single takes two equal planes of at most 512 x 512");
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    StagedPlane sa, sb;
+    AB_TRY(ab_stage_in(ctx, a, &sa));
+    int rc = ab_stage_in(ctx, b, &sb);
+    if (rc == AB_OK) {
+        PcScratch s;
+        rc = pc_carve(ctx, &s);
+        if (rc == AB_OK)
+            rc = correlate_single(ctx, View{sa.dptr, (int)sa.rows, (int)sa.cols, sa.cols}, View{sb.dptr, (int)sb.rows, (int)sb.cols, sb.cols},
+                                  s, &out->dx, &out->dy, &out->confidence, surface_host);
+        ab_stage_release(ctx, &sb);
+    }
+    ab_stage_release(ctx, &sa);
+    return rc;
+}
+
+}  // extern "C"

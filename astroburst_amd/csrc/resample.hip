@@ -35,13 +35,13 @@ __device__ __forceinline__ int clamp_i32(int idx, int len) {  // boundary.rs:9-2
 
 // sampling.rs:51-80 with 32-bit indexing (callers guarantee rows*cols < 2^31 and |x|,|y| sane).
 // `row_val += s*w` starts from 0.0, so the first add is exact and is skipped.
-__device__ __forceinline__ float bicubic_taps(const float *__restrict__ src, int rows, int cols, int ix, int iy,
+__device__ __forceinline__ float bicubic_taps(const float *__restrict__ src, int rows, int cols, int ld, int ix, int iy,
                                               double wx0, double wx1, double wx2, double wx3, double wy0, double wy1,
                                               double wy2, double wy3) {
     const int c0 = clamp_i32(ix - 1, cols), c1 = clamp_i32(ix, cols), c2 = clamp_i32(ix + 1, cols),
               c3 = clamp_i32(ix + 2, cols);
-    const int r0 = clamp_i32(iy - 1, rows) * cols, r1 = clamp_i32(iy, rows) * cols, r2 = clamp_i32(iy + 1, rows) * cols,
-              r3 = clamp_i32(iy + 2, rows) * cols;
+    const int r0 = clamp_i32(iy - 1, rows) * ld, r1 = clamp_i32(iy, rows) * ld, r2 = clamp_i32(iy + 1, rows) * ld,
+              r3 = clamp_i32(iy + 2, rows) * ld;
     const double wy[4] = {wy0, wy1, wy2, wy3};
     const int rr[4] = {r0, r1, r2, r3};
     double val = 0.0;
@@ -58,17 +58,17 @@ __device__ __forceinline__ float bicubic_taps(const float *__restrict__ src, int
     return (float)val;
 }
 
-__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int rows, int cols, double y, double x) {
+__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int rows, int cols, int ld, double y, double x) {
     const double xf = floor(x), yf = floor(y);
     double wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3;
     catmull_weights(x - xf, wx0, wx1, wx2, wx3);
     catmull_weights(y - yf, wy0, wy1, wy2, wy3);
-    return bicubic_taps(src, rows, cols, (int)xf, (int)yf, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
+    return bicubic_taps(src, rows, cols, ld, (int)xf, (int)yf, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
 }
 
 // align.rs:46-55
-__global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ src, int rows, int cols, double dy, double dx,
-                                                    float *__restrict__ out) {
+__global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ src, int rows, int cols, int ld, double dy,
+                                                    double dx, float *__restrict__ out) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= cols) return;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ sr
     const double sx = (double)x + dx;
     float r = 0.0f;
     if (!(sy < -0.5 || sy > (double)rows - 0.5 || sx < -0.5 || sx > (double)cols - 0.5))
-        r = bicubic_sample(src, rows, cols, sy, sx);
+        r = bicubic_sample(src, rows, cols, ld, sy, sx);
     out[(size_t)y * cols + x] = r;
 }
 
@@ -92,24 +92,26 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
     const double sy = c * xf + d * yf + ty;
     float r = 0.0f;
     if (sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1))
-        r = bicubic_sample(src, src_rows, src_cols, sy, sx);
+        r = bicubic_sample(src, src_rows, src_cols, src_cols, sy, sx);
     out[(size_t)y * out_cols + x] = r;
 }
 
 }  // namespace
 
-int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, double dy, double dx, float *out) {
+// src is a rows x cols window with row stride src_ld (>= cols); out is contiguous rows x cols
+int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, int64_t src_ld, double dy, double dx, float *out) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     if (fabs(dy) < 1e-12 && fabs(dx) < 1e-12) {  // align.rs:37-39: image.clone()
         if (src != out)
-            AB_HIP(ctx, hipMemcpyAsync(out, src, (size_t)rows * cols * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            AB_HIP(ctx, hipMemcpy2DAsync(out, cols * sizeof(float), src, src_ld * sizeof(float), cols * sizeof(float), rows,
+                                         hipMemcpyDeviceToDevice, ctx->stream));
         return AB_OK;
     }
     AB_CHECK(ctx, src != out, "shift_image_subpixel cannot run in place");
-    AB_CHECK(ctx, rows <= 65535 && rows * cols < (int64_t(1) << 31),
+    AB_CHECK(ctx, rows <= 65535 && rows * src_ld < (int64_t(1) << 31),
              "image of %lld x %lld needs a tiled launch (not in this build)", (long long)rows, (long long)cols);
     const dim3 grid((unsigned)((cols + 255) / 256), (unsigned)rows), block(256);
-    hipLaunchKernelGGL(shift_kernel, grid, block, 0, ctx->stream, src, (int)rows, (int)cols, dy, dx, out);
+    hipLaunchKernelGGL(shift_kernel, grid, block, 0, ctx->stream, src, (int)rows, (int)cols, (int)src_ld, dy, dx, out);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -138,7 +140,7 @@ int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, double 
     StagedOut so;
     int rc = ab_stage_out_begin(ctx, out, &so);
     if (rc == AB_OK) {
-        rc = ab_shift_device(ctx, in.dptr, in.rows, in.cols, dy, dx, so.dptr);
+        rc = ab_shift_device(ctx, in.dptr, in.rows, in.cols, in.cols, dy, dx, so.dptr);
         if (rc == AB_OK)
             rc = ab_stage_out_finish(ctx, &so);
         else

@@ -1,10 +1,27 @@
 // stack_images driver (core/stacking/combine.rs:94-193): crop to the minimum dims, register
-// frames 1..n-1 on frame 0, then per-pixel kappa-sigma combine.
+// frames 1..n-1 on frame 0 by phase correlation + bicubic sub-pixel shift, then per-pixel
+// kappa-sigma combine.  Everything stays in HBM between the stages; the top-left crop
+// (combine.rs:107-113) is only a row stride.
 #include "ab_common.hpp"
+
+#include <cmath>
 
 int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
                     const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev,
                     uint64_t *out_rejected, bool median_only);
+int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, int64_t ref_cols, int64_t ref_ld, const float *tgt,
+                              int64_t tgt_rows, int64_t tgt_cols, int64_t tgt_ld, double *dx, double *dy, double *confidence);
+int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, int64_t src_ld, double dy, double dx, float *out);
+
+namespace {
+int32_t round_to_i32(double v) {  // `result.offset.0.round() as i32` (combine.rs:135-136): saturating, NaN -> 0
+    const double r = std::round(v);
+    if (std::isnan(r)) return 0;
+    if (r >= 2147483647.0) return INT32_MAX;
+    if (r <= -2147483648.0) return INT32_MIN;
+    return (int32_t)r;
+}
+}  // namespace
 
 extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
                                ab_plane_mut *out, int32_t *offsets_dy_dx, uint64_t *out_rejected) {
@@ -18,12 +35,61 @@ extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, co
     }
     AB_CHECK(ctx, out->rows == min_rows && out->cols == min_cols, "output must be %lldx%lld (minimum frame dims)",
              (long long)min_rows, (long long)min_cols);
-    if (cfg->align && n > 1)
-        return ab_set_error(ctx, AB_ERR_UNSUPPORTED,
-                            "stack_images(align=true): phase-correlation registration is not in this build yet; "
-                            "register with ab_shift_image_subpixel / ab_warp_image and stack with align=false");
     if (offsets_dy_dx)
         for (size_t i = 0; i < 2 * n; ++i) offsets_dy_dx[i] = 0;  // combine.rs:121,140
-    // the top-left crop (combine.rs:107-113) is the row stride handed to the kernel
-    return ab_stack_sigma_clip(ctx, planes, n, cfg, out, out_rejected);
+    if (!cfg->align || n == 1) return ab_stack_sigma_clip(ctx, planes, n, cfg, out, out_rejected);
+
+    // ---- align == true: PhaseCorrelation against frame 0 (combine.rs:123-138, align.rs:92-106) ----
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<StagedPlane> st(n);
+    std::vector<const float *> dp(n);
+    std::vector<int64_t> ld(n);
+    std::vector<void *> shifted(n, nullptr);
+    int rc = AB_OK;
+    size_t staged = 0;
+    for (; staged < n; ++staged) {
+        rc = ab_stage_in(ctx, &planes[staged], &st[staged]);
+        if (rc != AB_OK) break;
+        dp[staged] = st[staged].dptr;
+        ld[staged] = st[staged].cols;
+    }
+    const size_t plane_bytes = (size_t)min_rows * (size_t)min_cols * sizeof(float);
+    for (size_t i = 1; rc == AB_OK && i < n; ++i) {
+        double dx = 0.0, dy = 0.0, conf = 0.0;
+        rc = ab_phase_correlate_device(ctx, dp[0], min_rows, min_cols, ld[0], dp[i], min_rows, min_cols, ld[i], &dx, &dy, &conf);
+        if (rc != AB_OK) break;
+        if (offsets_dy_dx) {
+            offsets_dy_dx[2 * i] = round_to_i32(dy);
+            offsets_dy_dx[2 * i + 1] = round_to_i32(dx);
+        }
+        if (std::fabs(dy) < 1e-12 && std::fabs(dx) < 1e-12) continue;  // align.rs:37-39: clone -> read the frame in place
+        hipError_t e = hipMalloc(&shifted[i], plane_bytes);
+        if (e != hipSuccess) {
+            rc = ab_set_error(ctx, AB_ERR_HIP, "hipMalloc(%zu) for aligned frame %zu: %s", plane_bytes, i, hipGetErrorString(e));
+            break;
+        }
+        rc = ab_shift_device(ctx, dp[i], min_rows, min_cols, ld[i], dy, dx, (float *)shifted[i]);
+        dp[i] = (const float *)shifted[i];
+        ld[i] = min_cols;
+    }
+    StagedOut so;
+    bool so_open = false;
+    if (rc == AB_OK) {
+        rc = ab_stage_out_begin(ctx, out, &so);
+        so_open = (rc == AB_OK);
+    }
+    uint64_t rejected = 0;
+    if (rc == AB_OK)
+        rc = ab_stack_device(ctx, dp.data(), ld.data(), n, min_rows, min_cols, cfg, so.dptr, nullptr, nullptr, &rejected, false);
+    if (rc == AB_OK) {
+        rc = ab_stage_out_finish(ctx, &so);
+        so_open = false;
+    }
+    if (so_open) ab_stage_out_abort(ctx, &so);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (size_t i = 0; i < n; ++i)
+        if (shifted[i]) (void)hipFree(shifted[i]);
+    for (size_t i = 0; i < staged; ++i) ab_stage_release(ctx, &st[i]);
+    if (rc == AB_OK && out_rejected) *out_rejected = rejected;
+    return rc;
 }

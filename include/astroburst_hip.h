@@ -126,6 +126,19 @@ AB_API int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, 
  * OUTPUT (x,y) to SOURCE (sx,sy) (affine.rs:74-80); 0.0 outside 0<=sx<cols-1, 0<=sy<rows-1. */
 AB_API int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out);
 
+/* ---- a8  core/alignment/phase_correlation.rs ------------------------------------------------- */
+typedef struct { double dx, dy, confidence; } ab_phase_correlation_result; /* PhaseCorrelationResult, :15-20 */
+/* phase_correlate(reference, target) (phase_correlation.rs:22-89): crops both to the common dims,
+ * returns (0, 0, 0) for constant / nearly empty images, correlates directly up to 512 x 512 and
+ * coarse (area-averaged 512 x 512) + fine (centred 512 x 512 crop) above.  The FFT arithmetic is
+ * ours (the reference uses rustfft); the reference's own tests pin the shift to +-1 px. */
+AB_API int ab_phase_correlate(ab_ctx *ctx, const ab_plane *reference, const ab_plane *target,
+                              ab_phase_correlation_result *out);
+/* correlate_single (phase_correlation.rs:105-141) for two equal planes of at most 512 x 512;
+ * surface_host (nullable) receives the fft_rows x fft_cols correlation surface (parity tests) */
+AB_API int ab_correlate_single(ab_ctx *ctx, const ab_plane *a, const ab_plane *b, ab_phase_correlation_result *out,
+                               double *surface_host);
+
 /* ---- a9  core/imaging/stats.rs ------------------------------------------------------------- */
 typedef struct { /* ImageStats, types/image.rs:2-10 */
     double min, max, median, mad, sigma, mean;

@@ -134,6 +134,21 @@ void orc_calibrate_image(const float *raw, const float *bias, const float *dark,
                          size_t n, float *out);                                        /* calibration.rs:47-82 */
 void orc_median_combine(const float *const *planes, size_t n_frames, size_t npix, float *out); /* :84-125 */
 
+/* ---- core/alignment/phase_correlation.rs, downsample.rs (orc_phasecorr.c) ------------------ */
+void orc_hann_periodic(size_t n, double *w);                                           /* window.rs:3-18 */
+void orc_fft_twiddles(size_t n, double *tw_interleaved);            /* exp(-2 pi i k/n), k < n/2 */
+void orc_fft2d(double *buf_interleaved, size_t rows, size_t cols, int inverse);        /* fft.rs:136-167 */
+void orc_area_downsample(const float *src, size_t in_rows, size_t in_cols, size_t out_rows, size_t out_cols,
+                         float *out);                                                  /* downsample.rs:6-46 */
+void orc_phase_correlate(const float *reference, size_t ref_rows, size_t ref_cols, const float *target,
+                         size_t tgt_rows, size_t tgt_cols, double *dx, double *dy, double *confidence); /* :22-89 */
+void orc_correlate_single(const float *a, const float *b, size_t rows, size_t cols, double *dx, double *dy,
+                          double *conf, double *surface);                              /* :105-141 */
+/* combine.rs:94-193 with align == true */
+int orc_stack_images_align(const float *const *planes, const int64_t *rows, const int64_t *cols, size_t n_images,
+                           float sigma_low, float sigma_high, size_t max_iter, int order_mode, int threads, float *out,
+                           uint64_t *out_rejected, int32_t *offsets_dy_dx);
+
 /* utility */
 int orc_max_threads(void);
 

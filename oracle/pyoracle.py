@@ -134,6 +134,75 @@ def lib():
     return L
 
 
+# ---- phase correlation (orc_phasecorr.c) ---------------------------------------------------------------
+def _pc_protos():
+    L = lib()
+    if getattr(L, "_pc_ready", False):
+        return L
+    fp = C.POINTER(C.c_float)
+    dp = C.POINTER(C.c_double)
+    L.orc_phase_correlate.argtypes = [fp, C.c_size_t, C.c_size_t, fp, C.c_size_t, C.c_size_t, dp, dp, dp]
+    L.orc_correlate_single.argtypes = [fp, fp, C.c_size_t, C.c_size_t, dp, dp, dp, dp]
+    L.orc_area_downsample.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, fp]
+    L.orc_fft2d.argtypes = [dp, C.c_size_t, C.c_size_t, C.c_int]
+    L.orc_stack_images_align.restype = C.c_int
+    L.orc_stack_images_align.argtypes = [C.POINTER(fp), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_size_t,
+                                         C.c_float, C.c_float, C.c_size_t, C.c_int, C.c_int, fp,
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+    L._pc_ready = True
+    return L
+
+
+def phase_correlate(reference, target):
+    r, t = _f32(reference), _f32(target)
+    dx, dy, cf = C.c_double(), C.c_double(), C.c_double()
+    _pc_protos().orc_phase_correlate(_fp(r), r.shape[0], r.shape[1], _fp(t), t.shape[0], t.shape[1], C.byref(dx),
+                                     C.byref(dy), C.byref(cf))
+    return dx.value, dy.value, cf.value
+
+
+def correlate_single(a, b, want_surface=False):
+    a, b = _f32(a), _f32(b)
+    fr = 1 << max(0, (a.shape[0] - 1).bit_length())
+    fc = 1 << max(0, (a.shape[1] - 1).bit_length())
+    surf = np.zeros((fr, fc), np.float64)
+    dx, dy, cf = C.c_double(), C.c_double(), C.c_double()
+    _pc_protos().orc_correlate_single(_fp(a), _fp(b), a.shape[0], a.shape[1], C.byref(dx), C.byref(dy), C.byref(cf),
+                                      surf.ctypes.data_as(C.POINTER(C.c_double)))
+    return (dx.value, dy.value, cf.value, surf) if want_surface else (dx.value, dy.value, cf.value)
+
+
+def area_downsample(image, out_rows, out_cols) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros((out_rows, out_cols), np.float32)
+    _pc_protos().orc_area_downsample(_fp(im), im.shape[0], im.shape[1], out_rows, out_cols, _fp(out))
+    return out
+
+
+def fft2d(buf, inverse=False) -> np.ndarray:
+    z = np.ascontiguousarray(buf, dtype=np.complex128).copy()
+    _pc_protos().orc_fft2d(z.view(np.float64).ctypes.data_as(C.POINTER(C.c_double)), z.shape[0], z.shape[1],
+                           1 if inverse else 0)
+    return z
+
+
+def stack_images_align(images, sigma_low=3.0, sigma_high=3.0, max_iterations=5, order=ORDER_ASCENDING, threads=0):
+    """combine.rs:94-193 with align=true.  Returns (image, rejected_pixels, offsets[(dy, dx)])."""
+    imgs = [_f32(im) for im in images]
+    n = len(imgs)
+    if n == 0:
+        raise ValueError("No images to stack")
+    rows = (C.c_int64 * n)(*[im.shape[0] for im in imgs])
+    cols = (C.c_int64 * n)(*[im.shape[1] for im in imgs])
+    ptrs = (C.POINTER(C.c_float) * n)(*[_fp(im) for im in imgs])
+    out = np.zeros((min(im.shape[0] for im in imgs), min(im.shape[1] for im in imgs)), np.float32)
+    rej = C.c_uint64(0)
+    offs = (C.c_int32 * (2 * n))()
+    _pc_protos().orc_stack_images_align(ptrs, rows, cols, n, sigma_low, sigma_high, max_iterations, order, threads,
+                                        _fp(out), C.byref(rej), offs)
+    return out, int(rej.value), [(int(offs[2 * i]), int(offs[2 * i + 1])) for i in range(n)]
+
+
 # ---- colour / tone / calibration maps (orc_color.c) ------------------------------------------------
 def apply_scnr(r, g, b, method="average", amount=1.0, preserve_luminance=False):
     """returns new (r, g, b) after apply_scnr_inplace (scnr.rs:18-53)"""
