@@ -149,6 +149,34 @@ int orc_stack_images_align(const float *const *planes, const int64_t *rows, cons
                            float sigma_low, float sigma_high, size_t max_iter, int order_mode, int threads, float *out,
                            uint64_t *out_rejected, int32_t *offsets_dy_dx);
 
+/* ---- core/analysis/star_detection.rs, core/alignment/affine.rs (orc_detect.c, orc_affine.c) ---- */
+typedef struct { /* DetectedStar, star_detection.rs:10-20 (+ discovery order for stable sorting) */
+    double x, y, flux, fwhm, eccentricity, peak, snr;
+    uint64_t npix, order;
+} orc_star;
+void orc_estimate_background(const float *image, size_t rows, size_t cols, size_t tile_size, double *out_median,
+                             double *out_sigma);                                       /* :32-84 */
+size_t orc_detect_stars(const float *image, size_t rows, size_t cols, double sigma_threshold, orc_star *out,
+                        size_t cap, size_t *total, double *bg_median, double *bg_sigma); /* :86-258 */
+int orc_normalize_for_detection(const float *image, size_t len, float *out);           /* affine.rs:24-53 */
+
+typedef struct { /* AffineAlignResult, affine.rs:82-89; method 0 affine, 1 rigid, 2 phase_correlation, 3 identity */
+    double t[6]; /* a, b, tx, c, d, ty */
+    uint64_t matched_stars, inliers;
+    double residual_px;
+    int32_t method;
+} orc_affine_result;
+/* align_channel_affine (affine.rs:129-212).  num_threads pins rayon::current_num_threads()
+ * (RANSAC chunking and seeds depend on it, :410-416); vote ties are broken by (ref idx, tgt idx)
+ * ascending (the reference iterates a HashMap: unspecified). */
+void orc_align_channel_affine(const float *reference, const float *target, size_t rows, size_t cols, int num_threads,
+                              orc_affine_result *out);
+/* the star-list half of it (triangles -> votes -> RANSAC -> sanity), on given centroids (x, y pairs) */
+int orc_affine_from_stars(const double *ref_xy, size_t n_ref, const double *tgt_xy, size_t n_tgt, size_t rows, size_t cols,
+                          int num_threads, orc_affine_result *out);   /* returns 0 if it fell through to phase correlation */
+int orc_fit_rigid(const double *matches, size_t n, double t[6]);                       /* affine.rs:597-642 */
+int orc_fit_affine(const double *matches, size_t n, double t[6]);                      /* affine.rs:519-536 */
+
 /* utility */
 int orc_max_threads(void);
 

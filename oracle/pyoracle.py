@@ -203,6 +203,127 @@ def stack_images_align(images, sigma_low=3.0, sigma_high=3.0, max_iterations=5, 
     return out, int(rej.value), [(int(offs[2 * i]), int(offs[2 * i + 1])) for i in range(n)]
 
 
+# ---- star detection / affine registration (orc_detect.c, orc_affine.c) -----------------------------------
+class _Star(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("flux", C.c_double), ("fwhm", C.c_double),
+                ("eccentricity", C.c_double), ("peak", C.c_double), ("snr", C.c_double), ("npix", C.c_uint64),
+                ("order", C.c_uint64)]
+
+
+class _Affine(C.Structure):
+    _fields_ = [("t", C.c_double * 6), ("matched_stars", C.c_uint64), ("inliers", C.c_uint64),
+                ("residual_px", C.c_double), ("method", C.c_int32)]
+
+
+@dataclass
+class DetectedStar:  # star_detection.rs:10-20
+    x: float
+    y: float
+    flux: float
+    fwhm: float
+    eccentricity: float
+    peak: float
+    npix: int
+    snr: float
+
+
+@dataclass
+class AffineAlignResult:  # affine.rs:82-89
+    transform: tuple
+    matched_stars: int
+    inliers: int
+    residual_px: float
+    method: str
+
+
+AFFINE_METHODS = ("affine", "rigid", "phase_correlation", "identity")
+
+
+def _det_protos():
+    L = lib()
+    if getattr(L, "_det_ready", False):
+        return L
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    L.orc_estimate_background.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_size_t, dp, dp]
+    L.orc_detect_stars.restype = C.c_size_t
+    L.orc_detect_stars.argtypes = [fp, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(_Star), C.c_size_t,
+                                   C.POINTER(C.c_size_t), dp, dp]
+    L.orc_normalize_for_detection.restype = C.c_int
+    L.orc_normalize_for_detection.argtypes = [fp, C.c_size_t, fp]
+    L.orc_align_channel_affine.argtypes = [fp, fp, C.c_size_t, C.c_size_t, C.c_int, C.POINTER(_Affine)]
+    L.orc_affine_from_stars.restype = C.c_int
+    L.orc_affine_from_stars.argtypes = [dp, C.c_size_t, dp, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int,
+                                        C.POINTER(_Affine)]
+    L.orc_fit_rigid.restype = C.c_int
+    L.orc_fit_rigid.argtypes = [dp, C.c_size_t, dp]
+    L.orc_fit_affine.restype = C.c_int
+    L.orc_fit_affine.argtypes = [dp, C.c_size_t, dp]
+    L._det_ready = True
+    return L
+
+
+def estimate_background(image, tile_size):
+    im = _f32(image)
+    m, s = C.c_double(), C.c_double()
+    _det_protos().orc_estimate_background(_fp(im), im.shape[0], im.shape[1], tile_size, C.byref(m), C.byref(s))
+    return m.value, s.value
+
+
+def detect_stars(image, sigma_threshold, max_stars=100000):
+    """detect_stars (star_detection.rs:86-258) -> (stars, background_median, background_sigma)"""
+    im = _f32(image)
+    buf = (_Star * max_stars)()
+    tot = C.c_size_t(0)
+    m, s = C.c_double(), C.c_double()
+    n = _det_protos().orc_detect_stars(_fp(im), im.shape[0], im.shape[1], sigma_threshold, buf, max_stars,
+                                       C.byref(tot), C.byref(m), C.byref(s))
+    stars = [DetectedStar(b.x, b.y, b.flux, b.fwhm, b.eccentricity, b.peak, int(b.npix), b.snr) for b in buf[:n]]
+    return stars, m.value, s.value
+
+
+def normalize_for_detection(image) -> np.ndarray:
+    im = _f32(image)
+    out = np.zeros_like(im)
+    _det_protos().orc_normalize_for_detection(_fp(im), im.size, _fp(out))
+    return out
+
+
+def _affine_out(a: _Affine) -> AffineAlignResult:
+    return AffineAlignResult(tuple(a.t), int(a.matched_stars), int(a.inliers), a.residual_px, AFFINE_METHODS[a.method])
+
+
+def align_channel_affine(reference, target, num_threads=8) -> AffineAlignResult:
+    r, t = _f32(reference), _f32(target)
+    _pc_protos()
+    a = _Affine()
+    _det_protos().orc_align_channel_affine(_fp(r), _fp(t), r.shape[0], r.shape[1], num_threads, C.byref(a))
+    return _affine_out(a)
+
+
+def affine_from_stars(ref_xy, tgt_xy, rows, cols, num_threads=8):
+    r = np.ascontiguousarray(np.asarray(ref_xy, np.float64).reshape(-1, 2))
+    t = np.ascontiguousarray(np.asarray(tgt_xy, np.float64).reshape(-1, 2))
+    a = _Affine()
+    ok = _det_protos().orc_affine_from_stars(r.ctypes.data_as(C.POINTER(C.c_double)), r.shape[0],
+                                             t.ctypes.data_as(C.POINTER(C.c_double)), t.shape[0], rows, cols,
+                                             num_threads, C.byref(a))
+    return _affine_out(a) if ok else None
+
+
+def fit_rigid(matches):
+    m = np.ascontiguousarray(np.asarray(matches, np.float64).reshape(-1, 4))
+    t = (C.c_double * 6)()
+    ok = _det_protos().orc_fit_rigid(m.ctypes.data_as(C.POINTER(C.c_double)), m.shape[0], t)
+    return tuple(t) if ok else None
+
+
+def fit_affine(matches):
+    m = np.ascontiguousarray(np.asarray(matches, np.float64).reshape(-1, 4))
+    t = (C.c_double * 6)()
+    ok = _det_protos().orc_fit_affine(m.ctypes.data_as(C.POINTER(C.c_double)), m.shape[0], t)
+    return tuple(t) if ok else None
+
+
 # ---- colour / tone / calibration maps (orc_color.c) ------------------------------------------------
 def apply_scnr(r, g, b, method="average", amount=1.0, preserve_luminance=False):
     """returns new (r, g, b) after apply_scnr_inplace (scnr.rs:18-53)"""
