@@ -49,6 +49,16 @@ class AutoStfConfigC(C.Structure):  # types/image.rs:52-65
     _fields_ = [("target_bg", C.c_double), ("shadow_k", C.c_double)]
 
 
+class DetectedStarC(C.Structure):  # star_detection.rs:10-20
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("flux", C.c_double), ("fwhm", C.c_double),
+                ("eccentricity", C.c_double), ("peak", C.c_double), ("snr", C.c_double), ("npix", C.c_uint64)]
+
+
+class AffineAlignResultC(C.Structure):  # affine.rs:82-89
+    _fields_ = [("transform", C.c_double * 6), ("matched_stars", C.c_uint64), ("inliers", C.c_uint64),
+                ("residual_px", C.c_double), ("method", C.c_int32)]
+
+
 class PhaseCorrelationResultC(C.Structure):  # phase_correlation.rs:15-20
     _fields_ = [("dx", C.c_double), ("dy", C.c_double), ("confidence", C.c_double)]
 
@@ -131,6 +141,13 @@ def lib() -> C.CDLL:
     L.ab_apply_stf_u8.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32]
     L.ab_apply_stf_f32.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), pp]
     L.ab_bench_copy.argtypes = [vp, vp, vp, C.c_size_t]
+    L.ab_estimate_background.argtypes = [vp, pp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ab_detect_stars.argtypes = [vp, pp, C.c_double, C.POINTER(DetectedStarC), C.c_size_t, C.POINTER(C.c_size_t),
+                                  C.POINTER(C.c_size_t), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ab_normalize_for_detection.argtypes = [vp, pp, pp]
+    L.ab_align_channel_affine.argtypes = [vp, pp, pp, C.c_int, C.POINTER(AffineAlignResultC)]
+    L.ab_affine_from_stars.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.POINTER(C.c_double), C.c_size_t, C.c_int64,
+                                       C.c_int64, C.c_int, C.POINTER(AffineAlignResultC), C.POINTER(C.c_int)]
     L.ab_phase_correlate.argtypes = [vp, pp, pp, C.POINTER(PhaseCorrelationResultC)]
     L.ab_correlate_single.argtypes = [vp, pp, pp, C.POINTER(PhaseCorrelationResultC), vp]
     L.ab_apply_scnr_inplace.argtypes = [vp, pp, pp, pp, C.POINTER(ScnrConfigC)]

@@ -48,6 +48,30 @@ class StackResult:  # types/stacking.rs:22-28
     offsets: list
 
 
+@dataclass
+class DetectedStar:  # star_detection.rs:10-20
+    x: float
+    y: float
+    flux: float
+    fwhm: float
+    eccentricity: float
+    peak: float
+    npix: int
+    snr: float
+
+
+@dataclass
+class AffineAlignResult:  # affine.rs:82-89
+    transform: tuple
+    matched_stars: int
+    inliers: int
+    residual_px: float
+    method: str
+
+
+AFFINE_METHODS = ("affine", "rigid", "phase_correlation", "identity")
+
+
 def _is_torch(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
@@ -300,6 +324,53 @@ class Context:
         s = self._stats_in(stats)
         self._check(self._L.ab_apply_stf_f32(self._h, C.byref(pi), C.byref(p), C.byref(s), C.byref(po)))
         return out
+
+    # ---- core/analysis/star_detection.rs, core/alignment/affine.rs ------------------------------------
+    def estimate_background(self, image, tile_size: int):
+        keep = []
+        pi = self._plane(image, keep)
+        m, s = C.c_double(), C.c_double()
+        self._check(self._L.ab_estimate_background(self._h, C.byref(pi), tile_size, C.byref(m), C.byref(s)))
+        return m.value, s.value
+
+    def detect_stars(self, image, sigma_threshold: float, max_stars: int = 100000):
+        """detect_stars(image, sigma) -> (stars, background_median, background_sigma) (star_detection.rs:86-258)"""
+        keep = []
+        pi = self._plane(image, keep)
+        buf = (_lib.DetectedStarC * max_stars)()
+        n, tot = C.c_size_t(0), C.c_size_t(0)
+        m, s = C.c_double(), C.c_double()
+        self._check(self._L.ab_detect_stars(self._h, C.byref(pi), sigma_threshold, buf, max_stars, C.byref(n),
+                                            C.byref(tot), C.byref(m), C.byref(s)))
+        stars = [DetectedStar(b.x, b.y, b.flux, b.fwhm, b.eccentricity, b.peak, int(b.npix), b.snr)
+                 for b in buf[:n.value]]
+        return stars, m.value, s.value
+
+    def normalize_for_detection(self, image, out=None):
+        return self._unary(self._L.ab_normalize_for_detection, image, out)
+
+    def align_channel_affine(self, reference, target, num_threads: int = 8) -> "AffineAlignResult":
+        """align_channel_affine(reference, target) (affine.rs:129-212)"""
+        keep = []
+        pr, pt = self._plane(reference, keep), self._plane(target, keep)
+        res = _lib.AffineAlignResultC()
+        self._check(self._L.ab_align_channel_affine(self._h, C.byref(pr), C.byref(pt), num_threads, C.byref(res)))
+        return AffineAlignResult(tuple(res.transform), int(res.matched_stars), int(res.inliers), res.residual_px,
+                                 AFFINE_METHODS[res.method])
+
+    def affine_from_stars(self, ref_xy, tgt_xy, rows, cols, num_threads: int = 8):
+        r = np.ascontiguousarray(np.asarray(ref_xy, np.float64).reshape(-1, 2))
+        t = np.ascontiguousarray(np.asarray(tgt_xy, np.float64).reshape(-1, 2))
+        res, found = _lib.AffineAlignResultC(), C.c_int(0)
+        rc = self._L.ab_affine_from_stars(r.ctypes.data_as(C.POINTER(C.c_double)), r.shape[0],
+                                          t.ctypes.data_as(C.POINTER(C.c_double)), t.shape[0], rows, cols,
+                                          num_threads, C.byref(res), C.byref(found))
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "ab_affine_from_stars: bad arguments")
+        if not found.value:
+            return None
+        return AffineAlignResult(tuple(res.transform), int(res.matched_stars), int(res.inliers), res.residual_px,
+                                 AFFINE_METHODS[res.method])
 
     # ---- core/alignment/phase_correlation.rs ----------------------------------------------------------
     def phase_correlate(self, reference, target):

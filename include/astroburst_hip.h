@@ -139,6 +139,43 @@ AB_API int ab_phase_correlate(ab_ctx *ctx, const ab_plane *reference, const ab_p
 AB_API int ab_correlate_single(ab_ctx *ctx, const ab_plane *a, const ab_plane *b, ab_phase_correlation_result *out,
                                double *surface_host);
 
+/* ---- a7  core/analysis/star_detection.rs ------------------------------------------------------ */
+typedef struct { /* DetectedStar, star_detection.rs:10-20 */
+    double x, y, flux, fwhm, eccentricity, peak, snr;
+    uint64_t npix;
+} ab_detected_star;
+/* estimate_background (star_detection.rs:32-84): per-tile sigma-clipped median / sigma, then the
+ * [len/2] element of the sorted tile medians and sigmas; (0, 1) if no tile has 8 valid pixels */
+AB_API int ab_estimate_background(ab_ctx *ctx, const ab_plane *img, int64_t tile_size, double *out_median,
+                                  double *out_sigma);
+/* detect_stars(image, sigma) (star_detection.rs:86-258): threshold at median + sigma * bg_sigma,
+ * 8-connected components seeded from interior pixels, 3 <= npix <= 5000, flux-weighted moments,
+ * FWHM in [0.5, 30], sorted by flux (descending), deduplicated within 3 px.  Writes at most cap
+ * stars; *out_total (nullable) is the number found.  Segmentation (component set, npix, order)
+ * is exact; the f64 moments are summed in raster instead of BFS order (~1e-15 relative). */
+AB_API int ab_detect_stars(ab_ctx *ctx, const ab_plane *img, double sigma_threshold, ab_detected_star *out, size_t cap,
+                           size_t *out_count, size_t *out_total, double *bg_median, double *bg_sigma);
+
+/* ---- a6  core/alignment/affine.rs -------------------------------------------------------------- */
+typedef struct { /* AffineAlignResult, affine.rs:82-89 */
+    double transform[6]; /* AffineTransform a, b, tx, c, d, ty: output (x, y) -> source (affine.rs:55-80) */
+    uint64_t matched_stars, inliers;
+    double residual_px;
+    int32_t method; /* 0 affine, 1 rigid, 2 phase_correlation, 3 identity (AffineAlignMethod, :91-97) */
+} ab_affine_align_result;
+/* normalize_for_detection (affine.rs:24-53): clamp((v - p1) / (p99.9 - p1), 0, 1) on a <= 100 k subsample's percentiles */
+AB_API int ab_normalize_for_detection(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out);
+/* align_channel_affine(reference, target) (affine.rs:129-212): normalise, detect at 3.5 sigma, top 120
+ * stars, triangle voting, RANSAC affine then rigid (2000 draws, 3 px inliers), sanity limits, else
+ * phase correlation (confidence >= 1.5), else identity.  num_threads pins what the reference takes
+ * from rayon::current_num_threads() (the draws are partitioned and seeded per worker, :410-416);
+ * vote ties are broken by (ref, tgt) index (the reference iterates a HashMap). */
+AB_API int ab_align_channel_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane *target, int num_threads,
+                                   ab_affine_align_result *out);
+/* the star-list half (triangles -> votes -> RANSAC -> sanity) on given centroids; host only */
+AB_API int ab_affine_from_stars(const double *ref_xy, size_t n_ref, const double *tgt_xy, size_t n_tgt, int64_t rows,
+                                int64_t cols, int num_threads, ab_affine_align_result *out, int *found);
+
 /* ---- a9  core/imaging/stats.rs ------------------------------------------------------------- */
 typedef struct { /* ImageStats, types/image.rs:2-10 */
     double min, max, median, mad, sigma, mean;

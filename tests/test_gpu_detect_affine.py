@@ -1,0 +1,124 @@
+"""GPU parity: star detection / segmentation (star_detection.rs) and affine registration (affine.rs).
+
+Bar: the segmentation is integer work -- star count, order, npix and the tile background statistics are
+exact; centroids / fluxes / shape moments are f64 sums whose order differs from the reference's BFS
+order (1e-12 relative); the RANSAC geometry is the same host code on the same star lists, so the
+transform is compared at 1e-9."""
+import math
+
+import numpy as np
+import pytest
+
+from test_oracle_detect_cases import make_test_image
+
+pytestmark = pytest.mark.gpu
+
+
+def compare_stars(got, ref):
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert g.npix == r.npix
+        for f in ("x", "y", "flux", "fwhm", "peak", "snr"):
+            a, b = getattr(g, f), getattr(r, f)
+            assert abs(a - b) <= 1e-10 * max(1.0, abs(b)), (f, a, b)
+        assert abs(g.eccentricity - r.eccentricity) <= 1e-6
+
+
+def test_reference_cases(ctx):                                      # star_detection.rs:289-328
+    stars, med, sig = ctx.detect_stars(make_test_image(300, 300), 5.0)
+    assert len(stars) >= 3 and sig > 0.0 and stars[0].flux >= stars[1].flux
+    assert abs(stars[0].x - 150.0) < 2.0 and abs(stars[0].y - 200.0) < 2.0
+    assert ctx.detect_stars(np.full((100, 100), 50.0, np.float32), 5.0)[0] == []
+    med, sig = ctx.estimate_background(np.full((200, 200), 100.0, np.float32), 64)
+    assert abs(med - 100.0) < 1.0 and sig < 1.0
+    assert ctx.detect_stars(np.ones((2, 50), np.float32), 5.0) == ([], 0.0, 1.0)
+
+
+@pytest.mark.parametrize("shape,tile", [((300, 300), 37), ((200, 513), 64), ((1000, 700), 125), ((64, 64), 16), ((257, 300), 256)])
+def test_estimate_background_exact(ctx, oracle, shape, tile):
+    rng = np.random.default_rng(shape[0] + tile)
+    img = rng.normal(500, 20, shape).astype(np.float32)
+    img[rng.random(shape) < 0.01] *= 30
+    img[:10, :] = 0.0
+    img[20:23, 30:90] = np.nan
+    img[50:60, 50:60] = 1e-8
+    assert ctx.estimate_background(img, tile) == oracle.estimate_background(img, tile)
+
+
+@pytest.mark.parametrize("seed,sigma", [(1, 5.0), (2, 3.5), (3, 8.0)])
+def test_detect_stars_matches_oracle(ctx, oracle, seed, sigma):
+    from astroburst_amd import synth
+    rows, cols = 500, 640
+    y, x, flux = synth.star_catalog(rows, cols, 250, seed=seed)
+    img = synth.make_frame(rows, cols, seed, cat=(y, x, flux * 20.0), bad_patch_rate=1e-5).numpy()
+    img[:, 0] += 5000.0                                              # a bright border column: growth may enter the border,
+    img[0, 100:140] += 5000.0                                        # but border-only components are never seeded
+    got, gm, gs = ctx.detect_stars(img, sigma)
+    ref, rm, rs = oracle.detect_stars(img, sigma)
+    assert (gm, gs) == (rm, rs)
+    assert len(ref) > 20
+    compare_stars(got, ref)
+
+
+def test_detect_touching_blobs_and_size_limits(ctx, oracle):
+    img = np.full((200, 200), 100.0, np.float32) + np.random.default_rng(0).normal(0, 1, (200, 200)).astype(np.float32)
+    img[50:52, 50] += 500.0                                          # 2 px: below the 3 px minimum
+    img[80:160, 20:100] += 500.0                                     # 6400 px: above the 5000 px maximum
+    img[20, 20] += 500.0; img[21, 21] += 500.0; img[22, 20] += 500.0  # diagonal links: one 8-connected component
+    img[100:104, 150:154] += 800.0
+    img[104, 154] += 800.0                                           # corner-touching pixel joins the 4x4 block
+    got, _, _ = ctx.detect_stars(img, 5.0)
+    ref, _, _ = oracle.detect_stars(img, 5.0)
+    compare_stars(got, ref)
+    assert sorted(s.npix for s in got) == [3, 17]
+
+
+def test_normalize_for_detection(ctx, oracle):
+    rng = np.random.default_rng(2)
+    img = rng.normal(1000, 30, (300, 400)).astype(np.float32)
+    img[5, 5], img[6, 6] = np.nan, np.inf
+    assert np.array_equal(ctx.normalize_for_detection(img), oracle.normalize_for_detection(img), equal_nan=True)
+    small = np.arange(50, dtype=np.float32).reshape(5, 10)
+    assert np.array_equal(ctx.normalize_for_detection(small), small)
+
+
+def test_affine_from_stars_matches_oracle(ctx, oracle):
+    rng = np.random.default_rng(1)
+    ref = np.column_stack([rng.uniform(20, 1180, 90), rng.uniform(20, 980, 90)])
+    ang = math.radians(-0.8)
+    c, s = math.cos(ang), math.sin(ang)
+    tgt = np.column_stack([c * ref[:, 0] - s * ref[:, 1] - 21.0, s * ref[:, 0] + c * ref[:, 1] + 6.5]) + rng.normal(0, 0.1, ref.shape)
+    tgt = tgt[rng.permutation(90)][:70]                               # 20 stars missing in the target
+    for nt in (1, 4, 8, 13):
+        g = ctx.affine_from_stars(ref, tgt, 1000, 1200, num_threads=nt)
+        r = oracle.affine_from_stars(ref, tgt, 1000, 1200, num_threads=nt)
+        assert g is not None and r is not None
+        assert g.method == r.method and g.matched_stars == r.matched_stars and g.inliers == r.inliers
+        assert np.allclose(g.transform, r.transform, rtol=0, atol=1e-9) and abs(g.residual_px - r.residual_px) < 1e-9
+    assert ctx.affine_from_stars(ref[:3], tgt[:3], 1000, 1200) is None
+
+
+def test_align_channel_affine_end_to_end(ctx, oracle):
+    from astroburst_amd import synth
+    rows, cols = 600, 800
+    y, x, flux = synth.star_catalog(rows, cols, 400, seed=5)
+    cat = (y, x, flux * 30.0)
+    ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=0.0).numpy()
+    tgt = synth.make_frame(rows, cols, 1, cat=cat, shift=(3.0, -2.0), bad_patch_rate=0.0, cosmic_rate=0.0).numpy()
+    g = ctx.align_channel_affine(ref, tgt, num_threads=8)
+    r = oracle.align_channel_affine(ref, tgt, num_threads=8)
+    assert g.method == r.method and g.method in ("affine", "rigid")
+    assert g.matched_stars == r.matched_stars and g.inliers == r.inliers
+    assert np.allclose(g.transform, r.transform, rtol=0, atol=1e-8)
+    # and the estimated transform registers the frame: warp the target with it and compare star positions
+    assert abs(g.transform[2] + 2.0) < 0.3 and abs(g.transform[5] - 3.0) < 0.3
+
+
+def test_align_channel_affine_falls_back(ctx, oracle):
+    rng = np.random.default_rng(9)
+    from scipy.ndimage import gaussian_filter
+    base = gaussian_filter(rng.standard_normal((500, 500)), 3.0).astype(np.float32) * 100 + 1000   # no stars at all
+    ref, tgt = base[10:410, 10:410].copy(), base[14:414, 7:407].copy()
+    g, r = ctx.align_channel_affine(ref, tgt), oracle.align_channel_affine(ref, tgt)
+    assert g.method == r.method and g.method in ("phase_correlation", "identity")
+    assert g.transform == r.transform
