@@ -76,6 +76,15 @@ class LevelsParamsC(C.Structure):  # curves.rs:4-9
     _fields_ = [("black", C.c_double), ("gamma", C.c_double), ("white", C.c_double)]
 
 
+class BackgroundConfigC(C.Structure):  # background.rs:14-33
+    _fields_ = [("grid_size", C.c_size_t), ("poly_degree", C.c_size_t), ("sigma_clip", C.c_float),
+                ("iterations", C.c_size_t), ("mode", C.c_int)]
+
+
+class BackgroundInfoC(C.Structure):  # scalars of BackgroundResult, background.rs:35-42
+    _fields_ = [("sample_count", C.c_size_t), ("rms_residual", C.c_double), ("coeffs", C.c_double * 21)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into astroburst_amd/libastroburst_hip.so."""
     cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
@@ -160,6 +169,7 @@ def lib() -> C.CDLL:
     L.ab_scale.argtypes = [vp, pp, C.c_float, pp]
     L.ab_calibrate_image.argtypes = [vp, pp, pp, pp, pp, C.c_float, pp]
     L.ab_median_combine.argtypes = [vp, pp, C.c_size_t, pp]
+    L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift
         if fn.restype is C.c_int and name not in ("ab_last_error", "ab_version", "ab_ctx_get_stream"):

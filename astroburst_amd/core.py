@@ -41,6 +41,15 @@ class StfParams:  # types/image.rs:36-50
 
 
 @dataclass
+class BackgroundResult:  # background.rs:35-42
+    model: object
+    corrected: object
+    sample_count: int
+    rms_residual: float
+    coeffs: np.ndarray
+
+
+@dataclass
 class StackResult:  # types/stacking.rs:22-28
     image: object
     frame_count: int
@@ -495,6 +504,29 @@ class Context:
         po = self._out_plane(out, keep, rows, cols)
         self._check(self._L.ab_median_combine(self._h, planes, len(frames), C.byref(po)))
         return out
+
+    # ---- a12 background extraction ------------------------------------------------------------------
+    def extract_background(self, image, grid_size=8, poly_degree=3, sigma_clip=2.5, iterations=3, mode="subtract",
+                           want_model=True):
+        """extract_background (background.rs:55-116) -> BackgroundResult(model, corrected, sample_count, rms_residual).
+
+        mode: "subtract" | "divide" (BackgroundMode).  Raises AstroBurstError with the reference's message when the
+        image is too small for the grid, too few samples survive, or the fit is singular."""
+        keep = []
+        pi = self._plane(image, keep)
+        rows, cols = pi.rows, pi.cols
+        corrected = self._new_like(image, rows, cols)
+        pc = self._out_plane(corrected, keep, rows, cols)
+        model, pm = None, None
+        if want_model:
+            model = self._new_like(image, rows, cols)
+            pm = C.byref(self._out_plane(model, keep, rows, cols))
+        cfg = _lib.BackgroundConfigC(grid_size, poly_degree, sigma_clip, iterations,
+                                     {"subtract": 0, "divide": 1}[mode] if isinstance(mode, str) else int(mode))
+        info = _lib.BackgroundInfoC()
+        self._check(self._L.ab_extract_background(self._h, C.byref(pi), C.byref(cfg), pm, C.byref(pc), C.byref(info)))
+        return BackgroundResult(model, corrected, int(info.sample_count), float(info.rms_residual),
+                                np.array(info.coeffs[:], dtype=np.float64))
 
     # ---- bench support -----------------------------------------------------------------------------
     def bench_copy(self, src, dst):

@@ -82,13 +82,34 @@ std::vector<Match> match_triangles(const std::vector<Pt> &rs, const std::vector<
                                    const std::vector<Tri> &tt) {  // :320-384
     const size_t nr = rs.size(), nt = ts.size();
     std::vector<uint32_t> votes(nr * nt, 0);
-    for (const Tri &a : rt)
-        for (const Tri &b : tt) {
+    // The reference compares every ref triangle with every tgt triangle (up to 34 220^2 pairs).  Votes are
+    // integer counts, so the visiting order is free: sort the tgt triangles by ratio_mid and only visit the
+    // window that can pass `|d_mid| <= 0.02` (a hair wider than the tolerance; the exact test decides).
+    std::vector<size_t> order(tt.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tt[a].ratio_mid < tt[b].ratio_mid; });
+    std::vector<double> mids(tt.size());
+    std::vector<std::array<size_t, 3>> tverts(tt.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        mids[i] = tt[order[i]].ratio_mid;
+        tverts[i] = sort_triangle_vertices(ts, tt[order[i]].idx);
+    }
+    for (const Tri &a : rt) {
+        const double lo = a.ratio_mid - kTriangleTolerance * 1.000001 - 1e-12, hi = a.ratio_mid + kTriangleTolerance * 1.000001 + 1e-12;
+        const size_t i0 = std::lower_bound(mids.begin(), mids.end(), lo) - mids.begin();
+        bool have_ra = false;
+        std::array<size_t, 3> ra{};
+        for (size_t i = i0; i < mids.size() && mids[i] <= hi; ++i) {
+            const Tri &b = tt[order[i]];
             if (std::fabs(a.ratio_mid - b.ratio_mid) > kTriangleTolerance || std::fabs(a.ratio_long - b.ratio_long) > kTriangleTolerance)
                 continue;
-            const auto ra = sort_triangle_vertices(rs, a.idx), tb = sort_triangle_vertices(ts, b.idx);
-            for (int p = 0; p < 3; ++p) votes[ra[p] * nt + tb[p]] += 1;
+            if (!have_ra) {
+                ra = sort_triangle_vertices(rs, a.idx);
+                have_ra = true;
+            }
+            for (int p = 0; p < 3; ++p) votes[ra[p] * nt + tverts[i][p]] += 1;
         }
+    }
     struct Pair {
         size_t ri, ti;
         uint32_t v;

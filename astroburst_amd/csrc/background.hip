@@ -1,0 +1,444 @@
+// Background extraction (gradient removal) on gfx950.
+//
+// Replaces core/imaging/background.rs: extract_background (:55-116), auto_sample_grid (:118-210),
+// fit_polynomial_surface (:251-290), evaluate_polynomial_surface (:307-341), apply_correction
+// (:343-383), compute_rms_residual (:385-415), solve_linear_system (:417-459).
+//
+// Device work (all HBM-bound passes over the plane):
+//   * global median / MAD of the positive finite pixels: whole-image 11/11/10-bit radix select on
+//     the f32 bit patterns (exact order statistics, even counts averaged in f32 as median_f32_mut);
+//   * one workgroup per grid cell takes the median of the cell's inner 50 % window
+//     (block_select.hpp);
+//   * the fitted surface is evaluated per pixel in f64 with the reference's cumulative power
+//     tables and term order, then the correction (subtract / divide, re-centred on the model's
+//     median) is applied in f32.
+// Host work: the <= 32 x 32 samples' kappa-sigma rejection and the <= 21-term least-squares fit
+// (Gaussian elimination with partial pivoting, f64) -- scalar maths the reference also runs serially.
+#include "ab_common.hpp"
+#include "block_select.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxPolyTerms = 21;
+constexpr float kMadToSigmaF32 = (float)1.4826;
+
+// ---- whole-image radix select over {finite, > min_valid} -------------------------------------------
+struct ImgSel {
+    const float *data;
+    int64_t n;
+    float min_valid;
+    int use_dev;  // key = bits(|v - center|) (f32) instead of bits(v)
+    float center;
+    uint32_t prefix_mask, prefix_val;
+    int shift, nbits;
+    unsigned int *hist;
+};
+
+__global__ __launch_bounds__(kBlock) void img_select_hist_kernel(const ImgSel a) {
+    __shared__ unsigned int lds[2048];
+    const uint32_t nb = 1u << a.nbits;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBlock) lds[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        const float v = a.data[i];
+        if (__builtin_isfinite(v) && v > a.min_valid) {
+            const float k = a.use_dev ? fabsf(v - a.center) : v;
+            const uint32_t key = __float_as_uint(k);
+            if ((key & a.prefix_mask) == a.prefix_val) atomicAdd(&lds[(key >> a.shift) & (nb - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += kBlock)
+        if (lds[i]) atomicAdd(&a.hist[i], lds[i]);
+}
+
+int img_select(ab_ctx *ctx, const float *data, int64_t n, float min_valid, int use_dev, float center, uint64_t rank,
+               unsigned int *dhist, float *out, uint64_t *count_out) {
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    uint32_t mask = 0, val = 0;
+    std::vector<unsigned int> h(2048);
+    const int grid = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8);
+    for (int p = 0; p < 3; ++p) {
+        const uint32_t nb = 1u << bits[p];
+        AB_HIP(ctx, hipMemsetAsync(dhist, 0, nb * sizeof(unsigned int), ctx->stream));
+        ImgSel a{data, n, min_valid, use_dev, center, mask, val, shifts[p], bits[p], dhist};
+        hipLaunchKernelGGL(img_select_hist_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+        AB_HIP(ctx, hipGetLastError());
+        AB_HIP(ctx, hipMemcpyAsync(h.data(), dhist, nb * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t cum = 0, tot = 0;
+        uint32_t bin = nb - 1;
+        bool found = false;
+        for (uint32_t i = 0; i < nb; ++i) {
+            if (!found && cum + h[i] > rank) {
+                bin = i;
+                found = true;
+            }
+            if (!found) cum += h[i];
+            tot += h[i];
+        }
+        if (p == 0 && count_out) *count_out = tot;
+        rank -= cum;
+        val |= bin << shifts[p];
+        mask |= (nb - 1) << shifts[p];
+    }
+    memcpy(out, &val, sizeof(float));
+    return AB_OK;
+}
+
+// median_f32_mut (math/median.rs:46-63) of {finite, > min_valid} (or of their |v - center|); 0 if none
+int img_median_f32(ab_ctx *ctx, const float *data, int64_t n, float min_valid, int use_dev, float center, unsigned int *dhist,
+                   float *out, uint64_t *count_out) {
+    uint64_t cnt = 0;
+    float probe;
+    AB_TRY(img_select(ctx, data, n, min_valid, use_dev, center, 0, dhist, &probe, &cnt));
+    if (count_out) *count_out = cnt;
+    if (cnt == 0) {
+        *out = 0.0f;
+        return AB_OK;
+    }
+    const uint64_t mid = cnt / 2;
+    float right, left;
+    AB_TRY(img_select(ctx, data, n, min_valid, use_dev, center, mid, dhist, &right, nullptr));
+    if (cnt % 2 == 0) {
+        AB_TRY(img_select(ctx, data, n, min_valid, use_dev, center, mid - 1, dhist, &left, nullptr));
+        *out = (left + right) / 2.0f;
+    } else {
+        *out = right;
+    }
+    return AB_OK;
+}
+
+// ---- grid-cell medians (background.rs:151-190) ---------------------------------------------------------
+struct CellOut {
+    float median;
+    unsigned int count;  // pixels that are finite and > 1e-7
+};
+
+__global__ __launch_bounds__(absel::kBlock) void cell_median_kernel(const float *__restrict__ img, int64_t ld, int grid,
+                                                                    int cell_h, int cell_w, int margin_h, int margin_w,
+                                                                    int inner_h, int inner_w, CellOut *__restrict__ out) {
+    __shared__ unsigned int hist[2048];
+    const int gy = blockIdx.x / grid, gx = blockIdx.x % grid;
+    absel::Window w;
+    w.img = img;
+    w.ld = ld;
+    w.y0 = gy * cell_h + margin_h;
+    w.x0 = gx * cell_w + margin_w;
+    w.y1 = w.y0 + inner_h;
+    w.x1 = w.x0 + inner_w;
+    w.min_valid = 1e-7f;
+    w.lo = -__builtin_inff();
+    w.hi = __builtin_inff();
+    const unsigned int n = absel::count(w, hist);
+    float med = 0.0f;
+    if (n > 0) med = absel::median_f32(w, 0, 0.0, 0.0f, n, hist);
+    if (threadIdx.x == 0) {
+        out[blockIdx.x].median = med;
+        out[blockIdx.x].count = n;
+    }
+}
+
+// ---- surface evaluation + correction (background.rs:307-383) ----------------------------------------------
+struct PolyArgs {
+    double coeffs[kMaxPolyTerms];
+    int degree;
+    int rows, cols;
+    double row_scale, col_scale;
+};
+
+__device__ __forceinline__ double eval_poly(const PolyArgs &p, const double *y_pows, const double *x_pows) {  // :230-249
+    double val = 0.0;
+    int idx = 0;
+    for (int total = 0; total <= p.degree; ++total)
+        for (int yp = total; yp >= 0; --yp) {
+            const int xp = total - yp;
+            val += p.coeffs[idx] * y_pows[yp] * x_pows[xp];
+            ++idx;
+        }
+    return val;
+}
+
+__global__ __launch_bounds__(kBlock) void poly_model_kernel(const PolyArgs p, float *__restrict__ model) {
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= p.cols) return;
+    double y_pows[7] = {1.0, 0, 0, 0, 0, 0, 0}, x_pows[7] = {1.0, 0, 0, 0, 0, 0, 0};
+    const double ny = (double)y / p.row_scale - 0.5, nx = (double)x / p.col_scale - 0.5;
+    const int lim = p.degree < 6 ? p.degree : 6;
+    for (int i = 1; i <= lim; ++i) {
+        y_pows[i] = y_pows[i - 1] * ny;
+        x_pows[i] = x_pows[i - 1] * nx;
+    }
+    model[(size_t)y * p.cols + x] = (float)eval_poly(p, y_pows, x_pows);
+}
+
+__global__ __launch_bounds__(kBlock) void bg_apply_kernel(const float *__restrict__ img, const float *__restrict__ model, int64_t n,
+                                                          int mode, float model_median, float *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float v = img[i], bg = model[i];
+        float r;
+        if (mode == 0) {
+            r = v - bg + model_median;                                    // :367-369
+        } else {
+            r = fabsf(bg) > 1e-10f ? (v / bg) * model_median : v;        // :370-376
+        }
+        out[i] = r;
+    }
+}
+
+// ---- host scalar maths ----------------------------------------------------------------------------------------
+double powi(double a, int b) {  // f64::powi = compiler-rt __powidf2 (square-and-multiply, LSB first)
+    double r = 1.0;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return r;
+}
+
+int poly_basis_into(double y, double x, int degree, double *out) {  // :217-228
+    int idx = 0;
+    for (int total = 0; total <= degree; ++total)
+        for (int yp = total; yp >= 0; --yp) out[idx++] = powi(y, yp) * powi(x, total - yp);
+    return idx;
+}
+
+bool solve_linear_system(std::vector<double> &a, std::vector<double> &b, int n) {  // :417-459
+    for (int col = 0; col < n; ++col) {
+        int max_row = col;
+        double max_val = std::fabs(a[col * n + col]);
+        for (int row = col + 1; row < n; ++row) {
+            const double v = std::fabs(a[row * n + col]);
+            if (v > max_val) {
+                max_val = v;
+                max_row = row;
+            }
+        }
+        if (max_val < 1e-14) return false;
+        if (max_row != col) {
+            for (int k = 0; k < n; ++k) std::swap(a[col * n + k], a[max_row * n + k]);
+            std::swap(b[col], b[max_row]);
+        }
+        const double pivot = a[col * n + col];
+        for (int row = col + 1; row < n; ++row) {
+            const double factor = a[row * n + col] / pivot;
+            for (int k = col; k < n; ++k) a[row * n + k] -= factor * a[col * n + k];
+            b[row] -= factor * b[col];
+        }
+    }
+    for (int col = n - 1; col >= 0; --col) {
+        double sum = b[col];
+        for (int k = col + 1; k < n; ++k) sum -= a[col * n + k] * b[k];
+        b[col] = sum / a[col * n + col];
+    }
+    return true;
+}
+
+float host_median_f32(std::vector<float> v) {  // median_f32_mut on a copy
+    const size_t n = v.size();
+    if (n == 0) return 0.0f;
+    const size_t mid = n / 2;
+    std::nth_element(v.begin(), v.begin() + mid, v.end());
+    if (n % 2 == 0) {
+        const float right = v[mid];
+        const float left = *std::max_element(v.begin(), v.begin() + mid);
+        return (left + right) / 2.0f;
+    }
+    return v[mid];
+}
+
+struct Sample {
+    float y, x, value;
+};
+
+}  // namespace
+
+extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_background_config *cfg, ab_plane_mut *out_model,
+                                     ab_plane_mut *out_corrected, ab_background_info *info) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, img && cfg && out_corrected, "null argument");
+    const int64_t rows = img->rows, cols = img->cols, npix = rows * cols;
+    AB_CHECK(ctx, out_corrected->rows == rows && out_corrected->cols == cols && (!out_model || (out_model->rows == rows && out_model->cols == cols)),
+             "model / corrected planes must have the image's dims");
+    const int grid = (int)cfg->grid_size, degree = (int)cfg->poly_degree;
+    AB_CHECK(ctx, grid >= 1 && grid <= 64 && degree >= 0 && degree <= 5, "grid_size must be 1..64 and poly_degree 0..5 (<= 21 terms)");
+    AB_CHECK(ctx, rows <= 65535 && npix < (int64_t(1) << 31), "image too large for this build");
+    const int cell_h = (int)(rows / grid), cell_w = (int)(cols / grid);
+    if (cell_h < 4 || cell_w < 4) return ab_set_error(ctx, AB_ERR_INVALID, "Image too small for grid_size=%d", grid);  // :127-129
+    AB_CHECK(ctx, (int64_t)cell_h * cell_w <= 4 * 65536, "grid cells larger than 512 x 512 px are not supported");
+    const int margin_h = cell_h / 4, margin_w = cell_w / 4, inner_h = cell_h - 2 * margin_h, inner_w = cell_w - 2 * margin_w;
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, img, &in));
+    float *model = nullptr;
+    unsigned int *dhist = nullptr;
+    CellOut *dcells = nullptr;
+    StagedOut so_corr, so_model;
+    bool corr_open = false, model_open = false, model_owned = false;
+    int rc = AB_OK;
+    auto cleanup = [&]() {
+        if (corr_open) ab_stage_out_abort(ctx, &so_corr);
+        if (model_open) ab_stage_out_abort(ctx, &so_model);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (model_owned && model) (void)hipFree(model);
+        if (dhist) (void)hipFree(dhist);
+        if (dcells) (void)hipFree(dcells);
+        ab_stage_release(ctx, &in);
+    };
+#define BG_TRY(expr)          \
+    do {                      \
+        rc = (expr);          \
+        if (rc != AB_OK) {    \
+            cleanup();        \
+            return rc;        \
+        }                     \
+    } while (0)
+#define BG_HIP(call)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            rc = ab_set_error(ctx, AB_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));     \
+            cleanup();                                                                             \
+            return rc;                                                                             \
+        }                                                                                          \
+    } while (0)
+
+    BG_HIP(hipMalloc((void **)&dhist, 2048 * sizeof(unsigned int)));
+    BG_HIP(hipMalloc((void **)&dcells, (size_t)grid * grid * sizeof(CellOut)));
+
+    // global median / MAD over finite, > 0 pixels (:135-146)
+    float global_median, global_mad;
+    BG_TRY(img_median_f32(ctx, in.dptr, npix, 0.0f, 0, 0.0f, dhist, &global_median, nullptr));
+    BG_TRY(img_median_f32(ctx, in.dptr, npix, 0.0f, 1, global_median, dhist, &global_mad, nullptr));
+    const float sigma = global_mad * kMadToSigmaF32;
+
+    // grid-cell medians (:150-190)
+    hipLaunchKernelGGL(cell_median_kernel, dim3(grid * grid), dim3(absel::kBlock), 0, ctx->stream, in.dptr, in.cols, grid, cell_h,
+                       cell_w, margin_h, margin_w, inner_h, inner_w, dcells);
+    BG_HIP(hipGetLastError());
+    std::vector<CellOut> cells((size_t)grid * grid);
+    BG_HIP(hipMemcpyAsync(cells.data(), dcells, cells.size() * sizeof(CellOut), hipMemcpyDeviceToHost, ctx->stream));
+    BG_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<Sample> samples;
+    const size_t total_cell = (size_t)inner_h * inner_w;
+    for (int gy = 0; gy < grid; ++gy)
+        for (int gx = 0; gx < grid; ++gx) {
+            const CellOut &c = cells[(size_t)gy * grid + gx];
+            const size_t zero_count = total_cell - c.count;
+            if (c.count == 0 || (double)zero_count / (double)total_cell > 0.3) continue;
+            const float lo = global_median - cfg->sigma_clip * sigma, hi = global_median + cfg->sigma_clip * sigma;
+            if (c.median >= lo && c.median <= hi) {
+                const int y0 = gy * cell_h + margin_h, x0 = gx * cell_w + margin_w;
+                samples.push_back({(float)(y0 + inner_h / 2), (float)(x0 + inner_w / 2), c.median});
+            }
+        }
+    const size_t n_terms = (size_t)(degree + 1) * (degree + 2) / 2, min_samples = n_terms + 2;
+    for (size_t it = 1; it < cfg->iterations; ++it) {  // :192-207
+        if (samples.size() < min_samples) break;
+        std::vector<float> values;
+        for (const Sample &s : samples) values.push_back(s.value);
+        const float med = host_median_f32(values);
+        for (float &v : values) v = std::fabs(v - med);
+        const float mad = host_median_f32(values);
+        const float sig = mad * kMadToSigmaF32;
+        const float lo = med - cfg->sigma_clip * sig, hi = med + cfg->sigma_clip * sig;
+        samples.erase(std::remove_if(samples.begin(), samples.end(), [&](const Sample &s) { return !(s.value >= lo && s.value <= hi); }),
+                      samples.end());
+    }
+    if (info) info->sample_count = samples.size();
+    if (samples.size() < min_samples) {  // :71-77
+        rc = ab_set_error(ctx, AB_ERR_INVALID, "Not enough background samples (%zu) for polynomial degree %d", samples.size(), degree);
+        cleanup();
+        return rc;
+    }
+
+    // fit_polynomial_surface (:251-290)
+    PolyArgs pa;
+    memset(&pa, 0, sizeof pa);
+    pa.degree = degree;
+    pa.rows = (int)rows;
+    pa.cols = (int)cols;
+    pa.row_scale = (double)rows;
+    pa.col_scale = (double)cols;
+    std::vector<double> ata(n_terms * n_terms, 0.0), atb(n_terms, 0.0);
+    double basis[kMaxPolyTerms];
+    for (const Sample &s : samples) {
+        const double ny = (double)s.y / pa.row_scale - 0.5, nx = (double)s.x / pa.col_scale - 0.5, val = (double)s.value;
+        const int cnt = poly_basis_into(ny, nx, degree, basis);
+        for (int i = 0; i < cnt; ++i) {
+            atb[i] += basis[i] * val;
+            for (int j = 0; j < cnt; ++j) ata[i * n_terms + j] += basis[i] * basis[j];
+        }
+    }
+    for (size_t i = 0; i < n_terms; ++i) ata[i * n_terms + i] += 1e-8;
+    if (!solve_linear_system(ata, atb, (int)n_terms)) {
+        rc = ab_set_error(ctx, AB_ERR_INVALID, "Failed to solve polynomial fit: Singular matrix in polynomial fit");
+        cleanup();
+        return rc;
+    }
+    for (size_t i = 0; i < n_terms; ++i) pa.coeffs[i] = atb[i];
+    if (info) memcpy(info->coeffs, pa.coeffs, sizeof pa.coeffs);
+
+    // evaluate_polynomial_surface + apply_correction (:307-383)
+    if (out_model) {
+        BG_TRY(ab_stage_out_begin(ctx, out_model, &so_model));
+        model_open = true;
+        model = so_model.dptr;
+    } else {
+        BG_HIP(hipMalloc((void **)&model, (size_t)npix * sizeof(float)));
+        model_owned = true;
+    }
+    hipLaunchKernelGGL(poly_model_kernel, dim3((unsigned)((cols + kBlock - 1) / kBlock), (unsigned)rows), dim3(kBlock), 0, ctx->stream, pa,
+                       model);
+    BG_HIP(hipGetLastError());
+    float model_median = 0.0f;
+    BG_TRY(img_median_f32(ctx, model, npix, 0.0f, 0, 0.0f, dhist, &model_median, nullptr));
+    BG_TRY(ab_stage_out_begin(ctx, out_corrected, &so_corr));
+    corr_open = true;
+    const int g = (int)std::min<int64_t>((npix + kBlock - 1) / kBlock, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8);
+    hipLaunchKernelGGL(bg_apply_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, in.dptr, model, npix, (int)cfg->mode, model_median,
+                       so_corr.dptr);
+    BG_HIP(hipGetLastError());
+    rc = ab_stage_out_finish(ctx, &so_corr);
+    corr_open = false;
+    if (rc == AB_OK && model_open) {
+        rc = ab_stage_out_finish(ctx, &so_model);
+        model_open = false;
+    }
+    // compute_rms_residual (:385-415)
+    if (rc == AB_OK && info) {
+        double sum_sq = 0.0;
+        for (const Sample &s : samples) {
+            double yp[7] = {1.0, 0, 0, 0, 0, 0, 0}, xp[7] = {1.0, 0, 0, 0, 0, 0, 0};
+            const double ny = (double)s.y / pa.row_scale - 0.5, nx = (double)s.x / pa.col_scale - 0.5;
+            for (int i = 1; i <= std::min(degree, 6); ++i) {
+                yp[i] = yp[i - 1] * ny;
+                xp[i] = xp[i - 1] * nx;
+            }
+            double val = 0.0;
+            int idx = 0;
+            for (int total = 0; total <= degree; ++total)
+                for (int ypow = total; ypow >= 0; --ypow) {
+                    val += pa.coeffs[idx] * yp[ypow] * xp[total - ypow];
+                    ++idx;
+                }
+            const double diff = (double)s.value - val;
+            sum_sq += diff * diff;
+        }
+        info->rms_residual = std::sqrt(sum_sq / (double)samples.size());
+    }
+    cleanup();
+    return rc;
+#undef BG_TRY
+#undef BG_HIP
+}

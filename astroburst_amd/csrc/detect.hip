@@ -20,6 +20,7 @@
 //     each and are finished on the host in raster order (the reference sums in BFS order: the two
 //     agree to ~1e-15 relative; counts, npix and the component set are exact).
 #include "ab_common.hpp"
+#include "block_select.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -29,7 +30,6 @@
 namespace {
 
 constexpr double kMadToSigma = 1.4826;
-constexpr int kTileBlock = 1024;
 
 // ---- per-tile sigma-clipped statistics ---------------------------------------------------------
 struct TileOut {
@@ -38,99 +38,25 @@ struct TileOut {
     int pad;
 };
 
-struct TileCtx {
-    const float *img;
-    int64_t ld;
-    int y0, y1, x0, x1;
-    float lo, hi;  // cumulative `retain` bounds (sigma_clip.rs:21-23)
-};
-
-__device__ __forceinline__ bool tile_valid(float v) { return __builtin_isfinite(v) && v > 1e-7f; }  // star_detection.rs:56
-
-// counts[] = histogram over bits [shift, shift+nbits) of the keys of the tile's retained pixels whose key
-// matches the prefix; mode 0: key = bits(v); mode 1: key = bits((f32)|v - median|) (sigma_clip.rs:15)
-__device__ void tile_hist(const TileCtx &t, int mode, double median, uint32_t prefix_mask, uint32_t prefix_val, int shift,
-                          int nbits, unsigned int *hist) {
-    const int nb = 1 << nbits;
-    for (int i = threadIdx.x; i < nb; i += kTileBlock) hist[i] = 0;
-    __syncthreads();
-    const int w = t.x1 - t.x0, n = w * (t.y1 - t.y0);
-    for (int i = threadIdx.x; i < n; i += kTileBlock) {
-        const int r = t.y0 + i / w, c = t.x0 + i % w;
-        const float v = t.img[r * t.ld + c];
-        if (tile_valid(v) && v >= t.lo && v <= t.hi) {
-            const float k = mode ? (float)fabs((double)v - median) : v;
-            const uint32_t key = __float_as_uint(k);
-            if ((key & prefix_mask) == prefix_val) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
-        }
-    }
-    __syncthreads();
-}
-
-// the bin holding 0-based rank `rank` and the count before it; serial over 2048 bins by one lane
-__device__ void tile_find(const unsigned int *hist, int nb, unsigned int rank, unsigned int *bin_out,
-                          unsigned int *before_out, unsigned int *total_out) {
-    __shared__ unsigned int s_bin, s_before, s_total;
-    if (threadIdx.x == 0) {
-        unsigned int cum = 0, bin = nb - 1, before = 0;
-        bool found = false;
-        for (int i = 0; i < nb; ++i) {
-            const unsigned int h = hist[i];
-            if (!found && cum + h > rank) {
-                bin = i;
-                before = cum;
-                found = true;
-            }
-            cum += h;
-        }
-        s_bin = bin;
-        s_before = before;
-        s_total = cum;
-    }
-    __syncthreads();
-    *bin_out = s_bin;
-    *before_out = s_before;
-    *total_out = s_total;
-    __syncthreads();
-}
-
-__device__ float tile_select(const TileCtx &t, int mode, double median, unsigned int rank, unsigned int *hist,
-                             unsigned int *count_out) {
-    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-    uint32_t mask = 0, val = 0;
-    unsigned int total0 = 0;
-    for (int p = 0; p < 3; ++p) {
-        tile_hist(t, mode, median, mask, val, shifts[p], bits[p], hist);
-        unsigned int bin, before, total;
-        tile_find(hist, 1 << bits[p], rank, &bin, &before, &total);
-        if (p == 0) total0 = total;
-        rank -= before;
-        val |= bin << shifts[p];
-        mask |= ((1u << bits[p]) - 1u) << shifts[p];
-    }
-    if (count_out) *count_out = total0;
-    return __uint_as_float(val);
-}
-
 // estimate_background's per-tile body (star_detection.rs:47-68) = sigma_clipped_stats(vals, 3.0, 2)
-__global__ __launch_bounds__(kTileBlock) void tile_background_kernel(const float *__restrict__ img, int rows, int cols,
-                                                                     int64_t ld, int step, int ntx, TileOut *__restrict__ out) {
+// (math/sigma_clip.rs:4-34); order statistics by workgroup radix select (block_select.hpp)
+__global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const float *__restrict__ img, int rows, int cols,
+                                                                        int64_t ld, int step, int ntx,
+                                                                        TileOut *__restrict__ out) {
     __shared__ unsigned int hist[2048];
     const int ty = blockIdx.x / ntx, tx = blockIdx.x % ntx;
-    TileCtx t;
+    absel::Window t;
     t.img = img;
     t.ld = ld;
     t.y0 = ty * step;
     t.x0 = tx * step;
     t.y1 = min(t.y0 + step, rows);
     t.x1 = min(t.x0 + step, cols);
+    t.min_valid = 1e-7f;  // star_detection.rs:56
     t.lo = -__builtin_inff();
     t.hi = __builtin_inff();
 
-    // n = number of valid pixels (a pass-0 histogram's total)
-    tile_hist(t, 0, 0.0, 0, 0, 21, 11, hist);
-    unsigned int b_, bf_, n;
-    tile_find(hist, 2048, 0xffffffffu, &b_, &bf_, &n);
+    unsigned int n = absel::count(t, hist);
     TileOut res = {0.0, 1.0, 0, 0};
     if (n >= 8) {
         res.valid = 1;
@@ -142,22 +68,8 @@ __global__ __launch_bounds__(kTileBlock) void tile_background_kernel(const float
                 sigma = 1.0;
                 break;
             }
-            const unsigned int mid = n / 2;
-            // exact_median_mut (median.rs:27-44)
-            const float right = tile_select(t, 0, 0.0, mid, hist, nullptr);
-            if (n % 2 == 0) {
-                const float left = tile_select(t, 0, 0.0, mid - 1, hist, nullptr);
-                median = ((double)left + (double)right) / 2.0;
-            } else {
-                median = (double)right;
-            }
-            // median_f32_mut of |v - median| as f32 (sigma_clip.rs:14-16, median.rs:46-63)
-            const float dr = tile_select(t, 1, median, mid, hist, nullptr);
-            float mad_f32 = dr;
-            if (n % 2 == 0) {
-                const float dl = tile_select(t, 1, median, mid - 1, hist, nullptr);
-                mad_f32 = (dl + dr) / 2.0f;
-            }
+            median = absel::exact_median(t, n, hist);                                  // median.rs:27-44
+            const float mad_f32 = absel::median_f32(t, 1, median, 0.0f, n, hist);      // sigma_clip.rs:14-16
             const double sig = fmax((double)mad_f32 * kMadToSigma, 1e-30);
             if (it == 2) {
                 sigma = sig;
@@ -171,8 +83,7 @@ __global__ __launch_bounds__(kTileBlock) void tile_background_kernel(const float
                 t.lo = __builtin_inff();
                 t.hi = -__builtin_inff();
             }
-            tile_hist(t, 0, 0.0, 0, 0, 21, 11, hist);
-            tile_find(hist, 2048, 0xffffffffu, &b_, &bf_, &n);
+            n = absel::count(t, hist);
         }
         res.median = median;
         res.sigma = sigma;
@@ -300,7 +211,7 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
     const int ntiles = nty * ntx;
     void *d = nullptr;
     AB_TRY(ab_scratch(ctx, (size_t)ntiles * sizeof(TileOut), &d));
-    hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(kTileBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
+    hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(absel::kBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
                        ntx, (TileOut *)d);
     AB_HIP(ctx, hipGetLastError());
     std::vector<TileOut> h(ntiles);

@@ -255,6 +255,25 @@ AB_API int ab_calibrate_image(ab_ctx *ctx, const ab_plane *raw, const ab_plane *
  * element [len/2] of the finite samples (upper median), 0 if none.  1 <= n <= 64. */
 AB_API int ab_median_combine(ab_ctx *ctx, const ab_plane *planes, size_t n, ab_plane_mut *out);
 
+/* ---- a12  core/imaging/background.rs ---------------------------------------------------------------------------- */
+typedef struct { /* BackgroundConfig, background.rs:14-33 (defaults 8, 3, 2.5, 3, Subtract) */
+    size_t grid_size, poly_degree;
+    float sigma_clip;
+    size_t iterations;
+    int mode; /* CorrectionMode: 0 Subtract, 1 Divide */
+} ab_background_config;
+typedef struct { /* BackgroundResult's scalars (:35-42) + the fitted coefficients */
+    size_t sample_count;
+    double rms_residual;
+    double coeffs[21];
+} ab_background_info;
+/* extract_background(image, config) (background.rs:55-116): grid of cell medians clipped against the global
+ * median / MAD -> polynomial surface (degree <= 5) by ridge least squares -> model and corrected image.
+ * out_model may be NULL.  Error strings follow the reference ("Image too small for grid_size=..",
+ * "Not enough background samples (..) for polynomial degree ..", "Failed to solve polynomial fit: ..."). */
+AB_API int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_background_config *cfg, ab_plane_mut *out_model,
+                                 ab_plane_mut *out_corrected, ab_background_info *info);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

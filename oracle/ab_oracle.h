@@ -177,6 +177,13 @@ int orc_affine_from_stars(const double *ref_xy, size_t n_ref, const double *tgt_
 int orc_fit_rigid(const double *matches, size_t n, double t[6]);                       /* affine.rs:597-642 */
 int orc_fit_affine(const double *matches, size_t n, double t[6]);                      /* affine.rs:519-536 */
 
+/* ---- core/imaging/background.rs (orc_background.c) ------------------------------------------ */
+/* extract_background (:55-116).  Returns 0 ok; 1 "Image too small for grid_size"; 2 "Not enough background
+ * samples"; 3 singular fit.  mode 0 subtract, 1 divide; model / corrected may be NULL; coeffs_out: 21 doubles. */
+int orc_extract_background(const float *image, size_t rows, size_t cols, size_t grid, size_t degree, float sigma_clip,
+                           size_t iterations, int mode, float *model, float *corrected, size_t *sample_count_out,
+                           double *rms_out, double *coeffs_out);
+
 /* utility */
 int orc_max_threads(void);
 

@@ -406,6 +406,38 @@ def median_combine(frames) -> np.ndarray:
     return out
 
 
+@dataclass
+class BackgroundResult:  # background.rs:35-42 (+ fitted coefficients)
+    model: np.ndarray
+    corrected: np.ndarray
+    sample_count: int
+    rms_residual: float
+    coeffs: np.ndarray
+
+
+_BG_ERRORS = {1: "Image too small for grid_size={grid}",
+              2: "Not enough background samples ({n}) for polynomial degree {degree}",
+              3: "Failed to solve polynomial fit: Singular matrix in polynomial fit"}
+
+
+def extract_background(image, grid_size=8, poly_degree=3, sigma_clip=2.5, iterations=3, mode=0) -> BackgroundResult:
+    """background.rs:55-116; raises ValueError with the reference's message on its Err paths."""
+    L = lib()
+    L.orc_extract_background.restype = C.c_int
+    L.orc_extract_background.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float,
+                                         C.c_size_t, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                         C.POINTER(C.c_size_t), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    im = _f32(image)
+    model, corr = np.zeros_like(im), np.zeros_like(im)
+    ns, rms = C.c_size_t(0), C.c_double(0.0)
+    coeffs = np.zeros(21, dtype=np.float64)
+    rc = L.orc_extract_background(_fp(im), im.shape[0], im.shape[1], grid_size, poly_degree, sigma_clip, iterations, mode,
+                                  _fp(model), _fp(corr), C.byref(ns), C.byref(rms), coeffs.ctypes.data_as(C.POINTER(C.c_double)))
+    if rc != 0:
+        raise ValueError(_BG_ERRORS[rc].format(grid=grid_size, n=ns.value, degree=poly_degree))
+    return BackgroundResult(model, corr, int(ns.value), float(rms.value), coeffs)
+
+
 def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
