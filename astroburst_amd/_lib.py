@@ -85,6 +85,27 @@ class BackgroundInfoC(C.Structure):  # scalars of BackgroundResult, background.r
     _fields_ = [("sample_count", C.c_size_t), ("rms_residual", C.c_double), ("coeffs", C.c_double * 21)]
 
 
+class StarMaskConfigC(C.Structure):  # star_mask.rs:6-30
+    _fields_ = [("growth_factor", C.c_double), ("softness", C.c_double), ("detection_sigma", C.c_double),
+                ("min_fwhm", C.c_double), ("max_fwhm", C.c_double), ("luminance_protect", C.c_int),
+                ("luminance_ceiling", C.c_double)]
+
+
+class StarMaskInfoC(C.Structure):  # star_mask.rs:32-37
+    _fields_ = [("stars_masked", C.c_size_t), ("coverage_fraction", C.c_double)]
+
+
+class MaskedStretchConfigC(C.Structure):  # masked_stretch.rs:7-32
+    _fields_ = [("iterations", C.c_size_t), ("target_background", C.c_double), ("mask_growth", C.c_double),
+                ("mask_softness", C.c_double), ("luminance_protect", C.c_int), ("luminance_ceiling", C.c_double),
+                ("protection_amount", C.c_double), ("convergence_threshold", C.c_double)]
+
+
+class MaskedStretchResultC(C.Structure):  # masked_stretch.rs:34-42
+    _fields_ = [("iterations_run", C.c_size_t), ("final_background", C.c_double), ("stars_masked", C.c_size_t),
+                ("mask_coverage", C.c_double), ("converged", C.c_int)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into astroburst_amd/libastroburst_hip.so."""
     cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
@@ -169,6 +190,14 @@ def lib() -> C.CDLL:
     L.ab_scale.argtypes = [vp, pp, C.c_float, pp]
     L.ab_calibrate_image.argtypes = [vp, pp, pp, pp, pp, C.c_float, pp]
     L.ab_median_combine.argtypes = [vp, pp, C.c_size_t, pp]
+    L.ab_generate_star_mask.argtypes = [vp, pp, C.POINTER(StarMaskConfigC), pp, C.POINTER(StarMaskInfoC)]
+    L.ab_generate_star_mask_from_stars.argtypes = [vp, pp, C.POINTER(DetectedStarC), C.c_size_t, C.POINTER(StarMaskConfigC),
+                                                   pp, C.POINTER(StarMaskInfoC)]
+    L.ab_masked_stretch.argtypes = [vp, pp, C.POINTER(MaskedStretchConfigC), pp, C.POINTER(MaskedStretchResultC)]
+    L.ab_masked_stretch_with_mask.argtypes = [vp, pp, pp, C.POINTER(StarMaskInfoC), C.POINTER(MaskedStretchConfigC), pp,
+                                              C.POINTER(MaskedStretchResultC)]
+    L.ab_masked_stretch_rgb_shared.argtypes = [vp, pp, pp, pp, C.POINTER(MaskedStretchConfigC), pp, pp, pp,
+                                               C.POINTER(MaskedStretchResultC), C.POINTER(StarMaskInfoC)]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift

@@ -41,6 +41,23 @@ class StfParams:  # types/image.rs:36-50
 
 
 @dataclass
+class StarMaskResult:  # star_mask.rs:32-37
+    mask: object
+    stars_masked: int
+    coverage_fraction: float
+
+
+@dataclass
+class MaskedStretchResult:  # masked_stretch.rs:34-42
+    image: object
+    iterations_run: int
+    final_background: float
+    stars_masked: int
+    mask_coverage: float
+    converged: bool
+
+
+@dataclass
 class BackgroundResult:  # background.rs:35-42
     model: object
     corrected: object
@@ -527,6 +544,80 @@ class Context:
         self._check(self._L.ab_extract_background(self._h, C.byref(pi), C.byref(cfg), pm, C.byref(pc), C.byref(info)))
         return BackgroundResult(model, corrected, int(info.sample_count), float(info.rms_residual),
                                 np.array(info.coeffs[:], dtype=np.float64))
+
+    # ---- a13 star mask + masked stretch ---------------------------------------------------------------
+    @staticmethod
+    def _mask_cfg(growth_factor, softness, detection_sigma, min_fwhm, max_fwhm, luminance_protect, luminance_ceiling):
+        return _lib.StarMaskConfigC(growth_factor, softness, detection_sigma, min_fwhm, max_fwhm, int(bool(luminance_protect)),
+                                    luminance_ceiling)
+
+    def generate_star_mask(self, image, growth_factor=2.5, softness=4.0, detection_sigma=5.0, min_fwhm=1.5, max_fwhm=30.0,
+                           luminance_protect=False, luminance_ceiling=0.85, stars=None) -> StarMaskResult:
+        """generate_star_mask (star_mask.rs:38-44); with stars=[DetectedStar | (x, y, fwhm)] it is
+        generate_star_mask_from_detection (:46-138) on that detection."""
+        keep = []
+        pi = self._plane(image, keep)
+        mask = self._new_like(image, pi.rows, pi.cols)
+        pm = self._out_plane(mask, keep, pi.rows, pi.cols)
+        cfg = self._mask_cfg(growth_factor, softness, detection_sigma, min_fwhm, max_fwhm, luminance_protect, luminance_ceiling)
+        info = _lib.StarMaskInfoC()
+        if stars is None:
+            self._check(self._L.ab_generate_star_mask(self._h, C.byref(pi), C.byref(cfg), C.byref(pm), C.byref(info)))
+        else:
+            buf = (_lib.DetectedStarC * max(len(stars), 1))()
+            for b, s in zip(buf, stars):
+                b.x, b.y, b.fwhm = (s.x, s.y, s.fwhm) if hasattr(s, "fwhm") else s
+            self._check(self._L.ab_generate_star_mask_from_stars(self._h, C.byref(pi), buf, len(stars), C.byref(cfg),
+                                                                 C.byref(pm), C.byref(info)))
+        return StarMaskResult(mask, int(info.stars_masked), float(info.coverage_fraction))
+
+    @staticmethod
+    def _ms_cfg(iterations, target_background, mask_growth, mask_softness, luminance_protect, luminance_ceiling,
+                protection_amount, convergence_threshold):
+        return _lib.MaskedStretchConfigC(iterations, target_background, mask_growth, mask_softness, int(bool(luminance_protect)),
+                                         luminance_ceiling, protection_amount, convergence_threshold)
+
+    @staticmethod
+    def _ms_result(image, r):
+        return MaskedStretchResult(image, int(r.iterations_run), float(r.final_background), int(r.stars_masked),
+                                   float(r.mask_coverage), bool(r.converged))
+
+    def masked_stretch(self, image, iterations=10, target_background=0.25, mask_growth=2.5, mask_softness=4.0,
+                       luminance_protect=True, luminance_ceiling=0.85, protection_amount=0.85, convergence_threshold=1e-5,
+                       mask: "StarMaskResult | None" = None) -> MaskedStretchResult:
+        """masked_stretch (masked_stretch.rs:44-58); with mask=StarMaskResult it is masked_stretch_with_mask (:60-118)."""
+        keep = []
+        pi = self._plane(image, keep)
+        out = self._new_like(image, pi.rows, pi.cols)
+        po = self._out_plane(out, keep, pi.rows, pi.cols)
+        cfg = self._ms_cfg(iterations, target_background, mask_growth, mask_softness, luminance_protect, luminance_ceiling,
+                           protection_amount, convergence_threshold)
+        res = _lib.MaskedStretchResultC()
+        if mask is None:
+            self._check(self._L.ab_masked_stretch(self._h, C.byref(pi), C.byref(cfg), C.byref(po), C.byref(res)))
+        else:
+            pm = self._plane(mask.mask, keep)
+            mi = _lib.StarMaskInfoC(mask.stars_masked, mask.coverage_fraction)
+            self._check(self._L.ab_masked_stretch_with_mask(self._h, C.byref(pi), C.byref(pm), C.byref(mi), C.byref(cfg),
+                                                            C.byref(po), C.byref(res)))
+        return self._ms_result(out, res)
+
+    def masked_stretch_rgb_shared(self, r, g, b, iterations=10, target_background=0.25, mask_growth=2.5, mask_softness=4.0,
+                                  luminance_protect=True, luminance_ceiling=0.85, protection_amount=0.85,
+                                  convergence_threshold=1e-5):
+        """masked_stretch_rgb_shared (masked_stretch.rs:155-193) -> (res_r, res_g, res_b, shared StarMask scalars)."""
+        keep = []
+        ps = [self._plane(x, keep) for x in (r, g, b)]
+        outs = [self._new_like(x, p.rows, p.cols) for x, p in zip((r, g, b), ps)]
+        pos = [self._out_plane(o, keep, p.rows, p.cols) for o, p in zip(outs, ps)]
+        cfg = self._ms_cfg(iterations, target_background, mask_growth, mask_softness, luminance_protect, luminance_ceiling,
+                           protection_amount, convergence_threshold)
+        res = (_lib.MaskedStretchResultC * 3)()
+        shared = _lib.StarMaskInfoC()
+        self._check(self._L.ab_masked_stretch_rgb_shared(self._h, *[C.byref(p) for p in ps], C.byref(cfg),
+                                                         *[C.byref(p) for p in pos], res, C.byref(shared)))
+        return (*[self._ms_result(o, x) for o, x in zip(outs, res)],
+                StarMaskResult(None, int(shared.stars_masked), float(shared.coverage_fraction)))
 
     # ---- bench support -----------------------------------------------------------------------------
     def bench_copy(self, src, dst):

@@ -28,6 +28,7 @@ struct ab_ctx {
     // device-side u64 counters (rejected pixels etc.)
     unsigned long long *counters = nullptr;  // AB_REJ_SLOTS x u64
     int cu_count = 0;
+    unsigned int *sel_hist = nullptr;  // 2048-bin device histogram of plane_select.hip
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
 };
@@ -77,5 +78,26 @@ struct StagedOut {
 int ab_stage_out_begin(ab_ctx *ctx, const ab_plane_mut *p, StagedOut *out);
 int ab_stage_out_finish(ab_ctx *ctx, StagedOut *o);  // downloads (sync) + frees when host
 void ab_stage_out_abort(ab_ctx *ctx, StagedOut *o);
+
+// plane_select.hip: exact order statistics of {v : finite, v > min_valid, (mask == nullptr || mask < 0.5)};
+// keys are v or, with use_dev, |v - center| (f32).
+struct ab_plane_sel {
+    const float *data = nullptr;
+    const float *mask = nullptr;
+    int64_t n = 0;
+    float min_valid = 0.0f;
+    int use_dev = 0;
+    float center = 0.0f;
+};
+// count, the [count/2] element and (want_lower, even count) the [count/2 - 1] element
+int ab_plane_order_stats(ab_ctx *ctx, const ab_plane_sel &s, int want_lower, uint64_t *count_out, float *mid_out, float *lower_out);
+// median_f32_mut (math/median.rs:46-63) of the candidates; 0 when there are none
+int ab_plane_median_f32(ab_ctx *ctx, const ab_plane_sel &s, float *out, uint64_t *count_out);
+
+// device-level entry points shared between translation units
+int ab_stats_device(ab_ctx *ctx, const float *data, int64_t n, int use_known, double known_min, double known_max,
+                    ab_image_stats *out);
+int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
+                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out);
 
 static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

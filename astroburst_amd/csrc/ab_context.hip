@@ -55,6 +55,7 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -5,8 +5,8 @@
 // (:343-383), compute_rms_residual (:385-415), solve_linear_system (:417-459).
 //
 // Device work (all HBM-bound passes over the plane):
-//   * global median / MAD of the positive finite pixels: whole-image 11/11/10-bit radix select on
-//     the f32 bit patterns (exact order statistics, even counts averaged in f32 as median_f32_mut);
+//   * global median / MAD of the positive finite pixels: whole-image radix select (plane_select.hip;
+//     exact order statistics, even counts averaged in f32 as median_f32_mut);
 //   * one workgroup per grid cell takes the median of the cell's inner 50 % window
 //     (block_select.hpp);
 //   * the fitted surface is evaluated per pixel in f64 with the reference's cumulative power
@@ -25,94 +25,6 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxPolyTerms = 21;
 constexpr float kMadToSigmaF32 = (float)1.4826;
-
-// ---- whole-image radix select over {finite, > min_valid} -------------------------------------------
-struct ImgSel {
-    const float *data;
-    int64_t n;
-    float min_valid;
-    int use_dev;  // key = bits(|v - center|) (f32) instead of bits(v)
-    float center;
-    uint32_t prefix_mask, prefix_val;
-    int shift, nbits;
-    unsigned int *hist;
-};
-
-__global__ __launch_bounds__(kBlock) void img_select_hist_kernel(const ImgSel a) {
-    __shared__ unsigned int lds[2048];
-    const uint32_t nb = 1u << a.nbits;
-    for (uint32_t i = threadIdx.x; i < nb; i += kBlock) lds[i] = 0;
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
-        const float v = a.data[i];
-        if (__builtin_isfinite(v) && v > a.min_valid) {
-            const float k = a.use_dev ? fabsf(v - a.center) : v;
-            const uint32_t key = __float_as_uint(k);
-            if ((key & a.prefix_mask) == a.prefix_val) atomicAdd(&lds[(key >> a.shift) & (nb - 1)], 1u);
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += kBlock)
-        if (lds[i]) atomicAdd(&a.hist[i], lds[i]);
-}
-
-int img_select(ab_ctx *ctx, const float *data, int64_t n, float min_valid, int use_dev, float center, uint64_t rank,
-               unsigned int *dhist, float *out, uint64_t *count_out) {
-    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-    uint32_t mask = 0, val = 0;
-    std::vector<unsigned int> h(2048);
-    const int grid = (int)std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8);
-    for (int p = 0; p < 3; ++p) {
-        const uint32_t nb = 1u << bits[p];
-        AB_HIP(ctx, hipMemsetAsync(dhist, 0, nb * sizeof(unsigned int), ctx->stream));
-        ImgSel a{data, n, min_valid, use_dev, center, mask, val, shifts[p], bits[p], dhist};
-        hipLaunchKernelGGL(img_select_hist_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-        AB_HIP(ctx, hipGetLastError());
-        AB_HIP(ctx, hipMemcpyAsync(h.data(), dhist, nb * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        uint64_t cum = 0, tot = 0;
-        uint32_t bin = nb - 1;
-        bool found = false;
-        for (uint32_t i = 0; i < nb; ++i) {
-            if (!found && cum + h[i] > rank) {
-                bin = i;
-                found = true;
-            }
-            if (!found) cum += h[i];
-            tot += h[i];
-        }
-        if (p == 0 && count_out) *count_out = tot;
-        rank -= cum;
-        val |= bin << shifts[p];
-        mask |= (nb - 1) << shifts[p];
-    }
-    memcpy(out, &val, sizeof(float));
-    return AB_OK;
-}
-
-// median_f32_mut (math/median.rs:46-63) of {finite, > min_valid} (or of their |v - center|); 0 if none
-int img_median_f32(ab_ctx *ctx, const float *data, int64_t n, float min_valid, int use_dev, float center, unsigned int *dhist,
-                   float *out, uint64_t *count_out) {
-    uint64_t cnt = 0;
-    float probe;
-    AB_TRY(img_select(ctx, data, n, min_valid, use_dev, center, 0, dhist, &probe, &cnt));
-    if (count_out) *count_out = cnt;
-    if (cnt == 0) {
-        *out = 0.0f;
-        return AB_OK;
-    }
-    const uint64_t mid = cnt / 2;
-    float right, left;
-    AB_TRY(img_select(ctx, data, n, min_valid, use_dev, center, mid, dhist, &right, nullptr));
-    if (cnt % 2 == 0) {
-        AB_TRY(img_select(ctx, data, n, min_valid, use_dev, center, mid - 1, dhist, &left, nullptr));
-        *out = (left + right) / 2.0f;
-    } else {
-        *out = right;
-    }
-    return AB_OK;
-}
 
 // ---- grid-cell medians (background.rs:151-190) ---------------------------------------------------------
 struct CellOut {
@@ -281,7 +193,6 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
     StagedPlane in;
     AB_TRY(ab_stage_in(ctx, img, &in));
     float *model = nullptr;
-    unsigned int *dhist = nullptr;
     CellOut *dcells = nullptr;
     StagedOut so_corr, so_model;
     bool corr_open = false, model_open = false, model_owned = false;
@@ -291,7 +202,6 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
         if (model_open) ab_stage_out_abort(ctx, &so_model);
         (void)hipStreamSynchronize(ctx->stream);
         if (model_owned && model) (void)hipFree(model);
-        if (dhist) (void)hipFree(dhist);
         if (dcells) (void)hipFree(dcells);
         ab_stage_release(ctx, &in);
     };
@@ -313,13 +223,17 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
         }                                                                                          \
     } while (0)
 
-    BG_HIP(hipMalloc((void **)&dhist, 2048 * sizeof(unsigned int)));
     BG_HIP(hipMalloc((void **)&dcells, (size_t)grid * grid * sizeof(CellOut)));
 
     // global median / MAD over finite, > 0 pixels (:135-146)
     float global_median, global_mad;
-    BG_TRY(img_median_f32(ctx, in.dptr, npix, 0.0f, 0, 0.0f, dhist, &global_median, nullptr));
-    BG_TRY(img_median_f32(ctx, in.dptr, npix, 0.0f, 1, global_median, dhist, &global_mad, nullptr));
+    ab_plane_sel sel;
+    sel.data = in.dptr;
+    sel.n = npix;
+    BG_TRY(ab_plane_median_f32(ctx, sel, &global_median, nullptr));
+    sel.use_dev = 1;
+    sel.center = global_median;
+    BG_TRY(ab_plane_median_f32(ctx, sel, &global_mad, nullptr));
     const float sigma = global_mad * kMadToSigmaF32;
 
     // grid-cell medians (:150-190)
@@ -402,7 +316,10 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
                        model);
     BG_HIP(hipGetLastError());
     float model_median = 0.0f;
-    BG_TRY(img_median_f32(ctx, model, npix, 0.0f, 0, 0.0f, dhist, &model_median, nullptr));
+    ab_plane_sel msel;
+    msel.data = model;
+    msel.n = npix;
+    BG_TRY(ab_plane_median_f32(ctx, msel, &model_median, nullptr));
     BG_TRY(ab_stage_out_begin(ctx, out_corrected, &so_corr));
     corr_open = true;
     const int g = (int)std::min<int64_t>((npix + kBlock - 1) / kBlock, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8);

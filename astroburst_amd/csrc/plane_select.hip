@@ -1,0 +1,122 @@
+// Exact order statistics over a whole plane (gfx950): 11/11/10-bit radix select on f32 bit patterns.
+//
+// Serves every place the reference collects the valid pixels of a full image into a Vec and calls
+// select_nth_unstable on it: background.rs:135-146 (global median / MAD), :350-361 (model median),
+// masked_stretch.rs:213-229 (median of the unmasked pixels, once per stretch iteration).  Candidates
+// are finite and > min_valid >= 0, so their bit patterns (and those of absolute deviations) order
+// like the values.  Pass 0 histograms the top 11 bits and yields the candidate count; each requested
+// rank then costs two more streaming passes.  All passes are HBM-bound reads of the plane (+ mask).
+#include "ab_common.hpp"
+
+#include <algorithm>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+struct SelArgs {
+    const float *data, *mask;
+    int64_t n;
+    float min_valid;
+    int use_dev;
+    float center;
+    uint32_t prefix_mask, prefix_val;
+    int shift, nbits;
+    unsigned int *hist;
+};
+
+__global__ __launch_bounds__(kBlock) void plane_select_hist_kernel(const SelArgs a) {
+    __shared__ unsigned int lds[2048];
+    const uint32_t nb = 1u << a.nbits;
+    for (uint32_t i = threadIdx.x; i < nb; i += kBlock) lds[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        const float v = a.data[i];
+        bool ok = __builtin_isfinite(v) && v > a.min_valid;
+        if (a.mask) ok = ok && a.mask[i] < 0.5f;
+        if (ok) {
+            const float k = a.use_dev ? fabsf(v - a.center) : v;
+            const uint32_t key = __float_as_uint(k);
+            if ((key & a.prefix_mask) == a.prefix_val) atomicAdd(&lds[(key >> a.shift) & (nb - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += kBlock)
+        if (lds[i]) atomicAdd(&a.hist[i], lds[i]);
+}
+
+int run_pass(ab_ctx *ctx, const ab_plane_sel &s, uint32_t mask, uint32_t val, int shift, int nbits, unsigned int *host) {
+    const uint32_t nb = 1u << nbits;
+    AB_HIP(ctx, hipMemsetAsync(ctx->sel_hist, 0, nb * sizeof(unsigned int), ctx->stream));
+    const int grid = (int)std::max<int64_t>(
+        1, std::min<int64_t>((s.n + kBlock - 1) / kBlock, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8));
+    SelArgs a{s.data, s.mask, s.n, s.min_valid, s.use_dev, s.center, mask, val, shift, nbits, ctx->sel_hist};
+    hipLaunchKernelGGL(plane_select_hist_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    AB_HIP(ctx, hipGetLastError());
+    AB_HIP(ctx, hipMemcpyAsync(host, ctx->sel_hist, nb * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AB_OK;
+}
+
+// bin containing 0-based rank; rank becomes the rank within the bin
+uint32_t locate(const unsigned int *h, uint32_t nb, uint64_t *rank) {
+    uint64_t cum = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+        if (cum + h[i] > *rank) {
+            *rank -= cum;
+            return i;
+        }
+        cum += h[i];
+    }
+    *rank = 0;
+    return nb - 1;
+}
+
+}  // namespace
+
+int ab_plane_order_stats(ab_ctx *ctx, const ab_plane_sel &s, int want_lower, uint64_t *count_out, float *mid_out, float *lower_out) {
+    *count_out = 0;
+    *mid_out = 0.0f;
+    if (lower_out) *lower_out = 0.0f;
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->sel_hist) AB_HIP(ctx, hipMalloc((void **)&ctx->sel_hist, 2048 * sizeof(unsigned int)));
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, 3 * 2048 * sizeof(unsigned int), &pin));
+    unsigned int *h0 = (unsigned int *)pin, *h1 = h0 + 2048, *h2 = h1 + 2048;
+    if (s.n <= 0) return AB_OK;
+    AB_TRY(run_pass(ctx, s, 0, 0, 21, 11, h0));
+    uint64_t count = 0;
+    for (int i = 0; i < 2048; ++i) count += h0[i];
+    *count_out = count;
+    if (count == 0) return AB_OK;
+    const uint64_t mid = count / 2;
+    const int n_ranks = (want_lower && count % 2 == 0) ? 2 : 1;
+    for (int r = 0; r < n_ranks; ++r) {
+        uint64_t rank = r == 0 ? mid : mid - 1;
+        uint32_t val = locate(h0, 2048, &rank) << 21, mask = 0x7ffu << 21;
+        AB_TRY(run_pass(ctx, s, mask, val, 10, 11, h1));
+        val |= locate(h1, 2048, &rank) << 10;
+        mask |= 0x7ffu << 10;
+        AB_TRY(run_pass(ctx, s, mask, val, 0, 10, h2));
+        val |= locate(h2, 1024, &rank);
+        float f;
+        memcpy(&f, &val, sizeof f);
+        if (r == 0) {
+            *mid_out = f;
+            if (lower_out) *lower_out = f;
+        } else {
+            *lower_out = f;
+        }
+    }
+    return AB_OK;
+}
+
+int ab_plane_median_f32(ab_ctx *ctx, const ab_plane_sel &s, float *out, uint64_t *count_out) {
+    uint64_t cnt;
+    float mid, lower;
+    AB_TRY(ab_plane_order_stats(ctx, s, 1, &cnt, &mid, &lower));
+    if (count_out) *count_out = cnt;
+    *out = cnt == 0 ? 0.0f : (cnt % 2 == 0 ? (lower + mid) / 2.0f : mid);
+    return AB_OK;
+}

@@ -274,6 +274,48 @@ typedef struct { /* BackgroundResult's scalars (:35-42) + the fitted coefficient
 AB_API int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_background_config *cfg, ab_plane_mut *out_model,
                                  ab_plane_mut *out_corrected, ab_background_info *info);
 
+/* ---- a13  core/imaging/star_mask.rs, masked_stretch.rs --------------------------------------------------------- */
+typedef struct { /* StarMaskConfig, star_mask.rs:6-30 (defaults 2.5, 4.0, 5.0, 1.5, 30.0, false, 0.85) */
+    double growth_factor, softness, detection_sigma, min_fwhm, max_fwhm;
+    int luminance_protect;
+    double luminance_ceiling;
+} ab_star_mask_config;
+typedef struct { size_t stars_masked; double coverage_fraction; } ab_star_mask_info; /* StarMaskResult scalars, :32-37 */
+/* generate_star_mask (star_mask.rs:38-44) = detect_stars(image, detection_sigma) + the painter below */
+AB_API int ab_generate_star_mask(ab_ctx *ctx, const ab_plane *img, const ab_star_mask_config *cfg, ab_plane_mut *out_mask,
+                                 ab_star_mask_info *info);
+/* generate_star_mask_from_detection (star_mask.rs:46-138): stars with min_fwhm <= fwhm <= max_fwhm paint a disc of
+ * radius fwhm * growth_factor plus a smoothstep skirt `softness` wide (max-combined); optional luminance protection
+ * above luminance_ceiling; coverage = fraction of mask > 0.01.  Only x, y, fwhm of each star are read. */
+AB_API int ab_generate_star_mask_from_stars(ab_ctx *ctx, const ab_plane *img, const ab_detected_star *stars, size_t n_stars,
+                                            const ab_star_mask_config *cfg, ab_plane_mut *out_mask, ab_star_mask_info *info);
+typedef struct { /* MaskedStretchConfig, masked_stretch.rs:7-32 (defaults 10, 0.25, 2.5, 4.0, true, 0.85, 0.85, 1e-5) */
+    size_t iterations;
+    double target_background, mask_growth, mask_softness;
+    int luminance_protect;
+    double luminance_ceiling, protection_amount, convergence_threshold;
+} ab_masked_stretch_config;
+typedef struct { /* MaskedStretchResult scalars, masked_stretch.rs:34-42 */
+    size_t iterations_run;
+    double final_background;
+    size_t stars_masked;
+    double mask_coverage;
+    int converged;
+} ab_masked_stretch_result;
+/* masked_stretch (masked_stretch.rs:44-58): star mask from the image itself, then the loop below */
+AB_API int ab_masked_stretch(ab_ctx *ctx, const ab_plane *img, const ab_masked_stretch_config *cfg, ab_plane_mut *out,
+                             ab_masked_stretch_result *res);
+/* masked_stretch_with_mask (:60-118): normalise to [0,1]; up to `iterations` times: bg = [len/2] element of the
+ * unmasked (mask < 0.5) positive pixels, stop at target / stagnation, else blend the MTF-stretched image in with
+ * weight 1 - mask * protection; clamp.  mask_info (nullable) is echoed into res (stars_masked, mask_coverage). */
+AB_API int ab_masked_stretch_with_mask(ab_ctx *ctx, const ab_plane *img, const ab_plane *mask,
+                                       const ab_star_mask_info *mask_info, const ab_masked_stretch_config *cfg,
+                                       ab_plane_mut *out, ab_masked_stretch_result *res);
+/* masked_stretch_rgb_shared (:155-193): one mask from the luminance (:120-153), applied to r, g, b; res3[0..3] */
+AB_API int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b,
+                                        const ab_masked_stretch_config *cfg, ab_plane_mut *out_r, ab_plane_mut *out_g,
+                                        ab_plane_mut *out_b, ab_masked_stretch_result *res3, ab_star_mask_info *shared);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

@@ -184,6 +184,19 @@ int orc_extract_background(const float *image, size_t rows, size_t cols, size_t 
                            size_t iterations, int mode, float *model, float *corrected, size_t *sample_count_out,
                            double *rms_out, double *coeffs_out);
 
+/* ---- core/imaging/star_mask.rs, masked_stretch.rs (orc_masked.c) -------------------------------- */
+/* generate_star_mask_from_detection (star_mask.rs:46-138) on the stars' (x, y, fwhm); returns stars_masked */
+size_t orc_star_mask_from_stars(const float *image, size_t h, size_t w, const double *xs, const double *ys,
+                                const double *fwhms, size_t n_stars, double growth_factor, double softness,
+                                double min_fwhm, double max_fwhm, int luminance_protect, double luminance_ceiling,
+                                float *mask, double *coverage_out);
+size_t orc_generate_star_mask(const float *image, size_t h, size_t w, double growth_factor, double softness,
+                              double detection_sigma, double min_fwhm, double max_fwhm, int luminance_protect,
+                              double luminance_ceiling, float *mask, double *coverage_out);      /* :38-44 */
+void orc_masked_stretch_with_mask(const float *image, const float *mask, size_t n, size_t iterations, double target_bg,
+                                  double protection_amount, double convergence_threshold, float *out,
+                                  size_t *iterations_run_out, double *final_bg_out, int *converged_out); /* :60-118 */
+
 /* utility */
 int orc_max_threads(void);
 

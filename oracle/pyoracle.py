@@ -438,6 +438,84 @@ def extract_background(image, grid_size=8, poly_degree=3, sigma_clip=2.5, iterat
     return BackgroundResult(model, corr, int(ns.value), float(rms.value), coeffs)
 
 
+@dataclass
+class StarMaskResult:  # star_mask.rs:32-37
+    mask: np.ndarray
+    stars_masked: int
+    coverage_fraction: float
+
+
+@dataclass
+class MaskedStretchResult:  # masked_stretch.rs:34-42
+    image: np.ndarray
+    iterations_run: int
+    final_background: float
+    stars_masked: int
+    mask_coverage: float
+    converged: bool
+
+
+def generate_star_mask(image, growth_factor=2.5, softness=4.0, detection_sigma=5.0, min_fwhm=1.5, max_fwhm=30.0,
+                       luminance_protect=False, luminance_ceiling=0.85, stars=None) -> StarMaskResult:
+    """star_mask.rs:38-138; stars = [(x, y, fwhm)] or DetectedStar list selects generate_star_mask_from_detection."""
+    L = lib()
+    dp = C.POINTER(C.c_double)
+    L.orc_star_mask_from_stars.restype = C.c_size_t
+    L.orc_star_mask_from_stars.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, dp, dp, dp, C.c_size_t, C.c_double,
+                                           C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_float), dp]
+    L.orc_generate_star_mask.restype = C.c_size_t
+    L.orc_generate_star_mask.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, C.c_double, C.c_int, C.c_double, C.POINTER(C.c_float), dp]
+    im = _f32(image)
+    mask = np.zeros_like(im)
+    cov = C.c_double(0.0)
+    if stars is None:
+        n = L.orc_generate_star_mask(_fp(im), im.shape[0], im.shape[1], growth_factor, softness, detection_sigma, min_fwhm,
+                                     max_fwhm, int(bool(luminance_protect)), luminance_ceiling, _fp(mask), C.byref(cov))
+    else:
+        xyz = np.array([(s.x, s.y, s.fwhm) if hasattr(s, "fwhm") else tuple(s) for s in stars], np.float64).reshape(-1, 3)
+        xs, ys, fw = (np.ascontiguousarray(xyz[:, k]) for k in range(3))
+        n = L.orc_star_mask_from_stars(_fp(im), im.shape[0], im.shape[1], xs.ctypes.data_as(dp), ys.ctypes.data_as(dp),
+                                       fw.ctypes.data_as(dp), len(xs), growth_factor, softness, min_fwhm, max_fwhm,
+                                       int(bool(luminance_protect)), luminance_ceiling, _fp(mask), C.byref(cov))
+    return StarMaskResult(mask, int(n), float(cov.value))
+
+
+def masked_stretch(image, iterations=10, target_background=0.25, mask_growth=2.5, mask_softness=4.0, luminance_protect=True,
+                   luminance_ceiling=0.85, protection_amount=0.85, convergence_threshold=1e-5, mask=None) -> MaskedStretchResult:
+    """masked_stretch (masked_stretch.rs:44-58) / masked_stretch_with_mask (:60-118) when mask is given."""
+    L = lib()
+    L.orc_masked_stretch_with_mask.restype = None
+    L.orc_masked_stretch_with_mask.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_double,
+                                               C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_size_t),
+                                               C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    im = _f32(image)
+    if mask is None:
+        mask = generate_star_mask(im, growth_factor=mask_growth, softness=mask_softness, luminance_protect=luminance_protect,
+                                  luminance_ceiling=luminance_ceiling)
+    mk = _f32(mask.mask)
+    out = np.zeros_like(im)
+    it, fb, cv = C.c_size_t(0), C.c_double(0.0), C.c_int(0)
+    L.orc_masked_stretch_with_mask(_fp(im), _fp(mk), im.size, iterations, target_background, protection_amount,
+                                   convergence_threshold, _fp(out), C.byref(it), C.byref(fb), C.byref(cv))
+    return MaskedStretchResult(out, int(it.value), float(fb.value), mask.stars_masked, mask.coverage_fraction, bool(cv.value))
+
+
+def masked_stretch_luminance(r, g, b) -> np.ndarray:
+    """compute_luminance (masked_stretch.rs:120-153): non-finite -> 0, 0.2126 r + 0.7152 g + 0.0722 b in f32."""
+    rn, gn, bn = (np.where(np.isfinite(x), x, np.float32(0)).astype(np.float32) for x in (_f32(r), _f32(g), _f32(b)))
+    return (np.float32(0.2126) * rn + np.float32(0.7152) * gn) + np.float32(0.0722) * bn
+
+
+def masked_stretch_rgb_shared(r, g, b, **cfg):
+    """masked_stretch_rgb_shared (masked_stretch.rs:155-193)."""
+    lum = masked_stretch_luminance(r, g, b)
+    mask = generate_star_mask(lum, growth_factor=cfg.get("mask_growth", 2.5), softness=cfg.get("mask_softness", 4.0),
+                              luminance_protect=cfg.get("luminance_protect", True),
+                              luminance_ceiling=cfg.get("luminance_ceiling", 0.85))
+    return tuple(masked_stretch(x, mask=mask, **cfg) for x in (r, g, b)) + (mask,)
+
+
 def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
