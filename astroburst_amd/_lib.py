@@ -106,6 +106,18 @@ class MaskedStretchResultC(C.Structure):  # masked_stretch.rs:34-42
                 ("mask_coverage", C.c_double), ("converged", C.c_int)]
 
 
+class RgbComposeConfigC(C.Structure):  # types/compose.rs:47-75
+    _fields_ = [("white_balance", C.c_int32), ("wb_manual", C.c_double * 3), ("auto_stretch", C.c_int32),
+                ("linked_stf", C.c_int32), ("has_stf", C.c_int32 * 3), ("stf", StfParamsC * 3), ("align", C.c_int32),
+                ("align_method", C.c_int32), ("has_scnr", C.c_int32), ("scnr", ScnrConfigC), ("num_threads", C.c_int32)]
+
+
+class ProcessedRgbInfoC(C.Structure):  # rgb.rs:18-40
+    _fields_ = [("rows", C.c_uint64), ("cols", C.c_uint64), ("stf", StfParamsC * 3), ("chan_stats", (C.c_double * 4) * 3),
+                ("offset_g", C.c_double * 2), ("offset_b", C.c_double * 2), ("scnr_applied", C.c_int32),
+                ("resampled", C.c_int32), ("stats_wb", ImageStatsC * 3)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into astroburst_amd/libastroburst_hip.so."""
     cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
@@ -198,6 +210,10 @@ def lib() -> C.CDLL:
                                               C.POINTER(MaskedStretchResultC)]
     L.ab_masked_stretch_rgb_shared.argtypes = [vp, pp, pp, pp, C.POINTER(MaskedStretchConfigC), pp, pp, pp,
                                                C.POINTER(MaskedStretchResultC), C.POINTER(StarMaskInfoC)]
+    L.ab_resample_image.argtypes = [vp, pp, pp]
+    L.ab_select_wb_reference.argtypes = [C.POINTER(ImageStatsC)] * 3 + [C.POINTER(C.c_double)]
+    L.ab_process_rgb.argtypes = [vp, pp, pp, pp, C.POINTER(RgbComposeConfigC), pp, pp, pp, pp, pp, pp,
+                                 C.POINTER(ProcessedRgbInfoC)]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift

@@ -41,6 +41,23 @@ class StfParams:  # types/image.rs:36-50
 
 
 @dataclass
+class ProcessedRgb:  # rgb.rs:18-40
+    r: object
+    g: object
+    b: object
+    rows: int
+    cols: int
+    stf: tuple            # (StfParams r, g, b)
+    channel_stats: tuple  # 3 x (min, max, median, mean) before white balance
+    offset_g: tuple
+    offset_b: tuple
+    scnr_applied: bool
+    resampled: bool
+    pre_stretch: tuple    # (r, g, b) white-balanced, pre-STF planes (or Nones)
+    stats_wb: tuple       # 3 x ImageStats after white balance
+
+
+@dataclass
 class StarMaskResult:  # star_mask.rs:32-37
     mask: object
     stars_masked: int
@@ -544,6 +561,71 @@ class Context:
         self._check(self._L.ab_extract_background(self._h, C.byref(pi), C.byref(cfg), pm, C.byref(pc), C.byref(info)))
         return BackgroundResult(model, corrected, int(info.sample_count), float(info.rms_residual),
                                 np.array(info.coeffs[:], dtype=np.float64))
+
+    # ---- a17 RGB composition -------------------------------------------------------------------------
+    def resample_image(self, image, target_rows: int, target_cols: int, out=None):
+        """resample_image(image, target_rows, target_cols) (resample.rs:25-61)"""
+        keep = []
+        pi = self._plane(image, keep)
+        if out is None:
+            out = self._new_like(image, target_rows, target_cols)
+        po = self._out_plane(out, keep, target_rows, target_cols)
+        self._check(self._L.ab_resample_image(self._h, C.byref(pi), C.byref(po)))
+        return out
+
+    def select_wb_reference(self, sr: ImageStats, sg: ImageStats, sb: ImageStats):
+        """select_wb_reference (white_balance.rs:3-20) -> (wb_r, wb_g, wb_b)"""
+        out = (C.c_double * 3)()
+        rc = self._L.ab_select_wb_reference(*[C.byref(self._stats_in(s)) for s in (sr, sg, sb)], out)
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "select_wb_reference: null argument")
+        return tuple(out)
+
+    def process_rgb(self, r, g, b, white_balance="auto", auto_stretch=True, stf=(None, None, None), linked_stf=False,
+                    align=True, align_method="phase_correlation", scnr=None, num_threads=8, want_pre_stretch=True
+                    ) -> ProcessedRgb:
+        """process_rgb(r?, g?, b?, &RgbComposeConfig) (rgb.rs:209-323).  Absent channels are None.
+        white_balance: "auto" | "none" | (r, g, b) manual multipliers; stf: per-channel StfParams or None (used when
+        auto_stretch is False); scnr: None or dict(method=, amount=, preserve_luminance=)."""
+        keep = []
+        chans = [None if x is None else self._plane(x, keep) for x in (r, g, b)]
+        present = [p for p in chans if p is not None]
+        first = next((x for x in (r, g, b) if x is not None), None)
+        rows = max((p.rows for p in present), default=0)
+        cols = max((p.cols for p in present), default=0)
+        cfg = _lib.RgbComposeConfigC()
+        if isinstance(white_balance, str):
+            cfg.white_balance = {"auto": 0, "none": 2}[white_balance]
+        else:
+            cfg.white_balance = 1
+            cfg.wb_manual[:] = [float(v) for v in white_balance]
+        cfg.auto_stretch, cfg.linked_stf = int(bool(auto_stretch)), int(bool(linked_stf))
+        for c, p in enumerate(stf):
+            if p is not None:
+                cfg.has_stf[c] = 1
+                cfg.stf[c] = StfParamsC(p.shadow, p.midtone, p.highlight)
+        cfg.align = int(bool(align))
+        cfg.align_method = {"phase_correlation": 0, "affine": 1}[align_method]
+        if scnr is not None:
+            cfg.has_scnr = 1
+            m = scnr.get("method", "average")
+            cfg.scnr = _lib.ScnrConfigC(0 if m in ("average", "AverageNeutral", 0) else 1, scnr.get("amount", 1.0),
+                                        int(bool(scnr.get("preserve_luminance", False))))
+        cfg.num_threads = num_threads
+        if first is None:
+            first = np.empty((0, 0), np.float32)
+        outs = [self._new_like(first, rows, cols) for _ in range(3)]
+        pos = [self._out_plane(o, keep, rows, cols) for o in outs]
+        pres = [self._new_like(first, rows, cols) if want_pre_stretch else None for _ in range(3)]
+        pps = [None if p is None else C.byref(self._out_plane(p, keep, rows, cols)) for p in pres]
+        info = _lib.ProcessedRgbInfoC()
+        self._check(self._L.ab_process_rgb(self._h, *[None if p is None else C.byref(p) for p in chans], C.byref(cfg),
+                                           *[C.byref(p) for p in pos], *pps, C.byref(info)))
+        return ProcessedRgb(outs[0], outs[1], outs[2], int(info.rows), int(info.cols),
+                            tuple(StfParams(p.shadow, p.midtone, p.highlight) for p in info.stf),
+                            tuple(tuple(row) for row in info.chan_stats), tuple(info.offset_g), tuple(info.offset_b),
+                            bool(info.scnr_applied), bool(info.resampled), tuple(pres),
+                            tuple(self._stats_out(s) for s in info.stats_wb))
 
     # ---- a13 star mask + masked stretch ---------------------------------------------------------------
     @staticmethod

@@ -100,4 +100,14 @@ int ab_stats_device(ab_ctx *ctx, const float *data, int64_t n, int use_known, do
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out);
 
+int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, int64_t ref_cols, int64_t ref_ld, const float *tgt,
+                              int64_t tgt_rows, int64_t tgt_cols, int64_t tgt_ld, double *dx, double *dy, double *confidence);
+int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
+                                   ab_affine_align_result *out);
+int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, int64_t src_ld, double dy, double dx, float *out);
+int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
+                   int64_t out_cols, float *out);
+int ab_resample_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, int64_t out_rows, int64_t out_cols,
+                       float *out);
+
 static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

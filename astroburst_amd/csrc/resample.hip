@@ -1,7 +1,8 @@
 // Sub-pixel registration resampling on gfx950: bicubic (Catmull-Rom) shift and affine warp.
 //
 // Replaces core/stacking/align.rs:36-57 (shift_image_subpixel),
-// core/alignment/affine.rs:663-690 (warp_image) and the sampler they share,
+// core/alignment/affine.rs:663-690 (warp_image),
+// core/imaging/resample.rs:25-61 (resample_image) and the sampler they share,
 // core/imaging/sampling.rs:4-14,51-80 (catmull_rom, bicubic_sample) with
 // core/imaging/boundary.rs:9-20 (clamp_index).
 //
@@ -96,7 +97,40 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
     out[(size_t)y * out_cols + x] = r;
 }
 
+// resample.rs:41-58: target pixel centres mapped onto the source grid
+__global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__ src, int src_rows, int src_cols, double scale_y,
+                                                       double scale_x, double half_shift_y, double half_shift_x, int out_cols,
+                                                       float *__restrict__ out) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= out_cols) return;
+    const double sy = (double)y * scale_y + half_shift_y;
+    const double sx = (double)x * scale_x + half_shift_x;
+    out[(size_t)y * out_cols + x] = bicubic_sample(src, src_rows, src_cols, src_cols, sy, sx);
+}
+
 }  // namespace
+
+// resample_image (core/imaging/resample.rs:25-61) on device planes
+int ab_resample_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, int64_t out_rows, int64_t out_cols,
+                       float *out) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    if (out_rows == 0 || out_cols == 0) return ab_set_error(ctx, AB_ERR_INVALID, "Target dimensions must be > 0");  // :32-34
+    if (out_rows == src_rows && out_cols == src_cols) {  // :36-38
+        if (src != out) AB_HIP(ctx, hipMemcpyAsync(out, src, (size_t)src_rows * src_cols * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return AB_OK;
+    }
+    AB_CHECK(ctx, src != out, "resample_image cannot run in place");
+    AB_CHECK(ctx, src_rows > 0 && src_cols > 0, "resample_image: empty source");
+    AB_CHECK(ctx, out_rows <= 65535 && out_rows * out_cols < (int64_t(1) << 31) && src_rows * src_cols < (int64_t(1) << 31),
+             "image of %lld x %lld needs a tiled launch (not in this build)", (long long)out_rows, (long long)out_cols);
+    const double scale_y = (double)src_rows / (double)out_rows, scale_x = (double)src_cols / (double)out_cols;
+    const dim3 grid((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block(256);
+    hipLaunchKernelGGL(resample_kernel, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, scale_y, scale_x,
+                       (scale_y - 1.0) * 0.5, (scale_x - 1.0) * 0.5, (int)out_cols, out);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
 
 // src is a rows x cols window with row stride src_ld (>= cols); out is contiguous rows x cols
 int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, int64_t src_ld, double dy, double dx, float *out) {
@@ -159,6 +193,25 @@ int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], a
     int rc = ab_stage_out_begin(ctx, out, &so);
     if (rc == AB_OK) {
         rc = ab_warp_device(ctx, in.dptr, in.rows, in.cols, transform, out->rows, out->cols, so.dptr);
+        if (rc == AB_OK)
+            rc = ab_stage_out_finish(ctx, &so);
+        else
+            ab_stage_out_abort(ctx, &so);
+    }
+    ab_stage_release(ctx, &in);
+    return rc;
+}
+
+int ab_resample_image(ab_ctx *ctx, const ab_plane *src, ab_plane_mut *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, src && out, "null plane");
+    if (out->rows == 0 || out->cols == 0) return ab_set_error(ctx, AB_ERR_INVALID, "Target dimensions must be > 0");  // :32-34
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, src, &in));
+    StagedOut so;
+    int rc = ab_stage_out_begin(ctx, out, &so);
+    if (rc == AB_OK) {
+        rc = ab_resample_device(ctx, in.dptr, in.rows, in.cols, out->rows, out->cols, so.dptr);
         if (rc == AB_OK)
             rc = ab_stage_out_finish(ctx, &so);
         else

@@ -316,6 +316,39 @@ AB_API int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab
                                         const ab_masked_stretch_config *cfg, ab_plane_mut *out_r, ab_plane_mut *out_g,
                                         ab_plane_mut *out_b, ab_masked_stretch_result *res3, ab_star_mask_info *shared);
 
+/* ---- a17  core/compose/rgb.rs, white_balance.rs, core/imaging/resample.rs ----------------------------------------- */
+/* resample_image(image, target_rows, target_cols) (resample.rs:25-61): bicubic resize to out's dims */
+AB_API int ab_resample_image(ab_ctx *ctx, const ab_plane *src, ab_plane_mut *out);
+/* select_wb_reference (white_balance.rs:3-20): multipliers (r, g, b) against the most stable channel (host maths) */
+AB_API int ab_select_wb_reference(const ab_image_stats *sr, const ab_image_stats *sg, const ab_image_stats *sb,
+                                  double out_rgb[3]);
+typedef struct { /* RgbComposeConfig, types/compose.rs:47-75 */
+    int32_t white_balance;      /* WhiteBalance: 0 Auto, 1 Manual(wb_manual), 2 None */
+    double wb_manual[3];
+    int32_t auto_stretch, linked_stf;
+    int32_t has_stf[3];         /* Option<StfParams> stf_r / stf_g / stf_b (used when !auto_stretch) */
+    ab_stf_params stf[3];
+    int32_t align, align_method; /* AlignMethod: 0 PhaseCorrelation, 1 Affine */
+    int32_t has_scnr;           /* Option<ScnrConfig> */
+    ab_scnr_config scnr;
+    int32_t num_threads;        /* rayon::current_num_threads() of the host being replaced (affine RANSAC seeds) */
+} ab_rgb_compose_config;
+typedef struct { /* scalars of ProcessedRgb, rgb.rs:18-40 */
+    uint64_t rows, cols;
+    ab_stf_params stf[3];
+    double chan_stats[3][4];    /* ChannelStats {min, max, median, mean} per channel, before white balance */
+    double offset_g[2], offset_b[2]; /* (dy, dx) resp. (ty, tx) */
+    int32_t scnr_applied, resampled;
+    ab_image_stats stats_wb[3]; /* stats after white balance (the ones the STF is applied with) */
+} ab_processed_rgb_info;
+/* process_rgb(r?, g?, b?, &config) (rgb.rs:209-323): harmonise dims (bicubic up to the largest), synthesise a missing
+ * channel, align G and B to the first present channel, white balance, (linked) auto-STF, compose-local STF
+ * (rgb.rs:191-207), SCNR.  Absent channels are NULL; at least two must be present.  out_* (and the nullable
+ * pre_* = white-balanced, pre-stretch copies) must have the largest channel's dims. */
+AB_API int ab_process_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b,
+                          const ab_rgb_compose_config *cfg, ab_plane_mut *out_r, ab_plane_mut *out_g, ab_plane_mut *out_b,
+                          ab_plane_mut *pre_r, ab_plane_mut *pre_g, ab_plane_mut *pre_b, ab_processed_rgb_info *info);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

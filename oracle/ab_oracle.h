@@ -197,6 +197,37 @@ void orc_masked_stretch_with_mask(const float *image, const float *mask, size_t 
                                   double protection_amount, double convergence_threshold, float *out,
                                   size_t *iterations_run_out, double *final_bg_out, int *converged_out); /* :60-118 */
 
+/* ---- core/compose/rgb.rs, white_balance.rs, core/imaging/resample.rs (orc_compose.c) ----------- */
+int orc_resample_image(const float *src, size_t src_rows, size_t src_cols, size_t target_rows, size_t target_cols,
+                       float *out);                                                  /* resample.rs:25-61 */
+void orc_select_wb_reference(const orc_image_stats *sr, const orc_image_stats *sg, const orc_image_stats *sb,
+                             double out[3]);                                         /* white_balance.rs:3-20 */
+void orc_compose_apply_stf_inplace(float *data, size_t n, const orc_stf_params *p, const orc_image_stats *st); /* rgb.rs:191-207 */
+typedef struct { /* RgbComposeConfig, types/compose.rs:47-75 */
+    int32_t white_balance;          /* 0 Auto, 1 Manual(wb_manual), 2 None */
+    double wb_manual[3];
+    int32_t auto_stretch, linked_stf;
+    int32_t has_stf[3];
+    orc_stf_params stf[3];
+    int32_t align, align_method;    /* AlignMethod: 0 PhaseCorrelation, 1 Affine */
+    int32_t has_scnr, scnr_method;
+    float scnr_amount;
+    int32_t scnr_preserve;
+    int32_t num_threads;            /* pins rayon's worker count for the affine RANSAC */
+} orc_rgb_config;
+typedef struct { /* scalars of ProcessedRgb, rgb.rs:18-40 */
+    uint64_t rows, cols;
+    orc_stf_params stf[3];
+    double chan_stats[3][4];        /* ChannelStats {min, max, median, mean} before white balance */
+    double offset_g[2], offset_b[2];
+    int32_t scnr_applied, resampled;
+    orc_image_stats stats_wb[3];
+} orc_rgb_result;
+int orc_process_rgb(const float *r, size_t r_rows, size_t r_cols, const float *g, size_t g_rows, size_t g_cols,
+                    const float *b, size_t b_rows, size_t b_cols, const orc_rgb_config *cfg, float *out_r, float *out_g,
+                    float *out_b, float *pre_r, float *pre_g, float *pre_b, orc_rgb_result *res, char *err,
+                    size_t err_cap);                                                 /* rgb.rs:209-323 */
+
 /* utility */
 int orc_max_threads(void);
 

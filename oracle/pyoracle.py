@@ -516,6 +516,115 @@ def masked_stretch_rgb_shared(r, g, b, **cfg):
     return tuple(masked_stretch(x, mask=mask, **cfg) for x in (r, g, b)) + (mask,)
 
 
+class _RgbConfig(C.Structure):  # orc_rgb_config
+    _fields_ = [("white_balance", C.c_int32), ("wb_manual", C.c_double * 3), ("auto_stretch", C.c_int32),
+                ("linked_stf", C.c_int32), ("has_stf", C.c_int32 * 3), ("stf", _Stf * 3), ("align", C.c_int32),
+                ("align_method", C.c_int32), ("has_scnr", C.c_int32), ("scnr_method", C.c_int32),
+                ("scnr_amount", C.c_float), ("scnr_preserve", C.c_int32), ("num_threads", C.c_int32)]
+
+
+class _RgbResult(C.Structure):  # orc_rgb_result
+    _fields_ = [("rows", C.c_uint64), ("cols", C.c_uint64), ("stf", _Stf * 3), ("chan_stats", (C.c_double * 4) * 3),
+                ("offset_g", C.c_double * 2), ("offset_b", C.c_double * 2), ("scnr_applied", C.c_int32),
+                ("resampled", C.c_int32), ("stats_wb", _Stats * 3)]
+
+
+@dataclass
+class ProcessedRgb:  # rgb.rs:18-40
+    r: np.ndarray
+    g: np.ndarray
+    b: np.ndarray
+    rows: int
+    cols: int
+    stf: tuple
+    channel_stats: tuple
+    offset_g: tuple
+    offset_b: tuple
+    scnr_applied: bool
+    resampled: bool
+    pre_stretch: tuple
+    stats_wb: tuple
+
+
+def resample_image(image, target_rows: int, target_cols: int) -> np.ndarray:
+    """resample.rs:25-61"""
+    L = lib()
+    L.orc_resample_image.restype = C.c_int
+    L.orc_resample_image.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]
+    im = _f32(image)
+    out = np.zeros((target_rows, target_cols), np.float32)
+    if L.orc_resample_image(_fp(im), im.shape[0], im.shape[1], target_rows, target_cols, _fp(out)) != 0:
+        raise ValueError("Target dimensions must be > 0")
+    return out
+
+
+def select_wb_reference(sr: ImageStats, sg: ImageStats, sb: ImageStats):
+    """white_balance.rs:3-20"""
+    L = lib()
+    L.orc_select_wb_reference.argtypes = [C.POINTER(_Stats)] * 3 + [C.POINTER(C.c_double)]
+    out = (C.c_double * 3)()
+    L.orc_select_wb_reference(*[C.byref(_stats_in(s)) for s in (sr, sg, sb)], out)
+    return tuple(out)
+
+
+def compose_apply_stf(image, params: StfParams, stats: ImageStats) -> np.ndarray:
+    """the compose-local apply_stf_inplace (rgb.rs:191-207)"""
+    L = lib()
+    L.orc_compose_apply_stf_inplace.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(_Stf), C.POINTER(_Stats)]
+    out = _f32(image).copy()
+    p = _Stf(params.shadow, params.midtone, params.highlight)
+    L.orc_compose_apply_stf_inplace(_fp(out), out.size, C.byref(p), C.byref(_stats_in(stats)))
+    return out
+
+
+def process_rgb(r, g, b, white_balance="auto", auto_stretch=True, stf=(None, None, None), linked_stf=False, align=True,
+                align_method="phase_correlation", scnr=None, num_threads=8) -> ProcessedRgb:
+    """process_rgb (rgb.rs:209-323); raises ValueError with the reference's message on its Err paths."""
+    L = _pc_protos()
+    _det_protos()
+    fp = C.POINTER(C.c_float)
+    L.orc_process_rgb.restype = C.c_int
+    L.orc_process_rgb.argtypes = [fp, C.c_size_t, C.c_size_t] * 3 + [C.POINTER(_RgbConfig)] + [fp] * 6 + [
+        C.POINTER(_RgbResult), C.c_char_p, C.c_size_t]
+    chans = [None if x is None else _f32(x) for x in (r, g, b)]
+    present = [x for x in chans if x is not None]
+    rows = max((x.shape[0] for x in present), default=0)
+    cols = max((x.shape[1] for x in present), default=0)
+    cfg = _RgbConfig()
+    if isinstance(white_balance, str):
+        cfg.white_balance = {"auto": 0, "none": 2}[white_balance]
+    else:
+        cfg.white_balance = 1
+        cfg.wb_manual[:] = [float(v) for v in white_balance]
+    cfg.auto_stretch, cfg.linked_stf = int(bool(auto_stretch)), int(bool(linked_stf))
+    for c, p in enumerate(stf):
+        if p is not None:
+            cfg.has_stf[c] = 1
+            cfg.stf[c] = _Stf(p.shadow, p.midtone, p.highlight)
+    cfg.align = int(bool(align))
+    cfg.align_method = {"phase_correlation": 0, "affine": 1}[align_method]
+    if scnr is not None:
+        cfg.has_scnr = 1
+        cfg.scnr_method = 0 if scnr.get("method", "average") in ("average", "AverageNeutral", 0) else 1
+        cfg.scnr_amount = scnr.get("amount", 1.0)
+        cfg.scnr_preserve = int(bool(scnr.get("preserve_luminance", False)))
+    cfg.num_threads = num_threads
+    outs = [np.zeros((rows, cols), np.float32) for _ in range(6)]
+    res = _RgbResult()
+    err = C.create_string_buffer(512)
+    args = []
+    for x in chans:
+        args += [None, 0, 0] if x is None else [_fp(x), x.shape[0], x.shape[1]]
+    rc = L.orc_process_rgb(*args, C.byref(cfg), *[_fp(o) for o in outs], C.byref(res), err, 512)
+    if rc != 0:
+        raise ValueError(err.value.decode())
+    return ProcessedRgb(outs[0], outs[1], outs[2], int(res.rows), int(res.cols),
+                        tuple(StfParams(p.shadow, p.midtone, p.highlight) for p in res.stf),
+                        tuple(tuple(row) for row in res.chan_stats), tuple(res.offset_g), tuple(res.offset_b),
+                        bool(res.scnr_applied), bool(res.resampled), tuple(outs[3:]),
+                        tuple(_stats_out(s) for s in res.stats_wb))
+
+
 def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
