@@ -118,6 +118,16 @@ class ProcessedRgbInfoC(C.Structure):  # rgb.rs:18-40
                 ("resampled", C.c_int32), ("stats_wb", ImageStatsC * 3)]
 
 
+class SpccConfigC(C.Structure):  # spcc.rs:9-28
+    _fields_ = [("min_snr", C.c_double), ("max_stars", C.c_uint64), ("saturation_limit", C.c_double),
+                ("white_reference", C.c_int32), ("custom", C.c_double * 3)]
+
+
+class SpccResultC(C.Structure):  # spcc.rs:45-56
+    _fields_ = [("r_factor", C.c_double), ("g_factor", C.c_double), ("b_factor", C.c_double),
+                ("stars_matched", C.c_uint64), ("stars_total", C.c_uint64), ("avg_color_index", C.c_double)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into astroburst_amd/libastroburst_hip.so."""
     cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
@@ -214,6 +224,10 @@ def lib() -> C.CDLL:
     L.ab_select_wb_reference.argtypes = [C.POINTER(ImageStatsC)] * 3 + [C.POINTER(C.c_double)]
     L.ab_process_rgb.argtypes = [vp, pp, pp, pp, C.POINTER(RgbComposeConfigC), pp, pp, pp, pp, pp, pp,
                                  C.POINTER(ProcessedRgbInfoC)]
+    L.ab_spcc_calibrate_rgb.argtypes = [vp, pp, pp, pp, C.c_double, C.POINTER(SpccConfigC), C.POINTER(SpccResultC)]
+    L.ab_spcc_from_detection.argtypes = [vp, pp, pp, pp, C.POINTER(DetectedStarC), C.c_size_t, C.c_double, C.c_double,
+                                         C.POINTER(SpccConfigC), C.POINTER(SpccResultC)]
+    L.ab_spcc_white_reference_rgb.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift

@@ -40,6 +40,22 @@ class StfParams:  # types/image.rs:36-50
     highlight: float = 1.0
 
 
+WHITE_REFERENCES = {"average_spiral": 0, "g2v": 1, "photopic": 2}
+
+
+@dataclass
+class SpccResult:  # spcc.rs:45-56
+    r_factor: float
+    g_factor: float
+    b_factor: float
+    stars_matched: int
+    stars_total: int
+    avg_color_index: float
+    white_ref_name: str
+    catalog_name: str = "Built-in Bp-Rp"
+    is_synthetic_catalog: bool = True
+
+
 @dataclass
 class ProcessedRgb:  # rgb.rs:18-40
     r: object
@@ -626,6 +642,49 @@ class Context:
                             tuple(tuple(row) for row in info.chan_stats), tuple(info.offset_g), tuple(info.offset_b),
                             bool(info.scnr_applied), bool(info.resampled), tuple(pres),
                             tuple(self._stats_out(s) for s in info.stats_wb))
+
+    # ---- a18 spectrophotometric colour calibration -------------------------------------------------------
+    @staticmethod
+    def _spcc_cfg(min_snr, max_stars, saturation_limit, white_reference):
+        cfg = _lib.SpccConfigC(min_snr, max_stars, saturation_limit, 0, (C.c_double * 3)(0, 0, 0))
+        if isinstance(white_reference, str):
+            cfg.white_reference = WHITE_REFERENCES[white_reference]
+            name = {"average_spiral": "Average Spiral Galaxy", "g2v": "G2V (Solar)", "photopic": "Photopic (Human Eye)"}[white_reference]
+        else:
+            cfg.white_reference = 3
+            cfg.custom[:] = [float(v) for v in white_reference]
+            name = "Custom ({:.2f},{:.2f},{:.2f})".format(*cfg.custom)
+        return cfg, name
+
+    def spcc_calibrate_rgb(self, r, g, b, pixel_scale_arcsec: float, min_snr=20.0, max_stars=200, saturation_limit=0.90,
+                           white_reference="average_spiral", detection=None) -> SpccResult:
+        """spcc_calibrate_rgb (spcc.rs:73-183), built-in Bp-Rp catalogue; pixel_scale_arcsec = WCS pixel scale.
+        detection=(stars, lum_max) runs the part after detect_stars on a given detection (:90-183)."""
+        keep = []
+        ps = [self._plane(x, keep) for x in (r, g, b)]
+        cfg, name = self._spcc_cfg(min_snr, max_stars, saturation_limit, white_reference)
+        res = _lib.SpccResultC()
+        if detection is None:
+            rc = self._L.ab_spcc_calibrate_rgb(self._h, *[C.byref(p) for p in ps], pixel_scale_arcsec, C.byref(cfg), C.byref(res))
+        else:
+            stars, lum_max = detection
+            buf = (_lib.DetectedStarC * max(len(stars), 1))()
+            for d, s in zip(buf, stars):
+                d.x, d.y, d.flux, d.fwhm, d.eccentricity, d.peak, d.snr, d.npix = (s.x, s.y, s.flux, s.fwhm, s.eccentricity,
+                                                                                   s.peak, s.snr, s.npix)
+            rc = self._L.ab_spcc_from_detection(self._h, *[C.byref(p) for p in ps], buf, len(stars), lum_max,
+                                                pixel_scale_arcsec, C.byref(cfg), C.byref(res))
+        self._check(rc)
+        return SpccResult(res.r_factor, res.g_factor, res.b_factor, int(res.stars_matched), int(res.stars_total),
+                          res.avg_color_index, name)
+
+    def spcc_white_reference_rgb(self, white_reference="average_spiral"):
+        cfg, _ = self._spcc_cfg(20.0, 200, 0.9, white_reference)
+        out = (C.c_double * 3)()
+        rc = self._L.ab_spcc_white_reference_rgb(cfg.white_reference, cfg.custom, out)
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "spcc_white_reference_rgb: invalid argument")
+        return tuple(out)
 
     # ---- a13 star mask + masked stretch ---------------------------------------------------------------
     @staticmethod

@@ -349,6 +349,33 @@ AB_API int ab_process_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, con
                           const ab_rgb_compose_config *cfg, ab_plane_mut *out_r, ab_plane_mut *out_g, ab_plane_mut *out_b,
                           ab_plane_mut *pre_r, ab_plane_mut *pre_g, ab_plane_mut *pre_b, ab_processed_rgb_info *info);
 
+/* ---- a18  core/astrometry/spcc.rs -------------------------------------------------------------------------------- */
+typedef struct { /* SpccConfig, spcc.rs:9-28 (defaults 20.0, 200, 0.90, AverageSpiral; catalog = BuiltinBpRp) */
+    double min_snr;
+    uint64_t max_stars;
+    double saturation_limit;
+    int32_t white_reference; /* WhiteReference: 0 AverageSpiral, 1 G2V, 2 Photopic, 3 Custom(custom) */
+    double custom[3];
+} ab_spcc_config;
+typedef struct { /* the numbers of SpccResult, spcc.rs:45-56 */
+    double r_factor, g_factor, b_factor;
+    uint64_t stars_matched, stars_total;
+    double avg_color_index;
+} ab_spcc_result;
+/* spcc_calibrate_rgb(r, g, b, header, config) (spcc.rs:73-183) with the built-in Bp-Rp catalogue.  The header's
+ * WCS enters that path only through its pixel scale (the catalogue is synthesised from the detections' own
+ * sky positions, :257-273, so the cross-match is the identity whenever pixel_scale > 0): the caller passes
+ * WcsTransform::pixel_scale_arcsec().  Err strings as the reference ("Only N stars passed quality filters
+ * (need 5+). Try lowering min_snr." / "Only N stars cross-matched (need 3+). Check WCS solution quality."). */
+AB_API int ab_spcc_calibrate_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b,
+                                 double pixel_scale_arcsec, const ab_spcc_config *cfg, ab_spcc_result *res);
+/* the part after detection (spcc.rs:90-183) on a given detect_stars() result and luminance maximum */
+AB_API int ab_spcc_from_detection(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b,
+                                  const ab_detected_star *stars, size_t n_stars, double lum_max, double pixel_scale_arcsec,
+                                  const ab_spcc_config *cfg, ab_spcc_result *res);
+/* white_reference_rgb (spcc.rs:245-255); host maths */
+AB_API int ab_spcc_white_reference_rgb(int32_t kind, const double custom[3], double out_rgb[3]);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

@@ -228,6 +228,27 @@ int orc_process_rgb(const float *r, size_t r_rows, size_t r_cols, const float *g
                     float *out_b, float *pre_r, float *pre_g, float *pre_b, orc_rgb_result *res, char *err,
                     size_t err_cap);                                                 /* rgb.rs:209-323 */
 
+/* ---- core/astrometry/spcc.rs (orc_spcc.c; the reference has no tests here: parity unpinned) ------- */
+typedef struct { /* SpccConfig, spcc.rs:9-28 (defaults 20.0, 200, 0.90, AverageSpiral) */
+    double min_snr;
+    uint64_t max_stars;
+    double saturation_limit;
+    int32_t white_reference;   /* 0 AverageSpiral, 1 G2V, 2 Photopic, 3 Custom(custom) */
+    double custom[3];
+} orc_spcc_config;
+typedef struct { /* SpccResult numbers, spcc.rs:45-56 */
+    double r_factor, g_factor, b_factor;
+    uint64_t stars_matched, stars_total;
+    double avg_color_index;
+} orc_spcc_result;
+void orc_spcc_white_reference_rgb(int kind, const double custom[3], double out[3]);                     /* :245-255 */
+double orc_aperture_flux_f32(const float *image, size_t h, size_t w, double x, double y, double radius); /* :341-383 */
+int orc_spcc_from_detection(const float *r, const float *g, const float *b, size_t h, size_t w, const orc_star *stars,
+                            size_t n_stars, double lum_max, double pixel_scale_arcsec, const orc_spcc_config *cfg,
+                            orc_spcc_result *res);                                                       /* :90-183 */
+int orc_spcc_calibrate_rgb(const float *r, const float *g, const float *b, size_t h, size_t w, double pixel_scale_arcsec,
+                           const orc_spcc_config *cfg, orc_spcc_result *res);                            /* :73-183 */
+
 /* utility */
 int orc_max_threads(void);
 

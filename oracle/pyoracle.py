@@ -625,6 +625,92 @@ def process_rgb(r, g, b, white_balance="auto", auto_stretch=True, stf=(None, Non
                         tuple(_stats_out(s) for s in res.stats_wb))
 
 
+class _SpccConfig(C.Structure):  # orc_spcc_config
+    _fields_ = [("min_snr", C.c_double), ("max_stars", C.c_uint64), ("saturation_limit", C.c_double),
+                ("white_reference", C.c_int32), ("custom", C.c_double * 3)]
+
+
+class _SpccResult(C.Structure):  # orc_spcc_result
+    _fields_ = [("r_factor", C.c_double), ("g_factor", C.c_double), ("b_factor", C.c_double),
+                ("stars_matched", C.c_uint64), ("stars_total", C.c_uint64), ("avg_color_index", C.c_double)]
+
+
+@dataclass
+class SpccResult:  # spcc.rs:45-56
+    r_factor: float
+    g_factor: float
+    b_factor: float
+    stars_matched: int
+    stars_total: int
+    avg_color_index: float
+
+
+_WHITE_REFS = {"average_spiral": 0, "g2v": 1, "photopic": 2}
+
+
+def _spcc_cfg(min_snr, max_stars, saturation_limit, white_reference) -> _SpccConfig:
+    cfg = _SpccConfig(min_snr, max_stars, saturation_limit, 0, (C.c_double * 3)(0, 0, 0))
+    if isinstance(white_reference, str):
+        cfg.white_reference = _WHITE_REFS[white_reference]
+    else:
+        cfg.white_reference = 3
+        cfg.custom[:] = [float(v) for v in white_reference]
+    return cfg
+
+
+def spcc_white_reference_rgb(white_reference="average_spiral"):
+    """white_reference_rgb (spcc.rs:245-255)"""
+    cfg = _spcc_cfg(20.0, 200, 0.9, white_reference)
+    out = (C.c_double * 3)()
+    L = lib()
+    L.orc_spcc_white_reference_rgb.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_spcc_white_reference_rgb(cfg.white_reference, cfg.custom, out)
+    return tuple(out)
+
+
+def aperture_flux_f32(image, x: float, y: float, radius: float) -> float:
+    """aperture_flux_f32 (spcc.rs:341-383)"""
+    L = lib()
+    L.orc_aperture_flux_f32.restype = C.c_double
+    L.orc_aperture_flux_f32.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_double]
+    im = _f32(image)
+    return float(L.orc_aperture_flux_f32(_fp(im), im.shape[0], im.shape[1], x, y, radius))
+
+
+def spcc_calibrate_rgb(r, g, b, pixel_scale_arcsec: float, min_snr=20.0, max_stars=200, saturation_limit=0.90,
+                       white_reference="average_spiral", detection=None) -> SpccResult:
+    """spcc_calibrate_rgb (spcc.rs:73-183); detection=(stars, lum_max) skips detect_stars (:90-183 only).
+    Raises ValueError with the reference's message on its Err paths."""
+    L = _det_protos()
+    fp = C.POINTER(C.c_float)
+    L.orc_spcc_calibrate_rgb.restype = C.c_int
+    L.orc_spcc_calibrate_rgb.argtypes = [fp, fp, fp, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(_SpccConfig),
+                                         C.POINTER(_SpccResult)]
+    L.orc_spcc_from_detection.restype = C.c_int
+    L.orc_spcc_from_detection.argtypes = [fp, fp, fp, C.c_size_t, C.c_size_t, C.POINTER(_Star), C.c_size_t, C.c_double,
+                                          C.c_double, C.POINTER(_SpccConfig), C.POINTER(_SpccResult)]
+    rr, gg, bb = _f32(r), _f32(g), _f32(b)
+    cfg = _spcc_cfg(min_snr, max_stars, saturation_limit, white_reference)
+    res = _SpccResult()
+    if detection is None:
+        rc = L.orc_spcc_calibrate_rgb(_fp(rr), _fp(gg), _fp(bb), rr.shape[0], rr.shape[1], pixel_scale_arcsec, C.byref(cfg),
+                                      C.byref(res))
+    else:
+        stars, lum_max = detection
+        buf = (_Star * max(len(stars), 1))()
+        for i, (d, s) in enumerate(zip(buf, stars)):
+            d.x, d.y, d.flux, d.fwhm, d.eccentricity, d.peak, d.snr, d.npix, d.order = (
+                s.x, s.y, s.flux, s.fwhm, s.eccentricity, s.peak, s.snr, s.npix, i)
+        rc = L.orc_spcc_from_detection(_fp(rr), _fp(gg), _fp(bb), rr.shape[0], rr.shape[1], buf, len(stars), lum_max,
+                                       pixel_scale_arcsec, C.byref(cfg), C.byref(res))
+    if rc == 1:
+        raise ValueError(f"Only {res.stars_total} stars passed quality filters (need 5+). Try lowering min_snr.")
+    if rc == 2:
+        raise ValueError(f"Only {res.stars_matched} stars cross-matched (need 3+). Check WCS solution quality.")
+    return SpccResult(res.r_factor, res.g_factor, res.b_factor, int(res.stars_matched), int(res.stars_total),
+                      res.avg_color_index)
+
+
 def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
