@@ -228,6 +228,12 @@ def lib() -> C.CDLL:
     L.ab_spcc_from_detection.argtypes = [vp, pp, pp, pp, C.POINTER(DetectedStarC), C.c_size_t, C.c_double, C.c_double,
                                          C.POINTER(SpccConfigC), C.POINTER(SpccResultC)]
     L.ab_spcc_white_reference_rgb.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ab_apply_lrgb.argtypes = [vp, pp, pp, pp, pp, C.c_float, C.c_float]
+    L.ab_synthesize_luminance.argtypes = [vp, pp, pp, pp, pp]
+    L.ab_compute_linked_stf.argtypes = [C.POINTER(ImageStatsC)] * 3 + [C.POINTER(AutoStfConfigC), C.POINTER(StfParamsC),
+                                                                       C.POINTER(ImageStatsC)]
+    L.ab_calibrate_channel.argtypes = [vp, pp, C.c_float, C.POINTER(ImageStatsC), pp, C.POINTER(ImageStatsC)]
+    L.ab_create_master.argtypes = [vp, C.c_int32, pp, C.c_size_t, pp, pp, pp]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift

@@ -643,6 +643,61 @@ class Context:
                             bool(info.scnr_applied), bool(info.resampled), tuple(pres),
                             tuple(self._stats_out(s) for s in info.stats_wb))
 
+    # ---- caller-side helpers of a17 / a20 ----------------------------------------------------------------
+    def apply_lrgb(self, l, r, g, b, lightness_weight=1.0, chrominance_weight=1.0):
+        """apply_lrgb(l, &mut r, &mut g, &mut b, lw, cw) (lrgb.rs:4-45); mutates r, g, b."""
+        keep = []
+        pl = self._plane(l, keep)
+        pr, pg, pb = (self._out_plane(x, keep, x.shape[0], x.shape[1]) for x in (r, g, b))
+        self._check(self._L.ab_apply_lrgb(self._h, C.byref(pl), C.byref(pr), C.byref(pg), C.byref(pb), lightness_weight,
+                                          chrominance_weight))
+
+    def synthesize_luminance(self, r, g, b, out=None):
+        """synthesize_luminance (lrgb.rs:47-64 / spcc.rs:185-196): no finite guard."""
+        keep = []
+        pr, pg, pb = (self._plane(x, keep) for x in (r, g, b))
+        if out is None:
+            out = self._new_like(r, pr.rows, pr.cols)
+        po = self._out_plane(out, keep, pr.rows, pr.cols)
+        self._check(self._L.ab_synthesize_luminance(self._h, C.byref(pr), C.byref(pg), C.byref(pb), C.byref(po)))
+        return out
+
+    def compute_linked_stf(self, sr: ImageStats, sg: ImageStats, sb: ImageStats, target_bg=0.25, shadow_k=-2.8):
+        """compute_linked_stf_with_stats (cmd/helpers.rs:185-202) -> (StfParams, combined ImageStats)"""
+        cfg = AutoStfConfigC(target_bg, shadow_k)
+        stf, comb = StfParamsC(), ImageStatsC()
+        rc = self._L.ab_compute_linked_stf(*[C.byref(self._stats_in(s)) for s in (sr, sg, sb)], C.byref(cfg), C.byref(stf),
+                                           C.byref(comb))
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "compute_linked_stf: null argument")
+        return StfParams(stf.shadow, stf.midtone, stf.highlight), self._stats_out(comb)
+
+    def calibrate_channel(self, orig, factor: float, orig_stats: ImageStats):
+        """calibrate_channel (cmd/compose/color.rs:21-49) -> (scaled plane, ImageStats)"""
+        keep = []
+        pi = self._plane(orig, keep)
+        out = self._new_like(orig, pi.rows, pi.cols)
+        po = self._out_plane(out, keep, pi.rows, pi.cols)
+        st = ImageStatsC()
+        self._check(self._L.ab_calibrate_channel(self._h, C.byref(pi), factor, C.byref(self._stats_in(orig_stats)),
+                                                 C.byref(po), C.byref(st)))
+        return out, self._stats_out(st)
+
+    def create_master(self, kind: str, frames, master_bias=None, master_dark=None):
+        """create_master_bias / _dark / _flat on in-memory frames (calibration.rs:127-255); kind in bias|dark|flat."""
+        keep = []
+        k = {"bias": 0, "dark": 1, "flat": 2}[kind]
+        if len(frames) == 0:
+            self._check(self._L.ab_create_master(self._h, k, None, 0, None, None, C.byref(Plane(None, 0, 0, 0))))
+        planes = (Plane * len(frames))(*[self._plane(f, keep) for f in frames])
+        rows, cols = planes[0].rows, planes[0].cols
+        out = self._new_like(frames[0], rows, cols)
+        po = self._out_plane(out, keep, rows, cols)
+        pb = None if master_bias is None else C.byref(self._plane(master_bias, keep))
+        pd = None if master_dark is None else C.byref(self._plane(master_dark, keep))
+        self._check(self._L.ab_create_master(self._h, k, planes, len(frames), pb, pd, C.byref(po)))
+        return out
+
     # ---- a18 spectrophotometric colour calibration -------------------------------------------------------
     @staticmethod
     def _spcc_cfg(min_snr, max_stars, saturation_limit, white_reference):

@@ -376,6 +376,29 @@ AB_API int ab_spcc_from_detection(ab_ctx *ctx, const ab_plane *r, const ab_plane
 /* white_reference_rgb (spcc.rs:245-255); host maths */
 AB_API int ab_spcc_white_reference_rgb(int32_t kind, const double custom[3], double out_rgb[3]);
 
+/* ---- caller-side helpers of a17 / a20 ---------------------------------------------------------------------------- */
+/* apply_lrgb(l, &mut r, &mut g, &mut b, lightness_weight, chrominance_weight) (core/compose/lrgb.rs:4-45); mutates
+ * r, g, b; Err "L dimensions .. do not match RGB (..)" on mismatched dims */
+AB_API int ab_apply_lrgb(ab_ctx *ctx, const ab_plane *l, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b,
+                         float lightness_weight, float chrominance_weight);
+/* lrgb.rs:47-64 synthesize_luminance (= spcc.rs:185-196): r*0.2126 + g*0.7152 + b*0.0722, NO finite guard
+ * (ab_luminance is the guarded masked_stretch.rs variant) */
+AB_API int ab_synthesize_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, ab_plane_mut *out);
+/* compute_linked_stf_with_stats (cmd/helpers.rs:185-202): auto_stf of the channel-averaged statistics (host maths);
+ * out_combined nullable */
+AB_API int ab_compute_linked_stf(const ab_image_stats *sr, const ab_image_stats *sg, const ab_image_stats *sb,
+                                 const ab_auto_stf_config *cfg, ab_stf_params *out_stf, ab_image_stats *out_combined);
+/* calibrate_channel (cmd/compose/color.rs:21-49): out = orig * factor, statistics of the result (known-range fast
+ * path above 4 000 000 px) */
+AB_API int ab_calibrate_channel(ab_ctx *ctx, const ab_plane *orig, float factor, const ab_image_stats *orig_stats,
+                                ab_plane_mut *out, ab_image_stats *out_stats);
+/* create_master_bias / _dark / _flat on in-memory frames (calibration.rs:127-255): kind 0 bias = median combine;
+ * 1 dark = median of (frame - bias?); 2 flat = median of (frame - bias? - dark?), normalised to mean 1 over its
+ * finite positive pixels (others -> 1.0).  Err strings as the reference ("No bias frames provided", "Dimension
+ * mismatch: expected (..), got (..)").  1 <= n_frames <= 64. */
+AB_API int ab_create_master(ab_ctx *ctx, int32_t kind, const ab_plane *frames, size_t n_frames, const ab_plane *master_bias,
+                            const ab_plane *master_dark, ab_plane_mut *out);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

@@ -249,6 +249,17 @@ int orc_spcc_from_detection(const float *r, const float *g, const float *b, size
 int orc_spcc_calibrate_rgb(const float *r, const float *g, const float *b, size_t h, size_t w, double pixel_scale_arcsec,
                            const orc_spcc_config *cfg, orc_spcc_result *res);                            /* :73-183 */
 
+/* ---- small caller-side helpers (orc_extras.c) ------------------------------------------------------ */
+void orc_apply_lrgb(const float *l, float *r, float *g, float *b, size_t n, float lightness_weight,
+                    float chrominance_weight);                                         /* lrgb.rs:4-45 */
+void orc_synthesize_luminance(const float *r, const float *g, const float *b, size_t n, float *out); /* lrgb.rs:47-64 */
+void orc_compute_linked_stf(const orc_image_stats *sr, const orc_image_stats *sg, const orc_image_stats *sb, double target_bg,
+                            double shadow_k, orc_stf_params *stf, orc_image_stats *combined); /* cmd/helpers.rs:185-202 */
+void orc_calibrate_channel(const float *orig, size_t n, float factor, const orc_image_stats *orig_stats, float *out,
+                           orc_image_stats *stats);                                    /* cmd/compose/color.rs:21-49 */
+void orc_create_master(int kind, const float *const *frames, size_t n_frames, size_t npix, const float *master_bias,
+                       const float *master_dark, float *out);                          /* calibration.rs:127-255 */
+
 /* utility */
 int orc_max_threads(void);
 

@@ -711,6 +711,70 @@ def spcc_calibrate_rgb(r, g, b, pixel_scale_arcsec: float, min_snr=20.0, max_sta
                       res.avg_color_index)
 
 
+def apply_lrgb(l, r, g, b, lightness_weight=1.0, chrominance_weight=1.0):
+    """apply_lrgb (lrgb.rs:4-45) -> new (r, g, b); ValueError on mismatched dims."""
+    ll, rr, gg, bb = _f32(l), _f32(r).copy(), _f32(g).copy(), _f32(b).copy()
+    if not (rr.shape == gg.shape == bb.shape == ll.shape):
+        raise ValueError(f"L dimensions {ll.shape} do not match RGB (R: {rr.shape}, G: {gg.shape}, B: {bb.shape})")
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_apply_lrgb.argtypes = [fp, fp, fp, fp, C.c_size_t, C.c_float, C.c_float]
+    L.orc_apply_lrgb(_fp(ll), _fp(rr), _fp(gg), _fp(bb), ll.size, lightness_weight, chrominance_weight)
+    return rr, gg, bb
+
+
+def synthesize_luminance(r, g, b) -> np.ndarray:
+    """lrgb.rs:47-64"""
+    rr, gg, bb = _f32(r), _f32(g), _f32(b)
+    out = np.zeros_like(rr)
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_synthesize_luminance.argtypes = [fp, fp, fp, C.c_size_t, fp]
+    L.orc_synthesize_luminance(_fp(rr), _fp(gg), _fp(bb), rr.size, _fp(out))
+    return out
+
+
+def compute_linked_stf(sr: ImageStats, sg: ImageStats, sb: ImageStats, target_bg=0.25, shadow_k=-2.8):
+    """cmd/helpers.rs:185-202 -> (StfParams, combined ImageStats)"""
+    L = lib()
+    L.orc_compute_linked_stf.argtypes = [C.POINTER(_Stats)] * 3 + [C.c_double, C.c_double, C.POINTER(_Stf), C.POINTER(_Stats)]
+    p, c = _Stf(), _Stats()
+    L.orc_compute_linked_stf(*[C.byref(_stats_in(s)) for s in (sr, sg, sb)], target_bg, shadow_k, C.byref(p), C.byref(c))
+    return StfParams(p.shadow, p.midtone, p.highlight), _stats_out(c)
+
+
+def calibrate_channel(orig, factor: float, orig_stats: ImageStats):
+    """cmd/compose/color.rs:21-49 -> (scaled plane, ImageStats)"""
+    im = _f32(orig)
+    out = np.zeros_like(im)
+    st = _Stats()
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.orc_calibrate_channel.argtypes = [fp, C.c_size_t, C.c_float, C.POINTER(_Stats), fp, C.POINTER(_Stats)]
+    L.orc_calibrate_channel(_fp(im), im.size, factor, C.byref(_stats_in(orig_stats)), _fp(out), C.byref(st))
+    return out, _stats_out(st)
+
+
+def create_master(kind: str, frames, master_bias=None, master_dark=None) -> np.ndarray:
+    """create_master_bias / _dark / _flat on in-memory frames (calibration.rs:127-255)"""
+    if len(frames) == 0:
+        raise ValueError(f"No {kind} frames provided")
+    fr = [_f32(f) for f in frames]
+    for f in fr[1:]:
+        if f.shape != fr[0].shape:
+            raise ValueError(f"Dimension mismatch: expected {fr[0].shape}, got {f.shape}")
+    fp = C.POINTER(C.c_float)
+    ptrs = (fp * len(fr))(*[_fp(f) for f in fr])
+    out = np.zeros_like(fr[0])
+    mb = None if master_bias is None else _f32(master_bias)
+    md = None if master_dark is None else _f32(master_dark)
+    L = lib()
+    L.orc_create_master.argtypes = [C.c_int, C.POINTER(fp), C.c_size_t, C.c_size_t, fp, fp, fp]
+    L.orc_create_master({"bias": 0, "dark": 1, "flat": 2}[kind], ptrs, len(fr), fr[0].size,
+                        None if mb is None else _fp(mb), None if md is None else _fp(md), _fp(out))
+    return out
+
+
 def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
