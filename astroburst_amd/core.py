@@ -417,6 +417,17 @@ class Context:
         return AffineAlignResult(tuple(res.transform), int(res.matched_stars), int(res.inliers), res.residual_px,
                                  AFFINE_METHODS[res.method])
 
+    def register_frames(self, reference, targets, num_threads: int = 8):
+        """align_channel_affine(reference, t) for every t in targets, sharing the reference's detection
+        (affine.rs:129-212) -> [AffineAlignResult]"""
+        keep = []
+        pr = self._plane(reference, keep)
+        planes = (Plane * max(len(targets), 1))(*[self._plane(t, keep) for t in targets])
+        res = (_lib.AffineAlignResultC * max(len(targets), 1))()
+        self._check(self._L.ab_register_frames(self._h, C.byref(pr), planes, len(targets), num_threads, res))
+        return [AffineAlignResult(tuple(r.transform), int(r.matched_stars), int(r.inliers), r.residual_px, AFFINE_METHODS[r.method])
+                for r in res[:len(targets)]]
+
     def affine_from_stars(self, ref_xy, tgt_xy, rows, cols, num_threads: int = 8):
         r = np.ascontiguousarray(np.asarray(ref_xy, np.float64).reshape(-1, 2))
         t = np.ascontiguousarray(np.asarray(tgt_xy, np.float64).reshape(-1, 2))

@@ -14,6 +14,17 @@
 
 #define AB_REJ_SLOTS 2048
 
+enum {
+    AB_WS_DETECT_PARENT = 0,  // int[P] union-find forest
+    AB_WS_DETECT_CID,         // int[P] root -> component id (written at roots only)
+    AB_WS_DETECT_ROOTS,       // int[P/4 + 1] component roots + counters
+    AB_WS_DETECT_COMPS,       // per-component statistics / moment records
+    AB_WS_DETECT_LIST,        // int[P] indices of the above-threshold pixels
+    AB_WS_NORM,               // float[P] normalised copy for star detection
+    AB_WS_REGISTER,           // triangle tables / votes of the star matcher
+    AB_WS_SLOTS
+};
+
 struct ab_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -29,6 +40,14 @@ struct ab_ctx {
     unsigned long long *counters = nullptr;  // AB_REJ_SLOTS x u64
     int cu_count = 0;
     unsigned int *sel_hist = nullptr;  // 2048-bin device histogram of plane_select.hip
+    // named persistent device workspaces (grown on demand, kept until the context dies): the
+    // whole-image passes of detection / registration reuse them instead of hipMalloc per call
+    void *ws[AB_WS_SLOTS] = {};
+    size_t ws_bytes[AB_WS_SLOTS] = {};
+    // frame-parallel registration (affine.hip): child contexts (own stream + workspaces), one per host worker;
+    // AB_REGISTER_WORKERS overrides the default of 8
+    std::vector<ab_ctx *> workers;
+    int register_workers = 8;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
 };
@@ -57,6 +76,8 @@ int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);
 // Scratch arena: returns a device pointer valid until the next ab_scratch() call with a larger size.
 int ab_scratch(ab_ctx *ctx, size_t bytes, void **out);
 int ab_pinned(ab_ctx *ctx, size_t bytes, void **out);
+// persistent workspace `slot` of at least `bytes` (contents are undefined after a growth)
+int ab_workspace(ab_ctx *ctx, int slot, size_t bytes, void **out);
 
 // RAII staging of an input plane: host planes are uploaded to a temporary device buffer.
 struct StagedPlane {

@@ -1,6 +1,8 @@
 // Context, error reporting, HBM scratch and host<->device staging.
 #include "ab_common.hpp"
 
+#include <algorithm>
+
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap;
@@ -44,6 +46,7 @@ int ab_ctx_create(int device_id, ab_ctx **out) {
     ctx->stream = ctx->own_stream;
     const char *ex = getenv("AB_STACK_EXACT");
     ctx->stack_exact = ex && ex[0] == '1';
+    if (const char *rw = getenv("AB_REGISTER_WORKERS")) ctx->register_workers = std::max(1, atoi(rw));
     *out = ctx;
     return AB_OK;
 }
@@ -52,10 +55,14 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (ab_ctx *w : ctx->workers) ab_ctx_destroy(w);
+    ctx->workers.clear();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
+    for (int i = 0; i < AB_WS_SLOTS; ++i)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -135,6 +142,22 @@ int ab_scratch(ab_ctx *ctx, size_t bytes, void **out) {
         ctx->scratch_bytes = want;
     }
     *out = ctx->scratch;
+    return AB_OK;
+}
+
+int ab_workspace(ab_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (slot < 0 || slot >= AB_WS_SLOTS) return ab_set_error(ctx, AB_ERR_INVALID, "bad workspace slot %d", slot);
+    if (bytes > ctx->ws_bytes[slot]) {
+        if (ctx->ws[slot]) {
+            AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            AB_HIP(ctx, hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr;
+            ctx->ws_bytes[slot] = 0;
+        }
+        AB_HIP(ctx, hipMalloc(&ctx->ws[slot], bytes));
+        ctx->ws_bytes[slot] = bytes;
+    }
+    *out = ctx->ws[slot];
     return AB_OK;
 }
 

@@ -21,7 +21,9 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
+#include <thread>
 
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out);
@@ -39,6 +41,7 @@ constexpr double kRansacInlierPx = 3.0, kDetectionSigma = 3.5, kMinTriangleSide 
 constexpr uint32_t kMinVotes = 1;
 constexpr double kMinInlierRatio = 0.20, kMaxResidualPx = 5.0, kMaxOffsetFraction = 0.40, kMaxRotationDeg = 30.0;
 constexpr double kMinScale = 0.70, kMaxScale = 1.40;
+constexpr size_t kHostVoteDim = 64;  // >= build_triangles' 60-star limit
 
 using Pt = std::array<double, 2>;
 using Match = std::array<double, 4>;  // rx, ry, tx, ty
@@ -54,16 +57,28 @@ double dist(const Pt &a, const Pt &b) {  // :658-661
     return std::sqrt(dx * dx + dy * dy);
 }
 
+// stable sort of three elements (what slice::sort_by does for len 3: insertion sort), without std::stable_sort's
+// temporary buffer -- it runs 10^5 times per frame pair
+template <class A, class Less>
+void sort3(A &v, Less lt) {
+    if (lt(v[1], v[0])) std::swap(v[0], v[1]);
+    if (lt(v[2], v[1])) {
+        std::swap(v[1], v[2]);
+        if (lt(v[1], v[0])) std::swap(v[0], v[1]);
+    }
+}
+
 std::vector<Tri> build_triangles(const std::vector<Pt> &s) {  // :279-318
     std::vector<Tri> tris;
     const size_t n = s.size();
     if (n < 3) return tris;
     const size_t limit = std::min<size_t>(n, 60);
+    tris.reserve(limit * (limit - 1) * (limit - 2) / 6);
     for (size_t i = 0; i < limit; ++i)
         for (size_t j = i + 1; j < limit; ++j)
             for (size_t k = j + 1; k < limit; ++k) {
                 std::array<double, 3> sides = {dist(s[i], s[j]), dist(s[j], s[k]), dist(s[i], s[k])};
-                std::stable_sort(sides.begin(), sides.end());
+                sort3(sides, [](double a, double b) { return a < b; });
                 if (sides[0] < kMinTriangleSide) continue;
                 tris.push_back({{i, j, k}, sides[1] / sides[0], sides[2] / sides[0]});
             }
@@ -74,50 +89,22 @@ std::array<size_t, 3> sort_triangle_vertices(const std::vector<Pt> &s, const siz
     std::array<std::pair<size_t, double>, 3> v = {{{idx[0], dist(s[idx[1]], s[idx[2]])},
                                                    {idx[1], dist(s[idx[0]], s[idx[2]])},
                                                    {idx[2], dist(s[idx[0]], s[idx[1]])}}};
-    std::stable_sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.second < b.second; });
+    sort3(v, [](const auto &a, const auto &b) { return a.second < b.second; });
     return {v[0].first, v[1].first, v[2].first};
 }
 
-std::vector<Match> match_triangles(const std::vector<Pt> &rs, const std::vector<Pt> &ts, const std::vector<Tri> &rt,
-                                   const std::vector<Tri> &tt) {  // :320-384
+// votes -> one-to-one matches (:351-384): pairs by votes descending (ties: ref index, then tgt index -- pinned,
+// see the file header), greedily keeping pairs whose two stars are both still free
+std::vector<Match> matches_from_votes(const std::vector<Pt> &rs, const std::vector<Pt> &ts, const uint32_t *votes, size_t stride) {
     const size_t nr = rs.size(), nt = ts.size();
-    std::vector<uint32_t> votes(nr * nt, 0);
-    // The reference compares every ref triangle with every tgt triangle (up to 34 220^2 pairs).  Votes are
-    // integer counts, so the visiting order is free: sort the tgt triangles by ratio_mid and only visit the
-    // window that can pass `|d_mid| <= 0.02` (a hair wider than the tolerance; the exact test decides).
-    std::vector<size_t> order(tt.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return tt[a].ratio_mid < tt[b].ratio_mid; });
-    std::vector<double> mids(tt.size());
-    std::vector<std::array<size_t, 3>> tverts(tt.size());
-    for (size_t i = 0; i < order.size(); ++i) {
-        mids[i] = tt[order[i]].ratio_mid;
-        tverts[i] = sort_triangle_vertices(ts, tt[order[i]].idx);
-    }
-    for (const Tri &a : rt) {
-        const double lo = a.ratio_mid - kTriangleTolerance * 1.000001 - 1e-12, hi = a.ratio_mid + kTriangleTolerance * 1.000001 + 1e-12;
-        const size_t i0 = std::lower_bound(mids.begin(), mids.end(), lo) - mids.begin();
-        bool have_ra = false;
-        std::array<size_t, 3> ra{};
-        for (size_t i = i0; i < mids.size() && mids[i] <= hi; ++i) {
-            const Tri &b = tt[order[i]];
-            if (std::fabs(a.ratio_mid - b.ratio_mid) > kTriangleTolerance || std::fabs(a.ratio_long - b.ratio_long) > kTriangleTolerance)
-                continue;
-            if (!have_ra) {
-                ra = sort_triangle_vertices(rs, a.idx);
-                have_ra = true;
-            }
-            for (int p = 0; p < 3; ++p) votes[ra[p] * nt + tverts[i][p]] += 1;
-        }
-    }
     struct Pair {
         size_t ri, ti;
         uint32_t v;
     };
     std::vector<Pair> pairs;
-    for (size_t r = 0; r < nr; ++r)
-        for (size_t t = 0; t < nt; ++t)
-            if (votes[r * nt + t]) pairs.push_back({r, t, votes[r * nt + t]});
+    for (size_t r = 0; r < nr && r < stride; ++r)  // votes is stride x stride; only the first <= 60 stars of a list vote
+        for (size_t t = 0; t < nt && t < stride; ++t)
+            if (votes[r * stride + t]) pairs.push_back({r, t, votes[r * stride + t]});
     std::sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &b) {
         if (a.v != b.v) return a.v > b.v;
         if (a.ri != b.ri) return a.ri < b.ri;
@@ -132,6 +119,51 @@ std::vector<Match> match_triangles(const std::vector<Pt> &rs, const std::vector<
         out.push_back({rs[p.ri][0], rs[p.ri][1], ts[p.ti][0], ts[p.ti][1]});
     }
     return out;
+}
+
+std::vector<Match> match_triangles(const std::vector<Pt> &rs, const std::vector<Pt> &ts, const std::vector<Tri> &rt,
+                                   const std::vector<Tri> &tt) {  // :320-384
+    const size_t nr = rs.size(), nt = ts.size();
+    std::vector<uint32_t> votes(nr * nt, 0);
+    // The reference compares every ref triangle with every tgt triangle (up to 34 220^2 pairs).  Votes are
+    // integer counts, so the visiting order is free: sort the tgt triangles by ratio_mid and only visit the
+    // window that can pass `|d_mid| <= 0.02` (a hair wider than the tolerance; the exact test decides).
+    // Bucket the tgt triangles on a (ratio_mid, ratio_long) grid whose cells are a hair wider than the tolerance:
+    // two triangles within tolerance on both ratios sit in the same or in adjacent cells, so the 3 x 3
+    // neighbourhood is a superset of the matches and the reference's exact test decides inside it.
+    const double cell = kTriangleTolerance * 1.0001;
+    auto key_of = [&](double mid, double lng) { return ((uint64_t)(mid / cell) << 24) | (uint64_t)std::min(lng / cell, 16777215.0); };
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(tt.size());
+    for (size_t i = 0; i < tt.size(); ++i) keyed[i] = {key_of(tt[i].ratio_mid, tt[i].ratio_long), (uint32_t)i};
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<std::array<uint8_t, 3>> tverts(tt.size());
+    for (size_t i = 0; i < tt.size(); ++i) {
+        const auto v = sort_triangle_vertices(ts, tt[i].idx);
+        tverts[i] = {(uint8_t)v[0], (uint8_t)v[1], (uint8_t)v[2]};
+    }
+    for (const Tri &a : rt) {
+        const uint64_t cm = (uint64_t)(a.ratio_mid / cell), cl = (uint64_t)std::min(a.ratio_long / cell, 16777215.0);
+        bool have_ra = false;
+        std::array<size_t, 3> ra{};
+        for (uint64_t m = cm ? cm - 1 : 0; m <= cm + 1; ++m) {
+            const uint64_t k0 = (m << 24) | (cl ? cl - 1 : 0), k1 = (m << 24) | std::min<uint64_t>(cl + 1, 16777215);
+            auto it = std::lower_bound(keyed.begin(), keyed.end(), std::make_pair(k0, (uint32_t)0));
+            for (; it != keyed.end() && it->first <= k1; ++it) {
+                const Tri &b = tt[it->second];
+                if (std::fabs(a.ratio_mid - b.ratio_mid) > kTriangleTolerance || std::fabs(a.ratio_long - b.ratio_long) > kTriangleTolerance)
+                    continue;
+                if (!have_ra) {
+                    ra = sort_triangle_vertices(rs, a.idx);
+                    have_ra = true;
+                }
+                for (int p = 0; p < 3; ++p) votes[ra[p] * nt + tverts[it->second][p]] += 1;
+            }
+        }
+    }
+    std::vector<uint32_t> sq(kHostVoteDim * kHostVoteDim, 0);
+    for (size_t r = 0; r < nr && r < kHostVoteDim; ++r)
+        for (size_t t = 0; t < nt && t < kHostVoteDim; ++t) sq[r * kHostVoteDim + t] = votes[r * nt + t];
+    return matches_from_votes(rs, ts, sq.data(), kHostVoteDim);
 }
 
 bool solve_3x3(const double a[3][3], const double b[3], double x[3]) {  // :556-595
@@ -277,15 +309,8 @@ bool transform_sane(const ab_affine_align_result &r, int64_t rows, int64_t cols)
     return !(sx < kMinScale || sx > kMaxScale || sy < kMinScale || sy > kMaxScale);
 }
 
-// the star-list half of align_channel_affine (:146-209)
-bool affine_from_stars(std::vector<Pt> rs, std::vector<Pt> ts, int64_t rows, int64_t cols, int num_threads,
-                       ab_affine_align_result *out) {
-    if (rs.size() > kMaxStars) rs.resize(kMaxStars);  // top_n_stars
-    if (ts.size() > kMaxStars) ts.resize(kMaxStars);
-    if (rs.size() < kMinMatchesRigid || ts.size() < kMinMatchesRigid) return false;
-    const auto rt = build_triangles(rs), tt = build_triangles(ts);
-    if (rt.empty() || tt.empty()) return false;
-    const auto matches = match_triangles(rs, ts, rt, tt);
+// matches -> transform (:178-209): affine RANSAC, then rigid, each followed by the sanity check
+bool transform_from_matches(const std::vector<Match> &matches, int64_t rows, int64_t cols, int num_threads, ab_affine_align_result *out) {
     if (matches.size() < kMinMatchesRigid) return false;
     ab_affine_align_result r;
     if (matches.size() >= kMinMatchesAffine && ransac(matches, kAffine, num_threads, &r) && transform_sane(r, rows, cols)) {
@@ -299,32 +324,296 @@ bool affine_from_stars(std::vector<Pt> rs, std::vector<Pt> ts, int64_t rows, int
     return false;
 }
 
-}  // namespace
+// the star-list half of align_channel_affine (:146-209)
+bool affine_from_stars(std::vector<Pt> rs, std::vector<Pt> ts, int64_t rows, int64_t cols, int num_threads,
+                       ab_affine_align_result *out) {
+    if (rs.size() > kMaxStars) rs.resize(kMaxStars);  // top_n_stars
+    if (ts.size() > kMaxStars) ts.resize(kMaxStars);
+    if (rs.size() < kMinMatchesRigid || ts.size() < kMinMatchesRigid) return false;
+    const auto rt = build_triangles(rs), tt = build_triangles(ts);
+    if (rt.empty() || tt.empty()) return false;
+    return transform_from_matches(match_triangles(rs, ts, rt, tt), rows, cols, num_threads, out);
+}
 
-// align_channel_affine (affine.rs:129-212) on device planes of equal dims (row strides allowed)
-int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
-                                   ab_affine_align_result *out) {
-    AB_HIP(ctx, hipSetDevice(ctx->device));
-    const int64_t len = rows * cols;
-    float *norm = nullptr;
-    AB_HIP(ctx, hipMalloc((void **)&norm, (size_t)len * sizeof(float)));
-    std::vector<ab_detected_star> rstars, tstars;
+// ---- GPU triangle matcher -------------------------------------------------------------------------------
+// build_triangles + match_triangles compare up to 34 220 x 34 220 triangle pairs per frame pair: 1.2e9 pair tests of
+// four f64 ops each.  On the host that is tens of milliseconds even with bucketing; here the triangles of <= 60
+// stars are built by one thread per (i, j, k) and every ref triangle is tested against every tgt triangle staged
+// through LDS (~0.2 ms).  Side lengths, ratios and the tolerance tests are the same correctly-rounded f64
+// operations as the host path, and votes are integers, so the vote matrix is identical to the host's.
+struct DTri {
+    double mid, lng;
+    uint32_t verts;  // sort_triangle_vertices order: v0 | v1 << 8 | v2 << 16
+    uint32_t pad;
+};
+
+constexpr int kTriLimit = 60;            // build_triangles' `limit` (:285)
+constexpr int kMaxTris = 34220;          // C(60, 3)
+constexpr int kVoteDim = 64;             // vote matrix stride (>= kTriLimit)
+constexpr int kTriBins = 4096;           // ratio_mid buckets of the tgt table (cell = tolerance * 1.0001)
+
+__host__ __device__ __forceinline__ int tri_bin(double mid) {  // ratio_mid >= 1; monotone, so |d_mid| <= tol => |d_bin| <= 1
+    const double b = (mid - 1.0) / (kTriangleTolerance * 1.0001);
+    return b >= (double)(kTriBins - 1) ? kTriBins - 1 : (int)b;
+}
+
+__device__ __forceinline__ double ddist(double ax, double ay, double bx, double by) {
+    const double dx = ax - bx, dy = ay - by;
+    return sqrt(dx * dx + dy * dy);
+}
+
+struct StarXY {
+    double xy[kTriLimit * 2];
+};
+
+__global__ __launch_bounds__(256) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
+                                                        unsigned int *__restrict__ bin_hist /* nullable */) {
+    const double *xy = stars.xy;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int i = t / (limit * limit), j = (t / limit) % limit, k = t % limit;
+    bool ok = i < limit && i < j && j < k;
+    DTri tri = {0.0, 0.0, 0u, 0u};
+    if (ok) {
+        const double xi = xy[2 * i], yi = xy[2 * i + 1], xj = xy[2 * j], yj = xy[2 * j + 1], xk = xy[2 * k], yk = xy[2 * k + 1];
+        const double dij = ddist(xi, yi, xj, yj), djk = ddist(xj, yj, xk, yk), dik = ddist(xi, yi, xk, yk);
+        double s0 = dij, s1 = djk, s2 = dik;  // :295-297, then a stable sort of three
+        if (s1 < s0) { const double q = s0; s0 = s1; s1 = q; }
+        if (s2 < s1) {
+            const double q = s1; s1 = s2; s2 = q;
+            if (s1 < s0) { const double q2 = s0; s0 = s1; s1 = q2; }
+        }
+        ok = !(s0 < kMinTriangleSide);
+        tri.mid = s1 / s0;
+        tri.lng = s2 / s0;
+        // sort_triangle_vertices (:386-398): vertices by the length of the opposite side, stable
+        int v0 = i, v1 = j, v2 = k;
+        double o0 = ddist(xj, yj, xk, yk), o1 = ddist(xi, yi, xk, yk), o2 = ddist(xi, yi, xj, yj);
+        if (o1 < o0) { const double q = o0; o0 = o1; o1 = q; const int w = v0; v0 = v1; v1 = w; }
+        if (o2 < o1) {
+            { const double q = o1; o1 = o2; o2 = q; const int w = v1; v1 = v2; v2 = w; }
+            if (o1 < o0) { const double q = o0; o0 = o1; o1 = q; const int w = v0; v0 = v1; v1 = w; }
+        }
+        tri.verts = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16);
+    }
+    const unsigned long long m = __ballot(ok);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned int)__builtin_popcountll(m));
+    base = __shfl(base, leader, 64);
+    if (ok) {
+        out[base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = tri;
+        if (bin_hist) atomicAdd(&bin_hist[tri_bin(tri.mid)], 1u);
+    }
+}
+
+// exclusive scan of the 4096 bucket counts (one 1024-thread block); also rewinds the scatter cursors
+__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(const unsigned int *__restrict__ hist, unsigned int *__restrict__ off /* kTriBins + 1 */,
+                                                            unsigned int *__restrict__ cursor) {
+    __shared__ unsigned int wave_tot[16];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned int h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
+    const unsigned int s = h0 + h1 + h2 + h3;
+    unsigned int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    unsigned int base = 0;
+    for (int i = 0; i < wv; ++i) base += wave_tot[i];
+    const unsigned int e = base + inc - s;
+    off[4 * t] = e;
+    off[4 * t + 1] = e + h0;
+    off[4 * t + 2] = e + h0 + h1;
+    off[4 * t + 3] = e + h0 + h1 + h2;
+    cursor[4 * t] = e;
+    cursor[4 * t + 1] = e + h0;
+    cursor[4 * t + 2] = e + h0 + h1;
+    cursor[4 * t + 3] = e + h0 + h1 + h2;
+    if (t == 1023) off[kTriBins] = e + s;
+}
+
+__global__ __launch_bounds__(256) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
+                                                          DTri *__restrict__ sorted) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= *n_p) return;
+    const DTri t = in[i];
+    sorted[atomicAdd(&cursor[tri_bin(t.mid)], 1u)] = t;  // order inside a bucket is irrelevant: votes are counts
+}
+
+// The tgt table is bucketed by ratio_mid (tri_scatter_kernel); the ref table is sorted by (ratio_mid bucket,
+// ratio_long) once per batch on the host.  One wave owns 64 consecutive ref triangles: a narrow bucket range
+// [bmin, bmax] and a narrow ratio_long window [lmin, lmax].  It streams the tgt triangles of buckets bmin-1 ..
+// bmax+1 (a superset of every possible match), keeps those whose ratio_long can match anything in the window
+// (wave-wide compaction into LDS), and every lane applies the reference's exact test (:335-339) to the kept ones.
+// Votes collect in LDS; each wave then adds its non-zero entries to the global 64 x 64 matrix.
+__global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
+                                                      const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
+                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */) {
+    __shared__ unsigned int votes[kVoteDim * kVoteDim];
+    __shared__ double k_mid[64], k_lng[64];
+    __shared__ uint32_t k_verts[64];
+    const int lane = threadIdx.x;
+    const unsigned int nr = *nr_p, first = blockIdx.x * 64, r = first + lane;
+    if (first >= nr) return;
+    for (int i = lane; i < kVoteDim * kVoteDim; i += 64) votes[i] = 0;
+    const bool have = r < nr;
+    const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
+    double lmin = a.lng, lmax = a.lng;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lmin = fmin(lmin, __shfl_xor(lmin, off, 64));
+        lmax = fmax(lmax, __shfl_xor(lmax, off, 64));
+    }
+    const double win_lo = lmin - kTriangleTolerance * 1.0001, win_hi = lmax + kTriangleTolerance * 1.0001;
+    const int bmin = tri_bin(rt_sorted[first].mid), bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
+    unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
+    {  // blockIdx.y takes one slice of the candidate range: dense buckets would otherwise leave a few very long waves
+        const unsigned int per = (q1 - q0 + gridDim.y - 1) / gridDim.y;
+        q0 = min(q0 + blockIdx.y * per, q1);
+        q1 = min(q0 + per, q1);
+    }
+    __syncthreads();
+    for (unsigned int base = q0; base < q1; base += 64) {
+        const unsigned int idx = base + lane;
+        DTri t = {0.0, 0.0, 0u, 0u};
+        bool keep = false;
+        if (idx < q1) {
+            t = tt_sorted[idx];
+            keep = t.lng >= win_lo && t.lng <= win_hi;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m == 0) continue;
+        if (keep) {
+            const int pos = (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            k_mid[pos] = t.mid;
+            k_lng[pos] = t.lng;
+            k_verts[pos] = t.verts;
+        }
+        __syncthreads();
+        const int cnt = (int)__builtin_popcountll(m);
+        if (have)
+            for (int q = 0; q < cnt; ++q) {
+                if (fabs(a.mid - k_mid[q]) > kTriangleTolerance || fabs(a.lng - k_lng[q]) > kTriangleTolerance) continue;
+                const uint32_t b = k_verts[q];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) atomicAdd(&votes[((a.verts >> (8 * p)) & 255u) * kVoteDim + ((b >> (8 * p)) & 255u)], 1u);
+            }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = lane; i < kVoteDim * kVoteDim; i += 64) {
+        const unsigned int v = votes[i];
+        if (v) atomicAdd(&votes_out[i], v);
+    }
+}
+
+// device-side layout of the matcher's workspace (AB_WS_REGISTER)
+struct MatchWs {
+    DTri *ref_tris, *ref_sorted, *tgt_tris, *tgt_sorted;
+    unsigned int *counts;  // [0] ref, [1] tgt
+    unsigned int *bin_hist, *bin_off, *cursor;
+    unsigned int *votes;
+};
+
+int match_ws(ab_ctx *ctx, MatchWs *w) {
+    const size_t tri_bytes = (size_t)kMaxTris * sizeof(DTri), vote_bytes = kVoteDim * kVoteDim * sizeof(unsigned int);
+    const size_t bin_words = 64 + 3 * (size_t)kTriBins + 64;
+    const size_t total = 4 * tri_bytes + bin_words * sizeof(unsigned int) + vote_bytes;
+    char *p = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_REGISTER, total, (void **)&p));
+    w->ref_tris = (DTri *)p;
+    w->tgt_tris = (DTri *)(p + tri_bytes);
+    w->tgt_sorted = (DTri *)(p + 2 * tri_bytes);
+    w->ref_sorted = (DTri *)(p + 3 * tri_bytes);
+    unsigned int *u = (unsigned int *)(p + 4 * tri_bytes);
+    w->counts = u;
+    w->bin_hist = u + 64;
+    w->bin_off = w->bin_hist + kTriBins;  // kTriBins + 1 entries
+    w->cursor = w->bin_off + kTriBins + 32;
+    w->votes = u + bin_words;
+    return AB_OK;
+}
+
+// upload the first <= 60 stars and build their triangle table (which = 0 ref, 1 tgt)
+int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &stars, int which) {
+    const int limit = (int)std::min<size_t>(stars.size(), kTriLimit);
+    StarXY xy;  // 960 B of kernel arguments: no staging copy, nothing to keep alive
+    memset(&xy, 0, sizeof xy);
+    for (int i = 0; i < limit; ++i) {
+        xy.xy[2 * i] = stars[i][0];
+        xy.xy[2 * i + 1] = stars[i][1];
+    }
+    AB_HIP(ctx, hipMemsetAsync(w.counts + which, 0, sizeof(unsigned int), ctx->stream));
+    AB_HIP(ctx, hipMemsetAsync(w.bin_hist, 0, kTriBins * sizeof(unsigned int), ctx->stream));
+    if (limit >= 3) {
+        const int total = limit * limit * limit;
+        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, xy, limit, which ? w.tgt_tris : w.ref_tris,
+                           w.counts + which, w.bin_hist);
+    }
+    if (which) {  // bucket the tgt table by ratio_mid for the vote kernel
+        hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
+        hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 255) / 256), dim3(256), 0, ctx->stream, w.tgt_tris, w.counts + 1, w.cursor,
+                           w.tgt_sorted);
+    }
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+// votes of the current ref / tgt triangle tables -> host (kVoteDim x kVoteDim)
+int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std::vector<uint32_t> *votes) {
+    AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(tri_vote_kernel, dim3((kMaxTris + 63) / 64, 8), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes);
+    AB_HIP(ctx, hipGetLastError());
+    votes->resize(kVoteDim * kVoteDim);
+    AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AB_OK;
+}
+
+// normalize_for_detection + detect_stars(3.5 sigma) + top_n_stars of one frame (:134-160)
+int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, float *norm, std::vector<Pt> *out) {
+    std::vector<ab_detected_star> stars;
     double m, s;
     int cloned = 0;
-    int rc = ab_normalize_for_detection_device(ctx, ref, len, norm, &cloned);
-    if (rc == AB_OK) rc = ab_detect_stars_device(ctx, norm, rows, cols, cols, kDetectionSigma, &rstars, &m, &s);
-    if (rc == AB_OK) rc = ab_normalize_for_detection_device(ctx, tgt, len, norm, &cloned);
-    if (rc == AB_OK) rc = ab_detect_stars_device(ctx, norm, rows, cols, cols, kDetectionSigma, &tstars, &m, &s);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(norm);
-    if (rc != AB_OK) return rc;
-    std::vector<Pt> rs, ts;
-    for (const auto &st : rstars) rs.push_back({st.x, st.y});
-    for (const auto &st : tstars) ts.push_back({st.x, st.y});
-    if (affine_from_stars(rs, ts, rows, cols, num_threads, out)) return AB_OK;
+    AB_TRY(ab_normalize_for_detection_device(ctx, img, rows * cols, norm, &cloned));
+    AB_TRY(ab_detect_stars_device(ctx, norm, rows, cols, cols, kDetectionSigma, &stars, &m, &s));
+    out->clear();
+    for (const auto &st : stars) {
+        if (out->size() >= kMaxStars) break;  // top_n_stars (:272-277): detections are already sorted by flux
+        out->push_back({st.x, st.y});
+    }
+    return AB_OK;
+}
+
+}  // namespace
+
+// one target against the prepared reference (stars rs, triangle table in ref_ws); all device work on wc's stream
+static int register_one(ab_ctx *wc, const MatchWs &ref_ws, const std::vector<Pt> &rs, bool ref_ok, const float *ref, const float *tgt,
+                        int64_t rows, int64_t cols, int num_threads, ab_affine_align_result *out) {
+    float *norm = nullptr;
+    AB_TRY(ab_workspace(wc, AB_WS_NORM, (size_t)(rows * cols) * sizeof(float), (void **)&norm));
+    MatchWs w;
+    AB_TRY(match_ws(wc, &w));
+    std::vector<Pt> ts;
+    bool found = false;
+    AB_TRY(frame_stars(wc, tgt, rows, cols, norm, &ts));
+    if (ref_ok && ts.size() >= kMinMatchesRigid) {
+        AB_TRY(gpu_build_triangles(wc, w, ts, 1));
+        MatchWs mixed = w;  // tgt table, partials and votes of this worker; ref table of the caller
+        mixed.ref_sorted = ref_ws.ref_sorted;
+        std::vector<uint32_t> votes;
+        AB_TRY(gpu_votes(wc, mixed, ref_ws.counts, &votes));
+        // an empty triangle table on either side leaves the votes at zero -> no matches, as :166-168
+        found = transform_from_matches(matches_from_votes(rs, ts, votes.data(), kVoteDim), rows, cols, num_threads, out);
+    }
+    if (found) return AB_OK;
     // fallback_phase_correlation (:243-270) on the ORIGINAL planes
     double dx, dy, conf;
-    AB_TRY(ab_phase_correlate_device(ctx, ref, rows, cols, cols, tgt, rows, cols, cols, &dx, &dy, &conf));
+    AB_TRY(ab_phase_correlate_device(wc, ref, rows, cols, cols, tgt, rows, cols, cols, &dx, &dy, &conf));
     memset(out, 0, sizeof *out);
     out->transform[0] = 1.0;
     out->transform[4] = 1.0;
@@ -336,6 +625,76 @@ int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *t
         out->method = kPhaseCorr;
     }
     return AB_OK;
+}
+
+// align_channel_affine (affine.rs:129-212) of n targets against ONE reference.  The reference's normalisation,
+// detection and triangle table are computed once.  Targets are independent, so they are spread over up to
+// ctx->register_workers host threads, each driving its own HIP stream and workspaces (child contexts cached in
+// ctx): one frame's host geometry overlaps the other frames' GPU passes.  Results do not depend on the worker
+// count (each out[i] equals a stand-alone align_channel_affine(reference, targets[i])).
+int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const *targets, size_t n, int64_t rows, int64_t cols, int num_threads,
+                              ab_affine_align_result *out) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    float *norm = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_NORM, (size_t)(rows * cols) * sizeof(float), (void **)&norm));
+    MatchWs w;
+    AB_TRY(match_ws(ctx, &w));
+    std::vector<Pt> rs;
+    AB_TRY(frame_stars(ctx, ref, rows, cols, norm, &rs));
+    const bool ref_ok = rs.size() >= kMinMatchesRigid;
+    if (ref_ok) {
+        // reference table: built on the GPU, ordered by (ratio_mid bucket, ratio_long) once on the host
+        AB_TRY(gpu_build_triangles(ctx, w, rs, 0));
+        unsigned int nref = 0;
+        AB_HIP(ctx, hipMemcpyAsync(&nref, w.counts, sizeof nref, hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<DTri> tris(nref);
+        if (nref) AB_HIP(ctx, hipMemcpy(tris.data(), w.ref_tris, nref * sizeof(DTri), hipMemcpyDeviceToHost));
+        std::sort(tris.begin(), tris.end(), [](const DTri &x, const DTri &y) {
+            const int bx = tri_bin(x.mid), by = tri_bin(y.mid);
+            return bx != by ? bx < by : x.lng < y.lng;
+        });
+        if (nref) AB_HIP(ctx, hipMemcpy(w.ref_sorted, tris.data(), nref * sizeof(DTri), hipMemcpyHostToDevice));
+    }
+    const size_t workers = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1));
+    if (workers <= 1) {
+        for (size_t f = 0; f < n; ++f) AB_TRY(register_one(ctx, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]));
+        return AB_OK;
+    }
+    while (ctx->workers.size() < workers) {
+        ab_ctx *wc = nullptr;
+        if (ab_ctx_create(ctx->device, &wc) != AB_OK) return ab_set_error(ctx, AB_ERR_HIP, "cannot create registration worker context");
+        wc->register_workers = 1;
+        ctx->workers.push_back(wc);
+    }
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // reference table built, and the callers' frames are complete
+    std::atomic<size_t> next{0};
+    std::vector<int> rcs(workers, AB_OK);
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < workers; ++t)
+        pool.emplace_back([&, t]() {
+            ab_ctx *wc = ctx->workers[t];
+            if (hipSetDevice(wc->device) != hipSuccess) {
+                rcs[t] = AB_ERR_HIP;
+                return;
+            }
+            for (size_t f = next.fetch_add(1); f < n; f = next.fetch_add(1)) {
+                const int rc = register_one(wc, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]);
+                if (rc != AB_OK) {
+                    rcs[t] = rc;
+                    return;
+                }
+            }
+        });
+    for (std::thread &th : pool) th.join();
+    for (size_t t = 0; t < workers; ++t)
+        if (rcs[t] != AB_OK) return ab_set_error(ctx, rcs[t], "registration worker %zu: %s", t, ctx->workers[t]->err.c_str());
+    return AB_OK;
+}
+
+int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
+                                   ab_affine_align_result *out) {
+    return ab_register_frames_device(ctx, ref, &tgt, 1, rows, cols, num_threads, out);
 }
 
 extern "C" {
@@ -354,6 +713,31 @@ int ab_align_channel_affine(ab_ctx *ctx, const ab_plane *reference, const ab_pla
         rc = ab_align_channel_affine_device(ctx, r.dptr, t.dptr, r.rows, r.cols, num_threads, out);
         ab_stage_release(ctx, &t);
     }
+    ab_stage_release(ctx, &r);
+    return rc;
+}
+
+int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
+                       ab_affine_align_result *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, reference && out && (targets || n == 0), "null argument");
+    for (size_t i = 0; i < n; ++i)
+        AB_CHECK(ctx, targets[i].rows == reference->rows && targets[i].cols == reference->cols,
+                 "align_channel_affine takes two planes of the same dims (%lldx%lld vs %lldx%lld)", (long long)reference->rows,
+                 (long long)reference->cols, (long long)targets[i].rows, (long long)targets[i].cols);
+    StagedPlane r;
+    AB_TRY(ab_stage_in(ctx, reference, &r));
+    std::vector<StagedPlane> st(n);
+    std::vector<const float *> ptrs(n);
+    int rc = AB_OK;
+    size_t staged = 0;
+    for (; staged < n && rc == AB_OK; ++staged) {
+        rc = ab_stage_in(ctx, &targets[staged], &st[staged]);
+        if (rc != AB_OK) break;
+        ptrs[staged] = st[staged].dptr;
+    }
+    if (rc == AB_OK) rc = ab_register_frames_device(ctx, r.dptr, ptrs.data(), n, r.rows, r.cols, num_threads, out);
+    for (size_t i = 0; i < staged && i < n; ++i) ab_stage_release(ctx, &st[i]);
     ab_stage_release(ctx, &r);
     return rc;
 }

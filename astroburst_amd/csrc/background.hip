@@ -35,7 +35,7 @@ struct CellOut {
 __global__ __launch_bounds__(absel::kBlock) void cell_median_kernel(const float *__restrict__ img, int64_t ld, int grid,
                                                                     int cell_h, int cell_w, int margin_h, int margin_w,
                                                                     int inner_h, int inner_w, CellOut *__restrict__ out) {
-    __shared__ unsigned int hist[2048];
+    __shared__ unsigned int hist0[2048], hist[2048];
     const int gy = blockIdx.x / grid, gx = blockIdx.x % grid;
     absel::Window w;
     w.img = img;
@@ -47,9 +47,11 @@ __global__ __launch_bounds__(absel::kBlock) void cell_median_kernel(const float 
     w.min_valid = 1e-7f;
     w.lo = -__builtin_inff();
     w.hi = __builtin_inff();
-    const unsigned int n = absel::count(w, hist);
+    const absel::Keying by_value = {0, 0.0, 0.0f};
+    const absel::StreamSource src;  // cells reach 512 x 512 px: too many for registers, and only ~4 passes are needed
+    const unsigned int n = absel::prepare(src, w, by_value, hist0);
     float med = 0.0f;
-    if (n > 0) med = absel::median_f32(w, 0, 0.0, 0.0f, n, hist);
+    if (n > 0) med = absel::median_f32_from(src, w, by_value, hist0, n, hist);
     if (threadIdx.x == 0) {
         out[blockIdx.x].median = med;
         out[blockIdx.x].count = n;

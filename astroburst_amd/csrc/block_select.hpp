@@ -4,9 +4,19 @@
 // select_nth_unstable: the detection background tiles (core/analysis/star_detection.rs:47-68) and the
 // background-extraction grid cells (core/imaging/background.rs:151-190).  All candidate pixels are
 // positive finite floats (or absolute deviations), whose IEEE bit patterns are monotone as u32, so
-// rank k is found by an 11/11/10-bit radix select: three LDS-histogram passes over the window
-// (re-read from L2), one 1024-thread workgroup per window.  Exact for every rank -> medians of
-// even counts average the two middle order statistics just as math/median.rs does.
+// rank k is found by an 11/11/10-bit radix select: LDS-histogram passes over the window (re-read
+// from L2), one 1024-thread workgroup per window.  Exact for every rank -> medians of even counts
+// average the two middle order statistics just as math/median.rs does.
+//
+// Cost model: a pass is one read of the window + one LDS atomic per candidate.  Sky pixels share
+// their top 11 bits (sign, exponent, 3 mantissa bits), so a plain atomicAdd per lane would serialise
+// ~all 65 536 updates of a tile on ONE LDS address (measured: 110 us per pass, 4.3 ms per frame).
+// The top level therefore tallies each wave's dominant bin in a scalar (ModeTally: ballot + popcount, one
+// atomic per wave and pass) and only the other lanes issue atomics.  The lower levels (keys spread over
+// ~1000 bins) use plain per-lane atomics.
+// The top-level histogram is computed once per key mode (`prepare`) and shared by the count and by
+// every rank requested from it (the two middle ranks of an even count descend together while they
+// stay in the same bin), so a median costs 3 passes instead of 7.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -24,73 +34,167 @@ struct Window {
     float lo, hi;     // and lo <= v <= hi (cumulative `retain` bounds; +-inf when unused)
 };
 
+struct Keying {  // mode 0: key = bits(v); 1: bits((f32)|(f64)v - center64|); 2: bits(|v - center32|)
+    int mode;
+    double center64;
+    float center32;
+};
+
 __device__ __forceinline__ bool candidate(const Window &w, float v) {
     return __builtin_isfinite(v) && v > w.min_valid && v >= w.lo && v <= w.hi;
 }
 
-// histogram over bits [shift, shift+nbits) of the keys matching the prefix.
-// mode 0: key = bits(v); mode 1: key = bits((f32)|(f64)v - center_f64|); mode 2: key = bits(|v - center_f32|)
-__device__ inline void window_hist(const Window &w, int mode, double center64, float center32, uint32_t prefix_mask,
-                                   uint32_t prefix_val, int shift, int nbits, unsigned int *hist /* LDS, 2048 */) {
+__device__ __forceinline__ uint32_t key_of(const Keying &k, float v) {
+    float x = v;
+    if (k.mode == 1) x = (float)fabs((double)v - k.center64);
+    if (k.mode == 2) x = fabsf(v - k.center32);
+    return __float_as_uint(x);
+}
+
+// Where a pass gets the window's pixels from: the window is re-read (L2) every pass.  A pass is latency-bound --
+// one dependent load per 1024 pixels costs ~0.8 us -- so each thread keeps eight independent loads in flight
+// (out-of-window slots read as NaN, which is never a candidate).  Keeping a whole 256 x 256 tile in registers
+// instead was tried: at 1024 threads LLVM spills (128-VGPR budget), at 512 threads it still spills 60+ dwords.
+struct StreamSource {
+    // thread (tx, ty) of the 256 x 4 layout walks column x0 + tx (+ 256 per column block) downwards, four rows per
+    // sweep: consecutive lanes read consecutive pixels and no per-pixel integer division is needed
+    template <class F>
+    __device__ __forceinline__ void for_each(const Window &w, F f) const {
+        constexpr int U = 8;
+        const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
+        for (int cb = w.x0; cb < w.x1; cb += 256) {
+            const int c = cb + tx;
+            const bool col_ok = c < w.x1;
+            for (int rb = w.y0 + ty; rb < w.y1 + ty; rb += 4 * U) {  // uniform trip count over the block
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int r = rb + 4 * u;
+                    v[u] = __builtin_nanf("");
+                    if (col_ok && r < w.y1) v[u] = w.img[(int64_t)r * w.ld + c];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) f(v[u]);
+            }
+        }
+    }
+};
+
+// Top-level histogram update with the wave's dominant bin counted in a scalar: the first candidate a wave meets
+// names the "mode" bin; lanes hitting it are tallied with ballot + popcount (no atomic, no serialisation) and
+// flushed once at the end of the pass, everybody else uses a per-lane atomic.
+struct ModeTally {
+    uint32_t bin = 0;
+    unsigned int count = 0;
+    bool have = false;
+    __device__ __forceinline__ void add(unsigned int *hist, bool valid, uint32_t b) {
+        if (!have) {
+            const unsigned long long m = __ballot(valid);
+            if (m) {
+                bin = (uint32_t)__shfl((int)b, (int)__builtin_ctzll(m), 64);
+                have = true;
+            }
+        }
+        const bool hit = valid && have && b == bin;
+        count += (unsigned int)__builtin_popcountll(__ballot(hit));
+        if (valid && !hit) atomicAdd(&hist[b], 1u);
+    }
+    __device__ __forceinline__ void flush(unsigned int *hist) {
+        if (have && count && (threadIdx.x & 63) == 0) atomicAdd(&hist[bin], count);
+    }
+};
+
+// histogram over bits [shift, shift+nbits) of the keys matching the prefix
+template <class S>
+__device__ inline void window_hist(const S &src, const Window &w, const Keying &k, uint32_t prefix_mask, uint32_t prefix_val, int shift,
+                                   int nbits, unsigned int *hist /* LDS, 1 << nbits */) {
     const int nb = 1 << nbits;
     for (int i = threadIdx.x; i < nb; i += kBlock) hist[i] = 0;
     __syncthreads();
-    const int ww = w.x1 - w.x0, n = ww * (w.y1 - w.y0);
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-        const int r = w.y0 + i / ww, c = w.x0 + i % ww;
-        const float v = w.img[r * w.ld + c];
-        if (candidate(w, v)) {
-            float k = v;
-            if (mode == 1) k = (float)fabs((double)v - center64);
-            if (mode == 2) k = fabsf(v - center32);
-            const uint32_t key = __float_as_uint(k);
-            if ((key & prefix_mask) == prefix_val) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1u);
-        }
+    auto visit = [&](auto add) {
+        src.for_each(w, [&](float v) {
+            bool ok = candidate(w, v);
+            uint32_t bin = 0;
+            if (ok) {
+                const uint32_t key = key_of(k, v);
+                ok = (key & prefix_mask) == prefix_val;
+                bin = (key >> shift) & (uint32_t)(nb - 1);
+            }
+            add(ok, bin);
+        });
+    };
+    if (prefix_mask == 0) {  // top level: sky pixels pile up in one or two bins
+        ModeTally tally;
+        visit([&](bool ok, uint32_t bin) { tally.add(hist, ok, bin); });
+        tally.flush(hist);
+    } else {  // lower levels: keys are spread over the bins
+        visit([&](bool ok, uint32_t bin) {
+            if (ok) atomicAdd(&hist[bin], 1u);
+        });
     }
     __syncthreads();
 }
 
-// bin holding 0-based `rank`, the count before it, and the histogram total (broadcast to all threads)
-__device__ inline void find_bin(const unsigned int *hist, int nb, unsigned int rank, unsigned int *bin_out,
-                                unsigned int *before_out, unsigned int *total_out) {
+// bin holding 0-based `rank`, the count before it, the bin's own count and the histogram total
+// (broadcast to all threads)
+__device__ inline void find_bin(const unsigned int *hist, int nb, unsigned int rank, unsigned int *bin_out, unsigned int *before_out,
+                                unsigned int *total_out) {
     __shared__ unsigned int s_bin, s_before, s_total;
-    if (threadIdx.x == 0) {
-        unsigned int cum = 0, bin = nb - 1, before = 0;
-        bool found = false;
-        for (int i = 0; i < nb; ++i) {
-            const unsigned int h = hist[i];
-            if (!found && cum + h > rank) {
-                bin = i;
-                before = cum;
-                found = true;
-            }
-            cum += h;
+    __syncthreads();
+    if (threadIdx.x < 64) {  // wave 0: 64 partial sums -> lane scan -> the owning lane walks its bins
+        const int lane = threadIdx.x, per = nb / 64;
+        unsigned int s = 0;
+        for (int j = 0; j < per; ++j) s += hist[lane * per + j];
+        unsigned int inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
         }
-        s_bin = bin;
-        s_before = before;
-        s_total = cum;
+        const unsigned int exc = inc - s;
+        const unsigned int total = __shfl(inc, 63, 64);
+        if (lane == 0) {
+            s_total = total;
+            if (rank >= total) {  // not present: same answer as a linear scan that never fires
+                s_bin = nb - 1;
+                s_before = 0;
+            }
+        }
+        if (rank >= exc && rank < inc) {
+            unsigned int cum = exc;
+            for (int j = 0; j < per; ++j) {
+                const unsigned int h = hist[lane * per + j];
+                if (cum + h > rank) {
+                    s_bin = lane * per + j;
+                    s_before = cum;
+                    break;
+                }
+                cum += h;
+            }
+        }
     }
     __syncthreads();
     *bin_out = s_bin;
     *before_out = s_before;
     *total_out = s_total;
-    __syncthreads();
 }
 
-__device__ inline unsigned int count(const Window &w, unsigned int *hist) {
-    window_hist(w, 0, 0.0, 0.0f, 0, 0, 21, 11, hist);
+// top-level (bits 31..21) histogram of the window's keys into hist0; returns the candidate count
+template <class S>
+__device__ inline unsigned int prepare(const S &src, const Window &w, const Keying &k, unsigned int *hist0 /* LDS, 2048 */) {
+    window_hist(src, w, k, 0, 0, 21, 11, hist0);
     unsigned int b, bf, n;
-    find_bin(hist, 2048, 0xffffffffu, &b, &bf, &n);
+    find_bin(hist0, 2048, 0xffffffffu, &b, &bf, &n);
     return n;
 }
 
-// the rank-th smallest key (0-based) of the window's candidates
-__device__ inline float select(const Window &w, int mode, double center64, float center32, unsigned int rank,
-                               unsigned int *hist) {
+// levels 1 and 2 for a key whose top bits (val, mask) and in-bin rank are known
+template <class S>
+__device__ inline float descend(const S &src, const Window &w, const Keying &k, uint32_t mask, uint32_t val, unsigned int rank, int level,
+                                unsigned int *hist /* LDS, 2048 */) {
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-    uint32_t mask = 0, val = 0;
-    for (int p = 0; p < 3; ++p) {
-        window_hist(w, mode, center64, center32, mask, val, shifts[p], bits[p], hist);
+    for (int p = level; p < 3; ++p) {
+        window_hist(src, w, k, mask, val, shifts[p], bits[p], hist);
         unsigned int bin, before, total;
         find_bin(hist, 1 << bits[p], rank, &bin, &before, &total);
         rank -= before;
@@ -100,27 +204,67 @@ __device__ inline float select(const Window &w, int mode, double center64, float
     return __uint_as_float(val);
 }
 
-// median_f32_mut (math/median.rs:46-63) of the candidates (n > 0): f32 average of the two middle values
-__device__ inline float median_f32(const Window &w, int mode, double center64, float center32, unsigned int n,
-                                   unsigned int *hist) {
+// the rank-th smallest key (0-based) given the prepared top-level histogram
+template <class S>
+__device__ inline float select_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int rank, unsigned int *hist) {
+    unsigned int bin, before, total;
+    find_bin(hist0, 2048, rank, &bin, &before, &total);
+    return descend(src, w, k, 0x7ffu << 21, bin << 21, rank - before, 1, hist);
+}
+
+// keys of ranks r-1 and r (r >= 1): they share passes for as long as they sit in the same bin
+template <class S>
+__device__ inline void select_pair_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int r, unsigned int *hist,
+                                        float *lower_out, float *upper_out) {
+    const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+    uint32_t mask = 0, val = 0;
+    unsigned int rank_hi = r, rank_lo = r - 1;
+    for (int p = 0; p < 3; ++p) {
+        const unsigned int *h = hist0;
+        if (p > 0) {
+            window_hist(src, w, k, mask, val, shifts[p], bits[p], hist);
+            h = hist;
+        }
+        unsigned int bin_hi, before_hi, bin_lo, before_lo, total;
+        find_bin(h, 1 << bits[p], rank_hi, &bin_hi, &before_hi, &total);
+        find_bin(h, 1 << bits[p], rank_lo, &bin_lo, &before_lo, &total);
+        const uint32_t lvl_mask = ((1u << bits[p]) - 1u) << shifts[p];
+        if (bin_hi != bin_lo) {  // the pair straddles a bin boundary: finish each on its own
+            *lower_out = descend(src, w, k, mask | lvl_mask, val | (bin_lo << shifts[p]), rank_lo - before_lo, p + 1, hist);
+            *upper_out = descend(src, w, k, mask | lvl_mask, val | (bin_hi << shifts[p]), rank_hi - before_hi, p + 1, hist);
+            return;
+        }
+        rank_hi -= before_hi;
+        rank_lo -= before_lo;
+        val |= bin_hi << shifts[p];
+        mask |= lvl_mask;
+    }
+    *lower_out = __uint_as_float(val);  // identical keys
+    *upper_out = __uint_as_float(val);
+}
+
+// median_f32_mut (math/median.rs:46-63) of the n > 0 prepared keys: f32 average of the two middle values
+template <class S>
+__device__ inline float median_f32_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int n, unsigned int *hist) {
     const unsigned int mid = n / 2;
-    const float right = select(w, mode, center64, center32, mid, hist);
     if (n % 2 == 0) {
-        const float left = select(w, mode, center64, center32, mid - 1, hist);
+        float left, right;
+        select_pair_from(src, w, k, hist0, mid, hist, &left, &right);
         return (left + right) / 2.0f;
     }
-    return right;
+    return select_from(src, w, k, hist0, mid, hist);
 }
 
 // exact_median_mut (math/median.rs:27-44): f64 average of the two middle values
-__device__ inline double exact_median(const Window &w, unsigned int n, unsigned int *hist) {
+template <class S>
+__device__ inline double exact_median_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int n, unsigned int *hist) {
     const unsigned int mid = n / 2;
-    const float right = select(w, 0, 0.0, 0.0f, mid, hist);
     if (n % 2 == 0) {
-        const float left = select(w, 0, 0.0, 0.0f, mid - 1, hist);
+        float left, right;
+        select_pair_from(src, w, k, hist0, mid, hist, &left, &right);
         return ((double)left + (double)right) / 2.0;
     }
-    return (double)right;
+    return (double)select_from(src, w, k, hist0, mid, hist);
 }
 
 }  // namespace absel

@@ -25,11 +25,30 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <chrono>
 #include <unordered_map>
 
 namespace {
 
 constexpr double kMadToSigma = 1.4826;
+
+// AB_TRACE=1: wall-clock stamps of the host-visible stages on stderr (developer aid)
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    explicit Trace(const char *what) : on(getenv("AB_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {
+        if (on) fprintf(stderr, "[ab_trace] %s:", what);
+    }
+    void mark(const char *stage) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, " %s %.3f ms;", stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+    ~Trace() {
+        if (on) fprintf(stderr, "\n");
+    }
+};
 
 // ---- per-tile sigma-clipped statistics ---------------------------------------------------------
 struct TileOut {
@@ -40,23 +59,10 @@ struct TileOut {
 
 // estimate_background's per-tile body (star_detection.rs:47-68) = sigma_clipped_stats(vals, 3.0, 2)
 // (math/sigma_clip.rs:4-34); order statistics by workgroup radix select (block_select.hpp)
-__global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const float *__restrict__ img, int rows, int cols,
-                                                                        int64_t ld, int step, int ntx,
-                                                                        TileOut *__restrict__ out) {
-    __shared__ unsigned int hist[2048];
-    const int ty = blockIdx.x / ntx, tx = blockIdx.x % ntx;
-    absel::Window t;
-    t.img = img;
-    t.ld = ld;
-    t.y0 = ty * step;
-    t.x0 = tx * step;
-    t.y1 = min(t.y0 + step, rows);
-    t.x1 = min(t.x0 + step, cols);
-    t.min_valid = 1e-7f;  // star_detection.rs:56
-    t.lo = -__builtin_inff();
-    t.hi = __builtin_inff();
-
-    unsigned int n = absel::count(t, hist);
+template <class S>
+__device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, unsigned int *hist0, unsigned int *hist) {
+    const absel::Keying by_value = {0, 0.0, 0.0f};
+    unsigned int n = absel::prepare(src, t, by_value, hist0);  // count + top-level histogram of the values
     TileOut res = {0.0, 1.0, 0, 0};
     if (n >= 8) {
         res.valid = 1;
@@ -68,8 +74,10 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
                 sigma = 1.0;
                 break;
             }
-            median = absel::exact_median(t, n, hist);                                  // median.rs:27-44
-            const float mad_f32 = absel::median_f32(t, 1, median, 0.0f, n, hist);      // sigma_clip.rs:14-16
+            median = absel::exact_median_from(src, t, by_value, hist0, n, hist);             // median.rs:27-44
+            const absel::Keying by_dev = {1, median, 0.0f};
+            absel::prepare(src, t, by_dev, hist0);
+            const float mad_f32 = absel::median_f32_from(src, t, by_dev, hist0, n, hist);      // sigma_clip.rs:14-16
             const double sig = fmax((double)mad_f32 * kMadToSigma, 1e-30);
             if (it == 2) {
                 sigma = sig;
@@ -83,23 +91,65 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
                 t.lo = __builtin_inff();
                 t.hi = -__builtin_inff();
             }
-            n = absel::count(t, hist);
+            n = absel::prepare(src, t, by_value, hist0);
         }
         res.median = median;
         res.sigma = sigma;
     }
+    return res;
+}
+
+__global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const float *__restrict__ img, int rows, int cols,
+                                                                        int64_t ld, int step, int ntx,
+                                                                        TileOut *__restrict__ out) {
+    __shared__ unsigned int hist0[2048], hist[2048];
+    const int ty = blockIdx.x / ntx, tx = blockIdx.x % ntx;
+    absel::Window t;
+    t.img = img;
+    t.ld = ld;
+    t.y0 = ty * step;
+    t.x0 = tx * step;
+    t.y1 = min(t.y0 + step, rows);
+    t.x1 = min(t.x0 + step, cols);
+    t.min_valid = 1e-7f;  // star_detection.rs:56
+    t.lo = -__builtin_inff();
+    t.hi = __builtin_inff();
+    const absel::StreamSource src;
+    const TileOut res = tile_stats(src, t, hist0, hist);
     if (threadIdx.x == 0) out[blockIdx.x] = res;
 }
 
 // ---- threshold + union-find labelling -------------------------------------------------------------
 __device__ __forceinline__ bool above(float v, double threshold) { return __builtin_isfinite(v) && (double)v > threshold; }
 
+// threshold every pixel into the forest (parent = self / -1) and append the labelled ones -- a fraction of a percent
+// of the frame -- to a list, so that the merge / numbering / statistics kernels touch only those.  A block owns a
+// contiguous span of pixels, gathers its labelled indices in LDS and reserves list space with ONE global atomic
+// (a per-wave atomic on a single counter serialises at ~12 ns each: 0.4 ms per frame).
+constexpr int kInitSpan = 8192;  // pixels per block
 __global__ __launch_bounds__(256) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
-                                                         double threshold, int *__restrict__ parent) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int r = i / cols, c = i - r * cols;
-    parent[i] = above(img[r * ld + c], threshold) ? i : -1;
+                                                         double threshold, int *__restrict__ parent, int *__restrict__ plist,
+                                                         unsigned int *nlab) {
+    __shared__ int found[kInitSpan];
+    __shared__ unsigned int nfound, base;
+    if (threadIdx.x == 0) nfound = 0;
+    __syncthreads();
+    const int P = rows * cols, start = blockIdx.x * kInitSpan;
+#pragma unroll 4
+    for (int off = threadIdx.x; off < kInitSpan; off += 256) {
+        const int i = start + off;
+        if (i < P) {
+            const int r = i / cols, c = i - r * cols;
+            const bool is = above(img[r * ld + c], threshold);
+            parent[i] = is ? i : -1;
+            if (is) found[atomicAdd(&nfound, 1u)] = i;
+        }
+    }
+    __syncthreads();
+    if (nfound == 0) return;
+    if (threadIdx.x == 0) base = atomicAdd(nlab, nfound);
+    __syncthreads();
+    for (unsigned int k = threadIdx.x; k < nfound; k += 256) plist[base + k] = found[k];
 }
 
 __device__ __forceinline__ int uf_find(int *parent, int x) {
@@ -126,52 +176,156 @@ __device__ __forceinline__ void uf_union(int *parent, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void label_merge_kernel(int rows, int cols, int *parent) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * cols) return;
-    if (parent[i] < 0) return;
-    const int r = i / cols, c = i - r * cols;
-    // forward half of the 8-neighbourhood (star_detection.rs:120): E, SW, S, SE
-    if (c + 1 < cols && parent[i + 1] >= 0) uf_union(parent, i, i + 1);
-    if (r + 1 < rows) {
-        const int d = i + cols;
-        if (c > 0 && parent[d - 1] >= 0) uf_union(parent, i, d - 1);
-        if (parent[d] >= 0) uf_union(parent, i, d);
-        if (c + 1 < cols && parent[d + 1] >= 0) uf_union(parent, i, d + 1);
+__global__ __launch_bounds__(256) void label_merge_kernel(int rows, int cols, int *parent, const int *__restrict__ plist,
+                                                          const unsigned int *__restrict__ nlab) {
+    const unsigned int n = *nlab;
+    for (unsigned int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        const int i = plist[k];
+        const int r = i / cols, c = i - r * cols;
+        // forward half of the 8-neighbourhood (star_detection.rs:120): E, SW, S, SE
+        if (c + 1 < cols && parent[i + 1] >= 0) uf_union(parent, i, i + 1);
+        if (r + 1 < rows) {
+            const int d = i + cols;
+            if (c > 0 && parent[d - 1] >= 0) uf_union(parent, i, d - 1);
+            if (parent[d] >= 0) uf_union(parent, i, d);
+            if (c + 1 < cols && parent[d + 1] >= 0) uf_union(parent, i, d + 1);
+        }
     }
 }
 
-struct Triple {
-    int idx, root;
-    float value;
+// ---- per-component statistics and moments -------------------------------------------------------------
+struct CompStat {  // filled by atomics (order-independent integers)
+    int npix, x0, x1, y0, y1, first_interior;
 };
 
-// flatten + compact the labelled pixels; one atomic per wave on the list tail
-__global__ __launch_bounds__(256) void label_compact_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
-                                                            int *parent, Triple *__restrict__ list, unsigned int *count,
-                                                            unsigned int cap) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    bool is = false;
-    int root = -1;
-    if (i < rows * cols && parent[i] >= 0) {
-        root = uf_find(parent, i);
-        is = true;
-    }
-    const unsigned long long m = __ballot(is);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63;
-    unsigned int base = 0;
-    if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(count, (unsigned int)__builtin_popcountll(m));
-    base = __shfl(base, (int)__builtin_ctzll(m), 64);
-    if (is) {
-        const unsigned int pos = base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (pos < cap) {
-            const int r = i / cols, c = i - r * cols;
-            list[pos].idx = i;
-            list[pos].root = root;
-            list[pos].value = img[r * ld + c];
+struct CompRec {  // what the host needs to finish one star (star_detection.rs:147-213)
+    int first_interior, npix;
+    double sum_flux, sum_x, sum_y, peak, sum_r2, sum_xx, sum_yy, sum_xy;
+};
+
+// number the component roots (parent[i] == i) among the labelled pixels; one atomic per wave on the tail
+__global__ __launch_bounds__(256) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist,
+                                                    const unsigned int *__restrict__ nlab, int *__restrict__ roots, int *__restrict__ cid,
+                                                    unsigned int *nroots, unsigned int cap) {
+    const unsigned int n = *nlab;
+    const unsigned int rounds = (n + gridDim.x * 256 - 1) / (gridDim.x * 256);  // uniform trip count (ballots inside)
+    for (unsigned int it = 0; it < rounds; ++it) {
+        const unsigned int k = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        int i = -1;
+        bool is = false;
+        if (k < n) {
+            i = plist[k];
+            is = parent[i] == i;
+        }
+        const unsigned long long m = __ballot(is);
+        if (m == 0) continue;
+        const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(nroots, (unsigned int)__builtin_popcountll(m));
+        base = __shfl(base, leader, 64);
+        if (is) {
+            const unsigned int pos = base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) {
+                roots[pos] = i;
+                cid[i] = (int)pos;
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void comp_init_kernel(CompStat *st, unsigned int n) {
+    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) st[i] = CompStat{0, 0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff};
+}
+
+// flatten the forest and gather size / bounding box / first interior pixel of every component
+__global__ __launch_bounds__(256) void comp_stats_kernel(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st,
+                                                         const int *__restrict__ plist, const unsigned int *__restrict__ nlab) {
+    const unsigned int n = *nlab;
+    for (unsigned int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        const int i = plist[k];
+        const int root = uf_find(parent, i);
+        __hip_atomic_store(&parent[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CompStat *s = &st[cid[root]];
+        const int r = i / cols, c = i - r * cols;
+        atomicAdd(&s->npix, 1);
+        atomicMin(&s->x0, c);
+        atomicMax(&s->x1, c);
+        atomicMin(&s->y0, r);
+        atomicMax(&s->y1, r);
+        if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) atomicMin(&s->first_interior, i);  // BFS seeds are interior (:107-110)
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = fmax(x, __shfl_xor(x, off, 64));
+    return x;
+}
+
+// one wave per component: flux-weighted moments over the bounding box (star_detection.rs:147-189).  Lane l owns
+// the columns x0 + l + 64 k; lane partials are combined by a fixed butterfly, so results are reproducible
+// (the reference accumulates in BFS order: the two agree to ~1e-15 relative).
+__global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
+                                                           const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
+                                                           double bg_median, CompRec *__restrict__ rec) {
+    const unsigned int comp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (comp >= ncomp) return;
+    const CompStat s = st[comp];
+    const int root = roots[comp];
+    CompRec out;
+    out.first_interior = s.first_interior;
+    out.npix = s.npix;
+    out.sum_flux = out.sum_x = out.sum_y = out.peak = out.sum_r2 = out.sum_xx = out.sum_yy = out.sum_xy = 0.0;
+    if (s.npix >= 3 && s.npix <= 5000 && s.first_interior != 0x7fffffff) {  // :142-145
+        double f = 0.0, sx = 0.0, sy = 0.0, pk = 0.0;
+        for (int r = s.y0; r <= s.y1; ++r)
+            for (int cb = s.x0; cb <= s.x1; cb += 64) {
+                const int c = cb + lane;
+                if (c <= s.x1 && parent[r * cols + c] == root) {
+                    const double v = fmax((double)img[r * ld + c] - bg_median, 0.0);
+                    f += v;
+                    sx += (double)c * v;
+                    sy += (double)r * v;
+                    pk = fmax(pk, v);
+                }
+            }
+        f = wave_sum(f);
+        sx = wave_sum(sx);
+        sy = wave_sum(sy);
+        pk = wave_max(pk);
+        out.sum_flux = f;
+        out.sum_x = sx;
+        out.sum_y = sy;
+        out.peak = pk;
+        if (f > 0.0) {
+            const double cx = sx / f, cy = sy / f;
+            double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
+            for (int r = s.y0; r <= s.y1; ++r)
+                for (int cb = s.x0; cb <= s.x1; cb += 64) {
+                    const int c = cb + lane;
+                    if (c <= s.x1 && parent[r * cols + c] == root) {
+                        const double v = fmax((double)img[r * ld + c] - bg_median, 0.0);
+                        const double dx = (double)c - cx, dy = (double)r - cy;
+                        r2 += (dx * dx + dy * dy) * v;
+                        xx += dx * dx * v;
+                        yy += dy * dy * v;
+                        xy += dx * dy * v;
+                    }
+                }
+            out.sum_r2 = wave_sum(r2);
+            out.sum_xx = wave_sum(xx);
+            out.sum_yy = wave_sum(yy);
+            out.sum_xy = wave_sum(xy);
+        }
+    }
+    if (lane == 0) rec[comp] = out;
 }
 
 // ---- normalize_for_detection (affine.rs:24-53) ------------------------------------------------------
@@ -245,106 +399,67 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     if (rows < 3 || cols < 3) return AB_OK;  // :89-98
     AB_CHECK(ctx, rows * cols < (int64_t(1) << 31), "detect_stars: image too large for 32-bit labels");
     AB_HIP(ctx, hipSetDevice(ctx->device));
+    Trace trace("detect_stars");
     const int64_t m = std::min(rows, cols);
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // :100
     double bg_median, bg_sigma;
     AB_TRY(ab_estimate_background_device(ctx, img, rows, cols, ld, tile_size, &bg_median, &bg_sigma));
+    trace.mark("background");
     *bg_median_out = bg_median;
     *bg_sigma_out = bg_sigma;
     const double threshold = bg_median + sigma_threshold * bg_sigma;  // :103
 
     const int64_t P = rows * cols;
-    int *parent = nullptr;
-    unsigned int *count = nullptr;
-    Triple *list = nullptr;
-    const unsigned int cap = (unsigned int)std::min<int64_t>(P, int64_t(1) << 28);
-    AB_HIP(ctx, hipMalloc((void **)&parent, (size_t)P * sizeof(int)));
-    hipError_t e = hipMalloc((void **)&count, sizeof(unsigned int));
-    if (e == hipSuccess) e = hipMalloc((void **)&list, (size_t)cap * sizeof(Triple));
-    std::vector<Triple> h;
-    int rc = AB_OK;
-    if (e == hipSuccess) e = hipMemsetAsync(count, 0, sizeof(unsigned int), ctx->stream);
-    if (e == hipSuccess) {
-        const int g = (int)((P + 255) / 256);
-        hipLaunchKernelGGL(label_init_kernel, dim3(g), dim3(256), 0, ctx->stream, img, (int)rows, (int)cols, ld, threshold, parent);
-        hipLaunchKernelGGL(label_merge_kernel, dim3(g), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent);
-        hipLaunchKernelGGL(label_compact_kernel, dim3(g), dim3(256), 0, ctx->stream, img, (int)rows, (int)cols, ld, parent, list, count,
-                           cap);
-        e = hipGetLastError();
-    }
-    unsigned int n = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&n, count, sizeof n, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && n > cap) rc = ab_set_error(ctx, AB_ERR_NOMEM, "detect_stars: %u labelled pixels exceed the list capacity", n);
-    if (e == hipSuccess && rc == AB_OK && n > 0) {
-        h.resize(n);
-        e = hipMemcpyAsync(h.data(), list, (size_t)n * sizeof(Triple), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    }
-    if (parent) (void)hipFree(parent);
-    if (count) (void)hipFree(count);
-    if (list) (void)hipFree(list);
-    if (e != hipSuccess) return ab_set_error(ctx, AB_ERR_HIP, "detect_stars: %s", hipGetErrorString(e));
-    if (rc != AB_OK) return rc;
+    const unsigned int root_cap = (unsigned int)(P / 4 + 1);  // 8-connected components cannot be denser
+    int *parent = nullptr, *cid = nullptr, *roots = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_PARENT, (size_t)P * sizeof(int), (void **)&parent));
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_CID, (size_t)P * sizeof(int), (void **)&cid));
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_ROOTS, ((size_t)root_cap + 4) * sizeof(int), (void **)&roots));
+    unsigned int *nroots = (unsigned int *)(roots + root_cap), *nlab = nroots + 1;
+    int *plist = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)P * sizeof(int), (void **)&plist));
+    const int gl = (ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;  // list kernels: grid-stride over *nlab entries
+    AB_HIP(ctx, hipMemsetAsync(nroots, 0, 2 * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(label_init_kernel, dim3((unsigned)((P + kInitSpan - 1) / kInitSpan)), dim3(256), 0, ctx->stream, img, (int)rows,
+                       (int)cols, ld, threshold, parent, plist, nlab);
+    hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, plist, nlab);
+    hipLaunchKernelGGL(roots_kernel, dim3(gl), dim3(256), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
+    AB_HIP(ctx, hipGetLastError());
+    unsigned int ncomp = 0;
+    AB_HIP(ctx, hipMemcpyAsync(&ncomp, nroots, sizeof ncomp, hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    trace.mark("label+roots");
+    AB_CHECK(ctx, ncomp <= root_cap, "detect_stars: %u components exceed the table capacity", ncomp);
+    if (ncomp == 0) return AB_OK;
+    void *cbuf = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, (size_t)ncomp * (sizeof(CompStat) + sizeof(CompRec)), &cbuf));
+    CompRec *drec = (CompRec *)cbuf;
+    CompStat *dstat = (CompStat *)(drec + ncomp);
+    hipLaunchKernelGGL(comp_init_kernel, dim3((ncomp + 255) / 256), dim3(256), 0, ctx->stream, dstat, ncomp);
+    hipLaunchKernelGGL(comp_stats_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, cid, dstat, plist, nlab);
+    hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, roots, dstat, ncomp,
+                       bg_median, drec);
+    AB_HIP(ctx, hipGetLastError());
+    std::vector<CompRec> recs(ncomp);
+    AB_HIP(ctx, hipMemcpyAsync(recs.data(), drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
-    // ---- host: group by root in raster order, keep components that own an interior pixel ----
-    std::sort(h.begin(), h.end(), [](const Triple &a, const Triple &b) { return a.idx < b.idx; });
-    struct Comp {
-        int first_interior = -1;
-        std::vector<int> px;  // positions in h (raster order)
-    };
-    std::unordered_map<int, int> root_to_comp;
-    std::vector<Comp> comps;
-    for (size_t k = 0; k < h.size(); ++k) {
-        auto it = root_to_comp.find(h[k].root);
-        int ci;
-        if (it == root_to_comp.end()) {
-            ci = (int)comps.size();
-            root_to_comp.emplace(h[k].root, ci);
-            comps.emplace_back();
-        } else {
-            ci = it->second;
-        }
-        Comp &c = comps[ci];
-        c.px.push_back((int)k);
-        const int r = h[k].idx / (int)cols, cc = h[k].idx % (int)cols;
-        if (c.first_interior < 0 && r >= 1 && r < rows - 1 && cc >= 1 && cc < cols - 1) c.first_interior = h[k].idx;
-    }
-    std::vector<int> order;
-    for (int i = 0; i < (int)comps.size(); ++i)
-        if (comps[i].first_interior >= 0) order.push_back(i);
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return comps[a].first_interior < comps[b].first_interior; });  // discovery order
+    trace.mark("moments+D2H");
+    if (trace.on) fprintf(stderr, " (%u components)", ncomp);
+    // ---- host: finish the stars in discovery order (ascending first interior pixel = BFS seed order) ----
+    std::vector<const CompRec *> order;
+    for (const CompRec &c : recs)
+        if (c.first_interior != 0x7fffffff && c.npix >= 3 && c.npix <= 5000 && c.sum_flux > 0.0) order.push_back(&c);
+    std::sort(order.begin(), order.end(), [](const CompRec *a, const CompRec *b) { return a->first_interior < b->first_interior; });
 
     std::vector<ab_detected_star> found;
-    for (int ci : order) {
-        const Comp &c = comps[ci];
-        const size_t npix = c.px.size();
-        if (npix < 3 || npix > 5000) continue;  // :142-145
-        double sum_flux = 0.0, sum_x = 0.0, sum_y = 0.0, peak = 0.0;
-        for (int k : c.px) {
-            const double v = std::fmax((double)h[k].value - bg_median, 0.0);
-            const int pr = h[k].idx / (int)cols, pc = h[k].idx % (int)cols;
-            sum_flux += v;
-            sum_x += (double)pc * v;
-            sum_y += (double)pr * v;
-            peak = std::fmax(peak, v);
-        }
-        if (sum_flux <= 0.0) continue;
-        const double cx = sum_x / sum_flux, cy = sum_y / sum_flux;
-        double sum_r2 = 0.0, sum_xx = 0.0, sum_yy = 0.0, sum_xy = 0.0;
-        for (int k : c.px) {
-            const double v = std::fmax((double)h[k].value - bg_median, 0.0);
-            const int pr = h[k].idx / (int)cols, pc = h[k].idx % (int)cols;
-            const double dx = (double)pc - cx, dy = (double)pr - cy;
-            sum_r2 += (dx * dx + dy * dy) * v;
-            sum_xx += dx * dx * v;
-            sum_yy += dy * dy * v;
-            sum_xy += dx * dy * v;
-        }
-        const double sigma_star = std::sqrt(sum_r2 / (2.0 * sum_flux));
+    for (const CompRec *c : order) {
+        const double sum_flux = c->sum_flux;
+        const double cx = c->sum_x / sum_flux, cy = c->sum_y / sum_flux;
+        const double sigma_star = std::sqrt(c->sum_r2 / (2.0 * sum_flux));
         const double fwhm = sigma_star * 2.3548200450309493;
         if (fwhm < 0.5 || fwhm > 30.0) continue;
-        const double ixx = sum_xx / sum_flux, iyy = sum_yy / sum_flux, ixy = sum_xy / sum_flux;
+        const double ixx = c->sum_xx / sum_flux, iyy = c->sum_yy / sum_flux, ixy = c->sum_xy / sum_flux;
         const double trace = ixx + iyy;
         const double det = std::fmax(ixx * iyy - ixy * ixy, 0.0);
         const double disc = std::sqrt(std::fmax((trace * trace / 4.0) - det, 0.0));
@@ -360,23 +475,30 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
         s.flux = sum_flux;
         s.fwhm = fwhm;
         s.eccentricity = ecc;
-        s.peak = peak;
-        s.npix = npix;
-        s.snr = bg_sigma <= DBL_EPSILON ? 0.0 : peak / bg_sigma;  // confidence.rs:3-8
+        s.peak = c->peak;
+        s.npix = (uint64_t)c->npix;
+        s.snr = bg_sigma <= DBL_EPSILON ? 0.0 : c->peak / bg_sigma;  // confidence.rs:3-8
         found.push_back(s);
     }
+    trace.mark("finish");
     std::stable_sort(found.begin(), found.end(), [](const ab_detected_star &a, const ab_detected_star &b) { return b.flux < a.flux; });  // :215
     // dedup within 3 px, comparing only against kept stars in the 3 x 3 neighbourhood of 3 px grid cells (:217-248)
-    std::unordered_map<uint64_t, std::vector<int>> grid;
+    // (kept stars live in a chained hash table over the 3 px cells: no per-cell allocations)
+    size_t nbuckets = 64;
+    while (nbuckets < 2 * found.size()) nbuckets <<= 1;
+    std::vector<int> head(nbuckets, -1), next(found.size(), -1);
+    std::vector<uint64_t> cell_of(found.size());
     auto key = [](uint64_t gy, uint64_t gx) { return (gy << 32) | gx; };
+    auto bucket = [&](uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 32) & (nbuckets - 1); };
+    stars->reserve(found.size());
     for (size_t i = 0; i < found.size(); ++i) {
         const uint64_t gx = (uint64_t)(found[i].x / 3.0), gy = (uint64_t)(found[i].y / 3.0);
         bool too_close = false;
         for (uint64_t ny = gy ? gy - 1 : 0; ny <= gy + 1 && !too_close; ++ny)
             for (uint64_t nx = gx ? gx - 1 : 0; nx <= gx + 1 && !too_close; ++nx) {
-                auto it = grid.find(key(ny, nx));
-                if (it == grid.end()) continue;
-                for (int j : it->second) {
+                const uint64_t k = key(ny, nx);
+                for (int j = head[bucket(k)]; j >= 0; j = next[j]) {
+                    if (cell_of[j] != k) continue;
                     const double dx = found[i].x - found[j].x, dy = found[i].y - found[j].y;
                     if (dx * dx + dy * dy < 9.0) {
                         too_close = true;
@@ -385,10 +507,14 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
                 }
             }
         if (!too_close) {
-            grid[key(gy, gx)].push_back((int)i);
+            const uint64_t k = key(gy, gx);
+            cell_of[i] = k;
+            next[i] = head[bucket(k)];
+            head[bucket(k)] = (int)i;
             stars->push_back(found[i]);
         }
     }
+    trace.mark("sort+dedup");
     return AB_OK;
 }
 
@@ -413,8 +539,11 @@ int ab_normalize_for_detection_device(ab_ctx *ctx, const float *img, int64_t len
         return AB_OK;
     };
     if (s.size() < 100) return clone();
-    std::sort(s.begin(), s.end());
-    const double lo = (double)s[s.size() / 100], hi = (double)s[s.size() * 999 / 1000];
+    // the reference sorts the subsample (:37-40); only two order statistics of it are read
+    const size_t k_lo = s.size() / 100, k_hi = s.size() * 999 / 1000;
+    std::nth_element(s.begin(), s.begin() + k_hi, s.end());
+    std::nth_element(s.begin(), s.begin() + k_lo, s.begin() + k_hi);
+    const double lo = (double)s[k_lo], hi = (double)s[k_hi];
     const double range = hi - lo;
     if (range < 1e-15) return clone();
     *cloned = 0;

@@ -172,6 +172,11 @@ AB_API int ab_normalize_for_detection(ab_ctx *ctx, const ab_plane *img, ab_plane
  * vote ties are broken by (ref, tgt) index (the reference iterates a HashMap). */
 AB_API int ab_align_channel_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane *target, int num_threads,
                                    ab_affine_align_result *out);
+/* align_channel_affine(reference, targets[i]) for i < n in one call: the loop a stacking / compose caller runs
+ * (cmd/compose/blend.rs:226-232, rgb.rs:165-189).  The reference frame's normalisation, detection and triangle
+ * table are computed once; each out[i] equals what ab_align_channel_affine(reference, targets[i]) returns. */
+AB_API int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
+                              ab_affine_align_result *out);
 /* the star-list half (triangles -> votes -> RANSAC -> sanity) on given centroids; host only */
 AB_API int ab_affine_from_stars(const double *ref_xy, size_t n_ref, const double *tgt_xy, size_t n_tgt, int64_t rows,
                                 int64_t cols, int num_threads, ab_affine_align_result *out, int *found);
