@@ -45,9 +45,9 @@ struct ab_ctx {
     void *ws[AB_WS_SLOTS] = {};
     size_t ws_bytes[AB_WS_SLOTS] = {};
     // frame-parallel registration (affine.hip): child contexts (own stream + workspaces), one per host worker;
-    // AB_REGISTER_WORKERS overrides the default of 8
+    // AB_REGISTER_WORKERS overrides the default of 16
     std::vector<ab_ctx *> workers;
-    int register_workers = 8;
+    int register_workers = 16;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
 };

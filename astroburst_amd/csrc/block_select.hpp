@@ -40,8 +40,13 @@ struct Keying {  // mode 0: key = bits(v); 1: bits((f32)|(f64)v - center64|); 2:
     float center32;
 };
 
+// finite && v > min_valid && lo <= v <= hi, folded into two compares: the bounds below are loop invariants
+// (v > m  <=>  v >= next float above m, for m >= 0; |v| <= FLT_MAX  <=>  v is finite; NaN fails every compare)
 __device__ __forceinline__ bool candidate(const Window &w, float v) {
-    return __builtin_isfinite(v) && v > w.min_valid && v >= w.lo && v <= w.hi;
+    const float above_min = __uint_as_float(__float_as_uint(w.min_valid) + 1u);
+    const float lo = fmaxf(fmaxf(w.lo, -3.402823466e+38f), above_min);
+    const float hi = fminf(w.hi, 3.402823466e+38f);
+    return v >= lo && v <= hi;
 }
 
 __device__ __forceinline__ uint32_t key_of(const Keying &k, float v) {
@@ -179,6 +184,52 @@ __device__ inline void find_bin(const unsigned int *hist, int nb, unsigned int r
     *total_out = s_total;
 }
 
+// find_bin for two ranks (rank_lo <= rank_hi) off one prefix scan
+__device__ inline void find_bin2(const unsigned int *hist, int nb, unsigned int rank_lo, unsigned int rank_hi, unsigned int *bin_lo,
+                                 unsigned int *before_lo, unsigned int *bin_hi, unsigned int *before_hi) {
+    __shared__ unsigned int s_bin[2], s_before[2];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, per = nb / 64;
+        unsigned int s = 0;
+        for (int j = 0; j < per; ++j) s += hist[lane * per + j];
+        unsigned int inc = s;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        const unsigned int exc = inc - s;
+        const unsigned int total = __shfl(inc, 63, 64);
+        const unsigned int ranks[2] = {rank_lo, rank_hi};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned int rank = ranks[q];
+            if (lane == 0 && rank >= total) {
+                s_bin[q] = nb - 1;
+                s_before[q] = 0;
+            }
+            if (rank >= exc && rank < inc) {
+                unsigned int cum = exc;
+                for (int j = 0; j < per; ++j) {
+                    const unsigned int h = hist[lane * per + j];
+                    if (cum + h > rank) {
+                        s_bin[q] = lane * per + j;
+                        s_before[q] = cum;
+                        break;
+                    }
+                    cum += h;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    *bin_lo = s_bin[0];
+    *before_lo = s_before[0];
+    *bin_hi = s_bin[1];
+    *before_hi = s_before[1];
+}
+
 // top-level (bits 31..21) histogram of the window's keys into hist0; returns the candidate count
 template <class S>
 __device__ inline unsigned int prepare(const S &src, const Window &w, const Keying &k, unsigned int *hist0 /* LDS, 2048 */) {
@@ -225,9 +276,8 @@ __device__ inline void select_pair_from(const S &src, const Window &w, const Key
             window_hist(src, w, k, mask, val, shifts[p], bits[p], hist);
             h = hist;
         }
-        unsigned int bin_hi, before_hi, bin_lo, before_lo, total;
-        find_bin(h, 1 << bits[p], rank_hi, &bin_hi, &before_hi, &total);
-        find_bin(h, 1 << bits[p], rank_lo, &bin_lo, &before_lo, &total);
+        unsigned int bin_hi, before_hi, bin_lo, before_lo;
+        find_bin2(h, 1 << bits[p], rank_lo, rank_hi, &bin_lo, &before_lo, &bin_hi, &before_hi);
         const uint32_t lvl_mask = ((1u << bits[p]) - 1u) << shifts[p];
         if (bin_hi != bin_lo) {  // the pair straddles a bin boundary: finish each on its own
             *lower_out = descend(src, w, k, mask | lvl_mask, val | (bin_lo << shifts[p]), rank_lo - before_lo, p + 1, hist);

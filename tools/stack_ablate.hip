@@ -7,14 +7,15 @@
 __global__ void fill_kernel(float *p, int64_t n, uint32_t seed, float cr_rate) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // counter-based hash -> approx normal (sum of 4 uniforms), sky 1200 +- 12, rare x30 outliers
+    // counter-based hash -> Box-Muller normal (true Gaussian tails, like the bench's shot + read noise), sky 1200 +- 12.7,
+    // rare x30 outliers
     uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
-    float acc = 0.f;
-    for (int k = 0; k < 4; ++k) {
+    float u[2];
+    for (int k = 0; k < 2; ++k) {
         z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
-        acc += (float)(z >> 40) * (1.0f / 16777216.0f);
+        u[k] = ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);
     }
-    float v = 1200.0f + (acc - 2.0f) * 20.8f;
+    float v = 1200.0f + 12.7f * sqrtf(-2.0f * logf(u[0])) * cosf(6.2831853f * u[1]);
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
     if ((float)(z >> 40) * (1.0f / 16777216.0f) < cr_rate) v *= 30.0f;
     p[i] = v;
