@@ -85,6 +85,46 @@ struct StreamSource {
     }
 };
 
+// A window of <= 256 x 256 pixels held entirely on chip: the first NL of a thread's 64 sweeps live in LDS
+// (conflict-free, stride kBlock), the remaining NR in registers.  StreamSource re-reads a 256 KiB tile ~19 times;
+// with one tile per CU the live set (32 tiles = 8 MiB per XCD) overflows the 4 MiB L2, and rocprofv3 counted
+// 1.2 GB of fetches per 4096^2 frame for the tile kernel alone.  Same thread mapping as StreamSource.
+template <int NL, int NR>
+struct TileSource {
+    static_assert(NL + NR == 64, "a 256 x 256 tile is 64 sweeps of the 256 x 4 thread layout");
+    float *lds;  // NL * kBlock floats
+    mutable float regs[NR];
+    __device__ __forceinline__ void load(const Window &w) {
+        const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
+        const int c = w.x0 + tx;
+        const bool col_ok = c < w.x1;
+#pragma unroll 8
+        for (int k = 0; k < NL; ++k) {
+            const int r = w.y0 + ty + 4 * k;
+            float v = __builtin_nanf("");
+            if (col_ok && r < w.y1) v = w.img[(int64_t)r * w.ld + c];
+            lds[k * kBlock + threadIdx.x] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = w.y0 + ty + 4 * (NL + k);
+            float v = __builtin_nanf("");
+            if (col_ok && r < w.y1) v = w.img[(int64_t)r * w.ld + c];
+            regs[k] = v;
+        }
+    }
+    template <class F>
+    __device__ __forceinline__ void for_each(const Window &, F f) const {
+#pragma unroll 5
+        for (int k = 0; k < NL; ++k) f(lds[k * kBlock + threadIdx.x]);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            asm volatile("" : "+v"(regs[k]));  // keeps LLVM from hoisting per-pixel keys across the passes (spills)
+            f(regs[k]);
+        }
+    }
+};
+
 // Top-level histogram update with the wave's dominant bin counted in a scalar: the first candidate a wave meets
 // names the "mode" bin; lanes hitting it are tallied with ballot + popcount (no atomic, no serialisation) and
 // flushed once at the end of the pass, everybody else uses a per-lane atomic.

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
                                                                         int64_t ld, int step, int ntx,
                                                                         TileOut *__restrict__ out) {
     __shared__ unsigned int hist0[2048], hist[2048];
+    __shared__ float cache[35 * absel::kBlock];  // 140 KiB of the CU's 160 KiB
     const int ty = blockIdx.x / ntx, tx = blockIdx.x % ntx;
     absel::Window t;
     t.img = img;
@@ -114,7 +115,10 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
     t.min_valid = 1e-7f;  // star_detection.rs:56
     t.lo = -__builtin_inff();
     t.hi = __builtin_inff();
-    const absel::StreamSource src;
+    absel::TileSource<35, 29> src;  // the whole tile on chip: one read of the frame per estimate_background
+    src.lds = cache;
+    src.load(t);
+    __syncthreads();
     const TileOut res = tile_stats(src, t, hist0, hist);
     if (threadIdx.x == 0) out[blockIdx.x] = res;
 }
