@@ -235,6 +235,7 @@ def lib() -> C.CDLL:
     L.ab_calibrate_channel.argtypes = [vp, pp, C.c_float, C.POINTER(ImageStatsC), pp, C.POINTER(ImageStatsC)]
     L.ab_create_master.argtypes = [vp, C.c_int32, pp, C.c_size_t, pp, pp, pp]
     L.ab_register_frames.argtypes = [vp, pp, pp, C.c_size_t, C.c_int, C.POINTER(AffineAlignResultC)]
+    L.ab_align_pairs_affine.argtypes = [vp, pp, pp, C.c_size_t, C.c_int, C.POINTER(AffineAlignResultC), pp]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift

@@ -428,6 +428,18 @@ class Context:
         return [AffineAlignResult(tuple(r.transform), int(r.matched_stars), int(r.inliers), r.residual_px, AFFINE_METHODS[r.method])
                 for r in res[:len(targets)]]
 
+    def align_pairs_affine(self, reference, targets, outs, num_threads: int = 8):
+        """align_pair(reference, t, AlignMethod::Affine) for every t (pair.rs:41-77): estimate + warp_image into outs[i];
+        device planes only.  -> [AffineAlignResult]"""
+        keep = []
+        pr = self._plane(reference, keep)
+        planes = (Plane * max(len(targets), 1))(*[self._plane(t, keep) for t in targets])
+        pouts = (Plane * max(len(targets), 1))(*[self._plane(o, keep) for o in outs])
+        res = (_lib.AffineAlignResultC * max(len(targets), 1))()
+        self._check(self._L.ab_align_pairs_affine(self._h, C.byref(pr), planes, len(targets), num_threads, res, pouts))
+        return [AffineAlignResult(tuple(r.transform), int(r.matched_stars), int(r.inliers), r.residual_px, AFFINE_METHODS[r.method])
+                for r in res[:len(targets)]]
+
     def affine_from_stars(self, ref_xy, tgt_xy, rows, cols, num_threads: int = 8):
         r = np.ascontiguousarray(np.asarray(ref_xy, np.float64).reshape(-1, 2))
         t = np.ascontiguousarray(np.asarray(tgt_xy, np.float64).reshape(-1, 2))

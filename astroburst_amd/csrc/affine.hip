@@ -633,7 +633,7 @@ static int register_one(ab_ctx *wc, const MatchWs &ref_ws, const std::vector<Pt>
 // ctx): one frame's host geometry overlaps the other frames' GPU passes.  Results do not depend on the worker
 // count (each out[i] equals a stand-alone align_channel_affine(reference, targets[i])).
 int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const *targets, size_t n, int64_t rows, int64_t cols, int num_threads,
-                              ab_affine_align_result *out) {
+                              ab_affine_align_result *out, float *const *aligned /* nullable: warp_image(target, transform) per target */) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     float *norm = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_NORM, (size_t)(rows * cols) * sizeof(float), (void **)&norm));
@@ -658,7 +658,10 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     }
     const size_t workers = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1));
     if (workers <= 1) {
-        for (size_t f = 0; f < n; ++f) AB_TRY(register_one(ctx, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]));
+        for (size_t f = 0; f < n; ++f) {
+            AB_TRY(register_one(ctx, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]));
+            if (aligned) AB_TRY(ab_warp_device(ctx, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]));  // pair.rs:59-61
+        }
         return AB_OK;
     }
     while (ctx->workers.size() < workers) {
@@ -679,12 +682,15 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
                 return;
             }
             for (size_t f = next.fetch_add(1); f < n; f = next.fetch_add(1)) {
-                const int rc = register_one(wc, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]);
+                int rc = register_one(wc, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]);
+                // the warp of this frame (f64 VALU) overlaps the other workers' latency-bound detection passes
+                if (rc == AB_OK && aligned) rc = ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]);
                 if (rc != AB_OK) {
                     rcs[t] = rc;
                     return;
                 }
             }
+            if (aligned && hipStreamSynchronize(wc->stream) != hipSuccess) rcs[t] = AB_ERR_HIP;  // planes complete on return
         });
     for (std::thread &th : pool) th.join();
     for (size_t t = 0; t < workers; ++t)
@@ -694,7 +700,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
 
 int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
                                    ab_affine_align_result *out) {
-    return ab_register_frames_device(ctx, ref, &tgt, 1, rows, cols, num_threads, out);
+    return ab_register_frames_device(ctx, ref, &tgt, 1, rows, cols, num_threads, out, nullptr);
 }
 
 extern "C" {
@@ -736,10 +742,29 @@ int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *t
         if (rc != AB_OK) break;
         ptrs[staged] = st[staged].dptr;
     }
-    if (rc == AB_OK) rc = ab_register_frames_device(ctx, r.dptr, ptrs.data(), n, r.rows, r.cols, num_threads, out);
+    if (rc == AB_OK) rc = ab_register_frames_device(ctx, r.dptr, ptrs.data(), n, r.rows, r.cols, num_threads, out, nullptr);
     for (size_t i = 0; i < staged && i < n; ++i) ab_stage_release(ctx, &st[i]);
     ab_stage_release(ctx, &r);
     return rc;
+}
+
+int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
+                          ab_affine_align_result *out, ab_plane_mut *aligned) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, reference && out && aligned && (targets || n == 0), "null argument");
+    AB_CHECK(ctx, reference->on_device, "align_pairs takes device-resident planes");
+    std::vector<const float *> ptrs(n);
+    std::vector<float *> outs(n);
+    for (size_t i = 0; i < n; ++i) {
+        AB_CHECK(ctx, targets[i].on_device && aligned[i].on_device, "align_pairs takes device-resident planes");
+        AB_CHECK(ctx, targets[i].rows == reference->rows && targets[i].cols == reference->cols && aligned[i].rows == reference->rows &&
+                          aligned[i].cols == reference->cols,
+                 "align_pairs: target %zu / its output differ from the reference's dims", i);
+        AB_CHECK(ctx, targets[i].data != aligned[i].data, "warp_image cannot run in place");
+        ptrs[i] = targets[i].data;
+        outs[i] = aligned[i].data;
+    }
+    return ab_register_frames_device(ctx, reference->data, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data());
 }
 
 // the host geometry alone, on given centroids (x, y pairs): returns AB_OK and *found = 0/1

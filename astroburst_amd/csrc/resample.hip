@@ -59,12 +59,40 @@ __device__ __forceinline__ float bicubic_taps(const float *__restrict__ src, int
     return (float)val;
 }
 
-__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int rows, int cols, int ld, double y, double x) {
+// the same sum when the whole 4 x 4 footprint is inside the image: no index clamps, one address per row
+__device__ __forceinline__ float bicubic_taps_interior(const float *__restrict__ src, int ld, int ix, int iy, double wx0, double wx1,
+                                                       double wx2, double wx3, double wy0, double wy1, double wy2, double wy3) {
+    const float *p = src + (iy - 1) * ld + (ix - 1);
+    const double wy[4] = {wy0, wy1, wy2, wy3};
+    double val = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float *row = p + j * ld;
+        double row_val = (double)row[0] * wx0;
+        row_val += (double)row[1] * wx1;
+        row_val += (double)row[2] * wx2;
+        row_val += (double)row[3] * wx3;
+        const double t = row_val * wy[j];
+        val = (j == 0) ? t : val + t;
+    }
+    return (float)val;
+}
+
+// `inside` (wave-uniform): every active lane's footprint [ix-1, ix+2] x [iy-1, iy+2] lies inside the image
+__device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, int rows, int cols, int ld, double y, double x,
+                                                bool sample = true) {
     const double xf = floor(x), yf = floor(y);
     double wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3;
     catmull_weights(x - xf, wx0, wx1, wx2, wx3);
     catmull_weights(y - yf, wy0, wy1, wy2, wy3);
-    return bicubic_taps(src, rows, cols, ld, (int)xf, (int)yf, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
+    const int ix = (int)xf, iy = (int)yf;
+    const bool interior = ix >= 1 && ix + 2 < cols && iy >= 1 && iy + 2 < rows;
+    if (__all(interior || !sample)) {  // the usual case away from the frame edges
+        if (!sample) return 0.0f;
+        return bicubic_taps_interior(src, ld, ix, iy, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
+    }
+    if (!sample) return 0.0f;
+    return bicubic_taps(src, rows, cols, ld, ix, iy, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
 }
 
 // align.rs:46-55
@@ -91,9 +119,8 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
     const double xf = (double)x, yf = (double)y;
     const double sx = a * xf + b * yf + tx;
     const double sy = c * xf + d * yf + ty;
-    float r = 0.0f;
-    if (sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1))
-        r = bicubic_sample(src, src_rows, src_cols, src_cols, sy, sx);
+    const bool in = sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1);
+    const float r = bicubic_sample(src, src_rows, src_cols, src_cols, in ? sy : 0.0, in ? sx : 0.0, in);
     out[(size_t)y * out_cols + x] = r;
 }
 

@@ -177,6 +177,11 @@ AB_API int ab_align_channel_affine(ab_ctx *ctx, const ab_plane *reference, const
  * table are computed once; each out[i] equals what ab_align_channel_affine(reference, targets[i]) returns. */
 AB_API int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
                               ab_affine_align_result *out);
+/* align_pair(reference, targets[i], AlignMethod::Affine) for i < n (core/alignment/pair.rs:41-77): the estimate above
+ * followed by warp_image(target, transform) into aligned[i].  Device-resident planes only; each worker warps its
+ * frame right after estimating it, so the warps overlap the other frames' detection. */
+AB_API int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
+                                 ab_affine_align_result *out, ab_plane_mut *aligned);
 /* the star-list half (triangles -> votes -> RANSAC -> sanity) on given centroids; host only */
 AB_API int ab_affine_from_stars(const double *ref_xy, size_t n_ref, const double *tgt_xy, size_t n_tgt, int64_t rows,
                                 int64_t cols, int num_threads, ab_affine_align_result *out, int *found);

@@ -149,3 +149,23 @@ def test_register_frames_equals_pairwise_calls(ctx, oracle):
             assert b.method in ("affine", "rigid")
             assert abs(b.transform[2] - s[1]) < 0.3 and abs(b.transform[5] - s[0]) < 0.3   # output -> source mapping
     assert ctx.register_frames(ref.cuda(), []) == []
+
+
+def test_align_pairs_affine_equals_estimate_then_warp(ctx, oracle):
+    """ab_align_pairs_affine = align_pair(.., Affine) per target (pair.rs:41-77): the transforms of register_frames and
+    warp_image(target, transform) planes, bit for bit."""
+    import torch
+    from astroburst_amd import synth
+    rows, cols = 512, 640
+    y, x, flux = synth.star_catalog(rows, cols, 400, seed=13)
+    cat = (y, x, flux * 30.0)
+    ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=0.0).cuda()
+    tgts = [synth.make_frame(rows, cols, k + 1, cat=cat, shift=s, bad_patch_rate=0.0, cosmic_rate=0.0).cuda()
+            for k, s in enumerate([(2.5, -1.0), (-3.0, 4.0), (0.5, 0.25)])]
+    outs = [torch.empty_like(t) for t in tgts]
+    res = ctx.align_pairs_affine(ref, tgts, outs, num_threads=8)
+    again = ctx.register_frames(ref, tgts, num_threads=8)
+    for r, a, t, o in zip(res, again, tgts, outs):
+        assert (r.method, r.transform, r.inliers) == (a.method, a.transform, a.inliers)
+        want = oracle.warp_image(t.cpu().numpy(), r.transform, rows, cols)
+        assert np.array_equal(o.cpu().numpy(), want)
