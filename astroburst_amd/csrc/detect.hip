@@ -444,16 +444,20 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, roots, dstat, ncomp,
                        bg_median, drec);
     AB_HIP(ctx, hipGetLastError());
-    std::vector<CompRec> recs(ncomp);
-    AB_HIP(ctx, hipMemcpyAsync(recs.data(), drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
+    void *pin = nullptr;  // pinned staging: a pageable destination costs an extra bounce inside the runtime
+    AB_TRY(ab_pinned(ctx, (size_t)ncomp * sizeof(CompRec), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const CompRec *recs_begin = (const CompRec *)pin, *recs_end = recs_begin + ncomp;
 
     trace.mark("moments+D2H");
     if (trace.on) fprintf(stderr, " (%u components)", ncomp);
     // ---- host: finish the stars in discovery order (ascending first interior pixel = BFS seed order) ----
     std::vector<const CompRec *> order;
-    for (const CompRec &c : recs)
+    for (const CompRec *pc = recs_begin; pc != recs_end; ++pc) {
+        const CompRec &c = *pc;
         if (c.first_interior != 0x7fffffff && c.npix >= 3 && c.npix <= 5000 && c.sum_flux > 0.0) order.push_back(&c);
+    }
     std::sort(order.begin(), order.end(), [](const CompRec *a, const CompRec *b) { return a->first_interior < b->first_interior; });
 
     std::vector<ab_detected_star> found;
@@ -534,9 +538,11 @@ int ab_normalize_for_detection_device(ab_ctx *ctx, const float *img, int64_t len
     AB_TRY(ab_scratch(ctx, (size_t)ns * sizeof(float), &d));
     hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, len, step, (float *)d, ns);
     AB_HIP(ctx, hipGetLastError());
-    std::vector<float> s(ns);
-    AB_HIP(ctx, hipMemcpyAsync(s.data(), d, (size_t)ns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, (size_t)ns * sizeof(float), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, d, (size_t)ns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<float> s((const float *)pin, (const float *)pin + ns);
     s.erase(std::remove_if(s.begin(), s.end(), [](float v) { return !std::isfinite(v); }), s.end());
     auto clone = [&]() -> int {
         if (out != img) AB_HIP(ctx, hipMemcpyAsync(out, img, (size_t)len * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
