@@ -25,6 +25,20 @@ enum {
     AB_WS_SLOTS
 };
 
+// normalize_for_detection (affine.rs:24-53) as a per-pixel transform applied on load: consumers of a normalised frame
+// (tile statistics, threshold, moments) read the raw plane and evaluate clamp((v - lo) * inv, 0, 1) themselves, so
+// the normalised copy is never written (-128 MB of traffic and one kernel per frame).  on = 0: identity.
+struct ab_pixel_xf {
+    double lo = 0.0, inv = 1.0;
+    int on = 0;
+};
+__device__ __forceinline__ float ab_px(const ab_pixel_xf &x, float v) {
+    if (!x.on) return v;
+    double t = ((double)v - x.lo) * x.inv;
+    t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);  // f64::clamp: NaN stays NaN
+    return (float)t;
+}
+
 struct ab_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -119,7 +133,10 @@ int ab_plane_median_f32(ab_ctx *ctx, const ab_plane_sel &s, float *out, uint64_t
 int ab_stats_device(ab_ctx *ctx, const float *data, int64_t n, int use_known, double known_min, double known_max,
                     ab_image_stats *out);
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
-                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out);
+                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out,
+                           ab_pixel_xf xf = ab_pixel_xf());
+// the percentile normalisation's parameters (xf->on = 0 where the reference returns image.clone())
+int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf);
 
 int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, int64_t ref_cols, int64_t ref_ld, const float *tgt,
                               int64_t tgt_rows, int64_t tgt_cols, int64_t tgt_ld, double *dx, double *dy, double *confidence);

@@ -25,9 +25,6 @@
 #include <cmath>
 #include <thread>
 
-int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
-                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out);
-int ab_normalize_for_detection_device(ab_ctx *ctx, const float *img, int64_t len, float *out, int *cloned);
 int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, int64_t ref_cols, int64_t ref_ld, const float *tgt,
                               int64_t tgt_rows, int64_t tgt_cols, int64_t tgt_ld, double *dx, double *dy, double *confidence);
 
@@ -575,12 +572,12 @@ int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std:
 }
 
 // normalize_for_detection + detect_stars(3.5 sigma) + top_n_stars of one frame (:134-160)
-int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, float *norm, std::vector<Pt> *out) {
+int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::vector<Pt> *out) {
     std::vector<ab_detected_star> stars;
     double m, s;
-    int cloned = 0;
-    AB_TRY(ab_normalize_for_detection_device(ctx, img, rows * cols, norm, &cloned));
-    AB_TRY(ab_detect_stars_device(ctx, norm, rows, cols, cols, kDetectionSigma, &stars, &m, &s));
+    ab_pixel_xf xf;  // the normalised frame is never materialised: detection applies the transform on load
+    AB_TRY(ab_normalize_params_device(ctx, img, rows * cols, &xf));
+    AB_TRY(ab_detect_stars_device(ctx, img, rows, cols, cols, kDetectionSigma, &stars, &m, &s, xf));
     out->clear();
     for (const auto &st : stars) {
         if (out->size() >= kMaxStars) break;  // top_n_stars (:272-277): detections are already sorted by flux
@@ -594,13 +591,11 @@ int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, float
 // one target against the prepared reference (stars rs, triangle table in ref_ws); all device work on wc's stream
 static int register_one(ab_ctx *wc, const MatchWs &ref_ws, const std::vector<Pt> &rs, bool ref_ok, const float *ref, const float *tgt,
                         int64_t rows, int64_t cols, int num_threads, ab_affine_align_result *out) {
-    float *norm = nullptr;
-    AB_TRY(ab_workspace(wc, AB_WS_NORM, (size_t)(rows * cols) * sizeof(float), (void **)&norm));
     MatchWs w;
     AB_TRY(match_ws(wc, &w));
     std::vector<Pt> ts;
     bool found = false;
-    AB_TRY(frame_stars(wc, tgt, rows, cols, norm, &ts));
+    AB_TRY(frame_stars(wc, tgt, rows, cols, &ts));
     if (ref_ok && ts.size() >= kMinMatchesRigid) {
         AB_TRY(gpu_build_triangles(wc, w, ts, 1));
         MatchWs mixed = w;  // tgt table, partials and votes of this worker; ref table of the caller
@@ -635,12 +630,10 @@ static int register_one(ab_ctx *wc, const MatchWs &ref_ws, const std::vector<Pt>
 int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const *targets, size_t n, int64_t rows, int64_t cols, int num_threads,
                               ab_affine_align_result *out, float *const *aligned /* nullable: warp_image(target, transform) per target */) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
-    float *norm = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_NORM, (size_t)(rows * cols) * sizeof(float), (void **)&norm));
     MatchWs w;
     AB_TRY(match_ws(ctx, &w));
     std::vector<Pt> rs;
-    AB_TRY(frame_stars(ctx, ref, rows, cols, norm, &rs));
+    AB_TRY(frame_stars(ctx, ref, rows, cols, &rs));
     const bool ref_ok = rs.size() >= kMinMatchesRigid;
     if (ref_ok) {
         // reference table: built on the GPU, ordered by (ratio_mid bucket, ratio_long) once on the host

@@ -22,6 +22,8 @@
 
 #include <cstdint>
 
+#include "ab_common.hpp"
+
 namespace absel {
 
 constexpr int kBlock = 1024;
@@ -32,6 +34,7 @@ struct Window {
     int y0, y1, x0, x1;
     float min_valid;  // pixel is a candidate iff finite and > min_valid
     float lo, hi;     // and lo <= v <= hi (cumulative `retain` bounds; +-inf when unused)
+    ab_pixel_xf xf;   // optional normalisation applied to every pixel as it is loaded
 };
 
 struct Keying {  // mode 0: key = bits(v); 1: bits((f32)|(f64)v - center64|); 2: bits(|v - center32|)
@@ -76,7 +79,7 @@ struct StreamSource {
                 for (int u = 0; u < U; ++u) {
                     const int r = rb + 4 * u;
                     v[u] = __builtin_nanf("");
-                    if (col_ok && r < w.y1) v[u] = w.img[(int64_t)r * w.ld + c];
+                    if (col_ok && r < w.y1) v[u] = ab_px(w.xf, w.img[(int64_t)r * w.ld + c]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) f(v[u]);
@@ -102,14 +105,14 @@ struct TileSource {
         for (int k = 0; k < NL; ++k) {
             const int r = w.y0 + ty + 4 * k;
             float v = __builtin_nanf("");
-            if (col_ok && r < w.y1) v = w.img[(int64_t)r * w.ld + c];
+            if (col_ok && r < w.y1) v = ab_px(w.xf, w.img[(int64_t)r * w.ld + c]);
             lds[k * kBlock + threadIdx.x] = v;
         }
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
             const int r = w.y0 + ty + 4 * (NL + k);
             float v = __builtin_nanf("");
-            if (col_ok && r < w.y1) v = w.img[(int64_t)r * w.ld + c];
+            if (col_ok && r < w.y1) v = ab_px(w.xf, w.img[(int64_t)r * w.ld + c]);
             regs[k] = v;
         }
     }
@@ -180,94 +183,80 @@ __device__ inline void window_hist(const S &src, const Window &w, const Keying &
     __syncthreads();
 }
 
-// bin holding 0-based `rank`, the count before it, the bin's own count and the histogram total
-// (broadcast to all threads)
-__device__ inline void find_bin(const unsigned int *hist, int nb, unsigned int rank, unsigned int *bin_out, unsigned int *before_out,
-                                unsigned int *total_out) {
-    __shared__ unsigned int s_bin, s_before, s_total;
-    __syncthreads();
-    if (threadIdx.x < 64) {  // wave 0: 64 partial sums -> lane scan -> the owning lane walks its bins
-        const int lane = threadIdx.x, per = nb / 64;
-        unsigned int s = 0;
-        for (int j = 0; j < per; ++j) s += hist[lane * per + j];
-        unsigned int inc = s;
+// Block-wide exclusive scan of the histogram (every thread owns nb / kBlock consecutive bins: wave scan by
+// shuffles, 16 wave totals through LDS) and location of up to two ranks in it.  Results are broadcast.
+// For a rank >= total the answer is (nb - 1, 0), as a linear scan that never fires would give.
+struct BinHit {
+    unsigned int bin, before;
+};
+template <int NRANKS>
+__device__ inline void locate(const unsigned int *hist, int nb, const unsigned int (&ranks)[NRANKS], BinHit (&hits)[NRANKS],
+                              unsigned int *total_out) {
+    __shared__ unsigned int wave_tot[kBlock / 64], s_bin[2], s_before[2], s_total;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = nb / kBlock;  // 2 (2048 bins) or 1 (1024 bins)
+    __syncthreads();              // histogram complete; previous results consumed
+    const unsigned int h0 = hist[t * per], h1 = per == 2 ? hist[t * per + 1] : 0u;
+    const unsigned int s = h0 + h1;
+    unsigned int inc = s;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
-        }
-        const unsigned int exc = inc - s;
-        const unsigned int total = __shfl(inc, 63, 64);
-        if (lane == 0) {
-            s_total = total;
-            if (rank >= total) {  // not present: same answer as a linear scan that never fires
-                s_bin = nb - 1;
-                s_before = 0;
-            }
-        }
-        if (rank >= exc && rank < inc) {
-            unsigned int cum = exc;
-            for (int j = 0; j < per; ++j) {
-                const unsigned int h = hist[lane * per + j];
-                if (cum + h > rank) {
-                    s_bin = lane * per + j;
-                    s_before = cum;
-                    break;
-                }
-                cum += h;
-            }
-        }
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int u = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += u;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    if (t < NRANKS) {
+        s_bin[t] = (unsigned int)nb - 1u;
+        s_before[t] = 0u;
     }
     __syncthreads();
-    *bin_out = s_bin;
-    *before_out = s_before;
+    unsigned int base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; ++i) {
+        const unsigned int w = wave_tot[i];
+        base += i < wv ? w : 0u;
+        total += w;
+    }
+    const unsigned int exc = base + inc - s;
+#pragma unroll
+    for (int q = 0; q < NRANKS; ++q) {
+        const unsigned int rank = ranks[q];
+        if (rank >= exc && rank < exc + s) {  // exactly one thread (s > 0) owns the rank
+            const bool first = rank < exc + h0;
+            s_bin[q] = (unsigned int)(t * per) + (first ? 0u : 1u);
+            s_before[q] = first ? exc : exc + h0;
+        }
+    }
+    if (t == 0) s_total = total;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NRANKS; ++q) {
+        hits[q].bin = s_bin[q];
+        hits[q].before = s_before[q];
+    }
     *total_out = s_total;
 }
 
-// find_bin for two ranks (rank_lo <= rank_hi) off one prefix scan
+__device__ inline void find_bin(const unsigned int *hist, int nb, unsigned int rank, unsigned int *bin_out, unsigned int *before_out,
+                                unsigned int *total_out) {
+    const unsigned int ranks[1] = {rank};
+    BinHit hits[1];
+    locate<1>(hist, nb, ranks, hits, total_out);
+    *bin_out = hits[0].bin;
+    *before_out = hits[0].before;
+}
+
+// find_bin for two ranks (rank_lo <= rank_hi) off one scan
 __device__ inline void find_bin2(const unsigned int *hist, int nb, unsigned int rank_lo, unsigned int rank_hi, unsigned int *bin_lo,
                                  unsigned int *before_lo, unsigned int *bin_hi, unsigned int *before_hi) {
-    __shared__ unsigned int s_bin[2], s_before[2];
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x, per = nb / 64;
-        unsigned int s = 0;
-        for (int j = 0; j < per; ++j) s += hist[lane * per + j];
-        unsigned int inc = s;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int t = __shfl_up(inc, off, 64);
-            if (lane >= off) inc += t;
-        }
-        const unsigned int exc = inc - s;
-        const unsigned int total = __shfl(inc, 63, 64);
-        const unsigned int ranks[2] = {rank_lo, rank_hi};
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const unsigned int rank = ranks[q];
-            if (lane == 0 && rank >= total) {
-                s_bin[q] = nb - 1;
-                s_before[q] = 0;
-            }
-            if (rank >= exc && rank < inc) {
-                unsigned int cum = exc;
-                for (int j = 0; j < per; ++j) {
-                    const unsigned int h = hist[lane * per + j];
-                    if (cum + h > rank) {
-                        s_bin[q] = lane * per + j;
-                        s_before[q] = cum;
-                        break;
-                    }
-                    cum += h;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    *bin_lo = s_bin[0];
-    *before_lo = s_before[0];
-    *bin_hi = s_bin[1];
-    *before_hi = s_before[1];
+    const unsigned int ranks[2] = {rank_lo, rank_hi};
+    BinHit hits[2];
+    unsigned int total;
+    locate<2>(hist, nb, ranks, hits, &total);
+    *bin_lo = hits[0].bin;
+    *before_lo = hits[0].before;
+    *bin_hi = hits[1].bin;
+    *before_hi = hits[1].before;
 }
 
 // top-level (bits 31..21) histogram of the window's keys into hist0; returns the candidate count

@@ -100,7 +100,7 @@ __device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, un
 }
 
 __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const float *__restrict__ img, int rows, int cols,
-                                                                        int64_t ld, int step, int ntx,
+                                                                        int64_t ld, int step, int ntx, const ab_pixel_xf xf,
                                                                         TileOut *__restrict__ out) {
     __shared__ unsigned int hist0[2048], hist[2048];
     __shared__ float cache[35 * absel::kBlock];  // 140 KiB of the CU's 160 KiB
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
     t.min_valid = 1e-7f;  // star_detection.rs:56
     t.lo = -__builtin_inff();
     t.hi = __builtin_inff();
+    t.xf = xf;
     absel::TileSource<35, 29> src;  // the whole tile on chip: one read of the frame per estimate_background
     src.lds = cache;
     src.load(t);
@@ -132,8 +133,8 @@ __device__ __forceinline__ bool above(float v, double threshold) { return __buil
 // (a per-wave atomic on a single counter serialises at ~12 ns each: 0.4 ms per frame).
 constexpr int kInitSpan = 8192;  // pixels per block
 __global__ __launch_bounds__(256) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
-                                                         double threshold, int *__restrict__ parent, int *__restrict__ plist,
-                                                         unsigned int *nlab) {
+                                                         double threshold, const ab_pixel_xf xf, int *__restrict__ parent,
+                                                         int *__restrict__ plist, unsigned int *nlab) {
     __shared__ int found[kInitSpan];
     __shared__ unsigned int nfound, base;
     if (threadIdx.x == 0) nfound = 0;
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void label_init_kernel(const float *__restrict
         const int i = start + off;
         if (i < P) {
             const int r = i / cols, c = i - r * cols;
-            const bool is = above(img[r * ld + c], threshold);
+            const bool is = above(ab_px(xf, img[r * ld + c]), threshold);
             parent[i] = is ? i : -1;
             if (is) found[atomicAdd(&nfound, 1u)] = i;
         }
@@ -277,7 +278,7 @@ __device__ __forceinline__ double wave_max(double x) {
 // (the reference accumulates in BFS order: the two agree to ~1e-15 relative).
 __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
-                                                           double bg_median, CompRec *__restrict__ rec) {
+                                                           double bg_median, const ab_pixel_xf xf, CompRec *__restrict__ rec) {
     const unsigned int comp = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (comp >= ncomp) return;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
             for (int cb = s.x0; cb <= s.x1; cb += 64) {
                 const int c = cb + lane;
                 if (c <= s.x1 && parent[r * cols + c] == root) {
-                    const double v = fmax((double)img[r * ld + c] - bg_median, 0.0);
+                    const double v = fmax((double)ab_px(xf, img[r * ld + c]) - bg_median, 0.0);
                     f += v;
                     sx += (double)c * v;
                     sy += (double)r * v;
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
                 for (int cb = s.x0; cb <= s.x1; cb += 64) {
                     const int c = cb + lane;
                     if (c <= s.x1 && parent[r * cols + c] == root) {
-                        const double v = fmax((double)img[r * ld + c] - bg_median, 0.0);
+                        const double v = fmax((double)ab_px(xf, img[r * ld + c]) - bg_median, 0.0);
                         const double dx = (double)c - cx, dy = (double)r - cy;
                         r2 += (dx * dx + dy * dy) * v;
                         xx += dx * dx * v;
@@ -361,7 +362,7 @@ int f64_cmp(double a, double b) {  // math/median.rs:15-25
 
 // estimate_background (star_detection.rs:32-84) on a device plane
 int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, int64_t tile_size,
-                                  double *out_median, double *out_sigma) {
+                                  double *out_median, double *out_sigma, ab_pixel_xf xf = ab_pixel_xf()) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     const int step = (int)std::max<int64_t>(tile_size, 16);
     AB_CHECK(ctx, step <= 256, "background tiles larger than 256 px are not supported (tile_size %lld)", (long long)tile_size);
@@ -370,7 +371,7 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
     void *d = nullptr;
     AB_TRY(ab_scratch(ctx, (size_t)ntiles * sizeof(TileOut), &d));
     hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(absel::kBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
-                       ntx, (TileOut *)d);
+                       ntx, xf, (TileOut *)d);
     AB_HIP(ctx, hipGetLastError());
     std::vector<TileOut> h(ntiles);
     AB_HIP(ctx, hipMemcpyAsync(h.data(), d, (size_t)ntiles * sizeof(TileOut), hipMemcpyDeviceToHost, ctx->stream));
@@ -396,7 +397,7 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
 
 // detect_stars (star_detection.rs:86-258) on a device plane; stars sorted by flux, deduplicated
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
-                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out) {
+                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out, ab_pixel_xf xf) {
     stars->clear();
     *bg_median_out = 0.0;
     *bg_sigma_out = 1.0;
@@ -407,7 +408,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     const int64_t m = std::min(rows, cols);
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // :100
     double bg_median, bg_sigma;
-    AB_TRY(ab_estimate_background_device(ctx, img, rows, cols, ld, tile_size, &bg_median, &bg_sigma));
+    AB_TRY(ab_estimate_background_device(ctx, img, rows, cols, ld, tile_size, &bg_median, &bg_sigma, xf));
     trace.mark("background");
     *bg_median_out = bg_median;
     *bg_sigma_out = bg_sigma;
@@ -425,7 +426,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     const int gl = (ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;  // list kernels: grid-stride over *nlab entries
     AB_HIP(ctx, hipMemsetAsync(nroots, 0, 2 * sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(label_init_kernel, dim3((unsigned)((P + kInitSpan - 1) / kInitSpan)), dim3(256), 0, ctx->stream, img, (int)rows,
-                       (int)cols, ld, threshold, parent, plist, nlab);
+                       (int)cols, ld, threshold, xf, parent, plist, nlab);
     hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, plist, nlab);
     hipLaunchKernelGGL(roots_kernel, dim3(gl), dim3(256), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
     AB_HIP(ctx, hipGetLastError());
@@ -442,7 +443,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     hipLaunchKernelGGL(comp_init_kernel, dim3((ncomp + 255) / 256), dim3(256), 0, ctx->stream, dstat, ncomp);
     hipLaunchKernelGGL(comp_stats_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, cid, dstat, plist, nlab);
     hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, roots, dstat, ncomp,
-                       bg_median, drec);
+                       bg_median, xf, drec);
     AB_HIP(ctx, hipGetLastError());
     void *pin = nullptr;  // pinned staging: a pageable destination costs an extra bounce inside the runtime
     AB_TRY(ab_pinned(ctx, (size_t)ncomp * sizeof(CompRec), &pin));
@@ -526,11 +527,11 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     return AB_OK;
 }
 
-// normalize_for_detection (affine.rs:24-53) into a contiguous device buffer; *cloned = 1 when the
-// reference returns image.clone() (too few samples / flat range): out then equals the input
-int ab_normalize_for_detection_device(ab_ctx *ctx, const float *img, int64_t len, float *out, int *cloned) {
+// normalize_for_detection's parameters (affine.rs:24-47): the 1st and 99.9th percentile of an every-step subsample.
+// xf->on = 0 when the reference returns image.clone() (too few finite samples / flat range).
+int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
-    *cloned = 1;
+    *xf = ab_pixel_xf();
     if (len == 0) return AB_OK;
     const int64_t step = std::max<int64_t>(len / 100000, 1);
     const int64_t ns = (len + step - 1) / step;
@@ -544,21 +545,33 @@ int ab_normalize_for_detection_device(ab_ctx *ctx, const float *img, int64_t len
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<float> s((const float *)pin, (const float *)pin + ns);
     s.erase(std::remove_if(s.begin(), s.end(), [](float v) { return !std::isfinite(v); }), s.end());
-    auto clone = [&]() -> int {
-        if (out != img) AB_HIP(ctx, hipMemcpyAsync(out, img, (size_t)len * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-        return AB_OK;
-    };
-    if (s.size() < 100) return clone();
+    if (s.size() < 100) return AB_OK;
     // the reference sorts the subsample (:37-40); only two order statistics of it are read
     const size_t k_lo = s.size() / 100, k_hi = s.size() * 999 / 1000;
     std::nth_element(s.begin(), s.begin() + k_hi, s.end());
     std::nth_element(s.begin(), s.begin() + k_lo, s.begin() + k_hi);
     const double lo = (double)s[k_lo], hi = (double)s[k_hi];
     const double range = hi - lo;
-    if (range < 1e-15) return clone();
-    *cloned = 0;
+    if (range < 1e-15) return AB_OK;
+    xf->lo = lo;
+    xf->inv = 1.0 / range;
+    xf->on = 1;
+    return AB_OK;
+}
+
+// normalize_for_detection (affine.rs:24-53) into a contiguous device buffer; *cloned = 1 when the
+// reference returns image.clone() (too few samples / flat range): out then equals the input
+int ab_normalize_for_detection_device(ab_ctx *ctx, const float *img, int64_t len, float *out, int *cloned) {
+    ab_pixel_xf xf;
+    AB_TRY(ab_normalize_params_device(ctx, img, len, &xf));
+    *cloned = xf.on ? 0 : 1;
+    if (len == 0) return AB_OK;
+    if (!xf.on) {
+        if (out != img) AB_HIP(ctx, hipMemcpyAsync(out, img, (size_t)len * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return AB_OK;
+    }
     const int g = (int)std::min<int64_t>((len + 255) / 256, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8);
-    hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(256), 0, ctx->stream, img, len, lo, 1.0 / range, out);
+    hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(256), 0, ctx->stream, img, len, xf.lo, xf.inv, out);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
