@@ -167,6 +167,10 @@ class Context:
         """Launch on torch's current stream so torch.cuda.Event timing brackets our kernels."""
         self._check(self._L.ab_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def use_own_stream(self):
+        """Back to the context's private stream (inputs produced by torch must then be synchronised by the caller)."""
+        self._check(self._L.ab_ctx_reset_stream(self._h))
+
     def synchronize(self):
         self._check(self._L.ab_ctx_synchronize(self._h))
 
