@@ -20,7 +20,6 @@ enum {
     AB_WS_DETECT_ROOTS,       // int[P/4 + 1] component roots + counters
     AB_WS_DETECT_COMPS,       // per-component statistics / moment records
     AB_WS_DETECT_LIST,        // int[P] indices of the above-threshold pixels
-    AB_WS_NORM,               // float[P] normalised copy for star detection
     AB_WS_REGISTER,           // triangle tables / votes of the star matcher
     AB_WS_SLOTS
 };

@@ -6,10 +6,11 @@
 // (:400-517), fit_affine / solve_3x3_ls / solve_3x3 (:519-595), fit_rigid (:597-642),
 // compute_residual (:644-656).
 //
-// Split: the per-pixel work (percentile normalisation, tile background, threshold, labelling:
-// csrc/detect.hip; phase-correlation fallback: csrc/phase_corr.hip) runs on the GPU; what is left
-// is scalar f64 geometry over <= 120 stars (<= 34 220 triangles per image, 2000 RANSAC draws),
-// which the reference also runs as plain CPU code and which stays on the host here.
+// Split: the per-pixel work (percentile normalisation, tile background, threshold, labelling, moments:
+// csrc/detect.hip; phase-correlation fallback: csrc/phase_corr.hip) and the triangle table + vote matrix
+// (<= 34 220 triangles per image, up to 1.2e9 pair tests) run on the GPU; RANSAC (2000 draws over <= 60
+// matches) and the final fits are scalar f64 geometry that stays on the host.  ab_register_frames /
+// ab_align_pairs_affine spread the targets of one reference over host worker threads, one HIP stream each.
 //
 // Two places where the reference's answer is not a function of its inputs are pinned:
 //   * vote pairs are iterated out of a std::HashMap and stable-sorted by votes only (:351-360):
@@ -598,7 +599,7 @@ static int register_one(ab_ctx *wc, const MatchWs &ref_ws, const std::vector<Pt>
     AB_TRY(frame_stars(wc, tgt, rows, cols, &ts));
     if (ref_ok && ts.size() >= kMinMatchesRigid) {
         AB_TRY(gpu_build_triangles(wc, w, ts, 1));
-        MatchWs mixed = w;  // tgt table, partials and votes of this worker; ref table of the caller
+        MatchWs mixed = w;  // tgt table and votes of this worker; ref table of the caller
         mixed.ref_sorted = ref_ws.ref_sorted;
         std::vector<uint32_t> votes;
         AB_TRY(gpu_votes(wc, mixed, ref_ws.counts, &votes));

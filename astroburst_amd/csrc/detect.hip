@@ -5,20 +5,24 @@
 // core/analysis/confidence.rs:3-8, and core/alignment/affine.rs:24-53 (normalize_for_detection).
 //
 // Mapping (integer / index work, HBM- and latency-bound; no GEMM shapes):
-//   * tile background: one 1024-thread workgroup per tile (<= 256 x 256 px).  The reference's
-//     median / MAD selects become 11/11/10-bit radix selects over the tile's valid pixels, whose
-//     f32 bit patterns are monotone (valid means > 1e-7); histograms live in LDS, the tile itself is
-//     re-read from L2.  Even-count medians average the two middle order statistics exactly as
-//     exact_median_mut / median_f32_mut do, so tile medians and sigmas are bit-identical.
-//   * labelling: the reference's sequential raster scan + 8-connected BFS is replaced by a
-//     lock-free union-find over the above-threshold pixels (4 forward neighbours per pixel,
-//     atomicMin hooking, then path flattening).  The root of a component is its minimum raster
-//     index, which makes the label canonical; a component is reported only if it owns an
-//     INTERIOR pixel, because the reference seeds from 1..rows-1 x 1..cols-1 only.
-//   * the above-threshold pixels (a fraction of a percent of the frame) are compacted to
-//     (index, root, value) triples; the per-component moments are f64 sums over at most 5000 pixels
-//     each and are finished on the host in raster order (the reference sums in BFS order: the two
-//     agree to ~1e-15 relative; counts, npix and the component set are exact).
+//   * tile background: one 1024-thread workgroup per tile (<= 256 x 256 px), loaded once and kept on chip
+//     (LDS + registers).  The reference's median / MAD selects become 11/11/10-bit radix selects over the
+//     tile's valid pixels, whose f32 bit patterns are monotone (valid means > 1e-7).  Even-count medians
+//     average the two middle order statistics exactly as exact_median_mut / median_f32_mut do, so tile
+//     medians and sigmas are bit-identical (block_select.hpp has the cost model).
+//   * labelling: the reference's sequential raster scan + 8-connected BFS is replaced by a lock-free
+//     union-find over the above-threshold pixels (4 forward neighbours per pixel, atomicMin hooking, then
+//     path flattening).  The root of a component is its minimum raster index, which makes the label
+//     canonical; a component is reported only if it owns an INTERIOR pixel, because the reference seeds
+//     from 1..rows-1 x 1..cols-1 only.  Only the thresholding pass touches every pixel: it appends the
+//     labelled ones (a fraction of a percent of the frame) to a list that the later kernels iterate.
+//   * per-component size / bounding box / first interior pixel are integer atomics (order-independent);
+//     the flux-weighted moments are f64 sums over at most 5000 pixels, taken by one wave per component
+//     over its bounding box with a fixed-shape lane reduction (reproducible; the reference sums in BFS
+//     order: the two agree to ~1e-15 relative; counts, npix and the component set are exact).  The host
+//     finishes O(#components) work: discovery order, star parameters, flux sort, 3 px dedup.
+//   * a percentile normalisation (affine.rs:24-53) can ride along: consumers apply it per pixel on load
+//     (ab_px), so the registration path never materialises the normalised frame.
 #include "ab_common.hpp"
 #include "block_select.hpp"
 
@@ -26,7 +30,6 @@
 #include <cfloat>
 #include <cmath>
 #include <chrono>
-#include <unordered_map>
 
 namespace {
 
