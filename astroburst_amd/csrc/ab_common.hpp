@@ -21,6 +21,7 @@ enum {
     AB_WS_DETECT_COMPS,       // per-component statistics / moment records
     AB_WS_DETECT_LIST,        // int[P] indices of the above-threshold pixels
     AB_WS_REGISTER,           // triangle tables / votes of the star matcher
+    AB_WS_STACK_DEFER,        // per-slot pixel lists of the stacking kernel's two-pass mode
     AB_WS_SLOTS
 };
 

@@ -43,6 +43,8 @@ namespace {
 
 constexpr int kMaxFrames = 64;
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
+constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
+enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
 
 struct StackArgs {
@@ -57,6 +59,10 @@ struct StackArgs {
     double *out_sum;                 // partial mode
     uint32_t *out_cnt;               // partial mode
     unsigned long long *rejected;    // device counter
+    // two-pass mode (see stack_sigma_clip_kernel): per-slot lists of the pixels the fast pass hands to the general pass
+    int *defer_list;                 // kDeferSlots x defer_cap pixel indices
+    unsigned int *defer_count;       // kDeferSlots counters
+    unsigned int defer_cap;
 };
 
 // Compiler fences (no instructions).  launder() makes the sample vector look rewritten so LLVM
@@ -138,6 +144,7 @@ struct ClipResult {
     double sum;    // f64 sum of the survivors   (partial mode)
     int len;       // number of survivors        (partial mode)
     uint32_t rej;  // rejected samples of this pixel
+    bool defer = false;  // fast pass only: this pixel needs the general pass
 };
 
 // ---- clipping engine A: "exact" -- every iteration re-sums the survivors directly --------------
@@ -255,10 +262,13 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 }
 
 // One clipping pass over the two ends.  UPDATE: also fold the shaved samples into s_rem/q_rem.
-template <int NP, bool UPDATE>
+// DEFER (fast pass): look at the outermost chunk of each end only; a lane that would have to walk further is flagged
+// for the general pass instead of making its whole wave walk with it.
+template <int NP, bool UPDATE, bool DEFER = false>
 __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, int b, float center, float lo, float hi,
-                                          double c0d, float c0, int &cl_out, int &ch_out, double &e_rem, double &q_rem) {
-    constexpr int CH = NP >= 4 ? 4 : NP;
+                                          double c0d, float c0, int &cl_out, int &ch_out, double &e_rem, double &q_rem,
+                                          bool *defer = nullptr) {
+    constexpr int CH = NP >= 4 ? 4 : NP;  // DEFER: the only chunk looked at (8 was tried: +0.13 ms, the walk is per-element bound)
     int cl = 0, ch = 0;
     bool found_lo = false, found_hi = false;
 #pragma unroll
@@ -282,6 +292,10 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
             }
         }
         const bool more = go && !found_lo && (CH * c + CH - 1 < b);
+        if constexpr (DEFER) {
+            *defer = *defer || more;
+            break;
+        }
         if (!__any(more)) break;
     }
 #pragma unroll
@@ -305,15 +319,20 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
             }
         }
         const bool more = go && !found_hi && (NP - 1 - (CH * c + CH - 1) > a);
+        if constexpr (DEFER) {
+            *defer = *defer || more;
+            break;
+        }
         if (!__any(more)) break;
     }
     cl_out = cl;
     ch_out = ch;
 }
 
-template <int NP, int STAGE = 99>
+template <int NP, int STAGE = 99, bool DEFER = false>
 __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med, float mad, float sigma_low,
                                                 float sigma_high, uint32_t max_iter) {
+    bool defer = false;
     float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
     float center = med;
     int a = 0, b = n - 1, len = n;
@@ -330,7 +349,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         if (go) last_center = center;
         const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
         int cl, ch;
-        clip_ends<NP, false>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem);
+        clip_ends<NP, false, DEFER>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer);
         const int removed = (cl + ch > len) ? len : (cl + ch);
         if (go) {
             rej += (uint32_t)removed;
@@ -343,7 +362,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
                 b = 0;
             }
         }
-        active = go && (removed != 0);
+        active = go && (removed != 0) && !defer;
     }
 
     if constexpr (STAGE == 4) {
@@ -360,7 +379,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
     double E1 = 0.0, Q1 = 0.0;
     {
         constexpr int CH = NP >= 8 ? 8 : NP;
-        const int a_hi = wave_max_i32<NP>(a), b_lo = wave_min_i32<NP>(b);
+        const int a_hi = wave_max_i32<NP>(defer ? 0 : a), b_lo = wave_min_i32<NP>(defer ? NP - 1 : b);
 #pragma unroll
         for (int c = 0; c < NP / CH; ++c) {
             const bool interior = (CH * c >= a_hi) && (CH * c + CH - 1 <= b_lo);  // wave-uniform
@@ -406,12 +425,28 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         const double variance = ss / fmax(nn - 1.0, 1.0);
         center = (float)mean;
         sigma = (float)fmax(sqrt(variance), 1e-10);
+        if constexpr (STAGE == 6) {  // ablation: iteration 1's mean / sigma only
+            ClipResult r;
+            r.value = center + sigma;
+            r.sum = 0.0;
+            r.len = len;
+            r.rej = rej;
+            return r;
+        }
 
         const bool go = active && (len >= 2);
         if (go) last_center = center;
         const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
         int cl, ch;
-        clip_ends<NP, true>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem);
+        clip_ends<NP, true, DEFER>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer);
+        if constexpr (STAGE == 7) {  // ablation: + iteration 1's end walk
+            ClipResult r;
+            r.value = center + sigma + (float)(cl + ch) + (float)(e_rem + q_rem);
+            r.sum = 0.0;
+            r.len = len;
+            r.rej = rej;
+            return r;
+        }
         const int removed = (cl + ch > len) ? len : (cl + ch);
         if (go) {
             rej += (uint32_t)removed;
@@ -424,7 +459,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
                 b = 0;
             }
         }
-        active = go && (removed != 0);
+        active = go && (removed != 0) && !defer;
     }
 
     const double S = __builtin_fma((double)len, c0d, E1 - e_rem);
@@ -441,17 +476,23 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
     r.sum = (len > 0) ? S : 0.0;
     r.len = len > 0 ? len : 0;
     r.rej = rej;
+    r.defer = defer;
     return r;
 }
 
 // STAGE < 99 cuts the kernel short for the ablation bench (tools/stack_ablate.hip):
 //   1 = loads only, 2 = + pads + sort, 3 = + median/MAD, 99 = everything (the product).
-template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false>
-__global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(const StackArgs args) {
+//
+// Two-pass mode (MODE).  A wave walks the clipped ends of the sorted samples in lock step, so ONE lane with many
+// rejected samples -- a pixel inside a star profile, on a frame border -- makes all 64 lanes walk with it; on
+// registered frames more than half of the waves contain such a lane and the end walk of iteration 1 alone cost
+// 0.22 ms of 1.45.  kFastPass therefore only ever looks at the outermost 4 samples of each end; a lane that would
+// need more appends its pixel to one of kDeferSlots lists and writes nothing.  kGeneralPass re-runs the complete
+// algorithm for exactly those pixels (a few percent), densely packed into waves.  kPlain is the single-pass kernel
+// (partial frame sets, ragged strides, the exact engine).  All three produce bit-identical pixels.
+template <int NP, bool PARTIAL, bool EXACT, int STAGE, bool DIRECT, int MODE>
+__device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, const bool valid) {
     const int64_t total = args.rows * args.cols;
-    int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = g < total;
-    if (!valid) g = total - 1;
 
     int64_t y = 0, x = g;
     if (!args.contiguous) {
@@ -553,10 +594,11 @@ __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(co
     if constexpr (EXACT)
         r = clip_exact<NP>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
     else
-        r = clip_fast<NP, STAGE>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
+        r = clip_fast<NP, STAGE, MODE == kFastPass>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
 
     uint32_t rej = r.rej;
-    if (valid) {
+    const bool defer = MODE == kFastPass && valid && r.defer;
+    if (valid && !defer) {
         if constexpr (PARTIAL) {
             args.out_sum[g] = r.sum;
             args.out_cnt[g] = (uint32_t)r.len;
@@ -565,6 +607,21 @@ __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(co
         }
     } else {
         rej = 0;
+    }
+    if constexpr (MODE == kFastPass) {  // hand the pixel to the general pass: one atomic per wave, 2048 counters
+        const unsigned long long m = __ballot(defer);
+        if (m) {
+            const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
+            // slot: consecutive waves go to consecutive lists (each run of 2048 waves fills every list once, which
+            // bounds a list at defer_cap), rotated per run -- frame borders and star columns recur with the row
+            // period and would otherwise pile onto a few lists
+            const unsigned int w = blockIdx.x * 4u + (threadIdx.x >> 6);
+            const unsigned int slot = (w + (w / kDeferSlots) * 977u) & (kDeferSlots - 1);
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(&args.defer_count[slot], (unsigned int)__builtin_popcountll(m));
+            base = __shfl(base, leader, 64);
+            if (defer) args.defer_list[(size_t)slot * args.defer_cap + base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)g;
+        }
     }
 
     // rejection count: wavefront shuffle reduction, then ONE atomic per wave spread over kRejSlots
@@ -575,6 +632,26 @@ __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(co
     for (int off = 32; off >= 1; off >>= 1) rej += __shfl_xor(rej, off, 64);
     if ((threadIdx.x & 63) == 0 && rej != 0)
         atomicAdd(&args.rejected[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kRejSlots - 1)], (unsigned long long)rej);
+}
+
+template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain>
+__global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(const StackArgs args) {
+    if constexpr (MODE == kGeneralPass) {
+        const unsigned int cnt = args.defer_count[blockIdx.x];  // one block per list
+        const int *list = args.defer_list + (size_t)blockIdx.x * args.defer_cap;
+        for (unsigned int base = 0; base < cnt; base += 256) {
+            if (base + (threadIdx.x & ~63u) >= cnt) break;  // this wave has no pixel left (no barriers in the body)
+            const unsigned int k = base + threadIdx.x;
+            const bool valid = k < cnt;
+            stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE>(args, (int64_t)list[valid ? k : cnt - 1], valid);
+        }
+    } else {
+        const int64_t total = args.rows * args.cols;
+        int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        const bool valid = g < total;
+        if (!valid) g = total - 1;
+        stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE>(args, g, valid);
+    }
 }
 
 // single frame: sigma_clip_combine returns the value itself, or 0 if it is not finite
@@ -603,7 +680,16 @@ __global__ void finalize_partial_kernel(const double *sum, const uint32_t *cnt, 
 template <int NP, bool PARTIAL, bool EXACT, int STAGE>
 void launch_np(ab_ctx *ctx, const StackArgs &args, dim3 grid, dim3 block) {
     // DIRECT gather: no absent-frame slots, one row stride, byte offsets fit 32 bits
-    if (args.n == NP && args.contiguous && args.rows * args.cols < (int64_t(1) << 30))
+    const bool direct = args.n == NP && args.contiguous && args.rows * args.cols < (int64_t(1) << 30);
+    if constexpr (!EXACT && STAGE == 99 && NP >= 8) {
+        if (direct && args.defer_list) {  // two-pass mode: fast pass over every pixel, general pass over the deferred ones
+            hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, true, kFastPass>), grid, block, 0, ctx->stream, args);
+            hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, true, kGeneralPass>), dim3(kDeferSlots), block, 0,
+                               ctx->stream, args);
+            return;
+        }
+    }
+    if (direct)
         hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, true>), grid, block, 0, ctx->stream, args);
     else
         hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, false>), grid, block, 0, ctx->stream, args);
@@ -680,12 +766,38 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         args.rejected = ctx->counters;
         int np = 2;
         while (np < (int)n) np <<= 1;
+        if (!median_only && !ctx->stack_exact && (int)n == np && np >= 8 && contiguous && total < (int64_t(1) << 30) &&
+            !getenv("AB_STACK_SINGLE_PASS")) {
+            // deferred-pixel lists of the two-pass mode: slot = wave index & 2047, so a slot holds at most
+            // ceil(waves / 2048) waves' worth of pixels
+            const int64_t waves = ((total + 255) / 256) * 4;
+            const unsigned int cap = (unsigned int)(((waves + kDeferSlots - 1) / kDeferSlots) * 64);
+            char *ws = nullptr;
+            AB_TRY(ab_workspace(ctx, AB_WS_STACK_DEFER, (size_t)kDeferSlots * sizeof(unsigned int) + (size_t)kDeferSlots * cap * sizeof(int),
+                                (void **)&ws));
+            args.defer_count = (unsigned int *)ws;
+            args.defer_list = (int *)(ws + (size_t)kDeferSlots * sizeof(unsigned int));
+            args.defer_cap = cap;
+            AB_HIP(ctx, hipMemsetAsync(args.defer_count, 0, kDeferSlots * sizeof(unsigned int), ctx->stream));
+        }
         if (median_only)
             AB_TRY((launch_stack<false, false, 10>(ctx, args, np)));
         else if (ctx->stack_exact)
             AB_TRY(partial ? (launch_stack<true, true>(ctx, args, np)) : (launch_stack<false, true>(ctx, args, np)));
         else
             AB_TRY(partial ? (launch_stack<true, false>(ctx, args, np)) : (launch_stack<false, false>(ctx, args, np)));
+    }
+    if (getenv("AB_TRACE") && n > 1) {  // developer aid: how many pixels the fast pass handed to the general pass
+        std::vector<unsigned int> cnt(kDeferSlots, 0);
+        void *ws = ctx->ws[AB_WS_STACK_DEFER];
+        if (ws) {
+            AB_HIP(ctx, hipMemcpyAsync(cnt.data(), ws, kDeferSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+            AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            unsigned long long tot = 0, mx = 0;
+            for (unsigned int c : cnt) tot += c, mx = c > mx ? c : mx;
+            fprintf(stderr, "[ab_trace] stack: %llu of %lld pixels deferred (%.2f %%), fullest list %llu\n", tot, (long long)total,
+                    100.0 * (double)tot / (double)total, mx);
+        }
     }
     if (out_rejected) AB_TRY(read_rejected(ctx, out_rejected));
     return AB_OK;

@@ -193,7 +193,7 @@ def main():
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "stack_sigma_clip_kernel<64>", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "stack_sigma_clip_kernel<64> (fast pass + general pass over the deferred pixels = one stack launch)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes": algo_bytes, "avg_kernel_ms": round(stack_avg_ms, 4), "traffic": traffic,
                 "back_to_back_ms": None}

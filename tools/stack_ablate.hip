@@ -41,11 +41,24 @@ int main(int argc, char **argv) {
     ab_ctx *ctx = nullptr;
     if (ab_ctx_create(0, &ctx) != AB_OK) { fprintf(stderr, "no gfx950 device\n"); return 1; }
     const int64_t rows = 4096, cols = 4096, P = rows * cols;
-    const float cr = argc > 1 ? atof(argv[1]) : 1e-4f;
+    // usage: stack_ablate [cosmic_ray_rate]   |   stack_ablate --dir DIR   (DIR/frame_%02d.f32: 64 raw 4096^2 f32 planes,
+    // e.g. the bench's registered frames written by tools/time_stack_bench_data.py --dump DIR)
+    const bool from_dir = argc > 2 && std::string(argv[1]) == "--dir";
+    const float cr = (!from_dir && argc > 1) ? atof(argv[1]) : 1e-4f;
     StackArgs args; memset(&args, 0, sizeof args);
+    std::vector<float> host(from_dir ? P : 0);
     for (int f = 0; f < 64; ++f) {
         float *p; hipMalloc(&p, P * 4);
-        fill_kernel<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(p, P, 1000 + f, cr);
+        if (from_dir) {
+            char path[512];
+            snprintf(path, sizeof path, "%s/frame_%02d.f32", argv[2], f);
+            FILE *fp = fopen(path, "rb");
+            if (!fp || fread(host.data(), 4, P, fp) != (size_t)P) { fprintf(stderr, "cannot read %s\n", path); return 1; }
+            fclose(fp);
+            hipMemcpy(p, host.data(), P * 4, hipMemcpyHostToDevice);
+        } else {
+            fill_kernel<<<(unsigned)((P + 255) / 256), 256, 0, ctx->stream>>>(p, P, 1000 + f, cr);
+        }
         args.p[f] = p; args.ld[f] = cols;
     }
     float *out; hipMalloc(&out, P * 4);
@@ -58,6 +71,8 @@ int main(int argc, char **argv) {
     float t3 = time_stage<3, false>(ctx, args, 5);
     float t4 = time_stage<4, false>(ctx, args, 5);
     float t5 = time_stage<5, false>(ctx, args, 5);
+    float t6 = time_stage<6, false>(ctx, args, 5);
+    float t7 = time_stage<7, false>(ctx, args, 5);
     args.max_iter = 2;
     float t92 = time_stage<99, false>(ctx, args, 5);
     args.max_iter = 3;
@@ -79,6 +94,8 @@ int main(int argc, char **argv) {
     printf("stage 3 + median/MAD      %8.3f ms  %7.1f GB/s\n", t3, gb / t3 * 1e3);
     printf("stage 4 + clip 0          %8.3f ms  %7.1f GB/s\n", t4, gb / t4 * 1e3);
     printf("stage 5 + S1/Q1 pass      %8.3f ms  %7.1f GB/s\n", t5, gb / t5 * 1e3);
+    printf("stage 6 + iter-1 mean/sigma %6.3f ms  %7.1f GB/s\n", t6, gb / t6 * 1e3);
+    printf("stage 7 + iter-1 end walk %8.3f ms  %7.1f GB/s\n", t7, gb / t7 * 1e3);
     printf("full, max_iter=2          %8.3f ms  %7.1f GB/s\n", t92, gb / t92 * 1e3);
     printf("full, max_iter=3          %8.3f ms  %7.1f GB/s\n", t93, gb / t93 * 1e3);
     printf("stage 99 full (fast)      %8.3f ms  %7.1f GB/s\n", t9, gb / t9 * 1e3);

@@ -25,6 +25,12 @@ for k in range(N):
 warped = [raw[0]] + [torch.empty_like(raw[0]) for _ in range(1, N)]
 ctx.align_pairs_affine(raw[0], raw[1:], warped[1:], 8)
 out = torch.empty((R, C), device="cuda")
+if len(sys.argv) > 2 and sys.argv[1] == "--dump":   # raw f32 planes for tools/stack_ablate.hip --dir
+    os.makedirs(sys.argv[2], exist_ok=True)
+    for k, w in enumerate(warped):
+        w.cpu().numpy().tofile(os.path.join(sys.argv[2], f"frame_{k:02d}.f32"))
+    print("dumped", N, "frames to", sys.argv[2])
+    sys.exit(0)
 
 
 def t(frames, label, it=5):
