@@ -28,10 +28,12 @@ def capture(fn, path):
 
 
 def counter_avg(db, like):
+    """Per-launch counter value of one stack operation = sum over the distinct kernels it launches (fast pass + general
+    pass since the two-pass mode) of each kernel's average."""
     con = sqlite3.connect(db)
-    rows = con.execute("select value from counters_collection where kernel_name like ? order by start", (like,)).fetchall()
-    vals = [r[0] for r in rows]
-    return vals
+    rows = con.execute("select kernel_name, avg(value) from counters_collection where kernel_name like ? group by kernel_name",
+                       (like,)).fetchall()
+    return sum(r[1] for r in rows), [r[0] for r in rows]
 
 
 def main(tag, outdir=None, frames=64, pixels=4096 * 4096):
@@ -43,11 +45,9 @@ def main(tag, outdir=None, frames=64, pixels=4096 * 4096):
     txt = capture(rocpd_pmc.main, os.path.join(d, "fetch_results.db")) + capture(rocpd_pmc.main, os.path.join(d, "write_results.db"))
     with open(os.path.join(pdir, f"{tag}_pmc.txt"), "w") as f:
         f.write(txt)
-    fetch = counter_avg(os.path.join(d, "fetch_results.db"), "%stack_sigma_clip_kernel<64%")
-    write = counter_avg(os.path.join(d, "write_results.db"), "%stack_sigma_clip_kernel<64%")
-    fk = sum(fetch) / len(fetch)
-    wk = sum(write) / len(write)
-    out = {"source": f"profiles/{tag}_pmc.txt", "frames": frames, "pixels": pixels,
+    fk, names = counter_avg(os.path.join(d, "fetch_results.db"), "%stack_sigma_clip_kernel<64%")
+    wk, _ = counter_avg(os.path.join(d, "write_results.db"), "%stack_sigma_clip_kernel<64%")
+    out = {"source": f"profiles/{tag}_pmc.txt", "kernels_per_launch": len(names), "frames": frames, "pixels": pixels,
            "FETCH_SIZE_KiB_avg": fk, "WRITE_SIZE_KiB_avg": wk, "fetch_correction": 2.0,
            "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
            "algorithmic_bytes": 4 * frames * pixels + 4 * pixels}
