@@ -63,6 +63,7 @@ struct StackArgs {
     int *defer_list;                 // kDeferSlots x defer_cap pixel indices
     unsigned int *defer_count;       // kDeferSlots counters
     unsigned int defer_cap;
+    int keep_counts;                 // AB_TRACE: leave the counters for the host to read
 };
 
 // Compiler fences (no instructions).  launder() makes the sample vector look rewritten so LLVM
@@ -645,6 +646,8 @@ __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(co
             const bool valid = k < cnt;
             stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE>(args, (int64_t)list[valid ? k : cnt - 1], valid);
         }
+        __syncthreads();  // every wave has read its count
+        if (!args.keep_counts && threadIdx.x == 0) args.defer_count[blockIdx.x] = 0;  // ready for the next launch
     } else {
         const int64_t total = args.rows * args.cols;
         int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -773,12 +776,16 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             const int64_t waves = ((total + 255) / 256) * 4;
             const unsigned int cap = (unsigned int)(((waves + kDeferSlots - 1) / kDeferSlots) * 64);
             char *ws = nullptr;
+            const void *before = ctx->ws[AB_WS_STACK_DEFER];
             AB_TRY(ab_workspace(ctx, AB_WS_STACK_DEFER, (size_t)kDeferSlots * sizeof(unsigned int) + (size_t)kDeferSlots * cap * sizeof(int),
                                 (void **)&ws));
             args.defer_count = (unsigned int *)ws;
             args.defer_list = (int *)(ws + (size_t)kDeferSlots * sizeof(unsigned int));
             args.defer_cap = cap;
-            AB_HIP(ctx, hipMemsetAsync(args.defer_count, 0, kDeferSlots * sizeof(unsigned int), ctx->stream));
+            // the general pass leaves every counter at zero again, so only a fresh workspace needs clearing
+            args.keep_counts = getenv("AB_TRACE") ? 1 : 0;
+            if (ws != before || args.keep_counts)
+                AB_HIP(ctx, hipMemsetAsync(args.defer_count, 0, kDeferSlots * sizeof(unsigned int), ctx->stream));
         }
         if (median_only)
             AB_TRY((launch_stack<false, false, 10>(ctx, args, np)));
