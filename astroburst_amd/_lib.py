@@ -236,6 +236,11 @@ def lib() -> C.CDLL:
     L.ab_create_master.argtypes = [vp, C.c_int32, pp, C.c_size_t, pp, pp, pp]
     L.ab_register_frames.argtypes = [vp, pp, pp, C.c_size_t, C.c_int, C.POINTER(AffineAlignResultC)]
     L.ab_align_pairs_affine.argtypes = [vp, pp, pp, C.c_size_t, C.c_int, C.POINTER(AffineAlignResultC), pp]
+    L.ab_fits_decode_pixels.argtypes = [vp, vp, C.c_size_t, C.c_int32, C.c_int64, C.c_double, C.c_double, pp]
+    L.ab_fits_compute_bzero_bscale.argtypes = [vp, pp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ab_fits_encode_pixels.argtypes = [vp, pp, C.c_int32, C.c_double, C.c_double, vp, C.c_int32]
+    L.ab_stack_sigma_clip_raw.argtypes = [vp, C.POINTER(vp), C.c_size_t, C.c_int64, C.c_double, C.c_double, C.POINTER(StackConfig), pp,
+                                          C.POINTER(C.c_uint64)]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift

@@ -147,6 +147,7 @@ class Context:
                                       if rc == _lib.AB_ERR_NO_DEVICE else "ab_ctx_create failed")
         self._h = h
         self.device = device
+        self._stream = None   # the torch stream the context currently launches on (None: its own)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -164,12 +165,18 @@ class Context:
             raise AstroBurstError(rc, self._L.ab_last_error(self._h).decode())
 
     def use_torch_stream(self):
-        """Launch on torch's current stream so torch.cuda.Event timing brackets our kernels."""
-        self._check(self._L.ab_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        """Launch on torch's current stream: calls are then ordered with the torch kernels that produce their inputs and
+        consume their outputs, and torch.cuda.Event timing brackets them.  Done automatically whenever a torch tensor is
+        passed as a plane (a device plane handed over by torch is only meaningful in torch's stream order)."""
+        s = torch.cuda.current_stream().cuda_stream
+        if s != self._stream:
+            self._check(self._L.ab_ctx_set_stream(self._h, C.c_void_p(s)))
+            self._stream = s
 
     def use_own_stream(self):
-        """Back to the context's private stream (inputs produced by torch must then be synchronised by the caller)."""
+        """Back to the context's private stream (host planes; C callers that manage ordering themselves)."""
         self._check(self._L.ab_ctx_reset_stream(self._h))
+        self._stream = None
 
     def synchronize(self):
         self._check(self._L.ab_ctx_synchronize(self._h))
@@ -185,6 +192,7 @@ class Context:
         if _is_torch(x):
             assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous(), \
                 "device planes are contiguous 2-D float32 CUDA tensors"
+            self.use_torch_stream()
             keep.append(x)
             return Plane(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], 1)
         a = np.ascontiguousarray(x, dtype=np.float32)
@@ -669,6 +677,67 @@ class Context:
                             tuple(tuple(row) for row in info.chan_stats), tuple(info.offset_g), tuple(info.offset_b),
                             bool(info.scnr_applied), bool(info.resampled), tuple(pres),
                             tuple(self._stats_out(s) for s in info.stats_wb))
+
+    # ---- FITS pixel codecs ----------------------------------------------------------
+    _BPP = {8: 1, 16: 2, 32: 4, -32: 4, -64: 8}
+
+    def fits_decode_pixels(self, data, rows: int, cols: int, bitpix: int, bscale=1.0, bzero=0.0, out=None):
+        """decode_pixels (reader.rs:42-101): data = the big-endian data unit (bytes / numpy uint8 on the host, or a torch
+        uint8 CUDA tensor) -> f32 plane."""
+        if bitpix not in self._BPP:
+            raise AstroBurstError(_lib.AB_ERR_INVALID, f"unsupported BITPIX {bitpix}")
+        keep = []
+        if _is_torch(data):
+            assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+            self.use_torch_stream()
+            ptr, nbytes, on_dev = C.c_void_p(data.data_ptr()), data.numel(), 1
+            keep.append(data)
+            if out is None:
+                out = torch.empty((rows, cols), dtype=torch.float32, device=data.device)
+        else:
+            buf = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data, np.uint8)
+            keep.append(buf)
+            ptr, nbytes, on_dev = C.c_void_p(buf.ctypes.data), buf.size, 0
+            if out is None:
+                out = np.empty((rows, cols), np.float32)
+        po = self._out_plane(out, keep, rows, cols)
+        self._check(self._L.ab_fits_decode_pixels(self._h, ptr, nbytes, on_dev, bitpix, bscale, bzero, C.byref(po)))
+        return out
+
+    def fits_compute_bzero_bscale(self, image):
+        """compute_bzero_bscale (writer.rs:143-159) -> (bzero, bscale)"""
+        keep = []
+        pi = self._plane(image, keep)
+        bz, bs = C.c_double(), C.c_double()
+        self._check(self._L.ab_fits_compute_bzero_bscale(self._h, C.byref(pi), C.byref(bz), C.byref(bs)))
+        return bz.value, bs.value
+
+    def fits_encode_pixels(self, image, bitpix: int, bzero=0.0, bscale=1.0) -> np.ndarray:
+        """write_*_slice_as_be (writer.rs:82-135) -> the big-endian data unit as a host uint8 array"""
+        keep = []
+        pi = self._plane(image, keep)
+        if bitpix not in (-32, 16, -64):
+            raise AstroBurstError(_lib.AB_ERR_INVALID, f"the writer supports BITPIX -32, 16 and -64 (got {bitpix})")
+        out = np.empty(pi.rows * pi.cols * self._BPP[bitpix], np.uint8)
+        self._check(self._L.ab_fits_encode_pixels(self._h, C.byref(pi), bitpix, bzero, bscale, C.c_void_p(out.ctypes.data), 0))
+        return out
+
+    def stack_sigma_clip_raw(self, raw_planes, rows: int, cols: int, bitpix: int, bscale=1.0, bzero=0.0, sigma_low=3.0, sigma_high=3.0,
+                             max_iterations=5, out=None, want_rejected=True):
+        """ab_stack_sigma_clip over raw big-endian data units (torch uint8 CUDA tensors): decode fused into the stack."""
+        for t in raw_planes:
+            assert _is_torch(t) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+        self.use_torch_stream()
+        ptrs = (C.c_void_p * len(raw_planes))(*[t.data_ptr() for t in raw_planes])
+        if out is None:
+            out = torch.empty((rows, cols), dtype=torch.float32, device=raw_planes[0].device)
+        keep = []
+        po = self._out_plane(out, keep, rows, cols)
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 0)
+        rej = C.c_uint64(0)
+        self._check(self._L.ab_stack_sigma_clip_raw(self._h, ptrs, len(raw_planes), bitpix, bscale, bzero, C.byref(cfg), C.byref(po),
+                                                    C.byref(rej) if want_rejected else None))
+        return (out, int(rej.value)) if want_rejected else out
 
     # ---- caller-side helpers of a17 / a20 ----------------------------------------------------------------
     def apply_lrgb(self, l, r, g, b, lightness_weight=1.0, chrominance_weight=1.0):

@@ -45,6 +45,7 @@ constexpr int kMaxFrames = 64;
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
 enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
+enum { kInNative = 0, kInF32BE = 1, kInI16BE = 2 };  // sample encodings the gather understands
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
 
 struct StackArgs {
@@ -64,6 +65,9 @@ struct StackArgs {
     unsigned int *defer_count;       // kDeferSlots counters
     unsigned int defer_cap;
     int keep_counts;                 // AB_TRACE: leave the counters for the host to read
+    // raw FITS input (INPUT != kInNative): p[] point at big-endian data units, decoded on load as decode_pixels does
+    int identity;                    // is_identity_scaling(bscale, bzero) (reader.rs:36-39)
+    double bscale, bzero;
 };
 
 // Compiler fences (no instructions).  launder() makes the sample vector look rewritten so LLVM
@@ -491,8 +495,9 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
 // need more appends its pixel to one of kDeferSlots lists and writes nothing.  kGeneralPass re-runs the complete
 // algorithm for exactly those pixels (a few percent), densely packed into waves.  kPlain is the single-pass kernel
 // (partial frame sets, ragged strides, the exact engine).  All three produce bit-identical pixels.
-template <int NP, bool PARTIAL, bool EXACT, int STAGE, bool DIRECT, int MODE>
+template <int NP, bool PARTIAL, bool EXACT, int STAGE, bool DIRECT, int MODE, int INPUT = kInNative>
 __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, const bool valid) {
+    static_assert(INPUT == kInNative || DIRECT, "raw FITS planes are only read through the DIRECT gather");
     const int64_t total = args.rows * args.cols;
 
     int64_t y = 0, x = g;
@@ -514,8 +519,9 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         const uint64_t *kp = (const uint64_t *)__builtin_amdgcn_kernarg_segment_ptr();
         const uint64_t mine = kp[threadIdx.x & 63];
         const uint32_t plo = (uint32_t)mine, phi = (uint32_t)(mine >> 32);
-        const uint32_t off = (uint32_t)g * 4u;
-        const uint32_t plane_bytes = (uint32_t)total * 4u;
+        constexpr uint32_t kSampleBytes = INPUT == kInI16BE ? 2u : 4u;
+        const uint32_t off = (uint32_t)g * kSampleBytes;
+        const uint32_t plane_bytes = (uint32_t)total * kSampleBytes;
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
             const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, f) << 32) |
@@ -523,7 +529,16 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
             // buffer descriptor in 4 SGPRs -> `buffer_load_dword v, voffset, s[rsrc], 0 offen`
             const __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)plane_bytes, 0x00020000);
-            v[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+            if constexpr (INPUT == kInNative) {
+                v[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+            } else if constexpr (INPUT == kInF32BE) {  // reader.rs:71-83
+                const float x = __uint_as_float(__builtin_bswap32((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0)));
+                v[f] = args.identity ? x : (float)((double)x * args.bscale + args.bzero);
+            } else {  // BITPIX 16, reader.rs:56-62: 2 bytes per sample from HBM
+                const uint16_t u = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)off, 0, 0);
+                const int16_t x = (int16_t)(uint16_t)((u << 8) | (u >> 8));
+                v[f] = args.identity ? (float)x : (float)((double)x * args.bscale + args.bzero);
+            }
         }
 #pragma unroll
         for (int f = 0; f < NP; ++f) nf = __builtin_fmaf(v[f], 0.0f, nf);
@@ -635,7 +650,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         atomicAdd(&args.rejected[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kRejSlots - 1)], (unsigned long long)rej);
 }
 
-template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain>
+template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain, int INPUT = kInNative>
 __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(const StackArgs args) {
     if constexpr (MODE == kGeneralPass) {
         const unsigned int cnt = args.defer_count[blockIdx.x];  // one block per list
@@ -644,7 +659,7 @@ __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(co
             if (base + (threadIdx.x & ~63u) >= cnt) break;  // this wave has no pixel left (no barriers in the body)
             const unsigned int k = base + threadIdx.x;
             const bool valid = k < cnt;
-            stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE>(args, (int64_t)list[valid ? k : cnt - 1], valid);
+            stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE, INPUT>(args, (int64_t)list[valid ? k : cnt - 1], valid);
         }
         __syncthreads();  // every wave has read its count
         if (!args.keep_counts && threadIdx.x == 0) args.defer_count[blockIdx.x] = 0;  // ready for the next launch
@@ -653,7 +668,7 @@ __global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(co
         int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
         const bool valid = g < total;
         if (!valid) g = total - 1;
-        stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE>(args, g, valid);
+        stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE, INPUT>(args, g, valid);
     }
 }
 
@@ -678,6 +693,13 @@ __global__ void finalize_partial_kernel(const double *sum, const uint32_t *cnt, 
     if (g >= n) return;
     const uint32_t c = cnt[g];
     out[g] = c ? (float)(sum[g] / (double)c) : 0.0f;
+}
+
+// raw big-endian planes: two-pass DIRECT kernels only (the caller has checked n == NP, contiguous, < 2^30 px)
+template <int NP, int INPUT>
+void launch_raw(ab_ctx *ctx, const StackArgs &args, dim3 grid, dim3 block) {
+    hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, false, false, 99, true, kFastPass, INPUT>), grid, block, 0, ctx->stream, args);
+    hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, false, false, 99, true, kGeneralPass, INPUT>), dim3(kDeferSlots), block, 0, ctx->stream, args);
 }
 
 template <int NP, bool PARTIAL, bool EXACT, int STAGE>
@@ -728,6 +750,23 @@ static int read_rejected(ab_ctx *ctx, uint64_t *out) {
     return AB_OK;
 }
 
+// deferred-pixel lists of the two-pass mode: slot = wave index & 2047 (rotated), so a slot holds at most
+// ceil(waves / 2048) waves' worth of pixels
+static int setup_defer(ab_ctx *ctx, StackArgs *args, int64_t total) {
+    const int64_t waves = ((total + 255) / 256) * 4;
+    const unsigned int cap = (unsigned int)(((waves + kDeferSlots - 1) / kDeferSlots) * 64);
+    char *ws = nullptr;
+    const void *before = ctx->ws[AB_WS_STACK_DEFER];
+    AB_TRY(ab_workspace(ctx, AB_WS_STACK_DEFER, (size_t)kDeferSlots * sizeof(unsigned int) + (size_t)kDeferSlots * cap * sizeof(int), (void **)&ws));
+    args->defer_count = (unsigned int *)ws;
+    args->defer_list = (int *)(ws + (size_t)kDeferSlots * sizeof(unsigned int));
+    args->defer_cap = cap;
+    // the general pass leaves every counter at zero again, so only a fresh workspace needs clearing
+    args->keep_counts = getenv("AB_TRACE") ? 1 : 0;
+    if (ws != before || args->keep_counts) AB_HIP(ctx, hipMemsetAsync(args->defer_count, 0, kDeferSlots * sizeof(unsigned int), ctx->stream));
+    return AB_OK;
+}
+
 // Shared implementation.  dplanes: device pointers + row strides of the n frames.
 int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows,
                     int64_t cols, const ab_stack_config *cfg, float *out_dev, double *out_sum_dev,
@@ -771,21 +810,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         while (np < (int)n) np <<= 1;
         if (!median_only && !ctx->stack_exact && (int)n == np && np >= 8 && contiguous && total < (int64_t(1) << 30) &&
             !getenv("AB_STACK_SINGLE_PASS")) {
-            // deferred-pixel lists of the two-pass mode: slot = wave index & 2047, so a slot holds at most
-            // ceil(waves / 2048) waves' worth of pixels
-            const int64_t waves = ((total + 255) / 256) * 4;
-            const unsigned int cap = (unsigned int)(((waves + kDeferSlots - 1) / kDeferSlots) * 64);
-            char *ws = nullptr;
-            const void *before = ctx->ws[AB_WS_STACK_DEFER];
-            AB_TRY(ab_workspace(ctx, AB_WS_STACK_DEFER, (size_t)kDeferSlots * sizeof(unsigned int) + (size_t)kDeferSlots * cap * sizeof(int),
-                                (void **)&ws));
-            args.defer_count = (unsigned int *)ws;
-            args.defer_list = (int *)(ws + (size_t)kDeferSlots * sizeof(unsigned int));
-            args.defer_cap = cap;
-            // the general pass leaves every counter at zero again, so only a fresh workspace needs clearing
-            args.keep_counts = getenv("AB_TRACE") ? 1 : 0;
-            if (ws != before || args.keep_counts)
-                AB_HIP(ctx, hipMemsetAsync(args.defer_count, 0, kDeferSlots * sizeof(unsigned int), ctx->stream));
+            AB_TRY(setup_defer(ctx, &args, total));
         }
         if (median_only)
             AB_TRY((launch_stack<false, false, 10>(ctx, args, np)));
@@ -881,6 +906,60 @@ int ab_stack_sigma_clip_partial(ab_ctx *ctx, const ab_plane *planes, size_t n, c
     }
     return ab_stack_device(ctx, dp.data(), ld.data(), n, rows, cols, cfg, nullptr, out_sum_dev, out_cnt_dev, out_rejected,
                            false);
+}
+
+// stack_images' per-pixel loop fed straight from FITS data units (decode_pixels fused into the gather)
+int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size_t n, int64_t bitpix, double bscale, double bzero,
+                            const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, raw_planes_dev && cfg && out && out->data, "null argument");
+    AB_CHECK(ctx, out->on_device, "the fused raw stack writes a device plane");
+    AB_CHECK(ctx, bitpix == -32 || bitpix == 16, "fused decode handles BITPIX -32 and 16 (got %lld): decode with ab_fits_decode_pixels first",
+             (long long)bitpix);
+    const int64_t total = out->rows * out->cols;
+    if (!(n == 8 || n == 16 || n == 32 || n == 64) || total <= 0 || total >= (int64_t(1) << 30))
+        return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "fused raw stack takes 8, 16, 32 or 64 planes of < 2^30 pixels (got %zu x %lld): decode first", n,
+                            (long long)total);
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kRejSlots * sizeof(unsigned long long), ctx->stream));
+    StackArgs args;
+    memset(&args, 0, sizeof args);
+    for (size_t i = 0; i < n; ++i) {
+        AB_CHECK(ctx, raw_planes_dev[i] && ((uintptr_t)raw_planes_dev[i] & 3) == 0, "raw plane %zu is null or not 4-byte aligned", i);
+        args.p[i] = (const float *)raw_planes_dev[i];
+        args.ld[i] = out->cols;
+    }
+    args.n = (int)n;
+    args.contiguous = 1;
+    args.rows = out->rows;
+    args.cols = out->cols;
+    args.sigma_low = cfg->sigma_low;
+    args.sigma_high = cfg->sigma_high;
+    args.max_iter = cfg->max_iterations;
+    args.out = out->data;
+    args.rejected = ctx->counters;
+    args.identity = std::fabs(bscale - 1.0) < 1e-15 && std::fabs(bzero) < 1e-15;
+    args.bscale = bscale;
+    args.bzero = bzero;
+    AB_TRY(setup_defer(ctx, &args, total));
+    const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+#define AB_RAW_CASE(NPV)                                             \
+    case NPV:                                                        \
+        if (bitpix == -32)                                           \
+            launch_raw<NPV, kInF32BE>(ctx, args, grid, block);       \
+        else                                                         \
+            launch_raw<NPV, kInI16BE>(ctx, args, grid, block);       \
+        break;
+    switch ((int)n) {
+        AB_RAW_CASE(8)
+        AB_RAW_CASE(16)
+        AB_RAW_CASE(32)
+        AB_RAW_CASE(64)
+    }
+#undef AB_RAW_CASE
+    AB_HIP(ctx, hipGetLastError());
+    if (out_rejected) AB_TRY(read_rejected(ctx, out_rejected));
+    return AB_OK;
 }
 
 int ab_stack_last_rejected(ab_ctx *ctx, uint64_t *out_rejected) {

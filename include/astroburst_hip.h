@@ -409,6 +409,24 @@ AB_API int ab_calibrate_channel(ab_ctx *ctx, const ab_plane *orig, float factor,
 AB_API int ab_create_master(ab_ctx *ctx, int32_t kind, const ab_plane *frames, size_t n_frames, const ab_plane *master_bias,
                             const ab_plane *master_dark, ab_plane_mut *out);
 
+/* ---- FITS pixel codecs, infra/fits/reader.rs + writer.rs ------------------------------------------- */
+/* decode_pixels(data, bitpix, bscale, bzero) (reader.rs:42-101): big-endian BITPIX 8 / 16 / 32 / -32 / -64 -> f32,
+ * `v as f64 * bscale + bzero` unless is_identity_scaling (:36-39).  `data` = the HDU's data unit as it sits in the
+ * file (host or device); out must hold nbytes / bytes-per-pixel pixels. */
+AB_API int ab_fits_decode_pixels(ab_ctx *ctx, const void *data, size_t nbytes, int32_t data_on_device, int64_t bitpix, double bscale,
+                                 double bzero, ab_plane_mut *out);
+/* compute_bzero_bscale (writer.rs:143-159): i16 scaling from the finite min / max */
+AB_API int ab_fits_compute_bzero_bscale(ab_ctx *ctx, const ab_plane *img, double *bzero, double *bscale);
+/* write_f32 / i16 / f64_slice_as_be (writer.rs:82-135): the data unit for BITPIX -32, 16 (with bzero / bscale) or -64 */
+AB_API int ab_fits_encode_pixels(ab_ctx *ctx, const ab_plane *img, int32_t bitpix, double bzero, double bscale, void *out,
+                                 int32_t out_on_device);
+/* stack_images' per-pixel loop (combine.rs:160-182) fed straight from n device-resident data units (BITPIX -32 or 16,
+ * all rows x cols of `out`): decode_pixels is fused into the kernel's gather, so BITPIX 16 stacks read 2 bytes per
+ * sample from HBM and no decoded copy exists.  Result = ab_fits_decode_pixels + ab_stack_sigma_clip, bit for bit.
+ * n must be 8, 16, 32 or 64. */
+AB_API int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size_t n, int64_t bitpix, double bscale,
+                                   double bzero, const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

@@ -260,6 +260,13 @@ void orc_calibrate_channel(const float *orig, size_t n, float factor, const orc_
 void orc_create_master(int kind, const float *const *frames, size_t n_frames, size_t npix, const float *master_bias,
                        const float *master_dark, float *out);                          /* calibration.rs:127-255 */
 
+/* ---- infra/fits pixel codecs (orc_fits.c), SURVEY 8(f) row 1 ------------------------------------ */
+size_t orc_fits_decode_pixels(const uint8_t *data, size_t nbytes, int64_t bitpix, double bscale, double bzero,
+                              float *out);                                             /* reader.rs:42-101 */
+void orc_fits_compute_bzero_bscale(const float *data, size_t n, double *bzero, double *bscale); /* writer.rs:143-159 */
+size_t orc_fits_encode_pixels(const float *data, size_t n, int32_t bitpix, double bzero, double bscale,
+                              uint8_t *out);                                           /* writer.rs:82-135 */
+
 /* utility */
 int orc_max_threads(void);
 

@@ -775,6 +775,39 @@ def create_master(kind: str, frames, master_bias=None, master_dark=None) -> np.n
     return out
 
 
+def fits_decode_pixels(data, bitpix: int, bscale=1.0, bzero=0.0) -> np.ndarray:
+    """decode_pixels (infra/fits/reader.rs:42-101) -> flat f32 array (empty for an unknown BITPIX)"""
+    buf = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data, np.uint8)
+    bpp = {8: 1, 16: 2, 32: 4, -32: 4, -64: 8}.get(bitpix, 0)
+    out = np.zeros(buf.size // bpp if bpp else 0, np.float32)
+    L = lib()
+    L.orc_fits_decode_pixels.restype = C.c_size_t
+    L.orc_fits_decode_pixels.argtypes = [C.c_void_p, C.c_size_t, C.c_int64, C.c_double, C.c_double, C.POINTER(C.c_float)]
+    n = L.orc_fits_decode_pixels(C.c_void_p(buf.ctypes.data), buf.size, bitpix, bscale, bzero, _fp(out) if out.size else None)
+    return out[:n]
+
+
+def fits_compute_bzero_bscale(image):
+    """compute_bzero_bscale (writer.rs:143-159) -> (bzero, bscale)"""
+    im = _f32(image)
+    bz, bs = C.c_double(), C.c_double()
+    L = lib()
+    L.orc_fits_compute_bzero_bscale.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_fits_compute_bzero_bscale(_fp(im), im.size, C.byref(bz), C.byref(bs))
+    return bz.value, bs.value
+
+
+def fits_encode_pixels(image, bitpix: int, bzero=0.0, bscale=1.0) -> np.ndarray:
+    """write_f32 / i16 / f64_slice_as_be (writer.rs:82-135) -> uint8 data unit"""
+    im = _f32(image)
+    out = np.zeros(im.size * {-32: 4, 16: 2, -64: 8}[bitpix], np.uint8)
+    L = lib()
+    L.orc_fits_encode_pixels.restype = C.c_size_t
+    L.orc_fits_encode_pixels.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_int32, C.c_double, C.c_double, C.c_void_p]
+    L.orc_fits_encode_pixels(_fp(im), im.size, bitpix, bzero, bscale, C.c_void_p(out.ctypes.data))
+    return out
+
+
 def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
