@@ -529,15 +529,26 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
             // buffer descriptor in 4 SGPRs -> `buffer_load_dword v, voffset, s[rsrc], 0 offen`
             const __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)plane_bytes, 0x00020000);
-            if constexpr (INPUT == kInNative) {
-                v[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
-            } else if constexpr (INPUT == kInF32BE) {  // reader.rs:71-83
-                const float x = __uint_as_float(__builtin_bswap32((uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0)));
+            // raw words first (all NP loads in flight, exactly as for native planes); big-endian decode afterwards
+            constexpr uint32_t kAlign = INPUT == kInI16BE ? ~3u : ~0u;
+            v[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(off & kAlign), 0, 0));
+        }
+        if constexpr (INPUT == kInF32BE) {  // reader.rs:71-83
+#pragma unroll
+            for (int f = 0; f < NP; ++f) {
+                const float x = __uint_as_float(__builtin_bswap32(__float_as_uint(v[f])));
                 v[f] = args.identity ? x : (float)((double)x * args.bscale + args.bzero);
-            } else {  // BITPIX 16, reader.rs:56-62: 2 bytes per sample from HBM
-                const uint16_t u = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)off, 0, 0);
-                const int16_t x = (int16_t)(uint16_t)((u << 8) | (u >> 8));
-                v[f] = args.identity ? (float)x : (float)((double)x * args.bscale + args.bzero);
+            }
+        } else if constexpr (INPUT == kInI16BE) {  // BITPIX 16, reader.rs:56-62: 2 bytes per sample, two lanes per dword
+#pragma unroll
+            for (int f = 0; f < NP; ++f) {
+                const uint32_t w = __float_as_uint(v[f]);
+                const uint32_t u = (off & 2u) ? (w >> 16) : (w & 0xffffu);
+                const int16_t x = (int16_t)(uint16_t)(((u & 0xffu) << 8) | (u >> 8));
+                // identity == 1: v as f32;  identity == 2: BSCALE = 1 and an integer BZERO (unsigned-16 data: 32768) --
+                // x + bzero is then an integer below 2^24, so the f32 sum IS the f64 result rounded to f32
+                v[f] = args.identity == 1 ? (float)x
+                                          : (args.identity == 2 ? (float)x + (float)args.bzero : (float)((double)x * args.bscale + args.bzero));
             }
         }
 #pragma unroll
@@ -939,6 +950,7 @@ int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size
     args.out = out->data;
     args.rejected = ctx->counters;
     args.identity = std::fabs(bscale - 1.0) < 1e-15 && std::fabs(bzero) < 1e-15;
+    if (!args.identity && bitpix == 16 && bscale == 1.0 && bzero == std::floor(bzero) && std::fabs(bzero) <= 8.0e6) args.identity = 2;
     args.bscale = bscale;
     args.bzero = bzero;
     AB_TRY(setup_defer(ctx, &args, total));
