@@ -128,6 +128,26 @@ class SpccResultC(C.Structure):  # spcc.rs:45-56
                 ("stars_matched", C.c_uint64), ("stars_total", C.c_uint64), ("avg_color_index", C.c_double)]
 
 
+class TileLevelC(C.Structure):  # infra/render/tiles.rs:21-29 (+ offset into the packed tile buffer)
+    _fields_ = [("level", C.c_uint64), ("width", C.c_uint64), ("height", C.c_uint64), ("cols", C.c_uint64),
+                ("rows", C.c_uint64), ("scale_factor", C.c_double), ("offset", C.c_uint64)]
+
+
+MAX_TILE_LEVELS = 32
+
+
+class SubframeWeightConfigC(C.Structure):  # subframe.rs:24-49
+    _fields_ = [("fwhm_weight", C.c_double), ("eccentricity_weight", C.c_double), ("snr_weight", C.c_double),
+                ("noise_weight", C.c_double), ("max_fwhm", C.c_double), ("max_eccentricity", C.c_double),
+                ("min_snr", C.c_double), ("min_stars", C.c_uint64)]
+
+
+class SubframeMetricsC(C.Structure):  # subframe.rs:9-22
+    _fields_ = [("star_count", C.c_uint64), ("median_fwhm", C.c_double), ("median_eccentricity", C.c_double),
+                ("median_snr", C.c_double), ("background_median", C.c_double), ("background_sigma", C.c_double),
+                ("noise_ratio", C.c_double), ("weight", C.c_double), ("accepted", C.c_int32)]
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 every csrc/*.hip into astroburst_amd/libastroburst_hip.so."""
     cmd = ["make", "-C", CSRC, "-j8"] + (["-B"] if force else [])
@@ -241,6 +261,25 @@ def lib() -> C.CDLL:
     L.ab_fits_encode_pixels.argtypes = [vp, pp, C.c_int32, C.c_double, C.c_double, vp, C.c_int32]
     L.ab_stack_sigma_clip_raw.argtypes = [vp, C.POINTER(vp), C.c_size_t, C.c_int64, C.c_double, C.c_double, C.POINTER(StackConfig), pp,
                                           C.POINTER(C.c_uint64)]
+    L.ab_subframe_weight_config_default.argtypes = [C.POINTER(SubframeWeightConfigC)]
+    L.ab_subframe_weight_config_default.restype = None
+    L.ab_analyze_subframe.argtypes = [vp, pp, C.POINTER(SubframeWeightConfigC), C.POINTER(SubframeMetricsC)]
+    L.ab_analyze_subframes.argtypes = [vp, pp, C.c_size_t, C.POINTER(SubframeWeightConfigC), C.POINTER(SubframeMetricsC)]
+    L.ab_normalize_subframe_weights.argtypes = [C.POINTER(SubframeMetricsC), C.c_size_t]
+    L.ab_normalize_subframe_weights.restype = None
+    i64p = C.POINTER(C.c_int64)
+    L.ab_preview_dims.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p]
+    L.ab_render_rgb_preview.argtypes = [vp, pp, pp, pp, C.c_int64, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32]
+    L.ab_ipc_encode_with_header.argtypes = [vp, pp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_size_t)]
+    L.ab_tile_compute_num_levels.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    L.ab_tile_pyramid_layout.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.POINTER(TileLevelC), C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_size_t)]
+    L.ab_tile_downsample_2x.argtypes = [vp, pp, pp]
+    L.ab_tile_percentile_bounds.argtypes = [vp, pp, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ab_generate_tile_pyramid.argtypes = [vp, pp, C.c_int64, vp, C.c_int32, C.POINTER(TileLevelC), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ab_generate_tile_pyramid_rgb.argtypes = [vp, pp, pp, pp, C.c_int64, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32,
+                                               C.POINTER(TileLevelC), C.POINTER(C.c_int32)]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift

@@ -128,6 +128,35 @@ class AffineAlignResult:  # affine.rs:82-89
     method: str
 
 
+@dataclass
+class SubframeWeightConfig:  # subframe.rs:24-49
+    fwhm_weight: float = 1.0
+    eccentricity_weight: float = 0.5
+    snr_weight: float = 1.0
+    noise_weight: float = 0.3
+    max_fwhm: float = 8.0
+    max_eccentricity: float = 0.7
+    min_snr: float = 5.0
+    min_stars: int = 5
+
+    def _c(self):
+        return _lib.SubframeWeightConfigC(self.fwhm_weight, self.eccentricity_weight, self.snr_weight, self.noise_weight,
+                                          self.max_fwhm, self.max_eccentricity, self.min_snr, self.min_stars)
+
+
+@dataclass
+class SubframeMetrics:  # subframe.rs:9-22 (file_path stays with the caller)
+    star_count: int
+    median_fwhm: float
+    median_eccentricity: float
+    median_snr: float
+    background_median: float
+    background_sigma: float
+    noise_ratio: float
+    weight: float
+    accepted: bool
+
+
 AFFINE_METHODS = ("affine", "rigid", "phase_correlation", "identity")
 
 
@@ -396,6 +425,96 @@ class Context:
         self._check(self._L.ab_apply_stf_f32(self._h, C.byref(pi), C.byref(p), C.byref(s), C.byref(po)))
         return out
 
+    # ---- preview / tile renderers up to the PNG encoder --------------------------------
+    def _stf3(self, stf, stats):
+        if stf is None:
+            return None, None
+        return ((StfParamsC * 3)(*[StfParamsC(p.shadow, p.midtone, p.highlight) for p in stf]),
+                (_lib.ImageStatsC * 3)(*[self._stats_in(s) for s in stats]) if stats is not None else None)
+
+    def _bytes_out(self, like, shape):
+        """u8 output next to the input: a CUDA tensor for device planes, a numpy array for host planes -> (array, ptr, on_device)"""
+        if _is_torch(like):
+            out = torch.empty(shape, dtype=torch.uint8, device=like.device)
+            return out, C.c_void_p(out.data_ptr()), 1
+        out = np.empty(shape, np.uint8)
+        return out, C.c_void_p(out.ctypes.data), 0
+
+    def preview_dims(self, rows: int, cols: int, max_dim: int):
+        ph, pw = C.c_int64(), C.c_int64()
+        if self._L.ab_preview_dims(rows, cols, max_dim, C.byref(ph), C.byref(pw)) != _lib.AB_OK:
+            raise AstroBurstError(_lib.AB_ERR_INVALID, "ab_preview_dims: bad arguments")
+        return ph.value, pw.value
+
+    def render_rgb_preview(self, r, g, b, max_dim: int, stf=None, stats=None):
+        """render_rgb_preview / render_rgb (stf None) or render_rgb_preview_with_stf (stf, stats = 3 each)
+        (cmd/helpers.rs:204-322) -> (ph, pw, 3) u8"""
+        keep = []
+        pr, pg, pb = (self._plane(x, keep) for x in (r, g, b))
+        ph, pw = self.preview_dims(pr.rows, pr.cols, max_dim) if max_dim > 0 else (1, 1)
+        out, ptr, dev = self._bytes_out(r, (ph, pw, 3))
+        p, s = self._stf3(stf, stats)
+        self._check(self._L.ab_render_rgb_preview(self._h, C.byref(pr), C.byref(pg), C.byref(pb), max_dim, p, s, ptr, dev))
+        return out
+
+    def ipc_encode_with_header(self, image, max_dim: int = 0):
+        """encode_with_header / encode_with_header_downsampled (infra/ipc.rs:93-148) -> u8 buffer (header + f32 LE pixels)"""
+        keep = []
+        pi = self._plane(image, keep)
+        full = max_dim <= 0 or (pi.rows <= max_dim and pi.cols <= max_dim)
+        ph, pw = (pi.rows, pi.cols) if full else self.preview_dims(pi.rows, pi.cols, max_dim)
+        out, ptr, dev = self._bytes_out(image, (16 + 4 * ph * pw,))
+        n = C.c_size_t(0)
+        self._check(self._L.ab_ipc_encode_with_header(self._h, C.byref(pi), max_dim, ptr, dev, C.byref(n)))
+        assert n.value == out.shape[0]
+        return out
+
+    def tile_compute_num_levels(self, width: int, height: int, tile_size: int) -> int:
+        return self._L.ab_tile_compute_num_levels(width, height, tile_size)
+
+    def tile_pyramid_layout(self, rows: int, cols: int, tile_size: int, channels: int):
+        lv, n, total = (_lib.TileLevelC * _lib.MAX_TILE_LEVELS)(), C.c_int32(), C.c_size_t()
+        if self._L.ab_tile_pyramid_layout(rows, cols, tile_size, channels, lv, C.byref(n), C.byref(total)) != _lib.AB_OK:
+            raise AstroBurstError(_lib.AB_ERR_INVALID, "ab_tile_pyramid_layout: bad arguments")
+        return [{k: getattr(l, k) for k, _ in l._fields_} for l in lv[:n.value]], total.value
+
+    def tile_downsample_2x(self, image):
+        keep = []
+        pi = self._plane(image, keep)
+        out = self._new_like(image, (pi.rows + 1) // 2, (pi.cols + 1) // 2)
+        po = self._plane(out, keep) if _is_torch(out) else Plane(C.c_void_p(out.ctypes.data), out.shape[0], out.shape[1], 0)
+        self._check(self._L.ab_tile_downsample_2x(self._h, C.byref(pi), C.byref(po)))
+        return out
+
+    def tile_percentile_bounds(self, image, low_pct: float = 0.001, high_pct: float = 0.999):
+        keep = []
+        pi = self._plane(image, keep)
+        lo, hi = C.c_float(), C.c_float()
+        self._check(self._L.ab_tile_percentile_bounds(self._h, C.byref(pi), low_pct, high_pct, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def generate_tile_pyramid(self, normalized, tile_size: int = 256):
+        """generate_tile_pyramid (infra/render/tiles.rs:180-255) up to the encoder -> (packed tiles u8, levels, (gmin, gmax))"""
+        keep = []
+        pi = self._plane(normalized, keep)
+        levels, total = self.tile_pyramid_layout(pi.rows, pi.cols, tile_size, 1)
+        out, ptr, dev = self._bytes_out(normalized, (total,))
+        lv, n, lo, hi = (_lib.TileLevelC * _lib.MAX_TILE_LEVELS)(), C.c_int32(), C.c_float(), C.c_float()
+        self._check(self._L.ab_generate_tile_pyramid(self._h, C.byref(pi), tile_size, ptr, dev, lv, C.byref(n), C.byref(lo), C.byref(hi)))
+        return out, levels, (lo.value, hi.value)
+
+    def generate_tile_pyramid_rgb(self, r, g, b, tile_size: int = 256, stf=None, stats=None):
+        """generate_tile_pyramid_rgb / _rgb_stf (tiles.rs:363-481) up to the encoder -> (packed tiles u8, levels)"""
+        keep = []
+        pr, pg, pb = (self._plane(x, keep) for x in (r, g, b))
+        levels, total = self.tile_pyramid_layout(pr.rows, pr.cols, tile_size, 3)
+        out, ptr, dev = self._bytes_out(r, (total,))
+        lv, n = (_lib.TileLevelC * _lib.MAX_TILE_LEVELS)(), C.c_int32()
+        p, s = self._stf3(stf, stats)
+        self._check(self._L.ab_generate_tile_pyramid_rgb(self._h, C.byref(pr), C.byref(pg), C.byref(pb), tile_size, p, s, ptr, dev, lv,
+                                                         C.byref(n)))
+        return out, levels
+
     # ---- core/analysis/star_detection.rs, core/alignment/affine.rs ------------------------------------
     def estimate_background(self, image, tile_size: int):
         keep = []
@@ -451,6 +570,23 @@ class Context:
         self._check(self._L.ab_align_pairs_affine(self._h, C.byref(pr), planes, len(targets), num_threads, res, pouts))
         return [AffineAlignResult(tuple(r.transform), int(r.matched_stars), int(r.inliers), r.residual_px, AFFINE_METHODS[r.method])
                 for r in res[:len(targets)]]
+
+    def analyze_subframes(self, images, config: "SubframeWeightConfig | None" = None, normalize: bool = False):
+        """analyze_subframe(image, _, config) for every image (subframe.rs:51-121), frame-parallel -> [SubframeMetrics];
+        normalize=True also applies normalize_weights (:148-159)."""
+        keep = []
+        n = len(images)
+        planes = (Plane * max(n, 1))(*[self._plane(im, keep) for im in images])
+        res = (_lib.SubframeMetricsC * max(n, 1))()
+        cfg = (config or SubframeWeightConfig())._c()
+        self._check(self._L.ab_analyze_subframes(self._h, planes, n, C.byref(cfg), res))
+        if normalize:
+            self._L.ab_normalize_subframe_weights(res, n)
+        return [SubframeMetrics(int(r.star_count), r.median_fwhm, r.median_eccentricity, r.median_snr, r.background_median,
+                                r.background_sigma, r.noise_ratio, r.weight, bool(r.accepted)) for r in res[:n]]
+
+    def analyze_subframe(self, image, config: "SubframeWeightConfig | None" = None):
+        return self.analyze_subframes([image], config)[0]
 
     def affine_from_stars(self, ref_xy, tgt_xy, rows, cols, num_threads: int = 8):
         r = np.ascontiguousarray(np.asarray(ref_xy, np.float64).reshape(-1, 2))

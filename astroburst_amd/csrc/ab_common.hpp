@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -22,6 +23,7 @@ enum {
     AB_WS_DETECT_LIST,        // int[P] indices of the above-threshold pixels
     AB_WS_REGISTER,           // triangle tables / votes of the star matcher
     AB_WS_STACK_DEFER,        // per-slot pixel lists of the stacking kernel's two-pass mode
+    AB_WS_RENDER,             // the 2x-reduced levels of a tile pyramid
     AB_WS_SLOTS
 };
 
@@ -93,6 +95,11 @@ int ab_pinned(ab_ctx *ctx, size_t bytes, void **out);
 // persistent workspace `slot` of at least `bytes` (contents are undefined after a growth)
 int ab_workspace(ab_ctx *ctx, int slot, size_t bytes, void **out);
 
+// Frame-parallel fan-out: items 0..n-1 are pulled by up to ctx->register_workers host threads, each driving a child context
+// (own non-blocking stream + workspaces, cached in ctx->workers).  ctx->stream is drained first; each worker's stream is drained
+// before return.  With one worker fn runs inline on ctx.
+int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn);
+
 // RAII staging of an input plane: host planes are uploaded to a temporary device buffer.
 struct StagedPlane {
     const float *dptr = nullptr;
@@ -126,6 +133,10 @@ struct ab_plane_sel {
 };
 // count, the [count/2] element and (want_lower, even count) the [count/2 - 1] element
 int ab_plane_order_stats(ab_ctx *ctx, const ab_plane_sel &s, int want_lower, uint64_t *count_out, float *mid_out, float *lower_out);
+// the general form: ranks_of(count, ranks) fills up to max_ranks 0-based ranks (clamped to count - 1) and returns how many;
+// vals[i] = the ranks[i]-th smallest candidate.  Nothing is written to vals when there are no candidates.
+int ab_plane_select_ranks(ab_ctx *ctx, const ab_plane_sel &s, int max_ranks, const std::function<int(uint64_t, uint64_t *)> &ranks_of,
+                          uint64_t *count_out, float *vals);
 // median_f32_mut (math/median.rs:46-63) of the candidates; 0 when there are none
 int ab_plane_median_f32(ab_ctx *ctx, const ab_plane_sel &s, float *out, uint64_t *count_out);
 

@@ -2,6 +2,8 @@
 #include "ab_common.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
@@ -240,4 +242,42 @@ void ab_stage_out_abort(ab_ctx *ctx, StagedOut *o) {
         (void)hipFree(o->owned);
         o->owned = nullptr;
     }
+}
+
+int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn) {
+    const size_t workers = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1));
+    if (workers <= 1) {
+        for (size_t f = 0; f < n; ++f) AB_TRY(fn(ctx, f));
+        return AB_OK;
+    }
+    while (ctx->workers.size() < workers) {
+        ab_ctx *wc = nullptr;
+        if (ab_ctx_create(ctx->device, &wc) != AB_OK) return ab_set_error(ctx, AB_ERR_HIP, "cannot create %s worker context", what);
+        wc->register_workers = 1;
+        ctx->workers.push_back(wc);
+    }
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // whatever the caller queued on ctx (its frames, shared tables) is complete
+    std::atomic<size_t> next{0};
+    std::vector<int> rcs(workers, AB_OK);
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < workers; ++t)
+        pool.emplace_back([&, t]() {
+            ab_ctx *wc = ctx->workers[t];
+            if (hipSetDevice(wc->device) != hipSuccess) {
+                rcs[t] = AB_ERR_HIP;
+                return;
+            }
+            for (size_t f = next.fetch_add(1); f < n; f = next.fetch_add(1)) {
+                const int rc = fn(wc, f);
+                if (rc != AB_OK) {
+                    rcs[t] = rc;
+                    return;
+                }
+            }
+            if (hipStreamSynchronize(wc->stream) != hipSuccess) rcs[t] = AB_ERR_HIP;
+        });
+    for (std::thread &th : pool) th.join();
+    for (size_t t = 0; t < workers; ++t)
+        if (rcs[t] != AB_OK) return ab_set_error(ctx, rcs[t], "%s worker %zu: %s", what, t, ctx->workers[t]->err.c_str());
+    return AB_OK;
 }

@@ -650,46 +650,12 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         });
         if (nref) AB_HIP(ctx, hipMemcpy(w.ref_sorted, tris.data(), nref * sizeof(DTri), hipMemcpyHostToDevice));
     }
-    const size_t workers = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1));
-    if (workers <= 1) {
-        for (size_t f = 0; f < n; ++f) {
-            AB_TRY(register_one(ctx, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]));
-            if (aligned) AB_TRY(ab_warp_device(ctx, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]));  // pair.rs:59-61
-        }
-        return AB_OK;
-    }
-    while (ctx->workers.size() < workers) {
-        ab_ctx *wc = nullptr;
-        if (ab_ctx_create(ctx->device, &wc) != AB_OK) return ab_set_error(ctx, AB_ERR_HIP, "cannot create registration worker context");
-        wc->register_workers = 1;
-        ctx->workers.push_back(wc);
-    }
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // reference table built, and the callers' frames are complete
-    std::atomic<size_t> next{0};
-    std::vector<int> rcs(workers, AB_OK);
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < workers; ++t)
-        pool.emplace_back([&, t]() {
-            ab_ctx *wc = ctx->workers[t];
-            if (hipSetDevice(wc->device) != hipSuccess) {
-                rcs[t] = AB_ERR_HIP;
-                return;
-            }
-            for (size_t f = next.fetch_add(1); f < n; f = next.fetch_add(1)) {
-                int rc = register_one(wc, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]);
-                // the warp of this frame (f64 VALU) overlaps the other workers' latency-bound detection passes
-                if (rc == AB_OK && aligned) rc = ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]);
-                if (rc != AB_OK) {
-                    rcs[t] = rc;
-                    return;
-                }
-            }
-            if (aligned && hipStreamSynchronize(wc->stream) != hipSuccess) rcs[t] = AB_ERR_HIP;  // planes complete on return
-        });
-    for (std::thread &th : pool) th.join();
-    for (size_t t = 0; t < workers; ++t)
-        if (rcs[t] != AB_OK) return ab_set_error(ctx, rcs[t], "registration worker %zu: %s", t, ctx->workers[t]->err.c_str());
-    return AB_OK;
+    // the warp of a frame (f64 VALU) overlaps the other workers' latency-bound detection passes
+    return ab_parallel_frames(ctx, n, "registration", [&](ab_ctx *wc, size_t f) {
+        AB_TRY(register_one(wc, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]));
+        if (aligned) AB_TRY(ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]));  // pair.rs:59-61
+        return (int)AB_OK;
+    });
 }
 
 int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,

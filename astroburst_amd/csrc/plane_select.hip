@@ -75,10 +75,9 @@ uint32_t locate(const unsigned int *h, uint32_t nb, uint64_t *rank) {
 
 }  // namespace
 
-int ab_plane_order_stats(ab_ctx *ctx, const ab_plane_sel &s, int want_lower, uint64_t *count_out, float *mid_out, float *lower_out) {
+int ab_plane_select_ranks(ab_ctx *ctx, const ab_plane_sel &s, int max_ranks, const std::function<int(uint64_t, uint64_t *)> &ranks_of,
+                          uint64_t *count_out, float *vals) {
     *count_out = 0;
-    *mid_out = 0.0f;
-    if (lower_out) *lower_out = 0.0f;
     AB_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->sel_hist) AB_HIP(ctx, hipMalloc((void **)&ctx->sel_hist, 2048 * sizeof(unsigned int)));
     void *pin = nullptr;
@@ -90,25 +89,37 @@ int ab_plane_order_stats(ab_ctx *ctx, const ab_plane_sel &s, int want_lower, uin
     for (int i = 0; i < 2048; ++i) count += h0[i];
     *count_out = count;
     if (count == 0) return AB_OK;
-    const uint64_t mid = count / 2;
-    const int n_ranks = (want_lower && count % 2 == 0) ? 2 : 1;
+    std::vector<uint64_t> ranks((size_t)max_ranks);
+    const int n_ranks = std::min(max_ranks, ranks_of(count, ranks.data()));
     for (int r = 0; r < n_ranks; ++r) {
-        uint64_t rank = r == 0 ? mid : mid - 1;
+        uint64_t rank = std::min(ranks[r], count - 1);
         uint32_t val = locate(h0, 2048, &rank) << 21, mask = 0x7ffu << 21;
         AB_TRY(run_pass(ctx, s, mask, val, 10, 11, h1));
         val |= locate(h1, 2048, &rank) << 10;
         mask |= 0x7ffu << 10;
         AB_TRY(run_pass(ctx, s, mask, val, 0, 10, h2));
         val |= locate(h2, 1024, &rank);
-        float f;
-        memcpy(&f, &val, sizeof f);
-        if (r == 0) {
-            *mid_out = f;
-            if (lower_out) *lower_out = f;
-        } else {
-            *lower_out = f;
-        }
+        memcpy(&vals[r], &val, sizeof(float));
     }
+    return AB_OK;
+}
+
+int ab_plane_order_stats(ab_ctx *ctx, const ab_plane_sel &s, int want_lower, uint64_t *count_out, float *mid_out, float *lower_out) {
+    *mid_out = 0.0f;
+    if (lower_out) *lower_out = 0.0f;
+    float v[2] = {0.0f, 0.0f};
+    int got = 0;
+    AB_TRY(ab_plane_select_ranks(
+        ctx, s, 2,
+        [&](uint64_t count, uint64_t *ranks) {
+            ranks[0] = count / 2;
+            ranks[1] = count / 2 - (count > 1 ? 1 : 0);
+            return got = (want_lower && count % 2 == 0) ? 2 : 1;
+        },
+        count_out, v));
+    if (*count_out == 0) return AB_OK;
+    *mid_out = v[0];
+    if (lower_out) *lower_out = got == 2 ? v[1] : v[0];
     return AB_OK;
 }
 

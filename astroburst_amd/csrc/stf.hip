@@ -8,42 +8,11 @@
 // The per-pixel arithmetic is f64 in the reference's evaluation order, so the u8 output is
 // bit-exact against the CPU restatement.
 #include "ab_common.hpp"
+#include "stf_device.hpp"
 
 #include <cmath>
 
 namespace {
-
-constexpr float kPaddingThreshold = 1e-7f;  // types/constants.rs:6
-
-struct StfTx {  // stf.rs:60-78
-    double inv_range, dmin, shadow, inv_clip, midtone;
-};
-
-__device__ __forceinline__ bool is_valid_pixel(float v) { return __builtin_isfinite(v) && v > kPaddingThreshold; }
-
-__device__ __forceinline__ double mtf(double x, double m) {  // stf.rs:50-58
-    if (x <= 0.0) return 0.0;
-    if (x >= 1.0) return 1.0;
-    return (m - 1.0) * x / ((2.0 * m - 1.0) * x - m);
-}
-
-__device__ __forceinline__ double tx_apply(const StfTx &t, double v) {  // stf.rs:80-86
-    const double norm = (v - t.dmin) * t.inv_range;
-    double clipped = (norm - t.shadow) * t.inv_clip;
-    clipped = clipped < 0.0 ? 0.0 : (clipped > 1.0 ? 1.0 : clipped);  // f64::clamp (NaN stays NaN)
-    return mtf(clipped, t.midtone);
-}
-
-__device__ __forceinline__ unsigned char to_u8(float v, const StfTx &t) {  // stf.rs:96-100
-    if (!is_valid_pixel(v)) return 0;
-    double r = round(tx_apply(t, (double)v) * 255.0);
-    r = r < 0.0 ? 0.0 : (r > 255.0 ? 255.0 : r);
-    return (r > 0.0) ? (unsigned char)r : (unsigned char)0;  // `as u8`: NaN -> 0
-}
-
-__device__ __forceinline__ float to_f32(float v, const StfTx &t) {  // stf.rs:112-116
-    return is_valid_pixel(v) ? (float)tx_apply(t, (double)v) : 0.0f;
-}
 
 __global__ __launch_bounds__(256) void stf_u8_kernel(const float *__restrict__ in, int64_t n, StfTx t,
                                                      unsigned char *__restrict__ out) {
@@ -89,18 +58,6 @@ __global__ __launch_bounds__(256) void stf_f32_kernel(const float *in, int64_t n
 __global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
-}
-
-StfTx make_tx(const ab_stf_params *p, const ab_image_stats *st) {  // stf.rs:69-78
-    StfTx t;
-    const double range = std::fmax(st->max - st->min, 1e-30);
-    const double clip_range = std::fmax(p->highlight - p->shadow, 1e-15);
-    t.inv_range = 1.0 / range;
-    t.dmin = st->min;
-    t.shadow = p->shadow;
-    t.inv_clip = 1.0 / clip_range;
-    t.midtone = p->midtone;
-    return t;
 }
 
 inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }

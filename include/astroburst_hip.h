@@ -427,6 +427,62 @@ AB_API int ab_fits_encode_pixels(ab_ctx *ctx, const ab_plane *img, int32_t bitpi
 AB_API int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size_t n, int64_t bitpix, double bscale,
                                    double bzero, const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected);
 
+/* ---- subframe scoring, core/analysis/subframe.rs -------------------------------------------------- */
+typedef struct { /* SubframeWeightConfig (subframe.rs:24-49) */
+    double fwhm_weight, eccentricity_weight, snr_weight, noise_weight, max_fwhm, max_eccentricity, min_snr;
+    uint64_t min_stars;
+} ab_subframe_weight_config;
+typedef struct { /* the numbers of SubframeMetrics (subframe.rs:9-22); file_path stays with the caller */
+    uint64_t star_count;
+    double median_fwhm, median_eccentricity, median_snr, background_median, background_sigma, noise_ratio, weight;
+    int32_t accepted;
+} ab_subframe_metrics;
+AB_API void ab_subframe_weight_config_default(ab_subframe_weight_config *cfg);      /* Default, :36-49 */
+/* analyze_subframe(image, _, config) (subframe.rs:51-121): detect_stars(image, 4.0), medians of the finite fwhm /
+ * eccentricity / snr, noise_ratio, compute_weight (:123-146) and the accept flags.  config == NULL -> defaults. */
+AB_API int ab_analyze_subframe(ab_ctx *ctx, const ab_plane *image, const ab_subframe_weight_config *config, ab_subframe_metrics *out);
+/* the caller's loop over a night's subframes: n frames scored frame-parallel on the context's worker streams */
+AB_API int ab_analyze_subframes(ab_ctx *ctx, const ab_plane *images, size_t n, const ab_subframe_weight_config *config,
+                                ab_subframe_metrics *out);
+AB_API void ab_normalize_subframe_weights(ab_subframe_metrics *metrics, size_t n);  /* normalize_weights, :148-159 */
+
+/* ---- preview / tile renderers up to the PNG encoder ---------------------------------------------- */
+/* preview size for max_dim (cmd/helpers.rs:283-290, infra/ipc.rs:100-103): the plane's own dims when both fit */
+AB_API int ab_preview_dims(int64_t rows, int64_t cols, int64_t max_dim, int64_t *out_rows, int64_t *out_cols);
+/* render_rgb_preview (helpers.rs:204-262; == render_rgb, infra/render/rgb.rs:7-34, when the planes fit max_dim) with
+ * stf == NULL: nearest-neighbour pick, (v.clamp(0, 1) * 255.0) as u8.  render_rgb_preview_with_stf (:264-322) with
+ * stf / stats = 3 entries (R, G, B): make_stf_u8_fn(stf[c], stats[c]) (core/imaging/stf.rs:122-145) per channel.
+ * out_rgb = preview_rows x preview_cols x 3 interleaved bytes (host or device), i.e. the encoder's input. */
+AB_API int ab_render_rgb_preview(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, int64_t max_dim,
+                                 const ab_stf_params *stf, const ab_image_stats *stats, uint8_t *out_rgb, int32_t out_on_device);
+/* encode_with_header (infra/ipc.rs:93-103; max_dim == 0) / encode_with_header_downsampled (:105-148): 16-byte header
+ * (u32 width, u32 height, f32 data_min, f32 data_max, little-endian) + cleaned f32 pixels (non-finite -> 0).
+ * out holds 16 + 4 * preview_rows * preview_cols bytes; *out_len (nullable) = the length written. */
+AB_API int ab_ipc_encode_with_header(ab_ctx *ctx, const ab_plane *img, int64_t max_dim, void *out, int32_t out_on_device, size_t *out_len);
+#define AB_MAX_TILE_LEVELS 32
+typedef struct { /* TileLevel (infra/render/tiles.rs:21-29) + where the level's tiles start in the packed buffer */
+    uint64_t level, width, height, cols, rows;
+    double scale_factor;
+    uint64_t offset;
+} ab_tile_level;
+AB_API int ab_tile_compute_num_levels(int64_t width, int64_t height, int64_t tile_size);   /* tiles.rs:137-147; 0 = bad args */
+/* the pyramid's levels (level 0 = coarsest, tiles.rs:203-246) and the packed size: per level, tiles in (tile_y, tile_x)
+ * order, each tile_size x tile_size x channels bytes.  levels holds AB_MAX_TILE_LEVELS entries. */
+AB_API int ab_tile_pyramid_layout(int64_t rows, int64_t cols, int64_t tile_size, int32_t channels, ab_tile_level *levels,
+                                  int32_t *num_levels, size_t *total_bytes);
+AB_API int ab_tile_downsample_2x(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out);      /* downsample_2x, tiles.rs:41-70 */
+/* percentile_bounds (tiles.rs:149-178): order statistics of the finite pixels > 1e-7; finite min / max if there are none */
+AB_API int ab_tile_percentile_bounds(ab_ctx *ctx, const ab_plane *img, double low_pct, double high_pct, float *lo, float *hi);
+/* generate_tile_pyramid (tiles.rs:180-255) up to the encoder: percentile_bounds(0.001, 0.999), the 2x chain, and every
+ * render_tile buffer (:72-113) into `tiles` (layout above, channels = 1; zero outside the image). */
+AB_API int ab_generate_tile_pyramid(ab_ctx *ctx, const ab_plane *normalized, int64_t tile_size, uint8_t *tiles, int32_t tiles_on_device,
+                                    ab_tile_level *levels, int32_t *num_levels, float *global_min, float *global_max);
+/* generate_tile_pyramid_rgb / _rgb_stf (tiles.rs:363-481): stf == NULL -> render_tile_rgb (:257-298, rounded), else
+ * render_tile_rgb_stf (:300-341) with make_stf_u8_fn(stf[c], stats[c]); channels = 3 */
+AB_API int ab_generate_tile_pyramid_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, int64_t tile_size,
+                                        const ab_stf_params *stf, const ab_image_stats *stats, uint8_t *tiles, int32_t tiles_on_device,
+                                        ab_tile_level *levels, int32_t *num_levels);
+
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
 

@@ -267,6 +267,47 @@ void orc_fits_compute_bzero_bscale(const float *data, size_t n, double *bzero, d
 size_t orc_fits_encode_pixels(const float *data, size_t n, int32_t bitpix, double bzero, double bscale,
                               uint8_t *out);                                           /* writer.rs:82-135 */
 
+/* ---- core/analysis/subframe.rs (orc_subframe.c), SURVEY 8(f) row 3 -------------------------------- */
+typedef struct { /* SubframeWeightConfig, subframe.rs:24-49 (defaults 1.0, 0.5, 1.0, 0.3, 8.0, 0.7, 5.0, 5) */
+    double fwhm_weight, eccentricity_weight, snr_weight, noise_weight, max_fwhm, max_eccentricity, min_snr;
+    uint64_t min_stars;
+} orc_subframe_config;
+typedef struct { /* numbers of SubframeMetrics, subframe.rs:9-22 */
+    uint64_t star_count;
+    double median_fwhm, median_eccentricity, median_snr, background_median, background_sigma, noise_ratio, weight;
+    int32_t accepted;
+} orc_subframe_metrics;
+double orc_subframe_compute_weight(double fwhm, double ecc, double snr, double noise, const orc_subframe_config *c); /* :123-146 */
+void orc_subframe_from_detection(const orc_star *stars, size_t n, double bg_median, double bg_sigma, const orc_subframe_config *c,
+                                 orc_subframe_metrics *out);                           /* :62-120 */
+void orc_analyze_subframe(const float *image, size_t rows, size_t cols, const orc_subframe_config *c,
+                          orc_subframe_metrics *out);                                  /* :51-121 */
+void orc_subframe_normalize_weights(orc_subframe_metrics *m, size_t n);              /* :148-159 */
+
+/* ---- preview / tile renderers up to the PNG encoder (orc_render.c), SURVEY 8(f) row 4 ------------------ */
+typedef struct { /* TileLevel, tiles.rs:21-29, + the byte offset of the level's first tile in the packed buffer */
+    uint64_t level, width, height, cols, rows;
+    double scale_factor;
+    uint64_t offset;
+} orc_tile_level;
+void orc_preview_dims(size_t rows, size_t cols, size_t max_dim, size_t *ph, size_t *pw);       /* helpers.rs:283-290 */
+void orc_render_rgb_preview(const float *r, const float *g, const float *b, size_t rows, size_t cols, size_t max_dim,
+                            const orc_stf_params *stf, const orc_image_stats *stats, uint8_t *out); /* helpers.rs:204-322 */
+size_t orc_ipc_encode_with_header(const float *arr, size_t rows, size_t cols, size_t max_dim, uint8_t *out); /* ipc.rs:36-148 */
+size_t orc_tile_compute_num_levels(size_t width, size_t height, size_t tile_size);             /* tiles.rs:137-147 */
+void orc_tile_downsample_2x(const float *src, size_t rows, size_t cols, float *out);           /* tiles.rs:41-70 */
+void orc_tile_percentile_bounds(const float *slice, size_t n, double low_pct, double high_pct, float *lo, float *hi); /* :149-178 */
+void orc_render_tile(const float *src, size_t rows, size_t cols, size_t tx, size_t ty, size_t ts, float gmin, float gmax,
+                     uint8_t *buf);                                                            /* :72-113 */
+void orc_render_tile_rgb(const float *r, const float *g, const float *b, size_t rows, size_t cols, size_t tx, size_t ty, size_t ts,
+                         const orc_stf_params *stf, const orc_image_stats *stats, uint8_t *buf); /* :257-341 */
+size_t orc_tile_pyramid_layout(size_t rows, size_t cols, size_t ts, size_t channels, orc_tile_level *levels, size_t *num_levels);
+void orc_generate_tile_pyramid(const float *normalized, size_t rows, size_t cols, size_t ts, uint8_t *tiles, orc_tile_level *levels,
+                               size_t *num_levels, float *gmin_out, float *gmax_out);          /* :180-255 */
+void orc_generate_tile_pyramid_rgb(const float *r, const float *g, const float *b, size_t rows, size_t cols, size_t ts,
+                                   const orc_stf_params *stf, const orc_image_stats *stats, uint8_t *tiles, orc_tile_level *levels,
+                                   size_t *num_levels);                                        /* :383-481 */
+
 /* utility */
 int orc_max_threads(void);
 

@@ -1021,3 +1021,176 @@ def apply_stf_f32(image, params: StfParams, stats: ImageStats, threads=0) -> np.
     s = _stats_in(stats)
     lib().orc_apply_stf_f32(_fp(im), im.size, C.byref(p), C.byref(s), threads, _fp(out))
     return out
+
+
+# ---- subframe scoring (orc_subframe.c, core/analysis/subframe.rs) ------------------------------------------
+class _SubCfg(C.Structure):
+    _fields_ = [("fwhm_weight", C.c_double), ("eccentricity_weight", C.c_double), ("snr_weight", C.c_double),
+                ("noise_weight", C.c_double), ("max_fwhm", C.c_double), ("max_eccentricity", C.c_double),
+                ("min_snr", C.c_double), ("min_stars", C.c_uint64)]
+
+
+class _SubMetrics(C.Structure):
+    _fields_ = [("star_count", C.c_uint64), ("median_fwhm", C.c_double), ("median_eccentricity", C.c_double),
+                ("median_snr", C.c_double), ("background_median", C.c_double), ("background_sigma", C.c_double),
+                ("noise_ratio", C.c_double), ("weight", C.c_double), ("accepted", C.c_int32)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["star_count"], d["accepted"] = int(d["star_count"]), bool(d["accepted"])
+        return d
+
+
+SUBFRAME_DEFAULTS = dict(fwhm_weight=1.0, eccentricity_weight=0.5, snr_weight=1.0, noise_weight=0.3, max_fwhm=8.0,
+                         max_eccentricity=0.7, min_snr=5.0, min_stars=5)                    # subframe.rs:36-49
+
+
+def _sub_cfg(**kw):
+    d = dict(SUBFRAME_DEFAULTS)
+    d.update(kw)
+    return _SubCfg(*[d[k] for k, _ in _SubCfg._fields_])
+
+
+def subframe_compute_weight(fwhm, ecc, snr, noise, **cfg) -> float:
+    L = lib()
+    L.orc_subframe_compute_weight.restype = C.c_double
+    L.orc_subframe_compute_weight.argtypes = [C.c_double] * 4 + [C.POINTER(_SubCfg)]
+    return L.orc_subframe_compute_weight(fwhm, ecc, snr, noise, C.byref(_sub_cfg(**cfg)))
+
+
+def analyze_subframe(image, **cfg) -> dict:
+    im = _f32(image)
+    L = lib()
+    L.orc_analyze_subframe.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.POINTER(_SubCfg), C.POINTER(_SubMetrics)]
+    out = _SubMetrics()
+    L.orc_analyze_subframe(_fp(im), im.shape[0], im.shape[1], C.byref(_sub_cfg(**cfg)), C.byref(out))
+    return out.as_dict()
+
+
+def subframe_from_detection(stars, bg_median, bg_sigma, **cfg) -> dict:
+    """the metrics from a detect_stars() result; stars = [(fwhm, eccentricity, snr)]"""
+    L = lib()
+    L.orc_subframe_from_detection.argtypes = [C.POINTER(_Star), C.c_size_t, C.c_double, C.c_double, C.POINTER(_SubCfg),
+                                              C.POINTER(_SubMetrics)]
+    buf = (_Star * max(len(stars), 1))()
+    for b, (f, e, s) in zip(buf, stars):
+        b.fwhm, b.eccentricity, b.snr = f, e, s
+    out = _SubMetrics()
+    L.orc_subframe_from_detection(buf, len(stars), bg_median, bg_sigma, C.byref(_sub_cfg(**cfg)), C.byref(out))
+    return out.as_dict()
+
+
+def subframe_normalize_weights(weights):
+    L = lib()
+    L.orc_subframe_normalize_weights.argtypes = [C.POINTER(_SubMetrics), C.c_size_t]
+    buf = (_SubMetrics * max(len(weights), 1))()
+    for b, w in zip(buf, weights):
+        b.weight = w
+    L.orc_subframe_normalize_weights(buf, len(weights))
+    return [b.weight for b in buf[:len(weights)]]
+
+
+# ---- preview / tile renderers up to the PNG encoder (orc_render.c) -----------------------------------------
+class _TileLevel(C.Structure):
+    _fields_ = [("level", C.c_uint64), ("width", C.c_uint64), ("height", C.c_uint64), ("cols", C.c_uint64), ("rows", C.c_uint64),
+                ("scale_factor", C.c_double), ("offset", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def _stf3(stf, stats):
+    if stf is None:
+        return None, None
+    return ((_Stf * 3)(*[_Stf(p.shadow, p.midtone, p.highlight) for p in stf]), (_Stats * 3)(*[_stats_in(s) for s in stats]))
+
+
+def preview_dims(rows, cols, max_dim):
+    ph, pw = C.c_size_t(), C.c_size_t()
+    L = lib()
+    L.orc_preview_dims.argtypes = [C.c_size_t] * 3 + [C.POINTER(C.c_size_t)] * 2
+    L.orc_preview_dims(rows, cols, max_dim, C.byref(ph), C.byref(pw))
+    return ph.value, pw.value
+
+
+def render_rgb_preview(r, g, b, max_dim, stf=None, stats=None) -> np.ndarray:
+    r, g, b = _f32(r), _f32(g), _f32(b)
+    ph, pw = preview_dims(r.shape[0], r.shape[1], max_dim)
+    out = np.zeros((ph, pw, 3), np.uint8)
+    p, s = _stf3(stf, stats)
+    L = lib()
+    L.orc_render_rgb_preview.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_size_t] * 3 + [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_render_rgb_preview(_fp(r), _fp(g), _fp(b), r.shape[0], r.shape[1], max_dim, C.cast(p, C.c_void_p) if p else None,
+                             C.cast(s, C.c_void_p) if s else None, out.ctypes.data)
+    return out
+
+
+def ipc_encode_with_header(arr, max_dim=0) -> bytes:
+    a = _f32(arr)
+    out = np.zeros(16 + 4 * a.size, np.uint8)
+    L = lib()
+    L.orc_ipc_encode_with_header.restype = C.c_size_t
+    L.orc_ipc_encode_with_header.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+    n = L.orc_ipc_encode_with_header(_fp(a), a.shape[0], a.shape[1], max_dim, out.ctypes.data)
+    return out[:n].tobytes()
+
+
+def tile_compute_num_levels(width, height, tile_size) -> int:
+    L = lib()
+    L.orc_tile_compute_num_levels.restype = C.c_size_t
+    L.orc_tile_compute_num_levels.argtypes = [C.c_size_t] * 3
+    return L.orc_tile_compute_num_levels(width, height, tile_size)
+
+
+def tile_downsample_2x(arr) -> np.ndarray:
+    a = _f32(arr)
+    out = np.zeros(((a.shape[0] + 1) // 2, (a.shape[1] + 1) // 2), np.float32)
+    L = lib()
+    L.orc_tile_downsample_2x.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.POINTER(C.c_float)]
+    L.orc_tile_downsample_2x(_fp(a), a.shape[0], a.shape[1], _fp(out))
+    return out
+
+
+def tile_percentile_bounds(arr, low_pct=0.001, high_pct=0.999):
+    a = _f32(arr)
+    lo, hi = C.c_float(), C.c_float()
+    L = lib()
+    L.orc_tile_percentile_bounds.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_tile_percentile_bounds(_fp(a), a.size, low_pct, high_pct, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def tile_pyramid_layout(rows, cols, tile_size, channels):
+    lv, n = (_TileLevel * 64)(), C.c_size_t()
+    L = lib()
+    L.orc_tile_pyramid_layout.restype = C.c_size_t
+    L.orc_tile_pyramid_layout.argtypes = [C.c_size_t] * 4 + [C.POINTER(_TileLevel), C.POINTER(C.c_size_t)]
+    total = L.orc_tile_pyramid_layout(rows, cols, tile_size, channels, lv, C.byref(n))
+    return [l.as_dict() for l in lv[:n.value]], total
+
+
+def generate_tile_pyramid(normalized, tile_size):
+    """-> (packed tile bytes, levels, (global_min, global_max))"""
+    a = _f32(normalized)
+    levels, total = tile_pyramid_layout(a.shape[0], a.shape[1], tile_size, 1)
+    tiles = np.zeros(total, np.uint8)
+    lv, n, lo, hi = (_TileLevel * 64)(), C.c_size_t(), C.c_float(), C.c_float()
+    L = lib()
+    L.orc_generate_tile_pyramid.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.POINTER(_TileLevel),
+                                            C.POINTER(C.c_size_t), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.orc_generate_tile_pyramid(_fp(a), a.shape[0], a.shape[1], tile_size, tiles.ctypes.data, lv, C.byref(n), C.byref(lo), C.byref(hi))
+    return tiles, levels, (lo.value, hi.value)
+
+
+def generate_tile_pyramid_rgb(r, g, b, tile_size, stf=None, stats=None):
+    r, g, b = _f32(r), _f32(g), _f32(b)
+    levels, total = tile_pyramid_layout(r.shape[0], r.shape[1], tile_size, 3)
+    tiles = np.zeros(total, np.uint8)
+    lv, n = (_TileLevel * 64)(), C.c_size_t()
+    p, s = _stf3(stf, stats)
+    L = lib()
+    L.orc_generate_tile_pyramid_rgb.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_size_t] * 3 + [C.c_void_p] * 3 + [C.POINTER(_TileLevel),
+                                                                                                             C.POINTER(C.c_size_t)]
+    L.orc_generate_tile_pyramid_rgb(_fp(r), _fp(g), _fp(b), r.shape[0], r.shape[1], tile_size, C.cast(p, C.c_void_p) if p else None,
+                                    C.cast(s, C.c_void_p) if s else None, tiles.ctypes.data, lv, C.byref(n))
+    return tiles, levels
