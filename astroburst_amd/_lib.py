@@ -128,6 +128,24 @@ class SpccResultC(C.Structure):  # spcc.rs:45-56
                 ("stars_matched", C.c_uint64), ("stars_total", C.c_uint64), ("avg_color_index", C.c_double)]
 
 
+class BatchStackConfigC(C.Structure):  # calibration_pipeline.rs:20-37
+    _fields_ = [("sigma_low", C.c_float), ("sigma_high", C.c_float), ("max_iterations", C.c_uint64),
+                ("normalize_before_stack", C.c_int32)]
+
+
+class CalibrationMastersC(C.Structure):  # calibration_pipeline.rs:6-11 (NULL = None)
+    _fields_ = [("bias", C.POINTER(Plane)), ("dark", C.POINTER(Plane)), ("flat", C.POINTER(Plane))]
+
+
+class BatchChannelStatsC(C.Structure):  # calibration_pipeline.rs:65-72
+    _fields_ = [("lights_input", C.c_uint64), ("mean", C.c_double), ("stddev", C.c_double)]
+
+
+class BatchChannelInputC(C.Structure):  # calibration_pipeline.rs:13-17
+    _fields_ = [("label", C.c_char_p), ("lights", C.POINTER(Plane)), ("n_lights", C.c_size_t),
+                ("rejection_counts", C.POINTER(C.c_uint64))]
+
+
 class TileLevelC(C.Structure):  # infra/render/tiles.rs:21-29 (+ offset into the packed tile buffer)
     _fields_ = [("level", C.c_uint64), ("width", C.c_uint64), ("height", C.c_uint64), ("cols", C.c_uint64),
                 ("rows", C.c_uint64), ("scale_factor", C.c_double), ("offset", C.c_uint64)]
@@ -268,6 +286,17 @@ def lib() -> C.CDLL:
     L.ab_normalize_subframe_weights.argtypes = [C.POINTER(SubframeMetricsC), C.c_size_t]
     L.ab_normalize_subframe_weights.restype = None
     i64p = C.POINTER(C.c_int64)
+    u64p = C.POINTER(C.c_uint64)
+    L.ab_batch_stack_config_default.argtypes = [C.POINTER(BatchStackConfigC)]
+    L.ab_batch_stack_config_default.restype = None
+    L.ab_calibrate_light.argtypes = [vp, pp, C.POINTER(CalibrationMastersC), pp]
+    L.ab_normalize_frames.argtypes = [vp, pp, C.c_size_t, pp]
+    L.ab_sigma_clipped_mean_stack.argtypes = [vp, pp, C.c_size_t, C.POINTER(BatchStackConfigC), pp, u64p]
+    L.ab_run_batch_channel.argtypes = [vp, pp, C.c_size_t, C.POINTER(CalibrationMastersC), C.POINTER(BatchStackConfigC), pp, u64p,
+                                       C.POINTER(BatchChannelStatsC)]
+    L.ab_compose_rgb_from_masters.argtypes = [vp, pp, pp, pp, pp, vp, C.c_int32, i64p, i64p]
+    L.ab_run_batch_pipeline.argtypes = [vp, C.POINTER(BatchChannelInputC), C.c_size_t, C.POINTER(CalibrationMastersC),
+                                        C.POINTER(BatchStackConfigC), pp, C.POINTER(BatchChannelStatsC), vp, C.c_int32, i64p, i64p]
     L.ab_preview_dims.argtypes = [C.c_int64, C.c_int64, C.c_int64, i64p, i64p]
     L.ab_render_rgb_preview.argtypes = [vp, pp, pp, pp, C.c_int64, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32]
     L.ab_ipc_encode_with_header.argtypes = [vp, pp, C.c_int64, vp, C.c_int32, C.POINTER(C.c_size_t)]

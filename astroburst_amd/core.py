@@ -129,6 +129,36 @@ class AffineAlignResult:  # affine.rs:82-89
 
 
 @dataclass
+class BatchStackConfig:  # calibration_pipeline.rs:20-37
+    sigma_low: float = 2.5
+    sigma_high: float = 3.0
+    max_iterations: int = 5
+    normalize_before_stack: bool = True
+
+    def _c(self):
+        return _lib.BatchStackConfigC(self.sigma_low, self.sigma_high, self.max_iterations, int(self.normalize_before_stack))
+
+
+@dataclass
+class BatchChannelStats:  # calibration_pipeline.rs:65-72
+    label: str
+    lights_input: int
+    lights_after_rejection: list
+    mean: float
+    stddev: float
+
+
+@dataclass
+class BatchPipelineResult:  # calibration_pipeline.rs:51-56
+    master_channels: list          # [(label, master)]
+    rgb: object                    # (h, w, 3) f32 or None
+    channels: list                 # [BatchChannelStats]
+    darks_combined: int = 0
+    flats_combined: int = 0
+    bias_combined: int = 0
+
+
+@dataclass
 class SubframeWeightConfig:  # subframe.rs:24-49
     fwhm_weight: float = 1.0
     eccentricity_weight: float = 0.5
@@ -424,6 +454,118 @@ class Context:
         s = self._stats_in(stats)
         self._check(self._L.ab_apply_stf_f32(self._h, C.byref(pi), C.byref(p), C.byref(s), C.byref(po)))
         return out
+
+    # ---- core/imaging/calibration_pipeline.rs -------------------------------------------
+    def _masters(self, bias, dark, flat, keep):
+        m = _lib.CalibrationMastersC()
+        for name, x in (("bias", bias), ("dark", dark), ("flat", flat)):
+            if x is not None:
+                pl = self._plane(x, keep)
+                keep.append(pl)
+                setattr(m, name, C.pointer(pl))
+        return m
+
+    def _planes(self, xs, keep):
+        return (Plane * max(len(xs), 1))(*[self._plane(x, keep) for x in xs])
+
+    def calibrate_light(self, light, bias=None, dark=None, flat=None, out=None):
+        """calibrate_light (calibration_pipeline.rs:74-118)"""
+        keep = []
+        pi = self._plane(light, keep)
+        if out is None:
+            out = self._new_like(light, pi.rows, pi.cols)
+        po = self._plane(out, keep)
+        m = self._masters(bias, dark, flat, keep)
+        self._check(self._L.ab_calibrate_light(self._h, C.byref(pi), C.byref(m), C.byref(po)))
+        return out
+
+    def normalize_frames(self, frames):
+        """normalize_frames (:309-319) -> new frames"""
+        keep = []
+        outs = [self._new_like(f, f.shape[0], f.shape[1]) for f in frames]
+        self._check(self._L.ab_normalize_frames(self._h, self._planes(frames, keep), len(frames), self._planes(outs, keep)))
+        return outs
+
+    def sigma_clipped_mean_stack(self, frames, config: "BatchStackConfig | None" = None):
+        """sigma_clipped_mean_stack (:321-378) -> (stacked, rejection_counts)"""
+        keep = []
+        out = self._new_like(frames[0], frames[0].shape[0], frames[0].shape[1]) if len(frames) else None
+        rej = (C.c_uint64 * max(len(frames), 1))()
+        cfg = (config or BatchStackConfig())._c()
+        po = self._plane(out, keep) if out is not None else Plane()
+        self._check(self._L.ab_sigma_clipped_mean_stack(self._h, self._planes(frames, keep), len(frames), C.byref(cfg), C.byref(po), rej))
+        return out, list(rej[:len(frames)])
+
+    def run_batch_channel(self, lights, bias=None, dark=None, flat=None, config: "BatchStackConfig | None" = None):
+        """one channel of run_batch_pipeline (:157-190), fused -> (master, rejection_counts, mean, stddev)"""
+        keep = []
+        out = self._new_like(lights[0], lights[0].shape[0], lights[0].shape[1])
+        rej = (C.c_uint64 * max(len(lights), 1))()
+        st = _lib.BatchChannelStatsC()
+        cfg = (config or BatchStackConfig())._c()
+        m = self._masters(bias, dark, flat, keep)
+        po = self._plane(out, keep)
+        self._check(self._L.ab_run_batch_channel(self._h, self._planes(lights, keep), len(lights), C.byref(m), C.byref(cfg), C.byref(po), rej,
+                                                 C.byref(st)))
+        return out, list(rej[:len(lights)]), st.mean, st.stddev
+
+    def compose_rgb_from_masters(self, r, g, b, l=None):
+        """compose_rgb_from_masters (:201-267) -> (h, w, 3) f32"""
+        keep = []
+        pr, pg, pb = (self._plane(x, keep) for x in (r, g, b))
+        pl = self._plane(l, keep) if l is not None else None
+        h, w = min(pr.rows, pg.rows, pb.rows), min(pr.cols, pg.cols, pb.cols)
+        if _is_torch(r):
+            out = torch.empty((h, w, 3), dtype=torch.float32, device=r.device)
+            ptr, dev = C.c_void_p(out.data_ptr()), 1
+        else:
+            out = np.empty((h, w, 3), np.float32)
+            ptr, dev = C.c_void_p(out.ctypes.data), 0
+        oh, ow = C.c_int64(), C.c_int64()
+        self._check(self._L.ab_compose_rgb_from_masters(self._h, C.byref(pr), C.byref(pg), C.byref(pb), C.byref(pl) if pl is not None else None,
+                                                        ptr, dev, C.byref(oh), C.byref(ow)))
+        assert (oh.value, ow.value) == (h, w)
+        return out
+
+    def run_batch_pipeline(self, channels, bias=None, dark=None, flat=None, config: "BatchStackConfig | None" = None):
+        """run_batch_pipeline (:120-199); channels = [(label, [lights])] -> BatchPipelineResult"""
+        keep = []
+        n = len(channels)
+        cin = (_lib.BatchChannelInputC * max(n, 1))()
+        masters, rejs = [], []
+        for c, (label, lights) in enumerate(channels):
+            cin[c].label = label.encode()
+            planes = self._planes(lights, keep)
+            keep.append(planes)
+            cin[c].lights = planes if len(lights) else None
+            cin[c].n_lights = len(lights)
+            rej = (C.c_uint64 * max(len(lights), 1))()
+            rejs.append(rej)
+            cin[c].rejection_counts = rej
+            masters.append(self._new_like(lights[0], lights[0].shape[0], lights[0].shape[1]) if len(lights) else np.zeros((1, 1), np.float32))
+        pout = self._planes(masters, keep)
+        st = (_lib.BatchChannelStatsC * max(n, 1))()
+        cfg = (config or BatchStackConfig())._c()
+        m = self._masters(bias, dark, flat, keep)
+        find = {}
+        for c, (label, _) in enumerate(channels):
+            find.setdefault(label.upper(), c)
+        rgb, ptr, dev = None, None, 0
+        if n and all(k in find for k in "RGB"):
+            h = min(masters[find[k]].shape[0] for k in "RGB")
+            w = min(masters[find[k]].shape[1] for k in "RGB")
+            if _is_torch(masters[0]):
+                rgb = torch.empty((h, w, 3), dtype=torch.float32, device=masters[0].device)
+                ptr, dev = C.c_void_p(rgb.data_ptr()), 1
+            else:
+                rgb = np.empty((h, w, 3), np.float32)
+                ptr, dev = C.c_void_p(rgb.ctypes.data), 0
+        oh, ow = C.c_int64(), C.c_int64()
+        self._check(self._L.ab_run_batch_pipeline(self._h, cin, n, C.byref(m), C.byref(cfg), pout, st, ptr, dev, C.byref(oh), C.byref(ow)))
+        stats = [BatchChannelStats(channels[c][0], int(st[c].lights_input), list(rejs[c][:len(channels[c][1])]), st[c].mean, st[c].stddev)
+                 for c in range(n)]
+        return BatchPipelineResult([(channels[c][0], masters[c]) for c in range(n)], rgb, stats, int(dark is not None), int(flat is not None),
+                                   int(bias is not None))
 
     # ---- preview / tile renderers up to the PNG encoder (SURVEY 8f row 4) --------------------------------
     def _stf3(self, stf, stats):

@@ -24,6 +24,7 @@ enum {
     AB_WS_REGISTER,           // triangle tables / votes of the star matcher
     AB_WS_STACK_DEFER,        // per-slot pixel lists of the stacking kernel's two-pass mode
     AB_WS_RENDER,             // the 2x-reduced levels of a tile pyramid
+    AB_WS_BATCH_REJ,          // per-block per-frame rejection counters of the batch stack
     AB_WS_SLOTS
 };
 

@@ -1,0 +1,726 @@
+// Batch calibration pipeline on gfx950: core/imaging/calibration_pipeline.rs.
+//
+//   calibrate_light (:74-118), normalize_frames (:309-319), sigma_clipped_mean_stack (:321-378), the per-channel body
+//   of run_batch_pipeline (:157-190), normalize_channel / apply_luminance / compose_rgb_from_masters (:201-307).
+//
+// The reference materialises every calibrated frame, then every normalised frame, then stacks them: 6 full passes over
+// the light frames.  Here a channel costs TWO reads of the lights and nothing else of that size:
+//   1. cal_means_kernel   -- per-frame f64 sum of the calibrated samples (masters read once per pixel, 64 frames deep)
+//   2. scms_kernel<CAL>   -- the stack kernel re-applies bias / dark / flat / inv_mean in its gather, in the reference's
+//                            f32 operation order, so the samples it clips are bit-identical to the reference's frames.
+//
+// The clipping differs from combine.rs (stack_sigma_clip.hip): median and MAD are recomputed on EVERY iteration, the
+// z-test is strict on both sides, NaN samples take part (and are always rejected by a retain pass), rejections are
+// counted per frame, and the result is an f32 mean summed in FRAME order.  Mapping:
+//   * one lane = one pixel; its n samples stay in VGPRs in frame order (u[]) for the final frame-order sum;
+//   * a sorted copy (Batcher network, constant indices) is parked in LDS as [rank][lane] -- per-lane dynamic ranks then
+//     cost one conflict-free ds_read (bank = lane) instead of a scratch access;
+//   * survivors of every retain pass are an interval [lo, hi) of the sorted order (z is monotone in v), found by
+//     walking in from both ends with the reference's own f32 z arithmetic;
+//   * median = S[lo + len/2]; MAD = the len/2-th smallest of the two sorted deviation runs left / right of the median,
+//     by binary search on the split (<= 6 steps of two LDS reads);
+//   * the kept set is {f : S[lo] <= u_f <= S[hi-1]} (ties share their z, so they are kept or dropped together).
+// One wave per block (16 KB LDS at n = 64, ten waves per CU), persistent blocks striding over 64-pixel chunks, so the
+// per-frame rejection counters stay in a register (lane f owns frame f) until the block retires.
+#include "ab_common.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <strings.h>
+
+#define AB_CE(a, b)                         \
+    {                                       \
+        T lo_ = fminf(v[a], v[b]);          \
+        T hi_ = fmaxf(v[a], v[b]);          \
+        v[a] = lo_;                         \
+        v[b] = hi_;                         \
+    }
+#include "sortnet_gen.hpp"
+
+namespace {
+
+constexpr int kMaxFrames = 64;
+constexpr int kWave = 64;
+constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
+constexpr int kSumBlock = 256;
+
+struct Masters {  // calibrate_light's three optional planes; a null pointer = absent or of the wrong length (:87-89)
+    const float *bias, *dark, *flat;
+};
+
+struct BatchArgs {
+    const float *p[kMaxFrames];
+    float scale[kMaxFrames];  // normalize_frames' inv_mean (:313-314)
+    uint64_t scale_mask;      // bit f: frame f is scaled (its mean is > 0)
+    Masters m;
+    int n;
+    uint32_t npix;
+    float sigma_low, sigma_high;
+    int max_iter;
+    float *out;
+    unsigned long long *rej;  // [gridDim.x][64]
+};
+
+// calibrate_light's per-pixel chain (:93-113) in its f32 operation order
+struct CalPx {
+    float b, d, f;
+    bool has_b, has_d, div;
+};
+__device__ __forceinline__ CalPx cal_load(const Masters &m, uint32_t i) {
+    CalPx c;
+    c.has_b = m.bias != nullptr;
+    c.has_d = m.dark != nullptr;
+    c.b = c.has_b ? m.bias[i] : 0.0f;
+    c.d = c.has_d ? m.dark[i] : 0.0f;
+    c.f = m.flat ? m.flat[i] : 1.0f;
+    c.div = m.flat != nullptr && __builtin_isfinite(c.f) && fabsf(c.f) > 1e-4f;
+    return c;
+}
+__device__ __forceinline__ float cal_apply(float v, const CalPx &c) {
+    if (c.has_b) v -= c.b;
+    if (c.has_d) v -= c.d;
+    if (c.div) v = v / c.f;
+    return v < 0.0f ? 0.0f : v;  // NaN stays NaN
+}
+
+template <int NP, bool CAL>
+__global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
+    extern __shared__ float S_[];  // [NP][64] sorted samples of this wave's 64 pixels
+    const int lane = threadIdx.x;
+    unsigned long long mycount = 0;  // lane f: rejected samples of frame f, over every chunk of this block
+    const uint32_t nchunks = (a.npix + kWave - 1) / kWave;
+#define S(i) S_[(i) * kWave + lane]
+
+    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const uint32_t g = chunk * kWave + lane;
+        const bool valid = g < a.npix;
+        const uint32_t gi = valid ? g : a.npix - 1;
+
+        // ---- gather, frame order (:344-348) ----
+        float u[NP];
+#pragma unroll
+        for (int f = 0; f < NP; ++f) u[f] = f < a.n ? a.p[f][gi] : __builtin_inff();
+        if constexpr (CAL) {
+            const CalPx c = cal_load(a.m, gi);
+#pragma unroll
+            for (int f = 0; f < NP; ++f)
+                if (f < a.n) {
+                    float x = cal_apply(u[f], c);
+                    if ((a.scale_mask >> f) & 1) x = x * a.scale[f];
+                    u[f] = x;
+                }
+        }
+
+        // ---- sorted copy: NaN sorts last in f32_cmp (math/median.rs:4-13); it travels as +inf and is told apart by count ----
+        float v[NP];
+        int cnan = 0;
+#pragma unroll
+        for (int f = 0; f < NP; ++f) {
+            const bool isn = u[f] != u[f];
+            v[f] = isn ? __builtin_inff() : u[f];
+            cnan += isn ? 1 : 0;
+        }
+        SortNet<NP>::sort(v);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) S(i) = v[i];
+
+        // ---- the clipping loop (:350-367) on the window [lo, hi) of the sorted order ----
+        int lo = 0, hi = a.n;
+        for (int it = 0; it < a.max_iter; ++it) {
+            const int len = hi - lo;
+            if (len < 3) break;
+            const int k = len >> 1, c = lo + k;
+            float med = S(c);
+            // a NaN or infinite median makes every z NaN: the retain pass empties the pixel
+            if ((cnan > 0 && c >= a.n - cnan) || !__builtin_isfinite(med)) {
+                lo = hi = 0;
+                break;
+            }
+            const int nA = c - lo + 1, nB = hi - c - 1;  // deviation runs: A[j] = med - S[c-j], B[j] = S[c+1+j] - med
+            int i0 = max(0, k + 1 - nB), i1 = min(k + 1, nA);
+            while (i0 < i1) {
+                const int mid = (i0 + i1) >> 1, j = k + 1 - mid;
+                const float A = med - S(c - mid), B = S(c + j) - med;
+                if (A < B)
+                    i0 = mid + 1;
+                else
+                    i1 = mid;
+            }
+            const int j0 = k + 1 - i0;
+            const float ma = i0 > 0 ? med - S(c - (i0 - 1)) : -__builtin_inff();
+            const float mb = j0 > 0 ? S(c + j0) - med : -__builtin_inff();
+            float mad = fmaxf(ma, mb);
+            if (cnan > 0 && k >= len - cnan) mad = __builtin_nanf("");  // the rank falls among the NaN deviations
+            const float sigma = (float)((double)mad * kMadToSigma);
+            if (sigma < 1e-10f) break;
+            const float nsl = -a.sigma_low, sh = a.sigma_high;
+            int nlo = lo, nhi = hi;
+            while (nlo < nhi) {
+                const float z = (S(nlo) - med) / sigma;
+                if (z > nsl && z < sh) break;
+                ++nlo;
+            }
+            while (nhi > nlo) {
+                const float z = (S(nhi - 1) - med) / sigma;
+                if (z > nsl && z < sh) break;
+                --nhi;
+            }
+            cnan = 0;  // a retain pass never keeps a NaN
+            if (nlo == lo && nhi == hi) break;
+            lo = nlo;
+            hi = nhi;
+        }
+
+        // ---- frame-order f32 mean of the survivors (:369), per-frame rejection counts (:361) ----
+        const int len = hi - lo;
+        const bool all = lo == 0 && hi == a.n;
+        const float lov = len > 0 ? S(lo) : __builtin_inff(), hiv = len > 0 ? S(hi - 1) : -__builtin_inff();
+        float sum = 0.0f;
+#pragma unroll
+        for (int f = 0; f < NP; ++f)
+            if (f < a.n) {
+                const bool keep = all || (u[f] >= lov && u[f] <= hiv);
+                sum += keep ? u[f] : 0.0f;
+                const unsigned long long rejected = __ballot(valid && !keep);
+                if (lane == f) mycount += (unsigned long long)__popcll(rejected);
+            }
+        if (valid) a.out[g] = len == 0 ? 0.0f : sum / (float)len;
+    }
+#undef S
+    if (lane < kMaxFrames) a.rej[(size_t)blockIdx.x * kMaxFrames + lane] = mycount;
+}
+
+__global__ void rej_reduce_kernel(const unsigned long long *part, int blocks, unsigned long long *out) {
+    const int f = threadIdx.x;
+    unsigned long long s = 0;
+    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * kMaxFrames + f];
+    out[f] = s;
+}
+
+// per-frame f64 sums of the calibrated samples: part[block][f]
+template <int NP>
+__global__ __launch_bounds__(kSumBlock) void cal_means_kernel(const BatchArgs a, double *__restrict__ part) {
+    double acc[NP];
+#pragma unroll
+    for (int f = 0; f < NP; ++f) acc[f] = 0.0;
+    const uint32_t stride = gridDim.x * kSumBlock;
+    for (uint32_t g = blockIdx.x * kSumBlock + threadIdx.x; g < a.npix; g += stride) {
+        const CalPx c = cal_load(a.m, g);
+        float u[NP];
+#pragma unroll
+        for (int f = 0; f < NP; ++f) u[f] = f < a.n ? a.p[f][g] : 0.0f;
+#pragma unroll
+        for (int f = 0; f < NP; ++f) acc[f] += (double)cal_apply(u[f], c);
+    }
+    __shared__ double red[kSumBlock / kWave][kMaxFrames];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int f = 0; f < NP; ++f) {
+        double s = acc[f];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) red[wave][f] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NP) {
+        double s = 0.0;
+        for (int w = 0; w < kSumBlock / kWave; ++w) s += red[w][threadIdx.x];
+        part[(size_t)blockIdx.x * kMaxFrames + threadIdx.x] = s;
+    }
+}
+
+// mode 0: sum of v; mode 1: sum of (v - center)^2   (run_batch_pipeline's mean / variance, :173-179)
+__global__ __launch_bounds__(kSumBlock) void sum_f64_kernel(const float *__restrict__ data, int64_t n, int mode, double center,
+                                                            double *__restrict__ part) {
+    double s = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kSumBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kSumBlock + threadIdx.x; i < n; i += stride) {
+        const double v = (double)data[i];
+        s += mode ? (v - center) * (v - center) : v;
+    }
+    __shared__ double red[kSumBlock];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = kSumBlock / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void calibrate_kernel(const float *__restrict__ light, Masters m, uint32_t npix, float *__restrict__ out) {
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += stride) out[i] = cal_apply(light[i], cal_load(m, i));
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float *__restrict__ in, int64_t n, float k, float *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = in[i] * k;
+}
+
+// normalize_channel's scan (:293-299): `v < min` / `v > max` skip NaN and see the infinities
+__global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ src, int rows, int cols, int64_t ld, float2 *__restrict__ part) {
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    const int64_t n = (int64_t)rows * cols, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int64_t y = i / cols, x = i - y * cols;
+        const float v = src[y * ld + x];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    __shared__ float smn[256], smx[256];
+    smn[threadIdx.x] = mn;
+    smx[threadIdx.x] = mx;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) {
+            smn[threadIdx.x] = fminf(smn[threadIdx.x], smn[threadIdx.x + k]);
+            smx[threadIdx.x] = fmaxf(smx[threadIdx.x], smx[threadIdx.x + k]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = make_float2(smn[0], smx[0]);
+}
+
+struct ChanNorm {  // normalize_channel (:301-306) folded into the compose kernel
+    const float *p;
+    int64_t ld;
+    float mn, inv_range;
+    int zero;  // range < 1e-10: the channel becomes zeros
+};
+__device__ __forceinline__ float norm_px(const ChanNorm &c, int64_t y, int64_t x) {
+    if (c.zero) return 0.0f;
+    const float t = (c.p[y * c.ld + x] - c.mn) * c.inv_range;
+    return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+}
+struct ComposeArgs {
+    ChanNorm r, g, b, l;
+    int with_l;
+    int rows, cols;
+    float *out;
+};
+__global__ __launch_bounds__(256) void compose_masters_kernel(const ComposeArgs a) {  // :214-266, apply_luminance :269-289
+    const int64_t n = (int64_t)a.rows * a.cols, stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int64_t y = i / a.cols, x = i - y * a.cols;
+        float r = norm_px(a.r, y, x), g = norm_px(a.g, y, x), b = norm_px(a.b, y, x);
+        if (a.with_l) {
+            const float l = norm_px(a.l, y, x);
+            const float rgb_lum = 0.2126f * r + 0.7152f * g + 0.0722f * b;
+            const float scale = rgb_lum > 1e-10f ? l / rgb_lum : 1.0f;
+            r = r * scale;
+            g = g * scale;
+            b = b * scale;
+            r = r < 0.0f ? 0.0f : (r > 1.0f ? 1.0f : r);
+            g = g < 0.0f ? 0.0f : (g > 1.0f ? 1.0f : g);
+            b = b < 0.0f ? 0.0f : (b > 1.0f ? 1.0f : b);
+        }
+        a.out[i * 3] = r;
+        a.out[i * 3 + 1] = g;
+        a.out[i * 3 + 2] = b;
+    }
+}
+
+int cu_of(ab_ctx *ctx) { return ctx->cu_count > 0 ? ctx->cu_count : 256; }
+int np_for(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 32 ? 32 : 64)))); }
+
+template <bool CAL>
+void launch_scms(int np, int grid, hipStream_t s, const BatchArgs &a) {
+    const size_t lds = (size_t)np * kWave * sizeof(float);
+    switch (np) {
+    case 2: hipLaunchKernelGGL((scms_kernel<2, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((scms_kernel<4, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((scms_kernel<8, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 16: hipLaunchKernelGGL((scms_kernel<16, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 32: hipLaunchKernelGGL((scms_kernel<32, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    default: hipLaunchKernelGGL((scms_kernel<64, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    }
+}
+
+void launch_means(int np, int grid, hipStream_t s, const BatchArgs &a, double *part) {
+    switch (np) {
+    case 2: hipLaunchKernelGGL(cal_means_kernel<2>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
+    case 4: hipLaunchKernelGGL(cal_means_kernel<4>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
+    case 8: hipLaunchKernelGGL(cal_means_kernel<8>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
+    case 16: hipLaunchKernelGGL(cal_means_kernel<16>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
+    case 32: hipLaunchKernelGGL(cal_means_kernel<32>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
+    default: hipLaunchKernelGGL(cal_means_kernel<64>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
+    }
+}
+
+int download(ab_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, bytes, &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst, pin, bytes);
+    return AB_OK;
+}
+
+// sum (mode 0) or sum of squared deviations (mode 1) of a device plane: fixed-shape tree, partials added in block order
+int plane_sum(ab_ctx *ctx, const float *data, int64_t n, int mode, double center, double *out) {
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + kSumBlock - 1) / kSumBlock, (int64_t)cu_of(ctx) * 8));
+    void *d = nullptr;
+    AB_TRY(ab_scratch(ctx, grid * sizeof(double), &d));
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(grid), dim3(kSumBlock), 0, ctx->stream, data, n, mode, center, (double *)d);
+    AB_HIP(ctx, hipGetLastError());
+    std::vector<double> part(grid);
+    AB_TRY(download(ctx, part.data(), d, grid * sizeof(double)));
+    double s = 0.0;
+    for (double p : part) s += p;
+    *out = s;
+    return AB_OK;
+}
+
+struct StagedMasters {
+    StagedPlane p[3];
+    bool staged[3] = {false, false, false};
+    Masters m{nullptr, nullptr, nullptr};
+};
+// a master of another LENGTH is skipped, not an error (:87-89 compare slice lengths only)
+int stage_masters(ab_ctx *ctx, const ab_calibration_masters *masters, int64_t npix, StagedMasters *out) {
+    if (!masters) return AB_OK;
+    const ab_plane *src[3] = {masters->bias, masters->dark, masters->flat};
+    const float **dst[3] = {&out->m.bias, &out->m.dark, &out->m.flat};
+    for (int k = 0; k < 3; ++k) {
+        if (!src[k] || !src[k]->data || src[k]->rows * src[k]->cols != npix) continue;
+        AB_TRY(ab_stage_in(ctx, src[k], &out->p[k]));
+        out->staged[k] = true;
+        *dst[k] = out->p[k].dptr;
+    }
+    return AB_OK;
+}
+void release_masters(ab_ctx *ctx, StagedMasters *s) {
+    for (int k = 0; k < 3; ++k)
+        if (s->staged[k]) ab_stage_release(ctx, &s->p[k]);
+}
+
+ab_batch_stack_config config_or_default(const ab_batch_stack_config *cfg) {
+    ab_batch_stack_config c;
+    ab_batch_stack_config_default(&c);
+    if (cfg) c = *cfg;
+    return c;
+}
+
+// the device-resident body shared by ab_sigma_clipped_mean_stack (cal == false) and ab_run_batch_channel
+int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix, const Masters &m, bool cal, const ab_batch_stack_config &cfg,
+                 float *out, uint64_t *rejection_counts) {
+    AB_CHECK(ctx, n >= 1 && n <= (size_t)kMaxFrames, "sigma_clipped_mean_stack: %zu frames (this build stacks 1..%d)", n, kMaxFrames);
+    AB_CHECK(ctx, npix > 0 && npix < ((int64_t)1 << 30), "sigma_clipped_mean_stack: planes of 1 .. 2^30 - 1 pixels");
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    BatchArgs a;
+    memset(&a, 0, sizeof a);
+    for (size_t f = 0; f < n; ++f) a.p[f] = frames[f];
+    a.m = m;
+    a.n = (int)n;
+    a.npix = (uint32_t)npix;
+    a.sigma_low = cfg.sigma_low;
+    a.sigma_high = cfg.sigma_high;
+    a.max_iter = (int)std::min<uint64_t>(cfg.max_iterations, 1u << 20);
+    a.out = out;
+    const int np = np_for((int)n);
+    if (cal && cfg.normalize_before_stack) {  // normalize_frames (:309-319) on the calibrated samples, never materialised
+        const int grid = std::max(1, std::min<int>((int)((npix + kSumBlock - 1) / kSumBlock), cu_of(ctx) * 4));
+        void *d = nullptr;
+        AB_TRY(ab_scratch(ctx, (size_t)grid * kMaxFrames * sizeof(double), &d));
+        launch_means(np, grid, ctx->stream, a, (double *)d);
+        AB_HIP(ctx, hipGetLastError());
+        std::vector<double> part((size_t)grid * kMaxFrames);
+        AB_TRY(download(ctx, part.data(), d, part.size() * sizeof(double)));
+        for (size_t f = 0; f < n; ++f) {
+            double s = 0.0;
+            for (int b = 0; b < grid; ++b) s += part[(size_t)b * kMaxFrames + f];
+            const double mean = s / (double)npix;
+            if (mean > 0.0) {
+                a.scale[f] = 1.0f / (float)mean;
+                a.scale_mask |= (uint64_t)1 << f;
+            }
+        }
+    }
+    const uint32_t nchunks = (uint32_t)((npix + kWave - 1) / kWave);
+    const int grid = (int)std::min<uint32_t>(nchunks, (uint32_t)cu_of(ctx) * 10);
+    void *rej = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)grid + 1) * kMaxFrames * sizeof(unsigned long long), &rej));
+    a.rej = (unsigned long long *)rej;
+    if (cal)
+        launch_scms<true>(np, grid, ctx->stream, a);
+    else
+        launch_scms<false>(np, grid, ctx->stream, a);
+    AB_HIP(ctx, hipGetLastError());
+    unsigned long long *total = a.rej + (size_t)grid * kMaxFrames;
+    hipLaunchKernelGGL(rej_reduce_kernel, dim3(1), dim3(kMaxFrames), 0, ctx->stream, a.rej, grid, total);
+    AB_HIP(ctx, hipGetLastError());
+    unsigned long long host[kMaxFrames];
+    AB_TRY(download(ctx, host, total, sizeof host));
+    if (rejection_counts)
+        for (size_t f = 0; f < n; ++f) rejection_counts[f] = host[f];
+    return AB_OK;
+}
+
+int check_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, const char *what) {
+    AB_CHECK(ctx, frames && n > 0, "%s: no frames", what);
+    for (size_t i = 0; i < n; ++i) {
+        AB_CHECK(ctx, frames[i].data && frames[i].rows > 0 && frames[i].cols > 0, "%s: frame %zu is null or has a zero dimension", what, i);
+        AB_CHECK(ctx, frames[i].rows == frames[0].rows && frames[i].cols == frames[0].cols,
+                 "%s: frame %zu has shape (%lld, %lld) but frame 0 has (%lld, %lld). All frames must match.", what, i, (long long)frames[i].rows,
+                 (long long)frames[i].cols, (long long)frames[0].rows, (long long)frames[0].cols);
+    }
+    return AB_OK;
+}
+
+struct StagedFrames {
+    std::vector<StagedPlane> st;
+    std::vector<const float *> ptr;
+    size_t staged = 0;
+};
+int stage_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, StagedFrames *s) {
+    s->st.resize(n);
+    s->ptr.resize(n);
+    for (; s->staged < n; ++s->staged) {
+        AB_TRY(ab_stage_in(ctx, &frames[s->staged], &s->st[s->staged]));
+        s->ptr[s->staged] = s->st[s->staged].dptr;
+    }
+    return AB_OK;
+}
+void release_frames(ab_ctx *ctx, StagedFrames *s) {
+    for (size_t i = 0; i < s->staged; ++i) ab_stage_release(ctx, &s->st[i]);
+}
+
+int channel_minmax(ab_ctx *ctx, const float *p, int rows, int cols, int64_t ld, ChanNorm *c) {
+    const int64_t n = (int64_t)rows * cols;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)cu_of(ctx) * 8));
+    void *d = nullptr;
+    AB_TRY(ab_scratch(ctx, grid * sizeof(float2), &d));
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, ctx->stream, p, rows, cols, ld, (float2 *)d);
+    AB_HIP(ctx, hipGetLastError());
+    std::vector<float2> part(grid);
+    AB_TRY(download(ctx, part.data(), d, grid * sizeof(float2)));
+    float mn = INFINITY, mx = -INFINITY;
+    for (const float2 &q : part) {
+        mn = q.x < mn ? q.x : mn;
+        mx = q.y > mx ? q.y : mx;
+    }
+    const float range = mx - mn;
+    c->p = p;
+    c->ld = ld;
+    c->mn = mn;
+    c->zero = range < 1e-10f;  // NaN range (no comparable sample, or inf - inf) is not < 1e-10: the map then yields NaN, as the reference's
+    c->inv_range = 1.0f / range;
+    return AB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void ab_batch_stack_config_default(ab_batch_stack_config *cfg) {  // calibration_pipeline.rs:28-37
+    if (!cfg) return;
+    cfg->sigma_low = 2.5f;
+    cfg->sigma_high = 3.0f;
+    cfg->max_iterations = 5;
+    cfg->normalize_before_stack = 1;
+}
+
+int ab_calibrate_light(ab_ctx *ctx, const ab_plane *light, const ab_calibration_masters *masters, ab_plane_mut *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, light && out && out->rows == light->rows && out->cols == light->cols, "null plane or mismatched dims");
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, light, &in));
+    const int64_t npix = in.rows * in.cols;
+    StagedMasters sm;
+    int rc = npix < ((int64_t)1 << 32) ? AB_OK : ab_set_error(ctx, AB_ERR_INVALID, "calibrate_light: planes of less than 2^32 pixels");
+    if (rc == AB_OK) rc = stage_masters(ctx, masters, npix, &sm);
+    StagedOut so;
+    if (rc == AB_OK) rc = ab_stage_out_begin(ctx, out, &so);
+    if (rc == AB_OK) {
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((npix + 255) / 256, (int64_t)cu_of(ctx) * 16));
+        hipLaunchKernelGGL(calibrate_kernel, dim3(grid), dim3(256), 0, ctx->stream, in.dptr, sm.m, (uint32_t)npix, so.dptr);
+        if (hipGetLastError() != hipSuccess) {
+            ab_stage_out_abort(ctx, &so);
+            rc = ab_set_error(ctx, AB_ERR_HIP, "calibrate_light launch failed");
+        } else {
+            rc = ab_stage_out_finish(ctx, &so);
+        }
+    }
+    release_masters(ctx, &sm);
+    ab_stage_release(ctx, &in);
+    return rc;
+}
+
+int ab_normalize_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, ab_plane_mut *outs) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, (frames && outs) || n == 0, "null argument");
+    for (size_t f = 0; f < n; ++f) {
+        AB_CHECK(ctx, outs[f].rows == frames[f].rows && outs[f].cols == frames[f].cols, "normalize_frames: output %zu differs from its frame's dims", f);
+        StagedPlane in;
+        AB_TRY(ab_stage_in(ctx, &frames[f], &in));
+        const int64_t npix = in.rows * in.cols;
+        double s = 0.0;
+        int rc = plane_sum(ctx, in.dptr, npix, 0, 0.0, &s);
+        StagedOut so;
+        if (rc == AB_OK) rc = ab_stage_out_begin(ctx, &outs[f], &so);
+        if (rc == AB_OK) {
+            const double mean = s / (double)npix;
+            const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((npix + 255) / 256, (int64_t)cu_of(ctx) * 16));
+            if (mean > 0.0)
+                hipLaunchKernelGGL(scale_kernel, dim3(grid), dim3(256), 0, ctx->stream, in.dptr, npix, 1.0f / (float)mean, so.dptr);
+            else if (so.dptr != in.dptr)  // frame.clone()
+                (void)hipMemcpyAsync(so.dptr, in.dptr, (size_t)npix * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream);
+            if (hipGetLastError() != hipSuccess) {
+                ab_stage_out_abort(ctx, &so);
+                rc = ab_set_error(ctx, AB_ERR_HIP, "normalize_frames launch failed");
+            } else {
+                rc = ab_stage_out_finish(ctx, &so);
+            }
+        }
+        ab_stage_release(ctx, &in);
+        if (rc != AB_OK) return rc;
+    }
+    return AB_OK;
+}
+
+int ab_sigma_clipped_mean_stack(ab_ctx *ctx, const ab_plane *frames, size_t n, const ab_batch_stack_config *config, ab_plane_mut *out,
+                                uint64_t *rejection_counts) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, out, "null argument");
+    AB_TRY(check_frames(ctx, frames, n, "sigma_clipped_mean_stack"));
+    AB_CHECK(ctx, out->rows == frames[0].rows && out->cols == frames[0].cols, "sigma_clipped_mean_stack: the output differs from the frames' dims");
+    const ab_batch_stack_config cfg = config_or_default(config);
+    StagedFrames sf;
+    int rc = stage_frames(ctx, frames, n, &sf);
+    StagedOut so;
+    if (rc == AB_OK) rc = ab_stage_out_begin(ctx, out, &so);
+    if (rc == AB_OK) {
+        rc = stack_device(ctx, sf.ptr.data(), n, frames[0].rows * frames[0].cols, Masters{nullptr, nullptr, nullptr}, false, cfg, so.dptr, rejection_counts);
+        if (rc == AB_OK)
+            rc = ab_stage_out_finish(ctx, &so);
+        else
+            ab_stage_out_abort(ctx, &so);
+    }
+    release_frames(ctx, &sf);
+    return rc;
+}
+
+int ab_run_batch_channel(ab_ctx *ctx, const ab_plane *lights, size_t n, const ab_calibration_masters *masters, const ab_batch_stack_config *config,
+                         ab_plane_mut *out_master, uint64_t *rejection_counts, ab_batch_channel_stats *stats) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, out_master, "null argument");
+    AB_TRY(check_frames(ctx, lights, n, "run_batch_pipeline"));
+    AB_CHECK(ctx, out_master->rows == lights[0].rows && out_master->cols == lights[0].cols, "run_batch_pipeline: the master differs from the lights' dims");
+    const ab_batch_stack_config cfg = config_or_default(config);
+    const int64_t npix = lights[0].rows * lights[0].cols;
+    StagedFrames sf;
+    StagedMasters sm;
+    int rc = stage_frames(ctx, lights, n, &sf);
+    if (rc == AB_OK) rc = stage_masters(ctx, masters, npix, &sm);
+    StagedOut so;
+    if (rc == AB_OK) rc = ab_stage_out_begin(ctx, out_master, &so);
+    if (rc == AB_OK) {
+        rc = stack_device(ctx, sf.ptr.data(), n, npix, sm.m, true, cfg, so.dptr, rejection_counts);
+        double s = 0.0, q = 0.0;
+        if (rc == AB_OK && stats) {  // :173-179
+            rc = plane_sum(ctx, so.dptr, npix, 0, 0.0, &s);
+            if (rc == AB_OK) rc = plane_sum(ctx, so.dptr, npix, 1, s / (double)npix, &q);
+            if (rc == AB_OK) {
+                stats->lights_input = n;
+                stats->mean = s / (double)npix;
+                stats->stddev = std::sqrt(q / (double)npix);
+            }
+        }
+        if (rc == AB_OK)
+            rc = ab_stage_out_finish(ctx, &so);
+        else
+            ab_stage_out_abort(ctx, &so);
+    }
+    release_masters(ctx, &sm);
+    release_frames(ctx, &sf);
+    return rc;
+}
+
+int ab_compose_rgb_from_masters(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, const ab_plane *l, float *out_rgb,
+                                int32_t out_on_device, int64_t *out_rows, int64_t *out_cols) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, r && g && b && r->data && g->data && b->data, "null argument");
+    AB_CHECK(ctx, r->rows > 0 && r->cols > 0 && g->rows > 0 && g->cols > 0 && b->rows > 0 && b->cols > 0, "a master has a zero dimension");
+    const bool same = g->rows == r->rows && g->cols == r->cols && b->rows == r->rows && b->cols == r->cols;
+    const int64_t h = std::min(r->rows, std::min(g->rows, b->rows)), w = std::min(r->cols, std::min(g->cols, b->cols));  // :211-213
+    if (out_rows) *out_rows = h;
+    if (out_cols) *out_cols = w;
+    if (!out_rgb) return AB_OK;  // size query
+    const bool with_l = same && l && l->data && l->rows == h && l->cols == w;  // :237-238
+    const ab_plane *src[4] = {r, g, b, l};
+    StagedPlane st[4];
+    int staged = 0, rc = AB_OK;
+    ComposeArgs a;
+    memset(&a, 0, sizeof a);
+    ChanNorm *cn[4] = {&a.r, &a.g, &a.b, &a.l};
+    for (int c = 0; c < (with_l ? 4 : 3) && rc == AB_OK; ++c) {
+        rc = ab_stage_in(ctx, src[c], &st[c]);
+        if (rc != AB_OK) break;
+        ++staged;
+        rc = channel_minmax(ctx, st[c].dptr, (int)h, (int)w, src[c]->cols, cn[c]);
+    }
+    float *dout = out_rgb;
+    void *owned = nullptr;
+    const size_t bytes = (size_t)(h * w) * 3 * sizeof(float);
+    if (rc == AB_OK && !out_on_device) {
+        if (hipMalloc(&owned, bytes) != hipSuccess) rc = ab_set_error(ctx, AB_ERR_HIP, "cannot allocate the RGB cube");
+        dout = (float *)owned;
+    }
+    if (rc == AB_OK) {
+        a.with_l = with_l;
+        a.rows = (int)h;
+        a.cols = (int)w;
+        a.out = dout;
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((h * w + 255) / 256, (int64_t)cu_of(ctx) * 16));
+        hipLaunchKernelGGL(compose_masters_kernel, dim3(grid), dim3(256), 0, ctx->stream, a);
+        if (hipGetLastError() != hipSuccess) rc = ab_set_error(ctx, AB_ERR_HIP, "compose_rgb_from_masters launch failed");
+        if (rc == AB_OK && owned &&
+            (hipMemcpyAsync(out_rgb, owned, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess))
+            rc = ab_set_error(ctx, AB_ERR_HIP, "download of the RGB cube failed");
+    }
+    if (owned) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(owned);
+    }
+    for (int c = 0; c < staged; ++c) ab_stage_release(ctx, &st[c]);
+    return rc;
+}
+
+int ab_run_batch_pipeline(ab_ctx *ctx, const ab_batch_channel_input *channels, size_t n_channels, const ab_calibration_masters *masters,
+                          const ab_batch_stack_config *config, ab_plane_mut *out_masters, ab_batch_channel_stats *stats, float *out_rgb,
+                          int32_t rgb_on_device, int64_t *rgb_rows, int64_t *rgb_cols) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, channels && n_channels > 0, "No channels provided");  // :125-127
+    AB_CHECK(ctx, out_masters, "null argument");
+    for (size_t c = 0; c < n_channels; ++c) {  // :129-142
+        const char *label = channels[c].label ? channels[c].label : "";
+        AB_CHECK(ctx, channels[c].lights && channels[c].n_lights > 0, "Channel '%s' has no lights", label);
+        for (size_t i = 1; i < channels[c].n_lights; ++i)
+            AB_CHECK(ctx, channels[c].lights[i].rows == channels[c].lights[0].rows && channels[c].lights[i].cols == channels[c].lights[0].cols,
+                     "Channel '%s': frame %zu has shape (%lld, %lld) but frame 0 has (%lld, %lld). All frames must match.", label, i,
+                     (long long)channels[c].lights[i].rows, (long long)channels[c].lights[i].cols, (long long)channels[c].lights[0].rows,
+                     (long long)channels[c].lights[0].cols);
+    }
+    for (size_t c = 0; c < n_channels; ++c)
+        AB_TRY(ab_run_batch_channel(ctx, channels[c].lights, channels[c].n_lights, masters, config, &out_masters[c], channels[c].rejection_counts,
+                                    stats ? &stats[c] : nullptr));
+    // compose_rgb_from_masters (:201-207): the first master labelled R / G / B (and L), ASCII case-insensitive
+    auto find = [&](const char *want) -> const ab_plane_mut * {
+        for (size_t c = 0; c < n_channels; ++c)
+            if (channels[c].label && strcasecmp(channels[c].label, want) == 0) return &out_masters[c];
+        return nullptr;
+    };
+    const ab_plane_mut *m[4] = {find("R"), find("G"), find("B"), find("L")};
+    if (rgb_rows) *rgb_rows = 0;
+    if (rgb_cols) *rgb_cols = 0;
+    if (!m[0] || !m[1] || !m[2]) return AB_OK;  // rgb = None
+    ab_plane in[4];
+    for (int k = 0; k < 4; ++k)
+        if (m[k]) in[k] = ab_plane{m[k]->data, m[k]->rows, m[k]->cols, m[k]->on_device};
+    return ab_compose_rgb_from_masters(ctx, &in[0], &in[1], &in[2], m[3] ? &in[3] : nullptr, out_rgb, rgb_on_device, rgb_rows, rgb_cols);
+}
+
+}  // extern "C"

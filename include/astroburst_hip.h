@@ -427,6 +427,56 @@ AB_API int ab_fits_encode_pixels(ab_ctx *ctx, const ab_plane *img, int32_t bitpi
 AB_API int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size_t n, int64_t bitpix, double bscale,
                                    double bzero, const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected);
 
+/* ---- batch calibration pipeline, core/imaging/calibration_pipeline.rs ------------------------------- */
+typedef struct { /* BatchStackConfig (:20-37); defaults 2.5, 3.0, 5, true */
+    float sigma_low, sigma_high;
+    uint64_t max_iterations;
+    int32_t normalize_before_stack; /* bool */
+} ab_batch_stack_config;
+typedef struct { /* CalibrationMasters (:6-11); NULL = None.  A master whose rows * cols differs from the light's is skipped (:87-89) */
+    const ab_plane *bias, *dark, *flat;
+} ab_calibration_masters;
+typedef struct { /* BatchChannelStats (:65-72) without the label; lights_after_rejection is the rejection_counts array */
+    uint64_t lights_input;
+    double mean, stddev;
+} ab_batch_channel_stats;
+typedef struct { /* ChannelInput (:13-17) + where the channel's per-frame rejection counts go (n_lights entries, nullable) */
+    const char *label;
+    const ab_plane *lights;
+    size_t n_lights;
+    uint64_t *rejection_counts;
+} ab_batch_channel_input;
+AB_API void ab_batch_stack_config_default(ab_batch_stack_config *cfg);
+/* calibrate_light (:74-118): ((light - bias) - dark) / flat where flat is finite and |flat| > 1e-4, negatives -> 0 */
+AB_API int ab_calibrate_light(ab_ctx *ctx, const ab_plane *light, const ab_calibration_masters *masters, ab_plane_mut *out);
+/* normalize_frames (:309-319): frame * (1 / (mean as f32)) where the f64 mean is > 0, else a copy.  outs[i] may alias frames[i].
+ * The f64 mean is a fixed-shape tree sum (the reference's is sequential): equal to ~1e-13 relative. */
+AB_API int ab_normalize_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, ab_plane_mut *outs);
+/* sigma_clipped_mean_stack (:321-378): per pixel, up to max_iterations passes of { median, MAD -> sigma = 1.4826 MAD (f32);
+ * stop if sigma < 1e-10; keep -sigma_low < (v - median) / sigma < sigma_high }, NaN samples included and rejected by the
+ * first pass; result = f32 sum of the survivors in frame order / count (0 if none).  rejection_counts[f] (nullable) =
+ * samples of frame f rejected over the whole image.  1 <= n <= 64 frames of identical dims.  Bit-exact. */
+AB_API int ab_sigma_clipped_mean_stack(ab_ctx *ctx, const ab_plane *frames, size_t n, const ab_batch_stack_config *config, ab_plane_mut *out,
+                                       uint64_t *rejection_counts);
+/* one channel of run_batch_pipeline (:157-190): calibrate_light on every light, normalize_frames (if configured),
+ * sigma_clipped_mean_stack, mean / stddev of the master.  Fused: the lights are read twice (frame means, stack) and no
+ * calibrated or normalised frame is ever written; the stacked samples are bit-identical to the reference's. */
+AB_API int ab_run_batch_channel(ab_ctx *ctx, const ab_plane *lights, size_t n, const ab_calibration_masters *masters,
+                                const ab_batch_stack_config *config, ab_plane_mut *out_master, uint64_t *rejection_counts,
+                                ab_batch_channel_stats *stats);
+/* compose_rgb_from_masters (:201-267) for the R, G, B (and optional L) masters: normalize_channel (:291-307) on the common
+ * top-left crop, apply_luminance (:269-289) when all four share their dims; out_rgb = rows x cols x 3 interleaved f32
+ * (Array3), host or device.  out_rgb == NULL only reports the dims. */
+AB_API int ab_compose_rgb_from_masters(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, const ab_plane *l,
+                                       float *out_rgb, int32_t out_on_device, int64_t *out_rows, int64_t *out_cols);
+/* run_batch_pipeline (:120-199): validation with the reference's messages, every channel through ab_run_batch_channel into
+ * out_masters[c] (dims of the channel's lights), stats[c] (nullable), then compose_rgb_from_masters when channels labelled
+ * R, G and B exist (ASCII case-insensitive): out_rgb must then hold min-rows x min-cols x 3 floats; *rgb_rows = 0 = None. */
+AB_API int ab_run_batch_pipeline(ab_ctx *ctx, const ab_batch_channel_input *channels, size_t n_channels,
+                                 const ab_calibration_masters *masters, const ab_batch_stack_config *config, ab_plane_mut *out_masters,
+                                 ab_batch_channel_stats *stats, float *out_rgb, int32_t rgb_on_device, int64_t *rgb_rows,
+                                 int64_t *rgb_cols);
+
 /* ---- subframe scoring, core/analysis/subframe.rs -------------------------------------------------- */
 typedef struct { /* SubframeWeightConfig (subframe.rs:24-49) */
     double fwhm_weight, eccentricity_weight, snr_weight, noise_weight, max_fwhm, max_eccentricity, min_snr;

@@ -308,6 +308,20 @@ void orc_generate_tile_pyramid_rgb(const float *r, const float *g, const float *
                                    const orc_stf_params *stf, const orc_image_stats *stats, uint8_t *tiles, orc_tile_level *levels,
                                    size_t *num_levels);                                        /* :383-481 */
 
+/* ---- core/imaging/calibration_pipeline.rs (orc_batch.c); the reference has no tests here ---- */
+void orc_calibrate_light(const float *light, size_t npix, const float *bias, size_t bias_len, const float *dark, size_t dark_len,
+                         const float *flat, size_t flat_len, float *out);                      /* :74-118 */
+void orc_normalize_frame(const float *frame, size_t npix, float *out);                         /* :309-319 */
+void orc_sigma_clipped_mean_stack(const float *const *frames, size_t n, size_t npix, float sigma_low, float sigma_high, size_t max_iter,
+                                  float *out, uint64_t *rejection_counts);                     /* :321-378 */
+void orc_run_batch_channel(const float *const *lights, size_t n, size_t npix, const float *bias, size_t bias_len, const float *dark,
+                           size_t dark_len, const float *flat, size_t flat_len, float sigma_low, float sigma_high, size_t max_iter,
+                           int normalize, float *out, uint64_t *rejection_counts, double *mean_out, double *stddev_out); /* :157-190 */
+void orc_normalize_channel(const float *ch, size_t rows, size_t cols, size_t ld, float *out);  /* :291-307 */
+void orc_compose_rgb_from_masters(const float *r, size_t r_rows, size_t r_cols, const float *g, size_t g_rows, size_t g_cols,
+                                  const float *b, size_t b_rows, size_t b_cols, const float *l, size_t l_rows, size_t l_cols,
+                                  float *out, size_t *out_rows, size_t *out_cols);             /* :201-289 */
+
 /* utility */
 int orc_max_threads(void);
 

@@ -1194,3 +1194,84 @@ def generate_tile_pyramid_rgb(r, g, b, tile_size, stf=None, stats=None):
     L.orc_generate_tile_pyramid_rgb(_fp(r), _fp(g), _fp(b), r.shape[0], r.shape[1], tile_size, C.cast(p, C.c_void_p) if p else None,
                                     C.cast(s, C.c_void_p) if s else None, tiles.ctypes.data, lv, C.byref(n))
     return tiles, levels
+
+
+# ---- batch calibration pipeline (orc_batch.c, core/imaging/calibration_pipeline.rs) -------------------------
+def _opt(a):
+    if a is None:
+        return None, 0, None
+    x = _f32(a)
+    return _fp(x), x.size, x
+
+
+def calibrate_light(light, bias=None, dark=None, flat=None) -> np.ndarray:
+    im = _f32(light)
+    out = np.zeros_like(im)
+    (bp, bl, _b), (dp, dl, _d), (fp_, fl, _f) = _opt(bias), _opt(dark), _opt(flat)
+    L = lib()
+    F = C.POINTER(C.c_float)
+    L.orc_calibrate_light.argtypes = [F, C.c_size_t, F, C.c_size_t, F, C.c_size_t, F, C.c_size_t, F]
+    L.orc_calibrate_light(_fp(im), im.size, bp, bl, dp, dl, fp_, fl, _fp(out))
+    return out
+
+
+def normalize_frames(frames):
+    out = []
+    L = lib()
+    L.orc_normalize_frame.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.POINTER(C.c_float)]
+    for fr in frames:
+        im = _f32(fr)
+        o = np.zeros_like(im)
+        L.orc_normalize_frame(_fp(im), im.size, _fp(o))
+        out.append(o)
+    return out
+
+
+def _frame_ptrs(frames):
+    ims = [_f32(f) for f in frames]
+    return ims, (C.POINTER(C.c_float) * len(ims))(*[_fp(i) for i in ims])
+
+
+def sigma_clipped_mean_stack(frames, sigma_low=2.5, sigma_high=3.0, max_iterations=5):
+    """-> (stacked, rejection_counts)"""
+    ims, ptrs = _frame_ptrs(frames)
+    out = np.zeros_like(ims[0])
+    rej = (C.c_uint64 * len(ims))()
+    L = lib()
+    L.orc_sigma_clipped_mean_stack.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_size_t, C.POINTER(C.c_float),
+                                               C.POINTER(C.c_uint64)]
+    L.orc_sigma_clipped_mean_stack(ptrs, len(ims), ims[0].size, sigma_low, sigma_high, max_iterations, _fp(out), rej)
+    return out, list(rej)
+
+
+def run_batch_channel(lights, bias=None, dark=None, flat=None, sigma_low=2.5, sigma_high=3.0, max_iterations=5, normalize=True):
+    """-> (master, rejection_counts, mean, stddev)"""
+    ims, ptrs = _frame_ptrs(lights)
+    out = np.zeros_like(ims[0])
+    rej = (C.c_uint64 * len(ims))()
+    (bp, bl, _b), (dp, dl, _d), (fp_, fl, _f) = _opt(bias), _opt(dark), _opt(flat)
+    mean, std = C.c_double(), C.c_double()
+    L = lib()
+    F = C.POINTER(C.c_float)
+    L.orc_run_batch_channel.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, F, C.c_size_t, F, C.c_size_t, F, C.c_size_t, C.c_float, C.c_float,
+                                        C.c_size_t, C.c_int, F, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_run_batch_channel(ptrs, len(ims), ims[0].size, bp, bl, dp, dl, fp_, fl, sigma_low, sigma_high, max_iterations, int(normalize),
+                            _fp(out), rej, C.byref(mean), C.byref(std))
+    return out, list(rej), mean.value, std.value
+
+
+def compose_rgb_from_masters(r, g, b, l=None) -> np.ndarray:
+    r, g, b = _f32(r), _f32(g), _f32(b)
+    h = min(r.shape[0], g.shape[0], b.shape[0])
+    w = min(r.shape[1], g.shape[1], b.shape[1])
+    out = np.zeros((h, w, 3), np.float32)
+    (lp, _n, lk) = _opt(l)
+    oh, ow = C.c_size_t(), C.c_size_t()
+    L = lib()
+    F = C.POINTER(C.c_float)
+    L.orc_compose_rgb_from_masters.argtypes = [F, C.c_size_t, C.c_size_t] * 4 + [F, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.orc_compose_rgb_from_masters(_fp(r), r.shape[0], r.shape[1], _fp(g), g.shape[0], g.shape[1], _fp(b), b.shape[0], b.shape[1], lp,
+                                   lk.shape[0] if lk is not None else 0, lk.shape[1] if lk is not None else 0, _fp(out),
+                                   C.byref(oh), C.byref(ow))
+    assert (oh.value, ow.value) == (h, w)
+    return out
