@@ -52,15 +52,14 @@ struct Masters {  // calibrate_light's three optional planes; a null pointer = a
 
 struct BatchArgs {
     const float *p[kMaxFrames];
-    float scale[kMaxFrames];  // normalize_frames' inv_mean (:313-314)
-    uint64_t scale_mask;      // bit f: frame f is scaled (its mean is > 0)
+    float scale[kMaxFrames];  // normalize_frames' inv_mean (:313-314); 1 where the mean is <= 0 or NaN (x * 1.0f == x bit for bit)
     Masters m;
     int n;
     uint32_t npix;
     float sigma_low, sigma_high;
     int max_iter;
     float *out;
-    unsigned long long *rej;  // [gridDim.x][64]
+    uint32_t *rej;  // [gridDim.x][64]
 };
 
 // calibrate_light's per-pixel chain (:93-113) in its f32 operation order
@@ -85,42 +84,83 @@ __device__ __forceinline__ float cal_apply(float v, const CalPx &c) {
     return v < 0.0f ? 0.0f : v;  // NaN stays NaN
 }
 
-template <int NP, bool CAL>
+// The plane pointers and frame scales live in VGPRs, one frame per lane (64 uniform pointers would overflow the SGPR file
+// and get spilled lane by lane); each load pulls its base out with two v_readlane into a buffer descriptor and issues
+// `buffer_load_dword v, voffset, s[rsrc], 0 offen` -- no 64-bit address arithmetic, no flat-address aperture check.
+template <int NP>
+__device__ __forceinline__ void gather(float (&u)[NP], uint32_t plo, uint32_t phi, uint32_t gi, uint32_t plane_bytes) {
+    const uint32_t off = gi * 4u;  // < 2^32: planes hold fewer than 2^30 pixels
+    // opaque to loop-invariant code motion: hoisted out of the chunk loop, the 64 bases would be spilled right back
+    asm volatile("" : "+v"(plo), "+v"(phi));
+#pragma unroll
+    for (int f = 0; f < NP; ++f) {  // slots past n alias frame 0 (an L2 hit) and are overwritten with the +inf pad
+        const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, f) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)plo, f);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)plane_bytes, 0x00020000);
+        u[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
+    }
+}
+
+// FULL: n == NP.  Otherwise every `f < n` is evaluated against a per-chunk VGPR copy of n: as uniform scalar conditions
+// the 64 of them are hoisted out of the chunk loop as 64-bit lane masks and spill the SGPR file.
+template <int NP, bool CAL, bool FULL>
 __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
     extern __shared__ float S_[];  // [NP][64] sorted samples of this wave's 64 pixels
     const int lane = threadIdx.x;
-    unsigned long long mycount = 0;  // lane f: rejected samples of frame f, over every chunk of this block
+    uint32_t mycount = 0;  // lane f: rejected samples of frame f, over every chunk of this block (< 2^30 per block)
     const uint32_t nchunks = (a.npix + kWave - 1) / kWave;
 #define S(i) S_[(i) * kWave + lane]
+    const uint64_t myptr = (uint64_t)a.p[lane];
+    const uint32_t plo = (uint32_t)myptr, phi = (uint32_t)(myptr >> 32);
+    const float myscale = a.scale[lane];
 
+    // software pipeline: the next chunk's samples are in flight while this one is sorted and clipped (a wave computes
+    // for ~5 us per chunk and only two waves fit a SIMD, so nothing else would hide the HBM latency)
+    float nxt[NP];
+    CalPx cnxt{};
+    if (blockIdx.x < nchunks) {
+        const uint32_t g0 = blockIdx.x * kWave + lane, gi0 = g0 < a.npix ? g0 : a.npix - 1;
+        gather<NP>(nxt, plo, phi, gi0, a.npix * 4u);
+        if constexpr (CAL) cnxt = cal_load(a.m, gi0);
+    }
     for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const uint32_t g = chunk * kWave + lane;
         const bool valid = g < a.npix;
-        const uint32_t gi = valid ? g : a.npix - 1;
+        int nv = a.n;
+        asm volatile("" : "+v"(nv));
+#define HAS(f) (FULL || (f) < nv)
 
         // ---- gather, frame order (:344-348) ----
         float u[NP];
 #pragma unroll
-        for (int f = 0; f < NP; ++f) u[f] = f < a.n ? a.p[f][gi] : __builtin_inff();
+        for (int f = 0; f < NP; ++f) u[f] = HAS(f) ? nxt[f] : __builtin_inff();
+        const CalPx c = cnxt;
+        if (chunk + gridDim.x < nchunks) {
+            const uint32_t g1 = (chunk + gridDim.x) * kWave + lane, gi1 = g1 < a.npix ? g1 : a.npix - 1;
+            gather<NP>(nxt, plo, phi, gi1, a.npix * 4u);
+            if constexpr (CAL) cnxt = cal_load(a.m, gi1);
+        }
         if constexpr (CAL) {
-            const CalPx c = cal_load(a.m, gi);
 #pragma unroll
             for (int f = 0; f < NP; ++f)
-                if (f < a.n) {
-                    float x = cal_apply(u[f], c);
-                    if ((a.scale_mask >> f) & 1) x = x * a.scale[f];
-                    u[f] = x;
-                }
+                if (HAS(f)) u[f] = cal_apply(u[f], c) * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myscale), f));
         }
 
         // ---- sorted copy: NaN sorts last in f32_cmp (math/median.rs:4-13); it travels as +inf and is told apart by count ----
         float v[NP];
         int cnan = 0;
+        float nf = 0.0f;  // fma(x, 0, nf) stays 0 for finite x and turns NaN for inf / NaN
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
-            const bool isn = u[f] != u[f];
-            v[f] = isn ? __builtin_inff() : u[f];
-            cnan += isn ? 1 : 0;
+            v[f] = u[f];
+            if (HAS(f)) nf = __builtin_fmaf(u[f], 0.0f, nf);
+        }
+        if (__any(nf != nf)) {  // rare: some lane of this wave met a non-finite sample
+#pragma unroll
+            for (int f = 0; f < NP; ++f) {
+                const bool isn = u[f] != u[f];
+                v[f] = isn ? __builtin_inff() : u[f];
+                cnan += isn ? 1 : 0;
+            }
         }
         SortNet<NP>::sort(v);
 #pragma unroll
@@ -179,24 +219,35 @@ __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
         const float lov = len > 0 ? S(lo) : __builtin_inff(), hiv = len > 0 ? S(hi - 1) : -__builtin_inff();
         float sum = 0.0f;
 #pragma unroll
-        for (int f = 0; f < NP; ++f)
-            if (f < a.n) {
-                const bool keep = all || (u[f] >= lov && u[f] <= hiv);
-                sum += keep ? u[f] : 0.0f;
-                const unsigned long long rejected = __ballot(valid && !keep);
-                if (lane == f) mycount += (unsigned long long)__popcll(rejected);
-            }
+        for (int f = 0; f < NP; ++f) {
+            const bool keep = all | ((u[f] >= lov) & (u[f] <= hiv));  // bitwise: no short-circuit control flow
+            sum += (HAS(f) & keep) ? u[f] : 0.0f;
+            const int cnt = __popcll(__ballot(valid & HAS(f) & !keep));
+            // lane f's counter += cnt, through the scalar unit (a `lane == f` mask per frame would be hoisted and spilled)
+            const int upd = __builtin_amdgcn_readlane((int)mycount, f) + cnt;
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mycount) : "s"(upd), "n"(f));
+        }
         if (valid) a.out[g] = len == 0 ? 0.0f : sum / (float)len;
     }
 #undef S
-    if (lane < kMaxFrames) a.rej[(size_t)blockIdx.x * kMaxFrames + lane] = mycount;
+#undef HAS
+    a.rej[(size_t)blockIdx.x * kMaxFrames + lane] = mycount;
 }
 
-__global__ void rej_reduce_kernel(const unsigned long long *part, int blocks, unsigned long long *out) {
-    const int f = threadIdx.x;
+// [blocks][64] -> [64]: 16 slices of the block range per frame, then a fixed tree over the slices
+__global__ __launch_bounds__(1024) void rej_reduce_kernel(const uint32_t *__restrict__ part, int blocks, unsigned long long *__restrict__ out) {
+    const int f = threadIdx.x & 63, slice = threadIdx.x >> 6;
     unsigned long long s = 0;
-    for (int b = 0; b < blocks; ++b) s += part[(size_t)b * kMaxFrames + f];
-    out[f] = s;
+#pragma unroll 8
+    for (int b = slice; b < blocks; b += 16) s += part[(size_t)b * kMaxFrames + f];
+    __shared__ unsigned long long red[16][kMaxFrames];
+    red[slice][f] = s;
+    __syncthreads();
+    if (slice == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < 16; ++k) t += red[k][f];
+        out[f] = t;
+    }
 }
 
 // per-frame f64 sums of the calibrated samples: part[block][f]
@@ -206,13 +257,19 @@ __global__ __launch_bounds__(kSumBlock) void cal_means_kernel(const BatchArgs a,
 #pragma unroll
     for (int f = 0; f < NP; ++f) acc[f] = 0.0;
     const uint32_t stride = gridDim.x * kSumBlock;
-    for (uint32_t g = blockIdx.x * kSumBlock + threadIdx.x; g < a.npix; g += stride) {
-        const CalPx c = cal_load(a.m, g);
+    const uint64_t myptr = (uint64_t)a.p[threadIdx.x & 63];
+    const uint32_t plo = (uint32_t)myptr, phi = (uint32_t)(myptr >> 32);
+    // wave-uniform trip count: gather() moves the lane-resident pointers through a register copy, which only the ACTIVE
+    // lanes take part in -- a lane that had left the loop would hand v_readlane a stale base
+    for (uint32_t g0 = blockIdx.x * kSumBlock; g0 < a.npix; g0 += stride) {
+        const uint32_t g = g0 + threadIdx.x;
+        const bool valid = g < a.npix;
+        const uint32_t gi = valid ? g : a.npix - 1;
+        const CalPx c = cal_load(a.m, gi);
         float u[NP];
+        gather<NP>(u, plo, phi, gi, a.npix * 4u);  // slots past n alias frame 0; their sums are never read
 #pragma unroll
-        for (int f = 0; f < NP; ++f) u[f] = f < a.n ? a.p[f][g] : 0.0f;
-#pragma unroll
-        for (int f = 0; f < NP; ++f) acc[f] += (double)cal_apply(u[f], c);
+        for (int f = 0; f < NP; ++f) acc[f] += valid ? (double)cal_apply(u[f], c) : 0.0;
     }
     __shared__ double red[kSumBlock / kWave][kMaxFrames];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -326,16 +383,16 @@ __global__ __launch_bounds__(256) void compose_masters_kernel(const ComposeArgs 
 int cu_of(ab_ctx *ctx) { return ctx->cu_count > 0 ? ctx->cu_count : 256; }
 int np_for(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 32 ? 32 : 64)))); }
 
-template <bool CAL>
+template <bool CAL, bool FULL>
 void launch_scms(int np, int grid, hipStream_t s, const BatchArgs &a) {
     const size_t lds = (size_t)np * kWave * sizeof(float);
     switch (np) {
-    case 2: hipLaunchKernelGGL((scms_kernel<2, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((scms_kernel<4, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 8: hipLaunchKernelGGL((scms_kernel<8, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 16: hipLaunchKernelGGL((scms_kernel<16, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 32: hipLaunchKernelGGL((scms_kernel<32, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    default: hipLaunchKernelGGL((scms_kernel<64, CAL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((scms_kernel<2, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((scms_kernel<4, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((scms_kernel<8, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 16: hipLaunchKernelGGL((scms_kernel<16, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    case 32: hipLaunchKernelGGL((scms_kernel<32, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
+    default: hipLaunchKernelGGL((scms_kernel<64, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
     }
 }
 
@@ -412,7 +469,10 @@ int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix
     AB_HIP(ctx, hipSetDevice(ctx->device));
     BatchArgs a;
     memset(&a, 0, sizeof a);
-    for (size_t f = 0; f < n; ++f) a.p[f] = frames[f];
+    for (int f = 0; f < kMaxFrames; ++f) {
+        a.p[f] = frames[(size_t)f < n ? (size_t)f : 0];
+        a.scale[f] = 1.0f;
+    }
     a.m = m;
     a.n = (int)n;
     a.npix = (uint32_t)npix;
@@ -433,24 +493,22 @@ int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix
             double s = 0.0;
             for (int b = 0; b < grid; ++b) s += part[(size_t)b * kMaxFrames + f];
             const double mean = s / (double)npix;
-            if (mean > 0.0) {
-                a.scale[f] = 1.0f / (float)mean;
-                a.scale_mask |= (uint64_t)1 << f;
-            }
+            if (mean > 0.0) a.scale[f] = 1.0f / (float)mean;
         }
     }
     const uint32_t nchunks = (uint32_t)((npix + kWave - 1) / kWave);
     const int grid = (int)std::min<uint32_t>(nchunks, (uint32_t)cu_of(ctx) * 10);
     void *rej = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)grid + 1) * kMaxFrames * sizeof(unsigned long long), &rej));
-    a.rej = (unsigned long long *)rej;
+    AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)grid + 2) * kMaxFrames * sizeof(unsigned long long), &rej));
+    a.rej = (uint32_t *)((unsigned long long *)rej + kMaxFrames);  // [0, 64) u64 totals, then the per-block u32 partials
+    const bool full = (int)n == np;
     if (cal)
-        launch_scms<true>(np, grid, ctx->stream, a);
+        full ? launch_scms<true, true>(np, grid, ctx->stream, a) : launch_scms<true, false>(np, grid, ctx->stream, a);
     else
-        launch_scms<false>(np, grid, ctx->stream, a);
+        full ? launch_scms<false, true>(np, grid, ctx->stream, a) : launch_scms<false, false>(np, grid, ctx->stream, a);
     AB_HIP(ctx, hipGetLastError());
-    unsigned long long *total = a.rej + (size_t)grid * kMaxFrames;
-    hipLaunchKernelGGL(rej_reduce_kernel, dim3(1), dim3(kMaxFrames), 0, ctx->stream, a.rej, grid, total);
+    unsigned long long *total = (unsigned long long *)rej;
+    hipLaunchKernelGGL(rej_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.rej, grid, total);
     AB_HIP(ctx, hipGetLastError());
     unsigned long long host[kMaxFrames];
     AB_TRY(download(ctx, host, total, sizeof host));

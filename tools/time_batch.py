@@ -40,6 +40,9 @@ def main():
     t2 = timed(lambda: ctx.sigma_clipped_mean_stack(norm))
     print(f"sigma_clipped_mean_stack alone: {t2:.2f} ms   ({gb / t2:.2f} TB/s, {gb / t2 / 8.0:.2f} of the HBM roofline)")
     from astroburst_amd.core import BatchStackConfig
+    for it in (0, 1, 2, 3):
+        ti = timed(lambda: ctx.sigma_clipped_mean_stack(norm, BatchStackConfig(max_iterations=it)))
+        print(f"  max_iterations={it}: {ti:.2f} ms")
     t3 = timed(lambda: ctx.run_batch_channel(lights, bias=bias, flat=flat, config=BatchStackConfig(normalize_before_stack=False)))
     print(f"fused channel without normalisation (one read): {t3:.2f} ms")
 
