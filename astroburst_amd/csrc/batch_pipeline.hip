@@ -43,6 +43,7 @@ namespace {
 
 constexpr int kMaxFrames = 64;
 constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;  // the waves of a block take consecutive chunks: 1 KB contiguous per frame per block step
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
 constexpr int kSumBlock = 256;
 
@@ -59,7 +60,9 @@ struct BatchArgs {
     float sigma_low, sigma_high;
     int max_iter;
     float *out;
-    uint32_t *rej;  // [gridDim.x][64]
+    uint32_t *rej;  // [waves][64]
+    int stage;           // developer ablation (AB_BATCH_STAGE): 1 no sort, 2 no LDS copy, 3 no epilogue loop
+    uint32_t per_block;  // 0: block b takes chunks b, b + grid, ...; else chunks [b * per_block, (b + 1) * per_block)
 };
 
 // calibrate_light's per-pixel chain (:93-113) in its f32 operation order
@@ -103,12 +106,13 @@ __device__ __forceinline__ void gather(float (&u)[NP], uint32_t plo, uint32_t ph
 // FULL: n == NP.  Otherwise every `f < n` is evaluated against a per-chunk VGPR copy of n: as uniform scalar conditions
 // the 64 of them are hoisted out of the chunk loop as 64-bit lane masks and spill the SGPR file.
 template <int NP, bool CAL, bool FULL>
-__global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
+__global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const BatchArgs a) {
     extern __shared__ float S_[];  // [NP][64] sorted samples of this wave's 64 pixels
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wid = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;  // global wave id
     uint32_t mycount = 0;  // lane f: rejected samples of frame f, over every chunk of this block (< 2^30 per block)
     const uint32_t nchunks = (a.npix + kWave - 1) / kWave;
-#define S(i) S_[(i) * kWave + lane]
+#define S(i) S_[(i) * (kWave * kWavesPerBlock) + threadIdx.x]
     const uint64_t myptr = (uint64_t)a.p[lane];
     const uint32_t plo = (uint32_t)myptr, phi = (uint32_t)(myptr >> 32);
     const float myscale = a.scale[lane];
@@ -117,12 +121,14 @@ __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
     // for ~5 us per chunk and only two waves fit a SIMD, so nothing else would hide the HBM latency)
     float nxt[NP];
     CalPx cnxt{};
-    if (blockIdx.x < nchunks) {
-        const uint32_t g0 = blockIdx.x * kWave + lane, gi0 = g0 < a.npix ? g0 : a.npix - 1;
+    const uint32_t first = a.per_block ? wid * a.per_block : wid, step = a.per_block ? 1u : nwaves;
+    const uint32_t end = a.per_block ? min(first + a.per_block, nchunks) : nchunks;
+    if (first < end) {
+        const uint32_t g0 = first * kWave + lane, gi0 = g0 < a.npix ? g0 : a.npix - 1;
         gather<NP>(nxt, plo, phi, gi0, a.npix * 4u);
         if constexpr (CAL) cnxt = cal_load(a.m, gi0);
     }
-    for (uint32_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (uint32_t chunk = first; chunk < end; chunk += step) {
         const uint32_t g = chunk * kWave + lane;
         const bool valid = g < a.npix;
         int nv = a.n;
@@ -134,8 +140,8 @@ __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
 #pragma unroll
         for (int f = 0; f < NP; ++f) u[f] = HAS(f) ? nxt[f] : __builtin_inff();
         const CalPx c = cnxt;
-        if (chunk + gridDim.x < nchunks) {
-            const uint32_t g1 = (chunk + gridDim.x) * kWave + lane, gi1 = g1 < a.npix ? g1 : a.npix - 1;
+        if (chunk + step < end) {
+            const uint32_t g1 = (chunk + step) * kWave + lane, gi1 = g1 < a.npix ? g1 : a.npix - 1;
             gather<NP>(nxt, plo, phi, gi1, a.npix * 4u);
             if constexpr (CAL) cnxt = cal_load(a.m, gi1);
         }
@@ -162,9 +168,11 @@ __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
                 cnan += isn ? 1 : 0;
             }
         }
-        SortNet<NP>::sort(v);
+        if (a.stage != 1) SortNet<NP>::sort(v);
+        if (a.stage != 2) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) S(i) = v[i];
+            for (int i = 0; i < NP; ++i) S(i) = v[i];
+        }
 
         // ---- the clipping loop (:350-367) on the window [lo, hi) of the sorted order ----
         int lo = 0, hi = a.n;
@@ -172,21 +180,28 @@ __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
             const int len = hi - lo;
             if (len < 3) break;
             const int k = len >> 1, c = lo + k;
-            float med = S(c);
+            // one LDS round trip: the median and the two outermost samples of either end (all the retain pass reads for
+            // a pixel that loses at most two samples per end; len >= 3 keeps the four indices inside the window)
+            const float med = S(c), e0 = S(lo), e1 = S(lo + 1), f0 = S(hi - 1), f1 = S(hi - 2);
             // a NaN or infinite median makes every z NaN: the retain pass empties the pixel
             if ((cnan > 0 && c >= a.n - cnan) || !__builtin_isfinite(med)) {
                 lo = hi = 0;
                 break;
             }
-            const int nA = c - lo + 1, nB = hi - c - 1;  // deviation runs: A[j] = med - S[c-j], B[j] = S[c+1+j] - med
+            // MAD = the k-th smallest of the deviation runs A[j] = med - S[c-j] (j < nA), B[j] = S[c+1+j] - med (j < nB):
+            // the number i of A's among the k + 1 smallest is the first i with A[i] >= B[k-i]; 4-ary search, three
+            // independent probes (six reads) per round trip
+            const int nA = c - lo + 1, nB = hi - c - 1;
             int i0 = max(0, k + 1 - nB), i1 = min(k + 1, nA);
             while (i0 < i1) {
-                const int mid = (i0 + i1) >> 1, j = k + 1 - mid;
-                const float A = med - S(c - mid), B = S(c + j) - med;
-                if (A < B)
-                    i0 = mid + 1;
-                else
-                    i1 = mid;
+                const int w = i1 - i0;
+                const int m1 = i0 + (w >> 2), m2 = i0 + (w >> 1), m3 = i0 + ((3 * w) >> 2);  // all within [i0, i1 - 1]
+                const float a1 = S(c - m1), b1 = S(c + k + 1 - m1), a2 = S(c - m2), b2 = S(c + k + 1 - m2), a3 = S(c - m3), b3 = S(c + k + 1 - m3);
+                const bool p1 = (med - a1) < (b1 - med), p2 = (med - a2) < (b2 - med), p3 = (med - a3) < (b3 - med);
+                const int n0 = !p1 ? i0 : (!p2 ? m1 + 1 : (!p3 ? m2 + 1 : m3 + 1));
+                const int n1 = !p1 ? m1 : (!p2 ? m2 : (!p3 ? m3 : i1));
+                i0 = n0;
+                i1 = n1;
             }
             const int j0 = k + 1 - i0;
             const float ma = i0 > 0 ? med - S(c - (i0 - 1)) : -__builtin_inff();
@@ -196,16 +211,24 @@ __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
             const float sigma = (float)((double)mad * kMadToSigma);
             if (sigma < 1e-10f) break;
             const float nsl = -a.sigma_low, sh = a.sigma_high;
+            auto kept = [&](float x) {
+                const float z = (x - med) / sigma;
+                return z > nsl && z < sh;
+            };
             int nlo = lo, nhi = hi;
-            while (nlo < nhi) {
-                const float z = (S(nlo) - med) / sigma;
-                if (z > nsl && z < sh) break;
-                ++nlo;
+            if (!kept(e0)) {
+                nlo = lo + 1;
+                if (!kept(e1)) {
+                    nlo = lo + 2;
+                    while (nlo < nhi && !kept(S(nlo))) ++nlo;
+                }
             }
-            while (nhi > nlo) {
-                const float z = (S(nhi - 1) - med) / sigma;
-                if (z > nsl && z < sh) break;
-                --nhi;
+            if (nhi > nlo && !kept(f0)) {
+                nhi = hi - 1;
+                if (nhi > nlo && !kept(f1)) {
+                    nhi = hi - 2;
+                    while (nhi > nlo && !kept(S(nhi - 1))) --nhi;
+                }
             }
             cnan = 0;  // a retain pass never keeps a NaN
             if (nlo == lo && nhi == hi) break;
@@ -217,37 +240,50 @@ __global__ __launch_bounds__(kWave) void scms_kernel(const BatchArgs a) {
         const int len = hi - lo;
         const bool all = lo == 0 && hi == a.n;
         const float lov = len > 0 ? S(lo) : __builtin_inff(), hiv = len > 0 ? S(hi - 1) : -__builtin_inff();
+        // u_f survives <=> clamp(u_f, S[lo], S[hi-1]) == u_f (NaN never equals its clamp; an untouched pixel keeps
+        // everything, an emptied one nothing).  One v_med3 + one v_cmp per frame; the compare IS the wave's reject mask,
+        // so the per-frame count is a scalar popcount.
+        const unsigned long long live = __builtin_amdgcn_ballot_w64(valid & !all);   // lanes whose compare decides
+        const unsigned long long force = __builtin_amdgcn_ballot_w64(valid & !all & (len == 0));
         float sum = 0.0f;
+        float lo_s = lov;
+        uint32_t cnts = 0;  // lane f <- this chunk's rejections of frame f (one v_writelane each, summed into mycount below)
+        if (a.stage == 3) sum = u[0] + v[NP - 1];
+        else
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
-            const bool keep = all | ((u[f] >= lov) & (u[f] <= hiv));  // bitwise: no short-circuit control flow
-            sum += (HAS(f) & keep) ? u[f] : 0.0f;
-            const int cnt = __popcll(__ballot(valid & HAS(f) & !keep));
-            // lane f's counter += cnt, through the scalar unit (a `lane == f` mask per frame would be hoisted and spilled)
-            const int upd = __builtin_amdgcn_readlane((int)mycount, f) + cnt;
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(mycount) : "s"(upd), "n"(f));
+            // a sequencing point per frame: without it the scheduler evaluates all 64 masks first and spills them
+            asm volatile("" : "+v"(lo_s), "+v"(sum));
+            const float clamped = __builtin_amdgcn_fmed3f(u[f], lo_s, hiv);
+            unsigned long long rej = (__builtin_amdgcn_ballot_w64(clamped != u[f]) & live) | force;
+            if constexpr (!FULL) rej &= __builtin_amdgcn_ballot_w64(HAS(f));  // wave-uniform, as a lane mask
+            const bool mine = __builtin_amdgcn_inverse_ballot_w64(rej);  // the scalar mask back as a v_cndmask selector
+            sum += mine ? 0.0f : (HAS(f) ? u[f] : 0.0f);
+            int cnt = __popcll(rej);
+            asm volatile("" : "+s"(cnt));  // keep it a register operand even where the compiler can fold it to a constant
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cnts) : "s"(cnt), "n"(f));
         }
+        mycount += cnts;
         if (valid) a.out[g] = len == 0 ? 0.0f : sum / (float)len;
     }
 #undef S
 #undef HAS
-    a.rej[(size_t)blockIdx.x * kMaxFrames + lane] = mycount;
+    a.rej[(size_t)wid * kMaxFrames + lane] = mycount;
 }
 
-// [blocks][64] -> [64]: 16 slices of the block range per frame, then a fixed tree over the slices
-__global__ __launch_bounds__(1024) void rej_reduce_kernel(const uint32_t *__restrict__ part, int blocks, unsigned long long *__restrict__ out) {
-    const int f = threadIdx.x & 63, slice = threadIdx.x >> 6;
+// [blocks][64] -> [64]: one block per frame
+__global__ __launch_bounds__(256) void rej_reduce_kernel(const uint32_t *__restrict__ part, int blocks, unsigned long long *__restrict__ out) {
+    const int f = blockIdx.x;
     unsigned long long s = 0;
-#pragma unroll 8
-    for (int b = slice; b < blocks; b += 16) s += part[(size_t)b * kMaxFrames + f];
-    __shared__ unsigned long long red[16][kMaxFrames];
-    red[slice][f] = s;
+    for (int b = threadIdx.x; b < blocks; b += 256) s += part[(size_t)b * kMaxFrames + f];
+    __shared__ unsigned long long red[256];
+    red[threadIdx.x] = s;
     __syncthreads();
-    if (slice == 0) {
-        unsigned long long t = 0;
-        for (int k = 0; k < 16; ++k) t += red[k][f];
-        out[f] = t;
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
     }
+    if (threadIdx.x == 0) out[f] = red[0];
 }
 
 // per-frame f64 sums of the calibrated samples: part[block][f]
@@ -383,30 +419,6 @@ __global__ __launch_bounds__(256) void compose_masters_kernel(const ComposeArgs 
 int cu_of(ab_ctx *ctx) { return ctx->cu_count > 0 ? ctx->cu_count : 256; }
 int np_for(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 32 ? 32 : 64)))); }
 
-template <bool CAL, bool FULL>
-void launch_scms(int np, int grid, hipStream_t s, const BatchArgs &a) {
-    const size_t lds = (size_t)np * kWave * sizeof(float);
-    switch (np) {
-    case 2: hipLaunchKernelGGL((scms_kernel<2, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((scms_kernel<4, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 8: hipLaunchKernelGGL((scms_kernel<8, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 16: hipLaunchKernelGGL((scms_kernel<16, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    case 32: hipLaunchKernelGGL((scms_kernel<32, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    default: hipLaunchKernelGGL((scms_kernel<64, CAL, FULL>), dim3(grid), dim3(kWave), lds, s, a); break;
-    }
-}
-
-void launch_means(int np, int grid, hipStream_t s, const BatchArgs &a, double *part) {
-    switch (np) {
-    case 2: hipLaunchKernelGGL(cal_means_kernel<2>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
-    case 4: hipLaunchKernelGGL(cal_means_kernel<4>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
-    case 8: hipLaunchKernelGGL(cal_means_kernel<8>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
-    case 16: hipLaunchKernelGGL(cal_means_kernel<16>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
-    case 32: hipLaunchKernelGGL(cal_means_kernel<32>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
-    default: hipLaunchKernelGGL(cal_means_kernel<64>, dim3(grid), dim3(kSumBlock), 0, s, a, part); break;
-    }
-}
-
 int download(ab_ctx *ctx, void *dst, const void *src, size_t bytes) {
     void *pin = nullptr;
     AB_TRY(ab_pinned(ctx, bytes, &pin));
@@ -414,6 +426,71 @@ int download(ab_ctx *ctx, void *dst, const void *src, size_t bytes) {
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(dst, pin, bytes);
     return AB_OK;
+}
+
+// persistent kernels: exactly as many blocks as the chip keeps resident (a partial second round of 100-chunk blocks would
+// double the kernel time), but never more than there are work items
+template <class K>
+int resident_grid(ab_ctx *ctx, K kernel, int block, size_t lds, int64_t items) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)cu_of(ctx) * per_cu));
+}
+
+template <int NP, bool CAL, bool FULL>
+int launch_scms_np(ab_ctx *ctx, const BatchArgs &a, int64_t nchunks, uint32_t **rej_out) {
+    constexpr int kThreads = kWave * kWavesPerBlock;
+    const size_t lds = (size_t)NP * kThreads * sizeof(float);
+    const int grid = resident_grid(ctx, scms_kernel<NP, CAL, FULL>, kThreads, lds, (nchunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    const int waves = grid * kWavesPerBlock;
+    void *rej = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)waves + 2) * kMaxFrames * sizeof(unsigned long long), &rej));
+    BatchArgs b = a;
+    static const int contig = getenv("AB_BATCH_CONTIG") ? atoi(getenv("AB_BATCH_CONTIG")) : 0;
+    b.stage = getenv("AB_BATCH_STAGE") ? atoi(getenv("AB_BATCH_STAGE")) : 0;
+    b.per_block = contig ? (uint32_t)((nchunks + waves - 1) / waves) : 0;
+    b.rej = (uint32_t *)((unsigned long long *)rej + kMaxFrames);  // [0, 64) u64 totals, then the per-block u32 partials
+    hipLaunchKernelGGL((scms_kernel<NP, CAL, FULL>), dim3(grid), dim3(kThreads), lds, ctx->stream, b);
+    AB_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(rej_reduce_kernel, dim3(kMaxFrames), dim3(256), 0, ctx->stream, b.rej, waves, (unsigned long long *)rej);
+    AB_HIP(ctx, hipGetLastError());
+    *rej_out = (uint32_t *)rej;
+    return AB_OK;
+}
+
+template <bool CAL, bool FULL>
+int launch_scms(ab_ctx *ctx, int np, const BatchArgs &a, int64_t nchunks, uint32_t **rej_out) {
+    switch (np) {
+    case 2: return launch_scms_np<2, CAL, FULL>(ctx, a, nchunks, rej_out);
+    case 4: return launch_scms_np<4, CAL, FULL>(ctx, a, nchunks, rej_out);
+    case 8: return launch_scms_np<8, CAL, FULL>(ctx, a, nchunks, rej_out);
+    case 16: return launch_scms_np<16, CAL, FULL>(ctx, a, nchunks, rej_out);
+    case 32: return launch_scms_np<32, CAL, FULL>(ctx, a, nchunks, rej_out);
+    default: return launch_scms_np<64, CAL, FULL>(ctx, a, nchunks, rej_out);
+    }
+}
+
+template <int NP>
+int launch_means_np(ab_ctx *ctx, const BatchArgs &a, std::vector<double> *part, int *grid_out) {
+    const int grid = resident_grid(ctx, cal_means_kernel<NP>, kSumBlock, 0, ((int64_t)a.npix + kSumBlock - 1) / kSumBlock);
+    void *d = nullptr;
+    AB_TRY(ab_scratch(ctx, (size_t)grid * kMaxFrames * sizeof(double), &d));
+    hipLaunchKernelGGL(cal_means_kernel<NP>, dim3(grid), dim3(kSumBlock), 0, ctx->stream, a, (double *)d);
+    AB_HIP(ctx, hipGetLastError());
+    part->resize((size_t)grid * kMaxFrames);
+    *grid_out = grid;
+    return download(ctx, part->data(), d, part->size() * sizeof(double));
+}
+
+int launch_means(ab_ctx *ctx, int np, const BatchArgs &a, std::vector<double> *part, int *grid_out) {
+    switch (np) {
+    case 2: return launch_means_np<2>(ctx, a, part, grid_out);
+    case 4: return launch_means_np<4>(ctx, a, part, grid_out);
+    case 8: return launch_means_np<8>(ctx, a, part, grid_out);
+    case 16: return launch_means_np<16>(ctx, a, part, grid_out);
+    case 32: return launch_means_np<32>(ctx, a, part, grid_out);
+    default: return launch_means_np<64>(ctx, a, part, grid_out);
+    }
 }
 
 // sum (mode 0) or sum of squared deviations (mode 1) of a device plane: fixed-shape tree, partials added in block order
@@ -482,13 +559,9 @@ int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix
     a.out = out;
     const int np = np_for((int)n);
     if (cal && cfg.normalize_before_stack) {  // normalize_frames (:309-319) on the calibrated samples, never materialised
-        const int grid = std::max(1, std::min<int>((int)((npix + kSumBlock - 1) / kSumBlock), cu_of(ctx) * 4));
-        void *d = nullptr;
-        AB_TRY(ab_scratch(ctx, (size_t)grid * kMaxFrames * sizeof(double), &d));
-        launch_means(np, grid, ctx->stream, a, (double *)d);
-        AB_HIP(ctx, hipGetLastError());
-        std::vector<double> part((size_t)grid * kMaxFrames);
-        AB_TRY(download(ctx, part.data(), d, part.size() * sizeof(double)));
+        std::vector<double> part;
+        int grid = 0;
+        AB_TRY(launch_means(ctx, np, a, &part, &grid));
         for (size_t f = 0; f < n; ++f) {
             double s = 0.0;
             for (int b = 0; b < grid; ++b) s += part[(size_t)b * kMaxFrames + f];
@@ -496,20 +569,13 @@ int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix
             if (mean > 0.0) a.scale[f] = 1.0f / (float)mean;
         }
     }
-    const uint32_t nchunks = (uint32_t)((npix + kWave - 1) / kWave);
-    const int grid = (int)std::min<uint32_t>(nchunks, (uint32_t)cu_of(ctx) * 10);
-    void *rej = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)grid + 2) * kMaxFrames * sizeof(unsigned long long), &rej));
-    a.rej = (uint32_t *)((unsigned long long *)rej + kMaxFrames);  // [0, 64) u64 totals, then the per-block u32 partials
+    const int64_t nchunks = (npix + kWave - 1) / kWave;
     const bool full = (int)n == np;
+    uint32_t *total = nullptr;
     if (cal)
-        full ? launch_scms<true, true>(np, grid, ctx->stream, a) : launch_scms<true, false>(np, grid, ctx->stream, a);
+        AB_TRY((full ? launch_scms<true, true>(ctx, np, a, nchunks, &total) : launch_scms<true, false>(ctx, np, a, nchunks, &total)));
     else
-        full ? launch_scms<false, true>(np, grid, ctx->stream, a) : launch_scms<false, false>(np, grid, ctx->stream, a);
-    AB_HIP(ctx, hipGetLastError());
-    unsigned long long *total = (unsigned long long *)rej;
-    hipLaunchKernelGGL(rej_reduce_kernel, dim3(1), dim3(1024), 0, ctx->stream, a.rej, grid, total);
-    AB_HIP(ctx, hipGetLastError());
+        AB_TRY((full ? launch_scms<false, true>(ctx, np, a, nchunks, &total) : launch_scms<false, false>(ctx, np, a, nchunks, &total)));
     unsigned long long host[kMaxFrames];
     AB_TRY(download(ctx, host, total, sizeof host));
     if (rejection_counts)

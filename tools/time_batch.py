@@ -37,9 +37,20 @@ def main():
     t = timed(lambda: ctx.run_batch_channel(lights, bias=bias, flat=flat))
     print(f"fused channel (means + stack + stats): {t:.2f} ms   ({2 * gb / t:.2f} TB/s over two reads of the lights)")
     norm = ctx.normalize_frames([ctx.calibrate_light(l, bias=bias, flat=flat) for l in lights])
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(5):
+        ctx.sigma_clipped_mean_stack(norm)
+    ev1.record()
+    torch.cuda.synchronize()
+    print(f"sigma_clipped_mean_stack, GPU time between events: {ev0.elapsed_time(ev1) / 5:.2f} ms per call")
     t2 = timed(lambda: ctx.sigma_clipped_mean_stack(norm))
     print(f"sigma_clipped_mean_stack alone: {t2:.2f} ms   ({gb / t2:.2f} TB/s, {gb / t2 / 8.0:.2f} of the HBM roofline)")
     from astroburst_amd.core import BatchStackConfig
+    import os
+    if os.environ.get("AB_BATCH_STAGE"):
+        print("stage", os.environ["AB_BATCH_STAGE"], "max_iterations=0:", f"{timed(lambda: ctx.sigma_clipped_mean_stack(norm, BatchStackConfig(max_iterations=0))):.2f} ms")
+        return
     for it in (0, 1, 2, 3):
         ti = timed(lambda: ctx.sigma_clipped_mean_stack(norm, BatchStackConfig(max_iterations=it)))
         print(f"  max_iterations={it}: {ti:.2f} ms")
