@@ -62,9 +62,10 @@ struct ab_ctx {
     void *ws[AB_WS_SLOTS] = {};
     size_t ws_bytes[AB_WS_SLOTS] = {};
     // frame-parallel registration (affine.hip): child contexts (own stream + workspaces), one per host worker;
-    // AB_REGISTER_WORKERS overrides the default of 24 (measured optimum on MI355X: 8 -> 50 ms, 24 -> 44 ms, 48 -> 76 ms per 63 frames)
+    // AB_REGISTER_WORKERS overrides the default of 12.  The stage is GPU-throughput-bound, so past ~12 workers nothing is gained and
+    // the step time only gets noisier (MI355X, 63 frames, median of 8: 6 -> 49.5 ms, 8 -> 45.9, 12 -> 41.0, 16 -> 41.5, 24 -> 44-55, 32 -> 70)
     std::vector<ab_ctx *> workers;
-    int register_workers = 24;
+    int register_workers = 12;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
 };
@@ -97,9 +98,10 @@ int ab_pinned(ab_ctx *ctx, size_t bytes, void **out);
 int ab_workspace(ab_ctx *ctx, int slot, size_t bytes, void **out);
 
 // Frame-parallel fan-out: items 0..n-1 are pulled by up to ctx->register_workers host threads, each driving a child context
-// (own non-blocking stream + workspaces, cached in ctx->workers).  ctx->stream is drained first; each worker's stream is drained
+// (own non-blocking stream + workspaces, cached in ctx->workers).  ctx->stream is drained first (unless the caller did and keeps
+// using it concurrently); each worker's stream is drained
 // before return.  With one worker fn runs inline on ctx.
-int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn);
+int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn, bool drain_caller_stream = true);
 
 // RAII staging of an input plane: host planes are uploaded to a temporary device buffer.
 struct StagedPlane {

@@ -244,7 +244,7 @@ void ab_stage_out_abort(ab_ctx *ctx, StagedOut *o) {
     }
 }
 
-int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn) {
+int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn, bool drain_caller_stream) {
     const size_t workers = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1));
     if (workers <= 1) {
         for (size_t f = 0; f < n; ++f) AB_TRY(fn(ctx, f));
@@ -256,7 +256,7 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
         wc->register_workers = 1;
         ctx->workers.push_back(wc);
     }
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // whatever the caller queued on ctx (its frames, shared tables) is complete
+    if (drain_caller_stream) AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // whatever the caller queued on ctx (its frames, shared tables) is complete
     std::atomic<size_t> next{0};
     std::vector<int> rcs(workers, AB_OK);
     std::vector<std::thread> pool;

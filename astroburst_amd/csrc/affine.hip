@@ -21,6 +21,9 @@
 #include "ab_common.hpp"
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <array>
 #include <atomic>
 #include <cmath>
@@ -590,14 +593,41 @@ int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::
 }  // namespace
 
 // one target against the prepared reference (stars rs, triangle table in ref_ws); all device work on wc's stream
-static int register_one(ab_ctx *wc, const MatchWs &ref_ws, const std::vector<Pt> &rs, bool ref_ok, const float *ref, const float *tgt,
-                        int64_t rows, int64_t cols, int num_threads, ab_affine_align_result *out) {
+// The reference frame's star list and triangle table, prepared on the caller's context while the workers already run
+// their targets' detection (the targets' detection does not depend on it): wait() blocks until it is there.
+struct RefTable {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    int rc = AB_OK;
+    bool ok = false;  // enough reference stars to match at all
+    std::vector<Pt> stars;
+    void publish(int rc_, bool ok_) {
+        {
+            std::lock_guard<std::mutex> g(m);
+            rc = rc_;
+            ok = ok_;
+            done = true;
+        }
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [&] { return done; });
+        return rc;
+    }
+};
+
+static int register_one(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const float *ref, const float *tgt, int64_t rows, int64_t cols,
+                        int num_threads, ab_affine_align_result *out) {
     MatchWs w;
     AB_TRY(match_ws(wc, &w));
     std::vector<Pt> ts;
     bool found = false;
     AB_TRY(frame_stars(wc, tgt, rows, cols, &ts));
-    if (ref_ok && ts.size() >= kMinMatchesRigid) {
+    if (rt.wait() != AB_OK) return ab_set_error(wc, rt.rc, "the reference frame's detection failed");
+    const std::vector<Pt> &rs = rt.stars;
+    if (rt.ok && ts.size() >= kMinMatchesRigid) {
         AB_TRY(gpu_build_triangles(wc, w, ts, 1));
         MatchWs mixed = w;  // tgt table and votes of this worker; ref table of the caller
         mixed.ref_sorted = ref_ws.ref_sorted;
@@ -633,12 +663,12 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     AB_HIP(ctx, hipSetDevice(ctx->device));
     MatchWs w;
     AB_TRY(match_ws(ctx, &w));
-    std::vector<Pt> rs;
-    AB_TRY(frame_stars(ctx, ref, rows, cols, &rs));
-    const bool ref_ok = rs.size() >= kMinMatchesRigid;
-    if (ref_ok) {
+    RefTable rt;
+    auto prepare_reference = [&]() -> int {
+        AB_TRY(frame_stars(ctx, ref, rows, cols, &rt.stars));
+        if (rt.stars.size() < kMinMatchesRigid) return AB_OK;
         // reference table: built on the GPU, ordered by (ratio_mid bucket, ratio_long) once on the host
-        AB_TRY(gpu_build_triangles(ctx, w, rs, 0));
+        AB_TRY(gpu_build_triangles(ctx, w, rt.stars, 0));
         unsigned int nref = 0;
         AB_HIP(ctx, hipMemcpyAsync(&nref, w.counts, sizeof nref, hipMemcpyDeviceToHost, ctx->stream));
         AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -649,13 +679,31 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
             return bx != by ? bx < by : x.lng < y.lng;
         });
         if (nref) AB_HIP(ctx, hipMemcpy(w.ref_sorted, tris.data(), nref * sizeof(DTri), hipMemcpyHostToDevice));
-    }
+        return AB_OK;
+    };
     // the warp of a frame (f64 VALU) overlaps the other workers' latency-bound detection passes
-    return ab_parallel_frames(ctx, n, "registration", [&](ab_ctx *wc, size_t f) {
-        AB_TRY(register_one(wc, w, rs, ref_ok, ref, targets[f], rows, cols, num_threads, &out[f]));
+    auto one = [&](ab_ctx *wc, size_t f) -> int {
+        AB_TRY(register_one(wc, w, rt, ref, targets[f], rows, cols, num_threads, &out[f]));
         if (aligned) AB_TRY(ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]));  // pair.rs:59-61
-        return (int)AB_OK;
+        return AB_OK;
+    };
+    static const bool serial_ref = getenv("AB_REGISTER_SERIAL_REF") != nullptr;  // developer A/B switch
+    const bool inline_run = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1)) <= 1 || serial_ref;
+    if (inline_run) {  // the reference first, on ctx
+        const int rc = prepare_reference();
+        rt.publish(rc, rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
+        if (rc != AB_OK) return rc;
+        return ab_parallel_frames(ctx, n, "registration", one);
+    }
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's frames are complete before any other stream reads them
+    int prep_rc = AB_OK;
+    std::thread prep([&]() {
+        prep_rc = hipSetDevice(ctx->device) == hipSuccess ? prepare_reference() : AB_ERR_HIP;
+        rt.publish(prep_rc, prep_rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
     });
+    const int rc = ab_parallel_frames(ctx, n, "registration", one, /*drain_caller_stream=*/false);
+    prep.join();
+    return prep_rc != AB_OK ? prep_rc : rc;
 }
 
 int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
