@@ -451,64 +451,73 @@ __global__ __launch_bounds__(256) void tri_scatter_kernel(const DTri *__restrict
 // bmax+1 (a superset of every possible match), keeps those whose ratio_long can match anything in the window
 // (wave-wide compaction into LDS), and every lane applies the reference's exact test (:335-339) to the kept ones.
 // Votes collect in LDS; each wave then adds its non-zero entries to the global 64 x 64 matrix.
+__device__ __forceinline__ double lane_f64(double x, int lane) {  // wave-uniform lane index
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+constexpr int kVoteSlices = 8;    // slices of a ref group's candidate range (dense buckets would otherwise leave a few very long waves)
+constexpr int kVoteBlocks = 1024;  // persistent one-wave blocks: each flushes its LDS votes ONCE (a hot pair's global counter
+                                   // serialises its atomics at ~12 ns each: 4280 per-item flushes cost 50 us, 1024 cost 12)
 __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
-                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */) {
-    __shared__ unsigned int votes[kVoteDim * kVoteDim];
-    __shared__ double k_mid[64], k_lng[64];
-    __shared__ uint32_t k_verts[64];
+                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */, int ablate) {
+    // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and with a stride of 64
+    // (a multiple of the bank count) all of those atomics would land in one bank
+    constexpr int kLdsStride = kVoteDim + 1;
+    __shared__ unsigned int votes[kVoteDim * kLdsStride];
     const int lane = threadIdx.x;
-    const unsigned int nr = *nr_p, first = blockIdx.x * 64, r = first + lane;
-    if (first >= nr) return;
-    for (int i = lane; i < kVoteDim * kVoteDim; i += 64) votes[i] = 0;
-    const bool have = r < nr;
-    const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
-    double lmin = a.lng, lmax = a.lng;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        lmin = fmin(lmin, __shfl_xor(lmin, off, 64));
-        lmax = fmax(lmax, __shfl_xor(lmax, off, 64));
-    }
-    const double win_lo = lmin - kTriangleTolerance * 1.0001, win_hi = lmax + kTriangleTolerance * 1.0001;
-    const int bmin = tri_bin(rt_sorted[first].mid), bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
-    unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
-    {  // blockIdx.y takes one slice of the candidate range: dense buckets would otherwise leave a few very long waves
-        const unsigned int per = (q1 - q0 + gridDim.y - 1) / gridDim.y;
-        q0 = min(q0 + blockIdx.y * per, q1);
-        q1 = min(q0 + per, q1);
-    }
+    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * kVoteSlices;
+    if (blockIdx.x >= items) return;
+    for (int i = lane; i < kVoteDim * kLdsStride; i += 64) votes[i] = 0;
     __syncthreads();
-    for (unsigned int base = q0; base < q1; base += 64) {
-        const unsigned int idx = base + lane;
-        DTri t = {0.0, 0.0, 0u, 0u};
-        bool keep = false;
-        if (idx < q1) {
-            t = tt_sorted[idx];
-            keep = t.lng >= win_lo && t.lng <= win_hi;
-        }
-        const unsigned long long m = __ballot(keep);
-        if (m == 0) continue;
-        if (keep) {
-            const int pos = (int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            k_mid[pos] = t.mid;
-            k_lng[pos] = t.lng;
-            k_verts[pos] = t.verts;
-        }
-        __syncthreads();
-        const int cnt = (int)__builtin_popcountll(m);
-        if (have)
-            for (int q = 0; q < cnt; ++q) {
-                if (fabs(a.mid - k_mid[q]) > kTriangleTolerance || fabs(a.lng - k_lng[q]) > kTriangleTolerance) continue;
-                const uint32_t b = k_verts[q];
+    for (unsigned int item = blockIdx.x; item < items; item += gridDim.x) {
+        const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
+        const bool have = r < nr;
+        const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
+        double lmin = a.lng, lmax = a.lng;
 #pragma unroll
-                for (int p = 0; p < 3; ++p) atomicAdd(&votes[((a.verts >> (8 * p)) & 255u) * kVoteDim + ((b >> (8 * p)) & 255u)], 1u);
+        for (int off = 32; off >= 1; off >>= 1) {
+            lmin = fmin(lmin, __shfl_xor(lmin, off, 64));
+            lmax = fmax(lmax, __shfl_xor(lmax, off, 64));
+        }
+        const double win_lo = lmin - kTriangleTolerance * 1.0001, win_hi = lmax + kTriangleTolerance * 1.0001;
+        const int bmin = tri_bin(rt_sorted[first].mid), bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
+        unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
+        {
+            const unsigned int per = (q1 - q0 + kVoteSlices - 1) / kVoteSlices;
+            q0 = min(q0 + slice * per, q1);
+            q1 = min(q0 + per, q1);
+        }
+        // one wave per SIMD: nothing else hides the table's load latency, so the next 64 candidates are fetched
+        // while the current ones are tested
+        DTri nxt = {0.0, 0.0, 0u, 0u};
+        if (q0 + lane < q1) nxt = tt_sorted[q0 + lane];
+        for (unsigned int base = q0; base < q1; base += 64) {
+            const unsigned int idx = base + lane;
+            const DTri t = nxt;
+            if (idx + 64 < q1) nxt = tt_sorted[idx + 64];
+            const bool keep = idx < q1 && t.lng >= win_lo && t.lng <= win_hi;
+            // the kept candidates stay in their lanes' registers and are broadcast one by one through the scalar unit
+            // (v_readlane): staging them in LDS cost two dependent LDS round trips per candidate with nothing to hide them
+            unsigned long long m = __ballot(keep);
+            while (m) {
+                const int q = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const double c_mid = lane_f64(t.mid, q), c_lng = lane_f64(t.lng, q);
+                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)t.verts, q);
+                if (ablate == 2 || !have || fabs(a.mid - c_mid) > kTriangleTolerance || fabs(a.lng - c_lng) > kTriangleTolerance) continue;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) atomicAdd(&votes[((a.verts >> (8 * p)) & 255u) * kLdsStride + ((b >> (8 * p)) & 255u)], 1u);
             }
-        __syncthreads();
+        }
     }
     __syncthreads();
-    for (int i = lane; i < kVoteDim * kVoteDim; i += 64) {
-        const unsigned int v = votes[i];
-        if (v) atomicAdd(&votes_out[i], v);
+    if (ablate == 1) return;
+    for (int row = 0; row < kVoteDim; ++row) {  // lane = column
+        const unsigned int v = votes[row * kLdsStride + lane];
+        if (v) atomicAdd(&votes_out[row * kVoteDim + lane], v);
     }
 }
 
@@ -567,7 +576,8 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
 // votes of the current ref / tgt triangle tables -> host (kVoteDim x kVoteDim)
 int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std::vector<uint32_t> *votes) {
     AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(tri_vote_kernel, dim3((kMaxTris + 63) / 64, 8), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes);
+    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes,
+                       getenv("AB_VOTE_ABLATE") ? atoi(getenv("AB_VOTE_ABLATE")) : 0);
     AB_HIP(ctx, hipGetLastError());
     votes->resize(kVoteDim * kVoteDim);
     AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -592,7 +602,6 @@ int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::
 
 }  // namespace
 
-// one target against the prepared reference (stars rs, triangle table in ref_ws); all device work on wc's stream
 // The reference frame's star list and triangle table, prepared on the caller's context while the workers already run
 // their targets' detection (the targets' detection does not depend on it): wait() blocks until it is there.
 struct RefTable {
@@ -618,6 +627,7 @@ struct RefTable {
     }
 };
 
+// one target against the reference being prepared (stars + triangle table in rt / ref_ws); all device work on wc's stream
 static int register_one(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const float *ref, const float *tgt, int64_t rows, int64_t cols,
                         int num_threads, ab_affine_align_result *out) {
     MatchWs w;
