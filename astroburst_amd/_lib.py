@@ -215,6 +215,7 @@ def lib() -> C.CDLL:
     L.ab_device_info.argtypes = [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     L.ab_stack_sigma_clip.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, C.POINTER(C.c_uint64)]
     L.ab_stack_last_rejected.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ab_stack_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.ab_stack_images.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, C.POINTER(C.c_int32),
                                   C.POINTER(C.c_uint64)]
     L.ab_stack_sigma_clip_partial.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), C.c_int64, C.c_int64,

@@ -288,6 +288,12 @@ class Context:
         self._check(self._L.ab_stack_last_rejected(self._h, C.byref(rej)))
         return int(rej.value)
 
+
+    def stack_last_kernel_ms(self) -> float:
+        """duration of the last stack launch's kernels (HIP events recorded by the library on the launch stream)"""
+        ms = C.c_float()
+        self._check(self._L.ab_stack_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
     def stack_images(self, images, sigma_low=3.0, sigma_high=3.0, max_iterations=5, align=True) -> StackResult:
         """stack_images(&[Array2<f32>], &StackConfig) (combine.rs:94-193)."""
         n = len(images)

@@ -68,6 +68,9 @@ struct ab_ctx {
     int register_workers = 12;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
+    // HIP events recorded on ctx->stream right around the stack kernels of the last ab_stack_* call (ab_stack_last_kernel_ms)
+    hipEvent_t stack_ev[2] = {nullptr, nullptr};
+    bool stack_ev_valid = false;
 };
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);

@@ -65,6 +65,8 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     if (ctx->sel_hist) (void)hipFree(ctx->sel_hist);
     for (int i = 0; i < AB_WS_SLOTS; ++i)
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    for (hipEvent_t e : ctx->stack_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

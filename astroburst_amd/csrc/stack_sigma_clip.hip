@@ -823,12 +823,18 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             !getenv("AB_STACK_SINGLE_PASS")) {
             AB_TRY(setup_defer(ctx, &args, total));
         }
+        for (hipEvent_t &e : ctx->stack_ev)
+            if (!e) AB_HIP(ctx, hipEventCreate(&e));
+        ctx->stack_ev_valid = false;
+        AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
         if (median_only)
             AB_TRY((launch_stack<false, false, 10>(ctx, args, np)));
         else if (ctx->stack_exact)
             AB_TRY(partial ? (launch_stack<true, true>(ctx, args, np)) : (launch_stack<false, true>(ctx, args, np)));
         else
             AB_TRY(partial ? (launch_stack<true, false>(ctx, args, np)) : (launch_stack<false, false>(ctx, args, np)));
+        AB_HIP(ctx, hipEventRecord(ctx->stack_ev[1], ctx->stream));
+        ctx->stack_ev_valid = true;
     }
     if (getenv("AB_TRACE") && n > 1) {  // developer aid: how many pixels the fast pass handed to the general pass
         std::vector<unsigned int> cnt(kDeferSlots, 0);
@@ -971,6 +977,15 @@ int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size
 #undef AB_RAW_CASE
     AB_HIP(ctx, hipGetLastError());
     if (out_rejected) AB_TRY(read_rejected(ctx, out_rejected));
+    return AB_OK;
+}
+
+int ab_stack_last_kernel_ms(ab_ctx *ctx, float *out_ms) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, out_ms, "null argument");
+    AB_CHECK(ctx, ctx->stack_ev_valid, "no multi-frame stack has been launched on this context");
+    AB_HIP(ctx, hipEventSynchronize(ctx->stack_ev[1]));
+    AB_HIP(ctx, hipEventElapsedTime(out_ms, ctx->stack_ev[0], ctx->stack_ev[1]));
     return AB_OK;
 }
 

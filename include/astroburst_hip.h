@@ -98,6 +98,10 @@ AB_API int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, co
 /* Passing out_rejected = NULL to ab_stack_sigma_clip keeps the call fully asynchronous on the
  * context's stream; the count of that last stack can be fetched later (synchronises). */
 AB_API int ab_stack_last_rejected(ab_ctx *ctx, uint64_t *out_rejected);
+/* milliseconds between the HIP events the library records on the context's stream immediately before the first and
+ * after the last stack kernel of the most recent multi-frame ab_stack_* call (blocks until that call has finished):
+ * the kernels' own duration, free of the caller's launch overhead (bench.py's roofline) */
+AB_API int ab_stack_last_kernel_ms(ab_ctx *ctx, float *out_ms);
 
 /* stack_images (combine.rs:94-193): crops to the minimum dims, optionally registers frames
  * 1..n-1 on frame 0 (PhaseCorrelation, combine.rs:126-138), then sigma-clip combines.
