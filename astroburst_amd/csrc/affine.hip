@@ -345,7 +345,7 @@ bool affine_from_stars(std::vector<Pt> rs, std::vector<Pt> ts, int64_t rows, int
 struct DTri {
     double mid, lng;
     uint32_t verts;  // sort_triangle_vertices order: v0 | v1 << 8 | v2 << 16
-    uint32_t pad;
+    uint32_t bin;    // tri_bin(mid), kept so the bucketing passes need not redo the f64 division
 };
 
 constexpr int kTriLimit = 60;            // build_triangles' `limit` (:285)
@@ -367,10 +367,15 @@ struct StarXY {
     double xy[kTriLimit * 2];
 };
 
-__global__ __launch_bounds__(256) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
-                                                        unsigned int *__restrict__ bin_hist /* nullable */) {
+__global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
+                                                         unsigned int *__restrict__ bin_hist /* nullable; zero on entry */) {
+    __shared__ unsigned int lhist[kTriBins];  // this block's share of the bucket histogram: one global atomic per touched bucket
+    if (bin_hist) {
+        for (int b = threadIdx.x; b < kTriBins; b += 1024) lhist[b] = 0;
+        __syncthreads();
+    }
     const double *xy = stars.xy;
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.x * 1024 + threadIdx.x;
     const int i = t / (limit * limit), j = (t / limit) % limit, k = t % limit;
     bool ok = i < limit && i < j && j < k;
     DTri tri = {0.0, 0.0, 0u, 0u};
@@ -388,28 +393,43 @@ __global__ __launch_bounds__(256) void tri_build_kernel(const StarXY stars, int 
         tri.lng = s2 / s0;
         // sort_triangle_vertices (:386-398): vertices by the length of the opposite side, stable
         int v0 = i, v1 = j, v2 = k;
-        double o0 = ddist(xj, yj, xk, yk), o1 = ddist(xi, yi, xk, yk), o2 = ddist(xi, yi, xj, yj);
+        double o0 = djk, o1 = dik, o2 = dij;
         if (o1 < o0) { const double q = o0; o0 = o1; o1 = q; const int w = v0; v0 = v1; v1 = w; }
         if (o2 < o1) {
             { const double q = o1; o1 = o2; o2 = q; const int w = v1; v1 = v2; v2 = w; }
             if (o1 < o0) { const double q = o0; o0 = o1; o1 = q; const int w = v0; v0 = v1; v1 = w; }
         }
         tri.verts = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16);
+        tri.bin = ok ? (uint32_t)tri_bin(tri.mid) : 0u;
     }
+    // slots: one global atomic per BLOCK (a same-address atomic with return costs ~12 ns; 3375 per-wave ones were 40 us)
+    __shared__ unsigned int wave_cnt[16], block_base;
     const unsigned long long m = __ballot(ok);
-    if (m == 0) return;
-    const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(count, (unsigned int)__builtin_popcountll(m));
-    base = __shfl(base, leader, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wv] = (unsigned int)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int tot = 0;
+        for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+        block_base = tot ? atomicAdd(count, tot) : 0u;
+    }
+    __syncthreads();
     if (ok) {
+        unsigned int base = block_base;
+        for (int w = 0; w < wv; ++w) base += wave_cnt[w];
         out[base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = tri;
-        if (bin_hist) atomicAdd(&bin_hist[tri_bin(tri.mid)], 1u);
+        if (bin_hist) atomicAdd(&lhist[tri.bin], 1u);
+    }
+    if (bin_hist) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < kTriBins; b += 1024)
+            if (lhist[b]) atomicAdd(&bin_hist[b], lhist[b]);
     }
 }
 
-// exclusive scan of the 4096 bucket counts (one 1024-thread block); also rewinds the scatter cursors
-__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(const unsigned int *__restrict__ hist, unsigned int *__restrict__ off /* kTriBins + 1 */,
+// exclusive scan of the 4096 bucket counts (one 1024-thread block); sets the scatter cursors and re-zeroes the
+// histogram for the next table
+__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ off /* kTriBins + 1 */,
                                                             unsigned int *__restrict__ cursor) {
     __shared__ unsigned int wave_tot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -426,23 +446,39 @@ __global__ __launch_bounds__(1024) void tri_bin_scan_kernel(const unsigned int *
     unsigned int base = 0;
     for (int i = 0; i < wv; ++i) base += wave_tot[i];
     const unsigned int e = base + inc - s;
-    off[4 * t] = e;
-    off[4 * t + 1] = e + h0;
-    off[4 * t + 2] = e + h0 + h1;
-    off[4 * t + 3] = e + h0 + h1 + h2;
-    cursor[4 * t] = e;
-    cursor[4 * t + 1] = e + h0;
-    cursor[4 * t + 2] = e + h0 + h1;
-    cursor[4 * t + 3] = e + h0 + h1 + h2;
+    const unsigned int c[4] = {e, e + h0, e + h0 + h1, e + h0 + h1 + h2};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        off[4 * t + j] = c[j];
+        cursor[4 * t + j] = c[j];
+        hist[4 * t + j] = 0;
+    }
     if (t == 1023) off[kTriBins] = e + s;
 }
 
-__global__ __launch_bounds__(256) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
-                                                          DTri *__restrict__ sorted) {
-    const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= *n_p) return;
-    const DTri t = in[i];
-    sorted[atomicAdd(&cursor[tri_bin(t.mid)], 1u)] = t;  // order inside a bucket is irrelevant: votes are counts
+// Bucket scatter.  A block ranks its 1024 triangles inside their buckets with LDS atomics and reserves each touched
+// bucket's range with ONE global atomic (per-triangle global cursor atomics-with-return serialised on the dense buckets:
+// 845 triangles in the fullest one, ~12 ns each, 41 us for the kernel).
+__global__ __launch_bounds__(1024) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
+                                                           DTri *__restrict__ sorted) {
+    __shared__ unsigned int cnt[kTriBins];  // per-bucket count of this block, then the bucket's reserved base
+    const unsigned int n = *n_p, i = blockIdx.x * 1024 + threadIdx.x;
+    if (blockIdx.x * 1024 >= n) return;
+    for (int b = threadIdx.x; b < kTriBins; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    DTri t = {0.0, 0.0, 0u, 0u};
+    unsigned int rank = 0;
+    if (i < n) {
+        t = in[i];
+        rank = atomicAdd(&cnt[t.bin], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kTriBins; b += 1024) {
+        const unsigned int c = cnt[b];
+        if (c) cnt[b] = atomicAdd(&cursor[b], c);
+    }
+    __syncthreads();
+    if (i < n) sorted[cnt[t.bin] + rank] = t;  // order inside a bucket is irrelevant: votes are counts
 }
 
 // The tgt table is bucketed by ratio_mid (tri_scatter_kernel); the ref table is sorted by (ratio_mid bucket,
@@ -534,7 +570,10 @@ int match_ws(ab_ctx *ctx, MatchWs *w) {
     const size_t bin_words = 64 + 3 * (size_t)kTriBins + 64;
     const size_t total = 4 * tri_bytes + bin_words * sizeof(unsigned int) + vote_bytes;
     char *p = nullptr;
+    const void *before = ctx->ws[AB_WS_REGISTER];
     AB_TRY(ab_workspace(ctx, AB_WS_REGISTER, total, (void **)&p));
+    if (p != before)  // bin_hist is kept zero between uses (tri_bin_scan_kernel clears what it read): only a fresh workspace needs it
+        AB_HIP(ctx, hipMemsetAsync(p + 4 * tri_bytes, 0, bin_words * sizeof(unsigned int), ctx->stream));
     w->ref_tris = (DTri *)p;
     w->tgt_tris = (DTri *)(p + tri_bytes);
     w->tgt_sorted = (DTri *)(p + 2 * tri_bytes);
@@ -558,15 +597,14 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
         xy.xy[2 * i + 1] = stars[i][1];
     }
     AB_HIP(ctx, hipMemsetAsync(w.counts + which, 0, sizeof(unsigned int), ctx->stream));
-    AB_HIP(ctx, hipMemsetAsync(w.bin_hist, 0, kTriBins * sizeof(unsigned int), ctx->stream));
     if (limit >= 3) {
         const int total = limit * limit * limit;
-        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, xy, limit, which ? w.tgt_tris : w.ref_tris,
-                           w.counts + which, w.bin_hist);
+        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 1023) / 1024), dim3(1024), 0, ctx->stream, xy, limit, which ? w.tgt_tris : w.ref_tris,
+                           w.counts + which, which ? w.bin_hist : nullptr);
     }
-    if (which) {  // bucket the tgt table by ratio_mid for the vote kernel
+    if (which) {  // bucket the tgt table by ratio_mid for the vote kernel (the scan leaves bin_hist zeroed again)
         hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
-        hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 255) / 256), dim3(256), 0, ctx->stream, w.tgt_tris, w.counts + 1, w.cursor,
+        hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 1023) / 1024), dim3(1024), 0, ctx->stream, w.tgt_tris, w.counts + 1, w.cursor,
                            w.tgt_sorted);
     }
     AB_HIP(ctx, hipGetLastError());
