@@ -137,20 +137,43 @@ __device__ __forceinline__ bool above(float v, double threshold) { return __buil
 constexpr int kInitSpan = 8192;  // pixels per block
 __global__ __launch_bounds__(256) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
                                                          double threshold, const ab_pixel_xf xf, int *__restrict__ parent,
-                                                         int *__restrict__ plist, unsigned int *nlab) {
+                                                         int *__restrict__ plist, unsigned int *nlab, int vec_ok) {
     __shared__ int found[kInitSpan];
     __shared__ unsigned int nfound, base;
     if (threadIdx.x == 0) nfound = 0;
     __syncthreads();
     const int P = rows * cols, start = blockIdx.x * kInitSpan;
+    if (vec_ok) {  // contiguous 16-byte aligned plane of 4 k pixels: no row / column arithmetic (a 32-bit division per pixel), 16-byte accesses
+        const float4 *img4 = reinterpret_cast<const float4 *>(img);
+        int4 *parent4 = reinterpret_cast<int4 *>(parent);
+#pragma unroll 2
+        for (int off = threadIdx.x * 4; off < kInitSpan; off += 1024) {
+            const int i = start + off;
+            if (i < P) {
+                const float4 v = img4[i >> 2];
+                const bool b0 = above(ab_px(xf, v.x), threshold), b1 = above(ab_px(xf, v.y), threshold), b2 = above(ab_px(xf, v.z), threshold),
+                           b3 = above(ab_px(xf, v.w), threshold);
+                parent4[i >> 2] = make_int4(b0 ? i : -1, b1 ? i + 1 : -1, b2 ? i + 2 : -1, b3 ? i + 3 : -1);
+                const int cnt = (int)b0 + (int)b1 + (int)b2 + (int)b3;
+                if (cnt) {  // ascending order inside the thread; the list's order across threads is irrelevant
+                    unsigned int at = atomicAdd(&nfound, (unsigned int)cnt);
+                    if (b0) found[at++] = i;
+                    if (b1) found[at++] = i + 1;
+                    if (b2) found[at++] = i + 2;
+                    if (b3) found[at++] = i + 3;
+                }
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int off = threadIdx.x; off < kInitSpan; off += 256) {
-        const int i = start + off;
-        if (i < P) {
-            const int r = i / cols, c = i - r * cols;
-            const bool is = above(ab_px(xf, img[r * ld + c]), threshold);
-            parent[i] = is ? i : -1;
-            if (is) found[atomicAdd(&nfound, 1u)] = i;
+        for (int off = threadIdx.x; off < kInitSpan; off += 256) {
+            const int i = start + off;
+            if (i < P) {
+                const int r = i / cols, c = i - r * cols;
+                const bool is = above(ab_px(xf, img[r * ld + c]), threshold);
+                parent[i] = is ? i : -1;
+                if (is) found[atomicAdd(&nfound, 1u)] = i;
+            }
         }
     }
     __syncthreads();
@@ -250,18 +273,50 @@ __global__ __launch_bounds__(256) void comp_init_kernel(CompStat *st, unsigned i
 __global__ __launch_bounds__(256) void comp_stats_kernel(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st,
                                                          const int *__restrict__ plist, const unsigned int *__restrict__ nlab) {
     const unsigned int n = *nlab;
-    for (unsigned int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
-        const int i = plist[k];
-        const int root = uf_find(parent, i);
-        __hip_atomic_store(&parent[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        CompStat *s = &st[cid[root]];
+    const int lane = threadIdx.x & 63;
+    // wave-uniform trip count (the shuffles below need every lane); consecutive list entries are mostly row neighbours
+    // of one component, so each RUN of equal roots inside a wave is folded by shuffles and only its first lane issues
+    // the six atomics (per-pixel atomics on a component's record serialise: 46 us per frame)
+    for (unsigned int k0 = blockIdx.x * 256 + (threadIdx.x & ~63); k0 < n; k0 += gridDim.x * 256) {
+        const unsigned int k = k0 + lane;
+        const bool valid = k < n;
+        int root = -1 - lane, i = 0;  // invalid lanes: pairwise distinct pseudo-roots, never equal to a real one
+        if (valid) {
+            i = plist[k];
+            root = uf_find(parent, i);
+            __hip_atomic_store(&parent[i], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const int r = i / cols, c = i - r * cols;
-        atomicAdd(&s->npix, 1);
-        atomicMin(&s->x0, c);
-        atomicMax(&s->x1, c);
-        atomicMin(&s->y0, r);
-        atomicMax(&s->y1, r);
-        if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) atomicMin(&s->first_interior, i);  // BFS seeds are interior (:107-110)
+        const bool interior = r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1;  // BFS seeds are interior (:107-110)
+        int npix = 1, x0 = c, x1 = c, y0 = r, y1 = r, fi = interior ? i : 0x7fffffff;
+        const int prev = __shfl_up(root, 1, 64);
+        const bool head = lane == 0 || prev != root;
+        // run length to the right of every lane, by doubling: a lane folds in its right neighbour block only while that
+        // block still belongs to the same run (run id = number of heads up to the lane)
+        const unsigned long long heads = __ballot(head);
+        const int run = (int)__builtin_popcountll(heads & ((2ull << lane) - 1ull));
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o_run = __shfl_down(run, d, 64), o_n = __shfl_down(npix, d, 64), o_x0 = __shfl_down(x0, d, 64), o_x1 = __shfl_down(x1, d, 64),
+                      o_y0 = __shfl_down(y0, d, 64), o_y1 = __shfl_down(y1, d, 64), o_fi = __shfl_down(fi, d, 64);
+            if (lane + d < 64 && o_run == run) {
+                npix += o_n;
+                x0 = min(x0, o_x0);
+                x1 = max(x1, o_x1);
+                y0 = min(y0, o_y0);
+                y1 = max(y1, o_y1);
+                fi = min(fi, o_fi);
+            }
+        }
+        if (valid && head) {
+            CompStat *s = &st[cid[root]];
+            atomicAdd(&s->npix, npix);
+            atomicMin(&s->x0, x0);
+            atomicMax(&s->x1, x1);
+            atomicMin(&s->y0, y0);
+            atomicMax(&s->y1, y1);
+            if (fi != 0x7fffffff) atomicMin(&s->first_interior, fi);
+        }
     }
 }
 
@@ -429,7 +484,8 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     const int gl = (ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;  // list kernels: grid-stride over *nlab entries
     AB_HIP(ctx, hipMemsetAsync(nroots, 0, 2 * sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(label_init_kernel, dim3((unsigned)((P + kInitSpan - 1) / kInitSpan)), dim3(256), 0, ctx->stream, img, (int)rows,
-                       (int)cols, ld, threshold, xf, parent, plist, nlab);
+                       (int)cols, ld, threshold, xf, parent, plist, nlab,
+                       (int)(ld == cols && (P & 3) == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)parent & 15) == 0));
     hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, plist, nlab);
     hipLaunchKernelGGL(roots_kernel, dim3(gl), dim3(256), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
     AB_HIP(ctx, hipGetLastError());
