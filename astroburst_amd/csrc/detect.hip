@@ -234,14 +234,18 @@ struct CompRec {  // what the host needs to finish one star (star_detection.rs:1
     double sum_flux, sum_x, sum_y, peak, sum_r2, sum_xx, sum_yy, sum_xy;
 };
 
-// number the component roots (parent[i] == i) among the labelled pixels; one atomic per wave on the tail
-__global__ __launch_bounds__(256) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist,
-                                                    const unsigned int *__restrict__ nlab, int *__restrict__ roots, int *__restrict__ cid,
-                                                    unsigned int *nroots, unsigned int cap) {
+// number the component roots (parent[i] == i) among the labelled pixels; one atomic per 1024-thread block and round on the
+// tail (one per WAVE serialised on that single counter: ~2500 x 12 ns per frame)
+constexpr int kRootsBlock = 1024;
+__global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist,
+                                                            const unsigned int *__restrict__ nlab, int *__restrict__ roots, int *__restrict__ cid,
+                                                            unsigned int *nroots, unsigned int cap) {
+    __shared__ unsigned int wave_cnt[kRootsBlock / 64], block_base;
     const unsigned int n = *nlab;
-    const unsigned int rounds = (n + gridDim.x * 256 - 1) / (gridDim.x * 256);  // uniform trip count (ballots inside)
+    const unsigned int rounds = (n + gridDim.x * kRootsBlock - 1) / (gridDim.x * kRootsBlock);  // uniform trip count (barriers inside)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (unsigned int it = 0; it < rounds; ++it) {
-        const unsigned int k = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        const unsigned int k = (it * gridDim.x + blockIdx.x) * kRootsBlock + threadIdx.x;
         int i = -1;
         bool is = false;
         if (k < n) {
@@ -249,18 +253,23 @@ __global__ __launch_bounds__(256) void roots_kernel(const int *__restrict__ pare
             is = parent[i] == i;
         }
         const unsigned long long m = __ballot(is);
-        if (m == 0) continue;
-        const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
-        unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(nroots, (unsigned int)__builtin_popcountll(m));
-        base = __shfl(base, leader, 64);
+        if (lane == 0) wave_cnt[wv] = (unsigned int)__builtin_popcountll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int tot = 0;
+            for (int w = 0; w < kRootsBlock / 64; ++w) tot += wave_cnt[w];
+            block_base = tot ? atomicAdd(nroots, tot) : 0u;
+        }
+        __syncthreads();
         if (is) {
-            const unsigned int pos = base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            unsigned int pos = block_base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wv; ++w) pos += wave_cnt[w];
             if (pos < cap) {
                 roots[pos] = i;
                 cid[i] = (int)pos;
             }
         }
+        __syncthreads();  // wave_cnt / block_base are rewritten next round
     }
 }
 
@@ -487,7 +496,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
                        (int)cols, ld, threshold, xf, parent, plist, nlab,
                        (int)(ld == cols && (P & 3) == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)parent & 15) == 0));
     hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, plist, nlab);
-    hipLaunchKernelGGL(roots_kernel, dim3(gl), dim3(256), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
+    hipLaunchKernelGGL(roots_kernel, dim3(gl / 4), dim3(kRootsBlock), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
     AB_HIP(ctx, hipGetLastError());
     unsigned int ncomp = 0;
     AB_HIP(ctx, hipMemcpyAsync(&ncomp, nroots, sizeof ncomp, hipMemcpyDeviceToHost, ctx->stream));
