@@ -498,18 +498,18 @@ constexpr int kVoteBlocks = 1024;  // persistent one-wave blocks: each flushes i
                                    // serialises its atomics at ~12 ns each: 4280 per-item flushes cost 50 us, 1024 cost 12)
 __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
-                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */, int ablate) {
+                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */, int ablate, int nslices) {
     // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and with a stride of 64
     // (a multiple of the bank count) all of those atomics would land in one bank
     constexpr int kLdsStride = kVoteDim + 1;
     __shared__ unsigned int votes[kVoteDim * kLdsStride];
     const int lane = threadIdx.x;
-    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * kVoteSlices;
+    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * nslices;
     if (blockIdx.x >= items) return;
     for (int i = lane; i < kVoteDim * kLdsStride; i += 64) votes[i] = 0;
     __syncthreads();
     for (unsigned int item = blockIdx.x; item < items; item += gridDim.x) {
-        const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
+        const unsigned int first = (item / nslices) * 64, slice = item % nslices, r = first + lane;
         const bool have = r < nr;
         const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
         double lmin = a.lng, lmax = a.lng;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
         const int bmin = tri_bin(rt_sorted[first].mid), bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
         unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
         {
-            const unsigned int per = (q1 - q0 + kVoteSlices - 1) / kVoteSlices;
+            const unsigned int per = (q1 - q0 + nslices - 1) / nslices;
             q0 = min(q0 + slice * per, q1);
             q1 = min(q0 + per, q1);
         }
@@ -614,8 +614,10 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
 // votes of the current ref / tgt triangle tables -> host (kVoteDim x kVoteDim)
 int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std::vector<uint32_t> *votes) {
     AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes,
-                       getenv("AB_VOTE_ABLATE") ? atoi(getenv("AB_VOTE_ABLATE")) : 0);
+    static const int blocks = getenv("AB_VOTE_BLOCKS") ? atoi(getenv("AB_VOTE_BLOCKS")) : kVoteBlocks;
+    static const int slices = getenv("AB_VOTE_SLICES") ? atoi(getenv("AB_VOTE_SLICES")) : kVoteSlices;
+    hipLaunchKernelGGL(tri_vote_kernel, dim3(blocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes,
+                       getenv("AB_VOTE_ABLATE") ? atoi(getenv("AB_VOTE_ABLATE")) : 0, slices);
     AB_HIP(ctx, hipGetLastError());
     votes->resize(kVoteDim * kVoteDim);
     AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
