@@ -435,14 +435,15 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
     AB_CHECK(ctx, step <= 256, "background tiles larger than 256 px are not supported (tile_size %lld)", (long long)tile_size);
     const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step);
     const int ntiles = nty * ntx;
-    void *d = nullptr;
-    AB_TRY(ab_scratch(ctx, (size_t)ntiles * sizeof(TileOut), &d));
+    // small results go straight into the context's pinned host buffer (device-visible): no copy command, no bounce
+    // through the runtime's staging pages for a pageable destination, just the stream sync
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, (size_t)ntiles * sizeof(TileOut), &pin));
     hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(absel::kBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
-                       ntx, xf, (TileOut *)d);
+                       ntx, xf, (TileOut *)pin);
     AB_HIP(ctx, hipGetLastError());
-    std::vector<TileOut> h(ntiles);
-    AB_HIP(ctx, hipMemcpyAsync(h.data(), d, (size_t)ntiles * sizeof(TileOut), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const std::vector<TileOut> h((const TileOut *)pin, (const TileOut *)pin + ntiles);
     std::vector<double> med, sig;
     for (const auto &t : h)
         if (t.valid) {
@@ -498,24 +499,24 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, plist, nlab);
     hipLaunchKernelGGL(roots_kernel, dim3(gl / 4), dim3(kRootsBlock), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
     AB_HIP(ctx, hipGetLastError());
-    unsigned int ncomp = 0;
-    AB_HIP(ctx, hipMemcpyAsync(&ncomp, nroots, sizeof ncomp, hipMemcpyDeviceToHost, ctx->stream));
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, 64, &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, nroots, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned int ncomp = *(const unsigned int *)pin;
     trace.mark("label+roots");
     AB_CHECK(ctx, ncomp <= root_cap, "detect_stars: %u components exceed the table capacity", ncomp);
     if (ncomp == 0) return AB_OK;
     void *cbuf = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, (size_t)ncomp * (sizeof(CompStat) + sizeof(CompRec)), &cbuf));
-    CompRec *drec = (CompRec *)cbuf;
-    CompStat *dstat = (CompStat *)(drec + ncomp);
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, (size_t)ncomp * sizeof(CompStat), &cbuf));
+    CompStat *dstat = (CompStat *)cbuf;
+    AB_TRY(ab_pinned(ctx, (size_t)ncomp * sizeof(CompRec), &pin));  // the moments kernel writes its records straight to the host
+    CompRec *drec = (CompRec *)pin;
     hipLaunchKernelGGL(comp_init_kernel, dim3((ncomp + 255) / 256), dim3(256), 0, ctx->stream, dstat, ncomp);
     hipLaunchKernelGGL(comp_stats_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, cid, dstat, plist, nlab);
     hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, roots, dstat, ncomp,
                        bg_median, xf, drec);
     AB_HIP(ctx, hipGetLastError());
-    void *pin = nullptr;  // pinned staging: a pageable destination costs an extra bounce inside the runtime
-    AB_TRY(ab_pinned(ctx, (size_t)ncomp * sizeof(CompRec), &pin));
-    AB_HIP(ctx, hipMemcpyAsync(pin, drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const CompRec *recs_begin = (const CompRec *)pin, *recs_end = recs_begin + ncomp;
 
@@ -603,13 +604,10 @@ int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pi
     if (len == 0) return AB_OK;
     const int64_t step = std::max<int64_t>(len / 100000, 1);
     const int64_t ns = (len + step - 1) / step;
-    void *d = nullptr;
-    AB_TRY(ab_scratch(ctx, (size_t)ns * sizeof(float), &d));
-    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, len, step, (float *)d, ns);
-    AB_HIP(ctx, hipGetLastError());
-    void *pin = nullptr;
+    void *pin = nullptr;  // the subsample is written straight into pinned host memory
     AB_TRY(ab_pinned(ctx, (size_t)ns * sizeof(float), &pin));
-    AB_HIP(ctx, hipMemcpyAsync(pin, d, (size_t)ns * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, len, step, (float *)pin, ns);
+    AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<float> s((const float *)pin, (const float *)pin + ns);
     s.erase(std::remove_if(s.begin(), s.end(), [](float v) { return !std::isfinite(v); }), s.end());
