@@ -65,7 +65,9 @@ struct BatchArgs {
     uint32_t per_block;  // 0: block b takes chunks b, b + grid, ...; else chunks [b * per_block, (b + 1) * per_block)
 };
 
-// calibrate_light's per-pixel chain (:93-113) in its f32 operation order
+// calibrate_light's per-pixel chain (:93-113) in its f32 operation order.  (Tried: sharing the Newton-refined reciprocal
+// of the flat across a pixel's n frames and finishing each quotient with the four fma of the hardware-assisted expansion --
+// bit-exact on 50 M random operand pairs, but the per-sample range check and wave vote it needs made both kernels slower.)
 struct CalPx {
     float b, d, f;
     bool has_b, has_d, div;
@@ -286,41 +288,56 @@ __global__ __launch_bounds__(256) void rej_reduce_kernel(const uint32_t *__restr
     if (threadIdx.x == 0) out[f] = red[0];
 }
 
-// per-frame f64 sums of the calibrated samples: part[block][f]
-template <int NP>
+// per-frame f64 sums of the calibrated samples: part[block][f].  blockIdx.y selects a group of FR <= 32 frames (64
+// frames deep the accumulators alone would take 128 VGPRs and leave no room to prefetch); the next pixels' samples are
+// in flight while the current ones are converted and added.
+template <int FR>
 __global__ __launch_bounds__(kSumBlock) void cal_means_kernel(const BatchArgs a, double *__restrict__ part) {
-    double acc[NP];
+    double acc[FR];
 #pragma unroll
-    for (int f = 0; f < NP; ++f) acc[f] = 0.0;
-    const uint32_t stride = gridDim.x * kSumBlock;
-    const uint64_t myptr = (uint64_t)a.p[threadIdx.x & 63];
+    for (int f = 0; f < FR; ++f) acc[f] = 0.0;
+    const int first = blockIdx.y * FR;
+    const uint32_t stride = gridDim.x * kSumBlock, bytes = a.npix * 4u;
+    const uint64_t myptr = (uint64_t)a.p[first + ((threadIdx.x & 63) % FR)];
     const uint32_t plo = (uint32_t)myptr, phi = (uint32_t)(myptr >> 32);
     // wave-uniform trip count: gather() moves the lane-resident pointers through a register copy, which only the ACTIVE
     // lanes take part in -- a lane that had left the loop would hand v_readlane a stale base
-    for (uint32_t g0 = blockIdx.x * kSumBlock; g0 < a.npix; g0 += stride) {
-        const uint32_t g = g0 + threadIdx.x;
-        const bool valid = g < a.npix;
-        const uint32_t gi = valid ? g : a.npix - 1;
-        const CalPx c = cal_load(a.m, gi);
-        float u[NP];
-        gather<NP>(u, plo, phi, gi, a.npix * 4u);  // slots past n alias frame 0; their sums are never read
-#pragma unroll
-        for (int f = 0; f < NP; ++f) acc[f] += valid ? (double)cal_apply(u[f], c) : 0.0;
+    float nxt[FR];
+    CalPx cnxt{};
+    uint32_t g0 = blockIdx.x * kSumBlock;
+    if (g0 < a.npix) {
+        const uint32_t g = g0 + threadIdx.x, gi = g < a.npix ? g : a.npix - 1;
+        gather<FR>(nxt, plo, phi, gi, bytes);
+        cnxt = cal_load(a.m, gi);
     }
-    __shared__ double red[kSumBlock / kWave][kMaxFrames];
+    for (; g0 < a.npix; g0 += stride) {
+        const bool valid = g0 + threadIdx.x < a.npix;
+        float u[FR];
+#pragma unroll
+        for (int f = 0; f < FR; ++f) u[f] = nxt[f];
+        const CalPx c = cnxt;
+        if (g0 + stride < a.npix) {
+            const uint32_t g = g0 + stride + threadIdx.x, gi = g < a.npix ? g : a.npix - 1;
+            gather<FR>(nxt, plo, phi, gi, bytes);
+            cnxt = cal_load(a.m, gi);
+        }
+#pragma unroll
+        for (int f = 0; f < FR; ++f) acc[f] += valid ? (double)cal_apply(u[f], c) : 0.0;
+    }
+    __shared__ double red[kSumBlock / kWave][FR];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int f = 0; f < NP; ++f) {
+    for (int f = 0; f < FR; ++f) {
         double s = acc[f];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) red[wave][f] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NP) {
+    if (threadIdx.x < FR) {
         double s = 0.0;
         for (int w = 0; w < kSumBlock / kWave; ++w) s += red[w][threadIdx.x];
-        part[(size_t)blockIdx.x * kMaxFrames + threadIdx.x] = s;
+        part[(size_t)blockIdx.x * kMaxFrames + first + threadIdx.x] = s;
     }
 }
 
@@ -472,10 +489,11 @@ int launch_scms(ab_ctx *ctx, int np, const BatchArgs &a, int64_t nchunks, uint32
 
 template <int NP>
 int launch_means_np(ab_ctx *ctx, const BatchArgs &a, std::vector<double> *part, int *grid_out) {
-    const int grid = resident_grid(ctx, cal_means_kernel<NP>, kSumBlock, 0, ((int64_t)a.npix + kSumBlock - 1) / kSumBlock);
+    constexpr int FR = NP < 32 ? NP : 32, kGroups = NP / FR;
+    const int grid = std::max(1, resident_grid(ctx, cal_means_kernel<FR>, kSumBlock, 0, ((int64_t)a.npix + kSumBlock - 1) / kSumBlock * kGroups) / kGroups);
     void *d = nullptr;
     AB_TRY(ab_scratch(ctx, (size_t)grid * kMaxFrames * sizeof(double), &d));
-    hipLaunchKernelGGL(cal_means_kernel<NP>, dim3(grid), dim3(kSumBlock), 0, ctx->stream, a, (double *)d);
+    hipLaunchKernelGGL(cal_means_kernel<FR>, dim3(grid, kGroups), dim3(kSumBlock), 0, ctx->stream, a, (double *)d);
     AB_HIP(ctx, hipGetLastError());
     part->resize((size_t)grid * kMaxFrames);
     *grid_out = grid;

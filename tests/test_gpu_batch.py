@@ -55,6 +55,32 @@ def test_calibrate_and_normalize(ctx, oracle):
         assert same(g, w)
 
 
+def test_calibrate_light_division_is_ieee_exact_at_scale(ctx, oracle):
+    """3 x 16.7 M flat divisions with ordinary, extreme and special operands must equal the C division bit for bit
+    (guards any future shortcut in csrc/batch_pipeline.hip cal_apply)"""
+    rng = np.random.default_rng(7)
+    shape = (4096, 4096)
+    for case in range(3):
+        if case == 0:    # what frames look like: ADU counts over flats near 1
+            light = rng.uniform(0.0, 65535.0, shape).astype(np.float32)
+            flat = rng.normal(1.0, 0.15, shape).astype(np.float32)
+        elif case == 1:  # random bit patterns: every exponent, both signs, NaN / inf / denormals
+            light = rng.integers(0, 2**32, shape, dtype=np.uint32).view(np.float32)
+            flat = rng.integers(0, 2**32, shape, dtype=np.uint32).view(np.float32)
+        else:            # quotients around the range limits of the shortcut, exact zeros, flats at the 1e-4 threshold
+            light = (rng.uniform(1.0, 2.0, shape) * 2.0 ** rng.integers(-70, 70, shape)).astype(np.float32)
+            light[rng.random(shape) < 0.01] = 0.0
+            flat = (rng.uniform(1.0, 2.0, shape) * 2.0 ** rng.integers(-14, 70, shape)).astype(np.float32)
+            flat[rng.random(shape) < 0.01] = np.float32(1e-4)
+            flat[rng.random(shape) < 0.01] *= -1.0
+        with np.errstate(all="ignore"):
+            want = oracle.calibrate_light(light, None, None, flat)
+        got = ctx.calibrate_light(light, None, None, flat)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)) or same(got, want), case
+        bad = ~((got == want) | (np.isnan(got) & np.isnan(want)))
+        assert not bad.any(), (case, int(bad.sum()))
+
+
 @pytest.mark.parametrize("normalize", [True, False])
 @pytest.mark.parametrize("n", [5, 16, 40])
 def test_run_batch_channel_fused_equals_the_three_steps(ctx, oracle, n, normalize):
