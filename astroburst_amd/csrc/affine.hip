@@ -493,23 +493,25 @@ __device__ __forceinline__ double lane_f64(double x, int lane) {  // wave-unifor
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-constexpr int kVoteSlices = 8;    // slices of a ref group's candidate range (dense buckets would otherwise leave a few very long waves)
-constexpr int kVoteBlocks = 1024;  // persistent one-wave blocks: each flushes its LDS votes ONCE (a hot pair's global counter
-                                   // serialises its atomics at ~12 ns each: 4280 per-item flushes cost 50 us, 1024 cost 12)
+// slices of a ref group's candidate range (dense buckets would otherwise leave a few very long waves) x persistent one-wave
+// blocks, each flushing its LDS votes once.  Measured (blocks, slices) -> us per frame: (1024, 8) 62, (2048, 8) 74,
+// (2048, 16) 69, (1024, 4) 79, (4096, 8) 79: more blocks pay for more flushes, fewer slices for imbalance.
+constexpr int kVoteSlices = 8;
+constexpr int kVoteBlocks = 1024;
 __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
-                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */, int ablate, int nslices) {
+                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */) {
     // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and with a stride of 64
     // (a multiple of the bank count) all of those atomics would land in one bank
     constexpr int kLdsStride = kVoteDim + 1;
     __shared__ unsigned int votes[kVoteDim * kLdsStride];
     const int lane = threadIdx.x;
-    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * nslices;
+    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * kVoteSlices;
     if (blockIdx.x >= items) return;
     for (int i = lane; i < kVoteDim * kLdsStride; i += 64) votes[i] = 0;
     __syncthreads();
     for (unsigned int item = blockIdx.x; item < items; item += gridDim.x) {
-        const unsigned int first = (item / nslices) * 64, slice = item % nslices, r = first + lane;
+        const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
         const bool have = r < nr;
         const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
         double lmin = a.lng, lmax = a.lng;
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
         const int bmin = tri_bin(rt_sorted[first].mid), bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
         unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
         {
-            const unsigned int per = (q1 - q0 + nslices - 1) / nslices;
+            const unsigned int per = (q1 - q0 + kVoteSlices - 1) / kVoteSlices;
             q0 = min(q0 + slice * per, q1);
             q1 = min(q0 + per, q1);
         }
@@ -543,14 +545,13 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
                 m &= m - 1;
                 const double c_mid = lane_f64(t.mid, q), c_lng = lane_f64(t.lng, q);
                 const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)t.verts, q);
-                if (ablate == 2 || !have || fabs(a.mid - c_mid) > kTriangleTolerance || fabs(a.lng - c_lng) > kTriangleTolerance) continue;
+                if (!have || fabs(a.mid - c_mid) > kTriangleTolerance || fabs(a.lng - c_lng) > kTriangleTolerance) continue;
 #pragma unroll
                 for (int p = 0; p < 3; ++p) atomicAdd(&votes[((a.verts >> (8 * p)) & 255u) * kLdsStride + ((b >> (8 * p)) & 255u)], 1u);
             }
         }
     }
     __syncthreads();
-    if (ablate == 1) return;
     for (int row = 0; row < kVoteDim; ++row) {  // lane = column
         const unsigned int v = votes[row * kLdsStride + lane];
         if (v) atomicAdd(&votes_out[row * kVoteDim + lane], v);
@@ -614,10 +615,7 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
 // votes of the current ref / tgt triangle tables -> host (kVoteDim x kVoteDim)
 int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std::vector<uint32_t> *votes) {
     AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
-    static const int blocks = getenv("AB_VOTE_BLOCKS") ? atoi(getenv("AB_VOTE_BLOCKS")) : kVoteBlocks;
-    static const int slices = getenv("AB_VOTE_SLICES") ? atoi(getenv("AB_VOTE_SLICES")) : kVoteSlices;
-    hipLaunchKernelGGL(tri_vote_kernel, dim3(blocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes,
-                       getenv("AB_VOTE_ABLATE") ? atoi(getenv("AB_VOTE_ABLATE")) : 0, slices);
+    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes);
     AB_HIP(ctx, hipGetLastError());
     votes->resize(kVoteDim * kVoteDim);
     AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -737,8 +735,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         if (aligned) AB_TRY(ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]));  // pair.rs:59-61
         return AB_OK;
     };
-    static const bool serial_ref = getenv("AB_REGISTER_SERIAL_REF") != nullptr;  // developer A/B switch
-    const bool inline_run = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1)) <= 1 || serial_ref;
+    const bool inline_run = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1)) <= 1;
     if (inline_run) {  // the reference first, on ctx
         const int rc = prepare_reference();
         rt.publish(rc, rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);

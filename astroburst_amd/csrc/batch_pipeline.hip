@@ -463,9 +463,8 @@ int launch_scms_np(ab_ctx *ctx, const BatchArgs &a, int64_t nchunks, uint32_t **
     void *rej = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)waves + 2) * kMaxFrames * sizeof(unsigned long long), &rej));
     BatchArgs b = a;
-    static const int contig = getenv("AB_BATCH_CONTIG") ? atoi(getenv("AB_BATCH_CONTIG")) : 0;
     b.stage = getenv("AB_BATCH_STAGE") ? atoi(getenv("AB_BATCH_STAGE")) : 0;
-    b.per_block = contig ? (uint32_t)((nchunks + waves - 1) / waves) : 0;
+    b.per_block = 0;  // strided chunks; a contiguous range per wave measured the same
     b.rej = (uint32_t *)((unsigned long long *)rej + kMaxFrames);  // [0, 64) u64 totals, then the per-block u32 partials
     hipLaunchKernelGGL((scms_kernel<NP, CAL, FULL>), dim3(grid), dim3(kThreads), lds, ctx->stream, b);
     AB_HIP(ctx, hipGetLastError());

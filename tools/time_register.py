@@ -1,5 +1,5 @@
 """Developer tool: time ab_align_pairs_affine on the bench's 64 x 4096^2 frames (one reference, 63 targets).  A/B friendly:
-run it several times in one gpurun call with different env knobs (AB_REGISTER_WORKERS, AB_REGISTER_SERIAL_REF)."""
+run it several times in one gpurun call with different env knobs (AB_REGISTER_WORKERS)."""
 import os
 import sys
 import time
