@@ -139,7 +139,9 @@ struct ModeTally {
         if (!have) {
             const unsigned long long m = __ballot(valid);
             if (m) {
-                bin = (uint32_t)__shfl((int)b, (int)__builtin_ctzll(m), 64);
+                // v_readlane, not __shfl: a ds_bpermute here puts an s_waitcnt lgkmcnt(0) on the common path of EVERY
+                // pixel, which also waits for the previous pixel's histogram atomic
+                bin = (uint32_t)__builtin_amdgcn_readlane((int)b, (int)__builtin_ctzll(m));
                 have = true;
             }
         }
