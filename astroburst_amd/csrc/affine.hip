@@ -514,13 +514,17 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
         const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
         const bool have = r < nr;
         const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
-        double lmin = a.lng, lmax = a.lng;
+        double lmin = a.lng, lmax = a.lng, mmin = a.mid, mmax = a.mid;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             lmin = fmin(lmin, __shfl_xor(lmin, off, 64));
             lmax = fmax(lmax, __shfl_xor(lmax, off, 64));
+            mmin = fmin(mmin, __shfl_xor(mmin, off, 64));
+            mmax = fmax(mmax, __shfl_xor(mmax, off, 64));
         }
+        // a candidate can match SOME triangle of the group only inside the group's ratio windows (widened by the tolerance)
         const double win_lo = lmin - kTriangleTolerance * 1.0001, win_hi = lmax + kTriangleTolerance * 1.0001;
+        const double mwin_lo = mmin - kTriangleTolerance * 1.0001, mwin_hi = mmax + kTriangleTolerance * 1.0001;
         const int bmin = tri_bin(rt_sorted[first].mid), bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
         unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
         {
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
             const unsigned int idx = base + lane;
             const DTri t = nxt;
             if (idx + 64 < q1) nxt = tt_sorted[idx + 64];
-            const bool keep = idx < q1 && t.lng >= win_lo && t.lng <= win_hi;
+            const bool keep = idx < q1 && t.lng >= win_lo && t.lng <= win_hi && t.mid >= mwin_lo && t.mid <= mwin_hi;
             // the kept candidates stay in their lanes' registers and are broadcast one by one through the scalar unit
             // (v_readlane): staging them in LDS cost two dependent LDS round trips per candidate with nothing to hide them
             unsigned long long m = __ballot(keep);
