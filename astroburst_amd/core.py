@@ -251,7 +251,8 @@ class Context:
         if _is_torch(x):
             assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous(), \
                 "device planes are contiguous 2-D float32 CUDA tensors"
-            self.use_torch_stream()
+            if not keep or not _is_torch(keep[-1]):  # once per call: torch.cuda.current_stream() costs microseconds, a stack has 64 planes
+                self.use_torch_stream()
             keep.append(x)
             return Plane(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], 1)
         a = np.ascontiguousarray(x, dtype=np.float32)
@@ -288,12 +289,12 @@ class Context:
         self._check(self._L.ab_stack_last_rejected(self._h, C.byref(rej)))
         return int(rej.value)
 
-
     def stack_last_kernel_ms(self) -> float:
         """duration of the last stack launch's kernels (HIP events recorded by the library on the launch stream)"""
         ms = C.c_float()
         self._check(self._L.ab_stack_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
     def stack_images(self, images, sigma_low=3.0, sigma_high=3.0, max_iterations=5, align=True) -> StackResult:
         """stack_images(&[Array2<f32>], &StackConfig) (combine.rs:94-193)."""
         n = len(images)
