@@ -16,11 +16,12 @@
 #define AB_REJ_SLOTS 2048
 
 enum {
-    AB_WS_DETECT_PARENT = 0,  // int[P] union-find forest
+    AB_WS_DETECT_PARENT = 0,  // int[P] union-find forest (defined at labelled pixels only)
     AB_WS_DETECT_CID,         // int[P] root -> component id (written at roots only)
     AB_WS_DETECT_ROOTS,       // int[P/4 + 1] component roots + counters
     AB_WS_DETECT_COMPS,       // per-component statistics / moment records
     AB_WS_DETECT_LIST,        // int[P] indices of the above-threshold pixels
+    AB_WS_DETECT_MASK,        // u32[P / 32] one bit per pixel: above threshold
     AB_WS_REGISTER,           // triangle tables / votes of the star matcher
     AB_WS_STACK_DEFER,        // per-slot pixel lists of the stacking kernel's two-pass mode
     AB_WS_RENDER,             // the 2x-reduced levels of a tile pyramid

@@ -130,57 +130,87 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
 // ---- threshold + union-find labelling -------------------------------------------------------------
 __device__ __forceinline__ bool above(float v, double threshold) { return __builtin_isfinite(v) && (double)v > threshold; }
 
-// threshold every pixel into the forest (parent = self / -1) and append the labelled ones -- a fraction of a percent
-// of the frame -- to a list, so that the merge / numbering / statistics kernels touch only those.  A block owns a
-// contiguous span of pixels, gathers its labelled indices in LDS and reserves list space with ONE global atomic
-// (a per-wave atomic on a single counter serialises at ~12 ns each: 0.4 ms per frame).
-constexpr int kInitSpan = 8192;  // pixels per block
-__global__ __launch_bounds__(256) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
-                                                         double threshold, const ab_pixel_xf xf, int *__restrict__ parent,
-                                                         int *__restrict__ plist, unsigned int *nlab, int vec_ok) {
-    __shared__ int found[kInitSpan];
+// threshold every pixel (one mask bit each; parent = self where labelled) and append the labelled ones -- a fraction of a
+// percent of the frame -- to a list, so that the merge / numbering / statistics kernels touch only those.
+// "is pixel j labelled": one bit per pixel (2 MiB for 4096^2, L2-resident for the kernels that test neighbours) instead of
+// a -1 in the 64 MiB forest: the threshold pass writes P/8 bytes, not 4 P, and `parent` is only defined at labelled pixels
+__device__ __forceinline__ bool labelled(const unsigned int *__restrict__ mask, int j) { return (mask[j >> 5] >> (j & 31)) & 1u; }
+
+// A 1024-thread block owns kInitRounds consecutive sub-spans of 4096 pixels, collects their labelled indices in LDS and
+// reserves list space with ONE global atomic at the end (or whenever the LDS list could overflow, which needs > 75 % of
+// the pixels above threshold).  With one reservation per 8192 pixels the 2048 same-address atomics-with-return of a
+// 4096^2 frame took 25 of the kernel's 36 us.
+constexpr int kInitBlock = 1024, kInitSub = 4 * kInitBlock, kInitRounds = 8, kInitCap = 4 * kInitSub;
+__global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
+                                                                double threshold, const ab_pixel_xf xf, int *__restrict__ parent,
+                                                                unsigned int *__restrict__ mask, int *__restrict__ plist, unsigned int *nlab,
+                                                                int vec_ok) {
+    __shared__ int found[kInitCap];
     __shared__ unsigned int nfound, base;
     if (threadIdx.x == 0) nfound = 0;
     __syncthreads();
-    const int P = rows * cols, start = blockIdx.x * kInitSpan;
-    if (vec_ok) {  // contiguous 16-byte aligned plane of 4 k pixels: no row / column arithmetic (a 32-bit division per pixel), 16-byte accesses
-        const float4 *img4 = reinterpret_cast<const float4 *>(img);
-        int4 *parent4 = reinterpret_cast<int4 *>(parent);
-#pragma unroll 2
-        for (int off = threadIdx.x * 4; off < kInitSpan; off += 1024) {
-            const int i = start + off;
-            if (i < P) {
-                const float4 v = img4[i >> 2];
-                const bool b0 = above(ab_px(xf, v.x), threshold), b1 = above(ab_px(xf, v.y), threshold), b2 = above(ab_px(xf, v.z), threshold),
-                           b3 = above(ab_px(xf, v.w), threshold);
-                parent4[i >> 2] = make_int4(b0 ? i : -1, b1 ? i + 1 : -1, b2 ? i + 2 : -1, b3 ? i + 3 : -1);
-                const int cnt = (int)b0 + (int)b1 + (int)b2 + (int)b3;
-                if (cnt) {  // ascending order inside the thread; the list's order across threads is irrelevant
-                    unsigned int at = atomicAdd(&nfound, (unsigned int)cnt);
-                    if (b0) found[at++] = i;
-                    if (b1) found[at++] = i + 1;
-                    if (b2) found[at++] = i + 2;
-                    if (b3) found[at++] = i + 3;
+    const int P = rows * cols;
+    const int lane = threadIdx.x & 63;
+    auto flush = [&]() {  // block-uniform call sites only
+        __syncthreads();
+        const unsigned int n = nfound;
+        if (n) {
+            if (threadIdx.x == 0) base = atomicAdd(nlab, n);
+            __syncthreads();
+            for (unsigned int k = threadIdx.x; k < n; k += kInitBlock) plist[base + k] = found[k];
+            __syncthreads();
+            if (threadIdx.x == 0) nfound = 0;
+        }
+        __syncthreads();
+    };
+    // every loop below has a block-uniform trip count and predicates instead of early exits: the mask words are assembled
+    // across lanes
+    for (int round = 0; round < kInitRounds; ++round) {
+        const int64_t start64 = ((int64_t)blockIdx.x * kInitRounds + round) * kInitSub;
+        if (start64 >= P) break;  // uniform
+        const int start = (int)start64;
+        if (vec_ok) {  // contiguous 16-byte aligned plane of 4 k pixels: no row / column arithmetic, 16-byte loads
+            const int i = start + threadIdx.x * 4;  // i % 32 == 4 * (lane % 8): eight lanes make one mask word
+            const bool in = i < P;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (in) v = reinterpret_cast<const float4 *>(img)[i >> 2];
+            const bool b0 = in && above(ab_px(xf, v.x), threshold), b1 = in && above(ab_px(xf, v.y), threshold),
+                       b2 = in && above(ab_px(xf, v.z), threshold), b3 = in && above(ab_px(xf, v.w), threshold);
+            unsigned int w = ((unsigned int)b0 | ((unsigned int)b1 << 1) | ((unsigned int)b2 << 2) | ((unsigned int)b3 << 3)) << (4 * (lane & 7));
+            w |= __shfl_xor(w, 1, 64);
+            w |= __shfl_xor(w, 2, 64);
+            w |= __shfl_xor(w, 4, 64);
+            if ((lane & 7) == 0 && in) mask[i >> 5] = w;
+            const int cnt = (int)b0 + (int)b1 + (int)b2 + (int)b3;
+            if (cnt) {  // ascending order inside the thread; the list's order across threads is irrelevant
+                unsigned int at = atomicAdd(&nfound, (unsigned int)cnt);
+                if (b0) { parent[i] = i; found[at++] = i; }
+                if (b1) { parent[i + 1] = i + 1; found[at++] = i + 1; }
+                if (b2) { parent[i + 2] = i + 2; found[at++] = i + 2; }
+                if (b3) { parent[i + 3] = i + 3; found[at++] = i + 3; }
+            }
+        } else {
+            for (int off = threadIdx.x; off < kInitSub; off += kInitBlock) {
+                const int i = start + off;  // a wave covers the 64 consecutive pixels from i - lane (a multiple of 64)
+                bool is = false;
+                if (i < P) {
+                    const int r = i / cols, c = i - r * cols;
+                    is = above(ab_px(xf, img[r * ld + c]), threshold);
+                }
+                const unsigned long long m = __ballot(is);
+                const int i0 = i - lane;
+                if (lane == 0 && i0 < P) mask[i0 >> 5] = (unsigned int)m;
+                if (lane == 1 && i0 + 32 < P) mask[(i0 >> 5) + 1] = (unsigned int)(m >> 32);
+                if (is) {
+                    parent[i] = i;
+                    found[atomicAdd(&nfound, 1u)] = i;
                 }
             }
         }
-    } else {
-#pragma unroll 4
-        for (int off = threadIdx.x; off < kInitSpan; off += 256) {
-            const int i = start + off;
-            if (i < P) {
-                const int r = i / cols, c = i - r * cols;
-                const bool is = above(ab_px(xf, img[r * ld + c]), threshold);
-                parent[i] = is ? i : -1;
-                if (is) found[atomicAdd(&nfound, 1u)] = i;
-            }
-        }
+        __syncthreads();
+        if (nfound > (unsigned int)(kInitCap - kInitSub)) flush();  // uniform: nfound is read after the barrier
     }
-    __syncthreads();
-    if (nfound == 0) return;
-    if (threadIdx.x == 0) base = atomicAdd(nlab, nfound);
-    __syncthreads();
-    for (unsigned int k = threadIdx.x; k < nfound; k += 256) plist[base + k] = found[k];
+    flush();
 }
 
 __device__ __forceinline__ int uf_find(int *parent, int x) {
@@ -207,19 +237,19 @@ __device__ __forceinline__ void uf_union(int *parent, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void label_merge_kernel(int rows, int cols, int *parent, const int *__restrict__ plist,
-                                                          const unsigned int *__restrict__ nlab) {
+__global__ __launch_bounds__(256) void label_merge_kernel(int rows, int cols, int *parent, const unsigned int *__restrict__ mask,
+                                                          const int *__restrict__ plist, const unsigned int *__restrict__ nlab) {
     const unsigned int n = *nlab;
     for (unsigned int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
         const int i = plist[k];
         const int r = i / cols, c = i - r * cols;
         // forward half of the 8-neighbourhood (star_detection.rs:120): E, SW, S, SE
-        if (c + 1 < cols && parent[i + 1] >= 0) uf_union(parent, i, i + 1);
+        if (c + 1 < cols && labelled(mask, i + 1)) uf_union(parent, i, i + 1);
         if (r + 1 < rows) {
             const int d = i + cols;
-            if (c > 0 && parent[d - 1] >= 0) uf_union(parent, i, d - 1);
-            if (parent[d] >= 0) uf_union(parent, i, d);
-            if (c + 1 < cols && parent[d + 1] >= 0) uf_union(parent, i, d + 1);
+            if (c > 0 && labelled(mask, d - 1)) uf_union(parent, i, d - 1);
+            if (labelled(mask, d)) uf_union(parent, i, d);
+            if (c + 1 < cols && labelled(mask, d + 1)) uf_union(parent, i, d + 1);
         }
     }
 }
@@ -344,7 +374,7 @@ __device__ __forceinline__ double wave_max(double x) {
 // the columns x0 + l + 64 k; lane partials are combined by a fixed butterfly, so results are reproducible
 // (the reference accumulates in BFS order: the two agree to ~1e-15 relative).
 __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
-                                                           const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
+                                                           const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
                                                            double bg_median, const ab_pixel_xf xf, CompRec *__restrict__ rec) {
     const unsigned int comp = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -360,7 +390,7 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
         for (int r = s.y0; r <= s.y1; ++r)
             for (int cb = s.x0; cb <= s.x1; cb += 64) {
                 const int c = cb + lane;
-                if (c <= s.x1 && parent[r * cols + c] == root) {
+                if (c <= s.x1 && labelled(mask, r * cols + c) && parent[r * cols + c] == root) {
                     const double v = fmax((double)ab_px(xf, img[r * ld + c]) - bg_median, 0.0);
                     f += v;
                     sx += (double)c * v;
@@ -382,7 +412,7 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
             for (int r = s.y0; r <= s.y1; ++r)
                 for (int cb = s.x0; cb <= s.x1; cb += 64) {
                     const int c = cb + lane;
-                    if (c <= s.x1 && parent[r * cols + c] == root) {
+                    if (c <= s.x1 && labelled(mask, r * cols + c) && parent[r * cols + c] == root) {
                         const double v = fmax((double)ab_px(xf, img[r * ld + c]) - bg_median, 0.0);
                         const double dx = (double)c - cx, dy = (double)r - cy;
                         r2 += (dx * dx + dy * dy) * v;
@@ -491,12 +521,14 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     unsigned int *nroots = (unsigned int *)(roots + root_cap), *nlab = nroots + 1;
     int *plist = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)P * sizeof(int), (void **)&plist));
+    unsigned int *mask = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_MASK, ((size_t)P / 32 + 2) * sizeof(unsigned int), (void **)&mask));
     const int gl = (ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;  // list kernels: grid-stride over *nlab entries
     AB_HIP(ctx, hipMemsetAsync(nroots, 0, 2 * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(label_init_kernel, dim3((unsigned)((P + kInitSpan - 1) / kInitSpan)), dim3(256), 0, ctx->stream, img, (int)rows,
-                       (int)cols, ld, threshold, xf, parent, plist, nlab,
-                       (int)(ld == cols && (P & 3) == 0 && ((uintptr_t)img & 15) == 0 && ((uintptr_t)parent & 15) == 0));
-    hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, plist, nlab);
+    hipLaunchKernelGGL(label_init_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds))), dim3(kInitBlock), 0, ctx->stream, img, (int)rows,
+                       (int)cols, ld, threshold, xf, parent, mask, plist, nlab,
+                       (int)(ld == cols && (P & 3) == 0 && ((uintptr_t)img & 15) == 0));
+    hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, mask, plist, nlab);
     hipLaunchKernelGGL(roots_kernel, dim3(gl / 4), dim3(kRootsBlock), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
     AB_HIP(ctx, hipGetLastError());
     void *pin = nullptr;
@@ -514,7 +546,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     CompRec *drec = (CompRec *)pin;
     hipLaunchKernelGGL(comp_init_kernel, dim3((ncomp + 255) / 256), dim3(256), 0, ctx->stream, dstat, ncomp);
     hipLaunchKernelGGL(comp_stats_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, cid, dstat, plist, nlab);
-    hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, roots, dstat, ncomp,
+    hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, mask, roots, dstat, ncomp,
                        bg_median, xf, drec);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
