@@ -540,15 +540,16 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     AB_CHECK(ctx, ncomp <= root_cap, "detect_stars: %u components exceed the table capacity", ncomp);
     if (ncomp == 0) return AB_OK;
     void *cbuf = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, (size_t)ncomp * sizeof(CompStat), &cbuf));
-    CompStat *dstat = (CompStat *)cbuf;
-    AB_TRY(ab_pinned(ctx, (size_t)ncomp * sizeof(CompRec), &pin));  // the moments kernel writes its records straight to the host
-    CompRec *drec = (CompRec *)pin;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, (size_t)ncomp * (sizeof(CompStat) + sizeof(CompRec)), &cbuf));
+    CompRec *drec = (CompRec *)cbuf;  // 80-byte records from one lane per wave: written to HBM and copied in one piece (straight
+    CompStat *dstat = (CompStat *)(drec + ncomp);  // PCIe stores made the kernel 12 us slower than the copy costs)
+    AB_TRY(ab_pinned(ctx, (size_t)ncomp * sizeof(CompRec), &pin));
     hipLaunchKernelGGL(comp_init_kernel, dim3((ncomp + 255) / 256), dim3(256), 0, ctx->stream, dstat, ncomp);
     hipLaunchKernelGGL(comp_stats_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, cid, dstat, plist, nlab);
     hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, mask, roots, dstat, ncomp,
                        bg_median, xf, drec);
     AB_HIP(ctx, hipGetLastError());
+    AB_HIP(ctx, hipMemcpyAsync(pin, drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const CompRec *recs_begin = (const CompRec *)pin, *recs_end = recs_begin + ncomp;
 
