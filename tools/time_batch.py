@@ -22,7 +22,8 @@ def timed(fn, reps=5):
 
 
 def main():
-    n, rows, cols = 64, 4096, 4096
+    import os
+    n, rows, cols = int(os.environ.get("N_FRAMES", "64")), 4096, 4096
     ctx = Context(0)
     g = torch.Generator(device="cuda").manual_seed(11)
     bias = torch.randn((rows, cols), device="cuda", generator=g) * 2.0 + 100.0
