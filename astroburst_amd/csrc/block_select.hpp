@@ -185,6 +185,39 @@ __device__ inline void window_hist(const S &src, const Window &w, const Keying &
     __syncthreads();
 }
 
+// prepare() and the level-1 pass of the following select in ONE sweep: the top-level histogram as above, plus the
+// level-1 histogram (bits 20..10) of the candidates whose top bits equal `guess` -- the bin the wanted rank is expected
+// in (the previous iteration's median / MAD, or any sample of the window: all sky pixels share their top 11 bits).  A
+// select that then finds its rank in that bin skips its own level-1 pass; otherwise nothing is lost but the atomics.
+template <class S>
+__device__ inline void window_hist_fused(const S &src, const Window &w, const Keying &k, uint32_t guess, unsigned int *hist0 /* LDS, 2048 */,
+                                         unsigned int *hist1 /* LDS, 2048 */) {
+    for (int i = threadIdx.x; i < 2048; i += kBlock) {
+        hist0[i] = 0;
+        hist1[i] = 0;
+    }
+    __syncthreads();
+    ModeTally tally;
+    src.for_each(w, [&](float v) {
+        bool ok = candidate(w, v);
+        uint32_t bin = 0, key = 0;
+        if (ok) {
+            key = key_of(k, v);
+            bin = key >> 21;
+        }
+        tally.add(hist0, ok, bin);
+        if (ok && bin == guess) atomicAdd(&hist1[(key >> 10) & 2047u], 1u);
+    });
+    tally.flush(hist0);
+    __syncthreads();
+}
+
+// which top-level bin `hist` already holds the level-1 histogram of (none: valid == false)
+struct Spec {
+    bool valid = false;
+    uint32_t bin0 = 0;
+};
+
 // Block-wide exclusive scan of the histogram (every thread owns nb / kBlock consecutive bins: wave scan by
 // shuffles, 16 wave totals through LDS) and location of up to two ranks in it.  Results are broadcast.
 // For a rank >= total the answer is (nb - 1, 0), as a linear scan that never fires would give.
@@ -270,13 +303,25 @@ __device__ inline unsigned int prepare(const S &src, const Window &w, const Keyi
     return n;
 }
 
+// prepare() that also speculates the level-1 histogram of top-level bin `guess` into `hist` (see window_hist_fused)
+template <class S>
+__device__ inline unsigned int prepare_spec(const S &src, const Window &w, const Keying &k, unsigned int *hist0, unsigned int *hist, uint32_t guess,
+                                            Spec *spec) {
+    window_hist_fused(src, w, k, guess & 2047u, hist0, hist);
+    unsigned int b, bf, n;
+    find_bin(hist0, 2048, 0xffffffffu, &b, &bf, &n);
+    spec->valid = true;
+    spec->bin0 = guess & 2047u;
+    return n;
+}
+
 // levels 1 and 2 for a key whose top bits (val, mask) and in-bin rank are known
 template <class S>
 __device__ inline float descend(const S &src, const Window &w, const Keying &k, uint32_t mask, uint32_t val, unsigned int rank, int level,
-                                unsigned int *hist /* LDS, 2048 */) {
+                                unsigned int *hist /* LDS, 2048 */, bool first_level_ready = false) {
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     for (int p = level; p < 3; ++p) {
-        window_hist(src, w, k, mask, val, shifts[p], bits[p], hist);
+        if (!(first_level_ready && p == level)) window_hist(src, w, k, mask, val, shifts[p], bits[p], hist);
         unsigned int bin, before, total;
         find_bin(hist, 1 << bits[p], rank, &bin, &before, &total);
         rank -= before;
@@ -288,29 +333,31 @@ __device__ inline float descend(const S &src, const Window &w, const Keying &k, 
 
 // the rank-th smallest key (0-based) given the prepared top-level histogram
 template <class S>
-__device__ inline float select_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int rank, unsigned int *hist) {
+__device__ inline float select_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int rank, unsigned int *hist,
+                                    Spec spec = Spec()) {
     unsigned int bin, before, total;
     find_bin(hist0, 2048, rank, &bin, &before, &total);
-    return descend(src, w, k, 0x7ffu << 21, bin << 21, rank - before, 1, hist);
+    return descend(src, w, k, 0x7ffu << 21, bin << 21, rank - before, 1, hist, spec.valid && spec.bin0 == bin);
 }
 
 // keys of ranks r-1 and r (r >= 1): they share passes for as long as they sit in the same bin
 template <class S>
 __device__ inline void select_pair_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int r, unsigned int *hist,
-                                        float *lower_out, float *upper_out) {
+                                        float *lower_out, float *upper_out, Spec spec = Spec()) {
     const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
     uint32_t mask = 0, val = 0;
     unsigned int rank_hi = r, rank_lo = r - 1;
     for (int p = 0; p < 3; ++p) {
         const unsigned int *h = hist0;
         if (p > 0) {
-            window_hist(src, w, k, mask, val, shifts[p], bits[p], hist);
+            // level 1 may already sit in hist (prepare_spec guessed the pair's top-level bin)
+            if (!(p == 1 && spec.valid && (val >> 21) == spec.bin0)) window_hist(src, w, k, mask, val, shifts[p], bits[p], hist);
             h = hist;
         }
         unsigned int bin_hi, before_hi, bin_lo, before_lo;
         find_bin2(h, 1 << bits[p], rank_lo, rank_hi, &bin_lo, &before_lo, &bin_hi, &before_hi);
         const uint32_t lvl_mask = ((1u << bits[p]) - 1u) << shifts[p];
-        if (bin_hi != bin_lo) {  // the pair straddles a bin boundary: finish each on its own
+        if (bin_hi != bin_lo) {  // the pair straddles a bin boundary: finish each on its own (a speculated level 1 is simply not used)
             *lower_out = descend(src, w, k, mask | lvl_mask, val | (bin_lo << shifts[p]), rank_lo - before_lo, p + 1, hist);
             *upper_out = descend(src, w, k, mask | lvl_mask, val | (bin_hi << shifts[p]), rank_hi - before_hi, p + 1, hist);
             return;
@@ -326,26 +373,28 @@ __device__ inline void select_pair_from(const S &src, const Window &w, const Key
 
 // median_f32_mut (math/median.rs:46-63) of the n > 0 prepared keys: f32 average of the two middle values
 template <class S>
-__device__ inline float median_f32_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int n, unsigned int *hist) {
+__device__ inline float median_f32_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int n, unsigned int *hist,
+                                        Spec spec = Spec()) {
     const unsigned int mid = n / 2;
     if (n % 2 == 0) {
         float left, right;
-        select_pair_from(src, w, k, hist0, mid, hist, &left, &right);
+        select_pair_from(src, w, k, hist0, mid, hist, &left, &right, spec);
         return (left + right) / 2.0f;
     }
-    return select_from(src, w, k, hist0, mid, hist);
+    return select_from(src, w, k, hist0, mid, hist, spec);
 }
 
 // exact_median_mut (math/median.rs:27-44): f64 average of the two middle values
 template <class S>
-__device__ inline double exact_median_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int n, unsigned int *hist) {
+__device__ inline double exact_median_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int n, unsigned int *hist,
+                                           Spec spec = Spec()) {
     const unsigned int mid = n / 2;
     if (n % 2 == 0) {
         float left, right;
-        select_pair_from(src, w, k, hist0, mid, hist, &left, &right);
+        select_pair_from(src, w, k, hist0, mid, hist, &left, &right, spec);
         return ((double)left + (double)right) / 2.0;
     }
-    return (double)select_from(src, w, k, hist0, mid, hist);
+    return (double)select_from(src, w, k, hist0, mid, hist, spec);
 }
 
 }  // namespace absel

@@ -62,14 +62,22 @@ struct TileOut {
 
 // estimate_background's per-tile body (star_detection.rs:47-68) = sigma_clipped_stats(vals, 3.0, 2)
 // (math/sigma_clip.rs:4-34); order statistics by workgroup radix select (block_select.hpp)
+// Every select after the first knows where its rank will be: the median barely moves between clipping iterations and
+// the MAD shrinks by a percent, so the top-level pass of a select also builds the level-1 histogram of the previous
+// result's top-level bin (prepare_spec) and the select skips its own level-1 pass: 13 passes over the tile instead of 18.
+// `first_guess`: top 11 bits of any candidate of the tile (sky pixels share them), for the very first median.
 template <class S>
-__device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, unsigned int *hist0, unsigned int *hist) {
+__device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, unsigned int *hist0, unsigned int *hist, bool have_guess,
+                                              uint32_t first_guess) {
     const absel::Keying by_value = {0, 0.0, 0.0f};
-    unsigned int n = absel::prepare(src, t, by_value, hist0);  // count + top-level histogram of the values
+    absel::Spec spec_v;
+    unsigned int n = have_guess ? absel::prepare_spec(src, t, by_value, hist0, hist, first_guess, &spec_v)
+                                : absel::prepare(src, t, by_value, hist0);  // count + top-level histogram of the values
     TileOut res = {0.0, 1.0, 0, 0};
     if (n >= 8) {
         res.valid = 1;
         double median = 0.0, sigma = 1.0;
+        float prev_mad = 0.0f;
         for (int it = 0; it < 3; ++it) {  // 2 clipping iterations + the final statistics (sigma_clip.rs:7-33)
             if (it < 2 && n < 3) continue;
             if (n == 0) {  // sigma_clip.rs:26-28
@@ -77,10 +85,15 @@ __device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, un
                 sigma = 1.0;
                 break;
             }
-            median = absel::exact_median_from(src, t, by_value, hist0, n, hist);             // median.rs:27-44
+            median = absel::exact_median_from(src, t, by_value, hist0, n, hist, spec_v);      // median.rs:27-44
             const absel::Keying by_dev = {1, median, 0.0f};
-            absel::prepare(src, t, by_dev, hist0);
-            const float mad_f32 = absel::median_f32_from(src, t, by_dev, hist0, n, hist);      // sigma_clip.rs:14-16
+            absel::Spec spec_d;
+            if (it > 0)
+                absel::prepare_spec(src, t, by_dev, hist0, hist, __float_as_uint(prev_mad) >> 21, &spec_d);
+            else
+                absel::prepare(src, t, by_dev, hist0);
+            const float mad_f32 = absel::median_f32_from(src, t, by_dev, hist0, n, hist, spec_d);  // sigma_clip.rs:14-16
+            prev_mad = mad_f32;
             const double sig = fmax((double)mad_f32 * kMadToSigma, 1e-30);
             if (it == 2) {
                 sigma = sig;
@@ -94,7 +107,7 @@ __device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, un
                 t.lo = __builtin_inff();
                 t.hi = -__builtin_inff();
             }
-            n = absel::prepare(src, t, by_value, hist0);
+            n = absel::prepare_spec(src, t, by_value, hist0, hist, __float_as_uint((float)median) >> 21, &spec_v);
         }
         res.median = median;
         res.sigma = sigma;
@@ -123,7 +136,19 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
     src.lds = cache;
     src.load(t);
     __syncthreads();
-    const TileOut res = tile_stats(src, t, hist0, hist);
+    // a first guess for the very first median's top-level bin: the first candidate wave 0 holds in its first sweep
+    __shared__ uint32_t s_guess;
+    if (threadIdx.x == 0) s_guess = 0xffffffffu;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const float v0 = cache[threadIdx.x];
+        const bool ok = absel::candidate(t, v0);
+        const unsigned long long m = __ballot(ok);
+        if (m && threadIdx.x == (unsigned)__builtin_ctzll(m)) s_guess = __float_as_uint(v0) >> 21;
+    }
+    __syncthreads();
+    const uint32_t guess = s_guess;
+    const TileOut res = tile_stats(src, t, hist0, hist, guess != 0xffffffffu, guess);
     if (threadIdx.x == 0) out[blockIdx.x] = res;
 }
 
