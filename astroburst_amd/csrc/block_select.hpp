@@ -212,11 +212,20 @@ __device__ inline void window_hist_fused(const S &src, const Window &w, const Ke
     __syncthreads();
 }
 
-// which top-level bin `hist` already holds the level-1 histogram of (none: valid == false)
+// which top-level bin `hist` already holds the level-1 histogram of (none: valid == false).  lean: no top-level
+// histogram was built at all, only the candidate counts below (before0) and inside (in0) that bin -- enough whenever
+// the wanted ranks fall inside it (lean_holds), which the caller checks before it selects.
 struct Spec {
     bool valid = false;
     uint32_t bin0 = 0;
+    bool lean = false;
+    unsigned int before0 = 0, in0 = 0;
 };
+__device__ __forceinline__ bool lean_holds(const Spec &s, unsigned int n) {  // ranks n/2 (and n/2 - 1 for even n)
+    if (n == 0) return false;
+    const unsigned int mid = n / 2, lowest = (n % 2 == 0) ? mid - 1 : mid;
+    return lowest >= s.before0 && mid < s.before0 + s.in0;
+}
 
 // Block-wide exclusive scan of the histogram (every thread owns nb / kBlock consecutive bins: wave scan by
 // shuffles, 16 wave totals through LDS) and location of up to two ranks in it.  Results are broadcast.
@@ -315,6 +324,43 @@ __device__ inline unsigned int prepare_spec(const S &src, const Window &w, const
     return n;
 }
 
+// The lean form of prepare_spec: ONE sweep that histograms level 1 of the guessed top-level bin and merely counts the
+// candidates in lower / higher top-level bins (two compares and two predicated adds per pixel instead of the mode tally).
+template <class S>
+__device__ inline unsigned int prepare_lean(const S &src, const Window &w, const Keying &k, unsigned int *hist /* LDS, 2048 */, uint32_t guess,
+                                            Spec *spec, unsigned int *tally /* LDS, 2 */) {
+    guess &= 2047u;
+    for (int i = threadIdx.x; i < 2048; i += kBlock) hist[i] = 0;
+    if (threadIdx.x < 2) tally[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned int lt = 0, gt = 0;
+    src.for_each(w, [&](float v) {
+        if (candidate(w, v)) {
+            const uint32_t key = key_of(k, v), b0 = key >> 21;
+            lt += b0 < guess ? 1u : 0u;
+            gt += b0 > guess ? 1u : 0u;
+            if (b0 == guess) atomicAdd(&hist[(key >> 10) & 2047u], 1u);
+        }
+    });
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lt += __shfl_xor(lt, off, 64);
+        gt += __shfl_xor(gt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (lt) atomicAdd(&tally[0], lt);
+        if (gt) atomicAdd(&tally[1], gt);
+    }
+    unsigned int b, bf, in;
+    find_bin(hist, 2048, 0xffffffffu, &b, &bf, &in);  // (its leading barrier also publishes the tallies)
+    spec->valid = true;
+    spec->lean = true;
+    spec->bin0 = guess;
+    spec->before0 = tally[0];
+    spec->in0 = in;
+    return tally[0] + in + tally[1];
+}
+
 // levels 1 and 2 for a key whose top bits (val, mask) and in-bin rank are known
 template <class S>
 __device__ inline float descend(const S &src, const Window &w, const Keying &k, uint32_t mask, uint32_t val, unsigned int rank, int level,
@@ -335,8 +381,8 @@ __device__ inline float descend(const S &src, const Window &w, const Keying &k, 
 template <class S>
 __device__ inline float select_from(const S &src, const Window &w, const Keying &k, const unsigned int *hist0, unsigned int rank, unsigned int *hist,
                                     Spec spec = Spec()) {
-    unsigned int bin, before, total;
-    find_bin(hist0, 2048, rank, &bin, &before, &total);
+    unsigned int bin = spec.bin0, before = spec.before0, total;
+    if (!spec.lean) find_bin(hist0, 2048, rank, &bin, &before, &total);
     return descend(src, w, k, 0x7ffu << 21, bin << 21, rank - before, 1, hist, spec.valid && spec.bin0 == bin);
 }
 
@@ -355,7 +401,12 @@ __device__ inline void select_pair_from(const S &src, const Window &w, const Key
             h = hist;
         }
         unsigned int bin_hi, before_hi, bin_lo, before_lo;
-        find_bin2(h, 1 << bits[p], rank_lo, rank_hi, &bin_lo, &before_lo, &bin_hi, &before_hi);
+        if (p == 0 && spec.lean) {  // both ranks are known to sit in the guessed bin (lean_holds)
+            bin_hi = bin_lo = spec.bin0;
+            before_hi = before_lo = spec.before0;
+        } else {
+            find_bin2(h, 1 << bits[p], rank_lo, rank_hi, &bin_lo, &before_lo, &bin_hi, &before_hi);
+        }
         const uint32_t lvl_mask = ((1u << bits[p]) - 1u) << shifts[p];
         if (bin_hi != bin_lo) {  // the pair straddles a bin boundary: finish each on its own (a speculated level 1 is simply not used)
             *lower_out = descend(src, w, k, mask | lvl_mask, val | (bin_lo << shifts[p]), rank_lo - before_lo, p + 1, hist);

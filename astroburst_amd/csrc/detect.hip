@@ -62,17 +62,27 @@ struct TileOut {
 
 // estimate_background's per-tile body (star_detection.rs:47-68) = sigma_clipped_stats(vals, 3.0, 2)
 // (math/sigma_clip.rs:4-34); order statistics by workgroup radix select (block_select.hpp)
-// Every select after the first knows where its rank will be: the median barely moves between clipping iterations and
-// the MAD shrinks by a percent, so the top-level pass of a select also builds the level-1 histogram of the previous
-// result's top-level bin (prepare_spec) and the select skips its own level-1 pass: 13 passes over the tile instead of 18.
-// `first_guess`: top 11 bits of any candidate of the tile (sky pixels share them), for the very first median.
+// Every select knows where its rank will be: all sky pixels share their top 11 bits, the median barely moves between
+// clipping iterations and the MAD shrinks by a percent.  So a select's first sweep histograms LEVEL 1 of that top-level
+// bin directly and only counts the candidates in lower / higher bins (prepare_lean); when the wanted ranks do lie in the
+// bin (lean_holds: always, on sky tiles) two sweeps finish the select instead of three.  Otherwise the ordinary
+// three-level select runs; either way the result is exact.
 template <class S>
-__device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, unsigned int *hist0, unsigned int *hist, bool have_guess,
-                                              uint32_t first_guess) {
+__device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, unsigned int *hist0, unsigned int *hist, unsigned int *tally,
+                                              bool have_guess, uint32_t first_guess) {
     const absel::Keying by_value = {0, 0.0, 0.0f};
+    // count + (speculated) histograms of keying k; spec is reset when the ordinary path had to be taken
+    auto prepare_for = [&](const absel::Keying &k, bool guess_ok, uint32_t guess, absel::Spec *spec) -> unsigned int {
+        *spec = absel::Spec();
+        if (guess_ok) {
+            const unsigned int n = absel::prepare_lean(src, t, k, hist, guess, spec, tally);
+            if (absel::lean_holds(*spec, n)) return n;
+            *spec = absel::Spec();
+        }
+        return absel::prepare(src, t, k, hist0);
+    };
     absel::Spec spec_v;
-    unsigned int n = have_guess ? absel::prepare_spec(src, t, by_value, hist0, hist, first_guess, &spec_v)
-                                : absel::prepare(src, t, by_value, hist0);  // count + top-level histogram of the values
+    unsigned int n = prepare_for(by_value, have_guess, first_guess, &spec_v);
     TileOut res = {0.0, 1.0, 0, 0};
     if (n >= 8) {
         res.valid = 1;
@@ -88,10 +98,7 @@ __device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, un
             median = absel::exact_median_from(src, t, by_value, hist0, n, hist, spec_v);      // median.rs:27-44
             const absel::Keying by_dev = {1, median, 0.0f};
             absel::Spec spec_d;
-            if (it > 0)
-                absel::prepare_spec(src, t, by_dev, hist0, hist, __float_as_uint(prev_mad) >> 21, &spec_d);
-            else
-                absel::prepare(src, t, by_dev, hist0);
+            prepare_for(by_dev, it > 0, __float_as_uint(prev_mad) >> 21, &spec_d);
             const float mad_f32 = absel::median_f32_from(src, t, by_dev, hist0, n, hist, spec_d);  // sigma_clip.rs:14-16
             prev_mad = mad_f32;
             const double sig = fmax((double)mad_f32 * kMadToSigma, 1e-30);
@@ -107,7 +114,7 @@ __device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, un
                 t.lo = __builtin_inff();
                 t.hi = -__builtin_inff();
             }
-            n = absel::prepare_spec(src, t, by_value, hist0, hist, __float_as_uint((float)median) >> 21, &spec_v);
+            n = prepare_for(by_value, true, __float_as_uint((float)median) >> 21, &spec_v);
         }
         res.median = median;
         res.sigma = sigma;
@@ -118,7 +125,7 @@ __device__ __forceinline__ TileOut tile_stats(const S &src, absel::Window &t, un
 __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const float *__restrict__ img, int rows, int cols,
                                                                         int64_t ld, int step, int ntx, const ab_pixel_xf xf,
                                                                         TileOut *__restrict__ out) {
-    __shared__ unsigned int hist0[2048], hist[2048];
+    __shared__ unsigned int hist0[2048], hist[2048], tally[2];
     __shared__ float cache[35 * absel::kBlock];  // 140 KiB of the CU's 160 KiB
     const int ty = blockIdx.x / ntx, tx = blockIdx.x % ntx;
     absel::Window t;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
     }
     __syncthreads();
     const uint32_t guess = s_guess;
-    const TileOut res = tile_stats(src, t, hist0, hist, guess != 0xffffffffu, guess);
+    const TileOut res = tile_stats(src, t, hist0, hist, tally, guess != 0xffffffffu, guess);
     if (threadIdx.x == 0) out[blockIdx.x] = res;
 }
 
