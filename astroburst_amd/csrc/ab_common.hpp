@@ -26,6 +26,7 @@ enum {
     AB_WS_STACK_DEFER,        // per-slot pixel lists of the stacking kernel's two-pass mode
     AB_WS_RENDER,             // the 2x-reduced levels of a tile pyramid
     AB_WS_BATCH_REJ,          // per-block per-frame rejection counters of the batch stack
+    AB_WS_STACK_WIDE,         // plane pointer / stride tables of a > 64-frame stack
     AB_WS_SLOTS
 };
 
@@ -165,5 +166,9 @@ int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_
                    int64_t out_cols, float *out);
 int ab_resample_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, int64_t out_rows, int64_t out_cols,
                        float *out);
+
+// stack_wide.hip: 65 .. 512 frames, one wave per pixel (host tables of n plane pointers / strides; counters pre-cleared)
+int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
+                         const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only);
 
 static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -783,15 +783,24 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
                     int64_t cols, const ab_stack_config *cfg, float *out_dev, double *out_sum_dev,
                     uint32_t *out_cnt_dev, uint64_t *out_rejected, bool median_only) {
     AB_CHECK(ctx, n >= 1, "No images to stack");
-    if (n > (size_t)kMaxFrames)
-        return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "stack of %zu frames: this build keeps <= %d frames per pixel in registers",
-                            n, kMaxFrames);
+    if (n > 512) return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "stack of %zu frames: this build stacks up to 512 frames per call", n);
     AB_CHECK(ctx, rows > 0 && cols > 0, "stack output has a zero dimension");
     AB_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t total = rows * cols;
     const bool partial = out_sum_dev != nullptr;
 
     AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kRejSlots * sizeof(unsigned long long), ctx->stream));
+    if (n > (size_t)kMaxFrames) {  // deeper than one lane's registers: one wave per pixel (stack_wide.hip)
+        for (hipEvent_t &e : ctx->stack_ev)
+            if (!e) AB_HIP(ctx, hipEventCreate(&e));
+        ctx->stack_ev_valid = false;
+        AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
+        AB_TRY(ab_stack_wide_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
+        AB_HIP(ctx, hipEventRecord(ctx->stack_ev[1], ctx->stream));
+        ctx->stack_ev_valid = true;
+        if (out_rejected) AB_TRY(read_rejected(ctx, out_rejected));
+        return AB_OK;
+    }
     if (n == 1) {
         const dim3 grid((unsigned)((total + 255) / 256)), block(256);
         hipLaunchKernelGGL(stack_single_kernel, grid, block, 0, ctx->stream, dplanes[0], ld[0], rows, cols,
@@ -859,9 +868,7 @@ static int stack_planes(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");
     AB_CHECK(ctx, cfg && out, "null config or output");
-    if (n > (size_t)kMaxFrames)
-        return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "stack of %zu frames: this build keeps <= %d frames per pixel in registers",
-                            n, kMaxFrames);
+    if (n > 512) return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "stack of %zu frames: this build stacks up to 512 frames per call", n);
     for (size_t i = 0; i < n; ++i)
         AB_CHECK(ctx, planes[i].rows >= out->rows && planes[i].cols >= out->cols,
                  "frame %zu (%lldx%lld) is smaller than the output (%lldx%lld)", i, (long long)planes[i].rows,

@@ -1,0 +1,315 @@
+// Per-pixel kappa-sigma stacking of MORE than 64 frames (65 .. 512) on gfx950.
+//
+// stack_sigma_clip.hip keeps a pixel's samples in one lane's registers, which ends at 64.  Here one WAVE owns a pixel:
+// lane l holds the samples of frames l, l + 64, ... (K = 2, 4 or 8 registers), the wave sorts its 64 K values with a
+// bitonic network whose intra-lane stages use constant register indices and whose cross-lane stages are shuffles, and
+// everything sigma_clip_combine (core/stacking/combine.rs:14-92) needs is then a rank lookup (v_readlane) or a
+// wave-wide count.  The f64 sums run over the sorted survivors one by one in ascending order, exactly as the CPU
+// restatement's ORC_ORDER_ASCENDING does, so the result is bit-identical to the <= 64-frame kernel's definition.
+// ~2000 instructions per pixel and uncoalesced gathers (one lane per plane): tens of milliseconds for 4096^2 x 128,
+// a fallback for deep stacks rather than a roofline kernel.
+#include "ab_common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
+constexpr int kRejSlots = AB_REJ_SLOTS;
+
+struct WideArgs {
+    const float *const *p;  // n plane pointers (device array)
+    const int64_t *ld;      // n row strides
+    int n, contiguous;
+    int64_t rows, cols;
+    float sigma_low, sigma_high;
+    uint32_t max_iter;
+    float *out;       // full mode
+    double *out_sum;  // partial mode
+    uint32_t *out_cnt;
+    unsigned long long *rejected;
+    int median_only;  // median_combine_row_major (calibration.rs:84-125): [len/2] of the finite samples
+};
+
+template <int K>
+struct Log2;
+template <>
+struct Log2<2> {
+    static constexpr int v = 1;
+};
+template <>
+struct Log2<4> {
+    static constexpr int v = 2;
+};
+template <>
+struct Log2<8> {
+    static constexpr int v = 3;
+};
+
+// ascending bitonic sort of the wave's 64 K values; element index e = lane * K + k
+template <int K>
+__device__ __forceinline__ void wave_sort(float (&x)[K], int lane) {
+    constexpr int N = 64 * K;
+#pragma unroll
+    for (int size = 2; size <= N; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (stride < K) {  // both elements in this lane: constant register indices
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if ((k & stride) == 0) {
+                        const bool up = ((lane * K + k) & size) == 0;
+                        const float lo = fminf(x[k], x[k | stride]), hi = fmaxf(x[k], x[k | stride]);
+                        x[k] = up ? lo : hi;
+                        x[k | stride] = up ? hi : lo;
+                    }
+                }
+            } else {  // partner in lane ^ (stride / K), same register
+                const int ls = stride / K;
+                const bool lower = (lane & ls) == 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float y = __shfl_xor(x[k], ls, 64);
+                    const bool up = ((lane * K + k) & size) == 0;
+                    x[k] = (up == lower) ? fminf(x[k], y) : fmaxf(x[k], y);
+                }
+            }
+        }
+    }
+}
+
+// sorted element of wave-uniform rank r
+template <int K>
+__device__ __forceinline__ float elem(const float (&x)[K], int r) {
+    const int src = r >> Log2<K>::v, k = r & (K - 1);
+    float v = 0.0f;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (k == j) v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[j]), src));
+    return v;
+}
+
+// sum over the sorted ranks a..b, ascending, one f64 add per element (the oracle's order); mode 1: squared deviations
+template <int K, int MODE>
+__device__ __forceinline__ double ranked_sum(const float (&x)[K], int a, int b, double mean) {
+    double s = 0.0;
+    if (a > b) return s;
+    for (int src = a >> Log2<K>::v; src <= (b >> Log2<K>::v); ++src) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int e = src * K + j;
+            if (e < a || e > b) continue;  // wave-uniform
+            const double v = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x[j]), src));
+            if (MODE == 0) {
+                s += v;
+            } else {
+                const double d = v - mean;
+                s += d * d;
+            }
+        }
+    }
+    return s;
+}
+
+// sigma_clip_combine of one pixel whose samples sit in x[] (non-finite ones already replaced by +inf, `fin` of this lane's are
+// finite); returns the rejected-sample count and writes the outputs from lane 0
+template <int K>
+__device__ __forceinline__ uint32_t wide_pixel(const WideArgs &a, int64_t g, float (&x)[K], int fin, int lane) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) fin += __shfl_xor(fin, off, 64);
+    const int n = __builtin_amdgcn_readfirstlane(fin);  // finite samples: sorted ranks [0, n); uniform by construction
+    wave_sort<K>(x, lane);
+
+    float value = 0.0f;
+    double S = 0.0;
+    int len = n;
+    uint32_t rej = 0;
+    if (n == 1) {
+        value = elem<K>(x, 0);  // combine.rs:24-26
+        S = (double)value;
+    } else if (n >= 2) {
+        const float med = elem<K>(x, n >> 1);  // combine.rs:38-40
+        if (a.median_only) {
+            value = med;
+        } else {
+            // MAD (combine.rs:42-46): the n/2-th smallest |v - med| -- sort the deviations the same way
+            float d[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) d[k] = (lane * K + k) < n ? fabsf(x[k] - med) : __builtin_inff();
+            wave_sort<K>(d, lane);
+            const float mad = elem<K>(d, n >> 1);
+            float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
+            float center = med, last_center = __builtin_nanf("");
+            int lo_r = 0, hi_r = n - 1;  // survivors = sorted ranks lo_r..hi_r (`v - center` is monotone in v)
+            for (uint32_t it = 0; it < a.max_iter; ++it) {
+                if (len < 2) break;  // combine.rs:33-35
+                if (it > 0) {        // mean / sample variance of the survivors, f64, ascending (combine.rs:50-60)
+                    const double nn = (double)len;
+                    const double mean = ranked_sum<K, 0>(x, lo_r, hi_r, 0.0) / nn;
+                    const double q = ranked_sum<K, 1>(x, lo_r, hi_r, mean);
+                    const double variance = q / fmax(nn - 1.0, 1.0);
+                    center = (float)mean;
+                    sigma = (float)fmax(sqrt(variance), 1e-10);
+                }
+                last_center = center;                 // combine.rs:63
+                const float lo = -a.sigma_low * sigma;  // combine.rs:65-66
+                const float hi = a.sigma_high * sigma;
+                int cl = 0, ch = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int e = lane * K + k;
+                    const bool in = e >= lo_r && e <= hi_r;
+                    const float dev = x[k] - center;
+                    cl += (int)__builtin_popcountll(__ballot(in && !(dev >= lo)));
+                    ch += (int)__builtin_popcountll(__ballot(in && !(dev <= hi)));
+                }
+                // a sample can fail both tests only if nothing survives (lo > hi or NaN thresholds)
+                const int removed = (cl + ch > len) ? len : (cl + ch);
+                rej += (uint32_t)removed;  // combine.rs:76-78
+                len -= removed;
+                if (len > 0) {
+                    lo_r += cl;
+                    hi_r -= ch;
+                } else {
+                    lo_r = 1;
+                    hi_r = 0;
+                }
+                if (removed == 0) break;  // combine.rs:80-82
+            }
+            if (len == 0) {  // combine.rs:85-88
+                value = __builtin_isfinite(last_center) ? last_center : 0.0f;
+            } else {
+                S = ranked_sum<K, 0>(x, lo_r, hi_r, 0.0);  // combine.rs:90-91
+                value = (float)(S / (double)len);
+            }
+        }
+    }
+    if (lane == 0) {
+        if (a.out_sum) {
+            a.out_sum[g] = len > 0 ? S : 0.0;
+            a.out_cnt[g] = (uint32_t)(len > 0 ? len : 0);
+        } else {
+            a.out[g] = value;
+        }
+    }
+    return rej;
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void stack_wide_kernel(const WideArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t total = a.rows * a.cols, nwaves = (int64_t)gridDim.x * 4;
+    const unsigned int wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+    unsigned long long rej_total = 0;
+    for (int64_t g = wave_id; g < total; g += nwaves) {  // wave-uniform pixel
+        int64_t y = 0, xcol = g;
+        if (!a.contiguous) {
+            y = g / a.cols;
+            xcol = g - y * a.cols;
+        }
+        // ---- gather (combine.rs:170-175): only finite samples take part; the rest are +inf pads on top of the order ----
+        float x[K];
+        int fin = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int f = lane + 64 * k;
+            float s = __builtin_inff();
+            if (f < a.n) {
+                const float v = a.p[f][a.contiguous ? g : (y * a.ld[f] + xcol)];
+                if (__builtin_isfinite(v)) {
+                    s = v;
+                    ++fin;
+                }
+            }
+            x[k] = s;
+        }
+        rej_total += wide_pixel<K>(a, g, x, fin, lane);
+    }
+    if (lane == 0 && rej_total) atomicAdd(&a.rejected[wave_id & (kRejSlots - 1)], rej_total);
+}
+
+// contiguous 16-byte aligned planes of 4 k pixels: a lane fetches FOUR consecutive pixels of its frames with one 16-byte
+// load (a quarter of the load instructions, four times the use of every 64-byte sector) and the wave then combines the
+// four pixels one after the other
+template <int K>
+__global__ __launch_bounds__(256) void stack_wide_quad_kernel(const WideArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t quads = (a.rows * a.cols) >> 2, nwaves = (int64_t)gridDim.x * 4;
+    const unsigned int wave_id = blockIdx.x * 4u + (threadIdx.x >> 6);
+    unsigned long long rej_total = 0;
+    for (int64_t q = wave_id; q < quads; q += nwaves) {
+        float4 v[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int f = lane + 64 * k;
+            v[k] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff());
+            if (f < a.n) v[k] = reinterpret_cast<const float4 *>(a.p[f])[q];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x[K];
+            int fin = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float s = j == 0 ? v[k].x : (j == 1 ? v[k].y : (j == 2 ? v[k].z : v[k].w));
+                const bool ok = __builtin_isfinite(s);  // (the +inf of an absent frame is not finite either)
+                x[k] = ok ? s : __builtin_inff();
+                fin += ok ? 1 : 0;
+            }
+            rej_total += wide_pixel<K>(a, q * 4 + j, x, fin, lane);
+        }
+    }
+    if (lane == 0 && rej_total) atomicAdd(&a.rejected[wave_id & (kRejSlots - 1)], rej_total);
+}
+
+}  // namespace
+
+// dplanes / ld are HOST arrays of n entries (64 < n <= 512); counters already cleared by the caller
+int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
+                         const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only) {
+    AB_CHECK(ctx, n > 64 && n <= 512, "stack of %zu frames: this build stacks up to 512 frames per call", n);
+    void *ws = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, n * (sizeof(float *) + sizeof(int64_t)), &ws));
+    // the tables are tiny; a blocking copy keeps the host arrays' lifetime out of the picture
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AB_HIP(ctx, hipMemcpy(ws, dplanes, n * sizeof(float *), hipMemcpyHostToDevice));
+    AB_HIP(ctx, hipMemcpy((char *)ws + n * sizeof(float *), ld, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    WideArgs a;
+    a.p = (const float *const *)ws;
+    a.ld = (const int64_t *)((char *)ws + n * sizeof(float *));
+    a.n = (int)n;
+    a.contiguous = 1;
+    for (size_t i = 0; i < n; ++i)
+        if (ld[i] != cols) a.contiguous = 0;
+    a.rows = rows;
+    a.cols = cols;
+    a.sigma_low = cfg->sigma_low;
+    a.sigma_high = cfg->sigma_high;
+    a.max_iter = cfg->max_iterations;
+    a.out = out_dev;
+    a.out_sum = out_sum_dev;
+    a.out_cnt = out_cnt_dev;
+    a.rejected = ctx->counters;
+    a.median_only = median_only ? 1 : 0;
+    const int64_t total = rows * cols;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 3) / 4, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8));
+    bool quad = a.contiguous && (total & 3) == 0;
+    for (size_t i = 0; i < n && quad; ++i) quad = ((uintptr_t)dplanes[i] & 15) == 0;
+    if (quad) {
+        if (n <= 128)
+            hipLaunchKernelGGL(stack_wide_quad_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        else if (n <= 256)
+            hipLaunchKernelGGL(stack_wide_quad_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(stack_wide_quad_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else if (n <= 128) {
+        hipLaunchKernelGGL(stack_wide_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else if (n <= 256) {
+        hipLaunchKernelGGL(stack_wide_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else {
+        hipLaunchKernelGGL(stack_wide_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    }
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}

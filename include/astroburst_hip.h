@@ -89,7 +89,8 @@ typedef struct {
  * All planes must be at least out->rows x out->cols; each is read with its own row stride
  * (= its cols), i.e. the reference's top-left crop to the minimum dims (combine.rs:104-113)
  * costs nothing.  *out_rejected receives StackResult.rejected_pixels (sum of per-pixel
- * rejection counts, combine.rs:158,181).  1 <= n <= 64 frames per call in this build.
+ * rejection counts, combine.rs:158,181).  1 <= n <= 512 frames per call in this build: up to 64 a pixel's samples
+ * live in one lane's registers (the HBM-bound kernel), 65 .. 512 take one wave per pixel (same results, ~30x slower).
  * Floating-point contract: the f64 sums of iterations >= 1 are taken over the survivors in
  * ascending value order (the reference's order is unspecified, SURVEY.md 7 hard part 2). */
 AB_API int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
@@ -266,7 +267,7 @@ AB_API int ab_scale(ab_ctx *ctx, const ab_plane *img, float factor, ab_plane_mut
 AB_API int ab_calibrate_image(ab_ctx *ctx, const ab_plane *raw, const ab_plane *bias, const ab_plane *dark,
                               const ab_plane *flat, float dark_exposure_ratio, ab_plane_mut *out);
 /* median_combine_row_major (calibration.rs:84-125), the per-pixel combine of create_master_{bias,dark,flat}:
- * element [len/2] of the finite samples (upper median), 0 if none.  1 <= n <= 64. */
+ * element [len/2] of the finite samples (upper median), 0 if none.  1 <= n <= 512. */
 AB_API int ab_median_combine(ab_ctx *ctx, const ab_plane *planes, size_t n, ab_plane_mut *out);
 
 /* ---- a12  core/imaging/background.rs ---------------------------------------------------------------------------- */
@@ -409,7 +410,7 @@ AB_API int ab_calibrate_channel(ab_ctx *ctx, const ab_plane *orig, float factor,
 /* create_master_bias / _dark / _flat on in-memory frames (calibration.rs:127-255): kind 0 bias = median combine;
  * 1 dark = median of (frame - bias?); 2 flat = median of (frame - bias? - dark?), normalised to mean 1 over its
  * finite positive pixels (others -> 1.0).  Err strings as the reference ("No bias frames provided", "Dimension
- * mismatch: expected (..), got (..)").  1 <= n_frames <= 64. */
+ * mismatch: expected (..), got (..)").  1 <= n_frames <= 512. */
 AB_API int ab_create_master(ab_ctx *ctx, int32_t kind, const ab_plane *frames, size_t n_frames, const ab_plane *master_bias,
                             const ab_plane *master_dark, ab_plane_mut *out);
 

@@ -142,9 +142,52 @@ def test_single_frame_and_no_frames(ctx, oracle):
 
 def test_too_many_frames_is_loud(ctx):
     import astroburst_amd as ab
-    frames = [np.ones((2, 2), np.float32)] * 65
-    with pytest.raises(ab.AstroBurstError, match="frames"):
+    frames = [np.ones((2, 2), np.float32)] * 513
+    with pytest.raises(ab.AstroBurstError, match="513 frames"):
         ctx.stack_sigma_clip(frames)
+
+
+def deep_frames(n, shape, seed):
+    rng = np.random.default_rng(seed)
+    fr = [rng.normal(1000, 20, shape).astype(np.float32) for _ in range(n)]
+    for k in range(n):
+        fr[k][rng.random(shape) < 0.01] += 400.0                      # outliers
+        fr[k][rng.random(shape) < 0.01] = np.nan
+        fr[k][rng.random(shape) < 0.003] = np.inf
+    for k in range(n):
+        fr[k][0, :3] = 7.0                                            # constant pixel: MAD 0
+        fr[k][1, :3] = np.nan                                         # no finite sample at all
+    for k in range(1, n):
+        fr[k][2, :3] = np.nan                                         # a single finite sample
+    fr[0][:] = np.round(fr[0])                                        # ties
+    return fr
+
+
+@pytest.mark.parametrize("shape", [(23, 41), (24, 40)])               # scalar gather / 16-byte quad gather (4 | pixels)
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 256, 257, 512])
+def test_deep_stacks_one_wave_per_pixel(ctx, oracle, n, shape):
+    """more than 64 frames: csrc/stack_wide.hip (bitonic sort across a wave) must equal the oracle bit for bit"""
+    fr = deep_frames(n, shape, n)
+    for sl, sh, it in ((3.0, 3.0, 5), (2.0, 2.5, 3), (1.0, 1.0, 1), (3.0, 3.0, 0)):
+        want, wrej = oracle.stack_images(fr, sl, sh, it)
+        got, rej = ctx.stack_sigma_clip(fr, sl, sh, it)
+        assert rej == wrej, (sl, sh, it)
+        assert np.array_equal(got, want, equal_nan=True), (sl, sh, it)
+
+
+def test_deep_stack_ragged_planes_partial_and_median(ctx, oracle):
+    import torch
+    n = 150
+    fr = deep_frames(n, (30, 37), 3)
+    big = [np.pad(f, ((0, k % 3), (0, (k * 7) % 5)), constant_values=np.nan) for k, f in enumerate(fr)]   # larger planes: top-left crop
+    want, wrej = oracle.stack_images(fr, 3.0, 3.0, 5)
+    got, rej = ctx.stack_sigma_clip(big, 3.0, 3.0, 5)
+    assert rej == wrej and np.array_equal(got, want, equal_nan=True)
+    assert np.array_equal(ctx.median_combine(fr), oracle.median_combine(fr), equal_nan=True)
+    dev = [torch.from_numpy(f).cuda() for f in fr]
+    s, c, prej = ctx.stack_partial(dev, 3.0, 3.0, 5)
+    ws, wc, wprej = oracle.stack_partial(fr, 3.0, 3.0, 5)
+    assert prej == wprej and np.array_equal(c.cpu().numpy(), wc) and np.array_equal(s.cpu().numpy(), ws)
 
 
 # ---- the reference's own unit tests, run through the HIP path (combine.rs:199-284) ----------------

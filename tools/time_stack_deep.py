@@ -1,0 +1,24 @@
+"""Developer tool: time the > 64-frame stack (csrc/stack_wide.hip, one wave per pixel) on 4096^2 device frames."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from astroburst_amd import Context  # noqa: E402
+
+ctx = Context(0)
+g = torch.Generator(device="cuda").manual_seed(1)
+for n in (64, 96, 128, 256):
+    fr = [torch.randn((4096, 4096), device="cuda", generator=g) * 15.0 + 1200.0 for _ in range(n)]
+    out = torch.empty((4096, 4096), device="cuda")
+    ctx.stack_sigma_clip(fr, out=out, want_rejected=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.stack_sigma_clip(fr, out=out, want_rejected=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(f"{n:4d} frames x 4096^2: {ms:8.2f} ms  ({n * 4096 * 4096 * 4 / ms / 1e9:.2f} TB/s of samples)  kernels {ctx.stack_last_kernel_ms():.2f} ms")
+    del fr
