@@ -27,6 +27,7 @@ enum {
     AB_WS_RENDER,             // the 2x-reduced levels of a tile pyramid
     AB_WS_BATCH_REJ,          // per-block per-frame rejection counters of the batch stack
     AB_WS_STACK_WIDE,         // plane pointer / stride tables of a > 64-frame stack
+    AB_WS_BATCH_WIDE,         // tables of a > 64-frame batch stack
     AB_WS_SLOTS
 };
 

@@ -23,6 +23,7 @@
 // One wave per block (16 KB LDS at n = 64, ten waves per CU), persistent blocks striding over 64-pixel chunks, so the
 // per-frame rejection counters stay in a register (lane f owns frame f) until the block retires.
 #include "ab_common.hpp"
+#include "wave_sort.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -433,6 +434,138 @@ __global__ __launch_bounds__(256) void compose_masters_kernel(const ComposeArgs 
     }
 }
 
+// ---- more than 64 frames (65 .. 512): one WAVE per pixel --------------------------------------------------------------
+// Lane l holds frames l, l + 64, ... (K = 2, 4 or 8 registers, in frame order by construction), a sorted copy comes from
+// wave_sort, ranks are v_readlane lookups, and every iteration re-sorts the window's deviations for its MAD.  Each lane
+// counts the rejections of ITS frames in registers across all the pixels of the wave.  Same definition as scms_kernel,
+// bit for bit; ~40x slower per sample.
+struct WideBatchArgs {
+    const float *const *p;  // n plane pointers (device array)
+    const float *scale;     // n inv_mean factors (1 where a frame is not scaled)
+    unsigned long long *rej;  // n per-frame counters (zeroed by the caller)
+    Masters m;
+    int n;
+    uint32_t npix;
+    float sigma_low, sigma_high;
+    int max_iter;
+    float *out;
+};
+
+template <int K, bool CAL>
+__global__ __launch_bounds__(256) void scms_wide_kernel(const WideBatchArgs a) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave_id = blockIdx.x * 4u + (threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+    uint32_t myrej[K];
+    float myscale[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        myrej[k] = 0;
+        myscale[k] = (CAL && lane + 64 * k < a.n) ? a.scale[lane + 64 * k] : 1.0f;
+    }
+    for (uint32_t g = wave_id; g < a.npix; g += nwaves) {  // wave-uniform pixel
+        float u[K], s[K];
+        int nan_here = 0;
+        CalPx c{};
+        if constexpr (CAL) c = cal_load(a.m, g);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int f = lane + 64 * k;
+            const bool present = f < a.n;
+            float v = __builtin_inff();
+            if (present) {
+                v = a.p[f][g];
+                if constexpr (CAL) v = cal_apply(v, c) * myscale[k];
+            }
+            u[k] = v;
+            const bool isn = present && v != v;  // NaN sorts last in f32_cmp: it travels as +inf and is told apart by count
+            s[k] = isn ? __builtin_inff() : v;
+            nan_here += isn ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nan_here += __shfl_xor(nan_here, off, 64);
+        int cnan = __builtin_amdgcn_readfirstlane(nan_here);
+        wave_sort<K>(s, lane);  // ranks [0, n) hold the n samples (absent slots are +inf pads above them)
+
+        int lo = 0, hi = a.n;
+        for (int it = 0; it < a.max_iter; ++it) {  // calibration_pipeline.rs:350-367; every condition is wave-uniform
+            const int len = hi - lo;
+            if (len < 3) break;
+            const int k2 = len >> 1, cpos = lo + k2;
+            const float med = elem<K>(s, cpos);
+            if ((cnan > 0 && cpos >= a.n - cnan) || !__builtin_isfinite(med)) {  // every z is NaN: the pass empties the pixel
+                lo = hi = 0;
+                break;
+            }
+            float d[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int e = lane * K + k;
+                d[k] = (e >= lo && e < hi) ? fabsf(s[k] - med) : __builtin_inff();
+            }
+            wave_sort<K>(d, lane);
+            float mad = elem<K>(d, k2);
+            if (cnan > 0 && k2 >= len - cnan) mad = __builtin_nanf("");  // the rank falls among the NaN deviations
+            const float sigma = (float)((double)mad * kMadToSigma);
+            if (sigma < 1e-10f) break;
+            const float nsl = -a.sigma_low, sh = a.sigma_high;
+            int drop_lo = 0, drop_hi = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int e = lane * K + k;
+                const bool in = e >= lo && e < hi;
+                const float z = (s[k] - med) / sigma;
+                const bool keep = z > nsl && z < sh;
+                const bool low_side = s[k] < med;
+                drop_lo += (int)__builtin_popcountll(__ballot(in && !keep && low_side));
+                drop_hi += (int)__builtin_popcountll(__ballot(in && !keep && !low_side));
+            }
+            cnan = 0;  // a retain pass never keeps a NaN
+            if (drop_lo == 0 && drop_hi == 0) break;
+            lo += drop_lo;
+            hi -= drop_hi;
+            if (hi < lo) hi = lo;
+        }
+
+        const int len = hi - lo;
+        const bool all = lo == 0 && hi == a.n;
+        const float lov = len > 0 ? elem<K>(s, lo) : __builtin_inff(), hiv = len > 0 ? elem<K>(s, hi - 1) : -__builtin_inff();
+        float w[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const bool present = lane + 64 * k < a.n;
+            const bool keep = present && (all || (u[k] >= lov && u[k] <= hiv));
+            w[k] = keep ? u[k] : 0.0f;
+            myrej[k] += (present && !keep) ? 1u : 0u;
+        }
+        float sum = 0.0f;  // frame order: frame f lives in lane f % 64, register f / 64
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int cnt = min(64, a.n - 64 * k);  // uniform
+            for (int l = 0; l < cnt; ++l) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w[k]), l));
+        }
+        if (lane == 0) a.out[g] = len == 0 ? 0.0f : sum / (float)len;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (lane + 64 * k < a.n && myrej[k]) atomicAdd(&a.rej[lane + 64 * k], (unsigned long long)myrej[k]);
+}
+
+// f64 sum of the calibrated samples of ONE frame per blockIdx.y (deep stacks only: the masters are re-read per frame)
+__global__ __launch_bounds__(kSumBlock) void cal_frame_sum_kernel(const float *const *__restrict__ p, Masters m, uint32_t npix, double *__restrict__ part) {
+    const float *frame = p[blockIdx.y];
+    double s = 0.0;
+    const uint32_t stride = gridDim.x * kSumBlock;
+    for (uint32_t i = blockIdx.x * kSumBlock + threadIdx.x; i < npix; i += stride) s += (double)cal_apply(frame[i], cal_load(m, i));
+    __shared__ double red[kSumBlock];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = kSumBlock / 2; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
 int cu_of(ab_ctx *ctx) { return ctx->cu_count > 0 ? ctx->cu_count : 256; }
 int np_for(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 32 ? 32 : 64)))); }
 
@@ -555,12 +688,70 @@ ab_batch_stack_config config_or_default(const ab_batch_stack_config *cfg) {
     return c;
 }
 
+// 65 .. 512 frames: tables in a workspace, one wave per pixel
+int stack_wide_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix, const Masters &m, bool cal, const ab_batch_stack_config &cfg,
+                      float *out, uint64_t *rejection_counts) {
+    char *ws = nullptr;
+    const size_t ptr_bytes = n * sizeof(float *), scale_bytes = ((n * sizeof(float) + 7) / 8) * 8, rej_bytes = n * sizeof(unsigned long long);
+    AB_TRY(ab_workspace(ctx, AB_WS_BATCH_WIDE, ptr_bytes + scale_bytes + rej_bytes, (void **)&ws));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AB_HIP(ctx, hipMemcpy(ws, frames, ptr_bytes, hipMemcpyHostToDevice));
+    std::vector<float> scale(n, 1.0f);
+    if (cal && cfg.normalize_before_stack) {  // normalize_frames (:309-319) on the calibrated samples
+        const int gx = std::max(1, std::min<int>((int)((npix + kSumBlock - 1) / kSumBlock), cu_of(ctx) * 2));
+        void *d = nullptr;
+        AB_TRY(ab_scratch(ctx, (size_t)gx * n * sizeof(double), &d));
+        hipLaunchKernelGGL(cal_frame_sum_kernel, dim3(gx, (unsigned)n), dim3(kSumBlock), 0, ctx->stream, (const float *const *)ws, m, (uint32_t)npix,
+                           (double *)d);
+        AB_HIP(ctx, hipGetLastError());
+        std::vector<double> part((size_t)gx * n);
+        AB_TRY(download(ctx, part.data(), d, part.size() * sizeof(double)));
+        for (size_t f = 0; f < n; ++f) {
+            double s = 0.0;
+            for (int b = 0; b < gx; ++b) s += part[f * gx + b];
+            const double mean = s / (double)npix;
+            if (mean > 0.0) scale[f] = 1.0f / (float)mean;
+        }
+    }
+    AB_HIP(ctx, hipMemcpy(ws + ptr_bytes, scale.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    AB_HIP(ctx, hipMemsetAsync(ws + ptr_bytes + scale_bytes, 0, rej_bytes, ctx->stream));
+    WideBatchArgs a;
+    a.p = (const float *const *)ws;
+    a.scale = (const float *)(ws + ptr_bytes);
+    a.rej = (unsigned long long *)(ws + ptr_bytes + scale_bytes);
+    a.m = m;
+    a.n = (int)n;
+    a.npix = (uint32_t)npix;
+    a.sigma_low = cfg.sigma_low;
+    a.sigma_high = cfg.sigma_high;
+    a.max_iter = (int)std::min<uint64_t>(cfg.max_iterations, 1u << 20);
+    a.out = out;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((npix + 3) / 4, (int64_t)cu_of(ctx) * 8));
+    const int kk = n <= 128 ? 2 : (n <= 256 ? 4 : 8);
+    if (cal) {
+        if (kk == 2) hipLaunchKernelGGL((scms_wide_kernel<2, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else if (kk == 4) hipLaunchKernelGGL((scms_wide_kernel<4, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((scms_wide_kernel<8, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else {
+        if (kk == 2) hipLaunchKernelGGL((scms_wide_kernel<2, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else if (kk == 4) hipLaunchKernelGGL((scms_wide_kernel<4, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((scms_wide_kernel<8, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    }
+    AB_HIP(ctx, hipGetLastError());
+    std::vector<unsigned long long> host(n);
+    AB_TRY(download(ctx, host.data(), a.rej, rej_bytes));
+    if (rejection_counts)
+        for (size_t f = 0; f < n; ++f) rejection_counts[f] = host[f];
+    return AB_OK;
+}
+
 // the device-resident body shared by ab_sigma_clipped_mean_stack (cal == false) and ab_run_batch_channel
 int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix, const Masters &m, bool cal, const ab_batch_stack_config &cfg,
                  float *out, uint64_t *rejection_counts) {
-    AB_CHECK(ctx, n >= 1 && n <= (size_t)kMaxFrames, "sigma_clipped_mean_stack: %zu frames (this build stacks 1..%d)", n, kMaxFrames);
+    AB_CHECK(ctx, n >= 1 && n <= 512, "sigma_clipped_mean_stack: %zu frames (this build stacks 1..512)", n);
     AB_CHECK(ctx, npix > 0 && npix < ((int64_t)1 << 30), "sigma_clipped_mean_stack: planes of 1 .. 2^30 - 1 pixels");
     AB_HIP(ctx, hipSetDevice(ctx->device));
+    if (n > (size_t)kMaxFrames) return stack_wide_device(ctx, frames, n, npix, m, cal, cfg, out, rejection_counts);
     BatchArgs a;
     memset(&a, 0, sizeof a);
     for (int f = 0; f < kMaxFrames; ++f) {

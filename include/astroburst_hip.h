@@ -460,7 +460,8 @@ AB_API int ab_normalize_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, ab
 /* sigma_clipped_mean_stack (:321-378): per pixel, up to max_iterations passes of { median, MAD -> sigma = 1.4826 MAD (f32);
  * stop if sigma < 1e-10; keep -sigma_low < (v - median) / sigma < sigma_high }, NaN samples included and rejected by the
  * first pass; result = f32 sum of the survivors in frame order / count (0 if none).  rejection_counts[f] (nullable) =
- * samples of frame f rejected over the whole image.  1 <= n <= 64 frames of identical dims.  Bit-exact. */
+ * samples of frame f rejected over the whole image.  1 <= n <= 512 frames of identical dims (65 .. 512: one wave per
+ * pixel instead of one lane, ~40x slower per sample).  Bit-exact. */
 AB_API int ab_sigma_clipped_mean_stack(ab_ctx *ctx, const ab_plane *frames, size_t n, const ab_batch_stack_config *config, ab_plane_mut *out,
                                        uint64_t *rejection_counts);
 /* one channel of run_batch_pipeline (:157-190): calibrate_light on every light, normalize_frames (if configured),

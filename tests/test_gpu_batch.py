@@ -24,6 +24,34 @@ def test_stack_bit_exact_with_non_finite_samples(ctx, oracle, n):
         assert same(got, want), (sl, sh, it)
 
 
+@pytest.mark.parametrize("n", [65, 100, 128, 130, 257, 512])
+def test_deep_batch_stack_one_wave_per_pixel(ctx, oracle, n):
+    """more than 64 frames: scms_wide_kernel (a wave per pixel) must equal the oracle bit for bit, counts per frame included"""
+    fr = frames_with_trouble(n, (19, 37), n)
+    for sl, sh, it in ((2.5, 3.0, 5), (1.0, 1.0, 2), (3.0, 2.0, 1), (2.5, 3.0, 0)):
+        want, wrej = oracle.sigma_clipped_mean_stack(fr, sl, sh, it)
+        got, rej = ctx.sigma_clipped_mean_stack(fr, BatchStackConfig(sl, sh, it))
+        assert rej == wrej, (sl, sh, it)
+        assert same(got, want), (sl, sh, it)
+
+
+@pytest.mark.parametrize("normalize", [True, False])
+def test_deep_batch_channel_fused(ctx, oracle, normalize):
+    rng = np.random.default_rng(70)
+    shape, n = (60, 83), 70
+    lights = [rng.normal(400 + 3 * k, 12, shape).astype(np.float32) for k in range(n)]
+    lights[2][rng.random(shape) < 0.05] += 500.0
+    lights[1][5, 5] = np.nan
+    bias = rng.normal(100, 2, shape).astype(np.float32)
+    flat = rng.normal(1.0, 0.05, shape).astype(np.float32)
+    flat[3, 3] = 0.0
+    want, wrej, wmean, wstd = oracle.run_batch_channel(lights, bias, None, flat, normalize=normalize)
+    got, rej, mean, std = ctx.run_batch_channel(lights, bias, None, flat, BatchStackConfig(normalize_before_stack=normalize))
+    assert rej == wrej and same(got, want)
+    if np.isfinite(wmean):
+        assert mean == pytest.approx(wmean, rel=1e-12) and std == pytest.approx(wstd, rel=1e-10)
+
+
 @pytest.mark.parametrize("n,shape", [(12, (200, 333)), (64, (96, 257)), (20, (1, 7)), (7, (65, 1))])
 def test_stack_clean_data_and_device_planes(ctx, oracle, n, shape):
     import torch
@@ -143,8 +171,8 @@ def test_pipeline_errors(ctx):
         ctx.run_batch_pipeline([("R", [])])
     with pytest.raises(AstroBurstError, match=r"Channel 'G': frame 1 has shape \(8, 9\) but frame 0 has \(8, 8\). All frames must match."):
         ctx.run_batch_pipeline([("G", [z, np.zeros((8, 9), np.float32)])])
-    with pytest.raises(AstroBurstError, match="65 frames"):
-        ctx.sigma_clipped_mean_stack([z] * 65)
+    with pytest.raises(AstroBurstError, match="513 frames"):
+        ctx.sigma_clipped_mean_stack([z] * 513)
 
 
 def test_full_size_batch_channel(ctx):
