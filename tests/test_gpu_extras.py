@@ -75,6 +75,11 @@ def test_create_master(ctx, oracle):
         got = ctx.create_master("flat", frames, **kw)
         assert np.allclose(got, want, rtol=1.2e-7, atol=0)
         assert (got == 1.0).sum() >= (want == 1.0).sum() - 0 and abs(float(got.mean()) - 1.0) < 1e-4
+    many = [rng.uniform(900, 1100, (40, 52)).astype(np.float32) for _ in range(90)]   # > 64 frames: the wave-per-pixel stack
+    many[7][1, 2] = np.nan
+    assert np.array_equal(ctx.create_master("bias", many), oracle.create_master("bias", many))
+    assert np.array_equal(ctx.create_master("dark", many, master_bias=bias[:40, :52].copy()),
+                          oracle.create_master("dark", many, master_bias=bias[:40, :52].copy()))
     with pytest.raises(AstroBurstError, match="No dark frames provided"):
         ctx.create_master("dark", [])
     with pytest.raises(AstroBurstError, match=r"Dimension mismatch: expected \(200, 311\), got \(200, 310\)"):
