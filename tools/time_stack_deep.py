@@ -10,7 +10,7 @@ from astroburst_amd import Context  # noqa: E402
 
 ctx = Context(0)
 g = torch.Generator(device="cuda").manual_seed(1)
-for n in (64, 96, 128, 256):
+for n in [int(v) for v in os.environ.get("N_LIST", "64,96,128,256").split(",")]:
     fr = [torch.randn((4096, 4096), device="cuda", generator=g) * 15.0 + 1200.0 for _ in range(n)]
     out = torch.empty((4096, 4096), device="cuda")
     ctx.stack_sigma_clip(fr, out=out, want_rejected=False)
