@@ -41,7 +41,7 @@
 
 namespace {
 
-constexpr int kMaxFrames = 64;
+constexpr int kMaxFrames = 128;  // 65 .. 128: two registers of plane pointers, one wave per SIMD (see launch of NP = 128)
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
 enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
@@ -519,13 +519,17 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         const uint64_t *kp = (const uint64_t *)__builtin_amdgcn_kernarg_segment_ptr();
         const uint64_t mine = kp[threadIdx.x & 63];
         const uint32_t plo = (uint32_t)mine, phi = (uint32_t)(mine >> 32);
+        const uint64_t mine2 = NP > 64 ? kp[64 + (threadIdx.x & 63)] : 0;  // frames 64 .. 127
+        const uint32_t plo2 = (uint32_t)mine2, phi2 = (uint32_t)(mine2 >> 32);
         constexpr uint32_t kSampleBytes = INPUT == kInI16BE ? 2u : 4u;
         const uint32_t off = (uint32_t)g * kSampleBytes;
         const uint32_t plane_bytes = (uint32_t)total * kSampleBytes;
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
-            const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, f) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readlane((int)plo, f);
+            const uint64_t base = f < 64 ? (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, f & 63) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)plo, f & 63))
+                                         : (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi2, f & 63) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)plo2, f & 63));
             // buffer descriptor in 4 SGPRs -> `buffer_load_dword v, voffset, s[rsrc], 0 offen`
             const __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)plane_bytes, 0x00020000);
@@ -662,7 +666,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
 }
 
 template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain, int INPUT = kInNative>
-__global__ __launch_bounds__(256, EXACT ? 1 : 3) void stack_sigma_clip_kernel(const StackArgs args) {
+__global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : 3) void stack_sigma_clip_kernel(const StackArgs args) {
     if constexpr (MODE == kGeneralPass) {
         const unsigned int cnt = args.defer_count[blockIdx.x];  // one block per list
         const int *list = args.defer_list + (size_t)blockIdx.x * args.defer_cap;
@@ -790,7 +794,13 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     const bool partial = out_sum_dev != nullptr;
 
     AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kRejSlots * sizeof(unsigned long long), ctx->stream));
-    if (n > (size_t)kMaxFrames) {  // deeper than one lane's registers: one wave per pixel (stack_wide.hip)
+    // 65 .. 128 contiguous frames, plain full-image stack: still one lane per pixel, 128 samples in registers (one wave per
+    // SIMD).  Everything else beyond 64 frames -- ragged strides, partial sums, the median combine, the exact engine, more
+    // than 128 frames -- takes one wave per pixel (stack_wide.hip).
+    bool contig_all = total < (int64_t(1) << 30);
+    for (size_t i = 0; i < n && contig_all; ++i) contig_all = ld[i] == cols;
+    const bool reg128 = n > 64 && n <= 128 && contig_all && !partial && !median_only && !ctx->stack_exact;
+    if (n > 64 && !reg128) {  // deeper than one lane's registers: one wave per pixel (stack_wide.hip)
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
         ctx->stack_ev_valid = false;
@@ -858,7 +868,16 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
         ctx->stack_ev_valid = false;
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
-        if (median_only)
+        if (np == 128) {  // reg128 (checked above): only the direct-gather kernels exist for 128 samples per lane
+            const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+            if (args.defer_list) {
+                hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kFastPass>), grid, block, 0, ctx->stream, args);
+                hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kGeneralPass>), dim3(kDeferSlots), block, 0, ctx->stream, args);
+            } else {
+                hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true>), grid, block, 0, ctx->stream, args);
+            }
+            AB_HIP(ctx, hipGetLastError());
+        } else if (median_only)
             AB_TRY((launch_stack<false, false, 10>(ctx, args, np)));
         else if (ctx->stack_exact)
             AB_TRY(partial ? (launch_stack<true, true>(ctx, args, np)) : (launch_stack<false, true>(ctx, args, np)));
