@@ -113,15 +113,26 @@ __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ sr
 __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src, int src_rows, int src_cols, double a,
                                                    double b, double tx, double c, double d, double ty, int out_rows,
                                                    int out_cols, float *__restrict__ out) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    // two output pixels per lane (x and x + 256): their f64 chains are independent, which is the only instruction-level
+    // parallelism this f64-bound kernel can get
+    const int x0 = blockIdx.x * 512 + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= out_cols) return;
-    const double xf = (double)x, yf = (double)y;
-    const double sx = a * xf + b * yf + tx;
-    const double sy = c * xf + d * yf + ty;
-    const bool in = sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1);
-    const float r = bicubic_sample(src, src_rows, src_cols, src_cols, in ? sy : 0.0, in ? sx : 0.0, in);
-    out[(size_t)y * out_cols + x] = r;
+    const double yf = (double)y;
+    float r[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int x = x0 + 256 * u;
+        live[u] = x < out_cols;
+        const double xf = (double)x;
+        const double sx = a * xf + b * yf + tx;
+        const double sy = c * xf + d * yf + ty;
+        const bool in = live[u] && sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1);
+        r[u] = bicubic_sample(src, src_rows, src_cols, src_cols, in ? sy : 0.0, in ? sx : 0.0, in);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (live[u]) out[(size_t)y * out_cols + x0 + 256 * u] = r[u];
 }
 
 // resample.rs:41-58: target pixel centres mapped onto the source grid
@@ -183,7 +194,7 @@ int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_
     AB_CHECK(ctx, src != out, "warp_image cannot run in place");
     AB_CHECK(ctx, out_rows <= 65535 && out_rows * out_cols < (int64_t(1) << 31) && src_rows * src_cols < (int64_t(1) << 31),
              "image of %lld x %lld needs a tiled launch (not in this build)", (long long)out_rows, (long long)out_cols);
-    const dim3 grid((unsigned)((out_cols + 255) / 256), (unsigned)out_rows), block(256);
+    const dim3 grid((unsigned)((out_cols + 511) / 512), (unsigned)out_rows), block(256);
     hipLaunchKernelGGL(warp_kernel, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
                        t[4], t[5], (int)out_rows, (int)out_cols, out);
     AB_HIP(ctx, hipGetLastError());
