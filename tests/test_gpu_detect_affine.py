@@ -45,10 +45,10 @@ def test_estimate_background_exact(ctx, oracle, shape, tile):
     assert ctx.estimate_background(img, tile) == oracle.estimate_background(img, tile)
 
 
+@pytest.mark.parametrize("rows,cols", [(500, 640), (333, 257), (301, 515)])   # 4 | pixels: 16-byte threshold pass; odd: scalar pass
 @pytest.mark.parametrize("seed,sigma", [(1, 5.0), (2, 3.5), (3, 8.0)])
-def test_detect_stars_matches_oracle(ctx, oracle, seed, sigma):
+def test_detect_stars_matches_oracle(ctx, oracle, seed, sigma, rows, cols):
     from astroburst_amd import synth
-    rows, cols = 500, 640
     y, x, flux = synth.star_catalog(rows, cols, 250, seed=seed)
     img = synth.make_frame(rows, cols, seed, cat=(y, x, flux * 20.0), bad_patch_rate=1e-5).numpy()
     img[:, 0] += 5000.0                                              # a bright border column: growth may enter the border,
