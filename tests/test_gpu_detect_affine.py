@@ -60,6 +60,20 @@ def test_detect_stars_matches_oracle(ctx, oracle, seed, sigma, rows, cols):
     compare_stars(got, ref)
 
 
+def test_detect_with_a_large_bright_region(ctx, oracle):
+    """40 % of the frame above threshold in one slab: the threshold pass fills and flushes its LDS list several times per
+    block, the slab itself is one component far beyond 5000 pixels (dropped), the stars elsewhere survive"""
+    from astroburst_amd import synth
+    rows, cols = 512, 640
+    y, x, flux = synth.star_catalog(rows, cols, 120, seed=8)
+    img = synth.make_frame(rows, cols, 4, cat=(y, x, flux * 20.0), bad_patch_rate=0.0).numpy()
+    img[:200, :] += 3000.0
+    got, gm, gs = ctx.detect_stars(img, 5.0)
+    ref, rm, rs = oracle.detect_stars(img, 5.0)
+    assert (gm, gs) == (rm, rs) and len(ref) > 10
+    compare_stars(got, ref)
+
+
 def test_detect_touching_blobs_and_size_limits(ctx, oracle):
     img = np.full((200, 200), 100.0, np.float32) + np.random.default_rng(0).normal(0, 1, (200, 200)).astype(np.float32)
     img[50:52, 50] += 500.0                                          # 2 px: below the 3 px minimum
