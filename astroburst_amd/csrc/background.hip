@@ -48,7 +48,7 @@ __global__ __launch_bounds__(absel::kBlock) void cell_median_kernel(const float 
     w.lo = -__builtin_inff();
     w.hi = __builtin_inff();
     const absel::Keying by_value = {0, 0.0, 0.0f};
-    const absel::StreamSource src;  // cells reach 512 x 512 px: too many for registers, and only ~4 passes are needed
+    const absel::StreamSource src;  // a cell's inner window is streamed (any size): too many pixels for registers, and only ~4 passes are needed
     const unsigned int n = absel::prepare(src, w, by_value, hist0);
     float med = 0.0f;
     if (n > 0) med = absel::median_f32_from(src, w, by_value, hist0, n, hist);
@@ -188,7 +188,7 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
     AB_CHECK(ctx, rows <= 65535 && npix < (int64_t(1) << 31), "image too large for this build");
     const int cell_h = (int)(rows / grid), cell_w = (int)(cols / grid);
     if (cell_h < 4 || cell_w < 4) return ab_set_error(ctx, AB_ERR_INVALID, "Image too small for grid_size=%d", grid);  // :127-129
-    AB_CHECK(ctx, (int64_t)cell_h * cell_w <= 4 * 65536, "grid cells larger than 512 x 512 px are not supported");
+    AB_CHECK(ctx, (int64_t)cell_h * cell_w <= ((int64_t)1 << 26), "grid cells larger than 2^26 px are not supported");  // u32 ranks, one block per cell
     const int margin_h = cell_h / 4, margin_w = cell_w / 4, inner_h = cell_h - 2 * margin_h, inner_w = cell_w - 2 * margin_w;
     AB_HIP(ctx, hipSetDevice(ctx->device));
 

@@ -42,11 +42,10 @@ def assert_parity(got, want, model=True):
 
 
 @pytest.mark.parametrize("rows,cols,grid,degree", [(64, 64, 4, 1), (128, 128, 6, 1), (301, 517, 8, 3), (512, 768, 16, 5),
-                                                   (1000, 1200, 8, 2), (257, 130, 32, 0), (2048, 2048, 4, 4)])
+                                                   (1000, 1200, 8, 2), (257, 130, 32, 0), (2048, 2048, 4, 4),
+                                                   (2048, 2048, 2, 2), (2500, 3100, 3, 1)])  # cells past 512 x 512
 @pytest.mark.parametrize("mode", ["subtract", "divide"])
 def test_extract_background_parity(ctx, oracle, rows, cols, grid, degree, mode):
-    if (rows // grid) * (cols // grid) > 4 * 65536 or rows // grid < 4 or cols // grid < 4:
-        pytest.skip("outside the supported cell sizes")
     img = sky(np.random.default_rng(rows * 31 + cols), rows, cols, zeros=(grid >= 8 and degree == 3))
     kw = dict(grid_size=grid, poly_degree=degree, sigma_clip=2.5, iterations=3)
     try:
