@@ -106,8 +106,17 @@ __device__ __forceinline__ void gather(float (&u)[NP], uint32_t plo, uint32_t ph
     }
 }
 
-// FULL: n == NP.  Otherwise every `f < n` is evaluated against a per-chunk VGPR copy of n: as uniform scalar conditions
-// the 64 of them are hoisted out of the chunk loop as 64-bit lane masks and spill the SGPR file.
+// slot f of a ragged stack (n < NP) is a pad.  The frame count goes through an opaque scalar copy at every use: left to
+// itself LLVM evaluates all NP `f >= n` up front as 64-bit lane masks, keeps them for the whole chunk loop and spills the
+// SGPR file (157 spills, one wave per SIMD, 2x the time of the full kernel).
+__device__ __forceinline__ bool pad_slot(int n, int f) {
+    asm volatile("" : "+s"(n));
+    return f >= n;
+}
+
+// FULL: n == NP.  Otherwise the slots past n read a plane of FLT_MAX (set up by the host): finite, so the fast path needs
+// no per-slot predicate -- they sort above every sample that can be inside the window [0, n), which is all the clipping
+// loop ever looks at.  (When the wave meets a non-finite sample, the slow path turns them into +inf like NaN stand-ins.)
 template <int NP, bool CAL, bool FULL>
 __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const BatchArgs a) {
     extern __shared__ float S_[];  // [NP][64] sorted samples of this wave's 64 pixels
@@ -134,14 +143,12 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
     for (uint32_t chunk = first; chunk < end; chunk += step) {
         const uint32_t g = chunk * kWave + lane;
         const bool valid = g < a.npix;
-        int nv = a.n;
-        asm volatile("" : "+v"(nv));
-#define HAS(f) (FULL || (f) < nv)
+#define PAD(f) (!FULL && pad_slot(a.n, (f)))
 
         // ---- gather, frame order (:344-348) ----
         float u[NP];
 #pragma unroll
-        for (int f = 0; f < NP; ++f) u[f] = HAS(f) ? nxt[f] : __builtin_inff();
+        for (int f = 0; f < NP; ++f) u[f] = nxt[f];
         const CalPx c = cnxt;
         if (chunk + step < end) {
             const uint32_t g1 = (chunk + step) * kWave + lane, gi1 = g1 < a.npix ? g1 : a.npix - 1;
@@ -150,8 +157,10 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
         }
         if constexpr (CAL) {
 #pragma unroll
-            for (int f = 0; f < NP; ++f)
-                if (HAS(f)) u[f] = cal_apply(u[f], c) * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myscale), f));
+            for (int f = 0; f < NP; ++f) {
+                const float cv = cal_apply(u[f], c) * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myscale), f));
+                u[f] = PAD(f) ? __FLT_MAX__ : cv;  // (a pad must not be calibrated: a negative flat would clamp it to 0)
+            }
         }
 
         // ---- sorted copy: NaN sorts last in f32_cmp (math/median.rs:4-13); it travels as +inf and is told apart by count ----
@@ -161,13 +170,13 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
             v[f] = u[f];
-            if (HAS(f)) nf = __builtin_fmaf(u[f], 0.0f, nf);
+            nf = __builtin_fmaf(u[f], 0.0f, nf);
         }
         if (__any(nf != nf)) {  // rare: some lane of this wave met a non-finite sample
 #pragma unroll
             for (int f = 0; f < NP; ++f) {
                 const bool isn = u[f] != u[f];
-                v[f] = isn ? __builtin_inff() : u[f];
+                v[f] = (isn || PAD(f)) ? __builtin_inff() : u[f];  // pads go above real +inf samples again
                 cnan += isn ? 1 : 0;
             }
         }
@@ -259,9 +268,9 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
             asm volatile("" : "+v"(lo_s), "+v"(sum));
             const float clamped = __builtin_amdgcn_fmed3f(u[f], lo_s, hiv);
             unsigned long long rej = (__builtin_amdgcn_ballot_w64(clamped != u[f]) & live) | force;
-            if constexpr (!FULL) rej &= __builtin_amdgcn_ballot_w64(HAS(f));  // wave-uniform, as a lane mask
+            if constexpr (!FULL) rej = PAD(f) ? ~0ull : rej;  // a pad never enters the sum (its count lands on a lane >= n)
             const bool mine = __builtin_amdgcn_inverse_ballot_w64(rej);  // the scalar mask back as a v_cndmask selector
-            sum += mine ? 0.0f : (HAS(f) ? u[f] : 0.0f);
+            sum += mine ? 0.0f : u[f];
             int cnt = __popcll(rej);
             asm volatile("" : "+s"(cnt));  // keep it a register operand even where the compiler can fold it to a constant
             asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cnts) : "s"(cnt), "n"(f));
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
         if (valid) a.out[g] = len == 0 ? 0.0f : sum / (float)len;
     }
 #undef S
-#undef HAS
+#undef PAD
     a.rej[(size_t)wid * kMaxFrames + lane] = mycount;
 }
 
@@ -779,6 +788,15 @@ int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix
     }
     const int64_t nchunks = (npix + kWave - 1) / kWave;
     const bool full = (int)n == np;
+    if (!full) {  // the slots past n read FLT_MAX (see scms_kernel); one plane, L2-resident, shared by all of them
+        float *pad = nullptr;
+        const void *before = ctx->ws[AB_WS_BATCH_PAD];
+        const size_t had = ctx->ws_bytes[AB_WS_BATCH_PAD];
+        AB_TRY(ab_workspace(ctx, AB_WS_BATCH_PAD, (size_t)npix * sizeof(float), (void **)&pad));
+        if (pad != before || had < (size_t)npix * sizeof(float))
+            AB_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)pad, 0x7f7fffff, ctx->ws_bytes[AB_WS_BATCH_PAD] / sizeof(float), ctx->stream));
+        for (int f = (int)n; f < np; ++f) a.p[f] = pad;
+    }
     uint32_t *total = nullptr;
     if (cal)
         AB_TRY((full ? launch_scms<true, true>(ctx, np, a, nchunks, &total) : launch_scms<true, false>(ctx, np, a, nchunks, &total)));

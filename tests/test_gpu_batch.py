@@ -132,6 +132,32 @@ def test_run_batch_channel_fused_equals_the_three_steps(ctx, oracle, n, normaliz
             assert np.isnan(mean)
 
 
+@pytest.mark.parametrize("n", [6, 21, 48, 63])
+def test_ragged_stack_pads_stay_out_of_the_window(ctx, oracle, n):
+    """n below the kernel's slot count: the pad slots (a plane of FLT_MAX) must never be counted, summed or calibrated --
+    with FLT_MAX and +inf as real samples, negative / zero flat pixels, and untouched (all-kept) pixels next to them"""
+    rng = np.random.default_rng(100 + n)
+    shape = (64, 130)
+    lights = [rng.normal(300 + 5 * k, 8, shape).astype(np.float32) for k in range(n)]
+    fmax = np.finfo(np.float32).max
+    lights[0][10, :64] = fmax                                         # a real FLT_MAX sample ties with the pads
+    lights[1][11, :64] = np.inf
+    lights[2][12, 3] = np.nan
+    for k in range(n):
+        lights[k][20, :] = 250.0                                      # constant pixels: nothing rejected, every real frame summed
+    want, wrej = oracle.sigma_clipped_mean_stack(lights)
+    got, rej = ctx.sigma_clipped_mean_stack(lights, BatchStackConfig())
+    assert rej == wrej and same(got, want)
+    flat = rng.normal(1.0, 0.05, shape).astype(np.float32)
+    flat[:, ::7] *= -1.0                                              # negative flat: calibrated samples clamp to 0
+    flat[5, 5] = 0.0
+    bias = rng.normal(100, 2, shape).astype(np.float32)
+    for normalize in (False, True):
+        want, wrej, wmean, wstd = oracle.run_batch_channel(lights, bias, None, flat, normalize=normalize)
+        got, rej, mean, std = ctx.run_batch_channel(lights, bias, None, flat, BatchStackConfig(normalize_before_stack=normalize))
+        assert rej == wrej and same(got, want), normalize
+
+
 def test_compose_rgb_from_masters(ctx, oracle):
     import torch
     rng = np.random.default_rng(4)
