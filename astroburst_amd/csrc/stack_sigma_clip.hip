@@ -41,7 +41,8 @@
 
 namespace {
 
-constexpr int kMaxFrames = 128;  // 65 .. 128: two registers of plane pointers, one wave per SIMD (see launch of NP = 128)
+constexpr int kMaxFrames = 256;  // 65 .. 256: 2 / 4 registers of plane pointers, one wave per SIMD (see launch of NP = 128 / 256)
+constexpr int kMaxStrided = 64;  // ragged row strides only exist for the <= 64-frame kernels (deeper stacks are DIRECT or wide)
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
 enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
@@ -50,7 +51,7 @@ constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
 
 struct StackArgs {
     const float *p[kMaxFrames];
-    int64_t ld[kMaxFrames];  // row stride (= cols of that plane): top-left crop for free
+    int64_t ld[kMaxStrided];  // row stride (= cols of that plane): top-left crop for free
     int n;                   // frames actually present (<= NP)
     int contiguous;          // all ld == cols: linear pixel index is the element offset
     int64_t rows, cols;      // output dims
@@ -517,19 +518,21 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         // SGPR pair, and every sample load is `global_load_dword v, voffset, s[base]` -- no per-frame
         // scalar loads, no 64-bit address arithmetic, 64 loads issued back to back.
         const uint64_t *kp = (const uint64_t *)__builtin_amdgcn_kernarg_segment_ptr();
-        const uint64_t mine = kp[threadIdx.x & 63];
-        const uint32_t plo = (uint32_t)mine, phi = (uint32_t)(mine >> 32);
-        const uint64_t mine2 = NP > 64 ? kp[64 + (threadIdx.x & 63)] : 0;  // frames 64 .. 127
-        const uint32_t plo2 = (uint32_t)mine2, phi2 = (uint32_t)(mine2 >> 32);
+        constexpr int kPtrRegs = NP > 64 ? NP / 64 : 1;  // lane l of register r holds p[64 r + l]
+        uint32_t plo[kPtrRegs], phi[kPtrRegs];
+#pragma unroll
+        for (int r = 0; r < kPtrRegs; ++r) {
+            const uint64_t mine = kp[64 * r + (threadIdx.x & 63)];
+            plo[r] = (uint32_t)mine;
+            phi[r] = (uint32_t)(mine >> 32);
+        }
         constexpr uint32_t kSampleBytes = INPUT == kInI16BE ? 2u : 4u;
         const uint32_t off = (uint32_t)g * kSampleBytes;
         const uint32_t plane_bytes = (uint32_t)total * kSampleBytes;
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
-            const uint64_t base = f < 64 ? (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, f & 63) << 32) |
-                                            (uint32_t)__builtin_amdgcn_readlane((int)plo, f & 63))
-                                         : (((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi2, f & 63) << 32) |
-                                            (uint32_t)__builtin_amdgcn_readlane((int)plo2, f & 63));
+            const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi[f >> 6], f & 63) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)plo[f >> 6], f & 63);
             // buffer descriptor in 4 SGPRs -> `buffer_load_dword v, voffset, s[rsrc], 0 offen`
             const __amdgpu_buffer_rsrc_t rsrc =
                 __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)plane_bytes, 0x00020000);
@@ -799,7 +802,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     // than 128 frames -- takes one wave per pixel (stack_wide.hip).
     bool contig_all = total < (int64_t(1) << 30);
     for (size_t i = 0; i < n && contig_all; ++i) contig_all = ld[i] == cols;
-    const bool reg128 = n > 64 && n <= 128 && contig_all && !partial && !median_only && !ctx->stack_exact;
+    const bool reg128 = n > 64 && n <= 256 && contig_all && !partial && !median_only && !ctx->stack_exact;  // (and 129 .. 256)
     if (n > 64 && !reg128) {  // deeper than one lane's registers: one wave per pixel (stack_wide.hip)
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
@@ -822,7 +825,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         int contiguous = 1;
         for (size_t i = 0; i < n; ++i) {
             args.p[i] = dplanes[i];
-            args.ld[i] = ld[i];
+            if (i < (size_t)kMaxStrided) args.ld[i] = ld[i];
             if (ld[i] != cols) contiguous = 0;
         }
         args.n = (int)n;
@@ -852,7 +855,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
                 AB_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)inf_plane, 0x7f800000, ctx->ws_bytes[AB_WS_STACK_INF] / sizeof(float), ctx->stream));
             for (int f = (int)n; f < np; ++f) {
                 args.p[f] = inf_plane;
-                args.ld[f] = cols;
+                if (f < kMaxStrided) args.ld[f] = cols;
             }
             args.n = np;
             n = (size_t)np;
@@ -868,7 +871,11 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
         ctx->stack_ev_valid = false;
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
-        if (np == 128) {  // reg128 (checked above): only the direct-gather kernels exist for 128 samples per lane
+        if (np == 256) {  // 129 .. 256 contiguous frames: 256 samples per lane (VGPRs + AGPRs), single pass
+            const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+            hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 99, true>), grid, block, 0, ctx->stream, args);
+            AB_HIP(ctx, hipGetLastError());
+        } else if (np == 128) {  // reg128 (checked above): only the direct-gather kernels exist for 128 samples per lane
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
             if (args.defer_list) {
                 hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kFastPass>), grid, block, 0, ctx->stream, args);

@@ -89,9 +89,9 @@ typedef struct {
  * All planes must be at least out->rows x out->cols; each is read with its own row stride
  * (= its cols), i.e. the reference's top-left crop to the minimum dims (combine.rs:104-113)
  * costs nothing.  *out_rejected receives StackResult.rejected_pixels (sum of per-pixel
- * rejection counts, combine.rs:158,181).  1 <= n <= 512 frames per call in this build: up to 128 contiguous frames
- * a pixel's samples live in one lane's registers (64: the HBM-bound kernel; 65 .. 128: ~4 ms for 4096^2), beyond that --
- * or with ragged strides -- a wave owns a pixel (same results, ~70 ms for 4096^2 x 128).
+ * rejection counts, combine.rs:158,181).  1 <= n <= 512 frames per call in this build: up to 256 contiguous frames
+ * a pixel's samples live in one lane's registers (64: the HBM-bound kernel; 65 .. 128: ~4 ms and 129 .. 256: ~10-16 ms
+ * for 4096^2), beyond that -- or with ragged strides -- a wave owns a pixel (same results, ~180 ms for 4096^2 x 257).
  * Floating-point contract: the f64 sums of iterations >= 1 are taken over the survivors in
  * ascending value order (the reference's order is unspecified, SURVEY.md 7 hard part 2). */
 AB_API int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,

@@ -166,7 +166,8 @@ def deep_frames(n, shape, seed):
 @pytest.mark.parametrize("shape", [(23, 41), (24, 40)])               # scalar gather / 16-byte quad gather (4 | pixels)
 @pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 256, 257, 512])
 def test_deep_stacks_one_wave_per_pixel(ctx, oracle, n, shape):
-    """more than 64 frames: csrc/stack_wide.hip (bitonic sort across a wave) must equal the oracle bit for bit"""
+    """more than 64 frames: 128 / 256 samples per lane in registers (contiguous planes, up to 256 frames) or
+    csrc/stack_wide.hip (bitonic sort across a wave; 257 .. 512 here) must equal the oracle bit for bit"""
     fr = deep_frames(n, shape, n)
     for sl, sh, it in ((3.0, 3.0, 5), (2.0, 2.5, 3), (1.0, 1.0, 1), (3.0, 3.0, 0)):
         want, wrej = oracle.stack_images(fr, sl, sh, it)
