@@ -270,10 +270,12 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 // One clipping pass over the two ends.  UPDATE: also fold the shaved samples into s_rem/q_rem.
 // DEFER (fast pass): look at the outermost chunk of each end only; a lane that would have to walk further is flagged
 // for the general pass instead of making its whole wave walk with it.
-template <int NP, bool UPDATE, bool DEFER = false>
+// SKIP (single-pass kernel): the high-end walk starts at the chunk that holds the wave's largest b instead of stepping
+// over the pads of a ragged / padded stack four registers at a time (129 frames in 256 slots: 32 chunks per pass).
+template <int NP, bool UPDATE, bool DEFER = false, bool SKIP = false>
 __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, int b, float center, float lo, float hi,
                                           double c0d, float c0, int &cl_out, int &ch_out, double &e_rem, double &q_rem,
-                                          bool *defer = nullptr) {
+                                          bool *defer = nullptr, int skip_hi = 0) {
     constexpr int CH = NP >= 4 ? 4 : NP;  // DEFER: the only chunk looked at (8 was tried: +0.13 ms, the walk is per-element bound)
     int cl = 0, ch = 0;
     bool found_lo = false, found_hi = false;
@@ -306,6 +308,9 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
     }
 #pragma unroll
     for (int c = 0; c < NP / CH; ++c) {
+        if constexpr (SKIP) {
+            if (c < skip_hi) continue;  // wave-uniform: every slot of this chunk lies above every lane's b
+        }
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int i = NP - 1 - (CH * c + j);
@@ -335,10 +340,12 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
     ch_out = ch;
 }
 
-template <int NP, int STAGE = 99, bool DEFER = false>
+template <int NP, int STAGE = 99, bool DEFER = false, bool SKIP = false>
 __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med, float mad, float sigma_low,
                                                 float sigma_high, uint32_t max_iter) {
     bool defer = false;
+    const int top = SKIP ? wave_max_i32<NP>(n - 1) : NP - 1;      // no lane's interval reaches past this slot
+    const int skip_hi = SKIP ? (NP - 1 - top) / (NP >= 4 ? 4 : NP) : 0;  // whole clip_ends chunks above it
     float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
     float center = med;
     int a = 0, b = n - 1, len = n;
@@ -355,7 +362,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         if (go) last_center = center;
         const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
         int cl, ch;
-        clip_ends<NP, false, DEFER>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer);
+        clip_ends<NP, false, DEFER, SKIP>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer, skip_hi);
         const int removed = (cl + ch > len) ? len : (cl + ch);
         if (go) {
             rej += (uint32_t)removed;
@@ -388,6 +395,9 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         const int a_hi = wave_max_i32<NP>(defer ? 0 : a), b_lo = wave_min_i32<NP>(defer ? NP - 1 : b);
 #pragma unroll
         for (int c = 0; c < NP / CH; ++c) {
+            if constexpr (SKIP) {
+                if (CH * c > top) continue;  // pads only: every lane would add e = c0 - c0
+            }
             const bool interior = (CH * c >= a_hi) && (CH * c + CH - 1 <= b_lo);  // wave-uniform
             if (interior) {
 #pragma unroll
@@ -444,7 +454,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         if (go) last_center = center;
         const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
         int cl, ch;
-        clip_ends<NP, true, DEFER>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer);
+        clip_ends<NP, true, DEFER, SKIP>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer, skip_hi);
         if constexpr (STAGE == 7) {  // ablation: + iteration 1's end walk
             ClipResult r;
             r.value = center + sigma + (float)(cl + ch) + (float)(e_rem + q_rem);
@@ -628,7 +638,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
     if constexpr (EXACT)
         r = clip_exact<NP>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
     else
-        r = clip_fast<NP, STAGE, MODE == kFastPass>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
+        r = clip_fast<NP, STAGE, MODE == kFastPass, MODE == kPlain>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
 
     uint32_t rej = r.rej;
     const bool defer = MODE == kFastPass && valid && r.defer;
