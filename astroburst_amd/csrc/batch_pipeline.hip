@@ -42,7 +42,7 @@
 
 namespace {
 
-constexpr int kMaxFrames = 64;
+constexpr int kMaxFrames = 128;  // lane-per-pixel kernels; 65 .. 128: two lane-resident registers per table, no prefetch
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;  // the waves of a block take consecutive chunks: 1 KB contiguous per frame per block step
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
@@ -93,14 +93,22 @@ __device__ __forceinline__ float cal_apply(float v, const CalPx &c) {
 // The plane pointers and frame scales live in VGPRs, one frame per lane (64 uniform pointers would overflow the SGPR file
 // and get spilled lane by lane); each load pulls its base out with two v_readlane into a buffer descriptor and issues
 // `buffer_load_dword v, voffset, s[rsrc], 0 offen` -- no 64-bit address arithmetic, no flat-address aperture check.
-template <int NP>
-__device__ __forceinline__ void gather(float (&u)[NP], uint32_t plo, uint32_t phi, uint32_t gi, uint32_t plane_bytes) {
+template <int NP, int R>
+__device__ __forceinline__ void gather(float (&u)[NP], const uint32_t (&plo_in)[R], const uint32_t (&phi_in)[R], uint32_t gi, uint32_t plane_bytes) {
+    static_assert(NP <= 64 * R, "one pointer register per 64 frames");
     const uint32_t off = gi * 4u;  // < 2^32: planes hold fewer than 2^30 pixels
     // opaque to loop-invariant code motion: hoisted out of the chunk loop, the 64 bases would be spilled right back
-    asm volatile("" : "+v"(plo), "+v"(phi));
+    uint32_t plo[R], phi[R];
 #pragma unroll
-    for (int f = 0; f < NP; ++f) {  // slots past n alias frame 0 (an L2 hit) and are overwritten with the +inf pad
-        const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi, f) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)plo, f);
+    for (int r = 0; r < R; ++r) {
+        plo[r] = plo_in[r];
+        phi[r] = phi_in[r];
+        asm volatile("" : "+v"(plo[r]), "+v"(phi[r]));
+    }
+#pragma unroll
+    for (int f = 0; f < NP; ++f) {  // slots past n read the host's pad plane (see scms_kernel)
+        const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi[f >> 6], f & 63) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)plo[f >> 6], f & 63);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)plane_bytes, 0x00020000);
         u[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off, 0, 0));
     }
@@ -122,23 +130,34 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
     extern __shared__ float S_[];  // [NP][64] sorted samples of this wave's 64 pixels
     const int lane = threadIdx.x & 63;
     const uint32_t wid = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), nwaves = gridDim.x * kWavesPerBlock;  // global wave id
-    uint32_t mycount = 0;  // lane f: rejected samples of frame f, over every chunk of this block (< 2^30 per block)
+    constexpr int R = (NP + 63) / 64;  // lane-resident tables: lane l of register r belongs to frame 64 r + l
+    constexpr bool PF = NP <= 64;      // 128 slots: u[], v[] alone fill the register file, the next chunk is not prefetched
+    uint32_t mycount[R];  // rejected samples of this lane's frames, over every chunk of this block (< 2^30 per block)
+    uint32_t plo[R], phi[R];
+    float myscale[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint64_t myptr = (uint64_t)a.p[64 * r + lane];
+        plo[r] = (uint32_t)myptr;
+        phi[r] = (uint32_t)(myptr >> 32);
+        myscale[r] = a.scale[64 * r + lane];
+        mycount[r] = 0;
+    }
     const uint32_t nchunks = (a.npix + kWave - 1) / kWave;
 #define S(i) S_[(i) * (kWave * kWavesPerBlock) + threadIdx.x]
-    const uint64_t myptr = (uint64_t)a.p[lane];
-    const uint32_t plo = (uint32_t)myptr, phi = (uint32_t)(myptr >> 32);
-    const float myscale = a.scale[lane];
 
     // software pipeline: the next chunk's samples are in flight while this one is sorted and clipped (a wave computes
     // for ~5 us per chunk and only two waves fit a SIMD, so nothing else would hide the HBM latency)
-    float nxt[NP];
+    float nxt[PF ? NP : 1];
     CalPx cnxt{};
     const uint32_t first = a.per_block ? wid * a.per_block : wid, step = a.per_block ? 1u : nwaves;
     const uint32_t end = a.per_block ? min(first + a.per_block, nchunks) : nchunks;
-    if (first < end) {
-        const uint32_t g0 = first * kWave + lane, gi0 = g0 < a.npix ? g0 : a.npix - 1;
-        gather<NP>(nxt, plo, phi, gi0, a.npix * 4u);
-        if constexpr (CAL) cnxt = cal_load(a.m, gi0);
+    if constexpr (PF) {
+        if (first < end) {
+            const uint32_t g0 = first * kWave + lane, gi0 = g0 < a.npix ? g0 : a.npix - 1;
+            gather<NP>(nxt, plo, phi, gi0, a.npix * 4u);
+            if constexpr (CAL) cnxt = cal_load(a.m, gi0);
+        }
     }
     for (uint32_t chunk = first; chunk < end; chunk += step) {
         const uint32_t g = chunk * kWave + lane;
@@ -147,18 +166,25 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
 
         // ---- gather, frame order (:344-348) ----
         float u[NP];
+        CalPx c{};
+        if constexpr (PF) {
 #pragma unroll
-        for (int f = 0; f < NP; ++f) u[f] = nxt[f];
-        const CalPx c = cnxt;
-        if (chunk + step < end) {
-            const uint32_t g1 = (chunk + step) * kWave + lane, gi1 = g1 < a.npix ? g1 : a.npix - 1;
-            gather<NP>(nxt, plo, phi, gi1, a.npix * 4u);
-            if constexpr (CAL) cnxt = cal_load(a.m, gi1);
+            for (int f = 0; f < NP; ++f) u[f] = nxt[f];
+            c = cnxt;
+            if (chunk + step < end) {
+                const uint32_t g1 = (chunk + step) * kWave + lane, gi1 = g1 < a.npix ? g1 : a.npix - 1;
+                gather<NP>(nxt, plo, phi, gi1, a.npix * 4u);
+                if constexpr (CAL) cnxt = cal_load(a.m, gi1);
+            }
+        } else {
+            const uint32_t gi = valid ? g : a.npix - 1;
+            gather<NP>(u, plo, phi, gi, a.npix * 4u);
+            if constexpr (CAL) c = cal_load(a.m, gi);
         }
         if constexpr (CAL) {
 #pragma unroll
             for (int f = 0; f < NP; ++f) {
-                const float cv = cal_apply(u[f], c) * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myscale), f));
+                const float cv = cal_apply(u[f], c) * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, myscale[f >> 6]), f & 63));
                 u[f] = PAD(f) ? __FLT_MAX__ : cv;  // (a pad must not be calibrated: a negative flat would clamp it to 0)
             }
         }
@@ -259,7 +285,9 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
         const unsigned long long force = __builtin_amdgcn_ballot_w64(valid & !all & (len == 0));
         float sum = 0.0f;
         float lo_s = lov;
-        uint32_t cnts = 0;  // lane f <- this chunk's rejections of frame f (one v_writelane each, summed into mycount below)
+        uint32_t cnts[R];  // lane f & 63 of register f >> 6 <- this chunk's rejections of frame f (one v_writelane each)
+#pragma unroll
+        for (int r = 0; r < R; ++r) cnts[r] = 0;
         if (a.stage == 3) sum = u[0] + v[NP - 1];
         else
 #pragma unroll
@@ -273,14 +301,16 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
             sum += mine ? 0.0f : u[f];
             int cnt = __popcll(rej);
             asm volatile("" : "+s"(cnt));  // keep it a register operand even where the compiler can fold it to a constant
-            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cnts) : "s"(cnt), "n"(f));
+            asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cnts[f >> 6]) : "s"(cnt), "n"(f & 63));
         }
-        mycount += cnts;
+#pragma unroll
+        for (int r = 0; r < R; ++r) mycount[r] += cnts[r];
         if (valid) a.out[g] = len == 0 ? 0.0f : sum / (float)len;
     }
 #undef S
 #undef PAD
-    a.rej[(size_t)wid * kMaxFrames + lane] = mycount;
+#pragma unroll
+    for (int r = 0; r < R; ++r) a.rej[(size_t)wid * kMaxFrames + 64 * r + lane] = mycount[r];
 }
 
 // [blocks][64] -> [64]: one block per frame
@@ -309,7 +339,7 @@ __global__ __launch_bounds__(kSumBlock) void cal_means_kernel(const BatchArgs a,
     const int first = blockIdx.y * FR;
     const uint32_t stride = gridDim.x * kSumBlock, bytes = a.npix * 4u;
     const uint64_t myptr = (uint64_t)a.p[first + ((threadIdx.x & 63) % FR)];
-    const uint32_t plo = (uint32_t)myptr, phi = (uint32_t)(myptr >> 32);
+    const uint32_t plo[1] = {(uint32_t)myptr}, phi[1] = {(uint32_t)(myptr >> 32)};
     // wave-uniform trip count: gather() moves the lane-resident pointers through a register copy, which only the ACTIVE
     // lanes take part in -- a lane that had left the loop would hand v_readlane a stale base
     float nxt[FR];
@@ -576,7 +606,7 @@ __global__ __launch_bounds__(kSumBlock) void cal_frame_sum_kernel(const float *c
 }
 
 int cu_of(ab_ctx *ctx) { return ctx->cu_count > 0 ? ctx->cu_count : 256; }
-int np_for(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 32 ? 32 : 64)))); }
+int np_for(int n) { return n <= 2 ? 2 : (n <= 4 ? 4 : (n <= 8 ? 8 : (n <= 16 ? 16 : (n <= 32 ? 32 : (n <= 64 ? 64 : 128))))); }
 
 int download(ab_ctx *ctx, void *dst, const void *src, size_t bytes) {
     void *pin = nullptr;
@@ -600,6 +630,13 @@ template <int NP, bool CAL, bool FULL>
 int launch_scms_np(ab_ctx *ctx, const BatchArgs &a, int64_t nchunks, uint32_t **rej_out) {
     constexpr int kThreads = kWave * kWavesPerBlock;
     const size_t lds = (size_t)NP * kThreads * sizeof(float);
+    if constexpr (NP > 64) {  // 128 KiB of the CU's 160: above the default dynamic-LDS limit
+        static bool raised = false;
+        if (!raised) {
+            AB_HIP(ctx, hipFuncSetAttribute((const void *)scms_kernel<NP, CAL, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            raised = true;
+        }
+    }
     const int grid = resident_grid(ctx, scms_kernel<NP, CAL, FULL>, kThreads, lds, (nchunks + kWavesPerBlock - 1) / kWavesPerBlock);
     const int waves = grid * kWavesPerBlock;
     void *rej = nullptr;
@@ -624,13 +661,15 @@ int launch_scms(ab_ctx *ctx, int np, const BatchArgs &a, int64_t nchunks, uint32
     case 8: return launch_scms_np<8, CAL, FULL>(ctx, a, nchunks, rej_out);
     case 16: return launch_scms_np<16, CAL, FULL>(ctx, a, nchunks, rej_out);
     case 32: return launch_scms_np<32, CAL, FULL>(ctx, a, nchunks, rej_out);
-    default: return launch_scms_np<64, CAL, FULL>(ctx, a, nchunks, rej_out);
+    case 64: return launch_scms_np<64, CAL, FULL>(ctx, a, nchunks, rej_out);
+    default: return launch_scms_np<128, CAL, FULL>(ctx, a, nchunks, rej_out);
     }
 }
 
 template <int NP>
 int launch_means_np(ab_ctx *ctx, const BatchArgs &a, std::vector<double> *part, int *grid_out) {
-    constexpr int FR = NP < 32 ? NP : 32, kGroups = NP / FR;
+    constexpr int FR = NP < 32 ? NP : 32;
+    const int kGroups = (a.n + FR - 1) / FR;  // groups that hold a real frame (the slots past n would only re-read frame 0)
     const int grid = std::max(1, resident_grid(ctx, cal_means_kernel<FR>, kSumBlock, 0, ((int64_t)a.npix + kSumBlock - 1) / kSumBlock * kGroups) / kGroups);
     void *d = nullptr;
     AB_TRY(ab_scratch(ctx, (size_t)grid * kMaxFrames * sizeof(double), &d));
@@ -648,7 +687,8 @@ int launch_means(ab_ctx *ctx, int np, const BatchArgs &a, std::vector<double> *p
     case 8: return launch_means_np<8>(ctx, a, part, grid_out);
     case 16: return launch_means_np<16>(ctx, a, part, grid_out);
     case 32: return launch_means_np<32>(ctx, a, part, grid_out);
-    default: return launch_means_np<64>(ctx, a, part, grid_out);
+    case 64: return launch_means_np<64>(ctx, a, part, grid_out);
+    default: return launch_means_np<128>(ctx, a, part, grid_out);
     }
 }
 
