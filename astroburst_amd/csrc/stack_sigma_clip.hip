@@ -812,7 +812,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     // than 128 frames -- takes one wave per pixel (stack_wide.hip).
     bool contig_all = total < (int64_t(1) << 30);
     for (size_t i = 0; i < n && contig_all; ++i) contig_all = ld[i] == cols;
-    const bool reg128 = n > 64 && n <= 256 && contig_all && !partial && !median_only && !ctx->stack_exact;  // (and 129 .. 256)
+    const bool reg128 = n > 64 && n <= 256 && contig_all && !partial && !ctx->stack_exact;  // (and 129 .. 256; median_combine too)
     if (n > 64 && !reg128) {  // deeper than one lane's registers: one wave per pixel (stack_wide.hip)
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
@@ -883,11 +883,16 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
         if (np == 256) {  // 129 .. 256 contiguous frames: 256 samples per lane (VGPRs + AGPRs), single pass
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-            hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 99, true>), grid, block, 0, ctx->stream, args);
+            if (median_only)
+                hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 10, true>), grid, block, 0, ctx->stream, args);
+            else
+                hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 99, true>), grid, block, 0, ctx->stream, args);
             AB_HIP(ctx, hipGetLastError());
         } else if (np == 128) {  // reg128 (checked above): only the direct-gather kernels exist for 128 samples per lane
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-            if (args.defer_list) {
+            if (median_only) {
+                hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 10, true>), grid, block, 0, ctx->stream, args);
+            } else if (args.defer_list) {
                 hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kFastPass>), grid, block, 0, ctx->stream, args);
                 hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kGeneralPass>), dim3(kDeferSlots), block, 0, ctx->stream, args);
             } else {

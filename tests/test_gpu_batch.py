@@ -26,7 +26,8 @@ def test_stack_bit_exact_with_non_finite_samples(ctx, oracle, n):
 
 @pytest.mark.parametrize("n", [65, 100, 128, 130, 257, 512])
 def test_deep_batch_stack_one_wave_per_pixel(ctx, oracle, n):
-    """more than 64 frames: scms_wide_kernel (a wave per pixel) must equal the oracle bit for bit, counts per frame included"""
+    """more than 64 frames: the 128-slot lane-per-pixel kernel (65 .. 128) and scms_wide_kernel (a wave per pixel, beyond)
+    must equal the oracle bit for bit, counts per frame included"""
     fr = frames_with_trouble(n, (19, 37), n)
     for sl, sh, it in ((2.5, 3.0, 5), (1.0, 1.0, 2), (3.0, 2.0, 1), (2.5, 3.0, 0)):
         want, wrej = oracle.sigma_clipped_mean_stack(fr, sl, sh, it)

@@ -176,6 +176,13 @@ def test_deep_stacks_one_wave_per_pixel(ctx, oracle, n, shape):
         assert np.array_equal(got, want, equal_nan=True), (sl, sh, it)
 
 
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 256, 300])
+def test_deep_median_combine(ctx, oracle, n):
+    """median_combine (calibration masters) of deep stacks: the register kernels up to 256 contiguous frames, a wave per pixel beyond"""
+    fr = deep_frames(n, (21, 45), 1000 + n)
+    assert np.array_equal(ctx.median_combine(fr), oracle.median_combine(fr), equal_nan=True)
+
+
 def test_deep_stack_ragged_planes_partial_and_median(ctx, oracle):
     import torch
     n = 150
