@@ -53,6 +53,7 @@ struct StackArgs {
     const float *p[kMaxFrames];
     int64_t ld[kMaxStrided];  // row stride (= cols of that plane): top-left crop for free
     int n;                   // frames actually present (<= NP)
+    int n_real;              // DIRECT single-pass kernel: slots [n_real, n) alias the +inf pad plane (n_real == n: no pads)
     int contiguous;          // all ld == cols: linear pixel index is the element offset
     int64_t rows, cols;      // output dims
     float sigma_low, sigma_high;
@@ -568,8 +569,27 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
                                           : (args.identity == 2 ? (float)x + (float)args.bzero : (float)((double)x * args.bscale + args.bzero));
             }
         }
+        if constexpr (MODE == kPlain) {
+            // a padded stack: the pads must not trip the non-finite path for every wave.  Wave-uniform chunk tests on an
+            // opaque scalar copy of the count (or all NP `f < n_real` become lane masks held across the kernel)
+            constexpr int CH = NP >= 8 ? 8 : NP;
 #pragma unroll
-        for (int f = 0; f < NP; ++f) nf = __builtin_fmaf(v[f], 0.0f, nf);
+            for (int c = 0; c < NP / CH; ++c) {
+                int t = args.n_real;
+                asm volatile("" : "+s"(t));
+                if (CH * c + CH <= t) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) nf = __builtin_fmaf(v[CH * c + j], 0.0f, nf);
+                } else if (CH * c < t) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        if (CH * c + j < t) nf = __builtin_fmaf(v[CH * c + j], 0.0f, nf);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < NP; ++f) nf = __builtin_fmaf(v[f], 0.0f, nf);
+        }
     } else {
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
@@ -582,7 +602,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
             v[f] = s;
         }
     }
-    int n = DIRECT ? NP : args.n;
+    int n = DIRECT ? (MODE == kPlain ? args.n_real : NP) : args.n;
     if (__any(nf != nf)) {  // rare: some lane of this wave met a non-finite sample
         n = 0;
 #pragma unroll
@@ -839,6 +859,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             if (ld[i] != cols) contiguous = 0;
         }
         args.n = (int)n;
+    args.n_real = (int)n;
         args.contiguous = contiguous;
         args.rows = rows;
         args.cols = cols;
@@ -1017,6 +1038,7 @@ int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size
         args.ld[i] = out->cols;
     }
     args.n = (int)n;
+    args.n_real = (int)n;
     args.contiguous = 1;
     args.rows = out->rows;
     args.cols = out->cols;
