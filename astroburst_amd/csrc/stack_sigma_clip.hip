@@ -130,19 +130,25 @@ __device__ __forceinline__ void med_mad_at(const float (&v)[NP], float &med_out,
     mad_out = best;
 }
 
-// lanes of one wave can disagree on n/2 (non-finite samples): evaluate each position present
-template <int NP, int MM>
+// lanes of one wave can disagree on n/2 (non-finite samples): evaluate each position present.  `cur` is wave-uniform;
+// the positions [LO, HI] are bisected (a linear chain of NP/2 compares hops over as many cold code blocks, one
+// instruction-cache miss each: a padded 200-frame stack spent a quarter of its time there).
+template <int NP, int LO, int HI>
 __device__ __forceinline__ void med_mad_dispatch(const float (&v)[NP], int m, int cur, float &med, float &mad) {
-    if (cur == MM) {
+    if constexpr (LO == HI) {
         float md, ma;
-        med_mad_at<NP, MM>(v, md, ma);
-        if (m == MM) {
+        med_mad_at<NP, LO>(v, md, ma);
+        if (m == LO) {
             med = md;
             mad = ma;
         }
-        return;
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        if (cur <= MID)
+            med_mad_dispatch<NP, LO, MID>(v, m, cur, med, mad);
+        else
+            med_mad_dispatch<NP, MID + 1, HI>(v, m, cur, med, mad);
     }
-    if constexpr (MM > 0) med_mad_dispatch<NP, MM - 1>(v, m, cur, med, mad);
 }
 
 // Per-lane state handed from the prologue (gather + sort + median/MAD) to a clipping engine.
@@ -640,7 +646,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         while (todo) {
             launder<NP>(v);  // or LICM evaluates all NP/2+1 candidate positions up front and spills
             const int cur = __builtin_amdgcn_readlane(m, (int)__builtin_ctzll(todo));
-            med_mad_dispatch<NP, NP / 2>(v, m, cur, med, mad);
+            med_mad_dispatch<NP, 0, NP / 2>(v, m, cur, med, mad);
             todo &= ~__ballot(m == cur);
         }
     }
