@@ -159,6 +159,22 @@ def test_ragged_stack_pads_stay_out_of_the_window(ctx, oracle, n):
         assert rej == wrej and same(got, want), normalize
 
 
+def test_deep_batch_channel_at_scale(ctx, oracle):
+    """1024^2 x 100 lights through the 128-slot kernel (128 KiB of LDS per block, pad plane, two count registers)"""
+    rng = np.random.default_rng(77)
+    shape = (1024, 1024)
+    n = 100
+    lights = [(rng.normal(500 + k, 10, shape)).astype(np.float32) for k in range(n)]
+    for k in range(0, n, 9):
+        lights[k][(11 * k) % 1024, :] += 300.0
+    lights[5][7, 9] = np.nan
+    bias = rng.normal(100, 2, shape).astype(np.float32)
+    flat = rng.normal(1.0, 0.03, shape).astype(np.float32)
+    want, wrej, wmean, wstd = oracle.run_batch_channel(lights, bias, None, flat, normalize=True)
+    got, rej, mean, std = ctx.run_batch_channel(lights, bias, None, flat, BatchStackConfig(normalize_before_stack=True))
+    assert rej == wrej and same(got, want)
+
+
 def test_compose_rgb_from_masters(ctx, oracle):
     import torch
     rng = np.random.default_rng(4)

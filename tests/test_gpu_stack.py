@@ -183,6 +183,25 @@ def test_deep_median_combine(ctx, oracle, n):
     assert np.array_equal(ctx.median_combine(fr), oracle.median_combine(fr), equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [100, 200])
+def test_deep_stack_at_scale(ctx, oracle, n):
+    """1024^2 x 100 / 200 frames through the 128 / 256-sample register kernels (byte offsets, grid and pad plane at a real size)"""
+    import torch
+    rows = cols = 1024
+    g = torch.Generator(device="cuda").manual_seed(n)
+    dev = [1000.0 + 15.0 * torch.randn((rows, cols), device="cuda", generator=g) for _ in range(n)]
+    for k in range(0, n, 7):
+        dev[k][k % rows, :] = float("nan")                            # a dead row per 7th frame
+        dev[k][:, (3 * k) % cols] += 500.0                            # a hot column
+    dev[3][100:200, 100:200] = float("inf")
+    fr = [d.cpu().numpy() for d in dev]
+    want, wrej = oracle.stack_images(fr, 3.0, 3.0, 5)
+    got, rej = ctx.stack_sigma_clip(dev, 3.0, 3.0, 5)
+    assert rej == wrej
+    assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)
+    assert np.array_equal(ctx.median_combine(dev).cpu().numpy(), oracle.median_combine(fr), equal_nan=True)
+
+
 def test_deep_stack_ragged_planes_partial_and_median(ctx, oracle):
     import torch
     n = 150
