@@ -641,6 +641,10 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
     float med = 0.0f, mad = 0.0f;
     if (__all(m == NP / 2)) {
         med_mad_at<NP, NP / 2>(v, med, mad);  // the common case: every lane has all NP samples
+    } else if (__all(m == __builtin_amdgcn_readfirstlane(m))) {
+        // one position for the whole wave (a padded stack): no loop -- with the samples live around a back edge the
+        // 128 / 256-sample kernels lose ~4 ms per 4096^2 launch to register shuffling
+        med_mad_dispatch<NP, 0, NP / 2>(v, m, __builtin_amdgcn_readfirstlane(m), med, mad);
     } else {
         unsigned long long todo = __ballot(1);
         while (todo) {

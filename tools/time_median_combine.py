@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import astroburst_amd as ab
 ctx = ab.Context(0)
-for n in (90, 128, 200, 256):
+for n in [int(v) for v in os.environ.get("N_LIST", "90,128,200,256").split(",")]:
     fr = [1000 + 10 * torch.randn((4096, 4096), device="cuda") for _ in range(n)]
     ctx.median_combine(fr); torch.cuda.synchronize()
     t0 = time.perf_counter()
