@@ -631,11 +631,8 @@ int launch_scms_np(ab_ctx *ctx, const BatchArgs &a, int64_t nchunks, uint32_t **
     constexpr int kThreads = kWave * kWavesPerBlock;
     const size_t lds = (size_t)NP * kThreads * sizeof(float);
     if constexpr (NP > 64) {  // 128 KiB of the CU's 160: above the default dynamic-LDS limit
-        static bool raised = false;
-        if (!raised) {
-            AB_HIP(ctx, hipFuncSetAttribute((const void *)scms_kernel<NP, CAL, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            raised = true;
-        }
+        // (per device, and a process may hold contexts on several: set it on every launch, it is a table write)
+        AB_HIP(ctx, hipFuncSetAttribute((const void *)scms_kernel<NP, CAL, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int grid = resident_grid(ctx, scms_kernel<NP, CAL, FULL>, kThreads, lds, (nchunks + kWavesPerBlock - 1) / kWavesPerBlock);
     const int waves = grid * kWavesPerBlock;
