@@ -70,7 +70,7 @@ struct ab_ctx {
     // AB_REGISTER_WORKERS overrides the default of 12.  The stage is GPU-throughput-bound, so past ~12 workers nothing is gained and
     // the step time only gets noisier (MI355X, 63 frames, median of 8: 6 -> 49.5 ms, 8 -> 45.9, 12 -> 41.0, 16 -> 41.5, 24 -> 44-55, 32 -> 70)
     std::vector<ab_ctx *> workers;
-    int register_workers = 12;
+    int register_workers = 16;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
     // HIP events recorded on ctx->stream right around the stack kernels of the last ab_stack_* call (ab_stack_last_kernel_ms)
