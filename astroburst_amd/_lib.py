@@ -24,7 +24,12 @@ class AstroBurstError(RuntimeError):
         self.message = message
 
 
-AB_OK, AB_ERR_INVALID, AB_ERR_HIP, AB_ERR_NO_DEVICE, AB_ERR_UNSUPPORTED, AB_ERR_NOMEM = range(6)
+AB_OK, AB_ERR_INVALID, AB_ERR_HIP, AB_ERR_NO_DEVICE, AB_ERR_UNSUPPORTED, AB_ERR_NOMEM, AB_ERR_COMM, AB_ERR_CANCELLED = range(8)
+AB_DT_I32, AB_DT_U32, AB_DT_I64, AB_DT_U64, AB_DT_F32, AB_DT_F64 = range(6)
+AB_RED_SUM, AB_RED_MAX, AB_RED_MIN = range(3)
+AB_COMM_ID_BYTES = 128
+# void (*ab_progress_cb)(const char *stage, uint64_t current, uint64_t total, void *user)
+PROGRESS_CB = C.CFUNCTYPE(None, C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p)
 
 
 class Plane(C.Structure):
@@ -311,9 +316,40 @@ def lib() -> C.CDLL:
     L.ab_generate_tile_pyramid_rgb.argtypes = [vp, pp, pp, pp, C.c_int64, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), vp, C.c_int32,
                                                C.POINTER(TileLevelC), C.POINTER(C.c_int32)]
     L.ab_extract_background.argtypes = [vp, pp, C.POINTER(BackgroundConfigC), pp, pp, C.POINTER(BackgroundInfoC)]
+    # progress / cancel
+    L.ab_ctx_set_progress_cb.argtypes = [vp, PROGRESS_CB, vp]
+    L.ab_ctx_request_cancel.argtypes = [vp]
+    L.ab_ctx_clear_cancel.argtypes = [vp]
+    # (e) multi-GPU
+    u8p = C.POINTER(C.c_uint8)
+    L.ab_comm_get_unique_id.argtypes = [u8p]
+    L.ab_comm_init_rank.argtypes = [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ab_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+    L.ab_comm_destroy.argtypes = [vp]
+    L.ab_comm_destroy.restype = None
+    L.ab_comm_rank.argtypes = [vp]
+    L.ab_comm_size.argtypes = [vp]
+    L.ab_comm_collectives_issued.argtypes = [vp]
+    L.ab_comm_collectives_issued.restype = C.c_uint64
+    L.ab_comm_group_start.argtypes = []
+    L.ab_comm_group_end.argtypes = []
+    L.ab_comm_allreduce.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int]
+    L.ab_comm_allgather.argtypes = [vp, vp, vp, vp, C.c_size_t]
+    L.ab_comm_broadcast.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
+    L.ab_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
+    L.ab_shard_frames.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ab_stack_sigma_clip_rows.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), C.c_int64, pp, u64p]
+    L.ab_stack_sigma_clip_rowband.argtypes = [vp, vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, u64p]
+    L.ab_stack_sigma_clip_sharded.argtypes = [vp, vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, u64p]
+    L.ab_allgather_rows.argtypes = [vp, vp, pp, pp]
+    L.ab_register_frames_sharded.argtypes = [vp, vp, pp, pp, C.c_size_t, C.c_int, C.POINTER(AffineAlignResultC)]
+    L.ab_compute_image_stats_sharded.argtypes = [vp, vp, pp, C.c_int64, C.POINTER(ImageStatsC)]
+    L.ab_warp_image_rows.argtypes = [vp, pp, C.POINTER(C.c_double), C.c_int64, C.c_int64, pp]
+    L.ab_auto_stretch_preview.argtypes = [vp, vp, pp, C.c_int64, C.POINTER(AutoStfConfigC), vp, C.POINTER(ImageStatsC),
+                                          C.POINTER(StfParamsC)]
     for name in declared_symbols():
         fn = getattr(L, name)  # AttributeError here = header / library drift
-        if fn.restype is C.c_int and name not in ("ab_last_error", "ab_version", "ab_ctx_get_stream"):
+        if fn.restype is C.c_int and name not in ("ab_last_error", "ab_version", "ab_ctx_get_stream", "ab_comm_collectives_issued"):
             fn.restype = C.c_int
     _lib = L
     return L

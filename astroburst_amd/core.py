@@ -194,6 +194,62 @@ def _is_torch(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
 
+class Comm:
+    """One RCCL rank bound to a Context's GPU (include/astroburst_hip.h section (e)).  Multi-process: rank 0 calls
+    Comm.unique_id(), the host carries the 128 bytes to the other ranks, every rank constructs Comm(ctx, id, nranks, rank)."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * _lib.AB_COMM_ID_BYTES)()
+        rc = _lib.lib().ab_comm_get_unique_id(buf)
+        if rc != _lib.AB_OK:
+            raise AstroBurstError(rc, "ab_comm_get_unique_id failed (librccl.so.1 not loadable?)")
+        return bytes(buf)
+
+    def __init__(self, ctx: "Context", uid: bytes, nranks: int, rank: int):
+        assert len(uid) == _lib.AB_COMM_ID_BYTES
+        self._ctx = ctx
+        self._L = ctx._L
+        h = C.c_void_p()
+        buf = (C.c_uint8 * _lib.AB_COMM_ID_BYTES).from_buffer_copy(uid)
+        ctx._check(self._L.ab_comm_init_rank(ctx._h, buf, nranks, rank, C.byref(h)))
+        self._h = h
+
+    @property
+    def rank(self) -> int:
+        return self._L.ab_comm_rank(self._h)
+
+    @property
+    def size(self) -> int:
+        return self._L.ab_comm_size(self._h)
+
+    @property
+    def collectives_issued(self) -> int:
+        return int(self._L.ab_comm_collectives_issued(self._h))
+
+    _DT = {"torch.int32": _lib.AB_DT_I32, "torch.int64": _lib.AB_DT_I64, "torch.float32": _lib.AB_DT_F32, "torch.float64": _lib.AB_DT_F64,
+           "torch.uint32": _lib.AB_DT_U32, "torch.uint64": _lib.AB_DT_U64}
+
+    def allreduce(self, t, op: str = "sum"):
+        """in place, on the context's stream"""
+        assert t.is_cuda and t.is_contiguous()
+        self._ctx.use_torch_stream()
+        ops = {"sum": _lib.AB_RED_SUM, "max": _lib.AB_RED_MAX, "min": _lib.AB_RED_MIN}
+        self._ctx._check(self._L.ab_comm_allreduce(self._ctx._h, self._h, C.c_void_p(t.data_ptr()), t.numel(), self._DT[str(t.dtype)], ops[op]))
+        return t
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ab_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
     """One ab_ctx: a device, a stream, a scratch arena.  Not thread-safe; one per caller thread."""
 
@@ -360,6 +416,117 @@ class Context:
         self._check(self._L.ab_stack_finalize_partial(self._h, C.c_void_p(s.data_ptr()), C.c_void_p(cnt.data_ptr()),
                                                       s.numel(), C.c_void_p(out.data_ptr())))
         return out
+
+    # ---- progress / cancel (infra/progress.rs:39-74) ------------------------------------------
+    def set_progress_cb(self, fn):
+        """fn(stage: str, current: int, total: int) at the reference's stage boundaries; None removes it."""
+        if fn is None:
+            self._progress = None
+            self._check(self._L.ab_ctx_set_progress_cb(self._h, _lib.PROGRESS_CB(0), None))
+            return
+        self._progress = _lib.PROGRESS_CB(lambda stage, cur, tot, _u: fn(stage.decode(), int(cur), int(tot)))
+        self._check(self._L.ab_ctx_set_progress_cb(self._h, self._progress, None))
+
+    def request_cancel(self):
+        self._check(self._L.ab_ctx_request_cancel(self._h))
+
+    def clear_cancel(self):
+        self._check(self._L.ab_ctx_clear_cancel(self._h))
+
+    # ---- (e) multi-GPU: row bands, frame shards (SURVEY.md 8e; csrc/sharded.hip) ---------------
+    def shard_rows(self, rows: int, nranks: int, rank: int):
+        r0, nr = C.c_int64(), C.c_int64()
+        self._check(self._L.ab_shard_rows(rows, nranks, rank, C.byref(r0), C.byref(nr)))
+        return int(r0.value), int(nr.value)
+
+    def shard_frames(self, n_frames: int, nranks: int, rank: int):
+        f0, nf = C.c_size_t(), C.c_size_t()
+        self._check(self._L.ab_shard_frames(n_frames, nranks, rank, C.byref(f0), C.byref(nf)))
+        return int(f0.value), int(nf.value)
+
+    def stack_sigma_clip_rows(self, frames, row0: int, nrows: int, sigma_low=3.0, sigma_high=3.0, max_iterations=5, out=None,
+                              want_rejected=True):
+        """rows [row0, row0 + nrows) of the stack of ALL frames (the exact single-level estimator on a band)."""
+        keep = []
+        planes = (Plane * len(frames))(*[self._plane(f, keep) for f in frames])
+        cols = min(p.cols for p in planes)
+        if out is None:
+            out = torch.empty((nrows, cols), dtype=torch.float32, device=frames[0].device)
+        po = Plane(C.c_void_p(out.data_ptr()), nrows, cols, 1)
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 0)
+        rej = C.c_uint64(0)
+        self._check(self._L.ab_stack_sigma_clip_rows(self._h, planes, len(frames), C.byref(cfg), row0, C.byref(po),
+                                                     C.byref(rej) if want_rejected else None))
+        return out, (int(rej.value) if want_rejected else None)
+
+    def stack_sigma_clip_rowband(self, comm, frames, out_band, sigma_low=3.0, sigma_high=3.0, max_iterations=5, want_rejected=True):
+        """this rank's band of the exact stack + StackResult.rejected_pixels summed over the ranks"""
+        keep = []
+        planes = (Plane * len(frames))(*[self._plane(f, keep) for f in frames])
+        po = Plane(C.c_void_p(out_band.data_ptr()), out_band.shape[0], out_band.shape[1], 1)
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 0)
+        rej = C.c_uint64(0)
+        self._check(self._L.ab_stack_sigma_clip_rowband(self._h, comm._h if comm else None, planes, len(frames), C.byref(cfg), C.byref(po),
+                                                        C.byref(rej) if want_rejected else None))
+        return out_band, (int(rej.value) if want_rejected else None)
+
+    def stack_sigma_clip_sharded(self, comm, local_frames, out, sigma_low=3.0, sigma_high=3.0, max_iterations=5, want_rejected=False):
+        """frame-sharded two-level stack: partial over this rank's frames -> RCCL all-reduce(sum, count) -> divide"""
+        keep = []
+        planes = (Plane * len(local_frames))(*[self._plane(f, keep) for f in local_frames])
+        po = self._plane(out, keep)
+        cfg = StackConfig(sigma_low, sigma_high, max_iterations, 0)
+        rej = C.c_uint64(0)
+        self._check(self._L.ab_stack_sigma_clip_sharded(self._h, comm._h if comm else None, planes, len(local_frames), C.byref(cfg),
+                                                        C.byref(po), C.byref(rej) if want_rejected else None))
+        return out, (int(rej.value) if want_rejected else None)
+
+    def allgather_rows(self, comm, band, full):
+        keep = []
+        pb = Plane(C.c_void_p(band.data_ptr() if band.numel() else 0), band.shape[0], band.shape[1], 1)
+        pf = self._plane(full, keep)
+        self._check(self._L.ab_allgather_rows(self._h, comm._h if comm else None, C.byref(pb), C.byref(pf)))
+        return full
+
+    def register_frames_sharded(self, comm, reference, targets, num_threads: int = 8):
+        """align_channel_affine(reference, t) for every t, target i estimated on rank i mod size; all results everywhere"""
+        keep = []
+        pr = self._plane(reference, keep)
+        planes = (Plane * max(len(targets), 1))(*[self._plane(t, keep) for t in targets])
+        res = (_lib.AffineAlignResultC * max(len(targets), 1))()
+        self._check(self._L.ab_register_frames_sharded(self._h, comm._h if comm else None, C.byref(pr), planes, len(targets), num_threads, res))
+        return [AffineAlignResult(tuple(r.transform), int(r.matched_stars), int(r.inliers), r.residual_px, AFFINE_METHODS[r.method])
+                for r in res[:len(targets)]]
+
+    def compute_image_stats_sharded(self, comm, band, total_rows: int) -> ImageStats:
+        keep = []
+        pb = self._plane(band, keep)
+        s = ImageStatsC()
+        self._check(self._L.ab_compute_image_stats_sharded(self._h, comm._h if comm else None, C.byref(pb), total_rows, C.byref(s)))
+        return self._stats_out(s)
+
+    def warp_image_rows(self, image, transform, out_rows: int, row0: int, out_band):
+        keep = []
+        pi = self._plane(image, keep)
+        po = self._plane(out_band, keep)
+        t = (C.c_double * 6)(*[float(v) for v in transform])
+        self._check(self._L.ab_warp_image_rows(self._h, C.byref(pi), t, out_rows, row0, C.byref(po)))
+        return out_band
+
+    def auto_stretch_preview(self, image, out=None, comm=None, total_rows: int = 0, target_bg=0.25, shadow_k=-2.8, fetch=True):
+        """auto_stretch_preview (cmd/common.rs:18-22): compute_image_stats -> auto_stf -> apply_stf (u8) as one asynchronous device
+        chain.  -> (u8 plane, ImageStats | None, StfParams | None); fetch=False leaves the call fully asynchronous."""
+        keep = []
+        pi = self._plane(image, keep)
+        if out is None:
+            out = torch.empty((pi.rows, pi.cols), dtype=torch.uint8, device=image.device)
+        cfg = AutoStfConfigC(target_bg, shadow_k)
+        s, p = ImageStatsC(), StfParamsC()
+        self._check(self._L.ab_auto_stretch_preview(self._h, comm._h if comm else None, C.byref(pi), total_rows, C.byref(cfg),
+                                                    C.c_void_p(out.data_ptr()), C.byref(s) if fetch else None, C.byref(p) if fetch else None))
+        if not fetch:
+            return out, None, None
+        return out, self._stats_out(s), StfParams(p.shadow, p.midtone, p.highlight)
 
     # ---- core/stacking/align.rs, core/alignment/affine.rs -------------------------------------
     def shift_image_subpixel(self, image, dy: float, dx: float, out=None):

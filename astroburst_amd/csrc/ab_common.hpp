@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,6 +32,8 @@ enum {
     AB_WS_BATCH_WIDE,         // tables of a > 64-frame batch stack
     AB_WS_STACK_INF,          // one plane of +inf: stands in for the frames a stack is short of a power of two
     AB_WS_BATCH_PAD,          // one plane of FLT_MAX: the same for the batch stack (where +inf is a sample like any other)
+    AB_WS_STATS,              // state block, 65 536-bin histograms and partials of the statistics chain (stats.hip)
+    AB_WS_SHARD,              // (sum f64, count u32) partial planes of the frame-sharded stack (sharded.hip)
     AB_WS_SLOTS
 };
 
@@ -76,7 +80,19 @@ struct ab_ctx {
     // HIP events recorded on ctx->stream right around the stack kernels of the last ab_stack_* call (ab_stack_last_kernel_ms)
     hipEvent_t stack_ev[2] = {nullptr, nullptr};
     bool stack_ev_valid = false;
+    hipEvent_t switch_ev = nullptr;  // orders the stream being left before the one switched to (ab_ctx_set_stream)
+    // progress / cancel (infra/progress.rs:39-74): the callback is serialised by progress_mu (frame workers tick it too);
+    // worker contexts forward to their parent
+    ab_progress_cb progress_cb = nullptr;
+    void *progress_user = nullptr;
+    std::atomic<int> cancel{0};
+    std::mutex progress_mu;
+    std::mutex err_mu;  // ab_set_error may be reached from the reference-preparation thread and the caller at once (affine.hip)
+    ab_ctx *parent = nullptr;
 };
+
+// stage boundary: AB_ERR_CANCELLED ("Operation cancelled") if the host asked to stop, else ticks the callback (if any)
+int ab_progress(ab_ctx *ctx, const char *stage, uint64_t current, uint64_t total);
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);
 
@@ -154,6 +170,13 @@ int ab_plane_median_f32(ab_ctx *ctx, const ab_plane_sel &s, float *out, uint64_t
 // device-level entry points shared between translation units
 int ab_stats_device(ab_ctx *ctx, const float *data, int64_t n, int use_known, double known_min, double known_max,
                     ab_image_stats *out);
+// the asynchronous statistics chain (stats.hip): nothing is synchronised; *result_dev / *tx_dev / *stf_dev point into the context's
+// state block and are valid once the stream reaches this point.  comm joins row bands (n_total = the whole image's pixel count).
+int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, int64_t n_total, int use_known, double known_min,
+                     double known_max, const ab_auto_stf_config *stf_cfg, const ab_image_stats **result_dev, const void **tx_dev,
+                     const ab_stf_params **stf_dev);
+// apply_stf -> u8 with the transform (StfTx) read from device memory
+int ab_stf_u8_device_tx(ab_ctx *ctx, const float *in, int64_t n, const void *tx_dev, uint8_t *out);
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out,
                            ab_pixel_xf xf = ab_pixel_xf());
@@ -167,6 +190,8 @@ int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *t
 int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, int64_t src_ld, double dy, double dx, float *out);
 int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
                    int64_t out_cols, float *out);
+int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
+                        int64_t out_cols, int64_t row0, int64_t nrows, float *out);
 int ab_resample_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, int64_t out_rows, int64_t out_cols,
                        float *out);
 

@@ -11,13 +11,47 @@ int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(ctx->err_mu);
+        ctx->err = buf;
+    }
     return code;
+}
+
+int ab_progress(ab_ctx *ctx, const char *stage, uint64_t current, uint64_t total) {
+    ab_ctx *root = ctx;
+    while (root->parent) root = root->parent;
+    if (root->cancel.load(std::memory_order_relaxed)) return ab_set_error(ctx, AB_ERR_CANCELLED, "Operation cancelled");
+    if (root->progress_cb) {
+        std::lock_guard<std::mutex> lk(root->progress_mu);
+        root->progress_cb(stage, current, total, root->progress_user);
+    }
+    return AB_OK;
 }
 
 extern "C" {
 
-const char *ab_version(void) { return "astroburst_hip 0.1.0 (gfx950)"; }
+int ab_ctx_set_progress_cb(ab_ctx *ctx, ab_progress_cb cb, void *user) {
+    if (!ctx) return AB_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->progress_mu);
+    ctx->progress_cb = cb;
+    ctx->progress_user = user;
+    return AB_OK;
+}
+
+int ab_ctx_request_cancel(ab_ctx *ctx) {
+    if (!ctx) return AB_ERR_INVALID;
+    ctx->cancel.store(1);
+    return AB_OK;
+}
+
+int ab_ctx_clear_cancel(ab_ctx *ctx) {
+    if (!ctx) return AB_ERR_INVALID;
+    ctx->cancel.store(0);
+    return AB_OK;
+}
+
+const char *ab_version(void) { return "astroburst_hip 0.2.0 (gfx950)"; }
 
 int ab_ctx_create(int device_id, ab_ctx **out) {
     if (!out) return AB_ERR_INVALID;
@@ -40,7 +74,7 @@ int ab_ctx_create(int device_id, ab_ctx **out) {
         return AB_ERR_NO_DEVICE;
     }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->counters, AB_REJ_SLOTS * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc((void **)&ctx->counters, (AB_REJ_SLOTS + 8) * sizeof(unsigned long long)) != hipSuccess) {  // + spare slots (sharded.hip)
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         delete ctx;
         return AB_ERR_HIP;
@@ -67,23 +101,34 @@ void ab_ctx_destroy(ab_ctx *ctx) {
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     for (hipEvent_t e : ctx->stack_ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
 const char *ab_last_error(const ab_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+// State the context owns (rejection counters, scratch arena, defer lists, statistics block) may still be in use by asynchronous
+// work queued on the stream being left: the new stream waits for an event recorded there, so calls stay ordered across a switch.
+static int switch_stream(ab_ctx *ctx, hipStream_t next) {
+    if (next == ctx->stream) return AB_OK;
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->switch_ev) AB_HIP(ctx, hipEventCreateWithFlags(&ctx->switch_ev, hipEventDisableTiming));
+    AB_HIP(ctx, hipEventRecord(ctx->switch_ev, ctx->stream));
+    AB_HIP(ctx, hipStreamWaitEvent(next, ctx->switch_ev, 0));
+    ctx->stream = next;
+    return AB_OK;
+}
+
 int ab_ctx_set_stream(ab_ctx *ctx, void *hip_stream) {
     if (!ctx) return AB_ERR_INVALID;
     // a NULL handle IS a stream: HIP's legacy default stream (what PyTorch uses by default)
-    ctx->stream = (hipStream_t)hip_stream;
-    return AB_OK;
+    return switch_stream(ctx, (hipStream_t)hip_stream);
 }
 
 int ab_ctx_reset_stream(ab_ctx *ctx) {
     if (!ctx) return AB_ERR_INVALID;
-    ctx->stream = ctx->own_stream;
-    return AB_OK;
+    return switch_stream(ctx, ctx->own_stream);
 }
 
 void *ab_ctx_get_stream(ab_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -249,13 +294,17 @@ void ab_stage_out_abort(ab_ctx *ctx, StagedOut *o) {
 int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn, bool drain_caller_stream) {
     const size_t workers = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1));
     if (workers <= 1) {
-        for (size_t f = 0; f < n; ++f) AB_TRY(fn(ctx, f));
+        for (size_t f = 0; f < n; ++f) {
+            AB_TRY(ab_progress(ctx, what, f + 1, n));
+            AB_TRY(fn(ctx, f));
+        }
         return AB_OK;
     }
     while (ctx->workers.size() < workers) {
         ab_ctx *wc = nullptr;
         if (ab_ctx_create(ctx->device, &wc) != AB_OK) return ab_set_error(ctx, AB_ERR_HIP, "cannot create %s worker context", what);
         wc->register_workers = 1;
+        wc->parent = ctx;
         ctx->workers.push_back(wc);
     }
     if (drain_caller_stream) AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // whatever the caller queued on ctx (its frames, shared tables) is complete
@@ -270,13 +319,14 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
                 return;
             }
             for (size_t f = next.fetch_add(1); f < n; f = next.fetch_add(1)) {
-                const int rc = fn(wc, f);
+                int rc = ab_progress(wc, what, f + 1, n);  // per-frame tick; a cancel request stops the fan-out here
+                if (rc == AB_OK) rc = fn(wc, f);
                 if (rc != AB_OK) {
                     rcs[t] = rc;
-                    return;
+                    break;  // (the stream is still drained below: nothing of this worker may be in flight when the caller cleans up)
                 }
             }
-            if (hipStreamSynchronize(wc->stream) != hipSuccess) rcs[t] = AB_ERR_HIP;
+            if (hipStreamSynchronize(wc->stream) != hipSuccess && rcs[t] == AB_OK) rcs[t] = AB_ERR_HIP;
         });
     for (std::thread &th : pool) th.join();
     for (size_t t = 0; t < workers; ++t)

@@ -226,6 +226,7 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
     } while (0)
 
     BG_HIP(hipMalloc((void **)&dcells, (size_t)grid * grid * sizeof(CellOut)));
+    BG_TRY(ab_progress(ctx, "sampling background", 1, 4));  // background.rs:63-66
 
     // global median / MAD over finite, > 0 pixels (:135-146)
     float global_median, global_mad;
@@ -278,6 +279,7 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
         return rc;
     }
 
+    BG_TRY(ab_progress(ctx, "fitting polynomial surface", 2, 4));  // background.rs:79-84 (cancel checked, then tick)
     // fit_polynomial_surface (:251-290)
     PolyArgs pa;
     memset(&pa, 0, sizeof pa);
@@ -305,6 +307,7 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
     for (size_t i = 0; i < n_terms; ++i) pa.coeffs[i] = atb[i];
     if (info) memcpy(info->coeffs, pa.coeffs, sizeof pa.coeffs);
 
+    BG_TRY(ab_progress(ctx, "generating model", 3, 4));  // background.rs:88-93
     // evaluate_polynomial_surface + apply_correction (:307-383)
     if (out_model) {
         BG_TRY(ab_stage_out_begin(ctx, out_model, &so_model));
@@ -322,6 +325,7 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
     msel.data = model;
     msel.n = npix;
     BG_TRY(ab_plane_median_f32(ctx, msel, &model_median, nullptr));
+    BG_TRY(ab_progress(ctx, "applying correction", 4, 4));  // background.rs:97-99
     BG_TRY(ab_stage_out_begin(ctx, out_corrected, &so_corr));
     corr_open = true;
     const int g = (int)std::min<int64_t>((npix + kBlock - 1) / kBlock, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8);

@@ -112,11 +112,13 @@ __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ sr
 // affine.rs:674-687; map() is affine.rs:74-80
 __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src, int src_rows, int src_cols, double a,
                                                    double b, double tx, double c, double d, double ty, int out_rows,
-                                                   int out_cols, float *__restrict__ out) {
+                                                   int out_cols, float *__restrict__ out, int row0) {
     // two output pixels per lane (x and x + 256): their f64 chains are independent, which is the only instruction-level
     // parallelism this f64-bound kernel can get
     const int x0 = blockIdx.x * 512 + threadIdx.x;
-    const int y = blockIdx.y;
+    // row0: the band of output rows [row0, row0 + gridDim.y) this launch produces (row-band sharding); the
+    // coordinate arithmetic uses the row's index in the WHOLE output, so a band is bit-identical to the same rows of a full warp
+    const int y = blockIdx.y + row0;
     const double yf = (double)y;
     float r[2];
     bool live[2];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        if (live[u]) out[(size_t)y * out_cols + x0 + 256 * u] = r[u];
+        if (live[u]) out[(size_t)blockIdx.y * out_cols + x0 + 256 * u] = r[u];
 }
 
 // resample.rs:41-58: target pixel centres mapped onto the source grid
@@ -190,13 +192,22 @@ int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, i
 
 int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
                    int64_t out_cols, float *out) {
+    return ab_warp_rows_device(ctx, src, src_rows, src_cols, t, out_rows, out_cols, 0, out_rows, out);
+}
+
+// rows [row0, row0 + nrows) of warp_image(src, t, out_rows, out_cols) into the contiguous nrows x out_cols plane `out`
+int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
+                        int64_t out_cols, int64_t row0, int64_t nrows, float *out) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
+    AB_CHECK(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= out_rows, "row band [%lld, %lld) leaves the %lld output rows", (long long)row0,
+             (long long)(row0 + nrows), (long long)out_rows);
+    if (nrows == 0) return AB_OK;
     AB_CHECK(ctx, src != out, "warp_image cannot run in place");
     AB_CHECK(ctx, out_rows <= 65535 && out_rows * out_cols < (int64_t(1) << 31) && src_rows * src_cols < (int64_t(1) << 31),
              "image of %lld x %lld needs a tiled launch (not in this build)", (long long)out_rows, (long long)out_cols);
-    const dim3 grid((unsigned)((out_cols + 511) / 512), (unsigned)out_rows), block(256);
+    const dim3 grid((unsigned)((out_cols + 511) / 512), (unsigned)nrows), block(256);
     hipLaunchKernelGGL(warp_kernel, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
-                       t[4], t[5], (int)out_rows, (int)out_cols, out);
+                       t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -220,6 +231,14 @@ int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, double 
     }
     ab_stage_release(ctx, &in);
     return rc;
+}
+
+// rows [row0, row0 + out_band->rows) of warp_image(src, transform, out_rows, out_band->cols) (device planes)
+int ab_warp_image_rows(ab_ctx *ctx, const ab_plane *src, const double transform[6], int64_t out_rows, int64_t row0, ab_plane_mut *out_band) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, src && out_band && transform && src->data && out_band->data, "null plane or transform");
+    AB_CHECK(ctx, src->on_device && out_band->on_device, "ab_warp_image_rows takes device-resident planes");
+    return ab_warp_rows_device(ctx, src->data, src->rows, src->cols, transform, out_rows, out_band->cols, row0, out_band->rows, out_band->data);
 }
 
 int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out) {

@@ -1,0 +1,195 @@
+// The hot path across the GPUs of one node: one context + one communicator rank per GPU.
+//
+// What the reference shards naturally:
+//   * the per-pixel kappa-sigma loop (core/stacking/combine.rs:160-182: `par_chunks_mut(cols)`, rows are independent)
+//     -> ROW BANDS.  Rank r stacks rows [row0_r, row0_r + nrows_r) of ALL n frames with the single-GPU kernel; the result is
+//     the reference's single-level estimator bit for bit.  The only exchanged data are integers: the rejected-sample count
+//     (one u64), and for the statistics of the stacked image min / max and three 65 536-bin histograms (stats.hip).
+//   * per-frame whole-image work (align_channel_affine, core/alignment/affine.rs:129-212) -> BY FRAME (frame k on rank
+//     k mod G); the estimates are exchanged as N x 80 bytes.
+//   * BASELINE.json configs[3] names a third scheme: the FRAME SET is sharded (512 frames, 64 per GPU), every rank clips its
+//     own frames to per-pixel (sum of survivors f64, count u32), the partials are all-reduced over xGMI and divided.  That
+//     is a two-level estimator -- not the reference's -- checked against its own oracle (orc_stack_partial_noalign).
+#include "ab_common.hpp"
+
+#include <algorithm>
+
+int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
+                    const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, uint64_t *out_rejected,
+                    bool median_only);
+
+namespace {
+
+__global__ void sum_counters_kernel(const unsigned long long *__restrict__ counters, int n, unsigned long long *__restrict__ out) {
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < n; i += 64) s += counters[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) *out = s;
+}
+
+// rejected samples of the stack just enqueued on ctx, summed over the ranks of comm
+int total_rejected(ab_ctx *ctx, ab_comm *comm, uint64_t *out) {
+    unsigned long long *slot = ctx->counters + AB_REJ_SLOTS;  // one spare u64 behind the per-wave counters
+    hipLaunchKernelGGL(sum_counters_kernel, dim3(1), dim3(64), 0, ctx->stream, ctx->counters, AB_REJ_SLOTS, slot);
+    AB_HIP(ctx, hipGetLastError());
+    AB_TRY(ab_comm_allreduce(ctx, comm, slot, 1, AB_DT_U64, AB_RED_SUM));
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, sizeof(unsigned long long), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = *(const unsigned long long *)pin;
+    return AB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// rank r of nranks owns rows [row0, row0 + nrows): ceil(rows / nranks) rows each, the last bands shorter (possibly empty)
+int ab_shard_rows(int64_t rows, int nranks, int rank, int64_t *row0, int64_t *nrows) {
+    if (rows < 0 || nranks < 1 || rank < 0 || rank >= nranks || !row0 || !nrows) return AB_ERR_INVALID;
+    const int64_t per = (rows + nranks - 1) / nranks;
+    const int64_t lo = std::min<int64_t>(rows, per * rank), hi = std::min<int64_t>(rows, per * (rank + 1));
+    *row0 = lo;
+    *nrows = hi - lo;
+    return AB_OK;
+}
+
+// contiguous, balanced frame ranges: rank r gets frames [f0, f0 + nf)
+int ab_shard_frames(size_t n_frames, int nranks, int rank, size_t *f0, size_t *nf) {
+    if (nranks < 1 || rank < 0 || rank >= nranks || !f0 || !nf) return AB_ERR_INVALID;
+    const size_t base = n_frames / (size_t)nranks, extra = n_frames % (size_t)nranks;
+    *f0 = (size_t)rank * base + std::min<size_t>((size_t)rank, extra);
+    *nf = base + ((size_t)rank < extra ? 1 : 0);
+    return AB_OK;
+}
+
+// Rows [row0, row0 + out_band->rows) of stack_images' per-pixel loop over all n frames (combine.rs:160-182): the exact
+// single-level estimator, restricted to a band.  Frames are device-resident and at least (row0 + band rows) x band cols.
+int ab_stack_sigma_clip_rows(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, int64_t row0,
+                             ab_plane_mut *out_band, uint64_t *out_rejected) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, planes && n >= 1, "No images to stack");
+    AB_CHECK(ctx, cfg && out_band && out_band->data && out_band->on_device, "null config or output (device band expected)");
+    AB_CHECK(ctx, row0 >= 0 && out_band->rows >= 0 && out_band->cols > 0, "bad row band");
+    if (out_band->rows == 0) {  // an empty band (more ranks than rows): nothing to stack, nothing rejected
+        if (out_rejected) *out_rejected = 0;
+        AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, AB_REJ_SLOTS * sizeof(unsigned long long), ctx->stream));
+        return AB_OK;
+    }
+    std::vector<const float *> dp(n);
+    std::vector<int64_t> ld(n);
+    for (size_t i = 0; i < n; ++i) {
+        AB_CHECK(ctx, planes[i].on_device && planes[i].data, "row-band stacking takes device-resident frames");
+        AB_CHECK(ctx, planes[i].rows >= row0 + out_band->rows && planes[i].cols >= out_band->cols, "frame %zu is smaller than the band's extent", i);
+        dp[i] = planes[i].data + row0 * planes[i].cols;
+        ld[i] = planes[i].cols;
+    }
+    return ab_stack_device(ctx, dp.data(), ld.data(), n, out_band->rows, out_band->cols, cfg, out_band->data, nullptr, nullptr, out_rejected,
+                           false);
+}
+
+// The same with the band taken from the communicator (ab_shard_rows over the minimum frame dims, combine.rs:104-113) and
+// StackResult.rejected_pixels summed over the ranks.  out_band must hold this rank's rows x min cols.
+int ab_stack_sigma_clip_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
+                                ab_plane_mut *out_band, uint64_t *out_rejected_total) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, planes && n >= 1, "No images to stack");
+    AB_CHECK(ctx, cfg && out_band, "null config or output");
+    int64_t min_rows = planes[0].rows, min_cols = planes[0].cols;
+    for (size_t i = 1; i < n; ++i) {
+        min_rows = std::min(min_rows, planes[i].rows);
+        min_cols = std::min(min_cols, planes[i].cols);
+    }
+    int64_t row0 = 0, nrows = 0;
+    AB_CHECK(ctx, ab_shard_rows(min_rows, ab_comm_size(comm), ab_comm_rank(comm), &row0, &nrows) == AB_OK, "bad communicator");
+    AB_CHECK(ctx, out_band->rows == nrows && out_band->cols == min_cols, "this rank's band is %lld x %lld (got %lld x %lld)", (long long)nrows,
+             (long long)min_cols, (long long)out_band->rows, (long long)out_band->cols);
+    AB_TRY(ab_stack_sigma_clip_rows(ctx, planes, n, cfg, row0, out_band, nullptr));
+    if (out_rejected_total) AB_TRY(total_rejected(ctx, comm, out_rejected_total));
+    return AB_OK;
+}
+
+// Frame-sharded two-level stack (BASELINE configs[3]): per-GPU partial over THIS rank's frames -> all-reduce of the
+// per-pixel (sum f64, count u32) over xGMI -> divide.  `out` (device, rows x cols) is the full image on every rank.
+// The partial planes live in the context (12 bytes per pixel).  Collective payload: 12 x rows x cols bytes, independent
+// of the frame count.
+int ab_stack_sigma_clip_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *local_planes, size_t n_local, const ab_stack_config *cfg,
+                                ab_plane_mut *out, uint64_t *out_rejected_total) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, local_planes && n_local >= 1, "every rank needs at least one frame (No images to stack)");
+    AB_CHECK(ctx, cfg && out && out->data && out->on_device, "null config or output (device plane expected)");
+    const int64_t total = out->rows * out->cols;
+    AB_CHECK(ctx, total > 0, "stack output has a zero dimension");
+    char *ws = nullptr;
+    const size_t sum_bytes = (size_t)total * sizeof(double);
+    AB_TRY(ab_workspace(ctx, AB_WS_SHARD, sum_bytes + (size_t)total * sizeof(uint32_t), (void **)&ws));
+    double *psum = (double *)ws;
+    uint32_t *pcnt = (uint32_t *)(ws + sum_bytes);
+    AB_TRY(ab_stack_sigma_clip_partial(ctx, local_planes, n_local, cfg, out->rows, out->cols, psum, pcnt, nullptr));
+    AB_TRY(ab_comm_allreduce(ctx, comm, psum, (size_t)total, AB_DT_F64, AB_RED_SUM));
+    AB_TRY(ab_comm_allreduce(ctx, comm, pcnt, (size_t)total, AB_DT_U32, AB_RED_SUM));
+    AB_TRY(ab_stack_finalize_partial(ctx, psum, pcnt, total, out->data));
+    if (out_rejected_total) AB_TRY(total_rejected(ctx, comm, out_rejected_total));
+    return AB_OK;
+}
+
+// Assemble row bands into the full image on every rank: `full` (device, total rows x cols) receives rank r's band at
+// rows [row0_r, row0_r + nrows_r) (ab_shard_rows).  One broadcast per rank inside one RCCL group; bands may be unequal.
+int ab_allgather_rows(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, ab_plane_mut *full) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, band && full && full->data && full->on_device && (band->rows == 0 || (band->data && band->on_device)), "device planes expected");
+    const int size = ab_comm_size(comm), rank = ab_comm_rank(comm);
+    int64_t row0 = 0, nrows = 0;
+    AB_CHECK(ctx, ab_shard_rows(full->rows, size, rank, &row0, &nrows) == AB_OK && nrows == band->rows && (nrows == 0 || band->cols == full->cols),
+             "band does not match this rank's share of the image");
+    float *mine = full->data + row0 * full->cols;
+    if (nrows > 0 && band->data != mine)
+        AB_HIP(ctx, hipMemcpyAsync(mine, band->data, (size_t)nrows * full->cols * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    if (!comm || size == 1) return AB_OK;
+    AB_TRY(ab_comm_group_start());
+    int rc = AB_OK;
+    for (int r = 0; r < size && rc == AB_OK; ++r) {
+        int64_t r0 = 0, nr = 0;
+        ab_shard_rows(full->rows, size, r, &r0, &nr);
+        if (nr > 0) rc = ab_comm_broadcast(ctx, comm, full->data + r0 * full->cols, (size_t)nr * full->cols * sizeof(float), r);
+    }
+    const int rc2 = ab_comm_group_end();
+    if (rc != AB_OK) return rc;
+    if (rc2 != AB_OK) return ab_set_error(ctx, AB_ERR_COMM, "ncclGroupEnd failed");
+    return AB_OK;
+}
+
+// align_channel_affine(reference, targets[i]) for all i < n, the estimates computed by frame across the ranks (target i on
+// rank i mod size) and exchanged: every rank receives all n results.  Targets this rank does not own are not read.
+// The exchange is an all-reduce(SUM) of the results' bit patterns as u64 words over zero-initialised slots: adding zeros
+// is the identity on integers, so every f64 arrives bit for bit.
+int ab_register_frames_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
+                               ab_affine_align_result *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, reference && targets && out, "null argument");
+    const int size = ab_comm_size(comm), rank = ab_comm_rank(comm);
+    std::vector<ab_plane> mine;
+    std::vector<size_t> idx;
+    for (size_t i = (size_t)rank; i < n; i += (size_t)size) {
+        mine.push_back(targets[i]);
+        idx.push_back(i);
+    }
+    std::vector<ab_affine_align_result> res(mine.size());
+    if (!mine.empty()) AB_TRY(ab_register_frames(ctx, reference, mine.data(), mine.size(), num_threads, res.data()));
+    static_assert(sizeof(ab_affine_align_result) % 8 == 0, "results travel as u64 words");
+    memset(out, 0, n * sizeof *out);
+    for (size_t k = 0; k < idx.size(); ++k) out[idx[k]] = res[k];
+    if (!comm || size == 1 || n == 0) return AB_OK;
+    void *dev = nullptr;
+    const size_t bytes = n * sizeof *out;
+    AB_TRY(ab_scratch(ctx, bytes, &dev));
+    AB_HIP(ctx, hipMemcpyAsync(dev, out, bytes, hipMemcpyHostToDevice, ctx->stream));
+    AB_TRY(ab_comm_allreduce(ctx, comm, dev, bytes / 8, AB_DT_U64, AB_RED_SUM));
+    AB_HIP(ctx, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AB_OK;
+}
+
+}  // extern "C"

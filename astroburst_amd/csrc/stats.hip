@@ -2,25 +2,33 @@
 //
 // Replaces core/imaging/stats.rs: compute_image_stats (:15-23), the exact path (:43-73,
 // math/median.rs:27-73), the 65 536-bin histogram path for > 4 000 000 px (:75-210), the known-
-// range variant (:25-41) and build_histogram (:378-421).
+// range variant (:25-41) and build_histogram (:378-421); plus cmd/common.rs:18-22
+// (auto_stretch_preview = stats -> auto_stf -> apply_stf) as one asynchronous chain.
 //
 // Design (HBM-bound integer/histogram work -- no GEMM shapes here):
-//   * every pass is one grid-stride streaming read of the plane with float4 loads.
+//   * every pass is one streaming read of the plane, float4 loads, two loads in flight per lane.
 //   * 65 536-bin histograms are privatised per workgroup in LDS as PACKED 16-bit counters
 //     (65 536 x u16 = 128 KiB of the CU's 160 KiB).  A workgroup consumes at most 65 535 pixels
 //     between flushes, so a counter cannot overflow; a flush adds the non-zero counters to the
 //     global u64 histogram.  Bin indices are computed in f64 exactly as the reference does
 //     (`((v as f64 - min) * inv) as usize`, saturating), so every bin count is bit-exact.
-//   * sparse histograms (the refinement passes touch one coarse bin's worth of pixels) go
-//     straight to global 64-bit atomics.
 //   * the exact path (<= 4M px) needs order statistics, not a sort: valid pixels are positive
 //     finite floats, whose bit patterns are monotone as u32, so rank k is found by an 11/11/10-bit
-//     radix select (three small histogram passes), the same for |v - median|.
-//   * the scalar bookkeeping between passes (percentile bin, in-bin interpolation) runs on the
-//     host on the downloaded histograms, transcribing stats.rs:302-353.
+//     radix select; the two middle ranks of an even count descend together.
+//   * the scalar bookkeeping between passes (percentile bin, in-bin interpolation: stats.rs:302-353)
+//     runs ON THE DEVICE in one-workgroup kernels that write the next pass's parameters into a small
+//     state block in HBM: the host enqueues the whole chain and synchronises once, for the 56-byte
+//     result (round 1 downloaded four 512 KiB histograms and synchronised after each: 0.3 ms of host
+//     round trips in a 0.65 ms call).
+//   * row-band sharding: with a communicator every rank runs the same chain over ITS
+//     rows and the integer partials -- min/max, counts, the three 65 536-bin histograms -- are
+//     all-reduced in-stream between a pass and its bookkeeping kernel (comm.hip); histograms and
+//     counts are integers, so the sharded statistics equal the single-GPU ones bin for bin (the f64
+//     sum of the mean is reduced in a different order: 1e-16 relative).
 //   * f64 sums: per-thread sequential over a strided slice, then a fixed-shape tree; the
 //     reference's own order is rayon's unspecified reduce tree (stats.rs:252-257).
 #include "ab_common.hpp"
+#include "stf_device.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -28,14 +36,9 @@
 
 namespace {
 
-constexpr float kPaddingThreshold = 1e-7f;  // types/constants.rs:6
 constexpr double kMadToSigma = 1.4826;      // types/constants.rs:7
 constexpr int kHistBins = 65536;            // stats.rs:8
 constexpr int kExactLimit = 4000000;        // stats.rs:18
-
-__device__ __forceinline__ bool is_valid_pixel(float v) {  // stats.rs:10-13
-    return __builtin_isfinite(v) && v > kPaddingThreshold;
-}
 
 // Rust `f64 as usize` then `.min(last)`: saturating, NaN -> 0
 __device__ __forceinline__ uint32_t bin_index(double t, uint32_t last) {
@@ -50,19 +53,56 @@ struct ScanPartial {
 };
 
 constexpr int kScanBlock = 256;
+constexpr int kMaxPartials = 4096;
+constexpr int kBookBlock = 1024;
+
+// Parameters and results that travel from pass to pass in HBM (one per context, AB_WS_STATS).
+struct StatsDev {
+    double negmin_max[2];       // {-min, max} of the valid pixels: one all-reduce(MAX) serves both
+    double sum;                 // f64 sum of the valid pixels (all-reduce SUM)
+    int empty;                  // no valid pixel anywhere: result is all zeros (stats.rs:79-81,95-97)
+    int two;                    // exact path: even count, two middle ranks
+    // histogram path (stats.rs:85-210)
+    double gmin, inv, bin_width, range;
+    unsigned long long total_valid, half_count, count_before_median;
+    double median_bin_lo, median_bin_hi, refine_inv, refine_range;
+    double dev_inv, dev_bw;
+    double median;
+    double mad_region_lo, mad_refine_inv, mad_refine_range;
+    float coarse_med_f32, exact_med_f32, mad_lo_f32, mad_hi_f32;
+    // exact path (radix select; rank[0] = mid, rank[1] = mid - 1)
+    unsigned long long rank[2];
+    unsigned int prefix[2];
+    unsigned int prefix_mask;
+    int use_dev;
+    float center;
+    ab_image_stats result;
+    ab_stf_params stf;
+    StfTx tx;
+};
+
+// workspace carved from AB_WS_STATS
+struct Ws {
+    StatsDev *st;
+    unsigned long long *H;   // [0] = a count riding along with a histogram all-reduce; [1, 65537) = h0; [65537, 131073) = h1
+    ScanPartial *partials;   // kMaxPartials
+    unsigned int *sel;       // 2 x 2048
+};
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int off) { return __shfl_xor(v, off, 64); }
 
 __device__ __forceinline__ void block_reduce_scan(double mn, double mx, double sum, unsigned long long cnt,
                                                   ScanPartial *out) {
-    __shared__ double s_mn[kScanBlock / 64], s_mx[kScanBlock / 64], s_sum[kScanBlock / 64];
-    __shared__ unsigned long long s_cnt[kScanBlock / 64];
+    __shared__ double s_mn[16], s_mx[16], s_sum[16];
+    __shared__ unsigned long long s_cnt[16];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
-        mn = fmin(mn, __shfl_xor(mn, off, 64));
-        mx = fmax(mx, __shfl_xor(mx, off, 64));
-        sum += __shfl_xor(sum, off, 64);
+        mn = fmin(mn, shfl_xor_f64(mn, off));
+        mx = fmax(mx, shfl_xor_f64(mx, off));
+        sum += shfl_xor_f64(sum, off);
         cnt += __shfl_xor(cnt, off, 64);
     }
-    const int w = threadIdx.x >> 6;
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
     if ((threadIdx.x & 63) == 0) {
         s_mn[w] = mn;
         s_mx[w] = mx;
@@ -71,7 +111,7 @@ __device__ __forceinline__ void block_reduce_scan(double mn, double mx, double s
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < kScanBlock / 64; ++i) {
+        for (int i = 1; i < nw; ++i) {
             mn = fmin(mn, s_mn[i]);
             mx = fmax(mx, s_mx[i]);
             sum += s_sum[i];
@@ -84,14 +124,42 @@ __device__ __forceinline__ void block_reduce_scan(double mn, double mx, double s
     }
 }
 
+// Streams `n` floats through f(v): float4 loads, two in flight per lane, grid-stride over blocks of 8 floats per lane.
+// The plane base must be 16-byte aligned (checked by the callers; otherwise the scalar tail loop takes everything).
+template <typename F>
+__device__ __forceinline__ void stream_pixels(const float *__restrict__ data, int64_t begin, int64_t end, F &&f) {
+    const bool aligned = (((uintptr_t)(data + begin)) & 15) == 0;
+    int64_t i = begin;
+    if (aligned) {
+        const int64_t n8 = (end - begin) >> 3;
+        const float4 *d4 = reinterpret_cast<const float4 *>(data + begin);
+        const int64_t stride = (int64_t)blockDim.x;
+        for (int64_t k = threadIdx.x; k < n8; k += stride) {
+            const float4 a = d4[2 * k], b = d4[2 * k + 1];
+            f(a.x); f(a.y); f(a.z); f(a.w);
+            f(b.x); f(b.y); f(b.z); f(b.w);
+        }
+        i = begin + (n8 << 3);
+    }
+    for (int64_t k = i + threadIdx.x; k < end; k += blockDim.x) f(data[k]);
+}
+
+// block b of g owns the pixel range [lo, hi): equal contiguous slices, 8-float aligned
+__device__ __forceinline__ void block_slice(int64_t n, int64_t *lo, int64_t *hi) {
+    const int64_t per = (((n + gridDim.x - 1) / gridDim.x) + 7) & ~(int64_t)7;
+    const int64_t a = per * blockIdx.x;
+    *lo = a < n ? a : n;
+    *hi = (a + per) < n ? (a + per) : n;
+}
+
 // stats.rs:212-258: min / max / sum / count over valid pixels; one partial per workgroup
 __global__ __launch_bounds__(kScanBlock) void scan_kernel(const float *__restrict__ data, int64_t n,
                                                           ScanPartial *__restrict__ partials) {
     double mn = DBL_MAX, mx = -DBL_MAX, sum = 0.0;
     unsigned long long cnt = 0;
-    const int64_t stride = (int64_t)gridDim.x * kScanBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x; i < n; i += stride) {
-        const float v = data[i];
+    int64_t lo, hi;
+    block_slice(n, &lo, &hi);
+    stream_pixels(data, lo, hi, [&](float v) {
         if (is_valid_pixel(v)) {
             const double vf = (double)v;
             mn = fmin(mn, vf);
@@ -99,129 +167,305 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const float *__restric
             sum += vf;
             cnt += 1;
         }
-    }
+    });
     block_reduce_scan(mn, mx, sum, cnt, &partials[blockIdx.x]);
 }
 
-// ---- dense 65 536-bin histogram, LDS-privatised with packed u16 counters -------------------
+// one workgroup: fixed-shape reduction of the per-workgroup partials (thread t folds partials t, t + 1024, ...)
+__device__ __forceinline__ void reduce_partials(const ScanPartial *p, int np, double *mn, double *mx, double *sum,
+                                                unsigned long long *cnt) {
+    double a = DBL_MAX, b = -DBL_MAX, s = 0.0;
+    unsigned long long c = 0;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) {
+        a = fmin(a, p[i].mn);
+        b = fmax(b, p[i].mx);
+        s += p[i].sum;
+        c += p[i].cnt;
+    }
+    __shared__ ScanPartial tot;
+    block_reduce_scan(a, b, s, c, &tot);
+    __syncthreads();
+    *mn = tot.mn;
+    *mx = tot.mx;
+    *sum = tot.sum;
+    *cnt = tot.cnt;
+    __syncthreads();
+}
+
+// after scan_kernel: this rank's {-min, max}, sum and count into the state / the count slot
+__global__ __launch_bounds__(kBookBlock) void finish_scan_kernel(const ScanPartial *p, int np, StatsDev *st, unsigned long long *H) {
+    double mn, mx, sum;
+    unsigned long long cnt;
+    reduce_partials(p, np, &mn, &mx, &sum, &cnt);
+    if (threadIdx.x == 0) {
+        st->negmin_max[0] = -mn;
+        st->negmin_max[1] = mx;
+        st->sum = sum;
+        H[0] = cnt;
+    }
+}
+
+__global__ void set_range_kernel(StatsDev *st, double kmin, double kmax) {
+    st->negmin_max[0] = -kmin;
+    st->negmin_max[1] = kmax;
+}
+
+// ---- dense 65 536-bin histograms, LDS-privatised with packed u16 counters -------------------
 constexpr int kHistBlock = 1024;
-constexpr int kHistChunk = 61440;  // pixels per workgroup between flushes (< 65 536)
+constexpr int kHistChunkMax = 61440;  // pixels per workgroup between flushes (< 65 536)
 
-enum HistKind { HIST_VALUE = 0, HIST_DEV = 1 };
+enum HistKind { HIST_VALUE = 0, HIST_DEV = 1, HIST_MAD = 2 };
 
-struct HistArgs {
-    const float *data;
-    int64_t n;
-    double origin;   // value hist: data_min          dev hist: unused
-    double inv;      // bins / range
-    float center;    // dev hist: coarse median as f32 (stats.rs:114,131)
-    unsigned long long *hist;   // 65 536 x u64, zeroed by the caller
-    ScanPartial *partials;      // value hist only: per-workgroup sum/count (stats.rs:279-281)
-    // sparse side histogram taken in the same pass (stats.rs:127-130): refine of the median bin
-    int want_refine;
-    double refine_lo, refine_hi, refine_inv;
-    unsigned long long *refine;  // 65 536 x u64
-};
+__device__ __forceinline__ void lds_hist_add(unsigned int *lds, uint32_t idx) {
+    atomicAdd(&lds[idx >> 1], (idx & 1) ? 0x10000u : 1u);
+}
 
+__device__ __forceinline__ void lds_hist_flush(unsigned int *lds, unsigned long long *hist) {
+    __syncthreads();
+    for (int w = threadIdx.x; w < kHistBins / 2; w += kHistBlock) {
+        const unsigned int packed = lds[w];
+        if (packed) {
+            const unsigned int lo = packed & 0xffffu, hi = packed >> 16;
+            if (lo) atomicAdd(&hist[2 * w], (unsigned long long)lo);
+            if (hi) atomicAdd(&hist[2 * w + 1], (unsigned long long)hi);
+            lds[w] = 0;
+        }
+    }
+    __syncthreads();
+}
+
+// KIND = HIST_VALUE (stats.rs:260-300):   h0[bin(v)] += 1, per-workgroup sum / count of the valid pixels
+// KIND = HIST_DEV   (stats.rs:119-146):   h0[bin(|v - coarse_median|)] += 1 (dense, LDS) and the 65 536 sub-bins of the
+//                                         median bin in h1 (sparse: one coarse bin's worth of pixels, global atomics)
+// KIND = HIST_MAD   (stats.rs:166-191):   count of deviations below the MAD region (per-workgroup) and the region's
+//                                         65 536 sub-bins in h0 (three coarse bins' worth of pixels: LDS)
 template <int KIND>
-__global__ __launch_bounds__(kHistBlock) void dense_hist_kernel(const HistArgs a) {
+__global__ __launch_bounds__(kHistBlock) void dense_hist_kernel(const float *__restrict__ data, int64_t n, int64_t chunk,
+                                                                const StatsDev *__restrict__ st, unsigned long long *__restrict__ h0,
+                                                                unsigned long long *__restrict__ h1, ScanPartial *__restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // 32 768 words = 65 536 x u16
     for (int i = threadIdx.x; i < kHistBins / 2; i += kHistBlock) lds[i] = 0;
     __syncthreads();
 
+    const uint32_t last = kHistBins - 1;
     double sum = 0.0;
     unsigned long long cnt = 0;
-    const uint32_t last = kHistBins - 1;
-    const int64_t nchunks = (a.n + kHistChunk - 1) / kHistChunk;
-    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
-        const int64_t base = chunk * kHistChunk;
-        const int64_t end = (base + kHistChunk < a.n) ? base + kHistChunk : a.n;
-        for (int64_t i = base + threadIdx.x; i < end; i += kHistBlock) {
-            const float v = a.data[i];
+    // pass parameters (uniform; a handful of scalar loads)
+    const double origin = st->gmin, inv = st->inv;
+    const double refine_lo = st->median_bin_lo, refine_hi = st->median_bin_hi, refine_inv = st->refine_inv;
+    const double dev_inv = st->dev_inv;
+    const float center = KIND == HIST_DEV ? st->coarse_med_f32 : st->exact_med_f32;
+    const float mad_lo = st->mad_lo_f32, mad_hi = st->mad_hi_f32;
+    const double mad_region_lo = st->mad_region_lo, mad_inv = st->mad_refine_inv;
+    const int skip = st->empty;
+
+    const int64_t nchunks = skip ? 0 : (n + chunk - 1) / chunk;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        const int64_t base = c * chunk;
+        const int64_t end = (base + chunk < n) ? base + chunk : n;
+        stream_pixels(data, base, end, [&](float v) {
             if (is_valid_pixel(v)) {
-                uint32_t idx;
                 if (KIND == HIST_VALUE) {
                     const double vf = (double)v;
                     sum += vf;
                     cnt += 1;
-                    idx = bin_index((vf - a.origin) * a.inv, last);  // stats.rs:282-283
-                    if (a.want_refine && vf >= a.refine_lo && vf < a.refine_hi) {  // stats.rs:127-130
-                        const uint32_t r = bin_index((vf - a.refine_lo) * a.refine_inv, last);
-                        atomicAdd(&a.refine[r], 1ull);
-                    }
-                } else {
+                    lds_hist_add(lds, bin_index((vf - origin) * inv, last));  // stats.rs:282-283
+                } else if (KIND == HIST_DEV) {
                     const double vf = (double)v;
-                    if (a.want_refine && vf >= a.refine_lo && vf < a.refine_hi) {
-                        const uint32_t r = bin_index((vf - a.refine_lo) * a.refine_inv, last);
-                        atomicAdd(&a.refine[r], 1ull);
-                    }
-                    const float d = fabsf(v - a.center);              // stats.rs:131-133
-                    idx = bin_index((double)d * a.inv, last);
+                    if (vf >= refine_lo && vf < refine_hi)  // stats.rs:127-130
+                        atomicAdd(&h1[bin_index((vf - refine_lo) * refine_inv, last)], 1ull);
+                    const float d = fabsf(v - center);  // stats.rs:131-133
+                    lds_hist_add(lds, bin_index((double)d * dev_inv, last));
+                } else {
+                    const float dev = fabsf(v - center);  // stats.rs:172-181
+                    if (dev < mad_lo)
+                        cnt += 1;
+                    else if (dev < mad_hi)
+                        lds_hist_add(lds, bin_index(((double)dev - mad_region_lo) * mad_inv, last));
                 }
-                atomicAdd(&lds[idx >> 1], (idx & 1) ? 0x10000u : 1u);
             }
-        }
-        __syncthreads();
-        // flush: non-zero packed counters -> global u64 bins, then clear
-        for (int w = threadIdx.x; w < kHistBins / 2; w += kHistBlock) {
-            const unsigned int packed = lds[w];
-            if (packed) {
-                const unsigned int lo = packed & 0xffffu, hi = packed >> 16;
-                if (lo) atomicAdd(&a.hist[2 * w], (unsigned long long)lo);
-                if (hi) atomicAdd(&a.hist[2 * w + 1], (unsigned long long)hi);
-                lds[w] = 0;
-            }
-        }
-        __syncthreads();
+        });
+        lds_hist_flush(lds, h0);
     }
-    if (KIND == HIST_VALUE && a.partials) {
-        // block reduction of sum / count (fixed tree)
-        __shared__ double s_sum[kHistBlock / 64];
-        __shared__ unsigned long long s_cnt[kHistBlock / 64];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            sum += __shfl_xor(sum, off, 64);
-            cnt += __shfl_xor(cnt, off, 64);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            s_sum[threadIdx.x >> 6] = sum;
-            s_cnt[threadIdx.x >> 6] = cnt;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int i = 1; i < kHistBlock / 64; ++i) {
-                sum += s_sum[i];
-                cnt += s_cnt[i];
-            }
-            a.partials[blockIdx.x].sum = sum;
-            a.partials[blockIdx.x].cnt = cnt;
-            a.partials[blockIdx.x].mn = 0.0;
-            a.partials[blockIdx.x].mx = 0.0;
-        }
+    if (KIND != HIST_DEV) block_reduce_scan(0.0, 0.0, sum, cnt, &partials[blockIdx.x]);
+}
+
+// after the VALUE / MAD pass: per-rank sum and count
+__global__ __launch_bounds__(kBookBlock) void finish_hist_kernel(const ScanPartial *p, int np, StatsDev *st, unsigned long long *H, int want_sum) {
+    double mn, mx, sum;
+    unsigned long long cnt;
+    reduce_partials(p, np, &mn, &mx, &sum, &cnt);
+    if (threadIdx.x == 0) {
+        if (want_sum) st->sum = sum;
+        H[0] = cnt;
     }
 }
 
-// stats.rs:166-191: count of deviations below the MAD region + sparse refine of the region
-__global__ __launch_bounds__(kScanBlock) void mad_refine_kernel(const float *__restrict__ data, int64_t n, float med_f32,
-                                                                float lo_f32, float hi_f32, double region_lo, double inv,
-                                                                unsigned long long *__restrict__ refine,
-                                                                ScanPartial *__restrict__ partials) {
-    unsigned long long below = 0;
-    const uint32_t last = kHistBins - 1;
-    const int64_t stride = (int64_t)gridDim.x * kScanBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x; i < n; i += stride) {
-        const float v = data[i];
-        if (is_valid_pixel(v)) {
-            const float dev = fabsf(v - med_f32);
-            if (dev < lo_f32) {
-                below += 1;
-            } else if (dev < hi_f32) {
-                const uint32_t r = bin_index(((double)dev - region_lo) * inv, last);
-                atomicAdd(&refine[r], 1ull);
+// ---- one-workgroup bookkeeping between the passes (stats.rs:302-353 on the device) -----------------------------
+__device__ __forceinline__ unsigned long long f64_to_u64_sat(double v) {  // Rust `as u64`
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709551615.0) return 0xffffffffffffffffull;
+    return (unsigned long long)v;
+}
+
+// first bin i with cum(i) >= target over 65 536 bins (cum inclusive).  Every thread returns the same answer:
+// found, the bin, its count and the inclusive cumulative count there; `before` = cum - count.
+struct RankHit {
+    int found;
+    uint32_t bin;
+    unsigned long long count, cum;
+};
+__device__ __forceinline__ RankHit block_find_rank(const unsigned long long *hist, unsigned long long target) {
+    __shared__ unsigned long long s_part[kBookBlock];
+    __shared__ RankHit s_hit;
+    constexpr int PER = kHistBins / kBookBlock;  // 64 consecutive bins per thread
+    const int t = threadIdx.x;
+    unsigned long long local = 0;
+    for (int j = 0; j < PER; ++j) local += hist[t * PER + j];
+    s_part[t] = local;
+    if (t == 0) s_hit.found = 0;
+    __syncthreads();
+    // inclusive scan of 1024 partials (Hillis-Steele in LDS)
+    for (int off = 1; off < kBookBlock; off <<= 1) {
+        const unsigned long long add = t >= off ? s_part[t - off] : 0ull;
+        __syncthreads();
+        s_part[t] += add;
+        __syncthreads();
+    }
+    const unsigned long long incl = s_part[t], excl = incl - local;
+    if (excl < target && incl >= target) {  // the crossing lies in this thread's 64 bins (exactly one thread, target >= 1)
+        unsigned long long cum = excl;
+        for (int j = 0; j < PER; ++j) {
+            const unsigned long long c = hist[t * PER + j];
+            cum += c;
+            if (cum >= target) {
+                s_hit.found = 1;
+                s_hit.bin = (uint32_t)(t * PER + j);
+                s_hit.count = c;
+                s_hit.cum = cum;
+                break;
             }
         }
     }
-    block_reduce_scan(0.0, 0.0, 0.0, below, &partials[blockIdx.x]);
+    __syncthreads();
+    const RankHit r = s_hit;
+    __syncthreads();
+    return r;
+}
+
+// resolve_rank_in_hist (stats.rs:333-353)
+__device__ __forceinline__ double resolve_rank(const unsigned long long *hist, unsigned long long rank, double region_lo, double sub_bw) {
+    if (rank == 0) return region_lo;  // uniform
+    const RankHit h = block_find_rank(hist, rank);
+    if (!h.found) return region_lo + (double)kHistBins * sub_bw;
+    const unsigned long long overshoot = h.cum - rank;
+    const double frac = h.count > 0 ? 1.0 - ((double)overshoot / (double)h.count) : 0.5;
+    return region_lo + ((double)h.bin + frac) * sub_bw;
+}
+
+__device__ __forceinline__ void write_zero_result(StatsDev *st) {
+    st->empty = 1;
+    st->result.min = st->result.max = st->result.median = st->result.mad = st->result.sigma = st->result.mean = 0.0;
+    st->result.valid_count = 0;
+}
+
+// before the VALUE pass: the histogram's origin and scale from the (all-reduced) range
+__global__ void book_range_kernel(StatsDev *st) {
+    const double gmin = -st->negmin_max[0], gmax = st->negmin_max[1];
+    st->empty = 0;
+    st->two = 0;
+    if (gmin == DBL_MAX) {  // stats.rs:79-81: no valid pixel
+        write_zero_result(st);
+        return;
+    }
+    const double range = fmax(gmax - gmin, 1e-30);  // stats.rs:91-92
+    st->gmin = gmin;
+    st->range = range;
+    st->bin_width = range / (double)kHistBins;
+    st->inv = (double)kHistBins / range;  // stats.rs:269
+    st->result.min = gmin;
+    st->result.max = gmax;
+}
+
+// after the VALUE pass (stats.rs:94-117): mean, the median's coarse bin, parameters of the DEV pass
+__global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, const unsigned long long *H) {
+    if (st->empty) return;
+    const unsigned long long total = H[0];
+    if (total == 0) {  // stats.rs:95-97
+        __syncthreads();
+        if (threadIdx.x == 0) write_zero_result(st);
+        return;
+    }
+    const unsigned long long half = f64_to_u64_sat(ceil((double)total * 0.5));  // :100 (== find_percentile_bin's target)
+    const RankHit h = block_find_rank(H + 1, half);
+    if (threadIdx.x != 0) return;
+    const double gmin = st->gmin, bw = st->bin_width, range = st->range;
+    const uint32_t median_bin = h.found ? h.bin : (uint32_t)(kHistBins - 1);  // find_percentile_bin (:302-311)
+    // count_before_median = sum of the bins below the median bin (:103)
+    const unsigned long long before = h.found ? h.cum - h.count : total - H[1 + kHistBins - 1];
+    double coarse;  // interpolate_percentile (:313-331)
+    if (h.found) {
+        const unsigned long long overshoot = h.cum - half;
+        const double frac = h.count > 0 ? 1.0 - ((double)overshoot / (double)h.count) : 0.5;
+        coarse = gmin + ((double)h.bin + frac) * bw;
+    } else {
+        coarse = gmin + (double)kHistBins * bw;
+    }
+    st->total_valid = total;
+    st->half_count = half;
+    st->count_before_median = before;
+    st->median_bin_lo = gmin + (double)median_bin * bw;  // :104-105
+    st->median_bin_hi = st->median_bin_lo + bw;
+    st->refine_range = fmax(st->median_bin_hi - st->median_bin_lo, 1e-30);  // :116
+    st->refine_inv = (double)kHistBins / st->refine_range;
+    st->dev_bw = range / (double)kHistBins;  // :111-113
+    st->dev_inv = (double)kHistBins / range;
+    st->coarse_med_f32 = (float)coarse;  // :114
+    st->result.mean = st->sum / (double)total;  // :98
+    st->result.valid_count = total;
+}
+
+// after the DEV pass (stats.rs:148-164): the exact median from the refined bin, the MAD's coarse region
+__global__ __launch_bounds__(kBookBlock) void book_dev_kernel(StatsDev *st, const unsigned long long *H) {
+    if (st->empty) return;
+    const unsigned long long half = st->half_count, before = st->count_before_median;
+    const unsigned long long rank_in_bin = half > before ? half - before : 0;  // saturating_sub (:148)
+    const double median = resolve_rank(H + 1 + kHistBins, rank_in_bin, st->median_bin_lo, st->refine_range / (double)kHistBins);
+    const RankHit h = block_find_rank(H + 1, half);  // find_percentile_bin(dev_hist, total, 0.5) (:154)
+    if (threadIdx.x != 0) return;
+    const uint32_t mad_bin = h.found ? h.bin : (uint32_t)(kHistBins - 1);
+    const uint32_t expand_lo = mad_bin > 0 ? mad_bin - 1 : 0;                                         // :155
+    const uint32_t expand_hi = (mad_bin + 2 < (uint32_t)kHistBins) ? mad_bin + 2 : (uint32_t)kHistBins;  // :156
+    const double lo = (double)expand_lo * st->dev_bw, hi = (double)expand_hi * st->dev_bw;
+    st->median = median;
+    st->exact_med_f32 = (float)median;  // :160
+    st->mad_region_lo = lo;
+    st->mad_refine_range = fmax(hi - lo, 1e-30);
+    st->mad_refine_inv = (double)kHistBins / st->mad_refine_range;
+    st->mad_lo_f32 = (float)lo;  // :163-164
+    st->mad_hi_f32 = (float)hi;
+    st->result.median = median;
+}
+
+__device__ __forceinline__ void finish_result(StatsDev *st, double mad, const ab_auto_stf_config cfg) {
+    if (!st->empty) {  // (an empty image keeps the all-zero ImageStats, stats.rs:79-81)
+        st->result.mad = mad;
+        st->result.sigma = fmax(mad * kMadToSigma, 1e-30);
+    }
+    ab_auto_stf_hd(&st->result, &cfg, &st->stf);
+    st->tx = make_tx(&st->stf, &st->result);
+}
+
+// after the MAD pass (stats.rs:193-209)
+__global__ __launch_bounds__(kBookBlock) void book_mad_kernel(StatsDev *st, const unsigned long long *H, ab_auto_stf_config cfg) {
+    if (st->empty) {
+        if (threadIdx.x == 0) finish_result(st, 0.0, cfg);
+        return;
+    }
+    const unsigned long long below = H[0], half = st->half_count;
+    const unsigned long long rank = half > below ? half - below : 0;
+    const double mad = resolve_rank(H + 1, rank, st->mad_region_lo, st->mad_refine_range / (double)kHistBins);
+    if (threadIdx.x == 0) finish_result(st, mad, cfg);
 }
 
 // stats.rs:393-410 build_histogram: arbitrary bin count, u32 bins; sparse enough for global atomics
@@ -254,34 +498,98 @@ __global__ __launch_bounds__(kScanBlock) void small_hist_kernel(const float *__r
 }
 
 // ---- radix select for the exact path --------------------------------------------------------
-// keys: u32 bit pattern of v (valid pixels, positive) or of |v - center| (>= +0); both monotone.
-struct SelectArgs {
-    const float *data;
-    int64_t n;
-    int use_dev;     // 0: key = bits(v)   1: key = bits(|v - center|)
-    float center;
-    uint32_t prefix_mask, prefix_val;  // only keys with (key & mask) == val are counted
-    int shift, nbits;
-    unsigned int *hist;  // 2^nbits bins, zeroed
-};
-
-__global__ __launch_bounds__(kScanBlock) void select_hist_kernel(const SelectArgs a) {
-    __shared__ unsigned int lds[2048];
-    const uint32_t nb = 1u << a.nbits;
-    for (uint32_t i = threadIdx.x; i < nb; i += kScanBlock) lds[i] = 0;
+// keys: u32 bit pattern of v (valid pixels, positive) or of |v - center| (>= +0); both monotone.  Two ranks (the two
+// middle order statistics of an even count) descend together: sel[0 .. 2048) counts the keys under prefix[0],
+// sel[2048 .. 4096) those under prefix[1].
+__global__ __launch_bounds__(kScanBlock) void select_hist_kernel(const float *__restrict__ data, int64_t n, const StatsDev *__restrict__ st,
+                                                                 int shift, int nbits, unsigned int *__restrict__ sel) {
+    __shared__ unsigned int lds[4096];
+    for (uint32_t i = threadIdx.x; i < 4096; i += kScanBlock) lds[i] = 0;
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * kScanBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x; i < a.n; i += stride) {
-        const float v = a.data[i];
+    if (st->empty) return;
+    const uint32_t nb = 1u << nbits;
+    const uint32_t mask = st->prefix_mask, p0 = st->prefix[0], p1 = st->prefix[1];
+    const int two = st->two, use_dev = st->use_dev;
+    const float center = st->center;
+    int64_t lo, hi;
+    block_slice(n, &lo, &hi);
+    stream_pixels(data, lo, hi, [&](float v) {
         if (is_valid_pixel(v)) {
-            const float k = a.use_dev ? fabsf(v - a.center) : v;
+            const float k = use_dev ? fabsf(v - center) : v;
             const uint32_t key = __float_as_uint(k);
-            if ((key & a.prefix_mask) == a.prefix_val) atomicAdd(&lds[(key >> a.shift) & (nb - 1)], 1u);
+            const uint32_t bin = (key >> shift) & (nb - 1);
+            if ((key & mask) == p0) atomicAdd(&lds[bin], 1u);
+            if (two && (key & mask) == p1) atomicAdd(&lds[2048 + bin], 1u);
         }
+    });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 4096; i += kScanBlock)
+        if (lds[i]) atomicAdd(&sel[i], lds[i]);
+}
+
+// one workgroup of 64: each of the two ranks steps into the bin that holds it
+__global__ __launch_bounds__(64) void select_pick_kernel(StatsDev *st, const unsigned int *__restrict__ sel, int shift, int nbits) {
+    if (st->empty) return;
+    const uint32_t nb = 1u << nbits;
+    const int r = threadIdx.x;
+    if (r < 2 && (r == 0 || st->two)) {
+        const unsigned int *h = sel + 2048 * r;
+        unsigned long long rank = st->rank[r], cum = 0;
+        uint32_t bin = nb - 1;
+        for (uint32_t i = 0; i < nb; ++i) {
+            if (cum + h[i] > rank) {
+                bin = i;
+                break;
+            }
+            cum += h[i];
+        }
+        st->rank[r] = rank - cum;
+        st->prefix[r] |= bin << shift;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += kScanBlock)
-        if (lds[i]) atomicAdd(&a.hist[i], lds[i]);
+    if (threadIdx.x == 0) st->prefix_mask |= (nb - 1) << shift;
+}
+
+// exact path bookkeeping (stats.rs:43-73, math/median.rs:27-73)
+__global__ void exact_begin_kernel(StatsDev *st, const unsigned long long *H) {
+    const unsigned long long cnt = H[0];
+    st->empty = 0;
+    if (cnt == 0) {
+        write_zero_result(st);
+        return;
+    }
+    st->result.min = -st->negmin_max[0];
+    st->result.max = st->negmin_max[1];
+    st->result.mean = st->sum / (double)cnt;
+    st->result.valid_count = cnt;
+    st->two = (cnt % 2 == 0) ? 1 : 0;
+    st->rank[0] = cnt / 2;
+    st->rank[1] = cnt / 2 - (st->two ? 1 : 0);
+    st->prefix[0] = st->prefix[1] = 0;
+    st->prefix_mask = 0;
+    st->use_dev = 0;
+    st->center = 0.0f;
+}
+__global__ void exact_mid_kernel(StatsDev *st) {  // after the value select: the median, then the same select on |v - median|
+    if (st->empty) return;
+    const float right = __uint_as_float(st->prefix[0]), left = __uint_as_float(st->prefix[1]);
+    const double median = st->two ? ((double)left + (double)right) / 2.0 : (double)right;  // exact_median_mut (median.rs:27-44)
+    st->result.median = median;
+    st->center = (float)median;  // exact_mad_mut(valid, median as f32) (stats.rs:60)
+    st->use_dev = 1;
+    st->rank[0] = st->result.valid_count / 2;
+    st->rank[1] = st->result.valid_count / 2 - (st->two ? 1 : 0);
+    st->prefix[0] = st->prefix[1] = 0;
+    st->prefix_mask = 0;
+}
+__global__ void exact_end_kernel(StatsDev *st, ab_auto_stf_config cfg) {
+    if (st->empty) {
+        finish_result(st, 0.0, cfg);
+        return;
+    }
+    const float dr = __uint_as_float(st->prefix[0]), dl = __uint_as_float(st->prefix[1]);
+    const float mad_f32 = st->two ? (dl + dr) / 2.0f : dr;  // median_f32_mut (median.rs:46-63): f32 average
+    finish_result(st, (double)mad_f32, cfg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -291,360 +599,160 @@ int grid_for(ab_ctx *ctx, int64_t n, int block, int per_cu) {
     return (int)std::max<int64_t>(1, std::min(want, cap));
 }
 
-// host transcriptions of stats.rs:302-353
-inline uint64_t f64_to_u64_sat(double v) {
-    if (!(v > 0.0)) return 0;
-    if (v >= 18446744073709551615.0) return UINT64_MAX;
-    return (uint64_t)v;
-}
-size_t find_percentile_bin(const unsigned long long *hist, size_t nb, uint64_t total, double pct) {
-    const uint64_t target = f64_to_u64_sat(std::ceil((double)total * pct));
-    uint64_t cum = 0;
-    for (size_t i = 0; i < nb; ++i) {
-        cum += hist[i];
-        if (cum >= target) return i;
-    }
-    return nb - 1;
-}
-double interpolate_percentile(const unsigned long long *hist, size_t nb, uint64_t total, double pct, double data_min,
-                              double bin_width) {
-    const uint64_t target = f64_to_u64_sat(std::ceil((double)total * pct));
-    uint64_t cum = 0;
-    for (size_t i = 0; i < nb; ++i) {
-        const uint64_t count = hist[i];
-        cum += count;
-        if (cum >= target) {
-            const uint64_t overshoot = cum - target;
-            const double frac = count > 0 ? 1.0 - ((double)overshoot / (double)count) : 0.5;
-            return data_min + ((double)i + frac) * bin_width;
-        }
-    }
-    return data_min + (double)nb * bin_width;
-}
-double resolve_rank_in_hist(const unsigned long long *hist, size_t nb, uint64_t rank, double region_lo,
-                            double sub_bin_width) {
-    if (rank == 0) return region_lo;
-    uint64_t cum = 0;
-    for (size_t i = 0; i < nb; ++i) {
-        const uint64_t count = hist[i];
-        cum += count;
-        if (cum >= rank) {
-            const uint64_t overshoot = cum - rank;
-            const double frac = count > 0 ? 1.0 - ((double)overshoot / (double)count) : 0.5;
-            return region_lo + ((double)i + frac) * sub_bin_width;
-        }
-    }
-    return region_lo + (double)nb * sub_bin_width;
-}
-
-struct DeviceHists {  // carved from the context scratch arena
-    unsigned long long *h0, *h1;  // 2 x 65 536 u64
-    ScanPartial *partials;        // up to kMaxPartials
-    unsigned int *sel;            // 2048 u32
-};
-constexpr int kMaxPartials = 4096;
-
-int carve(ab_ctx *ctx, DeviceHists *d) {
-    const size_t bytes = 2 * kHistBins * sizeof(unsigned long long) + kMaxPartials * sizeof(ScanPartial) + 2048 * 4;
-    void *p = nullptr;
-    AB_TRY(ab_scratch(ctx, bytes, &p));
-    char *c = (char *)p;
-    d->h0 = (unsigned long long *)c;
-    c += kHistBins * sizeof(unsigned long long);
-    d->h1 = (unsigned long long *)c;
-    c += kHistBins * sizeof(unsigned long long);
-    d->partials = (ScanPartial *)c;
+int carve(ab_ctx *ctx, Ws *w) {
+    const size_t bytes = 1024 + (size_t)(1 + 2 * kHistBins) * sizeof(unsigned long long) + kMaxPartials * sizeof(ScanPartial) + 4096 * 4;
+    static_assert(sizeof(StatsDev) <= 1024, "StatsDev outgrew its slot");
+    char *c = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_STATS, bytes, (void **)&c));
+    w->st = (StatsDev *)c;
+    c += 1024;
+    w->H = (unsigned long long *)c;
+    c += (size_t)(1 + 2 * kHistBins) * sizeof(unsigned long long);
+    w->partials = (ScanPartial *)c;
     c += kMaxPartials * sizeof(ScanPartial);
-    d->sel = (unsigned int *)c;
+    w->sel = (unsigned int *)c;
     return AB_OK;
 }
 
-// D2H through the context's pinned buffer: a pageable destination makes the runtime bounce the copy through its own
-// staging pages (~100 us per 512 KiB histogram, four of them per compute_image_stats)
-int download(ab_ctx *ctx, void *dst, const void *src, size_t bytes) {
-    void *pin = nullptr;
-    AB_TRY(ab_pinned(ctx, bytes, &pin));
-    AB_HIP(ctx, hipMemcpyAsync(pin, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    memcpy(dst, pin, bytes);
-    return AB_OK;
+// pixels per workgroup between flushes: the chunks divide evenly among the workgroups (273 chunks of 61 440 px on 256
+// CUs made 17 workgroups do double duty: the pass took twice one chunk's time)
+void hist_launch_shape(ab_ctx *ctx, int64_t n, int *grid, int64_t *chunk) {
+    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    int64_t nchunks = (n + kHistChunkMax - 1) / kHistChunkMax;
+    const int g = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cus));
+    nchunks = ((nchunks + g - 1) / g) * g;
+    int64_t c = (n + nchunks - 1) / nchunks;
+    c = (c + 7) & ~(int64_t)7;  // keep every chunk 32-byte aligned relative to the plane
+    *grid = g;
+    *chunk = std::min<int64_t>(std::max<int64_t>(c, 8), kHistChunkMax);
 }
 
-int scan(ab_ctx *ctx, const float *data, int64_t n, const DeviceHists &d, double *mn, double *mx, double *sum,
-         uint64_t *cnt) {
-    const int grid = std::min(grid_for(ctx, n, kScanBlock, 8), kMaxPartials);
-    hipLaunchKernelGGL(scan_kernel, dim3(grid), dim3(kScanBlock), 0, ctx->stream, data, n, d.partials);
+template <int KIND>
+int launch_dense(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int *grid_out) {
+    int grid;
+    int64_t chunk;
+    hist_launch_shape(ctx, n, &grid, &chunk);
+    const size_t lds_bytes = kHistBins * sizeof(unsigned short);
+    AB_HIP(ctx, hipFuncSetAttribute((const void *)dense_hist_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(dense_hist_kernel<KIND>, dim3(grid), dim3(kHistBlock), lds_bytes, ctx->stream, data, n, chunk, w.st, w.H + 1,
+                       w.H + 1 + kHistBins, w.partials);
     AB_HIP(ctx, hipGetLastError());
-    std::vector<ScanPartial> host(grid);
-    AB_TRY(download(ctx, host.data(), d.partials, grid * sizeof(ScanPartial)));
-    double a = DBL_MAX, b = -DBL_MAX, s = 0.0;
-    uint64_t c = 0;
-    for (int i = 0; i < grid; ++i) {
-        a = std::fmin(a, host[i].mn);
-        b = std::fmax(b, host[i].mx);
-        s += host[i].sum;
-        c += host[i].cnt;
-    }
-    *mn = a;
-    *mx = b;
-    *sum = s;
-    *cnt = c;
+    *grid_out = grid;
     return AB_OK;
 }
 
-// rank-k order statistic (0-based) of the keys, by 11/11/10-bit radix select
-int radix_select(ab_ctx *ctx, const float *data, int64_t n, int use_dev, float center, uint64_t rank,
-                 const DeviceHists &d, float *out) {
+const ab_auto_stf_config kDefaultStf = {0.25, -2.8};  // AutoStfConfig::default (types/image.rs:52-65)
+
+// min / max / sum / count of this rank's pixels -> state, all-reduced
+int enqueue_scan(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, const Ws &w, bool need_sum) {
+    const int grid = std::min(grid_for(ctx, n, kScanBlock * 16, 8), kMaxPartials);
+    hipLaunchKernelGGL(scan_kernel, dim3(grid), dim3(kScanBlock), 0, ctx->stream, data, n, w.partials);
+    hipLaunchKernelGGL(finish_scan_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.partials, grid, w.st, w.H);
+    AB_HIP(ctx, hipGetLastError());
+    if (comm) {
+        AB_TRY(ab_comm_allreduce(ctx, comm, w.st->negmin_max, 2, AB_DT_F64, AB_RED_MAX));
+        if (need_sum) {  // the exact path takes its mean from this pass; the histogram path re-sums in its VALUE pass
+            AB_TRY(ab_comm_allreduce(ctx, comm, &w.st->sum, 1, AB_DT_F64, AB_RED_SUM));
+            AB_TRY(ab_comm_allreduce(ctx, comm, w.H, 1, AB_DT_U64, AB_RED_SUM));
+        }
+    }
+    return AB_OK;
+}
+
+// stats.rs:85-210, everything on the stream; w.st->result / stf / tx are final when the stream reaches this point
+int enqueue_hist_path(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, const Ws &w, const ab_auto_stf_config &cfg) {
+    int grid = 0;
+    hipLaunchKernelGGL(book_range_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st);
+    AB_HIP(ctx, hipMemsetAsync(w.H, 0, (size_t)(1 + 2 * kHistBins) * sizeof(unsigned long long), ctx->stream));
+    AB_TRY(launch_dense<HIST_VALUE>(ctx, data, n, w, &grid));
+    hipLaunchKernelGGL(finish_hist_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.partials, grid, w.st, w.H, 1);
+    if (comm) {
+        AB_TRY(ab_comm_allreduce(ctx, comm, w.H, 1 + kHistBins, AB_DT_U64, AB_RED_SUM));
+        AB_TRY(ab_comm_allreduce(ctx, comm, &w.st->sum, 1, AB_DT_F64, AB_RED_SUM));
+    }
+    hipLaunchKernelGGL(book_value_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H);
+    AB_HIP(ctx, hipMemsetAsync(w.H + 1, 0, (size_t)(2 * kHistBins) * sizeof(unsigned long long), ctx->stream));
+    AB_TRY(launch_dense<HIST_DEV>(ctx, data, n, w, &grid));
+    if (comm) AB_TRY(ab_comm_allreduce(ctx, comm, w.H + 1, 2 * kHistBins, AB_DT_U64, AB_RED_SUM));
+    hipLaunchKernelGGL(book_dev_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H);
+    AB_HIP(ctx, hipMemsetAsync(w.H, 0, (size_t)(1 + kHistBins) * sizeof(unsigned long long), ctx->stream));
+    AB_TRY(launch_dense<HIST_MAD>(ctx, data, n, w, &grid));
+    hipLaunchKernelGGL(finish_hist_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.partials, grid, w.st, w.H, 0);
+    if (comm) AB_TRY(ab_comm_allreduce(ctx, comm, w.H, 1 + kHistBins, AB_DT_U64, AB_RED_SUM));
+    hipLaunchKernelGGL(book_mad_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H, cfg);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+// stats.rs:43-73
+int enqueue_exact_path(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, const Ws &w, const ab_auto_stf_config &cfg) {
+    AB_TRY(enqueue_scan(ctx, comm, data, n, w, true));
+    hipLaunchKernelGGL(exact_begin_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st, w.H);
     const int shifts[3] = {21, 10, 0};
     const int bits[3] = {11, 11, 10};
-    uint32_t prefix_mask = 0, prefix_val = 0;
-    std::vector<unsigned int> host(2048);
-    const int grid = grid_for(ctx, n, kScanBlock, 8);
-    for (int pass = 0; pass < 3; ++pass) {
-        const uint32_t nb = 1u << bits[pass];
-        AB_HIP(ctx, hipMemsetAsync(d.sel, 0, nb * sizeof(unsigned int), ctx->stream));
-        SelectArgs a;
-        a.data = data;
-        a.n = n;
-        a.use_dev = use_dev;
-        a.center = center;
-        a.prefix_mask = prefix_mask;
-        a.prefix_val = prefix_val;
-        a.shift = shifts[pass];
-        a.nbits = bits[pass];
-        a.hist = d.sel;
-        hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(kScanBlock), 0, ctx->stream, a);
-        AB_HIP(ctx, hipGetLastError());
-        AB_TRY(download(ctx, host.data(), d.sel, nb * sizeof(unsigned int)));
-        uint64_t cum = 0;
-        uint32_t bin = nb - 1;
-        for (uint32_t i = 0; i < nb; ++i) {
-            if (cum + host[i] > rank) {
-                bin = i;
-                break;
-            }
-            cum += host[i];
+    const int grid = grid_for(ctx, n, kScanBlock * 8, 8);
+    for (int sel = 0; sel < 2; ++sel) {  // values, then deviations from the median
+        for (int pass = 0; pass < 3; ++pass) {
+            AB_HIP(ctx, hipMemsetAsync(w.sel, 0, 4096 * sizeof(unsigned int), ctx->stream));
+            hipLaunchKernelGGL(select_hist_kernel, dim3(grid), dim3(kScanBlock), 0, ctx->stream, data, n, w.st, shifts[pass], bits[pass], w.sel);
+            if (comm) AB_TRY(ab_comm_allreduce(ctx, comm, w.sel, 4096, AB_DT_U32, AB_RED_SUM));
+            hipLaunchKernelGGL(select_pick_kernel, dim3(1), dim3(64), 0, ctx->stream, w.st, w.sel, shifts[pass], bits[pass]);
         }
-        rank -= cum;
-        prefix_val |= bin << shifts[pass];
-        prefix_mask |= (nb - 1) << shifts[pass];
-    }
-    float f;
-    memcpy(&f, &prefix_val, sizeof f);
-    *out = f;
-    return AB_OK;
-}
-
-// stats.rs:43-73 with math/median.rs:27-73
-int stats_exact(ab_ctx *ctx, const float *data, int64_t n, const DeviceHists &d, ab_image_stats *out) {
-    double mn, mx, sum;
-    uint64_t cnt;
-    AB_TRY(scan(ctx, data, n, d, &mn, &mx, &sum, &cnt));
-    if (cnt == 0) {
-        memset(out, 0, sizeof *out);
-        return AB_OK;
-    }
-    const double mean = sum / (double)cnt;
-    const uint64_t mid = cnt / 2;
-    // exact_median_mut (median.rs:27-44): even n -> mean of the two middle order statistics in f64
-    float right, left = 0.0f;
-    AB_TRY(radix_select(ctx, data, n, 0, 0.0f, mid, d, &right));
-    double median;
-    if (cnt % 2 == 0) {
-        AB_TRY(radix_select(ctx, data, n, 0, 0.0f, mid - 1, d, &left));
-        median = ((double)left + (double)right) / 2.0;
-    } else {
-        median = (double)right;
-    }
-    // exact_mad_mut(valid, median as f32) -> median_f32_mut of |v - med| (median.rs:46-73), f32 average
-    const float med_f32 = (float)median;
-    float dr, dl = 0.0f;
-    AB_TRY(radix_select(ctx, data, n, 1, med_f32, mid, d, &dr));
-    float mad_f32;
-    if (cnt % 2 == 0) {
-        AB_TRY(radix_select(ctx, data, n, 1, med_f32, mid - 1, d, &dl));
-        mad_f32 = (dl + dr) / 2.0f;
-    } else {
-        mad_f32 = dr;
-    }
-    const double mad = (double)mad_f32;
-    out->min = mn;
-    out->max = mx;
-    out->mean = mean;
-    out->median = median;
-    out->mad = mad;
-    out->sigma = std::fmax(mad * kMadToSigma, 1e-30);
-    out->valid_count = cnt;
-    return AB_OK;
-}
-
-int launch_dense_hist(ab_ctx *ctx, int kind, const HistArgs &a, int *grid_out) {
-    const int64_t nchunks = (a.n + kHistChunk - 1) / kHistChunk;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, std::min(ctx->cu_count > 0 ? ctx->cu_count : 256, kMaxPartials)));
-    const size_t lds_bytes = kHistBins * sizeof(unsigned short);
-    if (kind == HIST_VALUE) {
-        AB_HIP(ctx, hipFuncSetAttribute((const void *)dense_hist_kernel<HIST_VALUE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(dense_hist_kernel<HIST_VALUE>, dim3(grid), dim3(kHistBlock), lds_bytes, ctx->stream, a);
-    } else {
-        AB_HIP(ctx, hipFuncSetAttribute((const void *)dense_hist_kernel<HIST_DEV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(dense_hist_kernel<HIST_DEV>, dim3(grid), dim3(kHistBlock), lds_bytes, ctx->stream, a);
+        if (sel == 0)
+            hipLaunchKernelGGL(exact_mid_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st);
+        else
+            hipLaunchKernelGGL(exact_end_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st, cfg);
     }
     AB_HIP(ctx, hipGetLastError());
-    if (grid_out) *grid_out = grid;
     return AB_OK;
-}
-
-// stats.rs:260-300
-int value_hist(ab_ctx *ctx, const float *data, int64_t n, double gmin, double gmax, const DeviceHists &d,
-               std::vector<unsigned long long> &hist, double *sum, uint64_t *cnt) {
-    const double range = std::fmax(gmax - gmin, 1e-30);
-    AB_HIP(ctx, hipMemsetAsync(d.h0, 0, kHistBins * sizeof(unsigned long long), ctx->stream));
-    HistArgs a;
-    memset(&a, 0, sizeof a);
-    a.data = data;
-    a.n = n;
-    a.origin = gmin;
-    a.inv = (double)kHistBins / range;
-    a.hist = d.h0;
-    a.partials = d.partials;
-    int grid = 0;
-    AB_TRY(launch_dense_hist(ctx, HIST_VALUE, a, &grid));
-    hist.resize(kHistBins);
-    std::vector<ScanPartial> parts(grid);
-    AB_HIP(ctx, hipMemcpyAsync(hist.data(), d.h0, kHistBins * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    AB_TRY(download(ctx, parts.data(), d.partials, grid * sizeof(ScanPartial)));
-    double s = 0.0;
-    uint64_t c = 0;
-    for (int i = 0; i < grid; ++i) {
-        s += parts[i].sum;
-        c += parts[i].cnt;
-    }
-    *sum = s;
-    *cnt = c;
-    return AB_OK;
-}
-
-// stats.rs:85-210
-int stats_hist_core(ab_ctx *ctx, const float *data, int64_t n, double global_min, double global_max,
-                    const DeviceHists &d, ab_image_stats *out) {
-    const double range = std::fmax(global_max - global_min, 1e-30);
-    const double bin_width = range / (double)kHistBins;
-
-    std::vector<unsigned long long> value_hist_h, refine_h(kHistBins), dev_h(kHistBins), mad_refine_h(kHistBins);
-    double global_sum;
-    uint64_t total_valid;
-    AB_TRY(value_hist(ctx, data, n, global_min, global_max, d, value_hist_h, &global_sum, &total_valid));
-    if (total_valid == 0) {
-        memset(out, 0, sizeof *out);
-        return AB_OK;
-    }
-    const double mean = global_sum / (double)total_valid;
-    const uint64_t half_count = f64_to_u64_sat(std::ceil((double)total_valid * 0.5));  // :100
-
-    const size_t median_bin = find_percentile_bin(value_hist_h.data(), kHistBins, total_valid, 0.5);
-    uint64_t count_before_median = 0;
-    for (size_t i = 0; i < median_bin; ++i) count_before_median += value_hist_h[i];
-    const double median_bin_lo = global_min + (double)median_bin * bin_width;
-    const double median_bin_hi = median_bin_lo + bin_width;
-    const double coarse_median =
-        interpolate_percentile(value_hist_h.data(), kHistBins, total_valid, 0.5, global_min, bin_width);
-
-    const double dev_range = range;  // :111-117
-    const double dev_bw = dev_range / (double)kHistBins;
-    const double dev_inv = (double)kHistBins / dev_range;
-    const float coarse_med_f32 = (float)coarse_median;
-    const double refine_range = std::fmax(median_bin_hi - median_bin_lo, 1e-30);
-    const double refine_inv = (double)kHistBins / refine_range;
-
-    // pass 3 (:119-146): deviation histogram (dense, LDS) + median-bin refinement (sparse, global)
-    AB_HIP(ctx, hipMemsetAsync(d.h0, 0, 2 * kHistBins * sizeof(unsigned long long), ctx->stream));
-    {
-        HistArgs a;
-        memset(&a, 0, sizeof a);
-        a.data = data;
-        a.n = n;
-        a.inv = dev_inv;
-        a.center = coarse_med_f32;
-        a.hist = d.h0;
-        a.want_refine = 1;
-        a.refine_lo = median_bin_lo;
-        a.refine_hi = median_bin_hi;
-        a.refine_inv = refine_inv;
-        a.refine = d.h1;
-        AB_TRY(launch_dense_hist(ctx, HIST_DEV, a, nullptr));
-    }
-    AB_HIP(ctx, hipMemcpyAsync(dev_h.data(), d.h0, kHistBins * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    AB_TRY(download(ctx, refine_h.data(), d.h1, kHistBins * sizeof(unsigned long long)));
-
-    const uint64_t median_rank_in_bin = half_count > count_before_median ? half_count - count_before_median : 0;
-    const double median_refine_bw = refine_range / (double)kHistBins;
-    const double median =
-        resolve_rank_in_hist(refine_h.data(), kHistBins, median_rank_in_bin, median_bin_lo, median_refine_bw);
-
-    const size_t mad_bin = find_percentile_bin(dev_h.data(), kHistBins, total_valid, 0.5);  // :154-164
-    const size_t expand_lo = mad_bin > 0 ? mad_bin - 1 : 0;
-    const size_t expand_hi = std::min<size_t>(mad_bin + 2, kHistBins);
-    const double mad_region_lo = (double)expand_lo * dev_bw;
-    const double mad_region_hi = (double)expand_hi * dev_bw;
-    const float exact_med_f32 = (float)median;
-    const double mad_refine_range = std::fmax(mad_region_hi - mad_region_lo, 1e-30);
-    const double mad_refine_inv = (double)kHistBins / mad_refine_range;
-    const float mad_lo_f32 = (float)mad_region_lo;
-    const float mad_hi_f32 = (float)mad_region_hi;
-
-    // pass 4 (:166-191)
-    AB_HIP(ctx, hipMemsetAsync(d.h0, 0, kHistBins * sizeof(unsigned long long), ctx->stream));
-    const int grid = std::min(grid_for(ctx, n, kScanBlock, 8), kMaxPartials);
-    hipLaunchKernelGGL(mad_refine_kernel, dim3(grid), dim3(kScanBlock), 0, ctx->stream, data, n, exact_med_f32, mad_lo_f32,
-                       mad_hi_f32, mad_region_lo, mad_refine_inv, d.h0, d.partials);
-    AB_HIP(ctx, hipGetLastError());
-    std::vector<ScanPartial> parts(grid);
-    AB_HIP(ctx, hipMemcpyAsync(mad_refine_h.data(), d.h0, kHistBins * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    AB_TRY(download(ctx, parts.data(), d.partials, grid * sizeof(ScanPartial)));
-    uint64_t count_below = 0;
-    for (int i = 0; i < grid; ++i) count_below += parts[i].cnt;
-
-    const uint64_t mad_rank_in_region = half_count > count_below ? half_count - count_below : 0;
-    const double mad_refine_bw = mad_refine_range / (double)kHistBins;
-    const double mad =
-        resolve_rank_in_hist(mad_refine_h.data(), kHistBins, mad_rank_in_region, mad_region_lo, mad_refine_bw);
-
-    out->min = global_min;
-    out->max = global_max;
-    out->mean = mean;
-    out->median = median;
-    out->mad = mad;
-    out->sigma = std::fmax(mad * kMadToSigma, 1e-30);
-    out->valid_count = total_valid;
-    return AB_OK;
-}
-
-// stats.rs:75-83
-int stats_hist(ab_ctx *ctx, const float *data, int64_t n, const DeviceHists &d, ab_image_stats *out) {
-    double mn, mx, sum;
-    uint64_t cnt;
-    AB_TRY(scan(ctx, data, n, d, &mn, &mx, &sum, &cnt));
-    if (mn == DBL_MAX) {
-        memset(out, 0, sizeof *out);
-        return AB_OK;
-    }
-    return stats_hist_core(ctx, data, n, mn, mx, d, out);
 }
 
 }  // namespace
 
+// The asynchronous form: enqueues compute_image_stats (+ auto_stf with `stf_cfg`, default config if null) of `data` on the
+// context's stream and returns the device addresses of the result / the STF transform; nothing is synchronised.
+// n_total = the pixel count that selects the exact (<= 4 000 000) or the histogram path: the plane's own n, or the
+// whole image's when `data` is one row band of it and `comm` joins the bands (stats.rs:18).
+int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, int64_t n_total, int use_known, double known_min,
+                     double known_max, const ab_auto_stf_config *stf_cfg, const ab_image_stats **result_dev, const void **tx_dev,
+                     const ab_stf_params **stf_dev) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    Ws w;
+    AB_TRY(carve(ctx, &w));
+    const ab_auto_stf_config cfg = stf_cfg ? *stf_cfg : kDefaultStf;
+    if (n_total <= kExactLimit) {  // stats.rs:18-22,32-34
+        AB_TRY(enqueue_exact_path(ctx, comm, data, n, w, cfg));
+    } else {
+        const bool known = use_known && std::isfinite(known_min) && std::isfinite(known_max) && known_min < known_max;  // stats.rs:36-38
+        if (known) {
+            hipLaunchKernelGGL(set_range_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st, known_min, known_max);
+        } else {
+            AB_TRY(enqueue_scan(ctx, comm, data, n, w, false));
+        }
+        AB_TRY(enqueue_hist_path(ctx, comm, data, n, w, cfg));
+    }
+    if (result_dev) *result_dev = &w.st->result;
+    if (tx_dev) *tx_dev = &w.st->tx;
+    if (stf_dev) *stf_dev = &w.st->stf;
+    return AB_OK;
+}
+
+static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_stats *out, ab_stf_params *stf_out) {
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, sizeof(ab_image_stats) + sizeof(ab_stf_params), &pin));
+    static_assert(offsetof(StatsDev, stf) == offsetof(StatsDev, result) + sizeof(ab_image_stats), "result and stf are adjacent");
+    AB_HIP(ctx, hipMemcpyAsync(pin, result_dev, sizeof(ab_image_stats) + sizeof(ab_stf_params), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (out) memcpy(out, pin, sizeof *out);
+    if (stf_out) memcpy(stf_out, (char *)pin + sizeof(ab_image_stats), sizeof *stf_out);
+    return AB_OK;
+}
+
 int ab_stats_device(ab_ctx *ctx, const float *data, int64_t n, int use_known, double known_min, double known_max,
                     ab_image_stats *out) {
-    AB_HIP(ctx, hipSetDevice(ctx->device));
-    DeviceHists d;
-    AB_TRY(carve(ctx, &d));
-    if (n <= kExactLimit) return stats_exact(ctx, data, n, d, out);  // stats.rs:18-22,32-34
-    if (use_known) {
-        if (!std::isfinite(known_min) || !std::isfinite(known_max) || known_min >= known_max)
-            return stats_hist(ctx, data, n, d, out);  // stats.rs:36-38
-        return stats_hist_core(ctx, data, n, known_min, known_max, d, out);
-    }
-    return stats_hist(ctx, data, n, d, out);
+    const ab_image_stats *res = nullptr;
+    AB_TRY(ab_stats_enqueue(ctx, nullptr, data, n, n, use_known, known_min, known_max, nullptr, &res, nullptr, nullptr));
+    return fetch_result(ctx, res, out, nullptr);
 }
 
 extern "C" {
@@ -670,6 +778,38 @@ int ab_compute_image_stats_with_known_range(ab_ctx *ctx, const ab_plane *img, do
     return rc;
 }
 
+// compute_image_stats of an image whose rows are spread over the ranks of `comm`: `band` is this rank's
+// rows, total_rows the whole image's.  Every rank receives the statistics of the WHOLE image.
+int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, int64_t total_rows, ab_image_stats *out) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, band && out && band->on_device, "sharded statistics take a device-resident row band");
+    AB_CHECK(ctx, total_rows >= band->rows && band->cols > 0, "total_rows (%lld) is smaller than the band (%lld rows)", (long long)total_rows,
+             (long long)band->rows);
+    const ab_image_stats *res = nullptr;
+    AB_TRY(ab_stats_enqueue(ctx, comm, band->data, band->rows * band->cols, total_rows * band->cols, 0, 0.0, 0.0, nullptr, &res, nullptr, nullptr));
+    return fetch_result(ctx, res, out, nullptr);
+}
+
+// auto_stretch_preview (cmd/common.rs:18-22): compute_image_stats -> auto_stf(default config) -> apply_stf, as one
+// asynchronous chain: the STF kernel reads its transform from the state block the statistics chain leaves in HBM.
+// out_u8_dev: rows x cols bytes on the device.  out_stats / out_stf (nullable): fetched at the end (one synchronisation;
+// pass both NULL to keep the call fully asynchronous).  With a communicator `img` is this rank's row band of an image of
+// total_rows rows and the statistics are those of the whole image (each rank stretches its own band).
+int ab_auto_stretch_preview(ab_ctx *ctx, ab_comm *comm, const ab_plane *img, int64_t total_rows, const ab_auto_stf_config *cfg,
+                            uint8_t *out_u8_dev, ab_image_stats *out_stats, ab_stf_params *out_stf) {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, img && img->data && img->on_device && out_u8_dev, "auto_stretch_preview takes a device plane and a device output");
+    AB_CHECK(ctx, img->rows > 0 && img->cols > 0, "plane has a zero dimension");
+    if (total_rows <= 0) total_rows = img->rows;
+    AB_CHECK(ctx, total_rows >= img->rows, "total_rows is smaller than the band");
+    const ab_image_stats *res = nullptr;
+    const void *tx = nullptr;
+    AB_TRY(ab_stats_enqueue(ctx, comm, img->data, img->rows * img->cols, total_rows * img->cols, 0, 0.0, 0.0, cfg, &res, &tx, nullptr));
+    AB_TRY(ab_stf_u8_device_tx(ctx, img->data, img->rows * img->cols, tx, out_u8_dev));
+    if (out_stats || out_stf) return fetch_result(ctx, res, out_stats, out_stf);
+    return AB_OK;
+}
+
 int ab_stats_value_hist(ab_ctx *ctx, const ab_plane *img, double gmin, double gmax, uint64_t *hist65536_host,
                         double *out_sum, uint64_t *out_cnt) {
     if (!ctx) return AB_ERR_INVALID;
@@ -677,16 +817,27 @@ int ab_stats_value_hist(ab_ctx *ctx, const ab_plane *img, double gmin, double gm
     AB_HIP(ctx, hipSetDevice(ctx->device));
     StagedPlane in;
     AB_TRY(ab_stage_in(ctx, img, &in));
-    DeviceHists d;
-    int rc = carve(ctx, &d);
-    std::vector<unsigned long long> h;
-    double s = 0.0;
-    uint64_t c = 0;
-    if (rc == AB_OK) rc = value_hist(ctx, in.dptr, in.rows * in.cols, gmin, gmax, d, h, &s, &c);
+    Ws w;
+    int rc = carve(ctx, &w);
     if (rc == AB_OK) {
-        memcpy(hist65536_host, h.data(), kHistBins * sizeof(uint64_t));
-        if (out_sum) *out_sum = s;
-        if (out_cnt) *out_cnt = c;
+        const int64_t n = in.rows * in.cols;
+        int grid = 0;
+        hipLaunchKernelGGL(set_range_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st, gmin, gmax);
+        hipLaunchKernelGGL(book_range_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st);
+        hipError_t e = hipMemsetAsync(w.H, 0, (size_t)(1 + kHistBins) * sizeof(unsigned long long), ctx->stream);
+        if (e == hipSuccess) rc = launch_dense<HIST_VALUE>(ctx, in.dptr, n, w, &grid);
+        if (e == hipSuccess && rc == AB_OK) {
+            hipLaunchKernelGGL(finish_hist_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.partials, grid, w.st, w.H, 1);
+            e = hipMemcpyAsync(hist65536_host, w.H + 1, kHistBins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+            unsigned long long cnt = 0;
+            double sum = 0.0;
+            if (e == hipSuccess) e = hipMemcpyAsync(&cnt, w.H, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&sum, &w.st->sum, sizeof sum, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (out_sum) *out_sum = sum;
+            if (out_cnt) *out_cnt = cnt;
+        }
+        if (e != hipSuccess) rc = ab_set_error(ctx, AB_ERR_HIP, "stats_value_hist: %s", hipGetErrorString(e));
     }
     ab_stage_release(ctx, &in);
     return rc;

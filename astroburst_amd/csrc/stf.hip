@@ -35,6 +35,30 @@ __global__ __launch_bounds__(256) void stf_u8_kernel(const float *__restrict__ i
     }
 }
 
+// the same map with the transform read from HBM (written by the statistics chain, stats.hip): no host round trip between
+// compute_image_stats -> auto_stf -> apply_stf (cmd/common.rs:18-22)
+__global__ __launch_bounds__(256) void stf_u8_tx_kernel(const float *__restrict__ in, int64_t n, const StfTx *__restrict__ tx,
+                                                        unsigned char *__restrict__ out) {
+    const StfTx t = *tx;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const float4 *in4 = reinterpret_cast<const float4 *>(in);
+    uchar4 *out4 = reinterpret_cast<uchar4 *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = in4[i];
+        uchar4 r;
+        r.x = to_u8(v.x, t);
+        r.y = to_u8(v.y, t);
+        r.z = to_u8(v.z, t);
+        r.w = to_u8(v.w, t);
+        out4[i] = r;
+    }
+    if (blockIdx.x == 0) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        if (i < n) out[i] = to_u8(in[i], t);
+    }
+}
+
 __global__ __launch_bounds__(256) void stf_f32_kernel(const float *in, int64_t n, StfTx t, float *out) {
     const int64_t n4 = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -60,8 +84,6 @@ __global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ sr
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
 }
 
-inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
-
 int stream_grid(ab_ctx *ctx, int64_t n4) {
     const int64_t want = (n4 + 255) / 256;
     const int64_t cap = (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8;
@@ -75,6 +97,14 @@ int ab_stf_u8_device(ab_ctx *ctx, const float *in, int64_t n, const ab_stf_param
     AB_HIP(ctx, hipSetDevice(ctx->device));
     AB_CHECK(ctx, ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 3) == 0, "apply_stf: planes must be 16-byte aligned");
     hipLaunchKernelGGL(stf_u8_kernel, dim3(stream_grid(ctx, n >> 2)), dim3(256), 0, ctx->stream, in, n, make_tx(p, st), out);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+int ab_stf_u8_device_tx(ab_ctx *ctx, const float *in, int64_t n, const void *tx_dev, uint8_t *out) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    AB_CHECK(ctx, ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 3) == 0, "apply_stf: planes must be 16-byte aligned");
+    hipLaunchKernelGGL(stf_u8_tx_kernel, dim3(stream_grid(ctx, n >> 2)), dim3(256), 0, ctx->stream, in, n, (const StfTx *)tx_dev, out);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -93,28 +123,7 @@ extern "C" {
 // stf.rs:13-39 (host scalar maths)
 int ab_auto_stf(const ab_image_stats *stats, const ab_auto_stf_config *cfg, ab_stf_params *out) {
     if (!stats || !cfg || !out) return AB_ERR_INVALID;
-    if (stats->valid_count == 0) {
-        out->shadow = 0.0;
-        out->midtone = 0.5;
-        out->highlight = 1.0;
-        return AB_OK;
-    }
-    const double range = std::fmax(stats->max - stats->min, 1e-30);
-    const double median_norm = (stats->median - stats->min) / range;
-    const double sigma_norm = stats->sigma / range;
-    const double shadow_norm = clampd(median_norm + cfg->shadow_k * sigma_norm, 0.0, 0.98);
-    const double highlight_norm = 1.0;
-    const double clip_range = std::fmax(highlight_norm - shadow_norm, 1e-15);
-    const double m_clipped = clampd((median_norm - shadow_norm) / clip_range, 0.0, 1.0);
-    double midtone = 0.5;
-    if (!(m_clipped <= 0.0 || m_clipped >= 1.0)) {
-        const double t = cfg->target_bg, m = m_clipped;  // mtf_balance, stf.rs:41-47
-        const double denom = 2.0 * t * m - t - m;
-        midtone = std::fabs(denom) < 1e-15 ? 0.5 : clampd(m * (t - 1.0) / denom, 0.0001, 0.9999);
-    }
-    out->shadow = shadow_norm;
-    out->midtone = midtone;
-    out->highlight = highlight_norm;
+    ab_auto_stf_hd(stats, cfg, out);
     return AB_OK;
 }
 

@@ -11,11 +11,15 @@ One STEP = one pass of the hot path over one device-resident synthetic stack of
    -> compute_image_stats -> auto_stf -> apply_stf (u8)
 all through the C ABI of libastroburst_hip.so, inputs already in HBM when the clock starts.
 
-N > 1 (one process per GPU, torch.distributed over RCCL): the frame set is sharded by frame
-(BASELINE.json configs[3]): every rank holds its own 64 frames of the same field, computes the
-per-pixel (sum, count) of its survivors, the partials are all-reduced over xGMI and divided, and
-the stretch runs on the result.  Work per GPU is fixed, so scaling is "weak"; `value` counts the
-frame-pixels all ranks processed.
+N > 1 (one process per GPU, torch.distributed over RCCL; without a launcher `--gpus N` spawns its own N ranks through
+torch.distributed.run): the frame set is sharded by frame (BASELINE.json configs[3]): every rank holds its own 64 frames
+of the same field, computes the per-pixel (sum, count) of its survivors, the partials are all-reduced over xGMI INSIDE
+the library (ab_stack_sigma_clip_sharded: RCCL behind the C ABI) and divided, and the stretch runs on the result.  Work
+per GPU is fixed, so scaling is "weak"; `value` counts the frame-pixels all ranks processed.
+`--force-sharded` runs exactly that code path on one GPU (a one-rank communicator: real ncclAllReduce calls).
+`--mode rowband` (N > 1) is the exact alternative: the same 64 frames on every rank, registration estimates sharded by
+frame and exchanged, each rank warps / stacks / stretches its row band, statistics joined by histogram all-reduces;
+total work is fixed, so scaling is "strong".
 
 Prints ONE JSON line (rank 0).  `value` = input MPix/s = frames x pixels / second for the whole
 step; `roofline` prices the stacking kernel alone against HBM; `cpu_baseline` times the CPU
@@ -49,7 +53,50 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline duration")
     ap.add_argument("--cpu-reg-frames", type=int, default=4, help="frame pairs the CPU baseline registers (each ~2 s on 8 threads)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="1 GPU: run the N > 1 code path (partial -> RCCL all-reduce on a one-rank communicator -> finalize)")
+    ap.add_argument("--mode", choices=("frames", "rowband"), default="frames",
+                    help="N > 1: 'frames' = BASELINE configs[3] (frame shards, two-level, weak scaling); 'rowband' = exact row bands (strong scaling)")
     return ap.parse_args()
+
+
+class stdout_to_stderr:
+    """RCCL prints a version banner on fd 1 when a communicator is created; bench.py's stdout carries ONE JSON line"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: re-run under torch.distributed.run with N ranks on this node."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def stack_source_hash():
+    """sha256 of the stack kernel's sources: ties profiles/stack_pmc.json (rocprofv3 --pmc passes) to the code that was profiled"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("stack_sigma_clip.hip", "sortnet_gen.hpp"):
+        with open(os.path.join(ROOT, "astroburst_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def rigid_transforms(n, rows, cols, seed=7):
@@ -69,24 +116,52 @@ def rigid_transforms(n, rows, cols, seed=7):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
     import torch
     import torch.distributed as dist
     import astroburst_amd as ab
     from astroburst_amd import synth
-    from astroburst_amd.distributed import sharded_stack
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus} GPUs")
+    if torch.cuda.device_count() < 1 or local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
     ctx = ab.Context(local_rank)
     ctx.use_torch_stream()
     name, cus, hbm = ctx.device_info()
+    sharded = world > 1 or args.force_sharded
+    rowband = world > 1 and args.mode == "rowband"
+    # the library's own communicator (RCCL behind the C ABI): rank 0 makes the id, torch.distributed carries it
+    comm = None
+    if sharded:
+        uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(ab.Comm.unique_id()), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(uid, 0)
+        with stdout_to_stderr():
+            comm = ab.Comm(ctx, bytes(uid.cpu().numpy().tobytes()), world, rank)
+            comm.allreduce(torch.zeros(8, dtype=torch.float32, device=dev))   # first collective: connects the ranks
+            torch.cuda.synchronize()
+        assert comm.size == world and comm.rank == rank
+    dev_names = [name]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, f"rank {rank}: cuda:{local_rank} {name}")
+        dev_names = gathered
 
     N, R, Cc = args.frames, args.rows, args.cols
     P = R * Cc
@@ -107,14 +182,15 @@ def main():
         cat_k = (c_ * cx0 + d_ * cy0 + ty_, a_ * cx0 + b_ * cy0 + tx_, cflux)
         truth = torch.full((R, Cc), 200.0, dtype=torch.float32, device=dev) + synth.render_stars(R, Cc, cat_k, device=dev)
         border = 16 if k % 10 == 9 else 0
-        raw.append(synth.make_frame(R, Cc, k + N * rank, device=dev, truth=truth, border=border))
+        raw.append(synth.make_frame(R, Cc, k + (0 if rowband else N * rank), device=dev, truth=truth, border=border))
     del truth
-    warped = [raw[0]] + [torch.empty_like(raw[0]) for _ in range(1, N)] if register else raw
-    stacked = torch.empty((R, Cc), dtype=torch.float32, device=dev)
-    u8 = torch.empty((R, Cc), dtype=torch.uint8, device=dev)
-    if world > 1:
-        psum = torch.empty((R, Cc), dtype=torch.float64, device=dev)
-        pcnt = torch.empty((R, Cc), dtype=torch.int32, device=dev)
+    row0, nrows = (0, R) if not rowband else ctx.shard_rows(R, world, rank)
+    if rowband:   # this rank's rows of every registered frame; frame 0 (the reference) needs no warp: a view of its rows
+        warped = [raw[0][row0:row0 + nrows]] + [torch.empty((nrows, Cc), dtype=torch.float32, device=dev) for _ in range(1, N)]
+    else:
+        warped = [raw[0]] + [torch.empty_like(raw[0]) for _ in range(1, N)] if register else raw
+    stacked = torch.empty((nrows, Cc), dtype=torch.float32, device=dev)
+    u8 = torch.empty((nrows, Cc), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     stack_ms, warp_ms, tail_ms, est_ms, kern_ms = [], [], [], [], []
@@ -125,30 +201,35 @@ def main():
     def step(i):
         e = ev[i]
         e[4].record()
-        if register and not args.known_transforms:
-            # align_pair(frame 0, frame k, Affine) x 63 (pair.rs:41-77): estimate + warp, frame-parallel workers
-            estimated[0] = ctx.align_pairs_affine(raw[0], raw[1:], warped[1:], num_threads=8)
-        e[0].record()
-        if register and args.known_transforms:
+        if rowband:
+            # estimates by frame across the ranks (frame k on rank (k - 1) mod G), exchanged as 80 bytes each; every rank then
+            # warps ITS rows of every frame with the whole-image coordinates (bit-identical to the rows of a full warp)
+            estimated[0] = ctx.register_frames_sharded(comm, raw[0], raw[1:], num_threads=8)
+            e[0].record()
             for k in range(1, N):
-                ctx.warp_image(raw[k], transforms[k], R, Cc, out=warped[k])
-        e[1].record()
-        if world == 1:
+                ctx.warp_image_rows(raw[k], estimated[0][k - 1].transform, R, row0, warped[k])
+            e[1].record()
             ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
             e[2].record()
         else:
-            def partial_fn(fr):
-                r = ctx.stack_partial_into(fr, psum, pcnt)
-                e[2].record()
-                return r
-
-            sharded_stack(warped, partial_fn, lambda s_, c_: ctx.stack_finalize_partial_into(s_, c_, stacked))
-        st = ctx.compute_image_stats(stacked)          # syncs the stream: the stack's events below are complete
+            if register and not args.known_transforms:
+                # align_pair(frame 0, frame k, Affine) x 63 (pair.rs:41-77): estimate + warp, frame-parallel workers
+                estimated[0] = ctx.align_pairs_affine(raw[0], raw[1:], warped[1:], num_threads=8)
+            e[0].record()
+            if register and args.known_transforms:
+                for k in range(1, N):
+                    ctx.warp_image(raw[k], transforms[k], R, Cc, out=warped[k])
+            e[1].record()
+            if not sharded:
+                ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
+            else:  # per-GPU partial -> RCCL all-reduce(sum f64, count u32) over xGMI -> divide, all inside the library
+                ctx.stack_sigma_clip_sharded(comm, warped, stacked, 3.0, 3.0, 5, want_rejected=False)
+            e[2].record()
+        # auto_stretch_preview (cmd/common.rs:18-22): statistics -> auto_stf -> apply_stf, one device chain, one sync
+        _, st, _ = ctx.auto_stretch_preview(stacked, out=u8, comm=comm if rowband else None, total_rows=R)
+        e[3].record()
         if i >= args.warmup:
             kern_ms.append(ctx.stack_last_kernel_ms())  # HIP events the library records right around its stack kernels
-        p = ctx.auto_stf(st)
-        ctx.apply_stf(stacked, p, st, out=u8)
-        e[3].record()
         return st
 
     for i in range(args.warmup):
@@ -177,7 +258,8 @@ def main():
     rejected = ctx.last_rejected()
 
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * N * P / 1e6 / (elapsed / args.steps)  # input MPix/s, whole job
+    job_frames = N if rowband else world * N               # rowband: the same N frames, split by rows (strong scaling)
+    value = job_frames * P / 1e6 / (elapsed / args.steps)  # input MPix/s, whole job
 
     # ---- roofline of the north-star kernel (stack): algorithmic bytes = 4*N*P read + 4*P (12*P partial) written,
     # divided by the kernel's average duration between HIP events on the launch stream
@@ -185,8 +267,9 @@ def main():
     stage_stack_ms = sum(stack_ms) / len(stack_ms)
     # the kernels' own duration: events recorded by the library on the launch stream immediately around the launches
     stack_avg_ms = sum(kern_ms) / len(kern_ms)
-    out_bytes = 4 * P if world == 1 else 12 * P
-    algo_bytes = 4 * N * P + out_bytes
+    Pb = nrows * Cc                                  # pixels this rank stacks (a row band in rowband mode, else the image)
+    out_bytes = 4 * Pb if not (sharded and not rowband) else 12 * Pb
+    algo_bytes = 4 * N * Pb + out_bytes
     achieved = algo_bytes / (stack_avg_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes committed with the profile of this same command
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
@@ -195,7 +278,8 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "stack_pmc.json")) as f:
             pmc = json.load(f)
-        if pmc.get("frames") == N and pmc.get("pixels") == P:
+        # only a counter taken from THIS kernel source counts: the profile script stores the hash of the stack kernel's sources
+        if pmc.get("frames") == N and pmc.get("pixels") == P and pmc.get("kernel_source_sha256") == stack_source_hash() and not sharded:
             traffic = pmc["hbm_bytes_per_launch"]
     except Exception:
         pass
@@ -207,11 +291,15 @@ def main():
     est_avg_ms = sum(est_ms) / len(est_ms)
     stage_ms = {"register_63_frames_estimate_and_warp" if not args.known_transforms else "register_estimate_skipped":
                 round(est_avg_ms, 4), "warps_with_known_transforms": round(warp_avg_ms, 4),
-                "stack": round(stage_stack_ms, 4),
-                "stats_stf" + ("_allreduce" if world > 1 else ""): round(sum(tail_ms) / len(tail_ms), 4)}
+                ("stack" if not sharded or rowband else "stack_partial_allreduce_finalize"): round(stage_stack_ms, 4),
+                "stats_stf" + ("_hist_allreduce" if rowband else ""): round(sum(tail_ms) / len(tail_ms), 4)}
+    stage_ms.pop("stack", None) if (sharded and not rowband) else None
+    if rowband:
+        stage_ms = {"register_estimates_sharded_by_frame_and_exchanged": round(est_avg_ms, 4), "warp_own_rows_of_63_frames": round(warp_avg_ms, 4),
+                    "stack_own_rows": round(stage_stack_ms, 4), "stats_stf_hist_allreduce": round(sum(tail_ms) / len(tail_ms), 4)}
     # the warp is f64-VALU bound (the reference's f64 bicubic, ~111 f64 ops per pixel), not HBM bound
     warp_roofline = None
-    if register:
+    if register and not rowband:
         if args.known_transforms:
             per = warp_avg_ms / (N - 1)
         else:  # the warps ran inside align_pairs_affine, overlapped with detection: time the kernel on its own here
@@ -233,7 +321,7 @@ def main():
     # the same stack launch back to back on the registered frames (no warps in between): isolates the kernel from the
     # clock / cache state the f64-heavy registration leaves behind
     iso_ms = None
-    if world == 1:
+    if world == 1 and not sharded:
         i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
         i0.record()
@@ -320,35 +408,64 @@ def main():
                "stack_stretch_only_mpix_s": round(N * rows_s * Cc / 1e6 / dt, 2)}
         if reg_parity:
             cpu["registration_parity_frame1"] = reg_parity
+        # the same oracle on ONE thread (SURVEY 8d asks for it beside the all-cores figure): a crop sized for ~3 s
+        rows_1 = int(max(1, min(rows_s, 3.0 / max(per_row * threads, 1e-9))))
+        crop1 = [c_[:rows_1] for c_ in crop]
+        t1 = time.perf_counter()
+        img1, _ = pyoracle.stack_images(crop1, 3.0, 3.0, 5, order=pyoracle.ORDER_SELECT, threads=1)
+        cst1 = pyoracle.compute_image_stats(img1)
+        pyoracle.apply_stf(img1, pyoracle.auto_stf(cst1), cst1, threads=1)
+        dt1 = time.perf_counter() - t1
+        cpu["one_thread"] = {"stack_stretch_only_mpix_s": round(N * rows_1 * Cc / 1e6 / dt1, 2), "cores": 1,
+                             "sample": f"{N}x{rows_1}x{Cc} crop, {dt1:.1f} s"}
         # parity spot check of the timed configuration on that crop
+        if sharded:   # the two-level estimator's own checker (one shard = all of this rank's frames)
+            ps, pc, _ = pyoracle.stack_partial(crop, 3.0, 3.0, 5)
+            img = np.where(pc > 0, (ps / np.maximum(pc, 1)).astype(np.float32), np.float32(0))
         got = stacked[:rows_s].cpu().numpy()
         bad = int((~((got == img) | (np.isnan(got) & np.isnan(img)))).sum())
         rel = float(np.nanmax(np.abs(got - img) / np.maximum(np.abs(img), 1e-30)))
-        cpu["parity_vs_gpu"] = {"pixels": int(img.size), "bit_mismatches": bad, "max_rel_err": rel}
+        cpu["parity_vs_gpu"] = {"pixels": int(img.size), "bit_mismatches": bad, "max_rel_err": rel,
+                                "checker": "oracle.stack_partial + divide (two-level)" if sharded else "oracle.stack_images (reference's single-level)"}
 
     if rank == 0:
+        # the whole step against HBM: every byte the step's stages must move at least once, over the step's wall time
+        step_bytes = (4 * N * P + 4 * P) + 21 * P + (8 * P * (N - 1) if register else 0)   # stack + stats(16P) + STF(5P) + unfused warps
+        step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9 * (1 if rowband else world)
         out = {
             "metric": "MPix/s sigma-clipped stack+stretch, 64x4096x4096 f32",
             "value": round(value, 1), "unit": "MPix/s (input frame-pixels)", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if rowband else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: {N}x{R}x{Cc} f32 synthetic frames per GPU: "
+            "config": {"workload": (f"C2: {N}x{R}x{Cc} f32 synthetic frames per GPU: " if not rowband else
+                                    f"C2 split by rows over {world} GPUs: {N}x{R}x{Cc} f32 synthetic frames in all: ")
                                    + ((f"affine register ({N - 1} x align_channel_affine estimate + bicubic warp) + "
                                        if not args.known_transforms else
                                        f"bicubic warp with the {N - 1} generating transforms (estimation skipped: diagnostic) + ")
                                       if register else "")
-                                   + ("kappa-sigma stack (3/3/5)" if world == 1 else
-                                      "per-GPU kappa-sigma partial + RCCL all-reduce(sum f64, count i32) + divide")
-                                   + " + image stats + auto-STF u8",
+                                   + ("kappa-sigma stack (3/3/5)" if not sharded else
+                                      "exact kappa-sigma stack of each GPU's row band" if rowband else
+                                      "per-GPU kappa-sigma partial + RCCL all-reduce(sum f64, count u32) inside the library + divide"
+                                      + (" [--force-sharded: one-rank communicator]" if world == 1 else ""))
+                                   + " + image stats + auto-STF u8 (auto_stretch_preview)"
+                                   + (" with histogram all-reduces" if rowband else ""),
                        "frames_per_gpu": N, "rows": R, "cols": Cc, "device": name, "cus": cus,
-                       "output_mpix_per_s": round(world * P / 1e6 / (elapsed / args.steps), 1),
+                       "rccl_ranks": (comm.size if comm else 0), "rccl_collectives_per_step": (comm.collectives_issued // nsteps if comm else 0),
+                       "devices": dev_names, "mode": ("rowband" if rowband else "frames") if sharded else "single",
+                       "output_mpix_per_s": round((1 if rowband else world) * P / 1e6 / (elapsed / args.steps), 1),
                        "rejected_pixels": rejected, "median": st.median,
                        "measured_copy_GBs": round(copy_gbs, 1), "stage_ms": stage_ms, "registration": reg_info},
             "roofline": roofline,
+            "roofline_step": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                              "frac": round(step_gbs / (HBM_PEAK_GBS * world), 4), "algorithmic_bytes": step_bytes,
+                              "note": "whole step (register + stack + stats + STF) bytes / ms_per_step: the registration estimate is latency / VALU bound, not HBM bound"},
             "roofline_warp": warp_roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -39,10 +39,13 @@ typedef enum {
     AB_ERR_HIP = 2,         /* HIP runtime error (message carries hipGetErrorString) */
     AB_ERR_NO_DEVICE = 3,   /* no gfx950 device / wrong architecture */
     AB_ERR_UNSUPPORTED = 4, /* valid request this build cannot serve yet */
-    AB_ERR_NOMEM = 5
+    AB_ERR_NOMEM = 5,
+    AB_ERR_COMM = 6,      /* RCCL unavailable or a collective failed (message carries ncclGetErrorString) */
+    AB_ERR_CANCELLED = 7  /* the host set the context's cancel flag (AppError::Cancelled, core/imaging/background.rs:80-82) */
 } ab_status;
 
 typedef struct ab_ctx ab_ctx;
+typedef struct ab_comm ab_comm; /* one RCCL rank bound to a context's GPU: section (e) at the end of this header */
 
 typedef struct {
     const float *data;
@@ -72,6 +75,16 @@ AB_API int ab_device_alloc(ab_ctx *ctx, size_t bytes, void **out_dptr);
 AB_API int ab_device_free(ab_ctx *ctx, void *dptr);
 AB_API int ab_upload(ab_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 AB_API int ab_download(ab_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+/* Progress / cancel (infra/progress.rs:39-74; taken as Option<&ProgressHandle> by core/imaging/background.rs:55-59).
+ * cb(stage, current, total, user) is called on the calling thread at the reference's own stage boundaries with its stage
+ * strings ("sampling background", "fitting polynomial surface", "generating model", "applying correction") and once per
+ * frame by the frame loops (stage "register" / "stack"); NULL removes it.  ab_ctx_request_cancel may be called from any
+ * thread: the next stage boundary returns AB_ERR_CANCELLED ("Operation cancelled") and leaves the flag set until
+ * ab_ctx_clear_cancel. */
+typedef void (*ab_progress_cb)(const char *stage, uint64_t current, uint64_t total, void *user);
+AB_API int ab_ctx_set_progress_cb(ab_ctx *ctx, ab_progress_cb cb, void *user);
+AB_API int ab_ctx_request_cancel(ab_ctx *ctx);
+AB_API int ab_ctx_clear_cancel(ab_ctx *ctx);
 /* device properties the bench prints: name, CU count, HBM bytes */
 AB_API int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint64_t *hbm_bytes);
 
@@ -131,6 +144,11 @@ AB_API int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, 
 /* warp_image(image, &AffineTransform{a,b,tx,c,d,ty}, out_rows, out_cols): the transform maps
  * OUTPUT (x,y) to SOURCE (sx,sy) (affine.rs:74-80); 0.0 outside 0<=sx<cols-1, 0<=sy<rows-1. */
 AB_API int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out);
+
+/* rows [row0, row0 + out_band->rows) of warp_image(src, transform, out_rows, out_band->cols): the band of a row-sharded
+ * registration; coordinates are those of the whole output, so the band equals the same rows of ab_warp_image. */
+AB_API int ab_warp_image_rows(ab_ctx *ctx, const ab_plane *src, const double transform[6], int64_t out_rows, int64_t row0,
+                              ab_plane_mut *out_band);
 
 /* ---- a8  core/alignment/phase_correlation.rs ------------------------------------------------- */
 typedef struct { double dx, dy, confidence; } ab_phase_correlation_result; /* PhaseCorrelationResult, :15-20 */
@@ -223,6 +241,14 @@ AB_API int ab_apply_stf_u8(ab_ctx *ctx, const ab_plane *img, const ab_stf_params
 /* apply_stf_f32 (stf.rs:104-120); out may alias img.data (apply_stf_inplace, stf.rs:147-155) */
 AB_API int ab_apply_stf_f32(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st,
                             ab_plane_mut *out);
+
+/* auto_stretch_preview (cmd/common.rs:18-22): compute_image_stats -> auto_stf -> apply_stf as ONE asynchronous chain on the
+ * device (the percentile bookkeeping between the histogram passes runs in one-workgroup kernels; the STF kernel reads its
+ * transform from HBM).  img, out_u8_dev: device.  cfg NULL = AutoStfConfig::default().  out_stats / out_stf (nullable) are
+ * fetched with the call's only synchronisation; both NULL keeps it fully asynchronous.  With a communicator, img is this
+ * rank's row band of an image of total_rows rows (0 = img->rows) and the statistics are the whole image's. */
+AB_API int ab_auto_stretch_preview(ab_ctx *ctx, ab_comm *comm, const ab_plane *img, int64_t total_rows, const ab_auto_stf_config *cfg,
+                                   uint8_t *out_u8_dev, ab_image_stats *out_stats, ab_stf_params *out_stf);
 
 /* ---- a14  core/imaging/scnr.rs ----------------------------------------------------------------- */
 typedef struct { /* ScnrConfig, types/image.rs:82-100 */
@@ -542,6 +568,60 @@ AB_API int ab_generate_tile_pyramid_rgb(ab_ctx *ctx, const ab_plane *r, const ab
 
 /* ---- bench support: a plain float4 device copy, the measured HBM ceiling ---- */
 AB_API int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats);
+
+/* ---- (e) multi-GPU: SURVEY.md 8e -------------------------------------------------------------- */
+/* The reference is one process on one machine (rayon); what shards is its per-pixel loop (combine.rs:160-182, rows are
+ * independent) and its frame list.  One ab_ctx + one ab_comm rank per GPU; collectives are RCCL (xGMI inside a node),
+ * enqueued on the context's stream.  librccl is dlopen'ed on first use: the rest of the library works without it. */
+#define AB_COMM_ID_BYTES 128
+typedef enum { AB_DT_I32 = 0, AB_DT_U32 = 1, AB_DT_I64 = 2, AB_DT_U64 = 3, AB_DT_F32 = 4, AB_DT_F64 = 5 } ab_dtype;
+typedef enum { AB_RED_SUM = 0, AB_RED_MAX = 1, AB_RED_MIN = 2 } ab_redop;
+/* multi-process: rank 0 makes the id, the host carries it to the other processes, every rank joins */
+AB_API int ab_comm_get_unique_id(uint8_t id[AB_COMM_ID_BYTES]);
+AB_API int ab_comm_init_rank(ab_ctx *ctx, const uint8_t id[AB_COMM_ID_BYTES], int nranks, int rank, ab_comm **out);
+/* single process, n contexts on n distinct devices: out_comms[i] is rank i, bound to ctxs[i]'s device.  Drive each
+ * context from its own host thread, or bracket the per-device calls with ab_comm_group_start / _end. */
+AB_API int ab_comm_init_all(ab_ctx *const *ctxs, int n, ab_comm **out_comms);
+AB_API void ab_comm_destroy(ab_comm *comm);
+AB_API int ab_comm_rank(const ab_comm *comm);  /* a NULL communicator is a world of one: rank 0 */
+AB_API int ab_comm_size(const ab_comm *comm);  /* ... of size 1 */
+AB_API uint64_t ab_comm_collectives_issued(const ab_comm *comm);
+AB_API int ab_comm_group_start(void);
+AB_API int ab_comm_group_end(void);
+/* in-place all-reduce of `count` elements on the context's stream (asynchronous) */
+AB_API int ab_comm_allreduce(ab_ctx *ctx, ab_comm *comm, void *buf_dev, size_t count, int dtype /* ab_dtype */, int op /* ab_redop */);
+/* recv_dev = size x bytes_per_rank bytes, rank r's block at r * bytes_per_rank */
+AB_API int ab_comm_allgather(ab_ctx *ctx, ab_comm *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank);
+AB_API int ab_comm_broadcast(ab_ctx *ctx, ab_comm *comm, void *buf_dev, size_t bytes, int root);
+
+/* partitions: rows [row0, row0 + nrows) (ceil(rows / nranks) per rank, trailing bands shorter or empty) and frames
+ * [f0, f0 + nf) (contiguous, balanced) of rank `rank` */
+AB_API int ab_shard_rows(int64_t rows, int nranks, int rank, int64_t *row0, int64_t *nrows);
+AB_API int ab_shard_frames(size_t n_frames, int nranks, int rank, size_t *f0, size_t *nf);
+
+/* ROW-BAND (exact) sharding of stack_images' per-pixel loop (combine.rs:160-182): rows [row0, row0 + out_band->rows) of
+ * the stack of ALL n frames -- the reference's single-level estimator restricted to a band, bit for bit.  Device planes. */
+AB_API int ab_stack_sigma_clip_rows(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, int64_t row0,
+                                    ab_plane_mut *out_band, uint64_t *out_rejected);
+/* the same with the band = this rank's share (ab_shard_rows over the minimum frame dims, combine.rs:104-113) and
+ * StackResult.rejected_pixels summed over the ranks (one u64 all-reduce) */
+AB_API int ab_stack_sigma_clip_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
+                                       ab_plane_mut *out_band, uint64_t *out_rejected_total);
+/* FRAME-SHARDED two-level stack (BASELINE configs[3]): ab_stack_sigma_clip_partial over this rank's frames ->
+ * all-reduce(sum f64, count u32) -> ab_stack_finalize_partial.  `out` (device) is the full image on every rank.  NOT the
+ * reference's estimator (a median over all frames is not decomposable); checker: orc_stack_partial_noalign. */
+AB_API int ab_stack_sigma_clip_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *local_planes, size_t n_local,
+                                       const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected_total);
+/* every rank's band -> the full image on every rank (one broadcast per rank inside one RCCL group) */
+AB_API int ab_allgather_rows(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, ab_plane_mut *full);
+/* align_channel_affine(reference, targets[i]) for i < n, target i estimated on rank i mod size, all n results on every
+ * rank (exchanged bit for bit as integer words); targets a rank does not own are not read there */
+AB_API int ab_register_frames_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *reference, const ab_plane *targets, size_t n,
+                                      int num_threads, ab_affine_align_result *out);
+/* compute_image_stats (stats.rs:15-210) of an image whose rows are spread over the ranks: `band` = this rank's rows,
+ * total_rows = the whole image's.  min / max, counts and the 65 536-bin histograms are all-reduced between the passes
+ * (integers: every bin equals the single-GPU bin); every rank receives the whole image's statistics. */
+AB_API int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, int64_t total_rows, ab_image_stats *out);
 
 #ifdef __cplusplus
 }

@@ -77,6 +77,48 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
                 if (OP == 31) CHAIN2("v_lshlrev_b32");
                 if (OP == 32) CHAIN2("v_sub_u32");
                 if (OP == 33) CHAIN2("v_max_i16");
+            } else if (OP >= 50 && OP < 70) {
+#define CHAIN2V(OPN) asm volatile(OPN " %0, vcc, %0, %1\n " OPN " %1, vcc, %1, %2\n " OPN " %2, vcc, %2, %3\n " OPN " %3, vcc, %3, %4\n " \
+                                 OPN " %4, vcc, %4, %5\n " OPN " %5, vcc, %5, %6\n " OPN " %6, vcc, %6, %7\n " OPN " %7, vcc, %7, %0\n"     \
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc")
+#define CHAINC(OPN) asm volatile(OPN " vcc, %0, %1\n " OPN " vcc, %1, %2\n " OPN " vcc, %2, %3\n " OPN " vcc, %3, %4\n " \
+                                 OPN " vcc, %4, %5\n " OPN " vcc, %5, %6\n " OPN " vcc, %6, %7\n " OPN " vcc, %7, %0\n"     \
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "vcc")
+#define CHAIN3(OPN) asm volatile(OPN " %0, %0, %1, %2\n " OPN " %1, %1, %2, %3\n " OPN " %2, %2, %3, %4\n " OPN " %3, %3, %4, %5\n " \
+                                 OPN " %4, %4, %5, %6\n " OPN " %5, %5, %6, %7\n " OPN " %6, %6, %7, %0\n " OPN " %7, %7, %0, %1\n"     \
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+                if (OP == 50) CHAIN2V("v_sub_co_u32");
+                if (OP == 51) CHAINC("v_cmp_lt_u32");
+                if (OP == 52) CHAINC("v_cmp_lt_i32");
+                if (OP == 53) CHAIN2("v_min_u32");
+                if (OP == 54) CHAIN2("v_max_i32");
+                if (OP == 55) CHAIN3("v_perm_b32");
+                if (OP == 56) CHAIN3("v_add3_u32");
+                if (OP == 57) CHAIN3("v_lshl_add_u32");
+                if (OP == 58) CHAIN3("v_and_or_b32");
+                if (OP == 59) CHAIN3("v_bfe_u32");
+                if (OP == 60) CHAIN3("v_minimum3_f32");
+                if (OP == 61) CHAIN3("v_mad_u32_u24");
+                                if (OP == 63) CHAIN3("v_alignbit_b32");
+                if (OP == 64) CHAIN3("v_sad_u32");
+                if (OP == 65) CHAIN3("v_max3_u32");
+                if (OP == 66) CHAIN2("v_max_u16");
+                if (OP == 67) CHAIN3("v_med3_f32");
+            } else if (OP == 70) {  // integer compare-exchange: v_sub_co_u32 -> vcc ; 2 x v_cndmask (3 instr per CE, 4 CEs)
+                float t0, t1, t2, t3;
+                asm volatile("v_sub_co_u32 %8, vcc, %0, %1\n v_cndmask_b32 %8, %0, %1, vcc\n v_cndmask_b32 %1, %1, %0, vcc\n v_mov_b32 %0, %8\n"
+                             "v_sub_co_u32 %9, vcc, %2, %3\n v_cndmask_b32 %9, %2, %3, vcc\n v_cndmask_b32 %3, %3, %2, vcc\n v_mov_b32 %2, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : : "vcc");
+            } else if (OP == 71) {  // CE through an SGPR pair (no vcc serialisation): v_cmp_lt_u32 s[..], 2 cndmask
+                float t0, t1; unsigned long long m0, m1;
+                asm volatile("v_cmp_lt_u32 %10, %0, %1\n v_cmp_lt_u32 %11, %2, %3\n v_cndmask_b32 %8, %0, %1, %10\n v_cndmask_b32 %1, %1, %0, %10\n"
+                             "v_cndmask_b32 %9, %2, %3, %11\n v_cndmask_b32 %3, %3, %2, %11\n v_mov_b32 %0, %8\n v_mov_b32 %2, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1), "=&s"(m0), "=&s"(m1));
+            } else if (OP == 72) {  // v_sub_co into sgpr pair then cndmask
+                float t0, t1, u0, u1; unsigned long long m0, m1;
+                asm volatile("v_sub_co_u32 %12, %10, %0, %1\n v_sub_co_u32 %13, %11, %2, %3\n v_cndmask_b32 %8, %0, %1, %10\n v_cndmask_b32 %1, %1, %0, %10\n"
+                             "v_cndmask_b32 %9, %2, %3, %11\n v_cndmask_b32 %3, %3, %2, %11\n v_mov_b32 %0, %8\n v_mov_b32 %2, %9\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1), "=&s"(m0), "=&s"(m1), "=&v"(u0), "=&v"(u1));
             } else if (OP == 40) {  // v_cmp_lt_f32 (vcc) only
                 asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_lt_f32 vcc, %1, %2\n v_cmp_lt_f32 vcc, %2, %3\n v_cmp_lt_f32 vcc, %3, %4\n"
                              "v_cmp_lt_f32 vcc, %4, %5\n v_cmp_lt_f32 vcc, %5, %6\n v_cmp_lt_f32 vcc, %6, %7\n v_cmp_lt_f32 vcc, %7, %0\n"
@@ -139,6 +181,14 @@ int main() {
             run<28>("v_add_f32", out, 4, cus, clk); run<29>("v_mul_f32", out, 4, cus, clk);
             run<40>("v_cmp_lt_f32 -> vcc", out, 4, cus, clk); run<41>("v_cndmask_b32 (const vcc)", out, 4, cus, clk);
             run<42>("v_min3/med3/max3_i32", out, 4, cus, clk);
+            run<50>("v_sub_co_u32 ->vcc", out, 4, cus, clk); run<51>("v_cmp_lt_u32 ->vcc", out, 4, cus, clk); run<52>("v_cmp_lt_i32 ->vcc", out, 4, cus, clk);
+            run<53>("v_min_u32", out, 4, cus, clk); run<54>("v_max_i32", out, 4, cus, clk); run<55>("v_perm_b32", out, 4, cus, clk);
+            run<56>("v_add3_u32", out, 4, cus, clk); run<57>("v_lshl_add_u32", out, 4, cus, clk); run<58>("v_and_or_b32", out, 4, cus, clk);
+            run<59>("v_bfe_u32", out, 4, cus, clk); run<60>("v_minimum3_f32", out, 4, cus, clk); run<61>("v_mad_u32_u24", out, 4, cus, clk);
+            run<63>("v_alignbit_b32", out, 4, cus, clk); run<64>("v_sad_u32", out, 4, cus, clk); run<65>("v_max3_u32", out, 4, cus, clk);
+            run<66>("v_max_u16", out, 4, cus, clk); run<67>("v_med3_f32", out, 4, cus, clk);
+            run<70>("CE int: sub_co+2cndmask+mov (8 instr/blk)", out, 4, cus, clk); run<71>("CE: cmp_u32->sgpr,2cndmask (8/blk)", out, 4, cus, clk);
+            run<72>("CE: sub_co->sgpr,2cndmask (8/blk)", out, 4, cus, clk);
         }
     }
     return 0;
