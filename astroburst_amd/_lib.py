@@ -238,6 +238,8 @@ def lib() -> C.CDLL:
     L.ab_apply_stf_f32.argtypes = [vp, pp, C.POINTER(StfParamsC), C.POINTER(ImageStatsC), pp]
     L.ab_bench_copy.argtypes = [vp, vp, vp, C.c_size_t]
     L.ab_estimate_background.argtypes = [vp, pp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ab_background_tile_stats.argtypes = [vp, pp, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_size_t,
+                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ab_detect_stars.argtypes = [vp, pp, C.c_double, C.POINTER(DetectedStarC), C.c_size_t, C.POINTER(C.c_size_t),
                                   C.POINTER(C.c_size_t), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.ab_normalize_for_detection.argtypes = [vp, pp, pp]

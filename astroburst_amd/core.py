@@ -839,6 +839,21 @@ class Context:
         self._check(self._L.ab_estimate_background(self._h, C.byref(pi), tile_size, C.byref(m), C.byref(s)))
         return m.value, s.value
 
+    def background_tile_stats(self, image, tile_size: int):
+        """per-tile sigma_clipped_stats of estimate_background's tiling -> (median[nty, ntx], sigma[nty, ntx], valid[nty, ntx])"""
+        keep = []
+        pi = self._plane(image, keep)
+        step = max(int(tile_size), 16)
+        nty, ntx = -(-pi.rows // step), -(-pi.cols // step)
+        med, sig = np.zeros(nty * ntx), np.zeros(nty * ntx)
+        val = np.zeros(nty * ntx, np.int32)
+        n, nx = C.c_size_t(), C.c_size_t()
+        self._check(self._L.ab_background_tile_stats(self._h, C.byref(pi), tile_size, med.ctypes.data_as(C.POINTER(C.c_double)),
+                                                     sig.ctypes.data_as(C.POINTER(C.c_double)), val.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                     nty * ntx, C.byref(n), C.byref(nx)))
+        assert (n.value, nx.value) == (nty * ntx, ntx)
+        return med.reshape(nty, ntx), sig.reshape(nty, ntx), val.reshape(nty, ntx).astype(bool)
+
     def detect_stars(self, image, sigma_threshold: float, max_stars: int = 100000):
         """detect_stars(image, sigma) -> (stars, background_median, background_sigma) (star_detection.rs:86-258)"""
         keep = []

@@ -115,6 +115,12 @@ int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);
         if (rc_ != AB_OK) return rc_; \
     } while (0)
 
+// Exception barrier of the C ABI (tools/add_exception_barrier.py wraps every entry point in a function-try-block): nothing may
+// unwind through `extern "C"` into a host built with panic = "abort" (Cargo.toml:64).
+int ab_catch(ab_ctx *ctx, const char *fn);
+#define AB_CATCH(ctx) catch (...) { return ab_catch((ctx), __func__); }
+#define AB_CATCH_NOCTX catch (...) { return ab_catch(nullptr, __func__); }
+
 // Scratch arena: returns a device pointer valid until the next ab_scratch() call with a larger size.
 int ab_scratch(ab_ctx *ctx, size_t bytes, void **out);
 int ab_pinned(ab_ctx *ctx, size_t bytes, void **out);

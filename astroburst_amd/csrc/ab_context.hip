@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <exception>
+#include <new>
 #include <thread>
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...) {
@@ -14,6 +16,30 @@ int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
         std::lock_guard<std::mutex> lk(ctx->err_mu);
         ctx->err = buf;
+    }
+    return code;
+}
+
+// the handler behind AB_CATCH: rethrows the exception in flight to classify it
+int ab_catch(ab_ctx *ctx, const char *fn) {
+    int code = AB_ERR_INVALID;
+    char msg[512];
+    try {
+        throw;
+    } catch (const std::bad_alloc &) {
+        code = AB_ERR_NOMEM;
+        snprintf(msg, sizeof msg, "%s: out of host memory (std::bad_alloc)", fn);
+    } catch (const std::exception &e) {
+        snprintf(msg, sizeof msg, "%s: internal error: %s", fn, e.what());
+    } catch (...) {
+        snprintf(msg, sizeof msg, "%s: internal error (unknown exception)", fn);
+    }
+    if (ctx) {
+        try {
+            std::lock_guard<std::mutex> lk(ctx->err_mu);
+            ctx->err.assign(msg);
+        } catch (...) {  // not even the message fits: the code still says what happened
+        }
     }
     return code;
 }
@@ -31,29 +57,29 @@ int ab_progress(ab_ctx *ctx, const char *stage, uint64_t current, uint64_t total
 
 extern "C" {
 
-int ab_ctx_set_progress_cb(ab_ctx *ctx, ab_progress_cb cb, void *user) {
+int ab_ctx_set_progress_cb(ab_ctx *ctx, ab_progress_cb cb, void *user) try {
     if (!ctx) return AB_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->progress_mu);
     ctx->progress_cb = cb;
     ctx->progress_user = user;
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_ctx_request_cancel(ab_ctx *ctx) {
+int ab_ctx_request_cancel(ab_ctx *ctx) try {
     if (!ctx) return AB_ERR_INVALID;
     ctx->cancel.store(1);
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_ctx_clear_cancel(ab_ctx *ctx) {
+int ab_ctx_clear_cancel(ab_ctx *ctx) try {
     if (!ctx) return AB_ERR_INVALID;
     ctx->cancel.store(0);
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 const char *ab_version(void) { return "astroburst_hip 0.2.0 (gfx950)"; }
 
-int ab_ctx_create(int device_id, ab_ctx **out) {
+int ab_ctx_create(int device_id, ab_ctx **out) try {
     if (!out) return AB_ERR_INVALID;
     *out = nullptr;
     int count = 0;
@@ -85,7 +111,7 @@ int ab_ctx_create(int device_id, ab_ctx **out) {
     if (const char *rw = getenv("AB_REGISTER_WORKERS")) ctx->register_workers = std::max(1, atoi(rw));
     *out = ctx;
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 void ab_ctx_destroy(ab_ctx *ctx) {
     if (!ctx) return;
@@ -120,53 +146,53 @@ static int switch_stream(ab_ctx *ctx, hipStream_t next) {
     return AB_OK;
 }
 
-int ab_ctx_set_stream(ab_ctx *ctx, void *hip_stream) {
+int ab_ctx_set_stream(ab_ctx *ctx, void *hip_stream) try {
     if (!ctx) return AB_ERR_INVALID;
     // a NULL handle IS a stream: HIP's legacy default stream (what PyTorch uses by default)
     return switch_stream(ctx, (hipStream_t)hip_stream);
-}
+} AB_CATCH(ctx)
 
-int ab_ctx_reset_stream(ab_ctx *ctx) {
+int ab_ctx_reset_stream(ab_ctx *ctx) try {
     if (!ctx) return AB_ERR_INVALID;
     return switch_stream(ctx, ctx->own_stream);
-}
+} AB_CATCH(ctx)
 
 void *ab_ctx_get_stream(ab_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
-int ab_ctx_synchronize(ab_ctx *ctx) {
+int ab_ctx_synchronize(ab_ctx *ctx) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_device_alloc(ab_ctx *ctx, size_t bytes, void **out_dptr) {
+int ab_device_alloc(ab_ctx *ctx, size_t bytes, void **out_dptr) try {
     if (!ctx || !out_dptr) return AB_ERR_INVALID;
     AB_HIP(ctx, hipSetDevice(ctx->device));
     AB_HIP(ctx, hipMalloc(out_dptr, bytes ? bytes : 1));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_device_free(ab_ctx *ctx, void *dptr) {
+int ab_device_free(ab_ctx *ctx, void *dptr) try {
     if (!ctx) return AB_ERR_INVALID;
     if (dptr) AB_HIP(ctx, hipFree(dptr));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_upload(ab_ctx *ctx, void *dst_device, const void *src_host, size_t bytes) {
+int ab_upload(ab_ctx *ctx, void *dst_device, const void *src_host, size_t bytes) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_HIP(ctx, hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_download(ab_ctx *ctx, void *dst_host, const void *src_device, size_t bytes) {
+int ab_download(ab_ctx *ctx, void *dst_host, const void *src_device, size_t bytes) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_HIP(ctx, hipMemcpyAsync(dst_host, src_device, bytes, hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint64_t *hbm_bytes) {
+int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint64_t *hbm_bytes) try {
     if (!ctx) return AB_ERR_INVALID;
     hipDeviceProp_t prop;
     AB_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -174,7 +200,7 @@ int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint
     if (cu_count) *cu_count = prop.multiProcessorCount;
     if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"
 

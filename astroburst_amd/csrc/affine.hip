@@ -765,7 +765,7 @@ int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *t
 extern "C" {
 
 int ab_align_channel_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane *target, int num_threads,
-                            ab_affine_align_result *out) {
+                            ab_affine_align_result *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, reference && target && out, "null argument");
     AB_CHECK(ctx, reference->rows == target->rows && reference->cols == target->cols,
@@ -780,10 +780,10 @@ int ab_align_channel_affine(ab_ctx *ctx, const ab_plane *reference, const ab_pla
     }
     ab_stage_release(ctx, &r);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
-                       ab_affine_align_result *out) {
+                       ab_affine_align_result *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, reference && out && (targets || n == 0), "null argument");
     for (size_t i = 0; i < n; ++i)
@@ -805,10 +805,10 @@ int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *t
     for (size_t i = 0; i < staged && i < n; ++i) ab_stage_release(ctx, &st[i]);
     ab_stage_release(ctx, &r);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
-                          ab_affine_align_result *out, ab_plane_mut *aligned) {
+                          ab_affine_align_result *out, ab_plane_mut *aligned) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, reference && out && aligned && (targets || n == 0), "null argument");
     AB_CHECK(ctx, reference->on_device, "align_pairs takes device-resident planes");
@@ -824,17 +824,17 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
         outs[i] = aligned[i].data;
     }
     return ab_register_frames_device(ctx, reference->data, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data());
-}
+} AB_CATCH(ctx)
 
 // the host geometry alone, on given centroids (x, y pairs): returns AB_OK and *found = 0/1
 int ab_affine_from_stars(const double *ref_xy, size_t n_ref, const double *tgt_xy, size_t n_tgt, int64_t rows, int64_t cols,
-                         int num_threads, ab_affine_align_result *out, int *found) {
+                         int num_threads, ab_affine_align_result *out, int *found) try {
     if ((!ref_xy && n_ref) || (!tgt_xy && n_tgt) || !out || !found) return AB_ERR_INVALID;
     std::vector<Pt> rs(n_ref), ts(n_tgt);
     for (size_t i = 0; i < n_ref; ++i) rs[i] = {ref_xy[2 * i], ref_xy[2 * i + 1]};
     for (size_t i = 0; i < n_tgt; ++i) ts[i] = {tgt_xy[2 * i], tgt_xy[2 * i + 1]};
     *found = affine_from_stars(rs, ts, rows, cols, num_threads, out) ? 1 : 0;
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 }  // extern "C"

@@ -177,7 +177,7 @@ struct Sample {
 }  // namespace
 
 extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_background_config *cfg, ab_plane_mut *out_model,
-                                     ab_plane_mut *out_corrected, ab_background_info *info) {
+                                     ab_plane_mut *out_corrected, ab_background_info *info) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && cfg && out_corrected, "null argument");
     const int64_t rows = img->rows, cols = img->cols, npix = rows * cols;
@@ -364,4 +364,4 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
     return rc;
 #undef BG_TRY
 #undef BG_HIP
-}
+} AB_CATCH(ctx)

@@ -910,7 +910,7 @@ void ab_batch_stack_config_default(ab_batch_stack_config *cfg) {  // calibration
     cfg->normalize_before_stack = 1;
 }
 
-int ab_calibrate_light(ab_ctx *ctx, const ab_plane *light, const ab_calibration_masters *masters, ab_plane_mut *out) {
+int ab_calibrate_light(ab_ctx *ctx, const ab_plane *light, const ab_calibration_masters *masters, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, light && out && out->rows == light->rows && out->cols == light->cols, "null plane or mismatched dims");
     StagedPlane in;
@@ -934,9 +934,9 @@ int ab_calibrate_light(ab_ctx *ctx, const ab_plane *light, const ab_calibration_
     release_masters(ctx, &sm);
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_normalize_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, ab_plane_mut *outs) {
+int ab_normalize_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, ab_plane_mut *outs) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, (frames && outs) || n == 0, "null argument");
     for (size_t f = 0; f < n; ++f) {
@@ -966,10 +966,10 @@ int ab_normalize_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, ab_plane_
         if (rc != AB_OK) return rc;
     }
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 int ab_sigma_clipped_mean_stack(ab_ctx *ctx, const ab_plane *frames, size_t n, const ab_batch_stack_config *config, ab_plane_mut *out,
-                                uint64_t *rejection_counts) {
+                                uint64_t *rejection_counts) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, out, "null argument");
     AB_TRY(check_frames(ctx, frames, n, "sigma_clipped_mean_stack"));
@@ -988,10 +988,10 @@ int ab_sigma_clipped_mean_stack(ab_ctx *ctx, const ab_plane *frames, size_t n, c
     }
     release_frames(ctx, &sf);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_run_batch_channel(ab_ctx *ctx, const ab_plane *lights, size_t n, const ab_calibration_masters *masters, const ab_batch_stack_config *config,
-                         ab_plane_mut *out_master, uint64_t *rejection_counts, ab_batch_channel_stats *stats) {
+                         ab_plane_mut *out_master, uint64_t *rejection_counts, ab_batch_channel_stats *stats) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, out_master, "null argument");
     AB_TRY(check_frames(ctx, lights, n, "run_batch_pipeline"));
@@ -1024,10 +1024,10 @@ int ab_run_batch_channel(ab_ctx *ctx, const ab_plane *lights, size_t n, const ab
     release_masters(ctx, &sm);
     release_frames(ctx, &sf);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_compose_rgb_from_masters(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, const ab_plane *l, float *out_rgb,
-                                int32_t out_on_device, int64_t *out_rows, int64_t *out_cols) {
+                                int32_t out_on_device, int64_t *out_rows, int64_t *out_cols) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, r && g && b && r->data && g->data && b->data, "null argument");
     AB_CHECK(ctx, r->rows > 0 && r->cols > 0 && g->rows > 0 && g->cols > 0 && b->rows > 0 && b->cols > 0, "a master has a zero dimension");
@@ -1074,11 +1074,11 @@ int ab_compose_rgb_from_masters(ab_ctx *ctx, const ab_plane *r, const ab_plane *
     }
     for (int c = 0; c < staged; ++c) ab_stage_release(ctx, &st[c]);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_run_batch_pipeline(ab_ctx *ctx, const ab_batch_channel_input *channels, size_t n_channels, const ab_calibration_masters *masters,
                           const ab_batch_stack_config *config, ab_plane_mut *out_masters, ab_batch_channel_stats *stats, float *out_rgb,
-                          int32_t rgb_on_device, int64_t *rgb_rows, int64_t *rgb_cols) {
+                          int32_t rgb_on_device, int64_t *rgb_rows, int64_t *rgb_cols) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, channels && n_channels > 0, "No channels provided");  // :125-127
     AB_CHECK(ctx, out_masters, "null argument");
@@ -1108,6 +1108,6 @@ int ab_run_batch_pipeline(ab_ctx *ctx, const ab_batch_channel_input *channels, s
     for (int k = 0; k < 4; ++k)
         if (m[k]) in[k] = ab_plane{m[k]->data, m[k]->rows, m[k]->cols, m[k]->on_device};
     return ab_compose_rgb_from_masters(ctx, &in[0], &in[1], &in[2], m[3] ? &in[3] : nullptr, out_rgb, rgb_on_device, rgb_rows, rgb_cols);
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

@@ -265,7 +265,7 @@ int unary_map(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out, F launch) {
 
 extern "C" {
 
-int ab_apply_scnr_inplace(ab_ctx *ctx, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b, const ab_scnr_config *cfg) {
+int ab_apply_scnr_inplace(ab_ctx *ctx, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b, const ab_scnr_config *cfg) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, r && g && b && cfg, "null argument");
     if (r->rows != g->rows || r->cols != g->cols || g->rows != b->rows || g->cols != b->cols) return AB_OK;  // scnr.rs:24-26
@@ -303,10 +303,10 @@ int ab_apply_scnr_inplace(ab_ctx *ctx, ab_plane_mut *r, ab_plane_mut *g, ab_plan
     if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return ab_set_error(ctx, AB_ERR_HIP, "SCNR: %s", hipGetErrorString(e));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 int ab_blend_channels(ab_ctx *ctx, const ab_plane *channels, size_t n_channels, const ab_blend_weight *weights,
-                      size_t n_weights, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b) {
+                      size_t n_weights, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, channels && weights && r && g && b, "null argument");
     AB_CHECK(ctx, n_channels >= 1 && n_channels <= (size_t)kMaxBlendChannels, "1..%d channels", kMaxBlendChannels);
@@ -358,9 +358,9 @@ int ab_blend_channels(ab_ctx *ctx, const ab_plane *channels, size_t n_channels, 
     }
     for (size_t i = 0; i < staged; ++i) ab_stage_release(ctx, &st[i]);
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_spline_lut_from_points(const double *points_xy, size_t n_in, float *lut4096) {
+int ab_spline_lut_from_points(const double *points_xy, size_t n_in, float *lut4096) try {
     if ((!points_xy && n_in) || !lut4096) return AB_ERR_INVALID;
     std::vector<std::pair<double, double>> pts(n_in);
     for (size_t i = 0; i < n_in; ++i) pts[i] = {points_xy[2 * i], points_xy[2 * i + 1]};
@@ -378,9 +378,9 @@ int ab_spline_lut_from_points(const double *points_xy, size_t n_in, float *lut40
     fritsch_carlson(px, py, tan);
     for (int i = 0; i < 4096; ++i) lut4096[i] = (float)clampd(hermite_eval(px, py, tan, (double)i / 4095.0), 0.0, 1.0);
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
-int ab_apply_curve(ab_ctx *ctx, const ab_plane *img, const float *lut4096_host, ab_plane_mut *out) {
+int ab_apply_curve(ab_ctx *ctx, const ab_plane *img, const float *lut4096_host, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, lut4096_host, "null LUT");
     void *dlut = nullptr;
@@ -391,9 +391,9 @@ int ab_apply_curve(ab_ctx *ctx, const ab_plane *img, const float *lut4096_host, 
     return unary_map(ctx, img, out, [&](const float *in, int64_t n, float *o) {
         hipLaunchKernelGGL(curve_kernel, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, in, n, (const float *)dlut, o);
     });
-}
+} AB_CATCH(ctx)
 
-int ab_apply_levels(ab_ctx *ctx, const ab_plane *img, const ab_levels_params *p, ab_plane_mut *out) {
+int ab_apply_levels(ab_ctx *ctx, const ab_plane *img, const ab_levels_params *p, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, p, "null params");
     const bool identity = std::fabs(p->black) < 1e-7 && std::fabs(p->gamma - 1.0) < 1e-7 && std::fabs(p->white - 1.0) < 1e-7;
@@ -407,10 +407,10 @@ int ab_apply_levels(ab_ctx *ctx, const ab_plane *img, const ab_levels_params *p,
         hipLaunchKernelGGL(levels_kernel, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, in, n, p->black, inv_range,
                            inv_gamma, o);
     });
-}
+} AB_CATCH(ctx)
 
 int ab_arcsinh_stretch_with_stats(ab_ctx *ctx, const ab_plane *img, float dmin, float dmax, float factor, float gamma,
-                                  ab_plane_mut *out) {
+                                  ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     if (std::fabs(factor) < 1e-10f)  // stretch.rs:17-19
         return unary_map(ctx, img, out, [&](const float *in, int64_t n, float *o) {
@@ -427,18 +427,18 @@ int ab_arcsinh_stretch_with_stats(ab_ctx *ctx, const ab_plane *img, float dmin, 
         hipLaunchKernelGGL(arcsinh_kernel, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, in, n, dmin, inv_range, factor,
                            inv_denom, apply_gamma, gamma, o);
     });
-}
+} AB_CATCH(ctx)
 
-int ab_scale(ab_ctx *ctx, const ab_plane *img, float factor, ab_plane_mut *out) {
+int ab_scale(ab_ctx *ctx, const ab_plane *img, float factor, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     return unary_map(ctx, img, out, [&](const float *in, int64_t n, float *o) {
         const int vec = (((uintptr_t)in | (uintptr_t)o) & 15) == 0;
         hipLaunchKernelGGL(scale_kernel, dim3(stream_grid(ctx, vec ? (n >> 2) : n)), dim3(kBlock), 0, ctx->stream, in, n, factor, o,
                            vec);
     });
-}
+} AB_CATCH(ctx)
 
-int ab_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, ab_plane_mut *out) {
+int ab_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, r && g && b && out, "null plane");
     AB_CHECK(ctx, r->rows == g->rows && r->cols == g->cols && g->rows == b->rows && g->cols == b->cols &&
@@ -470,10 +470,10 @@ int ab_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_pla
     }
     ab_stage_release(ctx, &sr);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_calibrate_image(ab_ctx *ctx, const ab_plane *raw, const ab_plane *bias, const ab_plane *dark, const ab_plane *flat,
-                       float dark_exposure_ratio, ab_plane_mut *out) {
+                       float dark_exposure_ratio, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, raw && out, "null plane");
     const ab_plane *opt[3] = {bias, dark, flat};
@@ -497,6 +497,6 @@ int ab_calibrate_image(ab_ctx *ctx, const ab_plane *raw, const ab_plane *bias, c
     for (int i = 0; i < staged; ++i)
         if (opt[i]) ab_stage_release(ctx, &so_[i]);
     return rc;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

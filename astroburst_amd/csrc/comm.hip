@@ -108,7 +108,7 @@ struct ab_comm {
 
 extern "C" {
 
-int ab_comm_get_unique_id(uint8_t id[AB_COMM_ID_BYTES]) {
+int ab_comm_get_unique_id(uint8_t id[AB_COMM_ID_BYTES]) try {
     if (!id) return AB_ERR_INVALID;
     const Rccl *r = rccl();
     if (!r) return AB_ERR_COMM;
@@ -117,9 +117,9 @@ int ab_comm_get_unique_id(uint8_t id[AB_COMM_ID_BYTES]) {
     static_assert(sizeof u == AB_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
     memcpy(id, &u, sizeof u);
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
-int ab_comm_init_rank(ab_ctx *ctx, const uint8_t id[AB_COMM_ID_BYTES], int nranks, int rank, ab_comm **out) {
+int ab_comm_init_rank(ab_ctx *ctx, const uint8_t id[AB_COMM_ID_BYTES], int nranks, int rank, ab_comm **out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, id && out, "null id or output");
     AB_CHECK(ctx, nranks >= 1 && rank >= 0 && rank < nranks, "rank %d of %d", rank, nranks);
@@ -141,9 +141,9 @@ int ab_comm_init_rank(ab_ctx *ctx, const uint8_t id[AB_COMM_ID_BYTES], int nrank
     c->device = ctx->device;
     *out = c;
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_comm_init_all(ab_ctx *const *ctxs, int n, ab_comm **out_comms) {
+int ab_comm_init_all(ab_ctx *const *ctxs, int n, ab_comm **out_comms) try {
     if (!ctxs || !out_comms || n < 1 || n > 64) return AB_ERR_INVALID;
     for (int i = 0; i < n; ++i) {
         if (!ctxs[i]) return AB_ERR_INVALID;
@@ -170,7 +170,7 @@ int ab_comm_init_all(ab_ctx *const *ctxs, int n, ab_comm **out_comms) {
         out_comms[i] = c;
     }
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 void ab_comm_destroy(ab_comm *c) {
     if (!c) return;
@@ -186,17 +186,17 @@ int ab_comm_rank(const ab_comm *c) { return c ? c->rank : 0; }
 int ab_comm_size(const ab_comm *c) { return c ? c->size : 1; }
 uint64_t ab_comm_collectives_issued(const ab_comm *c) { return c ? c->collectives : 0; }
 
-int ab_comm_group_start(void) {
+int ab_comm_group_start(void) try {
     const Rccl *r = rccl();
     return (r && r->GroupStart() == ncclSuccess) ? AB_OK : AB_ERR_COMM;
-}
-int ab_comm_group_end(void) {
+} AB_CATCH_NOCTX
+int ab_comm_group_end(void) try {
     const Rccl *r = rccl();
     return (r && r->GroupEnd() == ncclSuccess) ? AB_OK : AB_ERR_COMM;
-}
+} AB_CATCH_NOCTX
 
 // in place, on the context's stream, asynchronous; a NULL communicator is a world of one (no-op)
-int ab_comm_allreduce(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t count, int dtype, int op) {
+int ab_comm_allreduce(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t count, int dtype, int op) try {
     if (!ctx) return AB_ERR_INVALID;
     if (!c) return AB_OK;
     AB_CHECK(ctx, buf_dev && count > 0, "null or empty all-reduce buffer");
@@ -212,10 +212,10 @@ int ab_comm_allreduce(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t count, int 
     AB_NCCL(ctx, r, r->AllReduce(buf_dev, buf_dev, count, nt, nop, c->comm, ctx->stream));
     c->collectives++;
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 // recv_dev holds size x bytes_per_rank bytes, rank r's block at r * bytes_per_rank; send_dev may be its own block
-int ab_comm_allgather(ab_ctx *ctx, ab_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank) {
+int ab_comm_allgather(ab_ctx *ctx, ab_comm *c, const void *send_dev, void *recv_dev, size_t bytes_per_rank) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, send_dev && recv_dev && bytes_per_rank > 0, "null or empty all-gather buffer");
     if (!c) {
@@ -229,9 +229,9 @@ int ab_comm_allgather(ab_ctx *ctx, ab_comm *c, const void *send_dev, void *recv_
     AB_NCCL(ctx, r, r->AllGather(send_dev, recv_dev, bytes_per_rank, ncclUint8, c->comm, ctx->stream));
     c->collectives++;
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_comm_broadcast(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t bytes, int root) {
+int ab_comm_broadcast(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t bytes, int root) try {
     if (!ctx) return AB_ERR_INVALID;
     if (!c) return AB_OK;
     AB_CHECK(ctx, buf_dev && bytes > 0 && root >= 0 && root < c->size, "bad broadcast arguments");
@@ -241,6 +241,6 @@ int ab_comm_broadcast(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t bytes, int 
     AB_NCCL(ctx, r, r->Broadcast(buf_dev, buf_dev, bytes, ncclUint8, root, c->comm, ctx->stream));
     c->collectives++;
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

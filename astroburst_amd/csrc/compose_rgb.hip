@@ -109,7 +109,7 @@ int channel_or_synth(ab_ctx *ctx, const float *primary, const float *alt1, const
 
 extern "C" {
 
-int ab_select_wb_reference(const ab_image_stats *sr, const ab_image_stats *sg, const ab_image_stats *sb, double out[3]) {
+int ab_select_wb_reference(const ab_image_stats *sr, const ab_image_stats *sg, const ab_image_stats *sb, double out[3]) try {
     if (!sr || !sg || !sb || !out) return AB_ERR_INVALID;
     auto stability = [](const ab_image_stats *s) { return s->median > 1e-10 ? s->mad / s->median : DBL_MAX; };
     const double stab_r = stability(sr), stab_g = stability(sg), stab_b = stability(sb);
@@ -122,11 +122,11 @@ int ab_select_wb_reference(const ab_image_stats *sr, const ab_image_stats *sg, c
         out[0] = mg / mr, out[1] = 1.0, out[2] = mg / mb;
     }
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 int ab_process_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, const ab_rgb_compose_config *cfg,
                    ab_plane_mut *out_r, ab_plane_mut *out_g, ab_plane_mut *out_b, ab_plane_mut *pre_r, ab_plane_mut *pre_g,
-                   ab_plane_mut *pre_b, ab_processed_rgb_info *info) {
+                   ab_plane_mut *pre_b, ab_processed_rgb_info *info) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, cfg && out_r && out_g && out_b && info, "null argument");
     const ab_plane *ch[3] = {r, g, b};
@@ -302,6 +302,6 @@ int ab_process_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_p
         if (pres[c]) AB_TRY(ab_stage_out_finish(ctx, &sp[c]));
     }
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

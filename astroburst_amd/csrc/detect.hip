@@ -25,6 +25,7 @@
 //     (ab_px), so the registration path never materialises the normalised frame.
 #include "ab_common.hpp"
 #include "block_select.hpp"
+#include "tile_bucket.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -157,6 +158,45 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
     const uint32_t guess = s_guess;
     const TileOut res = tile_stats(src, t, hist0, hist, tally, guess != 0xffffffffu, guess);
     if (threadIdx.x == 0) out[blockIdx.x] = res;
+}
+
+// The same statistics from ONE histogram of the tile (tile_bucket.hpp): the product kernel.  tile_background_kernel above is
+// the round-1 radix-select version, kept behind AB_TILE_LEGACY=1 as an in-library cross-check (tests run both).
+__global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
+                                                                              int step, int ntx, const ab_pixel_xf xf, TileOut *__restrict__ out) {
+    __shared__ tb::Shared sh;
+    const int ty0 = (blockIdx.x / ntx) * step, tx0 = (blockIdx.x % ntx) * step;
+    const int y1 = min(ty0 + step, rows), x1 = min(tx0 + step, cols);
+    // thread (tx, ty) of the 256 x 4 layout walks column tx0 + tx downwards, four rows per slot: consecutive lanes read
+    // consecutive pixels; all 64 loads are issued before the first key is formed
+    const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
+    const int c = tx0 + tx;
+    const bool col_ok = c < x1;
+    tb::Keys K;
+    // two batches of 32 loads in flight (64 raw values + 64 keys live at once would spill at the 128-VGPR budget of 1024 threads)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        float raw[tb::kSlots / 2];
+#pragma unroll
+        for (int i = 0; i < tb::kSlots / 2; ++i) {
+            const int r = ty0 + ty + 4 * (h * (tb::kSlots / 2) + i);
+            raw[i] = (col_ok && r < y1) ? img[(int64_t)r * ld + c] : __builtin_nanf("");
+        }
+#pragma unroll
+        for (int i = 0; i < tb::kSlots / 2; ++i) {
+            const float v = ab_px(xf, raw[i]);
+            K.k[h * (tb::kSlots / 2) + i] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
+        }
+    }
+    const tb::TileResult r = tb::tile_stats(K, sh);
+    if (threadIdx.x == 0) {
+        TileOut o;
+        o.median = r.median;
+        o.sigma = r.sigma;
+        o.valid = r.valid;
+        o.pad = 0;
+        out[blockIdx.x] = o;
+    }
 }
 
 // ---- threshold + union-find labelling -------------------------------------------------------------
@@ -490,8 +530,9 @@ int f64_cmp(double a, double b) {  // math/median.rs:15-25
 }  // namespace
 
 // estimate_background (star_detection.rs:32-84) on a device plane
-int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, int64_t tile_size,
-                                  double *out_median, double *out_sigma, ab_pixel_xf xf = ab_pixel_xf()) {
+// per-tile sigma-clipped (median, sigma, valid) of estimate_background's tiling (star_detection.rs:36-68), row-major tiles
+static int tile_stats_host(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, int64_t tile_size, ab_pixel_xf xf,
+                           std::vector<TileOut> *out, int *ntx_out) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     const int step = (int)std::max<int64_t>(tile_size, 16);
     AB_CHECK(ctx, step <= 256, "background tiles larger than 256 px are not supported (tile_size %lld)", (long long)tile_size);
@@ -501,11 +542,24 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
     // through the runtime's staging pages for a pageable destination, just the stream sync
     void *pin = nullptr;
     AB_TRY(ab_pinned(ctx, (size_t)ntiles * sizeof(TileOut), &pin));
-    hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(absel::kBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
-                       ntx, xf, (TileOut *)pin);
+    static const bool legacy = getenv("AB_TILE_LEGACY") != nullptr;
+    if (legacy)
+        hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(absel::kBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
+                           ntx, xf, (TileOut *)pin);
+    else
+        hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(ntiles), dim3(tb::kThreads), 0, ctx->stream, img, (int)rows, (int)cols, ld,
+                           step, ntx, xf, (TileOut *)pin);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const std::vector<TileOut> h((const TileOut *)pin, (const TileOut *)pin + ntiles);
+    out->assign((const TileOut *)pin, (const TileOut *)pin + ntiles);
+    if (ntx_out) *ntx_out = ntx;
+    return AB_OK;
+}
+
+int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, int64_t tile_size,
+                                  double *out_median, double *out_sigma, ab_pixel_xf xf = ab_pixel_xf()) {
+    std::vector<TileOut> h;
+    AB_TRY(tile_stats_host(ctx, img, rows, cols, ld, tile_size, xf, &h, nullptr));
     std::vector<double> med, sig;
     for (const auto &t : h)
         if (t.valid) {
@@ -709,7 +763,30 @@ int ab_normalize_for_detection_device(ab_ctx *ctx, const float *img, int64_t len
 
 extern "C" {
 
-int ab_estimate_background(ab_ctx *ctx, const ab_plane *img, int64_t tile_size, double *out_median, double *out_sigma) {
+// the tile map behind estimate_background: per tile (row-major, ceil(rows / step) x ceil(cols / step), step = max(tile_size, 16))
+// the sigma-clipped median and sigma, and whether the tile had the 8 valid pixels it needs (star_detection.rs:47-68)
+int ab_background_tile_stats(ab_ctx *ctx, const ab_plane *img, int64_t tile_size, double *out_median, double *out_sigma, int32_t *out_valid,
+                             size_t cap, size_t *out_tiles, size_t *out_tiles_x) try {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, img && out_tiles, "null argument");
+    StagedPlane in;
+    AB_TRY(ab_stage_in(ctx, img, &in));
+    std::vector<TileOut> h;
+    int ntx = 0;
+    const int rc = tile_stats_host(ctx, in.dptr, in.rows, in.cols, in.cols, tile_size, ab_pixel_xf(), &h, &ntx);
+    ab_stage_release(ctx, &in);
+    if (rc != AB_OK) return rc;
+    *out_tiles = h.size();
+    if (out_tiles_x) *out_tiles_x = (size_t)ntx;
+    for (size_t i = 0; i < h.size() && i < cap; ++i) {
+        if (out_median) out_median[i] = h[i].median;
+        if (out_sigma) out_sigma[i] = h[i].sigma;
+        if (out_valid) out_valid[i] = h[i].valid;
+    }
+    return AB_OK;
+} AB_CATCH(ctx)
+
+int ab_estimate_background(ab_ctx *ctx, const ab_plane *img, int64_t tile_size, double *out_median, double *out_sigma) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out_median && out_sigma, "null argument");
     StagedPlane in;
@@ -717,10 +794,10 @@ int ab_estimate_background(ab_ctx *ctx, const ab_plane *img, int64_t tile_size, 
     const int rc = ab_estimate_background_device(ctx, in.dptr, in.rows, in.cols, in.cols, tile_size, out_median, out_sigma);
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_detect_stars(ab_ctx *ctx, const ab_plane *img, double sigma_threshold, ab_detected_star *out, size_t cap, size_t *out_count,
-                    size_t *out_total, double *bg_median, double *bg_sigma) {
+                    size_t *out_total, double *bg_median, double *bg_sigma) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out_count && (out || cap == 0), "null argument");
     AB_CHECK(ctx, img->data && img->rows > 0 && img->cols > 0, "plane is null or has a zero dimension");
@@ -738,9 +815,9 @@ int ab_detect_stars(ab_ctx *ctx, const ab_plane *img, double sigma_threshold, ab
     if (bg_median) *bg_median = m;
     if (bg_sigma) *bg_sigma = s;
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_normalize_for_detection(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out) {
+int ab_normalize_for_detection(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out && img->rows == out->rows && img->cols == out->cols, "null plane or mismatched dims");
     StagedPlane in;
@@ -757,6 +834,6 @@ int ab_normalize_for_detection(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *o
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void flat_normalise_kernel(float *__restric
 extern "C" {
 
 int ab_apply_lrgb(ab_ctx *ctx, const ab_plane *l, ab_plane_mut *r, ab_plane_mut *g, ab_plane_mut *b, float lightness_weight,
-                  float chrominance_weight) {
+                  float chrominance_weight) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, l && r && g && b, "null plane");
     const ab_plane_mut *ch[3] = {r, g, b};
@@ -140,9 +140,9 @@ int ab_apply_lrgb(ab_ctx *ctx, const ab_plane *l, ab_plane_mut *r, ab_plane_mut 
     ab_stage_release(ctx, &sl);
     if (e != hipSuccess) return ab_set_error(ctx, AB_ERR_HIP, "apply_lrgb: %s", hipGetErrorString(e));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_synthesize_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, ab_plane_mut *out) {
+int ab_synthesize_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, r && g && b && out, "null plane");
     AB_CHECK(ctx, g->rows == r->rows && g->cols == r->cols && b->rows == r->rows && b->cols == r->cols && out->rows == r->rows &&
@@ -170,10 +170,10 @@ int ab_synthesize_luminance(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, c
     }
     for (int i = 0; i < staged; ++i) ab_stage_release(ctx, &in[i]);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_compute_linked_stf(const ab_image_stats *sr, const ab_image_stats *sg, const ab_image_stats *sb, const ab_auto_stf_config *cfg,
-                          ab_stf_params *out_stf, ab_image_stats *out_combined) {
+                          ab_stf_params *out_stf, ab_image_stats *out_combined) try {
     if (!sr || !sg || !sb || !cfg || !out_stf) return AB_ERR_INVALID;
     ab_image_stats c;  // cmd/helpers.rs:191-199
     c.min = std::fmin(std::fmin(sr->min, sg->min), sb->min);
@@ -185,10 +185,10 @@ int ab_compute_linked_stf(const ab_image_stats *sr, const ab_image_stats *sg, co
     c.valid_count = sr->valid_count;
     if (out_combined) *out_combined = c;
     return ab_auto_stf(&c, cfg, out_stf);
-}
+} AB_CATCH_NOCTX
 
 int ab_calibrate_channel(ab_ctx *ctx, const ab_plane *orig, float factor, const ab_image_stats *orig_stats, ab_plane_mut *out,
-                         ab_image_stats *out_stats) {
+                         ab_image_stats *out_stats) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, orig && orig_stats && out && out_stats, "null argument");
     AB_CHECK(ctx, out->rows == orig->rows && out->cols == orig->cols, "output must have the channel's dims");
@@ -221,10 +221,10 @@ int ab_calibrate_channel(ab_ctx *ctx, const ab_plane *orig, float factor, const 
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_create_master(ab_ctx *ctx, int32_t kind, const ab_plane *frames, size_t n_frames, const ab_plane *master_bias,
-                     const ab_plane *master_dark, ab_plane_mut *out) {
+                     const ab_plane *master_dark, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, kind >= 0 && kind <= 2 && out, "kind must be 0 (bias), 1 (dark) or 2 (flat)");
     if (!frames || n_frames == 0)  // calibration.rs:128-130,158-160,199-201
@@ -314,6 +314,6 @@ int ab_create_master(ab_ctx *ctx, int32_t kind, const ab_plane *frames, size_t n
     if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return ab_set_error(ctx, AB_ERR_HIP, "master flat normalisation: %s", hipGetErrorString(e));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

@@ -132,7 +132,7 @@ int ab_fits_decode_device(ab_ctx *ctx, const uint8_t *raw, int64_t n, int64_t bi
 extern "C" {
 
 int ab_fits_decode_pixels(ab_ctx *ctx, const void *data, size_t nbytes, int32_t data_on_device, int64_t bitpix, double bscale, double bzero,
-                          ab_plane_mut *out) {
+                          ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, out && (data || nbytes == 0), "null argument");
     const int bpp = bytes_per_pixel(bitpix);
@@ -167,9 +167,9 @@ int ab_fits_decode_pixels(ab_ctx *ctx, const void *data, size_t nbytes, int32_t 
         (void)hipFree(tmp);
     }
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_fits_compute_bzero_bscale(ab_ctx *ctx, const ab_plane *img, double *bzero, double *bscale) {
+int ab_fits_compute_bzero_bscale(ab_ctx *ctx, const ab_plane *img, double *bzero, double *bscale) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && bzero && bscale, "null argument");
     AB_HIP(ctx, hipSetDevice(ctx->device));
@@ -202,9 +202,9 @@ int ab_fits_compute_bzero_bscale(ab_ctx *ctx, const ab_plane *img, double *bzero
         *bzero = dmin + *bscale * 32768.0;
     }
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_fits_encode_pixels(ab_ctx *ctx, const ab_plane *img, int32_t bitpix, double bzero, double bscale, void *out, int32_t out_on_device) {
+int ab_fits_encode_pixels(ab_ctx *ctx, const ab_plane *img, int32_t bitpix, double bzero, double bscale, void *out, int32_t out_on_device) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out, "null argument");
     AB_CHECK(ctx, bitpix == -32 || bitpix == 16 || bitpix == -64, "the writer supports BITPIX -32, 16 and -64 (got %d)", (int)bitpix);
@@ -241,6 +241,6 @@ int ab_fits_encode_pixels(ab_ctx *ctx, const ab_plane *img, int32_t bitpix, doub
     ab_stage_release(ctx, &in);
     if (e != hipSuccess) return ab_set_error(ctx, AB_ERR_HIP, "FITS encode failed: %s", hipGetErrorString(e));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

@@ -302,7 +302,7 @@ bool same_dims(const ab_plane *a, int64_t rows, int64_t cols) { return a->rows =
 extern "C" {
 
 int ab_generate_star_mask_from_stars(ab_ctx *ctx, const ab_plane *img, const ab_detected_star *stars, size_t n_stars,
-                                     const ab_star_mask_config *cfg, ab_plane_mut *out_mask, ab_star_mask_info *info) {
+                                     const ab_star_mask_config *cfg, ab_plane_mut *out_mask, ab_star_mask_info *info) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && cfg && out_mask && info && (stars || n_stars == 0), "null argument");
     AB_CHECK(ctx, out_mask->rows == img->rows && out_mask->cols == img->cols, "mask must have the image's dims");
@@ -319,9 +319,9 @@ int ab_generate_star_mask_from_stars(ab_ctx *ctx, const ab_plane *img, const ab_
     for (size_t i = 0; i < n_stars; ++i) discs.push_back({stars[i].x, stars[i].y, stars[i].fwhm});
     AB_TRY(star_mask_device(ctx, in.dptr, in.rows, in.cols, discs, *cfg, so.dptr, info, sc));
     return ab_stage_out_finish(ctx, &so);
-}
+} AB_CATCH(ctx)
 
-int ab_generate_star_mask(ab_ctx *ctx, const ab_plane *img, const ab_star_mask_config *cfg, ab_plane_mut *out_mask, ab_star_mask_info *info) {
+int ab_generate_star_mask(ab_ctx *ctx, const ab_plane *img, const ab_star_mask_config *cfg, ab_plane_mut *out_mask, ab_star_mask_info *info) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && cfg && out_mask && info, "null argument");
     AB_CHECK(ctx, out_mask->rows == img->rows && out_mask->cols == img->cols, "mask must have the image's dims");
@@ -338,10 +338,10 @@ int ab_generate_star_mask(ab_ctx *ctx, const ab_plane *img, const ab_star_mask_c
     AB_TRY(detect_discs(ctx, in.dptr, in.rows, in.cols, cfg->detection_sigma, &discs));
     AB_TRY(star_mask_device(ctx, in.dptr, in.rows, in.cols, discs, *cfg, so.dptr, info, sc));
     return ab_stage_out_finish(ctx, &so);
-}
+} AB_CATCH(ctx)
 
 int ab_masked_stretch_with_mask(ab_ctx *ctx, const ab_plane *img, const ab_plane *mask, const ab_star_mask_info *mask_info,
-                                const ab_masked_stretch_config *cfg, ab_plane_mut *out, ab_masked_stretch_result *res) {
+                                const ab_masked_stretch_config *cfg, ab_plane_mut *out, ab_masked_stretch_result *res) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && mask && cfg && out && res, "null argument");
     AB_CHECK(ctx, same_dims(mask, img->rows, img->cols) && out->rows == img->rows && out->cols == img->cols,
@@ -363,9 +363,9 @@ int ab_masked_stretch_with_mask(ab_ctx *ctx, const ab_plane *img, const ab_plane
         res->mask_coverage = mask_info->coverage_fraction;
     }
     return ab_stage_out_finish(ctx, &so);
-}
+} AB_CATCH(ctx)
 
-int ab_masked_stretch(ab_ctx *ctx, const ab_plane *img, const ab_masked_stretch_config *cfg, ab_plane_mut *out, ab_masked_stretch_result *res) {
+int ab_masked_stretch(ab_ctx *ctx, const ab_plane *img, const ab_masked_stretch_config *cfg, ab_plane_mut *out, ab_masked_stretch_result *res) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && cfg && out && res, "null argument");
     AB_CHECK(ctx, out->rows == img->rows && out->cols == img->cols, "output must have the image's dims");
@@ -391,11 +391,11 @@ int ab_masked_stretch(ab_ctx *ctx, const ab_plane *img, const ab_masked_stretch_
     res->stars_masked = mi.stars_masked;
     res->mask_coverage = mi.coverage_fraction;
     return ab_stage_out_finish(ctx, &so);
-}
+} AB_CATCH(ctx)
 
 int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, const ab_masked_stretch_config *cfg,
                                  ab_plane_mut *out_r, ab_plane_mut *out_g, ab_plane_mut *out_b, ab_masked_stretch_result *res3,
-                                 ab_star_mask_info *shared) {
+                                 ab_star_mask_info *shared) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, r && g && b && cfg && out_r && out_g && out_b && res3, "null argument");
     if (!same_dims(g, r->rows, r->cols) || !same_dims(b, r->rows, r->cols))  // masked_stretch.rs:126-134
@@ -437,6 +437,6 @@ int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab_plane 
     }
     for (int c = 0; c < 3; ++c) AB_TRY(ab_stage_out_finish(ctx, &so[c]));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

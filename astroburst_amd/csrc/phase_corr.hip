@@ -453,7 +453,7 @@ int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, i
 
 extern "C" {
 
-int ab_phase_correlate(ab_ctx *ctx, const ab_plane *reference, const ab_plane *target, ab_phase_correlation_result *out) {
+int ab_phase_correlate(ab_ctx *ctx, const ab_plane *reference, const ab_plane *target, ab_phase_correlation_result *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, reference && target && out, "null argument");
     StagedPlane r, t;
@@ -466,10 +466,10 @@ int ab_phase_correlate(ab_ctx *ctx, const ab_plane *reference, const ab_plane *t
     }
     ab_stage_release(ctx, &r);
     return rc;
-}
+} AB_CATCH(ctx)
 
 // test hook: correlate_single's full correlation surface (dims <= 512) for bit-level parity
-int ab_correlate_single(ab_ctx *ctx, const ab_plane *a, const ab_plane *b, ab_phase_correlation_result *out, double *surface_host) {
+int ab_correlate_single(ab_ctx *ctx, const ab_plane *a, const ab_plane *b, ab_phase_correlation_result *out, double *surface_host) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, a && b && out, "null argument");
     AB_CHECK(ctx, a->rows == b->rows && a->cols == b->cols && a->rows <= kCoarseMaxDim && a->cols <= kCoarseMaxDim,
@@ -488,6 +488,6 @@ int ab_correlate_single(ab_ctx *ctx, const ab_plane *a, const ab_plane *b, ab_ph
     }
     ab_stage_release(ctx, &sa);
     return rc;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

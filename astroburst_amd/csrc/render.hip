@@ -376,15 +376,15 @@ int pyramid(ab_ctx *ctx, const float *const *base, const ab_tile_level *levels, 
 
 extern "C" {
 
-int ab_preview_dims(int64_t rows, int64_t cols, int64_t max_dim, int64_t *out_rows, int64_t *out_cols) {
+int ab_preview_dims(int64_t rows, int64_t cols, int64_t max_dim, int64_t *out_rows, int64_t *out_cols) try {
     if (rows <= 0 || cols <= 0 || max_dim <= 0 || !out_rows || !out_cols) return AB_ERR_INVALID;
     double yr, xr;
     preview_dims(rows, cols, max_dim, out_rows, out_cols, &yr, &xr);
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 int ab_render_rgb_preview(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, int64_t max_dim, const ab_stf_params *stf,
-                          const ab_image_stats *stats, uint8_t *out_rgb, int32_t out_on_device) {
+                          const ab_image_stats *stats, uint8_t *out_rgb, int32_t out_on_device) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, r && g && b && out_rgb, "null argument");
     AB_CHECK(ctx, max_dim > 0, "max_dim must be > 0");
@@ -410,9 +410,9 @@ int ab_render_rgb_preview(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, con
     }
     release3(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_ipc_encode_with_header(ab_ctx *ctx, const ab_plane *img, int64_t max_dim, void *out, int32_t out_on_device, size_t *out_len) {
+int ab_ipc_encode_with_header(ab_ctx *ctx, const ab_plane *img, int64_t max_dim, void *out, int32_t out_on_device, size_t *out_len) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out, "null argument");
     AB_CHECK(ctx, max_dim >= 0, "max_dim must be >= 0 (0 = full resolution)");
@@ -457,15 +457,15 @@ int ab_ipc_encode_with_header(ab_ctx *ctx, const ab_plane *img, int64_t max_dim,
     ab_stage_release(ctx, &in);
     if (rc == AB_OK && out_len) *out_len = bytes;
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_tile_compute_num_levels(int64_t width, int64_t height, int64_t tile_size) {
+int ab_tile_compute_num_levels(int64_t width, int64_t height, int64_t tile_size) try {
     if (width <= 0 || height <= 0 || tile_size <= 0) return 0;
     return num_levels(width, height, tile_size);
-}
+} AB_CATCH_NOCTX
 
 int ab_tile_pyramid_layout(int64_t rows, int64_t cols, int64_t tile_size, int32_t channels, ab_tile_level *levels, int32_t *num_levels_out,
-                           size_t *total_bytes) {
+                           size_t *total_bytes) try {
     if (rows <= 0 || cols <= 0 || tile_size <= 0 || (channels != 1 && channels != 3) || !levels || !num_levels_out) return AB_ERR_INVALID;
     if (num_levels(cols, rows, tile_size) > AB_MAX_TILE_LEVELS) return AB_ERR_INVALID;
     int nl = 0;
@@ -473,9 +473,9 @@ int ab_tile_pyramid_layout(int64_t rows, int64_t cols, int64_t tile_size, int32_
     *num_levels_out = nl;
     if (total_bytes) *total_bytes = total;
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
-int ab_tile_downsample_2x(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out) {
+int ab_tile_downsample_2x(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out, "null argument");
     AB_CHECK(ctx, out->rows == (img->rows + 1) / 2 && out->cols == (img->cols + 1) / 2, "downsample_2x writes ((rows + 1) / 2) x ((cols + 1) / 2)");
@@ -495,9 +495,9 @@ int ab_tile_downsample_2x(ab_ctx *ctx, const ab_plane *img, ab_plane_mut *out) {
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_tile_percentile_bounds(ab_ctx *ctx, const ab_plane *img, double low_pct, double high_pct, float *lo, float *hi) {
+int ab_tile_percentile_bounds(ab_ctx *ctx, const ab_plane *img, double low_pct, double high_pct, float *lo, float *hi) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && lo && hi, "null argument");
     StagedPlane in;
@@ -505,10 +505,10 @@ int ab_tile_percentile_bounds(ab_ctx *ctx, const ab_plane *img, double low_pct, 
     const int rc = percentile_bounds(ctx, in.dptr, in.rows * in.cols, low_pct, high_pct, lo, hi);
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_generate_tile_pyramid(ab_ctx *ctx, const ab_plane *normalized, int64_t tile_size, uint8_t *tiles, int32_t tiles_on_device,
-                             ab_tile_level *levels, int32_t *num_levels_out, float *global_min, float *global_max) {
+                             ab_tile_level *levels, int32_t *num_levels_out, float *global_min, float *global_max) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, normalized && tiles && levels && num_levels_out, "null argument");
     AB_CHECK(ctx, tile_size > 0 && tile_size <= 4096, "tile_size must be in 1..4096");
@@ -537,11 +537,11 @@ int ab_generate_tile_pyramid(ab_ctx *ctx, const ab_plane *normalized, int64_t ti
     if (global_min) *global_min = gmin;
     if (global_max) *global_max = gmax;
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_generate_tile_pyramid_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, int64_t tile_size, const ab_stf_params *stf,
                                  const ab_image_stats *stats, uint8_t *tiles, int32_t tiles_on_device, ab_tile_level *levels,
-                                 int32_t *num_levels_out) {
+                                 int32_t *num_levels_out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, r && g && b && tiles && levels && num_levels_out, "null argument");
     AB_CHECK(ctx, tile_size > 0 && tile_size <= 4096, "tile_size must be in 1..4096");
@@ -566,6 +566,6 @@ int ab_generate_tile_pyramid_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane 
     }
     release3(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

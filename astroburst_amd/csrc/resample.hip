@@ -214,7 +214,7 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
 
 extern "C" {
 
-int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, double dx, ab_plane_mut *out) {
+int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, double dx, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, src && out, "null plane");
     AB_CHECK(ctx, src->rows == out->rows && src->cols == out->cols, "shift_image_subpixel keeps the image dims");
@@ -231,17 +231,17 @@ int ab_shift_image_subpixel(ab_ctx *ctx, const ab_plane *src, double dy, double 
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 // rows [row0, row0 + out_band->rows) of warp_image(src, transform, out_rows, out_band->cols) (device planes)
-int ab_warp_image_rows(ab_ctx *ctx, const ab_plane *src, const double transform[6], int64_t out_rows, int64_t row0, ab_plane_mut *out_band) {
+int ab_warp_image_rows(ab_ctx *ctx, const ab_plane *src, const double transform[6], int64_t out_rows, int64_t row0, ab_plane_mut *out_band) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, src && out_band && transform && src->data && out_band->data, "null plane or transform");
     AB_CHECK(ctx, src->on_device && out_band->on_device, "ab_warp_image_rows takes device-resident planes");
     return ab_warp_rows_device(ctx, src->data, src->rows, src->cols, transform, out_rows, out_band->cols, row0, out_band->rows, out_band->data);
-}
+} AB_CATCH(ctx)
 
-int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out) {
+int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, src && out && transform, "null plane or transform");
     StagedPlane in;
@@ -257,9 +257,9 @@ int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], a
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_resample_image(ab_ctx *ctx, const ab_plane *src, ab_plane_mut *out) {
+int ab_resample_image(ab_ctx *ctx, const ab_plane *src, ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, src && out, "null plane");
     if (out->rows == 0 || out->cols == 0) return ab_set_error(ctx, AB_ERR_INVALID, "Target dimensions must be > 0");  // :32-34
@@ -276,6 +276,6 @@ int ab_resample_image(ab_ctx *ctx, const ab_plane *src, ab_plane_mut *out) {
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

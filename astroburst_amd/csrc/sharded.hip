@@ -47,28 +47,28 @@ int total_rejected(ab_ctx *ctx, ab_comm *comm, uint64_t *out) {
 extern "C" {
 
 // rank r of nranks owns rows [row0, row0 + nrows): ceil(rows / nranks) rows each, the last bands shorter (possibly empty)
-int ab_shard_rows(int64_t rows, int nranks, int rank, int64_t *row0, int64_t *nrows) {
+int ab_shard_rows(int64_t rows, int nranks, int rank, int64_t *row0, int64_t *nrows) try {
     if (rows < 0 || nranks < 1 || rank < 0 || rank >= nranks || !row0 || !nrows) return AB_ERR_INVALID;
     const int64_t per = (rows + nranks - 1) / nranks;
     const int64_t lo = std::min<int64_t>(rows, per * rank), hi = std::min<int64_t>(rows, per * (rank + 1));
     *row0 = lo;
     *nrows = hi - lo;
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 // contiguous, balanced frame ranges: rank r gets frames [f0, f0 + nf)
-int ab_shard_frames(size_t n_frames, int nranks, int rank, size_t *f0, size_t *nf) {
+int ab_shard_frames(size_t n_frames, int nranks, int rank, size_t *f0, size_t *nf) try {
     if (nranks < 1 || rank < 0 || rank >= nranks || !f0 || !nf) return AB_ERR_INVALID;
     const size_t base = n_frames / (size_t)nranks, extra = n_frames % (size_t)nranks;
     *f0 = (size_t)rank * base + std::min<size_t>((size_t)rank, extra);
     *nf = base + ((size_t)rank < extra ? 1 : 0);
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 // Rows [row0, row0 + out_band->rows) of stack_images' per-pixel loop over all n frames (combine.rs:160-182): the exact
 // single-level estimator, restricted to a band.  Frames are device-resident and at least (row0 + band rows) x band cols.
 int ab_stack_sigma_clip_rows(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, int64_t row0,
-                             ab_plane_mut *out_band, uint64_t *out_rejected) {
+                             ab_plane_mut *out_band, uint64_t *out_rejected) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");
     AB_CHECK(ctx, cfg && out_band && out_band->data && out_band->on_device, "null config or output (device band expected)");
@@ -88,12 +88,12 @@ int ab_stack_sigma_clip_rows(ab_ctx *ctx, const ab_plane *planes, size_t n, cons
     }
     return ab_stack_device(ctx, dp.data(), ld.data(), n, out_band->rows, out_band->cols, cfg, out_band->data, nullptr, nullptr, out_rejected,
                            false);
-}
+} AB_CATCH(ctx)
 
 // The same with the band taken from the communicator (ab_shard_rows over the minimum frame dims, combine.rs:104-113) and
 // StackResult.rejected_pixels summed over the ranks.  out_band must hold this rank's rows x min cols.
 int ab_stack_sigma_clip_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
-                                ab_plane_mut *out_band, uint64_t *out_rejected_total) {
+                                ab_plane_mut *out_band, uint64_t *out_rejected_total) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");
     AB_CHECK(ctx, cfg && out_band, "null config or output");
@@ -109,14 +109,14 @@ int ab_stack_sigma_clip_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plane *plan
     AB_TRY(ab_stack_sigma_clip_rows(ctx, planes, n, cfg, row0, out_band, nullptr));
     if (out_rejected_total) AB_TRY(total_rejected(ctx, comm, out_rejected_total));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 // Frame-sharded two-level stack (BASELINE configs[3]): per-GPU partial over THIS rank's frames -> all-reduce of the
 // per-pixel (sum f64, count u32) over xGMI -> divide.  `out` (device, rows x cols) is the full image on every rank.
 // The partial planes live in the context (12 bytes per pixel).  Collective payload: 12 x rows x cols bytes, independent
 // of the frame count.
 int ab_stack_sigma_clip_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *local_planes, size_t n_local, const ab_stack_config *cfg,
-                                ab_plane_mut *out, uint64_t *out_rejected_total) {
+                                ab_plane_mut *out, uint64_t *out_rejected_total) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, local_planes && n_local >= 1, "every rank needs at least one frame (No images to stack)");
     AB_CHECK(ctx, cfg && out && out->data && out->on_device, "null config or output (device plane expected)");
@@ -133,11 +133,11 @@ int ab_stack_sigma_clip_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *loca
     AB_TRY(ab_stack_finalize_partial(ctx, psum, pcnt, total, out->data));
     if (out_rejected_total) AB_TRY(total_rejected(ctx, comm, out_rejected_total));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 // Assemble row bands into the full image on every rank: `full` (device, total rows x cols) receives rank r's band at
 // rows [row0_r, row0_r + nrows_r) (ab_shard_rows).  One broadcast per rank inside one RCCL group; bands may be unequal.
-int ab_allgather_rows(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, ab_plane_mut *full) {
+int ab_allgather_rows(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, ab_plane_mut *full) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, band && full && full->data && full->on_device && (band->rows == 0 || (band->data && band->on_device)), "device planes expected");
     const int size = ab_comm_size(comm), rank = ab_comm_rank(comm);
@@ -159,14 +159,14 @@ int ab_allgather_rows(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, ab_plane
     if (rc != AB_OK) return rc;
     if (rc2 != AB_OK) return ab_set_error(ctx, AB_ERR_COMM, "ncclGroupEnd failed");
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 // align_channel_affine(reference, targets[i]) for all i < n, the estimates computed by frame across the ranks (target i on
 // rank i mod size) and exchanged: every rank receives all n results.  Targets this rank does not own are not read.
 // The exchange is an all-reduce(SUM) of the results' bit patterns as u64 words over zero-initialised slots: adding zeros
 // is the identity on integers, so every f64 arrives bit for bit.
 int ab_register_frames_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
-                               ab_affine_align_result *out) {
+                               ab_affine_align_result *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, reference && targets && out, "null argument");
     const int size = ab_comm_size(comm), rank = ab_comm_rank(comm);
@@ -190,6 +190,6 @@ int ab_register_frames_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *refer
     AB_HIP(ctx, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

@@ -242,14 +242,14 @@ int check_planes(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_pla
 
 extern "C" {
 
-int ab_spcc_white_reference_rgb(int32_t kind, const double custom[3], double out[3]) {
+int ab_spcc_white_reference_rgb(int32_t kind, const double custom[3], double out[3]) try {
     if (!out || (kind == 3 && !custom) || kind < 0 || kind > 3) return AB_ERR_INVALID;
     white_reference_rgb(kind, custom, out);
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 int ab_spcc_from_detection(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, const ab_detected_star *stars,
-                           size_t n_stars, double lum_max, double pixel_scale_arcsec, const ab_spcc_config *cfg, ab_spcc_result *res) {
+                           size_t n_stars, double lum_max, double pixel_scale_arcsec, const ab_spcc_config *cfg, ab_spcc_result *res) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, cfg && res && (stars || n_stars == 0), "null argument");
     AB_TRY(check_planes(ctx, r, g, b));
@@ -258,10 +258,10 @@ int ab_spcc_from_detection(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, co
     AB_TRY(st.stage(r, g, b));
     std::vector<ab_detected_star> v(stars, stars + n_stars);
     return spcc_from_detection(ctx, st.p[0].dptr, st.p[1].dptr, st.p[2].dptr, r->rows, r->cols, v, lum_max, pixel_scale_arcsec, *cfg, res);
-}
+} AB_CATCH(ctx)
 
 int ab_spcc_calibrate_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, const ab_plane *b, double pixel_scale_arcsec,
-                          const ab_spcc_config *cfg, ab_spcc_result *res) {
+                          const ab_spcc_config *cfg, ab_spcc_result *res) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, cfg && res, "null argument");
     AB_TRY(check_planes(ctx, r, g, b));
@@ -287,6 +287,6 @@ int ab_spcc_calibrate_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, con
     (void)hipFree(lum);
     if (rc != AB_OK) return rc;
     return spcc_from_detection(ctx, st.p[0].dptr, st.p[1].dptr, st.p[2].dptr, h, w, stars, stats.max, pixel_scale_arcsec, *cfg, res);
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

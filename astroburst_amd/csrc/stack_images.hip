@@ -24,7 +24,7 @@ int32_t round_to_i32(double v) {  // `result.offset.0.round() as i32` (combine.r
 }  // namespace
 
 extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
-                               ab_plane_mut *out, int32_t *offsets_dy_dx, uint64_t *out_rejected) {
+                               ab_plane_mut *out, int32_t *offsets_dy_dx, uint64_t *out_rejected) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");  // combine.rs:98-100
     AB_CHECK(ctx, cfg && out, "null config or output");
@@ -92,4 +92,4 @@ extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, co
     for (size_t i = 0; i < staged; ++i) ab_stage_release(ctx, &st[i]);
     if (rc == AB_OK && out_rejected) *out_rejected = rejected;
     return rc;
-}
+} AB_CATCH(ctx)

@@ -999,18 +999,18 @@ static int stack_planes(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_
 }
 
 int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, ab_plane_mut *out,
-                        uint64_t *out_rejected) {
+                        uint64_t *out_rejected) try {
     return stack_planes(ctx, planes, n, cfg, out, out_rejected, false);
-}
+} AB_CATCH(ctx)
 
 // median_combine_row_major (calibration.rs:84-125): per-pixel [len/2] order statistic of the finite samples
-int ab_median_combine(ab_ctx *ctx, const ab_plane *planes, size_t n, ab_plane_mut *out) {
+int ab_median_combine(ab_ctx *ctx, const ab_plane *planes, size_t n, ab_plane_mut *out) try {
     const ab_stack_config cfg = {3.0f, 3.0f, 0, 0};
     return stack_planes(ctx, planes, n, &cfg, out, nullptr, true);
-}
+} AB_CATCH(ctx)
 
 int ab_stack_sigma_clip_partial(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg, int64_t rows,
-                                int64_t cols, double *out_sum_dev, uint32_t *out_cnt_dev, uint64_t *out_rejected) {
+                                int64_t cols, double *out_sum_dev, uint32_t *out_cnt_dev, uint64_t *out_rejected) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");
     AB_CHECK(ctx, cfg && out_sum_dev && out_cnt_dev, "null config or output");
@@ -1024,11 +1024,11 @@ int ab_stack_sigma_clip_partial(ab_ctx *ctx, const ab_plane *planes, size_t n, c
     }
     return ab_stack_device(ctx, dp.data(), ld.data(), n, rows, cols, cfg, nullptr, out_sum_dev, out_cnt_dev, out_rejected,
                            false);
-}
+} AB_CATCH(ctx)
 
 // stack_images' per-pixel loop fed straight from FITS data units (decode_pixels fused into the gather)
 int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size_t n, int64_t bitpix, double bscale, double bzero,
-                            const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected) {
+                            const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, raw_planes_dev && cfg && out && out->data, "null argument");
     AB_CHECK(ctx, out->on_device, "the fused raw stack writes a device plane");
@@ -1080,24 +1080,24 @@ int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size
     AB_HIP(ctx, hipGetLastError());
     if (out_rejected) AB_TRY(read_rejected(ctx, out_rejected));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_stack_last_kernel_ms(ab_ctx *ctx, float *out_ms) {
+int ab_stack_last_kernel_ms(ab_ctx *ctx, float *out_ms) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, out_ms, "null argument");
     AB_CHECK(ctx, ctx->stack_ev_valid, "no multi-frame stack has been launched on this context");
     AB_HIP(ctx, hipEventSynchronize(ctx->stack_ev[1]));
     AB_HIP(ctx, hipEventElapsedTime(out_ms, ctx->stack_ev[0], ctx->stack_ev[1]));
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
-int ab_stack_last_rejected(ab_ctx *ctx, uint64_t *out_rejected) {
+int ab_stack_last_rejected(ab_ctx *ctx, uint64_t *out_rejected) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, out_rejected, "null output");
     return read_rejected(ctx, out_rejected);
-}
+} AB_CATCH(ctx)
 
-int ab_stack_finalize_partial(ab_ctx *ctx, const double *sum_dev, const uint32_t *cnt_dev, int64_t n, float *out_dev) {
+int ab_stack_finalize_partial(ab_ctx *ctx, const double *sum_dev, const uint32_t *cnt_dev, int64_t n, float *out_dev) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, sum_dev && cnt_dev && out_dev && n > 0, "null buffer or empty range");
     AB_HIP(ctx, hipSetDevice(ctx->device));
@@ -1105,6 +1105,6 @@ int ab_stack_finalize_partial(ab_ctx *ctx, const double *sum_dev, const uint32_t
                        cnt_dev, n, out_dev);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

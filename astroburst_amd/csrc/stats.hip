@@ -238,14 +238,18 @@ __device__ __forceinline__ void lds_hist_flush(unsigned int *lds, unsigned long 
 // KIND = HIST_DEV   (stats.rs:119-146):   h0[bin(|v - coarse_median|)] += 1 (dense, LDS) and the 65 536 sub-bins of the
 //                                         median bin in h1 (sparse: one coarse bin's worth of pixels, global atomics)
 // KIND = HIST_MAD   (stats.rs:166-191):   count of deviations below the MAD region (per-workgroup) and the region's
-//                                         65 536 sub-bins in h0 (three coarse bins' worth of pixels: LDS)
+//                                         65 536 sub-bins in h0 (three coarse bins' worth of pixels spread over all the sub-bins:
+//                                         global atomics -- flushing 65 536 privatised counters per workgroup would issue
+//                                         20x more atomics than the pass has candidate pixels; measured 75 us that way)
 template <int KIND>
 __global__ __launch_bounds__(kHistBlock) void dense_hist_kernel(const float *__restrict__ data, int64_t n, int64_t chunk,
                                                                 const StatsDev *__restrict__ st, unsigned long long *__restrict__ h0,
                                                                 unsigned long long *__restrict__ h1, ScanPartial *__restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // 32 768 words = 65 536 x u16
-    for (int i = threadIdx.x; i < kHistBins / 2; i += kHistBlock) lds[i] = 0;
-    __syncthreads();
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // 32 768 words = 65 536 x u16 (none for HIST_MAD)
+    if (KIND != HIST_MAD) {
+        for (int i = threadIdx.x; i < kHistBins / 2; i += kHistBlock) lds[i] = 0;
+        __syncthreads();
+    }
 
     const uint32_t last = kHistBins - 1;
     double sum = 0.0;
@@ -281,11 +285,11 @@ __global__ __launch_bounds__(kHistBlock) void dense_hist_kernel(const float *__r
                     if (dev < mad_lo)
                         cnt += 1;
                     else if (dev < mad_hi)
-                        lds_hist_add(lds, bin_index(((double)dev - mad_region_lo) * mad_inv, last));
+                        atomicAdd(&h0[bin_index(((double)dev - mad_region_lo) * mad_inv, last)], 1ull);
                 }
             }
         });
-        lds_hist_flush(lds, h0);
+        if (KIND != HIST_MAD) lds_hist_flush(lds, h0);
     }
     if (KIND != HIST_DEV) block_reduce_scan(0.0, 0.0, sum, cnt, &partials[blockIdx.x]);
 }
@@ -318,12 +322,27 @@ struct RankHit {
 __device__ __forceinline__ RankHit block_find_rank(const unsigned long long *hist, unsigned long long target) {
     __shared__ unsigned long long s_part[kBookBlock];
     __shared__ RankHit s_hit;
+    __shared__ int s_owner;
     constexpr int PER = kHistBins / kBookBlock;  // 64 consecutive bins per thread
     const int t = threadIdx.x;
+    // 32 independent 16-byte loads per thread (the histogram is L2-resident: 512 KiB)
+    const ulonglong2 *h2 = reinterpret_cast<const ulonglong2 *>(hist + (size_t)t * PER);
+    const bool vec_ok = (((uintptr_t)hist) & 15) == 0;
     unsigned long long local = 0;
-    for (int j = 0; j < PER; ++j) local += hist[t * PER + j];
+    if (vec_ok) {
+#pragma unroll 8
+        for (int j = 0; j < PER / 2; ++j) {
+            const ulonglong2 v = h2[j];
+            local += v.x + v.y;
+        }
+    } else {
+        for (int j = 0; j < PER; ++j) local += hist[t * PER + j];
+    }
     s_part[t] = local;
-    if (t == 0) s_hit.found = 0;
+    if (t == 0) {
+        s_hit.found = 0;
+        s_owner = -1;
+    }
     __syncthreads();
     // inclusive scan of 1024 partials (Hillis-Steele in LDS)
     for (int off = 1; off < kBookBlock; off <<= 1) {
@@ -333,18 +352,24 @@ __device__ __forceinline__ RankHit block_find_rank(const unsigned long long *his
         __syncthreads();
     }
     const unsigned long long incl = s_part[t], excl = incl - local;
-    if (excl < target && incl >= target) {  // the crossing lies in this thread's 64 bins (exactly one thread, target >= 1)
-        unsigned long long cum = excl;
-        for (int j = 0; j < PER; ++j) {
-            const unsigned long long c = hist[t * PER + j];
-            cum += c;
-            if (cum >= target) {
-                s_hit.found = 1;
-                s_hit.bin = (uint32_t)(t * PER + j);
-                s_hit.count = c;
-                s_hit.cum = cum;
-                break;
-            }
+    if (excl < target && incl >= target) s_owner = t;  // the crossing lies in this thread's 64 bins (exactly one thread, target >= 1)
+    __syncthreads();
+    const int owner = s_owner;
+    if (owner >= 0 && t < 64) {  // wave 0 resolves the owner's 64 bins: one bin per lane, wave prefix sum, first lane at or past the target
+        const unsigned long long c = hist[(size_t)owner * PER + t];
+        unsigned long long cum = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(cum, off, 64);
+            if (t >= off) cum += up;
+        }
+        cum += s_part[owner] - __shfl(cum, 63, 64);  // + the exclusive prefix of the owner's range
+        const unsigned long long m = __ballot(cum >= target);
+        if (m && t == (int)__builtin_ctzll(m)) {
+            s_hit.found = 1;
+            s_hit.bin = (uint32_t)(owner * PER + t);
+            s_hit.count = c;
+            s_hit.cum = cum;
         }
     }
     __syncthreads();
@@ -632,7 +657,12 @@ int launch_dense(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int *gr
     int grid;
     int64_t chunk;
     hist_launch_shape(ctx, n, &grid, &chunk);
-    const size_t lds_bytes = kHistBins * sizeof(unsigned short);
+    const size_t lds_bytes = KIND == HIST_MAD ? 0 : kHistBins * sizeof(unsigned short);
+    if (KIND == HIST_MAD) {  // no privatised histogram: nothing limits residency, so smaller chunks and four workgroups per CU
+        grid = std::min<int>(4 * grid, kMaxPartials);
+        int64_t nchunks = ((n + kHistChunkMax - 1) / kHistChunkMax + grid - 1) / grid * grid;
+        chunk = std::max<int64_t>((((n + nchunks - 1) / nchunks) + 7) & ~(int64_t)7, 8);
+    }
     AB_HIP(ctx, hipFuncSetAttribute((const void *)dense_hist_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(dense_hist_kernel<KIND>, dim3(grid), dim3(kHistBlock), lds_bytes, ctx->stream, data, n, chunk, w.st, w.H + 1,
                        w.H + 1 + kHistBins, w.partials);
@@ -757,7 +787,7 @@ int ab_stats_device(ab_ctx *ctx, const float *data, int64_t n, int use_known, do
 
 extern "C" {
 
-int ab_compute_image_stats(ab_ctx *ctx, const ab_plane *img, ab_image_stats *out) {
+int ab_compute_image_stats(ab_ctx *ctx, const ab_plane *img, ab_image_stats *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out, "null plane or output");
     StagedPlane in;
@@ -765,10 +795,10 @@ int ab_compute_image_stats(ab_ctx *ctx, const ab_plane *img, ab_image_stats *out
     const int rc = ab_stats_device(ctx, in.dptr, in.rows * in.cols, 0, 0.0, 0.0, out);
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_compute_image_stats_with_known_range(ab_ctx *ctx, const ab_plane *img, double known_min, double known_max,
-                                            ab_image_stats *out) {
+                                            ab_image_stats *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out, "null plane or output");
     StagedPlane in;
@@ -776,11 +806,11 @@ int ab_compute_image_stats_with_known_range(ab_ctx *ctx, const ab_plane *img, do
     const int rc = ab_stats_device(ctx, in.dptr, in.rows * in.cols, 1, known_min, known_max, out);
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 // compute_image_stats of an image whose rows are spread over the ranks of `comm`: `band` is this rank's
 // rows, total_rows the whole image's.  Every rank receives the statistics of the WHOLE image.
-int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, int64_t total_rows, ab_image_stats *out) {
+int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, int64_t total_rows, ab_image_stats *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, band && out && band->on_device, "sharded statistics take a device-resident row band");
     AB_CHECK(ctx, total_rows >= band->rows && band->cols > 0, "total_rows (%lld) is smaller than the band (%lld rows)", (long long)total_rows,
@@ -788,7 +818,7 @@ int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *b
     const ab_image_stats *res = nullptr;
     AB_TRY(ab_stats_enqueue(ctx, comm, band->data, band->rows * band->cols, total_rows * band->cols, 0, 0.0, 0.0, nullptr, &res, nullptr, nullptr));
     return fetch_result(ctx, res, out, nullptr);
-}
+} AB_CATCH(ctx)
 
 // auto_stretch_preview (cmd/common.rs:18-22): compute_image_stats -> auto_stf(default config) -> apply_stf, as one
 // asynchronous chain: the STF kernel reads its transform from the state block the statistics chain leaves in HBM.
@@ -796,7 +826,7 @@ int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *b
 // pass both NULL to keep the call fully asynchronous).  With a communicator `img` is this rank's row band of an image of
 // total_rows rows and the statistics are those of the whole image (each rank stretches its own band).
 int ab_auto_stretch_preview(ab_ctx *ctx, ab_comm *comm, const ab_plane *img, int64_t total_rows, const ab_auto_stf_config *cfg,
-                            uint8_t *out_u8_dev, ab_image_stats *out_stats, ab_stf_params *out_stf) {
+                            uint8_t *out_u8_dev, ab_image_stats *out_stats, ab_stf_params *out_stf) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && img->data && img->on_device && out_u8_dev, "auto_stretch_preview takes a device plane and a device output");
     AB_CHECK(ctx, img->rows > 0 && img->cols > 0, "plane has a zero dimension");
@@ -808,10 +838,10 @@ int ab_auto_stretch_preview(ab_ctx *ctx, ab_comm *comm, const ab_plane *img, int
     AB_TRY(ab_stf_u8_device_tx(ctx, img->data, img->rows * img->cols, tx, out_u8_dev));
     if (out_stats || out_stf) return fetch_result(ctx, res, out_stats, out_stf);
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 int ab_stats_value_hist(ab_ctx *ctx, const ab_plane *img, double gmin, double gmax, uint64_t *hist65536_host,
-                        double *out_sum, uint64_t *out_cnt) {
+                        double *out_sum, uint64_t *out_cnt) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && hist65536_host, "null plane or output");
     AB_HIP(ctx, hipSetDevice(ctx->device));
@@ -841,9 +871,9 @@ int ab_stats_value_hist(ab_ctx *ctx, const ab_plane *img, double gmin, double gm
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_build_histogram(ab_ctx *ctx, const ab_plane *img, size_t bins, double dmin, double dmax, uint32_t *out_bins_host) {
+int ab_build_histogram(ab_ctx *ctx, const ab_plane *img, size_t bins, double dmin, double dmax, uint32_t *out_bins_host) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && out_bins_host && bins >= 1, "null plane/output or zero bins");
     memset(out_bins_host, 0, bins * sizeof(uint32_t));
@@ -870,6 +900,6 @@ int ab_build_histogram(ab_ctx *ctx, const ab_plane *img, size_t bins, double dmi
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

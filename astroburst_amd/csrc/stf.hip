@@ -121,14 +121,14 @@ int ab_stf_f32_device(ab_ctx *ctx, const float *in, int64_t n, const ab_stf_para
 extern "C" {
 
 // stf.rs:13-39 (host scalar maths)
-int ab_auto_stf(const ab_image_stats *stats, const ab_auto_stf_config *cfg, ab_stf_params *out) {
+int ab_auto_stf(const ab_image_stats *stats, const ab_auto_stf_config *cfg, ab_stf_params *out) try {
     if (!stats || !cfg || !out) return AB_ERR_INVALID;
     ab_auto_stf_hd(stats, cfg, out);
     return AB_OK;
-}
+} AB_CATCH_NOCTX
 
 int ab_apply_stf_u8(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st, uint8_t *out,
-                    int32_t out_on_device) {
+                    int32_t out_on_device) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && p && st && out, "null argument");
     StagedPlane in;
@@ -154,10 +154,10 @@ int ab_apply_stf_u8(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, co
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
 int ab_apply_stf_f32(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, const ab_image_stats *st,
-                     ab_plane_mut *out) {
+                     ab_plane_mut *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, img && p && st && out, "null argument");
     AB_CHECK(ctx, img->rows == out->rows && img->cols == out->cols, "apply_stf_f32 keeps the image dims");
@@ -174,9 +174,9 @@ int ab_apply_stf_f32(ab_ctx *ctx, const ab_plane *img, const ab_stf_params *p, c
     }
     ab_stage_release(ctx, &in);
     return rc;
-}
+} AB_CATCH(ctx)
 
-int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats) {
+int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_floats) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, src_dev && dst_dev && (n_floats % 4) == 0, "copy needs 16-byte multiples");
     AB_HIP(ctx, hipSetDevice(ctx->device));
@@ -185,6 +185,6 @@ int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_fl
                        (float4 *)dst_dev, n4);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
-}
+} AB_CATCH(ctx)
 
 }  // extern "C"

@@ -67,7 +67,7 @@ void ab_subframe_weight_config_default(ab_subframe_weight_config *c) {  // subfr
     *c = ab_subframe_weight_config{1.0, 0.5, 1.0, 0.3, 8.0, 0.7, 5.0, 5};
 }
 
-int ab_analyze_subframes(ab_ctx *ctx, const ab_plane *images, size_t n, const ab_subframe_weight_config *config, ab_subframe_metrics *out) {
+int ab_analyze_subframes(ab_ctx *ctx, const ab_plane *images, size_t n, const ab_subframe_weight_config *config, ab_subframe_metrics *out) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, (images && out) || n == 0, "null argument");
     ab_subframe_weight_config c;
@@ -77,11 +77,11 @@ int ab_analyze_subframes(ab_ctx *ctx, const ab_plane *images, size_t n, const ab
         AB_CHECK(ctx, images[i].data && images[i].rows > 0 && images[i].cols > 0, "subframe %zu is null or has a zero dimension", i);
     AB_HIP(ctx, hipSetDevice(ctx->device));
     return ab_parallel_frames(ctx, n, "subframe", [&](ab_ctx *wc, size_t f) { return analyze_one(wc, &images[f], c, &out[f]); });
-}
+} AB_CATCH(ctx)
 
-int ab_analyze_subframe(ab_ctx *ctx, const ab_plane *image, const ab_subframe_weight_config *config, ab_subframe_metrics *out) {
+int ab_analyze_subframe(ab_ctx *ctx, const ab_plane *image, const ab_subframe_weight_config *config, ab_subframe_metrics *out) try {
     return ab_analyze_subframes(ctx, image, 1, config, out);
-}
+} AB_CATCH(ctx)
 
 void ab_normalize_subframe_weights(ab_subframe_metrics *metrics, size_t n) {  // subframe.rs:148-159
     if (!metrics) return;

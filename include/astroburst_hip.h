@@ -172,6 +172,11 @@ typedef struct { /* DetectedStar, star_detection.rs:10-20 */
  * [len/2] element of the sorted tile medians and sigmas; (0, 1) if no tile has 8 valid pixels */
 AB_API int ab_estimate_background(ab_ctx *ctx, const ab_plane *img, int64_t tile_size, double *out_median,
                                   double *out_sigma);
+/* the tile map behind estimate_background (star_detection.rs:36-68): tiles in row-major order, step = max(tile_size, 16);
+ * per tile sigma_clipped_stats(valid pixels, 3.0, 2) = (median, sigma) and valid = the tile had >= 8 valid pixels.
+ * Writes at most cap tiles; *out_tiles = tile count, *out_tiles_x = tiles per row. */
+AB_API int ab_background_tile_stats(ab_ctx *ctx, const ab_plane *img, int64_t tile_size, double *out_median, double *out_sigma,
+                                    int32_t *out_valid, size_t cap, size_t *out_tiles, size_t *out_tiles_x);
 /* detect_stars(image, sigma) (star_detection.rs:86-258): threshold at median + sigma * bg_sigma,
  * 8-connected components seeded from interior pixels, 3 <= npix <= 5000, flux-weighted moments,
  * FWHM in [0.5, 30], sorted by flux (descending), deduplicated within 3 px.  Writes at most cap

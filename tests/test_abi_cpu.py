@@ -74,3 +74,83 @@ def test_oracle_order_modes_agree(oracle):
     assert ra == rb
     np.testing.assert_allclose(a, b, rtol=1e-6, atol=0)
     assert (a != b).mean() < 1e-3
+
+
+# ---- boundary hardening (round 2) -----------------------------------------------------------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tool(name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_rust_sys_bindings_are_complete_and_current():
+    """bindings/sys.rs (generated from the header) declares every exported symbol exactly once and is not stale"""
+    import re
+    from astroburst_amd import _lib
+    gen = _tool("gen_rust_sys")
+    text, structs, funcs = gen.generate()
+    assert open(os.path.join(ROOT, "bindings", "sys.rs")).read() == text, "run python tools/gen_rust_sys.py"
+    declared = re.findall(r"pub fn (ab_\w+)\(", text)
+    assert sorted(declared) == sorted(_lib.declared_symbols()) and len(set(declared)) == len(declared)
+    assert len(structs) >= 29
+
+
+def test_rust_repr_c_layout_equals_the_c_header(tmp_path):
+    """every header struct: sizeof / alignof / each field's offset under #[repr(C)] rules (computed from the generated Rust
+    types) == what gcc reports for include/astroburst_hip.h"""
+    import subprocess
+    gen = _tool("gen_rust_sys")
+    structs, enums, funcs, defines, cb = gen.parse(open(gen.HEADER).read())
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "astroburst_hip.h"', 'int main(void) {']
+    for name, fields in structs.items():
+        lines.append(f'    printf("{name} %zu %zu", sizeof({name}), _Alignof({name}));')
+        for fname, _, _, _ in fields:
+            lines.append(f'    printf(" %zu", offsetof({name}, {fname}));')
+        lines.append('    printf("\\n");')
+    lines.append('    return 0;\n}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert len(out) == len(structs)
+    for line in out:
+        toks = line.split()
+        name, nums = toks[0], [int(t) for t in toks[1:]]
+        size, align, lay = gen.layout(structs, name)
+        assert (size, align) == (nums[0], nums[1]), name
+        assert [off for _, off, _ in lay] == nums[2:], name
+
+
+def test_every_status_returning_entry_point_has_the_exception_barrier():
+    """no C++ exception may unwind through extern "C" (the host is built panic = "abort"): each int-returning entry point is
+    a function-try-block ending in AB_CATCH / AB_CATCH_NOCTX (tools/add_exception_barrier.py)"""
+    import glob
+    import re
+    from astroburst_amd import _lib
+    barrier = _tool("add_exception_barrier")
+    src = "".join(open(p).read() for p in sorted(glob.glob(os.path.join(ROOT, "astroburst_amd", "csrc", "*.hip"))))
+    wrapped = set(re.findall(r'^(?:extern "C" )?(?:int|uint64_t)\s+(ab_[a-z0-9_]+)\s*\([^;{}]*?\)\s*try\s*\{', src, re.M))
+    expected = set(_lib.declared_symbols()) - barrier.SKIP
+    assert expected - wrapped == set(), sorted(expected - wrapped)
+    assert src.count("AB_CATCH(ctx)") + src.count("AB_CATCH_NOCTX") >= len(expected)
+
+
+def test_allocation_failure_is_a_status_code_not_an_abort():
+    """ab_affine_from_stars is host-only: an absurd star count makes std::vector throw (length_error / bad_alloc) before any
+    input is read; the barrier turns it into AB_ERR_INVALID / AB_ERR_NOMEM and the process lives on"""
+    from astroburst_amd import _lib
+    L = _lib.lib()
+    xy = (ctypes.c_double * 8)(*range(8))
+    res, found = _lib.AffineAlignResultC(), ctypes.c_int(0)
+    rc = L.ab_affine_from_stars(xy, ctypes.c_size_t(1 << 61), xy, 4, 100, 100, 8, ctypes.byref(res), ctypes.byref(found))
+    assert rc == _lib.AB_ERR_INVALID          # std::length_error
+    rc = L.ab_affine_from_stars(xy, ctypes.c_size_t(1 << 44), xy, 4, 100, 100, 8, ctypes.byref(res), ctypes.byref(found))
+    assert rc == _lib.AB_ERR_NOMEM            # std::bad_alloc: 2^48 bytes exceed the address space
+    rc = L.ab_affine_from_stars(xy, 4, xy, 4, 100, 100, 8, ctypes.byref(res), ctypes.byref(found))
+    assert rc == _lib.AB_OK                   # and the library still works

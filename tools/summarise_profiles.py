@@ -52,6 +52,13 @@ def main(tag, outdir=None, frames=64, pixels=4096 * 4096):
            "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
            "algorithmic_bytes": 4 * frames * pixels + 4 * pixels}
     out["traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / out["algorithmic_bytes"], 4)
+    # ties the counters to the kernel source they were taken from: bench.py reports `traffic` only while this still matches
+    import hashlib
+    h = hashlib.sha256()
+    for fn in ("stack_sigma_clip.hip", "sortnet_gen.hpp"):
+        with open(os.path.join(ROOT, "astroburst_amd", "csrc", fn), "rb") as fh:
+            h.update(fh.read())
+    out["kernel_source_sha256"] = h.hexdigest()
     with open(os.path.join(pdir, "stack_pmc.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
