@@ -167,25 +167,26 @@ __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(co
     __shared__ tb::Shared sh;
     const int ty0 = (blockIdx.x / ntx) * step, tx0 = (blockIdx.x % ntx) * step;
     const int y1 = min(ty0 + step, rows), x1 = min(tx0 + step, cols);
-    // thread (tx, ty) of the 256 x 4 layout walks column tx0 + tx downwards, four rows per slot: consecutive lanes read
-    // consecutive pixels; all 64 loads are issued before the first key is formed
+    // thread (tx, ty) of the 256 x 2 layout walks column tx0 + tx downwards, two rows per slot: consecutive lanes read
+    // consecutive pixels; 32 loads are in flight before the first key is formed
+    constexpr int kRowPhases = tb::kThreads / 256;
     const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
     const int c = tx0 + tx;
     const bool col_ok = c < x1;
     tb::Keys K;
-    // two batches of 32 loads in flight (64 raw values + 64 keys live at once would spill at the 128-VGPR budget of 1024 threads)
+    constexpr int kBatch = 32;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        float raw[tb::kSlots / 2];
+    for (int h = 0; h < tb::kSlots / kBatch; ++h) {
+        float raw[kBatch];
 #pragma unroll
-        for (int i = 0; i < tb::kSlots / 2; ++i) {
-            const int r = ty0 + ty + 4 * (h * (tb::kSlots / 2) + i);
+        for (int i = 0; i < kBatch; ++i) {
+            const int r = ty0 + ty + kRowPhases * (h * kBatch + i);
             raw[i] = (col_ok && r < y1) ? img[(int64_t)r * ld + c] : __builtin_nanf("");
         }
 #pragma unroll
-        for (int i = 0; i < tb::kSlots / 2; ++i) {
+        for (int i = 0; i < kBatch; ++i) {
             const float v = ab_px(xf, raw[i]);
-            K.k[h * (tb::kSlots / 2) + i] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
+            K.k[h * kBatch + i] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
         }
     }
     const tb::TileResult r = tb::tile_stats(K, sh);

@@ -7,24 +7,28 @@
 // instructions and one LDS atomic per pixel and sweep; 180 us per 4096^2 frame, 36 % of a frame's registration time).
 // Here the tile is histogrammed ONCE and everything else is answered from that histogram plus cheap register sweeps:
 //
-//   * the 64 pixels of a thread stay in VGPRs as monotone u32 keys (valid pixels are positive finite floats, so the
+//   * the 128 pixels of a thread stay in VGPRs as monotone u32 keys (valid pixels are positive finite floats, so the
 //     IEEE bit pattern is the key; 0 = not a candidate);
-//   * one sweep with LDS atomics builds a 4096-bucket histogram of the keys over [min key, max key] (bucket =
-//     (key - base) >> shift, shift chosen so that the span fits), turned into an inclusive prefix sum;
+//   * one sweep with LDS atomics builds a 4096-bucket histogram of the keys, turned into an inclusive prefix sum.  The
+//     buckets are uniform in key space over a ZOOM window [mean - 6 d, mean + 6 d] of a 512-pixel sample (d = its mean
+//     absolute deviation) -- a few dozen pixels per bucket around the median -- with one catch-all bucket on each side for
+//     the tails (star pixels, the clamped 0s and 1s of a normalised frame);
 //   * the clipping windows of sigma_clipped_stats only ever cut tails, so "elements of the current window below bucket
 //     b" is a closed form of that one prefix sum (clamped between the counts below the window's ends) -- the histogram
 //     is never rebuilt;
-//   * an order statistic of the VALUES: the prefix sum names its bucket, a register sweep (two compares per pixel, no
-//     atomics except for the few matches) gathers that bucket's keys into an LDS list, one wave selects in the list;
+//   * an order statistic of the VALUES: the prefix sum names its bucket, a register sweep (one compare per pixel, no
+//     atomics: every wave appends to its own segment of an LDS list) gathers that bucket's keys, one wave selects in the list;
 //   * an order statistic of the DEVIATIONS |v - median| (the MAD): the deviations of a bucket's pixels lie between the
-//     deviations of its two boundary keys, so every bucket boundary yields a lower and an upper bound on the count of
-//     deviations below it; the tightest pair brackets the wanted deviation between two boundaries, only the pixels of
-//     the buckets straddling that bracket -- a few hundred -- are gathered (as deviation keys) and selected from;
-//   * a list that would overflow (heavy ties: a flat tile is one bucket of 65 536 equal keys) falls back to bisection
-//     on the key with counting sweeps; exact as well, just slower.
+//     deviations of its two boundary keys, so a threshold at a bucket boundary yields a lower and an upper bound on the
+//     count of deviations below it from the prefix sum alone; a two-round search over the boundaries brackets the wanted
+//     deviation between two of them, and only the pixels of the buckets straddling that bracket -- a few dozen -- are
+//     gathered (as deviation keys) and selected from;
+//   * a list that would overflow (heavy ties: a flat tile is one bucket of 65 536 equal keys; a rank inside a catch-all
+//     bucket) falls back to bisection on the key with counting sweeps; exact as well, just slower.
 //
 // Everything is integer comparison on keys plus the reference's own f64 / f32 arithmetic for the deviation
-// (`(v as f64 - median).abs() as f32`), so tile medians and sigmas are bit-identical to the oracle's.
+// (`(v as f64 - median).abs() as f32`), so tile medians and sigmas are bit-identical to the oracle's
+// (tests/test_gpu_tile_stats.py compares every tile of adversarial images).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -34,32 +38,51 @@
 
 namespace tb {
 
-constexpr int kThreads = 1024;  // one workgroup per tile
-constexpr int kSlots = 64;      // pixels per thread: 256 x 256 / 1024
+// 512 threads x 128 pixels, not 1024 x 64: with four waves per SIMD the register budget is 128 VGPRs, and 64 resident keys
+// plus the working set of the sweeps spilled ~90 registers -- every spilled key cost a serialised scratch round trip per sweep
+// (measured: 330 us per frame, slower than round 1).  Two waves per SIMD have 256 VGPRs; the sweeps are ALU work, not latency.
+constexpr int kThreads = 512;  // one workgroup per tile
+constexpr int kWaves = kThreads / 64;
+constexpr int kSlots = 128;    // pixels per thread: 256 x 256 / 512
 constexpr int kBuckets = 4096;
-constexpr int kListCap = 6144;  // gathered candidates (u32 keys)
+constexpr int kSeg = 256;                // gathered candidates a wave may append (its private segment of the list)
+constexpr int kListCap = kSeg * kWaves;  // 2048 u32 keys
 
 struct Shared {
     unsigned int prefix[kBuckets];  // bucket counts, then their inclusive prefix sum
-    unsigned int list[kListCap];
-    unsigned int wave_part[16 * 4];  // per-wave partials of the block reductions
-    unsigned int hist[256];          // wave 0's radix-select histogram
-    unsigned int scal[16];           // broadcast slots
+    unsigned int list[kListCap];    // per-wave segments while gathering
+    unsigned int tmp[kListCap];     // the segments compacted to the front (what the select reads) / scan scratch
+    unsigned int wave_part[kWaves * 4];  // per-wave partials of the block reductions
+    unsigned int seg_n[kWaves];
+    unsigned int hist[256];  // wave 0's radix-select histogram
+    unsigned int scal[16];   // broadcast slots
+    long long t_phase[8];    // AB_TILE_TIMING: cycles per phase (thread 0): 0 setup + histogram + scan + window counts; value select:
+                             // 1 bucket search 2 gather 3 select; deviation select: 4 round 1 5 round 2 + bounds 6 gather 7 select
+    long long t_mark;
 };
+
+#ifdef AB_TILE_TIMING
+#define TB_MARK(sh, i)                             \
+    do {                                           \
+        if (threadIdx.x == 0) {                    \
+            const long long now_ = clock64();      \
+            (sh).t_phase[i] += now_ - (sh).t_mark; \
+            (sh).t_mark = now_;                    \
+        }                                          \
+    } while (0)
+#else
+#define TB_MARK(sh, i) \
+    do {               \
+    } while (0)
+#endif
 
 struct Keys {
     uint32_t k[kSlots];  // 0 = not a candidate
 };
 
-struct Frame {  // histogram geometry
-    uint32_t base;   // key of bucket 0's first element
-    int shift;       // bucket = (key - base) >> shift
-    unsigned int total;  // valid pixels
-};
-
 // An opaque copy of a key (at most one v_mov): what a sweep computes from it cannot be hoisted out of the enclosing loops and
-// kept alive across the other sweeps (64 SGPR-pair masks per hoisted predicate, spilled lane by lane), and -- unlike marking
-// the key array itself as rewritten -- the 64 keys stay loop-invariant values (no 64-wide PHIs at every loop header).
+// kept alive across the other sweeps (SGPR-pair masks per hoisted predicate, spilled lane by lane), and -- unlike marking
+// the key array itself as rewritten -- the keys stay loop-invariant values (no 128-wide PHIs at every loop header).
 __device__ __forceinline__ uint32_t fresh(uint32_t k) {
     uint32_t o;
     asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(k));
@@ -79,6 +102,26 @@ __device__ __forceinline__ unsigned int wave_min(unsigned int x) {
 __device__ __forceinline__ unsigned int wave_max(unsigned int x) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) x = max(x, (unsigned int)__shfl_xor(x, off, 64));
+    return x;
+}
+
+// inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8, row_bcast 15/31: the gfx9 scan idiom) -- six VALU
+// instructions instead of six ds_bpermute round trips
+__device__ __forceinline__ unsigned int wave_scan_incl(unsigned int x) {
+    const int lane = threadIdx.x & 63;
+    unsigned int t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    if ((lane & 15) >= 1) x += t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    if ((lane & 15) >= 2) x += t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    if ((lane & 15) >= 4) x += t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    if ((lane & 15) >= 8) x += t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xf, 0xf, false);
+    if ((lane & 31) >= 16) x += t;
+    t = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xf, 0xf, false);
+    if (lane >= 32) x += t;
     return x;
 }
 
@@ -103,7 +146,7 @@ __device__ __forceinline__ void block_reduce4(Shared &sh, unsigned int &a, unsig
     __syncthreads();
     unsigned int ra = sh.wave_part[0], rb = sh.wave_part[1], rc = sh.wave_part[2], rd = sh.wave_part[3];
 #pragma unroll
-    for (int i = 1; i < kThreads / 64; ++i) {
+    for (int i = 1; i < kWaves; ++i) {
         ra = comb(ra, sh.wave_part[4 * i + 0], OP0);
         rb = comb(rb, sh.wave_part[4 * i + 1], OP1);
         rc = comb(rc, sh.wave_part[4 * i + 2], OP2);
@@ -115,19 +158,69 @@ __device__ __forceinline__ void block_reduce4(Shared &sh, unsigned int &a, unsig
     d = rd;
 }
 
+// two f32 sums over the workgroup (fixed shape: the result only steers where the histogram zooms, never a statistic)
+__device__ __forceinline__ void block_sum2f(Shared &sh, float &a, float &b) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sh.wave_part[2 * w] = __float_as_uint(a);
+        sh.wave_part[2 * w + 1] = __float_as_uint(b);
+    }
+    __syncthreads();
+    float ra = 0.0f, rb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) {
+        ra += __uint_as_float(sh.wave_part[2 * i]);
+        rb += __uint_as_float(sh.wave_part[2 * i + 1]);
+    }
+    a = ra;
+    b = rb;
+}
+
 // (v as f64 - median).abs() as f32, as a monotone key (sigma_clip.rs:15,31)
 __device__ __forceinline__ uint32_t dev_key(uint32_t key, double median) {
     return __float_as_uint((float)fabs((double)__uint_as_float(key) - median));
 }
 
+// ---- histogram geometry: catch-all bucket 0 | nc uniform buckets over [zlo, zhi] | catch-all bucket nb - 1 -----------------------------
+struct Frame {
+    uint32_t kmin, kmax;  // extreme candidate keys
+    uint32_t zlo, zhi;    // zoom window (kmin <= zlo <= zhi <= kmax)
+    int shift;            // central bucket = 1 + ((key - zlo) >> shift)
+    int nb;               // buckets in use (nc + 2)
+    __device__ __forceinline__ int bucket_of(uint32_t key) const {
+        if (key < zlo) return 0;
+        if (key > zhi) return nb - 1;
+        return 1 + (int)((key - zlo) >> shift);
+    }
+    __device__ __forceinline__ uint32_t first_key(int b) const {  // smallest key that maps to bucket b (b < nb)
+        if (b <= 0) return kmin;
+        if (b >= nb - 1) return zhi + 1u;  // zhi <= kmax <= 0x7f7fffff: no wrap
+        return zlo + ((uint32_t)(b - 1) << shift);
+    }
+    __device__ __forceinline__ uint32_t last_key(int b) const {  // largest key that maps to bucket b
+        if (b <= 0) return zlo - 1u;  // zlo >= kmin >= 1
+        if (b >= nb - 1) return kmax > zhi ? kmax : zhi + 1u;
+        const uint64_t k = (uint64_t)zlo + ((uint64_t)b << shift) - 1u;
+        return k > (uint64_t)zhi ? zhi : (uint32_t)k;
+    }
+};
+
 // count of candidates with key < a and with key <= b (one register sweep, no atomics)
 __device__ __forceinline__ void count_below(const Keys &K, Shared &sh, uint32_t a, uint32_t b, unsigned int *lt_a, unsigned int *le_b) {
     unsigned int ca = 0, cb = 0;
+    // k != 0 && k < a  <=>  k - 1 < a - 1 (unsigned, a >= 1; the non-candidate 0 wraps to the top); k != 0 && k <= b  <=>  k - 1 < b
+    const uint32_t a1 = a ? a - 1u : 0u;
 #pragma unroll
     for (int i = 0; i < kSlots; ++i) {
-        const uint32_t k = fresh(K.k[i]);
-        ca += (k != 0 && k < a) ? 1u : 0u;
-        cb += (k != 0 && k <= b) ? 1u : 0u;
+        const uint32_t k1 = fresh(K.k[i]) - 1u;
+        ca += (k1 < a1) ? 1u : 0u;
+        cb += (k1 < b) ? 1u : 0u;
     }
     unsigned int z0 = 0, z1 = 0;
     block_reduce4<OP_SUM, OP_SUM, OP_SUM, OP_SUM>(sh, ca, cb, z0, z1);
@@ -148,31 +241,95 @@ __device__ __forceinline__ unsigned int count_dev_le(const Keys &K, Shared &sh, 
     return c;
 }
 
-// append this lane's value to the LDS list (wave-aggregated: one atomic per wave); entries past the capacity are dropped,
-// the counter keeps counting
-__device__ __forceinline__ void list_push(Shared &sh, bool take, uint32_t v) {
-    const unsigned long long m = __ballot(take);
-    if (m) {
-        const int lane = threadIdx.x & 63, leader = (int)__builtin_ctzll(m);
-        unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(&sh.scal[0], (unsigned int)__builtin_popcountll(m));
-        base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-        const unsigned int at = base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-        if (take && at < (unsigned int)kListCap) sh.list[at] = v;
-    }
+// Gather: every wave appends to ITS segment of the list, the running count lives in a scalar register -- no atomics, nothing to
+// wait for.  `wcount` is wave-uniform; entries past the segment are dropped while the count keeps counting (overflow is detected
+// by the caller).
+__device__ __forceinline__ void seg_push(Shared &sh, unsigned int &wcount, unsigned long long m, bool take, uint32_t v) {
+    const unsigned int at = wcount + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+    if (take && at < (unsigned int)kSeg) sh.list[(threadIdx.x >> 6) * kSeg + at] = v;
+    wcount += (unsigned int)__builtin_popcountll(m);
 }
 
-// wave 0: the rank-th smallest (0-based) of sh.list[0 .. n) by an 8-bit radix select (4 digits), n <= kListCap.
-// Returns the key in every lane of wave 0; other waves must not call.
-__device__ __forceinline__ uint32_t wave_select(Shared &sh, unsigned int n, unsigned int rank) {
+struct GatherArgs {
+    uint32_t lo, hi;                      // outer key range (lo <= hi, lo >= 1)
+    uint32_t x1_lo, x1_hi, x2_lo, x2_hi;  // excluded runs (empty: lo > hi)
+    double median;
+};
+// one gather sweep over the thread's keys: appends every key in [lo, hi] outside the excluded runs -- as the key (DEV = false) or
+// as its deviation key.  Eight slots share one branch: a slot costs one subtract-compare, a group one scalar test; only the rare
+// group that holds a match goes through the excluded runs, forms deviations and appends.
+template <bool DEV>
+__device__ __forceinline__ unsigned int gather_sweep(const Keys &K, Shared &sh, const GatherArgs &g) {
+    unsigned int wcount = 0;
+    const uint32_t width = g.hi - g.lo;
+#pragma unroll
+    for (int grp = 0; grp < kSlots / 8; ++grp) {
+        uint32_t k[8];
+        unsigned long long any = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            k[u] = fresh(K.k[8 * grp + u]);
+            any |= __builtin_amdgcn_ballot_w64(k[u] - g.lo <= width);  // lo <= k <= hi in one unsigned compare
+        }
+        if (any) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                bool in = k[u] - g.lo <= width;
+                if (DEV) in = in && !(k[u] >= g.x1_lo && k[u] <= g.x1_hi) && !(k[u] >= g.x2_lo && k[u] <= g.x2_hi);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
+                if (m) seg_push(sh, wcount, m, in, DEV ? dev_key(k[u], g.median) : k[u]);
+            }
+        }
+    }
+    return wcount;
+}
+
+// after the sweep: segment sizes -> compact the segments to the front of sh.tmp.  Returns the total (every thread), or
+// 0xffffffff if a segment overflowed.
+__device__ __forceinline__ unsigned int seg_compact(Shared &sh, unsigned int wcount) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh.seg_n[w] = wcount;
+    __syncthreads();
+    unsigned int before = 0, total = 0, worst = 0;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) {
+        const unsigned int n = sh.seg_n[i];
+        before += i < w ? n : 0u;
+        total += n;
+        worst = worst > n ? worst : n;
+    }
+    if (worst > (unsigned int)kSeg) {
+        __syncthreads();
+        return 0xffffffffu;
+    }
+    for (unsigned int i = lane; i < wcount; i += 64) sh.tmp[before + i] = sh.list[w * kSeg + i];
+    __syncthreads();
+    return total;
+}
+
+// wave 0: the ranks r_hi and r_lo (= r_hi or r_hi - 1; 0-based) of sh.tmp[0 .. n) -- an 8-bit radix descent for r_hi over the
+// bytes in which the keys differ at all (the keys of one bucket share their high bytes), then one pass for its predecessor.
+// Results in every lane of wave 0; other waves must not call.
+__device__ __forceinline__ void wave_select2(Shared &sh, unsigned int n, unsigned int r_lo, unsigned int r_hi, uint32_t *k_lo, uint32_t *k_hi) {
     const int lane = threadIdx.x & 63;
-    uint32_t prefix = 0, mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    // bits in which any two keys differ
+    const uint32_t k0 = sh.tmp[0];
+    uint32_t diff = 0;
+    for (unsigned int i = lane; i < n; i += 64) diff |= sh.tmp[i] ^ k0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, off, 64);
+    diff = (uint32_t)__builtin_amdgcn_readfirstlane((int)diff);
+    int top = 24;
+    while (top > 0 && (diff >> top) == 0) top -= 8;  // the highest byte that varies
+    uint32_t mask = top == 24 ? 0u : (0xffffffffu << (top + 8));
+    uint32_t prefix = k0 & mask;
+    unsigned int rank = r_hi;
+    for (int shift = top; shift >= 0; shift -= 8) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) sh.hist[lane + 64 * i] = 0;
         __builtin_amdgcn_wave_barrier();
         for (unsigned int i = lane; i < n; i += 64) {
-            const uint32_t k = sh.list[i];
+            const uint32_t k = sh.tmp[i];
             if ((k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS atomics have landed (same wave)
@@ -180,18 +337,13 @@ __device__ __forceinline__ uint32_t wave_select(Shared &sh, unsigned int n, unsi
         // lane l owns digits 4l .. 4l+3
         const unsigned int c0 = sh.hist[4 * lane], c1 = sh.hist[4 * lane + 1], c2 = sh.hist[4 * lane + 2], c3 = sh.hist[4 * lane + 3];
         const unsigned int mine = c0 + c1 + c2 + c3;
-        unsigned int incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned int up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
-        }
+        const unsigned int incl = wave_scan_incl(mine);
         const unsigned int excl = incl - mine;
         const bool owner = rank >= excl && rank < incl;
         uint32_t digit = 0;
         unsigned int below = 0;
         if (owner) {
-            unsigned int r = rank - excl;
+            const unsigned int r = rank - excl;
             if (r < c0) {
                 digit = 4 * lane;
                 below = excl;
@@ -215,7 +367,22 @@ __device__ __forceinline__ uint32_t wave_select(Shared &sh, unsigned int n, unsi
         mask |= 255u << shift;
         __builtin_amdgcn_wave_barrier();
     }
-    return prefix;
+    *k_hi = prefix;
+    *k_lo = prefix;
+    if (r_lo != r_hi) {  // the element before rank r_hi: the same key if r_hi is not its first occurrence, else the largest key below
+        unsigned int less = 0;
+        uint32_t best = 0;
+        for (unsigned int i = lane; i < n; i += 64) {
+            const uint32_t k = sh.tmp[i];
+            if (k < prefix) {
+                ++less;
+                best = best > k ? best : k;
+            }
+        }
+        less = wave_sum(less);
+        best = wave_max(best);
+        if (r_lo < less) *k_lo = best;  // (r_lo == less - 1: adjacent ranks)
+    }
 }
 
 // ---- order statistics of the VALUE keys ---------------------------------------------------------------------------------
@@ -235,35 +402,38 @@ __device__ __forceinline__ void select_values(const Keys &K, Shared &sh, const F
         if (g_hi >= excl && g_hi < incl) b_hi = (unsigned int)b;
     }
     block_reduce4<OP_MIN, OP_MAX, OP_MIN, OP_SUM>(sh, b_lo, b_hi, ex_lo, z);
+    TB_MARK(sh, 1);
     // key range of the two buckets (everything in between is empty: the ranks are adjacent)
-    const uint64_t r_lo = (uint64_t)f.base + ((uint64_t)b_lo << f.shift);
-    const uint64_t r_hi = (uint64_t)f.base + (((uint64_t)b_hi + 1) << f.shift) - 1;
-    const uint32_t key_lo = (uint32_t)r_lo, key_hi = r_hi > 0xffffffffull ? 0xffffffffu : (uint32_t)r_hi;
+    const uint32_t key_lo = f.first_key((int)b_lo), key_hi = f.last_key((int)b_hi);
     const unsigned int in_range = sh.prefix[b_hi] - ex_lo;
     if (in_range <= (unsigned int)kListCap) {
-        if (threadIdx.x == 0) sh.scal[0] = 0;
-        __syncthreads();
-    #pragma unroll
-        for (int i = 0; i < kSlots; ++i) {
-            const uint32_t k = fresh(K.k[i]);
-            list_push(sh, k >= key_lo && k <= key_hi && k != 0, k);
-        }
-        __syncthreads();
-        if (threadIdx.x < 64) {
-            const uint32_t a = wave_select(sh, in_range, g_lo - ex_lo);
-            const uint32_t b = g_hi == g_lo ? a : wave_select(sh, in_range, g_hi - ex_lo);
-            if (threadIdx.x == 0) {
-                sh.scal[1] = a;
-                sh.scal[2] = b;
+        GatherArgs ga;
+        ga.lo = key_lo;  // (>= 1: a non-candidate never matches)
+        ga.hi = key_hi >= key_lo ? key_hi : key_lo;
+        ga.x1_lo = ga.x2_lo = 1;
+        ga.x1_hi = ga.x2_hi = 0;
+        ga.median = 0.0;
+        const unsigned int wcount = gather_sweep<false>(K, sh, ga);
+        const unsigned int n = seg_compact(sh, wcount);
+        TB_MARK(sh, 2);
+        if (n != 0xffffffffu) {
+            if (threadIdx.x < 64) {
+                uint32_t a, b;
+                wave_select2(sh, n, g_lo - ex_lo, g_hi - ex_lo, &a, &b);
+                if (threadIdx.x == 0) {
+                    sh.scal[1] = a;
+                    sh.scal[2] = b;
+                }
             }
+            __syncthreads();
+            *k_lo = sh.scal[1];
+            *k_hi = sh.scal[2];
+            __syncthreads();
+            TB_MARK(sh, 3);
+            return;
         }
-        __syncthreads();
-        *k_lo = sh.scal[1];
-        *k_hi = sh.scal[2];
-        __syncthreads();
-        return;
     }
-    // too many equal-ish keys for the list: bisect on the key with counting sweeps (smallest key x with count(<= x) > rank)
+    // too many keys in those buckets for the list: bisect on the key with counting sweeps (smallest key x with count(<= x) > rank)
     uint32_t res[2];
     for (int which = 0; which < 2; ++which) {
         const unsigned int g = which ? g_hi : g_lo;
@@ -285,16 +455,17 @@ __device__ __forceinline__ void select_values(const Keys &K, Shared &sh, const F
     }
     *k_lo = res[0];
     *k_hi = res[1];
+    TB_MARK(sh, 3);
 }
 
 // ---- order statistics of the DEVIATION keys ---------------------------------------------------------------------------------
 struct Window {
-    uint32_t lo, hi;            // candidate keys retained so far: lo <= key <= hi
+    uint32_t lo, hi;             // candidate keys retained so far: lo <= key <= hi
     unsigned int c_lo, c_le_hi;  // candidates with key < lo / key <= hi
     unsigned int n;              // = c_le_hi - c_lo
 };
 
-// window candidates with key < first key of bucket b  (b in [0, kBuckets])
+// window candidates with key < first key of bucket b  (b in [0, nb])
 __device__ __forceinline__ unsigned int wprefix(const Shared &sh, const Window &w, int b) {
     const unsigned int p = b <= 0 ? 0u : sh.prefix[b - 1];
     const unsigned int q = p < w.c_lo ? w.c_lo : (p > w.c_le_hi ? w.c_le_hi : p);
@@ -304,28 +475,21 @@ __device__ __forceinline__ unsigned int wprefix(const Shared &sh, const Window &
 struct DevCtx {
     Frame f;
     double median;
-    int nb;  // buckets in use: ((max key - base) >> shift) + 1
-    __device__ __forceinline__ uint32_t first_key(int b) const { return f.base + ((uint32_t)b << f.shift); }  // b < nb
-    __device__ __forceinline__ uint32_t last_key(int b) const {
-        const uint64_t k = (uint64_t)f.base + (((uint64_t)b + 1) << f.shift) - 1;
-        return k > 0x7f7fffffull ? 0x7f7fffffu : (uint32_t)k;
-    }
+    int bm;  // the bucket of the median: the last bucket whose first key is <= median
     __device__ __forceinline__ bool left_of_median(uint32_t key) const { return (double)__uint_as_float(key) <= median; }
-    __device__ __forceinline__ int bucket_of(uint32_t key) const {
-        if (key < f.base) return 0;
-        const uint32_t b = (key - f.base) >> f.shift;
-        return b >= (uint32_t)nb ? nb - 1 : (int)b;
-    }
     // Smallest bucket b in [0, bm] whose boundary key (FIRST or LAST key of the bucket) has deviation <= t, scanning the
     // side left of the median; bm + 1 if none.  The deviation of a key left of the median falls as the key rises, so the
-    // predicate is monotone in b; the start is the bucket of the float nearest median - t, corrected by stepping.
+    // predicate is monotone in b; the search starts at `hint` (or at the bucket of the float nearest median - t) and steps.
     template <bool LAST>
-    __device__ __forceinline__ int left_edge(uint32_t t, int bm) const {
-        const double x = median - (double)__uint_as_float(t);
-        int b = x <= 0.0 ? 0 : bucket_of(__float_as_uint((float)x));
+    __device__ __forceinline__ int left_edge(uint32_t t, int hint) const {
+        int b = hint;
+        if (b < 0) {
+            const double x = median - (double)__uint_as_float(t);
+            b = x <= 0.0 ? 0 : f.bucket_of(__float_as_uint((float)x));
+        }
         if (b > bm) b = bm;
         auto ok = [&](int bb) {
-            const uint32_t key = LAST ? last_key(bb) : first_key(bb);
+            const uint32_t key = LAST ? f.last_key(bb) : f.first_key(bb);
             return !left_of_median(key) || dev_key(key, median) <= t;  // a boundary key right of the median: the bucket holds the median
         };
         while (b > 0 && ok(b - 1)) --b;
@@ -334,36 +498,41 @@ struct DevCtx {
     }
     // Largest bucket b in [bm, nb) whose boundary key has deviation <= t on the right side; bm - 1 if none.
     template <bool LAST>
-    __device__ __forceinline__ int right_edge(uint32_t t, int bm) const {
-        const double x = median + (double)__uint_as_float(t);
-        int b = bucket_of(x >= 3.4028234663852886e38 ? 0x7f7fffffu : __float_as_uint((float)x));
+    __device__ __forceinline__ int right_edge(uint32_t t, int hint) const {
+        int b = hint;
+        if (b < 0) {
+            const double x = median + (double)__uint_as_float(t);
+            b = f.bucket_of(x >= 3.4028234663852886e38 ? 0x7f7fffffu : __float_as_uint((float)x));
+        }
         if (b < bm) b = bm;
         auto ok = [&](int bb) {
-            const uint32_t key = LAST ? last_key(bb) : first_key(bb);
+            const uint32_t key = LAST ? f.last_key(bb) : f.first_key(bb);
             return left_of_median(key) || dev_key(key, median) <= t;
         };
-        while (b < nb - 1 && ok(b + 1)) ++b;
+        while (b < f.nb - 1 && ok(b + 1)) ++b;
         while (b >= bm && !ok(b)) --b;
         return b;
     }
 };
 
 // window candidates in buckets that lie ENTIRELY at deviation <= t (full) / that reach down to deviation <= t (any);
-// also the two bucket ranges themselves ([fl, fr] full, [al, ar] any; empty ranges have l > r)
+// also the two bucket ranges themselves ([fl, fr] full with bm possibly left out, [al, ar] any)
 struct Bounds {
     unsigned int n_full, n_any;
     int fl, fr, al, ar;
+    bool bm_full;
 };
-__device__ __forceinline__ Bounds dev_bounds(const Shared &sh, const Window &w, const DevCtx &c, int bm, uint32_t t) {
+__device__ __forceinline__ Bounds dev_bounds(const Shared &sh, const Window &w, const DevCtx &c, uint32_t t, int hint_l, int hint_r) {
+    const int bm = c.bm;
     Bounds o;
     // left of the median a bucket's largest deviation sits at its FIRST key, its smallest at its LAST key; mirrored on the right
-    o.fl = c.left_edge<false>(t, bm);
-    o.fr = c.right_edge<true>(t, bm);
-    o.al = c.left_edge<true>(t, bm);
-    o.ar = c.right_edge<false>(t, bm);
+    o.fl = c.left_edge<false>(t, hint_l);
+    o.fr = c.right_edge<true>(t, hint_r);
+    o.al = c.left_edge<true>(t, o.fl > 0 ? o.fl - 1 : 0);  // the any-run starts at most a bucket or so further out than the full run
+    o.ar = c.right_edge<false>(t, o.fr < c.f.nb - 1 ? o.fr + 1 : o.fr);
     // the bucket that holds the median has deviations on both sides of it: full only if both of its boundary keys qualify
-    const bool bm_full = o.fl <= bm && o.fr >= bm;
-    if (!bm_full) {
+    o.bm_full = o.fl <= bm && o.fr >= bm;
+    if (!o.bm_full) {
         // full buckets are then [fl, bm - 1] on the left and [bm + 1, fr] on the right: two runs
         const unsigned int left = o.fl <= bm - 1 ? wprefix(sh, w, bm) - wprefix(sh, w, o.fl) : 0u;
         const unsigned int right = o.fr >= bm + 1 ? wprefix(sh, w, o.fr + 1) - wprefix(sh, w, bm + 1) : 0u;
@@ -371,8 +540,7 @@ __device__ __forceinline__ Bounds dev_bounds(const Shared &sh, const Window &w, 
     } else {
         o.n_full = wprefix(sh, w, o.fr + 1) - wprefix(sh, w, o.fl);
     }
-    // "any": the median's bucket always reaches deviation ~0 <= t ... unless it has no candidates; counting it is still a valid
-    // upper bound
+    // "any": counting the median's bucket even when it does not reach below t keeps n_any a valid upper bound
     if (o.al > bm) o.al = bm;
     if (o.ar < bm) o.ar = bm;
     o.n_any = wprefix(sh, w, o.ar + 1) - wprefix(sh, w, o.al);
@@ -380,98 +548,124 @@ __device__ __forceinline__ Bounds dev_bounds(const Shared &sh, const Window &w, 
 }
 
 // ranks r_lo <= r_hi (adjacent or equal, 0-based) of the deviation keys of the window's candidates
-__device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Frame &f, int nb, const Window &w, double median, unsigned int r_lo,
+__device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Frame &f, const Window &w, double median, unsigned int r_lo,
                                             unsigned int r_hi, uint32_t *d_lo, uint32_t *d_hi) {
     DevCtx c;
     c.f = f;
     c.median = median;
-    c.nb = nb;
-    // the bucket of the median: the last bucket whose first key is <= median
-    int bm;
     {
         const float mf = (float)median;  // may round up past the median: step back below
-        int b = mf <= 0.0f ? 0 : c.bucket_of(__float_as_uint(mf));
-        while (b > 0 && !c.left_of_median(c.first_key(b))) --b;
-        while (b < nb - 1 && c.left_of_median(c.first_key(b + 1))) ++b;
-        bm = b;
+        int b = mf <= 0.0f ? 0 : f.bucket_of(__float_as_uint(mf));
+        while (b > 0 && !c.left_of_median(f.first_key(b))) --b;
+        while (b < f.nb - 1 && c.left_of_median(f.first_key(b + 1))) ++b;
+        c.bm = b;
     }
-    // every non-empty bucket proposes its largest deviation as a threshold t:
+    // A bucket's largest deviation t is a threshold with two bounds on F(t) = #{deviation <= t} from the prefix sum alone:
     //   N_any(t) <= r_lo      =>  the wanted deviations are > t        (best such t: the largest)
     //   N_full(t) >= r_hi + 1 =>  the wanted deviations are <= t       (best such t: the smallest)
-    unsigned int t_lo = 0, have_lo = 0, t_hi = 0xffffffffu, z = 0;
-#pragma unroll 1
-    for (int j = 0; j < kBuckets / kThreads; ++j) {
-        const int b = threadIdx.x * (kBuckets / kThreads) + j;
-        if (b >= nb) continue;
-        if (wprefix(sh, w, b + 1) == wprefix(sh, w, b)) continue;  // no window candidates in this bucket
-        const uint32_t dl = dev_key(c.first_key(b), median), dh = dev_key(c.last_key(b), median);
+    // Both bounds grow with t, so a probe that cannot tighten the bracket found so far is skipped.
+    unsigned int t_lo = 0, t_hi = 0xffffffffu, z0 = 0, z1 = 0;  // t_lo is stored + 1 (0 = none): the first key above the bound
+    auto probe = [&](int b) {
+        if (b < 0 || b >= f.nb) return;
+        const uint32_t dl = dev_key(f.first_key(b), median), dh = dev_key(f.last_key(b), median);
         const uint32_t t = dl > dh ? dl : dh;
-        const Bounds o = dev_bounds(sh, w, c, bm, t);
-        if (o.n_any <= r_lo) {
-            t_lo = t_lo > t + 1 ? t_lo : t + 1;  // stored + 1 so that 0 means "none"
-            have_lo = 1;
-        }
-        if (o.n_full >= r_hi + 1) t_hi = t_hi < t ? t_hi : t;
-    }
-    block_reduce4<OP_MAX, OP_MAX, OP_MIN, OP_SUM>(sh, t_lo, have_lo, t_hi, z);
-    // candidates: window pixels outside the buckets entirely below t_lo and inside the buckets reaching below t_hi
-    Bounds lo_b, hi_b;
-    unsigned int c0 = 0;
-    bool lo_bm_full = false;
-    if (have_lo) {
-        lo_b = dev_bounds(sh, w, c, bm, t_lo - 1);
-        c0 = lo_b.n_full;
-        lo_bm_full = lo_b.fl <= bm && lo_b.fr >= bm;
-    }
-    uint32_t a_lo_key = w.lo, a_hi_key = w.hi;  // outer range: everything (t_hi unknown: cannot happen for r_hi < n, kept for safety)
-    unsigned int n_cand = w.n - c0;
-    if (t_hi != 0xffffffffu) {
-        hi_b = dev_bounds(sh, w, c, bm, t_hi);
-        a_lo_key = c.first_key(hi_b.al);
-        a_hi_key = c.last_key(hi_b.ar);
-        n_cand = hi_b.n_any - c0;
-    }
-    // excluded runs (entirely below t_lo): [fl, min(fr, bm - 1)] and [max(fl, bm + 1), fr], plus bm itself when full
-    uint32_t x1_lo = 1, x1_hi = 0, x2_lo = 1, x2_hi = 0;  // empty
-    if (have_lo) {
-        const int l_end = lo_bm_full ? lo_b.fr : (bm - 1 < lo_b.fr ? bm - 1 : lo_b.fr);
-        if (lo_b.fl <= bm && lo_b.fl <= l_end) {
-            x1_lo = c.first_key(lo_b.fl);
-            x1_hi = c.last_key(l_end);
-        }
-        if (!lo_bm_full && lo_b.fr >= bm + 1) {
-            x2_lo = c.first_key(bm + 1);
-            x2_hi = c.last_key(lo_b.fr);
-        }
-    }
-    const unsigned int want_lo = r_lo - c0, want_hi = r_hi - c0;
-    if (n_cand <= (unsigned int)kListCap) {
-        if (threadIdx.x == 0) sh.scal[0] = 0;
-        __syncthreads();
-    #pragma unroll
-        for (int i = 0; i < kSlots; ++i) {
-            const uint32_t k = fresh(K.k[i]);
-            const bool in = k != 0 && k >= w.lo && k <= w.hi && k >= a_lo_key && k <= a_hi_key && !(k >= x1_lo && k <= x1_hi) &&
-                            !(k >= x2_lo && k <= x2_hi);
-            list_push(sh, in, in ? dev_key(k, median) : 0u);
-        }
-        __syncthreads();
+        if (t + 1 <= t_lo || t >= t_hi) return;  // cannot improve the bracket
+        const Bounds o = dev_bounds(sh, w, c, t, b <= c.bm ? b : -1, b >= c.bm ? b : -1);
+        if (o.n_any <= r_lo) t_lo = t + 1;
+        if (o.n_full >= r_hi + 1) t_hi = t;
+    };
+    // Round 1: one bucket in eight, one per thread.
+    constexpr int PER = kBuckets / kThreads;
+    probe(threadIdx.x * PER + PER / 2);
+    block_reduce4<OP_MAX, OP_MIN, OP_SUM, OP_SUM>(sh, t_lo, t_hi, z0, z1);
+    TB_MARK(sh, 4);
+    // Round 2: the buckets whose threshold lies inside round 1's bracket are a run of at most PER on either side of the
+    // median.  Their probes go to the lanes of wave 0, one bucket each, instead of queueing up in the threads that own them.
+    {
+        const uint32_t hi_t = t_hi == 0xffffffffu ? 0x7f800000u : t_hi;
+        const int l_from = c.left_edge<false>(hi_t, -1);                             // left run: largest deviation <= hi_t ...
+        const int l_to = t_lo ? c.left_edge<false>(t_lo - 1, -1) - 1 : c.bm;        // ... and > t_lo - 1
+        const int r_to = c.right_edge<true>(hi_t, -1);
+        const int r_from = t_lo ? c.right_edge<true>(t_lo - 1, -1) + 1 : c.bm;
         if (threadIdx.x < 64) {
-            const unsigned int n_list = sh.scal[0];  // == n_cand
-            const uint32_t a = wave_select(sh, n_list, want_lo);
-            const uint32_t b = r_hi == r_lo ? a : wave_select(sh, n_list, want_hi);
-            if (threadIdx.x == 0) {
-                sh.scal[1] = a;
-                sh.scal[2] = b;
+            const int lane = threadIdx.x;
+            // lanes 0 .. 31 walk the left run outwards from its inner end, lanes 32 .. 63 the right run; a run longer than 32
+            // buckets (never, after round 1) is simply not refined beyond its first 32
+            const int b = lane < 32 ? l_to - lane : r_from + (lane - 32);
+            const bool mine = lane < 32 ? (b >= l_from && b <= l_to) : (b >= r_from && b <= r_to);
+            if (mine) probe(b);
+            t_lo = wave_max(t_lo);
+            t_hi = wave_min(t_hi);
+            if (lane == 0) {
+                sh.scal[4] = t_lo;
+                sh.scal[5] = t_hi;
             }
         }
         __syncthreads();
-        *d_lo = sh.scal[1];
-        *d_hi = sh.scal[2];
+        t_lo = sh.scal[4];
+        t_hi = sh.scal[5];
         __syncthreads();
-        return;
     }
-    // heavy ties: bisect on the deviation key inside the bracket (smallest d with count(dev <= d) > rank)
+    // candidates: window pixels outside the buckets entirely below t_lo and inside the buckets reaching below t_hi
+    const bool have_lo = t_lo != 0;
+    Bounds lo_b, hi_b;
+    unsigned int c0 = 0;
+    uint32_t x1_lo = 1, x1_hi = 0, x2_lo = 1, x2_hi = 0;  // excluded key runs (entirely below t_lo); empty
+    if (have_lo) {
+        lo_b = dev_bounds(sh, w, c, t_lo - 1, -1, -1);
+        c0 = lo_b.n_full;
+        const int bm = c.bm;
+        const int l_end = lo_b.bm_full ? lo_b.fr : (bm - 1 < lo_b.fr ? bm - 1 : lo_b.fr);
+        if (lo_b.fl <= bm && lo_b.fl <= l_end) {
+            x1_lo = f.first_key(lo_b.fl);
+            x1_hi = f.last_key(l_end);
+        }
+        if (!lo_b.bm_full && lo_b.fr >= bm + 1) {
+            x2_lo = f.first_key(bm + 1);
+            x2_hi = f.last_key(lo_b.fr);
+        }
+    }
+    uint32_t a_lo_key = w.lo, a_hi_key = w.hi;  // outer range (t_hi always exists for r_hi < n; the window is the safe default)
+    unsigned int n_cand = w.n - c0;
+    if (t_hi != 0xffffffffu) {
+        hi_b = dev_bounds(sh, w, c, t_hi, -1, -1);
+        a_lo_key = f.first_key(hi_b.al);
+        a_hi_key = f.last_key(hi_b.ar);
+        n_cand = hi_b.n_any - c0;
+    }
+    if (a_lo_key < w.lo) a_lo_key = w.lo;
+    if (a_hi_key > w.hi) a_hi_key = w.hi;
+    TB_MARK(sh, 5);
+    if (n_cand <= (unsigned int)kListCap && a_lo_key <= a_hi_key) {
+        GatherArgs ga;
+        ga.lo = a_lo_key;
+        ga.hi = a_hi_key;
+        ga.x1_lo = x1_lo;
+        ga.x1_hi = x1_hi;
+        ga.x2_lo = x2_lo;
+        ga.x2_hi = x2_hi;
+        ga.median = median;
+        const unsigned int wcount = gather_sweep<true>(K, sh, ga);
+        const unsigned int n = seg_compact(sh, wcount);  // == n_cand
+        TB_MARK(sh, 6);
+        if (n != 0xffffffffu) {
+            if (threadIdx.x < 64) {
+                uint32_t a, b;
+                wave_select2(sh, n, r_lo - c0, r_hi - c0, &a, &b);
+                if (threadIdx.x == 0) {
+                    sh.scal[1] = a;
+                    sh.scal[2] = b;
+                }
+            }
+            __syncthreads();
+            *d_lo = sh.scal[1];
+            *d_hi = sh.scal[2];
+            __syncthreads();
+            TB_MARK(sh, 7);
+            return;
+        }
+    }
+    // heavy ties / a bracket inside a catch-all bucket: bisect on the deviation key (smallest d with count(dev <= d) > rank)
     uint32_t res[2];
     for (int which = 0; which < 2; ++which) {
         const unsigned int r = which ? r_hi : r_lo;
@@ -479,7 +673,7 @@ __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Fra
             res[1] = res[0];
             break;
         }
-        uint32_t lo = have_lo ? t_lo : 0u, hi = t_hi == 0xffffffffu ? 0x7f800000u : t_hi;  // (t_lo is stored + 1: the first key above it)
+        uint32_t lo = t_lo, hi = t_hi == 0xffffffffu ? 0x7f800000u : t_hi;  // (t_lo is stored + 1: the first key above the bound)
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             if (count_dev_le(K, sh, w.lo, w.hi, median, mid) > r)
@@ -491,6 +685,7 @@ __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Fra
     }
     *d_lo = res[0];
     *d_hi = res[1];
+    TB_MARK(sh, 7);
 }
 
 struct TileResult {
@@ -498,14 +693,34 @@ struct TileResult {
     int valid;
 };
 
+// one of this thread's keys as a sample: waves take different slots (different rows of the tile); wave-uniform switch
+__device__ __forceinline__ uint32_t sample_key(const Keys &K) {
+    switch ((threadIdx.x >> 6) & 7) {
+        case 0: return K.k[kSlots / 16];
+        case 1: return K.k[3 * kSlots / 16];
+        case 2: return K.k[5 * kSlots / 16];
+        case 3: return K.k[7 * kSlots / 16];
+        case 4: return K.k[9 * kSlots / 16];
+        case 5: return K.k[11 * kSlots / 16];
+        case 6: return K.k[13 * kSlots / 16];
+        default: return K.k[15 * kSlots / 16];
+    }
+}
+
 // sigma_clipped_stats(values, 3.0, 2) of the candidates in K (sigma_clip.rs:4-34); needs >= 8 candidates (star_detection.rs:61)
 __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
     constexpr double kMadToSigma = 1.4826;
-    // ---- histogram geometry: min / max / count of the candidates ----
+#ifdef AB_TILE_TIMING
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 8; ++i) sh.t_phase[i] = 0;
+        sh.t_mark = clock64();
+    }
+#endif
+    // ---- min / max / count of the candidates ----
     unsigned int kmin = 0xffffffffu, kmax = 0, cnt = 0, z = 0;
 #pragma unroll
     for (int i = 0; i < kSlots; ++i) {
-        const uint32_t k = fresh(K.k[i]);
+        const uint32_t k = K.k[i];
         if (k) {
             kmin = min(kmin, k);
             kmax = max(kmax, k);
@@ -516,43 +731,59 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
     TileResult res = {0.0, 1.0, 0};
     if (cnt < 8) return res;
     res.valid = 1;
+    // ---- where to zoom: mean +- 6 mean-absolute-deviations of a 512-pixel sample (efficiency only: any window is exact) ----
     Frame f;
-    f.base = kmin;
-    f.total = cnt;
-    const uint32_t span = kmax - kmin;
-    f.shift = 0;
-    while ((span >> f.shift) >= (uint32_t)kBuckets) ++f.shift;
-    const int nb = (int)(span >> f.shift) + 1;
+    f.kmin = kmin;
+    f.kmax = kmax;
+    {
+        const uint32_t sk = sample_key(K);
+        float s1 = sk ? __uint_as_float(sk) : 0.0f, s0 = sk ? 1.0f : 0.0f;
+        block_sum2f(sh, s1, s0);
+        const float mean = s0 > 0.0f ? s1 / s0 : __uint_as_float(kmin);
+        float a1 = sk ? fabsf(__uint_as_float(sk) - mean) : 0.0f, a0 = 0.0f;
+        block_sum2f(sh, a1, a0);
+        const float mad = s0 > 0.0f ? a1 / s0 : 0.0f;
+        const float lo = mean - 6.0f * mad, hi = mean + 6.0f * mad;
+        uint32_t zlo = (lo > 0.0f && lo == lo) ? __float_as_uint(lo) : kmin;
+        uint32_t zhi = (hi > 0.0f && hi < 3.0e38f) ? __float_as_uint(hi) : kmax;
+        zlo = zlo < kmin ? kmin : (zlo > kmax ? kmax : zlo);
+        zhi = zhi > kmax ? kmax : (zhi < zlo ? zlo : zhi);
+        f.zlo = zlo;
+        f.zhi = zhi;
+        const uint32_t span = zhi - zlo;
+        f.shift = 0;
+        while ((span >> f.shift) >= (uint32_t)(kBuckets - 2)) ++f.shift;
+        f.nb = (int)(span >> f.shift) + 3;
+    }
     // ---- the one histogram sweep ----
     for (int i = threadIdx.x; i < kBuckets; i += kThreads) sh.prefix[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < kSlots; ++i) {
         const uint32_t k = fresh(K.k[i]);
-        if (k) atomicAdd(&sh.prefix[(k - f.base) >> f.shift], 1u);
+        if (k) atomicAdd(&sh.prefix[f.bucket_of(k)], 1u);
     }
     __syncthreads();
-    {  // inclusive prefix sum over 4096 buckets: 4 per thread + a scan of the 1024 thread totals in sh.list
-        const int b0 = threadIdx.x * (kBuckets / kThreads);
-        unsigned int v0 = sh.prefix[b0], v1 = sh.prefix[b0 + 1], v2 = sh.prefix[b0 + 2], v3 = sh.prefix[b0 + 3];
-        v1 += v0;
-        v2 += v1;
-        v3 += v2;
-        sh.list[threadIdx.x] = v3;
+    {  // inclusive prefix sum over 4096 buckets: PER per thread + a scan of the thread totals in sh.tmp
+        constexpr int PER = kBuckets / kThreads;
+        const int b0 = threadIdx.x * PER;
+        unsigned int v[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = sh.prefix[b0 + j] + (j ? v[j - 1] : 0u);
+        sh.tmp[threadIdx.x] = v[PER - 1];
         __syncthreads();
         for (int off = 1; off < kThreads; off <<= 1) {
-            const unsigned int add = threadIdx.x >= (unsigned)off ? sh.list[threadIdx.x - off] : 0u;
+            const unsigned int add = threadIdx.x >= (unsigned)off ? sh.tmp[threadIdx.x - off] : 0u;
             __syncthreads();
-            sh.list[threadIdx.x] += add;
+            sh.tmp[threadIdx.x] += add;
             __syncthreads();
         }
-        const unsigned int before = sh.list[threadIdx.x] - v3;
-        sh.prefix[b0] = v0 + before;
-        sh.prefix[b0 + 1] = v1 + before;
-        sh.prefix[b0 + 2] = v2 + before;
-        sh.prefix[b0 + 3] = v3 + before;
+        const unsigned int before = sh.tmp[threadIdx.x] - v[PER - 1];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) sh.prefix[b0 + j] = v[j] + before;
         __syncthreads();
     }
+    TB_MARK(sh, 0);
 
     Window w;
     w.lo = 1;
@@ -561,6 +792,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
     w.c_le_hi = cnt;
     w.n = cnt;
     double median = 0.0, sigma = 1.0;
+#pragma unroll 1
     for (int it = 0; it < 3; ++it) {  // 2 clipping iterations + the final statistics (sigma_clip.rs:7-33)
         if (it < 2 && w.n < 3) continue;  // `if values.len() < 3 { break }`: no more clipping, the final statistics still run
         if (w.n == 0) {                   // sigma_clip.rs:26-28
@@ -575,7 +807,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
         median = w.n % 2 == 0 ? ((double)__uint_as_float(ka) + (double)__uint_as_float(kb)) / 2.0 : (double)__uint_as_float(kb);
         // median_f32_mut of the deviations (median.rs:46-63): f32 average for even n
         uint32_t da, db;
-        select_devs(K, sh, f, nb, w, median, w.n % 2 == 0 ? mid - 1 : mid, mid, &da, &db);
+        select_devs(K, sh, f, w, median, w.n % 2 == 0 ? mid - 1 : mid, mid, &da, &db);
         const float mad_f32 = w.n % 2 == 0 ? (__uint_as_float(da) + __uint_as_float(db)) / 2.0f : __uint_as_float(db);
         const double sig = fmax((double)mad_f32 * kMadToSigma, 1e-30);
         if (it == 2) {
@@ -604,6 +836,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
         }
         count_below(K, sh, w.lo, w.hi, &w.c_lo, &w.c_le_hi);
         w.n = w.c_le_hi - w.c_lo;
+        TB_MARK(sh, 0);
     }
     res.median = median;
     res.sigma = sigma;
