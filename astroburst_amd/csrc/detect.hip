@@ -186,7 +186,7 @@ __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(co
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
             const float v = ab_px(xf, raw[i]);
-            K.k[h * kBatch + i] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
+            K.v[(h * kBatch + i) >> 5][(h * kBatch + i) & 31] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
         }
     }
     const tb::TileResult r = tb::tile_stats(K, sh);

@@ -87,6 +87,7 @@ struct Ws {
     unsigned long long *H;   // [0] = a count riding along with a histogram all-reduce; [1, 65537) = h0; [65537, 131073) = h1
     ScanPartial *partials;   // kMaxPartials
     unsigned int *sel;       // 2 x 2048
+    unsigned int *gsum;      // 2 x 1024 group totals (64 bins each) of h0 / h1
 };
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int off) { return __shfl_xor(v, off, 64); }
@@ -238,18 +239,16 @@ __device__ __forceinline__ void lds_hist_flush(unsigned int *lds, unsigned long 
 // KIND = HIST_DEV   (stats.rs:119-146):   h0[bin(|v - coarse_median|)] += 1 (dense, LDS) and the 65 536 sub-bins of the
 //                                         median bin in h1 (sparse: one coarse bin's worth of pixels, global atomics)
 // KIND = HIST_MAD   (stats.rs:166-191):   count of deviations below the MAD region (per-workgroup) and the region's
-//                                         65 536 sub-bins in h0 (three coarse bins' worth of pixels spread over all the sub-bins:
-//                                         global atomics -- flushing 65 536 privatised counters per workgroup would issue
-//                                         20x more atomics than the pass has candidate pixels; measured 75 us that way)
+//                                         65 536 sub-bins in h0 (three coarse bins' worth of pixels spread over all the sub-bins;
+//                                         LDS-privatised like the others: straight global atomics were tried and took 115 us
+//                                         against 75 -- device-scope atomics are served at the memory side, not in an XCD's L2)
 template <int KIND>
 __global__ __launch_bounds__(kHistBlock) void dense_hist_kernel(const float *__restrict__ data, int64_t n, int64_t chunk,
                                                                 const StatsDev *__restrict__ st, unsigned long long *__restrict__ h0,
                                                                 unsigned long long *__restrict__ h1, ScanPartial *__restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // 32 768 words = 65 536 x u16 (none for HIST_MAD)
-    if (KIND != HIST_MAD) {
-        for (int i = threadIdx.x; i < kHistBins / 2; i += kHistBlock) lds[i] = 0;
-        __syncthreads();
-    }
+    extern __shared__ __attribute__((aligned(16))) unsigned int lds[];  // 32 768 words = 65 536 x u16
+    for (int i = threadIdx.x; i < kHistBins / 2; i += kHistBlock) lds[i] = 0;
+    __syncthreads();
 
     const uint32_t last = kHistBins - 1;
     double sum = 0.0;
@@ -285,11 +284,11 @@ __global__ __launch_bounds__(kHistBlock) void dense_hist_kernel(const float *__r
                     if (dev < mad_lo)
                         cnt += 1;
                     else if (dev < mad_hi)
-                        atomicAdd(&h0[bin_index(((double)dev - mad_region_lo) * mad_inv, last)], 1ull);
+                        lds_hist_add(lds, bin_index(((double)dev - mad_region_lo) * mad_inv, last));
                 }
             }
         });
-        if (KIND != HIST_MAD) lds_hist_flush(lds, h0);
+        lds_hist_flush(lds, h0);
     }
     if (KIND != HIST_DEV) block_reduce_scan(0.0, 0.0, sum, cnt, &partials[blockIdx.x]);
 }
@@ -319,25 +318,29 @@ struct RankHit {
     uint32_t bin;
     unsigned long long count, cum;
 };
-__device__ __forceinline__ RankHit block_find_rank(const unsigned long long *hist, unsigned long long target) {
+// totals of the 1024 groups of 64 consecutive bins of `nhist` consecutive 65 536-bin histograms: 64 workgroups per histogram read
+// it coalesced (one workgroup reading 512 KiB on its own took 20 us of the bookkeeping kernels' 19 - 35)
+__global__ __launch_bounds__(256) void group_totals_kernel(const unsigned long long *__restrict__ hist, unsigned int *__restrict__ gsum) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const size_t g = (size_t)blockIdx.x * 16 + (size_t)w * 4 + i;  // group index over all histograms
+        // (a plane has fewer than 2^31 pixels, so do all the bins of a histogram together: group totals fit 32 bits)
+        unsigned int c = (unsigned int)hist[g * 64 + lane];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (lane == 0) gsum[g] = c;
+    }
+}
+
+// first bin i with cum(i) >= target over 65 536 bins (cum inclusive), given the 1024 group totals
+__device__ __forceinline__ RankHit block_find_rank(const unsigned long long *hist, const unsigned int *gsum, unsigned long long target) {
     __shared__ unsigned long long s_part[kBookBlock];
     __shared__ RankHit s_hit;
     __shared__ int s_owner;
     constexpr int PER = kHistBins / kBookBlock;  // 64 consecutive bins per thread
     const int t = threadIdx.x;
-    // 32 independent 16-byte loads per thread (the histogram is L2-resident: 512 KiB)
-    const ulonglong2 *h2 = reinterpret_cast<const ulonglong2 *>(hist + (size_t)t * PER);
-    const bool vec_ok = (((uintptr_t)hist) & 15) == 0;
-    unsigned long long local = 0;
-    if (vec_ok) {
-#pragma unroll 8
-        for (int j = 0; j < PER / 2; ++j) {
-            const ulonglong2 v = h2[j];
-            local += v.x + v.y;
-        }
-    } else {
-        for (int j = 0; j < PER; ++j) local += hist[t * PER + j];
-    }
+    const unsigned long long local = gsum[t];
     s_part[t] = local;
     if (t == 0) {
         s_hit.found = 0;
@@ -379,9 +382,10 @@ __device__ __forceinline__ RankHit block_find_rank(const unsigned long long *his
 }
 
 // resolve_rank_in_hist (stats.rs:333-353)
-__device__ __forceinline__ double resolve_rank(const unsigned long long *hist, unsigned long long rank, double region_lo, double sub_bw) {
+__device__ __forceinline__ double resolve_rank(const unsigned long long *hist, const unsigned int *gsum, unsigned long long rank, double region_lo,
+                                               double sub_bw) {
     if (rank == 0) return region_lo;  // uniform
-    const RankHit h = block_find_rank(hist, rank);
+    const RankHit h = block_find_rank(hist, gsum, rank);
     if (!h.found) return region_lo + (double)kHistBins * sub_bw;
     const unsigned long long overshoot = h.cum - rank;
     const double frac = h.count > 0 ? 1.0 - ((double)overshoot / (double)h.count) : 0.5;
@@ -413,7 +417,7 @@ __global__ void book_range_kernel(StatsDev *st) {
 }
 
 // after the VALUE pass (stats.rs:94-117): mean, the median's coarse bin, parameters of the DEV pass
-__global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, const unsigned long long *H) {
+__global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, const unsigned long long *H, const unsigned int *G) {
     if (st->empty) return;
     const unsigned long long total = H[0];
     if (total == 0) {  // stats.rs:95-97
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, co
         return;
     }
     const unsigned long long half = f64_to_u64_sat(ceil((double)total * 0.5));  // :100 (== find_percentile_bin's target)
-    const RankHit h = block_find_rank(H + 1, half);
+    const RankHit h = block_find_rank(H + 1, G, half);
     if (threadIdx.x != 0) return;
     const double gmin = st->gmin, bw = st->bin_width, range = st->range;
     const uint32_t median_bin = h.found ? h.bin : (uint32_t)(kHistBins - 1);  // find_percentile_bin (:302-311)
@@ -451,12 +455,12 @@ __global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, co
 }
 
 // after the DEV pass (stats.rs:148-164): the exact median from the refined bin, the MAD's coarse region
-__global__ __launch_bounds__(kBookBlock) void book_dev_kernel(StatsDev *st, const unsigned long long *H) {
+__global__ __launch_bounds__(kBookBlock) void book_dev_kernel(StatsDev *st, const unsigned long long *H, const unsigned int *G) {
     if (st->empty) return;
     const unsigned long long half = st->half_count, before = st->count_before_median;
     const unsigned long long rank_in_bin = half > before ? half - before : 0;  // saturating_sub (:148)
-    const double median = resolve_rank(H + 1 + kHistBins, rank_in_bin, st->median_bin_lo, st->refine_range / (double)kHistBins);
-    const RankHit h = block_find_rank(H + 1, half);  // find_percentile_bin(dev_hist, total, 0.5) (:154)
+    const double median = resolve_rank(H + 1 + kHistBins, G + 1024, rank_in_bin, st->median_bin_lo, st->refine_range / (double)kHistBins);
+    const RankHit h = block_find_rank(H + 1, G, half);  // find_percentile_bin(dev_hist, total, 0.5) (:154)
     if (threadIdx.x != 0) return;
     const uint32_t mad_bin = h.found ? h.bin : (uint32_t)(kHistBins - 1);
     const uint32_t expand_lo = mad_bin > 0 ? mad_bin - 1 : 0;                                         // :155
@@ -482,14 +486,14 @@ __device__ __forceinline__ void finish_result(StatsDev *st, double mad, const ab
 }
 
 // after the MAD pass (stats.rs:193-209)
-__global__ __launch_bounds__(kBookBlock) void book_mad_kernel(StatsDev *st, const unsigned long long *H, ab_auto_stf_config cfg) {
+__global__ __launch_bounds__(kBookBlock) void book_mad_kernel(StatsDev *st, const unsigned long long *H, const unsigned int *G, ab_auto_stf_config cfg) {
     if (st->empty) {
         if (threadIdx.x == 0) finish_result(st, 0.0, cfg);
         return;
     }
     const unsigned long long below = H[0], half = st->half_count;
     const unsigned long long rank = half > below ? half - below : 0;
-    const double mad = resolve_rank(H + 1, rank, st->mad_region_lo, st->mad_refine_range / (double)kHistBins);
+    const double mad = resolve_rank(H + 1, G, rank, st->mad_region_lo, st->mad_refine_range / (double)kHistBins);
     if (threadIdx.x == 0) finish_result(st, mad, cfg);
 }
 
@@ -625,7 +629,7 @@ int grid_for(ab_ctx *ctx, int64_t n, int block, int per_cu) {
 }
 
 int carve(ab_ctx *ctx, Ws *w) {
-    const size_t bytes = 1024 + (size_t)(1 + 2 * kHistBins) * sizeof(unsigned long long) + kMaxPartials * sizeof(ScanPartial) + 4096 * 4;
+    const size_t bytes = 1024 + (size_t)(1 + 2 * kHistBins) * sizeof(unsigned long long) + kMaxPartials * sizeof(ScanPartial) + 4096 * 4 + 2048 * 4;
     static_assert(sizeof(StatsDev) <= 1024, "StatsDev outgrew its slot");
     char *c = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_STATS, bytes, (void **)&c));
@@ -636,6 +640,8 @@ int carve(ab_ctx *ctx, Ws *w) {
     w->partials = (ScanPartial *)c;
     c += kMaxPartials * sizeof(ScanPartial);
     w->sel = (unsigned int *)c;
+    c += 4096 * sizeof(unsigned int);
+    w->gsum = (unsigned int *)c;
     return AB_OK;
 }
 
@@ -657,12 +663,7 @@ int launch_dense(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int *gr
     int grid;
     int64_t chunk;
     hist_launch_shape(ctx, n, &grid, &chunk);
-    const size_t lds_bytes = KIND == HIST_MAD ? 0 : kHistBins * sizeof(unsigned short);
-    if (KIND == HIST_MAD) {  // no privatised histogram: nothing limits residency, so smaller chunks and four workgroups per CU
-        grid = std::min<int>(4 * grid, kMaxPartials);
-        int64_t nchunks = ((n + kHistChunkMax - 1) / kHistChunkMax + grid - 1) / grid * grid;
-        chunk = std::max<int64_t>((((n + nchunks - 1) / nchunks) + 7) & ~(int64_t)7, 8);
-    }
+    const size_t lds_bytes = kHistBins * sizeof(unsigned short);
     AB_HIP(ctx, hipFuncSetAttribute((const void *)dense_hist_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(dense_hist_kernel<KIND>, dim3(grid), dim3(kHistBlock), lds_bytes, ctx->stream, data, n, chunk, w.st, w.H + 1,
                        w.H + 1 + kHistBins, w.partials);
@@ -700,16 +701,19 @@ int enqueue_hist_path(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, 
         AB_TRY(ab_comm_allreduce(ctx, comm, w.H, 1 + kHistBins, AB_DT_U64, AB_RED_SUM));
         AB_TRY(ab_comm_allreduce(ctx, comm, &w.st->sum, 1, AB_DT_F64, AB_RED_SUM));
     }
-    hipLaunchKernelGGL(book_value_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H);
+    hipLaunchKernelGGL(group_totals_kernel, dim3(64), dim3(256), 0, ctx->stream, w.H + 1, w.gsum);
+    hipLaunchKernelGGL(book_value_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H, w.gsum);
     AB_HIP(ctx, hipMemsetAsync(w.H + 1, 0, (size_t)(2 * kHistBins) * sizeof(unsigned long long), ctx->stream));
     AB_TRY(launch_dense<HIST_DEV>(ctx, data, n, w, &grid));
     if (comm) AB_TRY(ab_comm_allreduce(ctx, comm, w.H + 1, 2 * kHistBins, AB_DT_U64, AB_RED_SUM));
-    hipLaunchKernelGGL(book_dev_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H);
+    hipLaunchKernelGGL(group_totals_kernel, dim3(128), dim3(256), 0, ctx->stream, w.H + 1, w.gsum);
+    hipLaunchKernelGGL(book_dev_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H, w.gsum);
     AB_HIP(ctx, hipMemsetAsync(w.H, 0, (size_t)(1 + kHistBins) * sizeof(unsigned long long), ctx->stream));
     AB_TRY(launch_dense<HIST_MAD>(ctx, data, n, w, &grid));
     hipLaunchKernelGGL(finish_hist_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.partials, grid, w.st, w.H, 0);
     if (comm) AB_TRY(ab_comm_allreduce(ctx, comm, w.H, 1 + kHistBins, AB_DT_U64, AB_RED_SUM));
-    hipLaunchKernelGGL(book_mad_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H, cfg);
+    hipLaunchKernelGGL(group_totals_kernel, dim3(64), dim3(256), 0, ctx->stream, w.H + 1, w.gsum);
+    hipLaunchKernelGGL(book_mad_kernel, dim3(1), dim3(kBookBlock), 0, ctx->stream, w.st, w.H, w.gsum, cfg);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }

@@ -76,17 +76,24 @@ struct Shared {
     } while (0)
 #endif
 
+// The keys live in VGPRs as four 32-element vectors, and every sweep is a REAL loop of 32 iterations over a uniform index j
+// that reads v[0][j] .. v[3][j] through the VGPR index register (s_set_gpr_idx_on: no scratch).  The first version unrolled
+// its sweeps fully -- 128 slots x 6 sweeps x ~30 instructions = 180 KB of straight-line code, each line of it executed once:
+// the sweeps ran at the instruction-fetch rate (~100 cycles per 64-byte line: 14 000 cycles for a sweep whose ALU work is
+// 2 500), and the whole kernel was no faster than round 1's.  Looped, a sweep's body is a few hundred bytes.
+typedef uint32_t u32x32 __attribute__((ext_vector_type(32)));
+constexpr int kVecs = kSlots / 32;
 struct Keys {
-    uint32_t k[kSlots];  // 0 = not a candidate
+    u32x32 v[kVecs];  // key of slot s = v[s >> 5][s & 31]; 0 = not a candidate
 };
-
-// An opaque copy of a key (at most one v_mov): what a sweep computes from it cannot be hoisted out of the enclosing loops and
-// kept alive across the other sweeps (SGPR-pair masks per hoisted predicate, spilled lane by lane), and -- unlike marking
-// the key array itself as rewritten -- the keys stay loop-invariant values (no 128-wide PHIs at every loop header).
-__device__ __forceinline__ uint32_t fresh(uint32_t k) {
-    uint32_t o;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(o) : "v"(k));
-    return o;
+// f(key) for every key of the thread
+template <class F>
+__device__ __forceinline__ void for_each_key(const Keys &K, F f) {
+#pragma unroll 1
+    for (int j = 0; j < 32; ++j) {
+#pragma unroll
+        for (int c = 0; c < kVecs; ++c) f(K.v[c][j]);
+    }
 }
 
 __device__ __forceinline__ unsigned int wave_sum(unsigned int x) {
@@ -216,12 +223,11 @@ __device__ __forceinline__ void count_below(const Keys &K, Shared &sh, uint32_t 
     unsigned int ca = 0, cb = 0;
     // k != 0 && k < a  <=>  k - 1 < a - 1 (unsigned, a >= 1; the non-candidate 0 wraps to the top); k != 0 && k <= b  <=>  k - 1 < b
     const uint32_t a1 = a ? a - 1u : 0u;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        const uint32_t k1 = fresh(K.k[i]) - 1u;
+    for_each_key(K, [&](uint32_t k) {
+        const uint32_t k1 = k - 1u;
         ca += (k1 < a1) ? 1u : 0u;
         cb += (k1 < b) ? 1u : 0u;
-    }
+    });
     unsigned int z0 = 0, z1 = 0;
     block_reduce4<OP_SUM, OP_SUM, OP_SUM, OP_SUM>(sh, ca, cb, z0, z1);
     *lt_a = ca;
@@ -231,11 +237,9 @@ __device__ __forceinline__ void count_below(const Keys &K, Shared &sh, uint32_t 
 // count of window candidates whose deviation key is <= d
 __device__ __forceinline__ unsigned int count_dev_le(const Keys &K, Shared &sh, uint32_t wlo, uint32_t whi, double median, uint32_t d) {
     unsigned int c = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        const uint32_t k = fresh(K.k[i]);
+    for_each_key(K, [&](uint32_t k) {
         if (k >= wlo && k <= whi && k != 0) c += dev_key(k, median) <= d ? 1u : 0u;
-    }
+    });
     unsigned int z0 = 0, z1 = 0, z2 = 0;
     block_reduce4<OP_SUM, OP_SUM, OP_SUM, OP_SUM>(sh, c, z0, z1, z2);
     return c;
@@ -256,28 +260,28 @@ struct GatherArgs {
     double median;
 };
 // one gather sweep over the thread's keys: appends every key in [lo, hi] outside the excluded runs -- as the key (DEV = false) or
-// as its deviation key.  Eight slots share one branch: a slot costs one subtract-compare, a group one scalar test; only the rare
+// as its deviation key.  Four slots share one branch: a slot costs one subtract-compare, a group one scalar test; only the rare
 // group that holds a match goes through the excluded runs, forms deviations and appends.
 template <bool DEV>
 __device__ __forceinline__ unsigned int gather_sweep(const Keys &K, Shared &sh, const GatherArgs &g) {
     unsigned int wcount = 0;
     const uint32_t width = g.hi - g.lo;
-#pragma unroll
-    for (int grp = 0; grp < kSlots / 8; ++grp) {
-        uint32_t k[8];
+#pragma unroll 1
+    for (int j = 0; j < 32; ++j) {
+        uint32_t k[kVecs];
         unsigned long long any = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            k[u] = fresh(K.k[8 * grp + u]);
-            any |= __builtin_amdgcn_ballot_w64(k[u] - g.lo <= width);  // lo <= k <= hi in one unsigned compare
+        for (int c = 0; c < kVecs; ++c) {
+            k[c] = K.v[c][j];
+            any |= __builtin_amdgcn_ballot_w64(k[c] - g.lo <= width);  // lo <= k <= hi in one unsigned compare
         }
         if (any) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                bool in = k[u] - g.lo <= width;
-                if (DEV) in = in && !(k[u] >= g.x1_lo && k[u] <= g.x1_hi) && !(k[u] >= g.x2_lo && k[u] <= g.x2_hi);
+            for (int c = 0; c < kVecs; ++c) {
+                bool in = k[c] - g.lo <= width;
+                if (DEV) in = in && !(k[c] >= g.x1_lo && k[c] <= g.x1_hi) && !(k[c] >= g.x2_lo && k[c] <= g.x2_hi);
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
-                if (m) seg_push(sh, wcount, m, in, DEV ? dev_key(k[u], g.median) : k[u]);
+                if (m) seg_push(sh, wcount, m, in, DEV ? dev_key(k[c], g.median) : k[c]);
             }
         }
     }
@@ -696,14 +700,14 @@ struct TileResult {
 // one of this thread's keys as a sample: waves take different slots (different rows of the tile); wave-uniform switch
 __device__ __forceinline__ uint32_t sample_key(const Keys &K) {
     switch ((threadIdx.x >> 6) & 7) {
-        case 0: return K.k[kSlots / 16];
-        case 1: return K.k[3 * kSlots / 16];
-        case 2: return K.k[5 * kSlots / 16];
-        case 3: return K.k[7 * kSlots / 16];
-        case 4: return K.k[9 * kSlots / 16];
-        case 5: return K.k[11 * kSlots / 16];
-        case 6: return K.k[13 * kSlots / 16];
-        default: return K.k[15 * kSlots / 16];
+        case 0: return K.v[0][8];
+        case 1: return K.v[0][24];
+        case 2: return K.v[1][8];
+        case 3: return K.v[1][24];
+        case 4: return K.v[2][8];
+        case 5: return K.v[2][24];
+        case 6: return K.v[3][8];
+        default: return K.v[3][24];
     }
 }
 
@@ -718,15 +722,13 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
 #endif
     // ---- min / max / count of the candidates ----
     unsigned int kmin = 0xffffffffu, kmax = 0, cnt = 0, z = 0;
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        const uint32_t k = K.k[i];
-        if (k) {
-            kmin = min(kmin, k);
-            kmax = max(kmax, k);
-            ++cnt;
-        }
-    }
+    for_each_key(K, [&](uint32_t k) {
+        kmin = min(kmin, k - 1u);  // (k - 1: the non-candidate 0 wraps to the top and never wins the minimum)
+        kmax = max(kmax, k);
+        cnt += k ? 1u : 0u;
+    });
+    kmin += 1u;  // 0xffffffff + 1 = 0 when the thread holds no candidate: fixed up after the reduction
+    if (kmin == 0) kmin = 0xffffffffu;
     block_reduce4<OP_MIN, OP_MAX, OP_SUM, OP_SUM>(sh, kmin, kmax, cnt, z);
     TileResult res = {0.0, 1.0, 0};
     if (cnt < 8) return res;
@@ -758,11 +760,9 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
     // ---- the one histogram sweep ----
     for (int i = threadIdx.x; i < kBuckets; i += kThreads) sh.prefix[i] = 0;
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < kSlots; ++i) {
-        const uint32_t k = fresh(K.k[i]);
+    for_each_key(K, [&](uint32_t k) {
         if (k) atomicAdd(&sh.prefix[f.bucket_of(k)], 1u);
-    }
+    });
     __syncthreads();
     {  // inclusive prefix sum over 4096 buckets: PER per thread + a scan of the thread totals in sh.tmp
         constexpr int PER = kBuckets / kThreads;
@@ -804,6 +804,9 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
         const unsigned int mid = w.n / 2;
         uint32_t ka, kb;
         select_values(K, sh, f, w.c_lo + (w.n % 2 == 0 ? mid - 1 : mid), w.c_lo + mid, &ka, &kb);
+#ifdef AB_TILE_REPEAT  // developer experiment (tools/tile_bench.hip): the same select again, its code now warm in the instruction cache
+        select_values(K, sh, f, w.c_lo + (w.n % 2 == 0 ? mid - 1 : mid), w.c_lo + mid, &ka, &kb);
+#endif
         median = w.n % 2 == 0 ? ((double)__uint_as_float(ka) + (double)__uint_as_float(kb)) / 2.0 : (double)__uint_as_float(kb);
         // median_f32_mut of the deviations (median.rs:46-63): f32 average for even n
         uint32_t da, db;

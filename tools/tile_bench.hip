@@ -18,7 +18,7 @@ __global__ __launch_bounds__(tb::kThreads) void k(const float *img, int cols, do
 #pragma unroll
     for (int i = 0; i < tb::kSlots; ++i) {
         const float v = img[(size_t)(ty0 + ty + (tb::kThreads / 256) * i) * cols + tx0 + tx];
-        K.k[i] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;
+        K.v[i >> 5][i & 31] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;
     }
     const tb::TileResult r = tb::tile_stats(K, sh);
     if (threadIdx.x == 0) {
