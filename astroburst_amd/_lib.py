@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libastroburst_hip.so")
+LIB_PATH = os.environ.get("AB_LIB_PATH") or os.path.join(_HERE, "libastroburst_hip.so")  # AB_LIB_PATH: A/B-test a variant build
 HEADER_PATH = os.path.join(ROOT, "include", "astroburst_hip.h")
 CSRC = os.path.join(_HERE, "csrc")
 

@@ -1192,8 +1192,11 @@ class Context:
     def stack_sigma_clip_raw(self, raw_planes, rows: int, cols: int, bitpix: int, bscale=1.0, bzero=0.0, sigma_low=3.0, sigma_high=3.0,
                              max_iterations=5, out=None, want_rejected=True):
         """ab_stack_sigma_clip over raw big-endian data units (torch uint8 CUDA tensors): decode fused into the stack."""
+        need = rows * cols * (abs(int(bitpix)) // 8)
         for t in raw_planes:
             assert _is_torch(t) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+            if t.numel() < need:   # a truncated data unit would make the kernel read past the tensor
+                raise AstroBurstError(_lib.AB_ERR_INVALID, f"raw plane holds {t.numel()} bytes, {rows}x{cols} BITPIX {bitpix} needs {need}")
         self.use_torch_stream()
         ptrs = (C.c_void_p * len(raw_planes))(*[t.data_ptr() for t in raw_planes])
         if out is None:

@@ -529,7 +529,37 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
     // n finite samples end up on sorted positions [0, n).
     float v[NP];
     float nf = 0.0f;  // fma(x, 0, nf) stays 0 for finite x and turns NaN for inf / NaN
-    if constexpr (DIRECT) {
+    if constexpr (DIRECT && INPUT == kInNative && NP <= 64) {
+        // All NP frames present, contiguous, < 2^30 px.  The plane pointers come through the scalar cache (s_load_dwordx16 of the
+        // kernarg table, 8 pointers per load) and every sample is `global_load_dword v, voffset, s[base:base+1]` with one shared
+        // 32-bit byte offset: 64 loads issued back to back and ZERO vector instructions of address work.  (Round 1 broadcast the
+        // pointers out of a VGPR with 2 v_readlane per frame into buffer descriptors: 128 quarter-rate VALU instructions per
+        // wave, 6 % of a VALU-bound kernel -- 1.27 -> 1.16 ms on the bench stack.)  The tail block clamps g, so no lane is ever
+        // out of range.
+        const uint32_t boff = (uint32_t)g * 4u;
+#pragma unroll
+        for (int f = 0; f < NP; ++f) v[f] = *(const float *)((const char *)args.p[f] + boff);
+        if constexpr (MODE == kPlain) {
+            constexpr int CH = NP >= 8 ? 8 : NP;
+#pragma unroll
+            for (int c = 0; c < NP / CH; ++c) {
+                int t = args.n_real;
+                asm volatile("" : "+s"(t));
+                if (CH * c + CH <= t) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) nf = __builtin_fmaf(v[CH * c + j], 0.0f, nf);
+                } else if (CH * c < t) {
+#pragma unroll
+                    for (int j = 0; j < CH; ++j)
+                        if (CH * c + j < t) nf = __builtin_fmaf(v[CH * c + j], 0.0f, nf);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < NP; ++f) nf = __builtin_fmaf(v[f], 0.0f, nf);
+        }
+    } else if constexpr (DIRECT) {
+        // deeper stacks (128 / 256 samples per lane) and raw FITS planes: the pointer table does not fit the scalar registers
         // All NP frames present, contiguous, < 2^30 px: one vector load fetches the 64 plane pointers
         // (lane f reads p[f] straight from the kernarg segment), v_readlane broadcasts each into an
         // SGPR pair, and every sample load is `global_load_dword v, voffset, s[base]` -- no per-frame
@@ -545,7 +575,11 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         }
         constexpr uint32_t kSampleBytes = INPUT == kInI16BE ? 2u : 4u;
         const uint32_t off = (uint32_t)g * kSampleBytes;
-        const uint32_t plane_bytes = (uint32_t)total * kSampleBytes;
+        // BITPIX 16 fetches the aligned dword that holds a sample: with an odd pixel count the last sample's dword ends 2 bytes past
+        // the data unit, so the descriptor's range is rounded up to whole dwords (a range check on the exact byte count would
+        // return 0 for that dword and decode the last pixel as bzero).  The caller's buffer must be readable up to that boundary
+        // (include/astroburst_hip.h: ab_stack_sigma_clip_raw).
+        const uint32_t plane_bytes = ((uint32_t)total * kSampleBytes + 3u) & ~3u;
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
             const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi[f >> 6], f & 63) << 32) |

@@ -460,7 +460,9 @@ AB_API int ab_fits_encode_pixels(ab_ctx *ctx, const ab_plane *img, int32_t bitpi
 /* stack_images' per-pixel loop (combine.rs:160-182) fed straight from n device-resident data units (BITPIX -32 or 16,
  * all rows x cols of `out`): decode_pixels is fused into the kernel's gather, so BITPIX 16 stacks read 2 bytes per
  * sample from HBM and no decoded copy exists.  Result = ab_fits_decode_pixels + ab_stack_sigma_clip, bit for bit.
- * n must be 8, 16, 32 or 64. */
+ * n must be 8, 16, 32 or 64.  Every plane must hold rows x cols samples and be readable up to the next 4-byte boundary
+ * (BITPIX 16 with an odd pixel count: the last sample is fetched inside an aligned dword; a FITS data unit is padded to
+ * 2880 bytes, so a whole data unit always qualifies). */
 AB_API int ab_stack_sigma_clip_raw(ab_ctx *ctx, const void *const *raw_planes_dev, size_t n, int64_t bitpix, double bscale,
                                    double bzero, const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected);
 

@@ -42,7 +42,7 @@ def t(frames, label, it=5):
         ctx.stack_sigma_clip(frames, 3.0, 3.0, it, out=out, want_rejected=False)
     e1.record()
     torch.cuda.synchronize()
-    print(f"{label:46s} it={it}  {e0.elapsed_time(e1) / 5:7.3f} ms   rejected/px {ctx.last_rejected() / frames[0].numel():.3f}")
+    print(f"{label:46s} it={it}  {e0.elapsed_time(e1) / 5:7.3f} ms   kernels {ctx.stack_last_kernel_ms():6.3f} ms   rejected/px {ctx.last_rejected() / frames[0].numel():.3f}")
 
 
 for it in (1, 2, 3, 5):
