@@ -1195,7 +1195,7 @@ class Context:
         need = rows * cols * (abs(int(bitpix)) // 8)
         for t in raw_planes:
             assert _is_torch(t) and t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
-            if t.numel() < need:   # a truncated data unit would make the kernel read past the tensor
+            if bitpix in (-32, 16) and t.numel() < need:   # a truncated data unit would make the kernel read past the tensor
                 raise AstroBurstError(_lib.AB_ERR_INVALID, f"raw plane holds {t.numel()} bytes, {rows}x{cols} BITPIX {bitpix} needs {need}")
         self.use_torch_stream()
         ptrs = (C.c_void_p * len(raw_planes))(*[t.data_ptr() for t in raw_planes])

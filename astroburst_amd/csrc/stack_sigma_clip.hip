@@ -45,6 +45,7 @@ constexpr int kMaxFrames = 256;  // 65 .. 256: 2 / 4 registers of plane pointers
 constexpr int kMaxStrided = 64;  // ragged row strides only exist for the <= 64-frame kernels (deeper stacks are DIRECT or wide)
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
+constexpr int kDeferChunks = 2;          // chunks of 4 samples the fast pass may examine at either end before it defers a pixel
 enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
 enum { kInNative = 0, kInF32BE = 1, kInI16BE = 2 };  // sample encodings the gather understands
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
@@ -275,8 +276,11 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 }
 
 // One clipping pass over the two ends.  UPDATE: also fold the shaved samples into s_rem/q_rem.
-// DEFER (fast pass): look at the outermost chunk of each end only; a lane that would have to walk further is flagged
-// for the general pass instead of making its whole wave walk with it.
+// DEFER (fast pass): look at the outermost chunk of each end, and at a second one only if some lane of the wave asks for it;
+// a lane that would have to walk further still is flagged for the general pass instead of making its whole wave walk with
+// it.  (Round 1 stopped after ONE chunk: every pixel with 5 .. 8 rejected samples at one end -- the bands where a few frames
+// carry a zero border -- went to the general pass, whose scattered gathers cost ~6x a fast-pass pixel; a second chunk costs the
+// waves that need it ~40 instructions and everybody else one scalar branch.)
 // SKIP (single-pass kernel): the high-end walk starts at the chunk that holds the wave's largest b instead of stepping
 // over the pads of a ragged / padded stack four registers at a time (129 frames in 256 slots: 32 chunks per pass).
 template <int NP, bool UPDATE, bool DEFER = false, bool SKIP = false>
@@ -308,8 +312,10 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
         }
         const bool more = go && !found_lo && (CH * c + CH - 1 < b);
         if constexpr (DEFER) {
-            *defer = *defer || more;
-            break;
+            if (c == kDeferChunks - 1 || NP / CH == 1) {
+                *defer = *defer || more;
+                break;
+            }
         }
         if (!__any(more)) break;
     }
@@ -338,8 +344,10 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
         }
         const bool more = go && !found_hi && (NP - 1 - (CH * c + CH - 1) > a);
         if constexpr (DEFER) {
-            *defer = *defer || more;
-            break;
+            if (c == kDeferChunks - 1 || NP / CH == 1) {
+                *defer = *defer || more;
+                break;
+            }
         }
         if (!__any(more)) break;
     }
@@ -704,6 +712,10 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
     else
         r = clip_fast<NP, STAGE, MODE == kFastPass, MODE == kPlain>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
 
+    // (Tried: a wave with >= 4 deferring lanes -- the edge bands -- runs the general engine in place on the samples it still holds
+    // in registers: nothing is deferred any more, but the stack goes from 1.12 to 1.36 ms.  The second engine instance slows
+    // EVERY wave (1.07 vs 0.99 ms with the borders cropped away), and walking 60 zeros in 16 chunks costs those waves more than
+    // the general pass's gathers.)
     uint32_t rej = r.rej;
     const bool defer = MODE == kFastPass && valid && r.defer;
     if (valid && !defer) {
