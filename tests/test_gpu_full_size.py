@@ -100,3 +100,109 @@ def test_c5_narrowband_8192_masked_stretch_scnr_spcc(tctx):
     boosted = ctx.spcc_calibrate_rgb(red * 2.0, green, blue, 0.3)
     assert base.g_factor == 1.0 and base.stars_matched >= 50
     assert 0.4 < boosted.r_factor / base.r_factor < 0.75              # doubling R roughly halves its correction
+
+
+# ---- round 2: the configurations the round-1 verdict listed as never exercised at size ----------------------------------
+def test_c1_wfpc2_shape_align_stack_exact_stats_auto_stf(tctx, oracle):
+    """BASELINE configs[0] at its own size (4 x 1600 x 1600, the reference's CPU-runnable case), end to end against the oracle:
+    stack_from_paths (core/stacking/calibration.rs:297-318) = stack_images(align = true: phase correlation + sub-pixel shift)
+    -> compute_image_stats on the EXACT path (2.56 M px <= 4 M) -> auto_stf -> apply_stf."""
+    ctx = tctx
+    import torch
+    from astroburst_amd import synth
+    rows = cols = 1600
+    y, x, flux = synth.star_catalog(rows, cols, 300, seed=21)
+    cat = (y, x, flux * 20.0)
+    shifts = [(0.0, 0.0), (2.25, -1.5), (-3.0, 0.75), (1.5, 4.0)]
+    # a smooth nebular background (low dynamic range narrowband frame) + stars, each frame shifted and with its own noise
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, rows), torch.linspace(-1, 1, cols), indexing="ij")
+    nebula = 40.0 * torch.exp(-(xx ** 2 + 0.5 * yy ** 2) * 2.0)
+    frames = []
+    for k, sh in enumerate(shifts):
+        truth = 200.0 + nebula + synth.render_stars(rows, cols, cat, dy=sh[0], dx=sh[1])
+        frames.append(synth.make_frame(rows, cols, k, truth=truth, bad_patch_rate=0.0))
+    host = [f.numpy() for f in frames]
+    want, want_rej, want_off = oracle.stack_images_align(host, 3.0, 3.0, 5)
+    got = ctx.stack_images([f.cuda() for f in frames], 3.0, 3.0, 5, align=True)
+    assert got.offsets == want_off
+    assert got.rejected_pixels == want_rej
+    g = got.image.cpu().numpy()
+    assert np.array_equal(g, want, equal_nan=True)                   # shifts from our own FFT in both: bit for bit
+    st, wst = ctx.compute_image_stats(got.image), oracle.compute_image_stats(want)   # exact path: order statistics, not histograms
+    assert (st.min, st.max, st.median, st.mad, st.sigma, st.valid_count) == (wst.min, wst.max, wst.median, wst.mad, wst.sigma, wst.valid_count)
+    assert abs(st.mean - wst.mean) <= 1e-12 * abs(wst.mean)
+    p, wp = ctx.auto_stf(st), oracle.auto_stf(wst)
+    assert (p.shadow, p.midtone, p.highlight) == (wp.shadow, wp.midtone, wp.highlight)
+    u8, st2, p2 = ctx.auto_stretch_preview(got.image)                 # the same chain on the device, one synchronisation
+    assert (st2.median, st2.mad, p2.midtone) == (st.median, st.mad, p.midtone)
+    assert np.array_equal(u8.cpu().numpy(), oracle.apply_stf(want, wp, wst))
+
+
+def test_c4_per_gpu_leg_64x4096_partial_allreduce_finalize(tctx, oracle):
+    """BASELINE configs[3]'s per-GPU leg at full size: 64 x 4096 x 4096 frames -> ab_stack_sigma_clip_sharded on a one-rank
+    communicator (partial (sum f64, count u32) -> two real ncclAllReduce calls over 12 x 16.7 M bytes -> divide), against the
+    two-level estimator's own oracle on row crops (the oracle needs ~1 s per 8 rows at this width)."""
+    ctx = tctx
+    import torch
+    import astroburst_amd as ab
+    n, r, c = 64, 4096, 4096
+    frames = [gauss((r, c), 100 + k) for k in range(n)]
+    frames[5][2000:2004, :] = float("nan")
+    frames[9][:, 17] *= 30.0                                           # a hot column: rejected in every row
+    frames[9][0:16, :] = 0.0                                           # a zero border band: the deferred-pixel path
+    comm = ab.Comm(ctx, ab.Comm.unique_id(), 1, 0)
+    try:
+        out = torch.empty((r, c), device="cuda")
+        before = comm.collectives_issued
+        _, rej = ctx.stack_sigma_clip_sharded(comm, frames, out, want_rejected=True)
+        assert comm.collectives_issued - before == 3                    # sum, count, rejected
+        for row0 in (0, 1998, 4088):
+            crop = [f[row0:row0 + 8].cpu().numpy() for f in frames]
+            s, cnt, _ = oracle.stack_partial(crop, 3.0, 3.0, 5)
+            want = np.where(cnt > 0, (s / np.maximum(cnt, 1)).astype(np.float32), np.float32(0))
+            assert np.array_equal(out[row0:row0 + 8].cpu().numpy(), want), row0
+        # one shard holding every frame: the two-level estimate IS the single-level one wherever something survives
+        single, rej1 = ctx.stack_sigma_clip(frames, 3.0, 3.0, 5)
+        assert rej == rej1 and torch.equal(out, single)
+    finally:
+        comm.close()
+
+
+def test_c3_star_align_leg_at_nircam_size(tctx):
+    """BASELINE configs[2]'s registration leg at size: align_channel_affine on two 13759 x 12451 frames (171 Mpix: the detection
+    workspaces, 32-bit pixel indices and 54 x 49 tile grid at their largest), compared with the transform that generated
+    the target; then the warp and a 2-frame stack at that size."""
+    ctx = tctx
+    import math
+    import torch
+    from astroburst_amd import synth
+    rows, cols = 13759, 12451
+    n_stars = 6000
+    y, x, flux = synth.star_catalog(rows, cols, n_stars, seed=31)
+    flux = flux * 60.0
+    ang = math.radians(0.02)
+    ca, sa = math.cos(ang), math.sin(ang)
+    cx, cy = (cols - 1) / 2.0, (rows - 1) / 2.0
+    T = (ca, -sa, cx - ca * cx + sa * cy + 5.5, sa, ca, cy - sa * cx - ca * cy - 3.25)   # output (x, y) -> source
+    ref_truth = 200.0 + synth.render_stars(rows, cols, (y, x, flux), device="cuda")
+    ys, xs = T[3] * x + T[4] * y + T[5], T[0] * x + T[1] * y + T[2]
+    tgt_truth = 200.0 + synth.render_stars(rows, cols, (ys, xs, flux), device="cuda")
+    ref = synth.make_frame(rows, cols, 0, device="cuda", truth=ref_truth, bad_patch_rate=0.0)
+    tgt = synth.make_frame(rows, cols, 1, device="cuda", truth=tgt_truth, bad_patch_rate=0.0)
+    del ref_truth, tgt_truth
+    res = ctx.align_channel_affine(ref, tgt)
+    assert res.method in ("affine", "rigid"), res
+    assert res.inliers >= 10
+    worst = 0.0
+    for (px, py) in ((0.0, 0.0), (cols - 1.0, 0.0), (0.0, rows - 1.0), (cols - 1.0, rows - 1.0), (cx, cy)):
+        ex = (res.transform[0] - T[0]) * px + (res.transform[1] - T[1]) * py + (res.transform[2] - T[2])
+        ey = (res.transform[3] - T[3]) * px + (res.transform[4] - T[4]) * py + (res.transform[5] - T[5])
+        worst = max(worst, math.hypot(ex, ey))
+    assert worst < 0.5, worst                                          # sub-pixel at the corners of a 171 Mpix frame
+    aligned = ctx.warp_image(tgt, res.transform, rows, cols)
+    stacked, _ = ctx.stack_sigma_clip([ref, aligned], 3.0, 3.0, 5)
+    # the registered pair agrees where both are defined: star cores line up (a mis-registration would double every star)
+    inner = (slice(64, rows - 64), slice(64, cols - 64))
+    d = (aligned[inner] - ref[inner])
+    assert float(d.abs().median()) < 20.0
+    assert float(stacked[inner].max()) > 0.5 * float(ref[inner].max())
