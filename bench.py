@@ -118,6 +118,11 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
+    # stdout carries ONE JSON line: everything else that lands on fd 1 (RCCL prints a version banner there, at communicator
+    # creation and again at exit) goes to stderr; the JSON is written to the saved descriptor at the very end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import astroburst_amd as ab
@@ -463,7 +468,7 @@ def main():
             "roofline_warp": warp_roofline,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.close()
     if world > 1:
