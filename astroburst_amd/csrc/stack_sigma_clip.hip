@@ -39,13 +39,17 @@
     }
 #include "sortnet_gen.hpp"
 
+#ifndef AB_STACK_WAVES_PER_SIMD
+#define AB_STACK_WAVES_PER_SIMD 3  // 4 (128 VGPRs): 15 spilled registers, measured no faster
+#endif
+
 namespace {
 
 constexpr int kMaxFrames = 256;  // 65 .. 256: 2 / 4 registers of plane pointers, one wave per SIMD (see launch of NP = 128 / 256)
 constexpr int kMaxStrided = 64;  // ragged row strides only exist for the <= 64-frame kernels (deeper stacks are DIRECT or wide)
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
-constexpr int kDeferChunks = 2;          // chunks of 4 samples the fast pass may examine at either end before it defers a pixel
+constexpr int kDeferChunks = 2;          // chunks of 4 samples the fast pass may examine at either end before it defers a pixel (3: 1.165 ms against 1.116, every wave pays for the larger code)
 enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
 enum { kInNative = 0, kInF32BE = 1, kInI16BE = 2 };  // sample encodings the gather understands
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
@@ -755,7 +759,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
 }
 
 template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain, int INPUT = kInNative>
-__global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : 3) void stack_sigma_clip_kernel(const StackArgs args) {
+__global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : AB_STACK_WAVES_PER_SIMD) void stack_sigma_clip_kernel(const StackArgs args) {
     if constexpr (MODE == kGeneralPass) {
         const unsigned int cnt = args.defer_count[blockIdx.x];  // one block per list
         const int *list = args.defer_list + (size_t)blockIdx.x * args.defer_cap;

@@ -148,7 +148,7 @@ def main():
     ctx.use_torch_stream()
     name, cus, hbm = ctx.device_info()
     sharded = world > 1 or args.force_sharded
-    rowband = world > 1 and args.mode == "rowband"
+    rowband = sharded and args.mode == "rowband"   # (with --force-sharded: one band = the whole image, the same code path)
     # the library's own communicator (RCCL behind the C ABI): rank 0 makes the id, torch.distributed carries it
     comm = None
     if sharded:
