@@ -161,7 +161,7 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
 }
 
 // The same statistics from ONE histogram of the tile (tile_bucket.hpp): the product kernel.  tile_background_kernel above is
-// the round-1 radix-select version, kept behind AB_TILE_LEGACY=1 as an in-library cross-check (tests run both).
+// the round-1 radix-select version, kept behind AB_TILE_LEGACY=1 as an in-library cross-check (tests/test_gpu_tile_stats.py runs both).
 __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
                                                                               int step, int ntx, const ab_pixel_xf xf, TileOut *__restrict__ out) {
     __shared__ tb::Shared sh;

@@ -78,7 +78,8 @@ AB_API int ab_download(ab_ctx *ctx, void *dst_host, const void *src_device, size
 /* Progress / cancel (infra/progress.rs:39-74; taken as Option<&ProgressHandle> by core/imaging/background.rs:55-59).
  * cb(stage, current, total, user) is called on the calling thread at the reference's own stage boundaries with its stage
  * strings ("sampling background", "fitting polynomial surface", "generating model", "applying correction") and once per
- * frame by the frame loops (stage "register" / "stack"); NULL removes it.  ab_ctx_request_cancel may be called from any
+ * frame by the frame loops (stage "registration" for ab_register_frames / ab_align_pairs_affine, "subframe" for
+ * ab_analyze_subframes); NULL removes it.  ab_ctx_request_cancel may be called from any
  * thread: the next stage boundary returns AB_ERR_CANCELLED ("Operation cancelled") and leaves the flag set until
  * ab_ctx_clear_cancel. */
 typedef void (*ab_progress_cb)(const char *stage, uint64_t current, uint64_t total, void *user);

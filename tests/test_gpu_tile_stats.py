@@ -109,3 +109,26 @@ def test_normalised_frame_tiles(ctx, oracle):
     norm = oracle.normalize_for_detection(frame)
     check(ctx, oracle, norm, 128)
     check(ctx, oracle, frame, 128)
+
+
+def test_round1_kernel_behind_ab_tile_legacy():
+    """AB_TILE_LEGACY=1 (read once per process) selects round 1's radix-select tile kernel: same per-tile answers.
+    Run in a child process so that both kernels are exercised by one `pytest -m gpu`."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import astroburst_amd as ab\n"
+        "from oracle import pyoracle as oracle\n"
+        "from tests.test_gpu_tile_stats import adversarial_image, check\n"
+        "ctx = ab.Context(0)\n"
+        "with np.errstate(all='ignore'):\n"
+        "    for tile, seed in ((64, 4), (256, 7)):\n"
+        "        check(ctx, oracle, adversarial_image(tile, seed), tile)\n"
+        "print('legacy-ok')\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AB_TILE_LEGACY="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "legacy-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
