@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -34,6 +35,7 @@ enum {
     AB_WS_BATCH_PAD,          // one plane of FLT_MAX: the same for the batch stack (where +inf is a sample like any other)
     AB_WS_STATS,              // state block, 65 536-bin histograms and partials of the statistics chain (stats.hip)
     AB_WS_SHARD,              // (sum f64, count u32) partial planes of the frame-sharded stack (sharded.hip)
+    AB_WS_SUBSAMPLE,          // the <= ~100 000-pixel subsample normalize_for_detection takes its percentiles from
     AB_WS_SLOTS
 };
 
@@ -206,3 +208,21 @@ int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t
                          const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only);
 
 static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// AB_TRACE=1: wall-clock stamps of the host-visible stages on stderr (developer aid)
+struct ab_trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    explicit ab_trace(const char *what) : on(getenv("AB_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {
+        if (on) fprintf(stderr, "[ab_trace] %s:", what);
+    }
+    void mark(const char *stage) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, " %s %.3f ms;", stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+    ~ab_trace() {
+        if (on) fprintf(stderr, "\n");
+    }
+};

@@ -36,24 +36,6 @@ namespace {
 
 constexpr double kMadToSigma = 1.4826;
 
-// AB_TRACE=1: wall-clock stamps of the host-visible stages on stderr (developer aid)
-struct Trace {
-    bool on;
-    std::chrono::steady_clock::time_point t0;
-    explicit Trace(const char *what) : on(getenv("AB_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {
-        if (on) fprintf(stderr, "[ab_trace] %s:", what);
-    }
-    void mark(const char *stage) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, " %s %.3f ms;", stage, std::chrono::duration<double, std::milli>(t1 - t0).count());
-        t0 = t1;
-    }
-    ~Trace() {
-        if (on) fprintf(stderr, "\n");
-    }
-};
-
 // ---- per-tile sigma-clipped statistics ---------------------------------------------------------
 struct TileOut {
     double median, sigma;
@@ -174,6 +156,7 @@ __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(co
     const int c = tx0 + tx;
     const bool col_ok = c < x1;
     tb::Keys K;
+    tb::KeyRange kr;
     constexpr int kBatch = 32;
 #pragma unroll
     for (int h = 0; h < tb::kSlots / kBatch; ++h) {
@@ -186,10 +169,12 @@ __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(co
 #pragma unroll
         for (int i = 0; i < kBatch; ++i) {
             const float v = ab_px(xf, raw[i]);
-            K.v[(h * kBatch + i) >> 5][(h * kBatch + i) & 31] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
+            const uint32_t key = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
+            K.v[(h * kBatch + i) >> 5][(h * kBatch + i) & 31] = key;
+            kr.add(key);
         }
     }
-    const tb::TileResult r = tb::tile_stats(K, sh);
+    const tb::TileResult r = tb::tile_stats(K, sh, kr);
     if (threadIdx.x == 0) {
         TileOut o;
         o.median = r.median;
@@ -589,7 +574,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     if (rows < 3 || cols < 3) return AB_OK;  // :89-98
     AB_CHECK(ctx, rows * cols < (int64_t(1) << 31), "detect_stars: image too large for 32-bit labels");
     AB_HIP(ctx, hipSetDevice(ctx->device));
-    Trace trace("detect_stars");
+    ab_trace trace("detect_stars");
     const int64_t m = std::min(rows, cols);
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // :100
     double bg_median, bg_sigma;
@@ -718,25 +703,144 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
 
 // normalize_for_detection's parameters (affine.rs:24-47): the 1st and 99.9th percentile of an every-step subsample.
 // xf->on = 0 when the reference returns image.clone() (too few finite samples / flat range).
+// The 1 % / 99.9 % order statistics of the finite subsample values (affine.rs:33-42 sorts the subsample; only these two
+// elements of the sorted list are read), by ONE 1024-thread workgroup: an 11 / 11 / 10-bit radix select on the monotone image
+// of the float bit patterns (any sign), both ranks descending together -- three sweeps over ~100 000 values in L2.  The first
+// version copied the subsample to the host and ran std::nth_element twice: 0.7 .. 1.2 ms of a worker thread per frame, the
+// largest single item of the registration stage's per-frame host time.
+struct PercentileOut {
+    float lo, hi;
+    unsigned int finite;  // count of finite subsample values
+    unsigned int pad;
+};
+__device__ __forceinline__ uint32_t ordered_key(float v) {  // monotone for every finite float (-0.0 sorts just below +0.0)
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// histogram update with the wave's first bin tallied by ballot: sky pixels share their top bits, and 64 lanes adding to one LDS
+// address serialise
+__device__ __forceinline__ void tally(unsigned int *hist, bool on, uint32_t bin) {
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(on);
+    if (!act) return;
+    const uint32_t mode = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)__builtin_ctzll(act));
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(on && bin == mode);
+    if ((threadIdx.x & 63) == (int)__builtin_ctzll(act)) atomicAdd(&hist[mode], (unsigned int)__builtin_popcountll(same));
+    if (on && bin != mode) atomicAdd(&hist[bin], 1u);
+}
+
+// the bin of `hist[0 .. 2048)` that holds 0-based rank r, and r's rank inside it; every thread gets the answer (block of 1024)
+__device__ __forceinline__ void find_rank_2048(const unsigned int *hist, unsigned int *wave_tot /* 16 */, unsigned int *bcast /* 2 */,
+                                               unsigned int r, unsigned int *bin, unsigned int *within) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned int h0 = hist[2 * t], h1 = hist[2 * t + 1], mine = h0 + h1;
+    unsigned int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();  // (wave_tot / bcast may still be read from the previous call)
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    unsigned int base = 0;
+    for (int i = 0; i < wv; ++i) base += wave_tot[i];
+    const unsigned int excl = base + inc - mine;
+    if (r >= excl && r < excl + mine) {  // exactly one thread
+        const bool second = r - excl >= h0;
+        bcast[0] = 2u * t + (second ? 1u : 0u);
+        bcast[1] = r - excl - (second ? h0 : 0u);
+    }
+    __syncthreads();
+    *bin = bcast[0];
+    *within = bcast[1];
+}
+
+__global__ __launch_bounds__(1024) void subsample_percentiles_kernel(const float *__restrict__ s, unsigned int ns, PercentileOut *__restrict__ out) {
+    __shared__ unsigned int hist[2][2048];
+    __shared__ unsigned int wave_tot[16], bcast[2];
+    const int t = threadIdx.x;
+    for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    // level 0: key bits 31..21 of every finite value; the total is the finite count
+    for (unsigned int i0 = 0; i0 < ns; i0 += 1024) {
+        const unsigned int i = i0 + t;
+        const float v = i < ns ? s[i] : __builtin_nanf("");
+        const bool ok = fabsf(v) <= 3.4028234663852886e38f;  // finite (NaN fails)
+        tally(hist[0], ok, ordered_key(v) >> 21);
+    }
+    __syncthreads();
+    unsigned int m = 0;
+    {
+        const unsigned int mine = hist[0][2 * t] + hist[0][2 * t + 1];
+        unsigned int x = mine;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((t & 63) == 0) wave_tot[t >> 6] = x;
+        __syncthreads();
+        for (int i = 0; i < 16; ++i) m += wave_tot[i];
+    }
+    if (m < 100u) {  // affine.rs:34-36: too few samples, the frame is used as it is
+        if (t == 0) *out = PercentileOut{0.0f, 0.0f, m, 0u};
+        return;
+    }
+    unsigned int r[2] = {m / 100u, (unsigned int)((uint64_t)m * 999u / 1000u)};  // affine.rs:41-42
+    uint32_t prefix[2];
+    {
+        unsigned int b0, w0, b1, w1;
+        find_rank_2048(hist[0], wave_tot, bcast, r[0], &b0, &w0);
+        find_rank_2048(hist[0], wave_tot, bcast, r[1], &b1, &w1);
+        prefix[0] = b0 << 21;
+        prefix[1] = b1 << 21;
+        r[0] = w0;
+        r[1] = w1;
+    }
+    // levels 1 (bits 20..10) and 2 (bits 9..0): both ranks in the same sweep, one histogram each
+    for (int level = 1; level <= 2; ++level) {
+        const int shift = level == 1 ? 10 : 0;
+        const uint32_t digit_mask = level == 1 ? 2047u : 1023u, prefix_mask = level == 1 ? 0xffe00000u : 0xfffffc00u;
+        __syncthreads();
+        for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        for (unsigned int i0 = 0; i0 < ns; i0 += 1024) {
+            const unsigned int i = i0 + t;
+            const float v = i < ns ? s[i] : __builtin_nanf("");
+            const bool ok = fabsf(v) <= 3.4028234663852886e38f;
+            const uint32_t k = ordered_key(v), d = (k >> shift) & digit_mask;
+            if (ok && (k & prefix_mask) == prefix[0]) atomicAdd(&hist[0][d], 1u);
+            if (ok && (k & prefix_mask) == prefix[1]) atomicAdd(&hist[1][d], 1u);
+        }
+        __syncthreads();
+        for (int q = 0; q < 2; ++q) {
+            unsigned int b, w;
+            find_rank_2048(hist[q], wave_tot, bcast, r[q], &b, &w);
+            prefix[q] |= b << shift;
+            r[q] = w;
+        }
+    }
+    if (t == 0) *out = PercentileOut{ordered_value(prefix[0]), ordered_value(prefix[1]), m, 0u};
+}
+
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     *xf = ab_pixel_xf();
     if (len == 0) return AB_OK;
     const int64_t step = std::max<int64_t>(len / 100000, 1);
     const int64_t ns = (len + step - 1) / step;
-    void *pin = nullptr;  // the subsample is written straight into pinned host memory
-    AB_TRY(ab_pinned(ctx, (size_t)ns * sizeof(float), &pin));
-    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, len, step, (float *)pin, ns);
+    float *sub = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_SUBSAMPLE, (size_t)ns * sizeof(float), (void **)&sub));
+    void *pin = nullptr;  // the kernel writes its 16 bytes straight into pinned host memory
+    AB_TRY(ab_pinned(ctx, sizeof(PercentileOut), &pin));
+    ab_trace trace("normalize_params");
+    hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, len, step, sub, ns);
+    hipLaunchKernelGGL(subsample_percentiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<float> s((const float *)pin, (const float *)pin + ns);
-    s.erase(std::remove_if(s.begin(), s.end(), [](float v) { return !std::isfinite(v); }), s.end());
-    if (s.size() < 100) return AB_OK;
-    // the reference sorts the subsample (:37-40); only two order statistics of it are read
-    const size_t k_lo = s.size() / 100, k_hi = s.size() * 999 / 1000;
-    std::nth_element(s.begin(), s.begin() + k_hi, s.end());
-    std::nth_element(s.begin(), s.begin() + k_lo, s.begin() + k_hi);
-    const double lo = (double)s[k_lo], hi = (double)s[k_hi];
+    trace.mark("subsample+percentiles+sync");
+    const PercentileOut po = *(const PercentileOut *)pin;
+    if (po.finite < 100) return AB_OK;
+    const double lo = (double)po.lo, hi = (double)po.hi;
     const double range = hi - lo;
     if (range < 1e-15) return AB_OK;
     xf->lo = lo;

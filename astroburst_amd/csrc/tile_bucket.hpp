@@ -45,18 +45,18 @@ constexpr int kThreads = 512;  // one workgroup per tile
 constexpr int kWaves = kThreads / 64;
 constexpr int kSlots = 128;    // pixels per thread: 256 x 256 / 512
 constexpr int kBuckets = 4096;
-constexpr int kSeg = 256;                // gathered candidates a wave may append (its private segment of the list)
-constexpr int kListCap = kSeg * kWaves;  // 2048 u32 keys
+constexpr int kOwn = 8;         // gathered candidates a THREAD may hold (its private column of the list); more = overflow
+constexpr int kListCap = 2048;  // gathered candidates a select works on (u32 keys)
 
 struct Shared {
     unsigned int prefix[kBuckets];  // bucket counts, then their inclusive prefix sum
-    unsigned int list[kListCap];    // per-wave segments while gathering
-    unsigned int tmp[kListCap];     // the segments compacted to the front (what the select reads) / scan scratch
+    unsigned int list[(kOwn + 1 + kSlots / 32) * kThreads];  // while gathering: row r, column t = the r-th candidate of thread t (+ overflow rows)
+    unsigned int tmp[kListCap];     // the candidates compacted to the front (what the select reads) / scan scratch
     unsigned int wave_part[kWaves * 4];  // per-wave partials of the block reductions
-    unsigned int seg_n[kWaves];
+    unsigned int found_part[kWaves];     // per-wave totals of a gather (compact_list)
     unsigned int hist[256];  // wave 0's radix-select histogram
     unsigned int scal[16];   // broadcast slots
-    long long t_phase[8];    // AB_TILE_TIMING: cycles per phase (thread 0): 0 setup + histogram + scan + window counts; value select:
+    long long t_phase[16];   // AB_TILE_TIMING: cycles per phase (thread 0): 0 setup + histogram + scan + window counts; value select:
                              // 1 bucket search 2 gather 3 select; deviation select: 4 round 1 5 round 2 + bounds 6 gather 7 select
     long long t_mark;
 };
@@ -132,6 +132,21 @@ __device__ __forceinline__ unsigned int wave_scan_incl(unsigned int x) {
     return x;
 }
 
+// the wave's 64 values sorted ascending across its lanes (bitonic network on lane shuffles: 21 exchanges)
+__device__ __forceinline__ uint32_t wave_sort64(uint32_t x) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            const uint32_t y = (uint32_t)__shfl_xor((int)x, j, 64);
+            const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
+            x = keep_min ? min(x, y) : max(x, y);
+        }
+    }
+    return x;
+}
+
 // up to four values reduced over the workgroup; every thread gets the results (two barriers)
 enum { OP_SUM = 0, OP_MIN = 1, OP_MAX = 2 };
 template <int OP0, int OP1, int OP2, int OP3>
@@ -163,30 +178,6 @@ __device__ __forceinline__ void block_reduce4(Shared &sh, unsigned int &a, unsig
     b = rb;
     c = rc;
     d = rd;
-}
-
-// two f32 sums over the workgroup (fixed shape: the result only steers where the histogram zooms, never a statistic)
-__device__ __forceinline__ void block_sum2f(Shared &sh, float &a, float &b) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        a += __shfl_xor(a, off, 64);
-        b += __shfl_xor(b, off, 64);
-    }
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-        sh.wave_part[2 * w] = __float_as_uint(a);
-        sh.wave_part[2 * w + 1] = __float_as_uint(b);
-    }
-    __syncthreads();
-    float ra = 0.0f, rb = 0.0f;
-#pragma unroll
-    for (int i = 0; i < kWaves; ++i) {
-        ra += __uint_as_float(sh.wave_part[2 * i]);
-        rb += __uint_as_float(sh.wave_part[2 * i + 1]);
-    }
-    a = ra;
-    b = rb;
 }
 
 // (v as f64 - median).abs() as f32, as a monotone key (sigma_clip.rs:15,31)
@@ -245,68 +236,91 @@ __device__ __forceinline__ unsigned int count_dev_le(const Keys &K, Shared &sh, 
     return c;
 }
 
-// Gather: every wave appends to ITS segment of the list, the running count lives in a scalar register -- no atomics, nothing to
-// wait for.  `wcount` is wave-uniform; entries past the segment are dropped while the count keeps counting (overflow is detected
-// by the caller).
-__device__ __forceinline__ void seg_push(Shared &sh, unsigned int &wcount, unsigned long long m, bool take, uint32_t v) {
-    const unsigned int at = wcount + __builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
-    if (take && at < (unsigned int)kSeg) sh.list[(threadIdx.x >> 6) * kSeg + at] = v;
-    wcount += (unsigned int)__builtin_popcountll(m);
-}
-
 struct GatherArgs {
     uint32_t lo, hi;                      // outer key range (lo <= hi, lo >= 1)
     uint32_t x1_lo, x1_hi, x2_lo, x2_hi;  // excluded runs (empty: lo > hi)
     double median;
 };
-// one gather sweep over the thread's keys: appends every key in [lo, hi] outside the excluded runs -- as the key (DEV = false) or
-// as its deviation key.  Four slots share one branch: a slot costs one subtract-compare, a group one scalar test; only the rare
-// group that holds a match goes through the excluded runs, forms deviations and appends.
+// One gather sweep over the thread's keys: every key in [lo, hi] outside the excluded runs goes to the thread's OWN column of
+// the list -- row = how many it has found so far: no ballots, no lane ranks, a predicated store per key.  (The first version
+// appended per wave through ballot + mbcnt under a per-group branch; the rings of a deviation gather hold one key in a hundred,
+// so nine groups in ten took the slow path: 25 000 cycles per sweep.)  Returns the thread's count, kOwn + 1 meaning "more than
+// kOwn" (compact_list reports the overflow).
 template <bool DEV>
 __device__ __forceinline__ unsigned int gather_sweep(const Keys &K, Shared &sh, const GatherArgs &g) {
-    unsigned int wcount = 0;
-    const uint32_t width = g.hi - g.lo;
-#pragma unroll 1
-    for (int j = 0; j < 32; ++j) {
-        uint32_t k[kVecs];
-        unsigned long long any = 0;
-#pragma unroll
-        for (int c = 0; c < kVecs; ++c) {
-            k[c] = K.v[c][j];
-            any |= __builtin_amdgcn_ballot_w64(k[c] - g.lo <= width);  // lo <= k <= hi in one unsigned compare
-        }
-        if (any) {
-#pragma unroll
-            for (int c = 0; c < kVecs; ++c) {
-                bool in = k[c] - g.lo <= width;
-                if (DEV) in = in && !(k[c] >= g.x1_lo && k[c] <= g.x1_hi) && !(k[c] >= g.x2_lo && k[c] <= g.x2_hi);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(in);
-                if (m) seg_push(sh, wcount, m, in, DEV ? dev_key(k[c], g.median) : k[c]);
+    // the wanted keys as (at most) two plain runs [l1, l1 + w1] and [l2, l2 + w2]: the outer range with ONE excluded run cut
+    // out of it -- the usual shape of a deviation gather (two rings around the median).  With two excluded runs (the median's
+    // own bucket left between them) the outer range is tested and the runs are taken out explicitly.
+    constexpr uint32_t kNever = 0xffffffffu;  // run [kNever, kNever]: k - kNever <= 0 never holds for a key
+    const bool two_excl = DEV && g.x1_lo <= g.x1_hi && g.x2_lo <= g.x2_hi;
+    uint32_t l1 = g.lo, w1 = g.hi - g.lo, l2 = kNever, w2 = 0;
+    if (DEV && !two_excl) {
+        const uint32_t ex_lo = g.x1_lo <= g.x1_hi ? g.x1_lo : g.x2_lo, ex_hi = g.x1_lo <= g.x1_hi ? g.x1_hi : g.x2_hi;
+        if (ex_lo <= ex_hi && ex_hi >= g.lo && ex_lo <= g.hi) {  // an excluded run that meets the outer range
+            if (ex_lo > g.lo) {
+                l1 = g.lo;
+                w1 = ex_lo - 1u - g.lo;
+            } else {
+                l1 = kNever;
+                w1 = 0;
+            }
+            if (ex_hi < g.hi) {
+                l2 = ex_hi + 1u;
+                w2 = g.hi - l2;
             }
         }
     }
-    return wcount;
+    // the thread's write cursor: a row index; rows 0 .. kOwn - 1 are what compact_list reads, row kOwn marks "more than kOwn"
+    // (the cursor is clamped there once per group of kVecs keys, so up to kVecs - 1 further rows can be written in between)
+    unsigned int cnt = 0;
+    unsigned int *const col = &sh.list[threadIdx.x];
+    auto put = [&](uint32_t k, bool in) {
+        if (in) {
+            col[cnt * kThreads] = k;
+            ++cnt;
+        }
+    };
+#pragma unroll 1
+    for (int j = 0; j < 32; ++j) {
+#pragma unroll
+        for (int c = 0; c < kVecs; ++c) {
+            const uint32_t k = K.v[c][j];
+            bool in = (k - l1 <= w1) | (DEV & (k - l2 <= w2));  // lo <= k <= hi in one unsigned compare
+            if (two_excl) in = in & !((k >= g.x1_lo) & (k <= g.x1_hi)) & !((k >= g.x2_lo) & (k <= g.x2_hi));
+            put(k, in);
+        }
+        cnt = cnt < (unsigned int)(kOwn + 1) ? cnt : (unsigned int)(kOwn + 1);
+    }
+    return cnt;
 }
 
-// after the sweep: segment sizes -> compact the segments to the front of sh.tmp.  Returns the total (every thread), or
-// 0xffffffff if a segment overflowed.
-__device__ __forceinline__ unsigned int seg_compact(Shared &sh, unsigned int wcount) {
+// After the sweep: the columns compacted to the front of sh.tmp in thread order (as deviation keys if DEV).  Returns the total
+// (every thread), or 0xffffffff if a thread found more than kOwn or the total exceeds kListCap.
+template <bool DEV>
+__device__ __forceinline__ unsigned int compact_list(Shared &sh, unsigned int cnt, double median) {
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) sh.seg_n[w] = wcount;
+    const unsigned int incl = wave_scan_incl(cnt);
+    const unsigned int over = __builtin_amdgcn_ballot_w64(cnt > (unsigned int)kOwn) ? 1u : 0u;
+    if (lane == 63) sh.found_part[w] = incl | (over << 31);
     __syncthreads();
-    unsigned int before = 0, total = 0, worst = 0;
+    unsigned int before = 0, total = 0, bad = 0;
 #pragma unroll
     for (int i = 0; i < kWaves; ++i) {
-        const unsigned int n = sh.seg_n[i];
+        const unsigned int v = sh.found_part[i];
+        const unsigned int n = v & 0x7fffffffu;
+        bad |= v >> 31;
         before += i < w ? n : 0u;
         total += n;
-        worst = worst > n ? worst : n;
     }
-    if (worst > (unsigned int)kSeg) {
+    if (bad || total > (unsigned int)kListCap) {
         __syncthreads();
         return 0xffffffffu;
     }
-    for (unsigned int i = lane; i < wcount; i += 64) sh.tmp[before + i] = sh.list[w * kSeg + i];
+    const unsigned int at = before + incl - cnt;
+    for (unsigned int i = 0; i < cnt; ++i) {
+        const uint32_t k = sh.list[i * kThreads + threadIdx.x];
+        sh.tmp[at + i] = DEV ? dev_key(k, median) : k;
+    }
     __syncthreads();
     return total;
 }
@@ -417,8 +431,10 @@ __device__ __forceinline__ void select_values(const Keys &K, Shared &sh, const F
         ga.x1_lo = ga.x2_lo = 1;
         ga.x1_hi = ga.x2_hi = 0;
         ga.median = 0.0;
-        const unsigned int wcount = gather_sweep<false>(K, sh, ga);
-        const unsigned int n = seg_compact(sh, wcount);
+        TB_MARK(sh, 2);
+        const unsigned int found = gather_sweep<false>(K, sh, ga);
+        TB_MARK(sh, 14);
+        const unsigned int n = compact_list<false>(sh, found, 0.0);
         TB_MARK(sh, 2);
         if (n != 0xffffffffu) {
             if (threadIdx.x < 64) {
@@ -564,6 +580,101 @@ __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Fra
         while (b < f.nb - 1 && c.left_of_median(f.first_key(b + 1))) ++b;
         c.bm = b;
     }
+    // ---- fast path: guess the ring, verify afterwards ------------------------------------------------------------------------
+    // F~(t) = window candidates in the buckets that meet [median - t, median + t] is a step-function approximation of
+    // F(t) = #{deviation <= t}, good to a bucket or so on either side.  512 threads evaluate it at 4096 thresholds one bucket
+    // width apart (integer arithmetic on the prefix sum: no deviations are formed) and the first threshold t* with
+    // F~(t*) >= r_hi + 1 places the wanted deviations.  The candidates are then the buckets within kRing (2) bucket widths of
+    // median -+ t* (two rings), the buckets between the rings count as "smaller" and everything outside as "larger" -- a GUESS,
+    // turned into a proof after the select: the largest deviation possible between the rings must not exceed the smaller
+    // selected deviation and the smallest possible outside must not fall below the larger one (deviations fall towards the
+    // median and rise away from it, so both extremes sit at run ends).  A guess that fails, overflows the list or meets a
+    // catch-all bucket drops to the rigorous bracket search below (binade boundaries inside the window, bimodal tiles).
+    // Measured: the bracket search cost 32 000 of a tile's 130 000 cycles per clipping iteration, this path ~2 000.
+    if (c.bm > 0 && c.bm < f.nb - 1) {
+        constexpr int kRing = 2;
+        constexpr int PERT = kBuckets / kThreads;
+        const float mf = (float)median;
+        const float delta = __uint_as_float(f.first_key(c.bm) + (1u << f.shift)) - __uint_as_float(f.first_key(c.bm));
+        auto bucket_at = [&](float x) { return x > 0.0f ? f.bucket_of(x < 3.0e38f ? __float_as_uint(x) : 0x7f7fffffu) : 0; };
+        auto ring_of = [&](float t, int *bl, int *br) {  // the buckets that hold median - t and median + t, either side of bm
+            const int l = bucket_at(mf - t), r = bucket_at(mf + t);
+            *bl = l < c.bm ? l : c.bm;
+            *br = r > c.bm ? r : c.bm;
+        };
+        unsigned int first = 0xffffffffu, z0 = 0, z1 = 0, z2 = 0;
+#pragma unroll
+        for (int j = 0; j < PERT; ++j) {
+            const unsigned int i = (unsigned int)(j * kThreads) + threadIdx.x;
+            int bl, br;
+            ring_of((float)(i + 1u) * delta, &bl, &br);
+            const unsigned int F = wprefix(sh, w, br + 1) - wprefix(sh, w, bl);
+            if (F >= r_hi + 1u) first = first < i ? first : i;
+        }
+        block_reduce4<OP_MIN, OP_SUM, OP_SUM, OP_SUM>(sh, first, z0, z1, z2);
+        TB_MARK(sh, 4);
+        if (first != 0xffffffffu && delta > 0.0f) {
+            int bLo, bRo, bLi = 0, bRi = 0;
+            ring_of((float)(first + 1u + kRing) * delta, &bLo, &bRo);
+            const bool has_inner_t = first + 1u > (unsigned int)kRing;
+            if (has_inner_t) ring_of((float)(first + 1u - kRing) * delta, &bLi, &bRi);
+            const bool has_inner = has_inner_t && bLi + 1 <= bRi - 1;  // inner buckets: strictly between the two rings
+            const unsigned int c_in = has_inner ? wprefix(sh, w, bRi) - wprefix(sh, w, bLi + 1) : 0u;
+            const unsigned int n_cand = wprefix(sh, w, bRo + 1) - wprefix(sh, w, bLo) - c_in;
+            if (bLo > 0 && bRo < f.nb - 1 && c_in <= r_lo && c_in + n_cand >= r_hi + 1u && n_cand <= (unsigned int)kListCap) {
+                GatherArgs ga;
+                ga.lo = f.first_key(bLo) > w.lo ? f.first_key(bLo) : w.lo;
+                ga.hi = f.last_key(bRo) < w.hi ? f.last_key(bRo) : w.hi;
+                ga.x1_lo = ga.x2_lo = 1;
+                ga.x1_hi = ga.x2_hi = 0;
+                if (has_inner) {
+                    ga.x1_lo = f.first_key(bLi + 1);
+                    ga.x1_hi = f.last_key(bRi - 1);
+                }
+                ga.median = median;
+                TB_MARK(sh, 6);
+                const unsigned int found = gather_sweep<true>(K, sh, ga);
+                TB_MARK(sh, 14);
+                const unsigned int n = compact_list<true>(sh, found, median);
+                TB_MARK(sh, 6);
+                if (n == n_cand) {
+                    if (threadIdx.x < 64) {
+                        uint32_t a, b;
+                        wave_select2(sh, n, r_lo - c_in, r_hi - c_in, &a, &b);
+                        if (threadIdx.x == 0) {
+                            sh.scal[1] = a;
+                            sh.scal[2] = b;
+                        }
+                    }
+                    __syncthreads();
+                    const uint32_t sel_lo = sh.scal[1], sel_hi = sh.scal[2];
+                    __syncthreads();
+                    // the proof: inner deviations <= sel_lo, outer deviations >= sel_hi
+                    uint32_t t_in = 0, t_out = 0xffffffffu;
+                    if (has_inner) {
+                        const uint32_t ka = ga.x1_lo > w.lo ? ga.x1_lo : w.lo, kb = ga.x1_hi < w.hi ? ga.x1_hi : w.hi;
+                        if (ka <= kb) {
+                            const uint32_t da = dev_key(ka, median), db = dev_key(kb, median);
+                            t_in = da > db ? da : db;
+                        }
+                    }
+                    if (ga.lo > w.lo) t_out = dev_key(ga.lo - 1u, median);  // (ga.lo - 1 lies left of the median: bLo <= bm)
+                    if (ga.hi < w.hi) {
+                        const uint32_t d = dev_key(ga.hi + 1u, median);
+                        t_out = t_out < d ? t_out : d;
+                    }
+                    TB_MARK(sh, 7);
+                    if (t_in <= sel_lo && sel_hi <= t_out) {
+                        *d_lo = sel_lo;
+                        *d_hi = sel_hi;
+                        return;
+                    }
+                }
+            }
+        }
+    }
+    TB_MARK(sh, 13);
+    // ---- rigorous path ----------------------------------------------------------------------------------------------------
     // A bucket's largest deviation t is a threshold with two bounds on F(t) = #{deviation <= t} from the prefix sum alone:
     //   N_any(t) <= r_lo      =>  the wanted deviations are > t        (best such t: the largest)
     //   N_full(t) >= r_hi + 1 =>  the wanted deviations are <= t       (best such t: the smallest)
@@ -649,8 +760,8 @@ __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Fra
         ga.x2_lo = x2_lo;
         ga.x2_hi = x2_hi;
         ga.median = median;
-        const unsigned int wcount = gather_sweep<true>(K, sh, ga);
-        const unsigned int n = seg_compact(sh, wcount);  // == n_cand
+        const unsigned int found = gather_sweep<true>(K, sh, ga);
+        const unsigned int n = compact_list<true>(sh, found, median);  // == n_cand
         TB_MARK(sh, 6);
         if (n != 0xffffffffu) {
             if (threadIdx.x < 64) {
@@ -711,45 +822,84 @@ __device__ __forceinline__ uint32_t sample_key(const Keys &K) {
     }
 }
 
+// min / max / count of a thread's candidate keys, accumulated while the keys are formed (static register indices: three
+// instructions per key, where a separate sweep through the index register cost 30 000 cycles)
+struct KeyRange {
+    unsigned int kmin1 = 0xffffffffu, kmax = 0, cnt = 0;  // kmin1 = min(key - 1): the non-candidate 0 wraps to the top and never wins
+    __device__ __forceinline__ void add(uint32_t k) {
+        kmin1 = min(kmin1, k - 1u);
+        kmax = max(kmax, k);
+        cnt += k ? 1u : 0u;
+    }
+};
+
 // sigma_clipped_stats(values, 3.0, 2) of the candidates in K (sigma_clip.rs:4-34); needs >= 8 candidates (star_detection.rs:61)
-__device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
+__device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh, const KeyRange &kr) {
     constexpr double kMadToSigma = 1.4826;
 #ifdef AB_TILE_TIMING
     if (threadIdx.x == 0) {
-        for (int i = 0; i < 8; ++i) sh.t_phase[i] = 0;
+        for (int i = 0; i < 16; ++i) sh.t_phase[i] = 0;
         sh.t_mark = clock64();
     }
 #endif
     // ---- min / max / count of the candidates ----
-    unsigned int kmin = 0xffffffffu, kmax = 0, cnt = 0, z = 0;
-    for_each_key(K, [&](uint32_t k) {
-        kmin = min(kmin, k - 1u);  // (k - 1: the non-candidate 0 wraps to the top and never wins the minimum)
-        kmax = max(kmax, k);
-        cnt += k ? 1u : 0u;
-    });
+    unsigned int kmin = kr.kmin1, kmax = kr.kmax, cnt = kr.cnt, z = 0;
     kmin += 1u;  // 0xffffffff + 1 = 0 when the thread holds no candidate: fixed up after the reduction
     if (kmin == 0) kmin = 0xffffffffu;
     block_reduce4<OP_MIN, OP_MAX, OP_SUM, OP_SUM>(sh, kmin, kmax, cnt, z);
+    TB_MARK(sh, 9);
     TileResult res = {0.0, 1.0, 0};
     if (cnt < 8) return res;
     res.valid = 1;
-    // ---- where to zoom: mean +- 6 mean-absolute-deviations of a 512-pixel sample (efficiency only: any window is exact) ----
+    // ---- where to zoom (efficiency only: any window is exact) ----
+    // Every wave sorts 64 sample keys (one per thread, different rows per wave) across its lanes and reads off the quartiles of its
+    // valid ones; the block averages them: a median and a spread that stars and clamped pixels cannot drag about.  (Round 2's first
+    // version used mean +- 6 mean-absolute-deviations of the sample: one percent of star pixels tripled the deviation, and a sky
+    // three sigma above zero stretched the window over twenty binades of key space -- buckets of sigma / 15 .. sigma / 60 with
+    // 400 .. 1700 pixels each, which is what the selects then had to chew through.)  The buckets are 2^shift keys wide with
+    // sigma / 300 .. sigma / 600 per bucket (40 .. 90 pixels in the central ones), 4094 of them centred on the sample median: about
+    // +- 3.4 .. 6.8 sigma; the rest of the key range falls into the two catch-all buckets.
     Frame f;
     f.kmin = kmin;
     f.kmax = kmax;
     {
-        const uint32_t sk = sample_key(K);
-        float s1 = sk ? __uint_as_float(sk) : 0.0f, s0 = sk ? 1.0f : 0.0f;
-        block_sum2f(sh, s1, s0);
-        const float mean = s0 > 0.0f ? s1 / s0 : __uint_as_float(kmin);
-        float a1 = sk ? fabsf(__uint_as_float(sk) - mean) : 0.0f, a0 = 0.0f;
-        block_sum2f(sh, a1, a0);
-        const float mad = s0 > 0.0f ? a1 / s0 : 0.0f;
-        const float lo = mean - 6.0f * mad, hi = mean + 6.0f * mad;
-        uint32_t zlo = (lo > 0.0f && lo == lo) ? __float_as_uint(lo) : kmin;
-        uint32_t zhi = (hi > 0.0f && hi < 3.0e38f) ? __float_as_uint(hi) : kmax;
-        zlo = zlo < kmin ? kmin : (zlo > kmax ? kmax : zlo);
-        zhi = zhi > kmax ? kmax : (zhi < zlo ? zlo : zhi);
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const uint32_t sorted = wave_sort64(sample_key(K));
+        const int nz = __builtin_popcountll(__builtin_amdgcn_ballot_w64(sorted == 0u)), nv = 64 - nz;
+        const uint32_t q1 = (uint32_t)__shfl((int)sorted, nz + nv / 4 < 64 ? nz + nv / 4 : 63, 64);
+        const uint32_t q2 = (uint32_t)__shfl((int)sorted, nz + nv / 2 < 64 ? nz + nv / 2 : 63, 64);
+        const uint32_t q3 = (uint32_t)__shfl((int)sorted, nz + (3 * nv) / 4 < 64 ? nz + (3 * nv) / 4 : 63, 64);
+        __syncthreads();  // (the partial slots may still be read from the reduction above)
+        if (lane == 0) {
+            sh.wave_part[4 * wv + 0] = q1;
+            sh.wave_part[4 * wv + 1] = q2;
+            sh.wave_part[4 * wv + 2] = q3;
+            sh.wave_part[4 * wv + 3] = nv >= 8 ? 1u : 0u;
+        }
+        __syncthreads();
+        float s1 = 0.0f, s2 = 0.0f, s3 = 0.0f, sn = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i) {
+            const bool ok = sh.wave_part[4 * i + 3] != 0u;
+            s1 += ok ? __uint_as_float(sh.wave_part[4 * i + 0]) : 0.0f;
+            s2 += ok ? __uint_as_float(sh.wave_part[4 * i + 1]) : 0.0f;
+            s3 += ok ? __uint_as_float(sh.wave_part[4 * i + 2]) : 0.0f;
+            sn += ok ? 1.0f : 0.0f;
+        }
+        uint32_t zlo = kmin, zhi = kmax;
+        if (sn > 0.0f) {
+            const float Q1 = s1 / sn, Q2 = s2 / sn, Q3 = s3 / sn;
+            const float sig = (Q3 - Q1) * (1.0f / 1.349f);
+            uint32_t kc = __float_as_uint(Q2);
+            kc = kc < kmin ? kmin : (kc > kmax ? kmax : kc);
+            const float up = Q2 + sig;
+            const uint32_t wkeys = (sig > 0.0f && up < 3.0e38f) ? __float_as_uint(up) - __float_as_uint(Q2) : 0u;  // sigma in key units
+            const uint32_t bk = wkeys / 300u;
+            const int shift = bk >= 1u ? 31 - __builtin_clz(bk) : 0;
+            const uint64_t half = (uint64_t)(kBuckets - 2) / 2 << shift, width = ((uint64_t)(kBuckets - 2) << shift) - 1u;
+            zlo = (uint64_t)kc > half + kmin ? (uint32_t)(kc - half) : kmin;
+            zhi = (uint64_t)zlo + width < (uint64_t)kmax ? (uint32_t)(zlo + width) : kmax;
+        }
         f.zlo = zlo;
         f.zhi = zhi;
         const uint32_t span = zhi - zlo;
@@ -757,6 +907,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
         while ((span >> f.shift) >= (uint32_t)(kBuckets - 2)) ++f.shift;
         f.nb = (int)(span >> f.shift) + 3;
     }
+    TB_MARK(sh, 10);
     // ---- the one histogram sweep ----
     for (int i = threadIdx.x; i < kBuckets; i += kThreads) sh.prefix[i] = 0;
     __syncthreads();
@@ -764,6 +915,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
         if (k) atomicAdd(&sh.prefix[f.bucket_of(k)], 1u);
     });
     __syncthreads();
+    TB_MARK(sh, 11);
     {  // inclusive prefix sum over 4096 buckets: PER per thread + a scan of the thread totals in sh.tmp
         constexpr int PER = kBuckets / kThreads;
         const int b0 = threadIdx.x * PER;
@@ -783,7 +935,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh) {
         for (int j = 0; j < PER; ++j) sh.prefix[b0 + j] = v[j] + before;
         __syncthreads();
     }
-    TB_MARK(sh, 0);
+    TB_MARK(sh, 12);
 
     Window w;
     w.lo = 1;

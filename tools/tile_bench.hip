@@ -15,17 +15,26 @@ __global__ __launch_bounds__(tb::kThreads) void k(const float *img, int cols, do
     const int ty0 = (blockIdx.x / ntx) * 256, tx0 = (blockIdx.x % ntx) * 256;
     const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
     tb::Keys K;
+    tb::KeyRange kr;
+    const long long t_start = clock64();
 #pragma unroll
     for (int i = 0; i < tb::kSlots; ++i) {
         const float v = img[(size_t)(ty0 + ty + (tb::kThreads / 256) * i) * cols + tx0 + tx];
-        K.v[i >> 5][i & 31] = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;
+        const uint32_t key = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;
+        K.v[i >> 5][i & 31] = key;
+        kr.add(key);
     }
-    const tb::TileResult r = tb::tile_stats(K, sh);
+    long long t_load = clock64() - t_start;
+    if (K.v[0][0] == 0xdeadbeefu) t_load = 0;  // (keeps the reading after the loads)
+    const tb::TileResult r = tb::tile_stats(K, sh, kr);
+    const long long t_all = clock64() - t_start;
     if (threadIdx.x == 0) {
         out[2 * blockIdx.x] = r.median;
         out[2 * blockIdx.x + 1] = r.sigma;
 #ifdef AB_TILE_TIMING
-        for (int i = 0; i < 8; ++i) phases[8 * blockIdx.x + i] = sh.t_phase[i];
+        for (int i = 0; i < 16; ++i) phases[16 * blockIdx.x + i] = sh.t_phase[i];
+        phases[16 * blockIdx.x + 8] = t_load;
+        phases[16 * blockIdx.x + 15] = t_all;
 #endif
     }
 }
@@ -47,7 +56,7 @@ int main(int argc, char **argv) {
     long long *ph;
     hipMalloc(&d, h.size() * 4);
     hipMalloc(&out, 256 * 2 * 8);
-    hipMalloc(&ph, 256 * 8 * 8);
+    hipMalloc(&ph, 256 * 16 * 8);
     hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -60,14 +69,15 @@ int main(int argc, char **argv) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     printf("mode %d (%s): %.1f us per launch of 256 tiles\n", mode, mode == 0 ? "normalised [0,1] frame" : "raw ADU frame", ms * 100.0f);
-    std::vector<long long> p(256 * 8);
+    std::vector<long long> p(256 * 16);
     std::vector<double> o(512);
     hipMemcpy(p.data(), ph, p.size() * 8, hipMemcpyDeviceToHost);
     hipMemcpy(o.data(), out, o.size() * 8, hipMemcpyDeviceToHost);
-    const char *names[8] = {"setup+hist+counts", "v:bucket", "v:gather", "v:select", "d:round1", "d:round2+bounds", "d:gather", "d:select"};
+    const char *names[16] = {"window-counts", "v:bucket", "v:gather", "v:select", "d:round1", "d:round2+bounds", "d:gather", "d:select",
+                             "load", "minmax-reduce", "zoom-sums", "hist", "scan", "d:to-rigorous", "sweeps(v+d)", "TOTAL"};
     for (int t = 0; t < 3; ++t) {
         printf("tile %d: median %.6g sigma %.6g |", t, o[2 * t], o[2 * t + 1]);
-        for (int i = 0; i < 8; ++i) printf(" %s %lld;", names[i], p[8 * t + i]);
+        for (int i = 0; i < 16; ++i) printf(" %s %lld;", names[i], p[16 * t + i]);
         printf("\n");
     }
     return 0;
