@@ -481,6 +481,48 @@ __global__ __launch_bounds__(1024) void tri_scatter_kernel(const DTri *__restric
     if (i < n) sorted[cnt[t.bin] + rank] = t;  // order inside a bucket is irrelevant: votes are counts
 }
 
+// Orders every bucket of a scattered table by ratio_long (one 256-thread workgroup per bucket, bitonic network on
+// (ratio_long, slot) pairs in LDS).  Only the REFERENCE table needs it: a wave of the vote kernel owns 64 consecutive ref
+// triangles, and the narrower their ratio_long window, the fewer candidates it has to test.  Buckets of more than 1024
+// triangles (none in practice: the fullest holds ~850) stay unordered -- slower, not wrong.  This replaced a host std::sort of
+// the 34 220 triangles between two blocking copies: ~4 ms during which every worker that had finished its first detection
+// waited for the reference table.
+constexpr int kBucketSortCap = 1024;
+__global__ __launch_bounds__(256) void tri_bucket_sort_kernel(DTri *__restrict__ tris, const unsigned int *__restrict__ off) {
+    __shared__ double key[kBucketSortCap];
+    __shared__ unsigned short slot[kBucketSortCap];
+    __shared__ DTri item[kBucketSortCap];
+    const unsigned int b0 = off[blockIdx.x], n = off[blockIdx.x + 1] - b0;
+    if (n < 2 || n > (unsigned int)kBucketSortCap) return;
+    unsigned int np = 2;
+    while (np < n) np <<= 1;
+    for (unsigned int i = threadIdx.x; i < np; i += 256) {
+        if (i < n) item[i] = tris[b0 + i];
+        key[i] = i < n ? item[i].lng : __builtin_huge_val();  // ratios are finite: the pads sort last
+        slot[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (unsigned int k = 2; k <= np; k <<= 1)
+        for (unsigned int j = k >> 1; j >= 1; j >>= 1) {
+            for (unsigned int i = threadIdx.x; i < np; i += 256) {
+                const unsigned int p = i ^ j;
+                if (p > i) {
+                    const bool up = (i & k) == 0;
+                    const double a = key[i], c = key[p];
+                    if (up ? c < a : a < c) {
+                        key[i] = c;
+                        key[p] = a;
+                        const unsigned short q = slot[i];
+                        slot[i] = slot[p];
+                        slot[p] = q;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    for (unsigned int i = threadIdx.x; i < n; i += 256) tris[b0 + i] = item[slot[i]];
+}
+
 // The tgt table is bucketed by ratio_mid (tri_scatter_kernel); the ref table is sorted by (ratio_mid bucket,
 // ratio_long) once per batch on the host.  One wave owns 64 consecutive ref triangles: a narrow bucket range
 // [bmin, bmax] and a narrow ratio_long window [lmin, lmax].  It streams the tgt triangles of buckets bmin-1 ..
@@ -592,7 +634,9 @@ int match_ws(ab_ctx *ctx, MatchWs *w) {
     return AB_OK;
 }
 
-// upload the first <= 60 stars and build their triangle table (which = 0 ref, 1 tgt)
+// upload the first <= 60 stars and build their triangle table (which = 0 ref, 1 tgt), bucketed by ratio_mid; the ref table's
+// buckets are ordered by ratio_long as well.  Both tables use w's bucket arrays: the ref table is built once per batch on the
+// caller's context, whose own tgt slots are never used.
 int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &stars, int which) {
     const int limit = (int)std::min<size_t>(stars.size(), kTriLimit);
     StarXY xy;  // 960 B of kernel arguments: no staging copy, nothing to keep alive
@@ -601,17 +645,16 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
         xy.xy[2 * i] = stars[i][0];
         xy.xy[2 * i + 1] = stars[i][1];
     }
+    DTri *raw = which ? w.tgt_tris : w.ref_tris, *sorted = which ? w.tgt_sorted : w.ref_sorted;
     AB_HIP(ctx, hipMemsetAsync(w.counts + which, 0, sizeof(unsigned int), ctx->stream));
     if (limit >= 3) {
         const int total = limit * limit * limit;
-        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 1023) / 1024), dim3(1024), 0, ctx->stream, xy, limit, which ? w.tgt_tris : w.ref_tris,
-                           w.counts + which, which ? w.bin_hist : nullptr);
+        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 1023) / 1024), dim3(1024), 0, ctx->stream, xy, limit, raw, w.counts + which, w.bin_hist);
     }
-    if (which) {  // bucket the tgt table by ratio_mid for the vote kernel (the scan leaves bin_hist zeroed again)
-        hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
-        hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 1023) / 1024), dim3(1024), 0, ctx->stream, w.tgt_tris, w.counts + 1, w.cursor,
-                           w.tgt_sorted);
-    }
+    // (the scan leaves bin_hist zeroed again)
+    hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
+    hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 1023) / 1024), dim3(1024), 0, ctx->stream, raw, w.counts + which, w.cursor, sorted);
+    if (!which) hipLaunchKernelGGL(tri_bucket_sort_kernel, dim3(kTriBins), dim3(256), 0, ctx->stream, sorted, w.bin_off);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -725,18 +768,9 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     auto prepare_reference = [&]() -> int {
         AB_TRY(frame_stars(ctx, ref, rows, cols, &rt.stars));
         if (rt.stars.size() < kMinMatchesRigid) return AB_OK;
-        // reference table: built on the GPU, ordered by (ratio_mid bucket, ratio_long) once on the host
+        // reference table: built, bucketed by ratio_mid and ordered by ratio_long inside the buckets on the GPU
         AB_TRY(gpu_build_triangles(ctx, w, rt.stars, 0));
-        unsigned int nref = 0;
-        AB_HIP(ctx, hipMemcpyAsync(&nref, w.counts, sizeof nref, hipMemcpyDeviceToHost, ctx->stream));
-        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        std::vector<DTri> tris(nref);
-        if (nref) AB_HIP(ctx, hipMemcpy(tris.data(), w.ref_tris, nref * sizeof(DTri), hipMemcpyDeviceToHost));
-        std::sort(tris.begin(), tris.end(), [](const DTri &x, const DTri &y) {
-            const int bx = tri_bin(x.mid), by = tri_bin(y.mid);
-            return bx != by ? bx < by : x.lng < y.lng;
-        });
-        if (nref) AB_HIP(ctx, hipMemcpy(w.ref_sorted, tris.data(), nref * sizeof(DTri), hipMemcpyHostToDevice));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the workers' vote kernels read it from their own streams
         return AB_OK;
     };
     // the warp of a frame (f64 VALU) overlaps the other workers' latency-bound detection passes
