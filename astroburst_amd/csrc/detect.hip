@@ -757,19 +757,19 @@ __device__ __forceinline__ void find_rank_2048(const unsigned int *hist, unsigne
     *within = bcast[1];
 }
 
-__global__ __launch_bounds__(1024) void subsample_percentiles_kernel(const float *__restrict__ s, unsigned int ns, PercentileOut *__restrict__ out) {
+// SRC supplies sample i; the sweeps are written once for both sources below
+template <class SRC>
+__device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns, PercentileOut *__restrict__ out) {
     __shared__ unsigned int hist[2][2048];
     __shared__ unsigned int wave_tot[16], bcast[2];
     const int t = threadIdx.x;
     for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
     __syncthreads();
     // level 0: key bits 31..21 of every finite value; the total is the finite count
-    for (unsigned int i0 = 0; i0 < ns; i0 += 1024) {
-        const unsigned int i = i0 + t;
-        const float v = i < ns ? s[i] : __builtin_nanf("");
+    src.for_each(ns, [&](float v) {
         const bool ok = fabsf(v) <= 3.4028234663852886e38f;  // finite (NaN fails)
         tally(hist[0], ok, ordered_key(v) >> 21);
-    }
+    });
     __syncthreads();
     unsigned int m = 0;
     {
@@ -803,14 +803,13 @@ __global__ __launch_bounds__(1024) void subsample_percentiles_kernel(const float
         __syncthreads();
         for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
         __syncthreads();
-        for (unsigned int i0 = 0; i0 < ns; i0 += 1024) {
-            const unsigned int i = i0 + t;
-            const float v = i < ns ? s[i] : __builtin_nanf("");
+        const uint32_t p0 = prefix[0], p1 = prefix[1];
+        src.for_each(ns, [&](float v) {
             const bool ok = fabsf(v) <= 3.4028234663852886e38f;
             const uint32_t k = ordered_key(v), d = (k >> shift) & digit_mask;
-            if (ok && (k & prefix_mask) == prefix[0]) atomicAdd(&hist[0][d], 1u);
-            if (ok && (k & prefix_mask) == prefix[1]) atomicAdd(&hist[1][d], 1u);
-        }
+            if (ok && (k & prefix_mask) == p0) atomicAdd(&hist[0][d], 1u);
+            if (ok && (k & prefix_mask) == p1) atomicAdd(&hist[1][d], 1u);
+        });
         __syncthreads();
         for (int q = 0; q < 2; ++q) {
             unsigned int b, w;
@@ -822,19 +821,61 @@ __global__ __launch_bounds__(1024) void subsample_percentiles_kernel(const float
     if (t == 0) *out = PercentileOut{ordered_value(prefix[0]), ordered_value(prefix[1]), m, 0u};
 }
 
+// the subsample held in registers: <= kPctPer values per thread, all loads in flight at once; the three sweeps then read
+// registers.  (Sweeping the buffer in memory cost one dependent L2 round trip per value and sweep -- the LDS atomics keep the
+// compiler from pipelining the loads: 92 us for the workgroup.  Gathering every `step`-th pixel of the plane in this kernel,
+// without subsample_kernel, was worse still: 100 000 scattered cache lines through ONE compute unit, 0.3 ms.)
+constexpr int kPctPer = 100;
+struct RegSample {
+    float v[kPctPer];
+    template <class F>
+    __device__ __forceinline__ void for_each(unsigned int ns, F f) const {
+#pragma unroll
+        for (int j = 0; j < kPctPer; ++j)
+            if ((unsigned int)(j * 1024) < ns) f(v[j]);  // block-uniform; slots past ns hold NaN
+    }
+};
+__global__ __launch_bounds__(1024) void percentiles_reg_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
+    RegSample s;
+#pragma unroll
+    for (int j = 0; j < kPctPer; ++j) {
+        const unsigned int i = (unsigned int)(j * 1024) + threadIdx.x;
+        s.v[j] = i < ns ? sub[i] : __builtin_nanf("");
+    }
+    percentiles_body(s, ns, out);
+}
+
+// larger subsamples (planes of 100 000 .. 200 000 pixels are sampled at step 1): swept from a buffer
+struct MemSample {
+    const float *s;
+    template <class F>
+    __device__ __forceinline__ void for_each(unsigned int ns, F f) const {
+        for (unsigned int i0 = 0; i0 < ns; i0 += 1024) {
+            const unsigned int i = i0 + threadIdx.x;
+            f(i < ns ? s[i] : __builtin_nanf(""));
+        }
+    }
+};
+__global__ __launch_bounds__(1024) void percentiles_mem_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
+    percentiles_body(MemSample{sub}, ns, out);
+}
+
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     *xf = ab_pixel_xf();
     if (len == 0) return AB_OK;
     const int64_t step = std::max<int64_t>(len / 100000, 1);
     const int64_t ns = (len + step - 1) / step;
-    float *sub = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_SUBSAMPLE, (size_t)ns * sizeof(float), (void **)&sub));
     void *pin = nullptr;  // the kernel writes its 16 bytes straight into pinned host memory
     AB_TRY(ab_pinned(ctx, sizeof(PercentileOut), &pin));
     ab_trace trace("normalize_params");
+    float *sub = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_SUBSAMPLE, (size_t)ns * sizeof(float), (void **)&sub));
     hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, len, step, sub, ns);
-    hipLaunchKernelGGL(subsample_percentiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin);
+    if (ns <= (int64_t)kPctPer * 1024)
+        hipLaunchKernelGGL(percentiles_reg_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin);
+    else
+        hipLaunchKernelGGL(percentiles_mem_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     trace.mark("subsample+percentiles+sync");
