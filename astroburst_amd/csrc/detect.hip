@@ -144,6 +144,8 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
 
 // The same statistics from ONE histogram of the tile (tile_bucket.hpp): the product kernel.  tile_background_kernel above is
 // the round-1 radix-select version, kept behind AB_TILE_LEGACY=1 as an in-library cross-check (tests/test_gpu_tile_stats.py runs both).
+// (capping the registers at 168 so that another kernel's wave fits beside a tile on every SIMD -- amdgpu_waves_per_eu(3, 3) --
+// spills 65 registers: 104 -> 130 us alone and the registration stage 19.8 -> 21.4 ms)
 __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
                                                                               int step, int ntx, const ab_pixel_xf xf, TileOut *__restrict__ out) {
     __shared__ tb::Shared sh;

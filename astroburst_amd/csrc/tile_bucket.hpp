@@ -54,7 +54,8 @@ struct Shared {
     unsigned int tmp[kListCap];     // the candidates compacted to the front (what the select reads) / scan scratch
     unsigned int wave_part[kWaves * 4];  // per-wave partials of the block reductions
     unsigned int found_part[kWaves];     // per-wave totals of a gather (compact_list)
-    unsigned int hist[256];  // wave 0's radix-select histogram
+    unsigned int sel_hist[3][256];       // block_select2: rotating digit histograms
+    unsigned int sel_part[2 * kWaves];   // block_select2: per-wave partials
     unsigned int scal[16];   // broadcast slots
     long long t_phase[16];   // AB_TILE_TIMING: cycles per phase (thread 0): 0 setup + histogram + scan + window counts; value select:
                              // 1 bucket search 2 gather 3 select; deviation select: 4 round 1 5 round 2 + bounds 6 gather 7 select
@@ -96,21 +97,26 @@ __device__ __forceinline__ void for_each_key(const Keys &K, F f) {
     }
 }
 
-__device__ __forceinline__ unsigned int wave_sum(unsigned int x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
+// Wave reductions on DPP moves (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 / 31 across them; lanes without a source
+// take the identity): twelve VALU instructions and a v_readlane.  The __shfl_xor butterfly these replaced is six dependent
+// ds_bpermute round trips per value -- four values per workgroup reduction, nine reductions per tile: ~13 000 of a tile's
+// 230 000 cycles.
+enum { OP_SUM = 0, OP_MIN = 1, OP_MAX = 2 };
+template <int OP>
+__device__ __forceinline__ unsigned int wave_reduce(unsigned int x) {
+    constexpr unsigned int id = OP == OP_MIN ? 0xffffffffu : 0u;
+    auto op = [](unsigned int a, unsigned int b) { return OP == OP_SUM ? a + b : (OP == OP_MIN ? min(a, b) : max(a, b)); };
+    x = op(x, (unsigned int)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x111, 0xf, 0xf, false));
+    x = op(x, (unsigned int)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x112, 0xf, 0xf, false));
+    x = op(x, (unsigned int)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x114, 0xf, 0xf, false));
+    x = op(x, (unsigned int)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x118, 0xf, 0xf, false));
+    x = op(x, (unsigned int)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    x = op(x, (unsigned int)__builtin_amdgcn_update_dpp((int)id, (int)x, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3
+    return (unsigned int)__builtin_amdgcn_readlane((int)x, 63);
 }
-__device__ __forceinline__ unsigned int wave_min(unsigned int x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = min(x, (unsigned int)__shfl_xor(x, off, 64));
-    return x;
-}
-__device__ __forceinline__ unsigned int wave_max(unsigned int x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = max(x, (unsigned int)__shfl_xor(x, off, 64));
-    return x;
-}
+__device__ __forceinline__ unsigned int wave_sum(unsigned int x) { return wave_reduce<OP_SUM>(x); }
+__device__ __forceinline__ unsigned int wave_min(unsigned int x) { return wave_reduce<OP_MIN>(x); }
+__device__ __forceinline__ unsigned int wave_max(unsigned int x) { return wave_reduce<OP_MAX>(x); }
 
 // inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8, row_bcast 15/31: the gfx9 scan idiom) -- six VALU
 // instructions instead of six ds_bpermute round trips
@@ -148,7 +154,6 @@ __device__ __forceinline__ uint32_t wave_sort64(uint32_t x) {
 }
 
 // up to four values reduced over the workgroup; every thread gets the results (two barriers)
-enum { OP_SUM = 0, OP_MIN = 1, OP_MAX = 2 };
 template <int OP0, int OP1, int OP2, int OP3>
 __device__ __forceinline__ void block_reduce4(Shared &sh, unsigned int &a, unsigned int &b, unsigned int &c, unsigned int &d) {
     auto wred = [](unsigned int x, int op) { return op == OP_SUM ? wave_sum(x) : (op == OP_MIN ? wave_min(x) : wave_max(x)); };
@@ -325,38 +330,51 @@ __device__ __forceinline__ unsigned int compact_list(Shared &sh, unsigned int cn
     return total;
 }
 
-// wave 0: the ranks r_hi and r_lo (= r_hi or r_hi - 1; 0-based) of sh.tmp[0 .. n) -- an 8-bit radix descent for r_hi over the
-// bytes in which the keys differ at all (the keys of one bucket share their high bytes), then one pass for its predecessor.
-// Results in every lane of wave 0; other waves must not call.
-__device__ __forceinline__ void wave_select2(Shared &sh, unsigned int n, unsigned int r_lo, unsigned int r_hi, uint32_t *k_lo, uint32_t *k_hi) {
-    const int lane = threadIdx.x & 63;
-    // bits in which any two keys differ
+// The ranks r_hi and r_lo (= r_hi or r_hi - 1; 0-based) of sh.tmp[0 .. n), n <= kListCap, by the whole workgroup: a thread keeps
+// its <= 4 keys in registers; an 8-bit radix descent for r_hi over the bytes in which the keys differ at all (the keys of one
+// bucket share their high bytes), one barrier per byte -- every wave scans the 256-bin histogram for itself, so nothing is
+// broadcast, and three histograms rotate so that clearing the next one never meets a reader of the last.  Then the predecessor
+// of r_hi, if it is a different key.  Every thread returns both keys.  (One wave doing all of this alone took 9 400 cycles per
+// deviation select.)  The caller's last barrier lies after tmp was filled; none is needed after the call before tmp is refilled,
+// because a workgroup reduction always comes first.
+__device__ __forceinline__ void block_select2(Shared &sh, unsigned int n, unsigned int r_lo, unsigned int r_hi, uint32_t *k_lo, uint32_t *k_hi) {
+    constexpr int kMine = kListCap / kThreads;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    uint32_t mine[kMine];
     const uint32_t k0 = sh.tmp[0];
     uint32_t diff = 0;
-    for (unsigned int i = lane; i < n; i += 64) diff |= sh.tmp[i] ^ k0;
+#pragma unroll
+    for (int q = 0; q < kMine; ++q) {
+        const unsigned int i = (unsigned int)(q * kThreads + t);
+        mine[q] = i < n ? sh.tmp[i] : k0;  // pads repeat a real key and are skipped by index below
+        diff |= mine[q] ^ k0;
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) diff |= (uint32_t)__shfl_xor((int)diff, off, 64);
-    diff = (uint32_t)__builtin_amdgcn_readfirstlane((int)diff);
+    if (lane == 0) sh.sel_part[wv] = diff;
+    if (t < 256) sh.sel_hist[0][t] = 0;
+    __syncthreads();
+    diff = 0;
+#pragma unroll
+    for (int i = 0; i < kWaves; ++i) diff |= sh.sel_part[i];
     int top = 24;
     while (top > 0 && (diff >> top) == 0) top -= 8;  // the highest byte that varies
     uint32_t mask = top == 24 ? 0u : (0xffffffffu << (top + 8));
     uint32_t prefix = k0 & mask;
     unsigned int rank = r_hi;
+    int h = 0;
     for (int shift = top; shift >= 0; shift -= 8) {
+        unsigned int *const hist = sh.sel_hist[h], *const next = sh.sel_hist[h == 2 ? 0 : h + 1];
+        if (t < 256) next[t] = 0;  // last read two bytes ago: a barrier lies in between
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sh.hist[lane + 64 * i] = 0;
-        __builtin_amdgcn_wave_barrier();
-        for (unsigned int i = lane; i < n; i += 64) {
-            const uint32_t k = sh.tmp[i];
-            if ((k & mask) == prefix) atomicAdd(&sh.hist[(k >> shift) & 255u], 1u);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the LDS atomics have landed (same wave)
-        __builtin_amdgcn_wave_barrier();
+        for (int q = 0; q < kMine; ++q)
+            if ((unsigned int)(q * kThreads + t) < n && (mine[q] & mask) == prefix) atomicAdd(&hist[(mine[q] >> shift) & 255u], 1u);
+        __syncthreads();
         // lane l owns digits 4l .. 4l+3
-        const unsigned int c0 = sh.hist[4 * lane], c1 = sh.hist[4 * lane + 1], c2 = sh.hist[4 * lane + 2], c3 = sh.hist[4 * lane + 3];
-        const unsigned int mine = c0 + c1 + c2 + c3;
-        const unsigned int incl = wave_scan_incl(mine);
-        const unsigned int excl = incl - mine;
+        const unsigned int c0 = hist[4 * lane], c1 = hist[4 * lane + 1], c2 = hist[4 * lane + 2], c3 = hist[4 * lane + 3];
+        const unsigned int own = c0 + c1 + c2 + c3;
+        const unsigned int incl = wave_scan_incl(own);
+        const unsigned int excl = incl - own;
         const bool owner = rank >= excl && rank < incl;
         uint32_t digit = 0;
         unsigned int below = 0;
@@ -383,23 +401,23 @@ __device__ __forceinline__ void wave_select2(Shared &sh, unsigned int n, unsigne
         rank -= below;
         prefix |= digit << shift;
         mask |= 255u << shift;
-        __builtin_amdgcn_wave_barrier();
+        h = h == 2 ? 0 : h + 1;
     }
     *k_hi = prefix;
     *k_lo = prefix;
-    if (r_lo != r_hi) {  // the element before rank r_hi: the same key if r_hi is not its first occurrence, else the largest key below
-        unsigned int less = 0;
+    // `rank` is now r_hi's position among the keys equal to it: r_hi - rank keys are smaller.  The element before r_hi is the same
+    // key unless r_hi is its first occurrence; then it is the largest key below.
+    if (r_lo != r_hi && rank == 0) {
         uint32_t best = 0;
-        for (unsigned int i = lane; i < n; i += 64) {
-            const uint32_t k = sh.tmp[i];
-            if (k < prefix) {
-                ++less;
-                best = best > k ? best : k;
-            }
-        }
-        less = wave_sum(less);
+#pragma unroll
+        for (int q = 0; q < kMine; ++q)
+            if ((unsigned int)(q * kThreads + t) < n && mine[q] < prefix) best = best > mine[q] ? best : mine[q];
         best = wave_max(best);
-        if (r_lo < less) *k_lo = best;  // (r_lo == less - 1: adjacent ranks)
+        if (lane == 0) sh.sel_part[kWaves + wv] = best;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kWaves; ++i) best = best > sh.sel_part[kWaves + i] ? best : sh.sel_part[kWaves + i];
+        *k_lo = best;
     }
 }
 
@@ -437,18 +455,7 @@ __device__ __forceinline__ void select_values(const Keys &K, Shared &sh, const F
         const unsigned int n = compact_list<false>(sh, found, 0.0);
         TB_MARK(sh, 2);
         if (n != 0xffffffffu) {
-            if (threadIdx.x < 64) {
-                uint32_t a, b;
-                wave_select2(sh, n, g_lo - ex_lo, g_hi - ex_lo, &a, &b);
-                if (threadIdx.x == 0) {
-                    sh.scal[1] = a;
-                    sh.scal[2] = b;
-                }
-            }
-            __syncthreads();
-            *k_lo = sh.scal[1];
-            *k_hi = sh.scal[2];
-            __syncthreads();
+            block_select2(sh, n, g_lo - ex_lo, g_hi - ex_lo, k_lo, k_hi);
             TB_MARK(sh, 3);
             return;
         }
@@ -638,17 +645,8 @@ __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Fra
                 const unsigned int n = compact_list<true>(sh, found, median);
                 TB_MARK(sh, 6);
                 if (n == n_cand) {
-                    if (threadIdx.x < 64) {
-                        uint32_t a, b;
-                        wave_select2(sh, n, r_lo - c_in, r_hi - c_in, &a, &b);
-                        if (threadIdx.x == 0) {
-                            sh.scal[1] = a;
-                            sh.scal[2] = b;
-                        }
-                    }
-                    __syncthreads();
-                    const uint32_t sel_lo = sh.scal[1], sel_hi = sh.scal[2];
-                    __syncthreads();
+                    uint32_t sel_lo, sel_hi;
+                    block_select2(sh, n, r_lo - c_in, r_hi - c_in, &sel_lo, &sel_hi);
                     // the proof: inner deviations <= sel_lo, outer deviations >= sel_hi
                     uint32_t t_in = 0, t_out = 0xffffffffu;
                     if (has_inner) {
@@ -764,18 +762,7 @@ __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Fra
         const unsigned int n = compact_list<true>(sh, found, median);  // == n_cand
         TB_MARK(sh, 6);
         if (n != 0xffffffffu) {
-            if (threadIdx.x < 64) {
-                uint32_t a, b;
-                wave_select2(sh, n, r_lo - c0, r_hi - c0, &a, &b);
-                if (threadIdx.x == 0) {
-                    sh.scal[1] = a;
-                    sh.scal[2] = b;
-                }
-            }
-            __syncthreads();
-            *d_lo = sh.scal[1];
-            *d_hi = sh.scal[2];
-            __syncthreads();
+            block_select2(sh, n, r_lo - c0, r_hi - c0, d_lo, d_hi);
             TB_MARK(sh, 7);
             return;
         }
