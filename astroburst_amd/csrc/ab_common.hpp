@@ -187,7 +187,7 @@ int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, i
 int ab_stf_u8_device_tx(ab_ctx *ctx, const float *in, int64_t n, const void *tx_dev, uint8_t *out);
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out,
-                           ab_pixel_xf xf = ab_pixel_xf());
+                           ab_pixel_xf xf = ab_pixel_xf(), size_t max_keep = (size_t)-1 /* only the brightest max_keep stars are wanted */);
 // the percentile normalisation's parameters (xf->on = 0 where the reference returns image.clone())
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf);
 

@@ -569,7 +569,7 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
 
 // detect_stars (star_detection.rs:86-258) on a device plane; stars sorted by flux, deduplicated
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
-                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out, ab_pixel_xf xf) {
+                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out, ab_pixel_xf xf, size_t max_keep) {
     stars->clear();
     *bg_median_out = 0.0;
     *bg_sigma_out = 1.0;
@@ -629,16 +629,17 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
 
     trace.mark("moments+D2H");
     if (trace.on) fprintf(stderr, " (%u components)", ncomp);
-    // ---- host: finish the stars in discovery order (ascending first interior pixel = BFS seed order) ----
-    std::vector<const CompRec *> order;
+    // ---- host: the reference finishes the stars in discovery order (ascending first interior pixel = BFS seed order) and then
+    // sorts them stably by descending flux (:215).  The two orders are one: (flux descending, first interior pixel ascending).
+    struct Cand {
+        ab_detected_star s;
+        int first;
+    };
+    std::vector<Cand> cand;
+    cand.reserve(ncomp);
     for (const CompRec *pc = recs_begin; pc != recs_end; ++pc) {
-        const CompRec &c = *pc;
-        if (c.first_interior != 0x7fffffff && c.npix >= 3 && c.npix <= 5000 && c.sum_flux > 0.0) order.push_back(&c);
-    }
-    std::sort(order.begin(), order.end(), [](const CompRec *a, const CompRec *b) { return a->first_interior < b->first_interior; });
-
-    std::vector<ab_detected_star> found;
-    for (const CompRec *c : order) {
+        const CompRec *c = pc;
+        if (!(c->first_interior != 0x7fffffff && c->npix >= 3 && c->npix <= 5000 && c->sum_flux > 0.0)) continue;
         const double sum_flux = c->sum_flux;
         const double cx = c->sum_x / sum_flux, cy = c->sum_y / sum_flux;
         const double sigma_star = std::sqrt(c->sum_r2 / (2.0 * sum_flux));
@@ -654,37 +655,52 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
             ecc = std::sqrt(1.0 - l2 / l1);
             ecc = ecc < 0.0 ? 0.0 : (ecc > 1.0 ? 1.0 : ecc);
         }
-        ab_detected_star s;
-        s.x = cx;
-        s.y = cy;
-        s.flux = sum_flux;
-        s.fwhm = fwhm;
-        s.eccentricity = ecc;
-        s.peak = c->peak;
-        s.npix = (uint64_t)c->npix;
-        s.snr = bg_sigma <= DBL_EPSILON ? 0.0 : c->peak / bg_sigma;  // confidence.rs:3-8
-        found.push_back(s);
+        Cand k;
+        k.s.x = cx;
+        k.s.y = cy;
+        k.s.flux = sum_flux;
+        k.s.fwhm = fwhm;
+        k.s.eccentricity = ecc;
+        k.s.peak = c->peak;
+        k.s.npix = (uint64_t)c->npix;
+        k.s.snr = bg_sigma <= DBL_EPSILON ? 0.0 : c->peak / bg_sigma;  // confidence.rs:3-8
+        k.first = c->first_interior;
+        cand.push_back(k);
     }
     trace.mark("finish");
-    std::stable_sort(found.begin(), found.end(), [](const ab_detected_star &a, const ab_detected_star &b) { return b.flux < a.flux; });  // :215
+    auto before = [](const Cand &a, const Cand &b) { return a.s.flux != b.s.flux ? b.s.flux < a.s.flux : a.first < b.first; };
+    // a caller that wants only the max_keep brightest survivors of the 3 px dedup (registration: 120) does not need the faint
+    // thousands in order: the dedup only ever compares a star with brighter ones, so the brightest 4 max_keep are split off and
+    // sorted first, and the rest only if the dedup ate so many that they are needed after all
+    size_t sorted_upto = cand.size();
+    if (max_keep < cand.size() / 4) {
+        sorted_upto = 4 * max_keep;
+        std::nth_element(cand.begin(), cand.begin() + sorted_upto, cand.end(), before);
+    }
+    std::sort(cand.begin(), cand.begin() + sorted_upto, before);
     // dedup within 3 px, comparing only against kept stars in the 3 x 3 neighbourhood of 3 px grid cells (:217-248)
     // (kept stars live in a chained hash table over the 3 px cells: no per-cell allocations)
     size_t nbuckets = 64;
-    while (nbuckets < 2 * found.size()) nbuckets <<= 1;
-    std::vector<int> head(nbuckets, -1), next(found.size(), -1);
-    std::vector<uint64_t> cell_of(found.size());
+    while (nbuckets < 2 * std::min(cand.size(), std::max<size_t>(4 * std::min(max_keep, cand.size()), 64))) nbuckets <<= 1;
+    std::vector<int> head(nbuckets, -1), next(cand.size(), -1);
+    std::vector<uint64_t> cell_of(cand.size());
     auto key = [](uint64_t gy, uint64_t gx) { return (gy << 32) | gx; };
     auto bucket = [&](uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 32) & (nbuckets - 1); };
-    stars->reserve(found.size());
-    for (size_t i = 0; i < found.size(); ++i) {
-        const uint64_t gx = (uint64_t)(found[i].x / 3.0), gy = (uint64_t)(found[i].y / 3.0);
+    stars->reserve(std::min(cand.size(), max_keep));
+    for (size_t i = 0; i < cand.size() && stars->size() < max_keep; ++i) {
+        if (i == sorted_upto) {  // the brightest block did not yield max_keep survivors: order the rest too
+            std::sort(cand.begin() + sorted_upto, cand.end(), before);
+            sorted_upto = cand.size();
+        }
+        const ab_detected_star &fi = cand[i].s;
+        const uint64_t gx = (uint64_t)(fi.x / 3.0), gy = (uint64_t)(fi.y / 3.0);
         bool too_close = false;
         for (uint64_t ny = gy ? gy - 1 : 0; ny <= gy + 1 && !too_close; ++ny)
             for (uint64_t nx = gx ? gx - 1 : 0; nx <= gx + 1 && !too_close; ++nx) {
                 const uint64_t k = key(ny, nx);
                 for (int j = head[bucket(k)]; j >= 0; j = next[j]) {
                     if (cell_of[j] != k) continue;
-                    const double dx = found[i].x - found[j].x, dy = found[i].y - found[j].y;
+                    const double dx = fi.x - cand[j].s.x, dy = fi.y - cand[j].s.y;
                     if (dx * dx + dy * dy < 9.0) {
                         too_close = true;
                         break;
@@ -696,7 +712,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
             cell_of[i] = k;
             next[i] = head[bucket(k)];
             head[bucket(k)] = (int)i;
-            stars->push_back(found[i]);
+            stars->push_back(fi);
         }
     }
     trace.mark("sort+dedup");
