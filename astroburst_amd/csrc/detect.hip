@@ -726,6 +726,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
 // of the float bit patterns (any sign), both ranks descending together -- three sweeps over ~100 000 values in L2.  The first
 // version copied the subsample to the host and ran std::nth_element twice: 0.7 .. 1.2 ms of a worker thread per frame, the
 // largest single item of the registration stage's per-frame host time.
+namespace {
 struct PercentileOut {
     float lo, hi;
     unsigned int finite;  // count of finite subsample values
@@ -877,6 +878,8 @@ struct MemSample {
 __global__ __launch_bounds__(1024) void percentiles_mem_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
     percentiles_body(MemSample{sub}, ns, out);
 }
+
+}  // namespace
 
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
