@@ -37,6 +37,22 @@
         v[a] = lo_;                         \
         v[b] = hi_;                         \
     }
+// The base case of the network on four unsorted samples with the three-input operations: sort three (min3 / med3 / max3), then
+// place the fourth (min, med3, med3, max) -- 7 instructions where Batcher's five compare-exchanges take 10, all of them at the
+// same half rate as a two-input min / max (tools/valu_rate.hip): 48 of the sort's 1086 instructions, 1.18 -> 1.14 ms on the bench
+// stack (same box, AB_LIB_PATH A/B).  No NaN reaches the network (non-finite samples are replaced by +inf above it).
+#ifndef AB_STACK_NO_SORT4  // (A/B switch for tools/time_stack_bench_data.py)
+#define AB_SORT4(a, b, c, d)                                                         \
+    {                                                                                \
+        const T x0_ = v[a], x1_ = v[b], x2_ = v[c], x3_ = v[d];                      \
+        const T s0_ = fminf(fminf(x0_, x1_), x2_), s1_ = __builtin_amdgcn_fmed3f(x0_, x1_, x2_), \
+                s2_ = fmaxf(fmaxf(x0_, x1_), x2_);                                   \
+        v[a] = fminf(s0_, x3_);                                                      \
+        v[b] = __builtin_amdgcn_fmed3f(s0_, s1_, x3_);                               \
+        v[c] = __builtin_amdgcn_fmed3f(s1_, s2_, x3_);                               \
+        v[d] = fmaxf(s2_, x3_);                                                      \
+    }
+#endif
 #include "sortnet_gen.hpp"
 
 #ifndef AB_STACK_WAVES_PER_SIMD
@@ -359,6 +375,10 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
     ch_out = ch;
 }
 
+// (Tried: the two divisions of an iteration and the final mean as Markstein steps -- q = x r, rem = fma(-q, d, x), fma(rem, r, q)
+// with r = RN(1 / d) from a 65-entry LDS table, correctly rounded for divisors < 2^7 and bit-identical in every test -- three
+// FMAs instead of the ~11-instruction IEEE sequence.  The per-lane LDS look-ups and the workgroup barrier that fills the table
+// cost more than the divisions: 1.10 -> 1.18 ms.)
 template <int NP, int STAGE = 99, bool DEFER = false, bool SKIP = false>
 __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med, float mad, float sigma_low,
                                                 float sigma_high, uint32_t max_iter) {
@@ -716,6 +736,10 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
     else
         r = clip_fast<NP, STAGE, MODE == kFastPass, MODE == kPlain>(v, n, med, mad, args.sigma_low, args.sigma_high, args.max_iter);
 
+    // (Tried: handing a wave over WHOLE to the general pass when some pixel holds more than 8 exact zeros below a non-zero median
+    // -- the border bands of registered frames -- so that it is re-gathered coalesced instead of pixel by pixel: deferred pixels
+    // 0.80 % -> 0.09 %, launch time unchanged, 1.11 ms either way: the wasted sort and the unbounded end walk cost what the
+    // scattered gathers did.)
     // (Tried: a wave with >= 4 deferring lanes -- the edge bands -- runs the general engine in place on the samples it still holds
     // in registers: nothing is deferred any more, but the stack goes from 1.12 to 1.36 ms.  The second engine instance slows
     // EVERY wave (1.07 vs 0.99 ms with the borders cropped away), and walking 60 zeros in 16 chunks costs those waves more than
