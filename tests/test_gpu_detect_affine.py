@@ -96,6 +96,42 @@ def test_normalize_for_detection(ctx, oracle):
     assert np.array_equal(ctx.normalize_for_detection(small), small)
 
 
+@pytest.mark.parametrize("shape", [(300, 300), (300, 400), (1024, 1024), (2048, 2048)])
+@pytest.mark.parametrize("kind", ["sky", "signed", "ties", "wide", "holes", "flat", "few"])
+def test_normalize_percentiles_on_the_gpu(ctx, oracle, shape, kind):
+    """The 1 % / 99.9 % order statistics of the subsample come from a one-workgroup radix select (registers for <= 102 400
+    samples: 300 x 300 and 2048 x 2048 here; a buffer above that: 300 x 400, 1024 x 1024).  Same normalised frame as the
+    oracle's sorted subsample, bit for bit, for negative values, ties, thirty binades, NaN / inf holes, a flat frame
+    (range < 1e-15: returned unchanged) and a frame with fewer than 100 finite samples (unchanged)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(repr((shape, kind)).encode()))
+    n = shape[0] * shape[1]
+    if kind == "sky":
+        img = rng.normal(1000, 30, n)
+    elif kind == "signed":
+        img = rng.normal(0, 5, n)
+        img[::7] = -0.0
+        img[3::11] = 0.0
+    elif kind == "ties":
+        img = np.round(rng.normal(100, 3, n))
+    elif kind == "wide":
+        img = 10.0 ** rng.uniform(-20, 20, n) * rng.choice([-1.0, 1.0], n)
+    elif kind == "holes":
+        img = rng.normal(50, 10, n)
+        img[rng.random(n) < 0.3] = np.nan
+        img[rng.random(n) < 0.01] = np.inf
+        img[rng.random(n) < 0.01] = -np.inf
+    elif kind == "flat":
+        img = np.full(n, 7.25)
+    else:
+        img = np.full(n, np.nan)
+        img[rng.choice(n, 60, replace=False)] = rng.normal(5, 1, 60)
+    img = img.astype(np.float32).reshape(shape)
+    with np.errstate(all="ignore"):
+        want = oracle.normalize_for_detection(img)
+    assert np.array_equal(ctx.normalize_for_detection(img), want, equal_nan=True)
+
+
 def test_affine_from_stars_matches_oracle(ctx, oracle):
     rng = np.random.default_rng(1)
     ref = np.column_stack([rng.uniform(20, 1180, 90), rng.uniform(20, 980, 90)])
