@@ -36,6 +36,7 @@ enum {
     AB_WS_STATS,              // state block, 65 536-bin histograms and partials of the statistics chain (stats.hip)
     AB_WS_SHARD,              // (sum f64, count u32) partial planes of the frame-sharded stack (sharded.hip)
     AB_WS_SUBSAMPLE,          // the <= ~100 000-pixel subsample normalize_for_detection takes its percentiles from
+    AB_WS_DETECT_DEV,         // FrameDev + the tile statistics of the chained detection (detect.hip)
     AB_WS_SLOTS
 };
 
@@ -187,7 +188,8 @@ int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, i
 int ab_stf_u8_device_tx(ab_ctx *ctx, const float *in, int64_t n, const void *tx_dev, uint8_t *out);
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out,
-                           ab_pixel_xf xf = ab_pixel_xf(), size_t max_keep = (size_t)-1 /* only the brightest max_keep stars are wanted */);
+                           ab_pixel_xf xf = ab_pixel_xf(), size_t max_keep = (size_t)-1 /* only the brightest max_keep stars are wanted */,
+                           bool normalize_first = false /* normalize_for_detection's transform is derived and applied on the device */);
 // the percentile normalisation's parameters (xf->on = 0 where the reference returns image.clone())
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf);
 

@@ -698,9 +698,8 @@ int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std:
 int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::vector<Pt> *out) {
     std::vector<ab_detected_star> stars;
     double m, s;
-    ab_pixel_xf xf;  // the normalised frame is never materialised: detection applies the transform on load
-    AB_TRY(ab_normalize_params_device(ctx, img, rows * cols, &xf));
-    AB_TRY(ab_detect_stars_device(ctx, img, rows, cols, cols, kDetectionSigma, &stars, &m, &s, xf, kMaxStars));  // top_n_stars (:272-277)
+    // the normalised frame is never materialised: detection derives the transform on the device and applies it on load
+    AB_TRY(ab_detect_stars_device(ctx, img, rows, cols, cols, kDetectionSigma, &stars, &m, &s, ab_pixel_xf(), kMaxStars, /*normalize_first=*/true));  // top_n_stars (:272-277)
     out->clear();
     for (const auto &st : stars) {
         if (out->size() >= kMaxStars) break;  // top_n_stars (:272-277): detections are already sorted by flux

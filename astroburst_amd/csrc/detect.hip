@@ -36,6 +36,18 @@ namespace {
 
 constexpr double kMadToSigma = 1.4826;
 
+// Per-frame parameters that one kernel of the detection chain produces and the next consumes, kept in device memory so that the
+// host need not sit between them: the percentile kernel writes `xf`, the tile kernel reads it, bg_threshold_kernel reduces the
+// tiles to (bg_median, bg_sigma, threshold), the labelling and moment kernels read those.  A kernel given a null FrameDev uses
+// its by-value arguments instead (the stand-alone entry points, and the default registration path: see `chained` in
+// ab_detect_stars_device for why the host still joins after the percentiles and after the tiles).
+struct FrameDev {
+    ab_pixel_xf xf;
+    double bg_median, bg_sigma, threshold;
+    unsigned int finite;  // finite subsample values (< 100: xf.on = 0)
+    unsigned int pad;
+};
+
 // ---- per-tile sigma-clipped statistics ---------------------------------------------------------
 struct TileOut {
     double median, sigma;
@@ -147,8 +159,10 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
 // (capping the registers at 168 so that another kernel's wave fits beside a tile on every SIMD -- amdgpu_waves_per_eu(3, 3) --
 // spills 65 registers: 104 -> 130 us alone and the registration stage 19.8 -> 21.4 ms)
 __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
-                                                                              int step, int ntx, const ab_pixel_xf xf, TileOut *__restrict__ out) {
+                                                                              int step, int ntx, const ab_pixel_xf xf_arg, TileOut *__restrict__ out,
+                                                                              const FrameDev *__restrict__ fd) {
     __shared__ tb::Shared sh;
+    const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
     const int ty0 = (blockIdx.x / ntx) * step, tx0 = (blockIdx.x % ntx) * step;
     const int y1 = min(ty0 + step, rows), x1 = min(tx0 + step, cols);
     // thread (tx, ty) of the 256 x 2 layout walks column tx0 + tx downwards, two rows per slot: consecutive lanes read
@@ -202,9 +216,11 @@ __device__ __forceinline__ bool labelled(const unsigned int *__restrict__ mask, 
 // 4096^2 frame took 25 of the kernel's 36 us.
 constexpr int kInitBlock = 1024, kInitSub = 4 * kInitBlock, kInitRounds = 8, kInitCap = 4 * kInitSub;
 __global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
-                                                                double threshold, const ab_pixel_xf xf, int *__restrict__ parent,
+                                                                double threshold_arg, const ab_pixel_xf xf_arg, int *__restrict__ parent,
                                                                 unsigned int *__restrict__ mask, int *__restrict__ plist, unsigned int *nlab,
-                                                                int vec_ok) {
+                                                                int vec_ok, const FrameDev *__restrict__ fd) {
+    const double threshold = fd ? fd->threshold : threshold_arg;
+    const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
     __shared__ int found[kInitCap];
     __shared__ unsigned int nfound, base;
     if (threadIdx.x == 0) nfound = 0;
@@ -435,7 +451,10 @@ __device__ __forceinline__ double wave_max(double x) {
 // (the reference accumulates in BFS order: the two agree to ~1e-15 relative).
 __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
-                                                           double bg_median, const ab_pixel_xf xf, CompRec *__restrict__ rec) {
+                                                           double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
+                                                           const FrameDev *__restrict__ fd) {
+    const double bg_median = fd ? fd->bg_median : bg_median_arg;
+    const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
     const unsigned int comp = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (comp >= ncomp) return;
@@ -507,6 +526,238 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *__restrict_
     }
 }
 
+// normalize_for_detection's parameters (affine.rs:24-47): the 1st and 99.9th percentile of an every-step subsample.
+// xf->on = 0 when the reference returns image.clone() (too few finite samples / flat range).
+// The 1 % / 99.9 % order statistics of the finite subsample values (affine.rs:33-42 sorts the subsample; only these two
+// elements of the sorted list are read), by ONE 1024-thread workgroup: an 11 / 11 / 10-bit radix select on the monotone image
+// of the float bit patterns (any sign), both ranks descending together -- three sweeps over ~100 000 values in L2.  The first
+// version copied the subsample to the host and ran std::nth_element twice: 0.7 .. 1.2 ms of a worker thread per frame, the
+// largest single item of the registration stage's per-frame host time.
+struct PercentileOut {
+    float lo, hi;
+    unsigned int finite;  // count of finite subsample values
+    unsigned int pad;
+};
+__device__ __forceinline__ uint32_t ordered_key(float v) {  // monotone for every finite float (-0.0 sorts just below +0.0)
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// histogram update with the wave's first bin tallied by ballot: sky pixels share their top bits, and 64 lanes adding to one LDS
+// address serialise
+__device__ __forceinline__ void tally(unsigned int *hist, bool on, uint32_t bin) {
+    const unsigned long long act = __builtin_amdgcn_ballot_w64(on);
+    if (!act) return;
+    const uint32_t mode = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)__builtin_ctzll(act));
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(on && bin == mode);
+    if ((threadIdx.x & 63) == (int)__builtin_ctzll(act)) atomicAdd(&hist[mode], (unsigned int)__builtin_popcountll(same));
+    if (on && bin != mode) atomicAdd(&hist[bin], 1u);
+}
+
+// the bin of `hist[0 .. 2048)` that holds 0-based rank r, and r's rank inside it; every thread gets the answer (block of 1024)
+__device__ __forceinline__ void find_rank_2048(const unsigned int *hist, unsigned int *wave_tot /* 16 */, unsigned int *bcast /* 2 */,
+                                               unsigned int r, unsigned int *bin, unsigned int *within) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned int h0 = hist[2 * t], h1 = hist[2 * t + 1], mine = h0 + h1;
+    unsigned int inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    __syncthreads();  // (wave_tot / bcast may still be read from the previous call)
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    unsigned int base = 0;
+    for (int i = 0; i < wv; ++i) base += wave_tot[i];
+    const unsigned int excl = base + inc - mine;
+    if (r >= excl && r < excl + mine) {  // exactly one thread
+        const bool second = r - excl >= h0;
+        bcast[0] = 2u * t + (second ? 1u : 0u);
+        bcast[1] = r - excl - (second ? h0 : 0u);
+    }
+    __syncthreads();
+    *bin = bcast[0];
+    *within = bcast[1];
+}
+
+// SRC supplies sample i; the sweeps are written once for both sources below
+template <class SRC>
+__device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns, PercentileOut *__restrict__ out, FrameDev *__restrict__ fd) {
+    __shared__ unsigned int hist[2][2048];
+    __shared__ unsigned int wave_tot[16], bcast[2];
+    const int t = threadIdx.x;
+    for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
+    __syncthreads();
+    // level 0: key bits 31..21 of every finite value; the total is the finite count
+    src.for_each(ns, [&](float v) {
+        const bool ok = fabsf(v) <= 3.4028234663852886e38f;  // finite (NaN fails)
+        tally(hist[0], ok, ordered_key(v) >> 21);
+    });
+    __syncthreads();
+    unsigned int m = 0;
+    {
+        const unsigned int mine = hist[0][2 * t] + hist[0][2 * t + 1];
+        unsigned int x = mine;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
+        if ((t & 63) == 0) wave_tot[t >> 6] = x;
+        __syncthreads();
+        for (int i = 0; i < 16; ++i) m += wave_tot[i];
+    }
+    if (m < 100u) {  // affine.rs:34-36: too few samples, the frame is used as it is
+        if (t == 0) {
+            *out = PercentileOut{0.0f, 0.0f, m, 0u};
+            if (fd) {
+                fd->xf = ab_pixel_xf();
+                fd->finite = m;
+            }
+        }
+        return;
+    }
+    unsigned int r[2] = {m / 100u, (unsigned int)((uint64_t)m * 999u / 1000u)};  // affine.rs:41-42
+    uint32_t prefix[2];
+    {
+        unsigned int b0, w0, b1, w1;
+        find_rank_2048(hist[0], wave_tot, bcast, r[0], &b0, &w0);
+        find_rank_2048(hist[0], wave_tot, bcast, r[1], &b1, &w1);
+        prefix[0] = b0 << 21;
+        prefix[1] = b1 << 21;
+        r[0] = w0;
+        r[1] = w1;
+    }
+    // levels 1 (bits 20..10) and 2 (bits 9..0): both ranks in the same sweep, one histogram each
+    for (int level = 1; level <= 2; ++level) {
+        const int shift = level == 1 ? 10 : 0;
+        const uint32_t digit_mask = level == 1 ? 2047u : 1023u, prefix_mask = level == 1 ? 0xffe00000u : 0xfffffc00u;
+        __syncthreads();
+        for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t p0 = prefix[0], p1 = prefix[1];
+        src.for_each(ns, [&](float v) {
+            const bool ok = fabsf(v) <= 3.4028234663852886e38f;
+            const uint32_t k = ordered_key(v), d = (k >> shift) & digit_mask;
+            if (ok && (k & prefix_mask) == p0) atomicAdd(&hist[0][d], 1u);
+            if (ok && (k & prefix_mask) == p1) atomicAdd(&hist[1][d], 1u);
+        });
+        __syncthreads();
+        for (int q = 0; q < 2; ++q) {
+            unsigned int b, w;
+            find_rank_2048(hist[q], wave_tot, bcast, r[q], &b, &w);
+            prefix[q] |= b << shift;
+            r[q] = w;
+        }
+    }
+    if (t == 0) {
+        const float lo = ordered_value(prefix[0]), hi = ordered_value(prefix[1]);
+        *out = PercentileOut{lo, hi, m, 0u};
+        if (fd) {  // the host's arithmetic (ab_normalize_params_device), on the device
+            ab_pixel_xf xf;
+            const double range = (double)hi - (double)lo;
+            if (!(range < 1e-15)) {
+                xf.lo = (double)lo;
+                xf.inv = 1.0 / range;
+                xf.on = 1;
+            }
+            fd->xf = xf;
+            fd->finite = m;
+        }
+    }
+}
+
+// the subsample held in registers: <= kPctPer values per thread, all loads in flight at once; the three sweeps then read
+// registers.  (Sweeping the buffer in memory cost one dependent L2 round trip per value and sweep -- the LDS atomics keep the
+// compiler from pipelining the loads: 92 us for the workgroup.  Gathering every `step`-th pixel of the plane in this kernel,
+// without subsample_kernel, was worse still: 100 000 scattered cache lines through ONE compute unit, 0.3 ms.)
+constexpr int kPctPer = 100;
+struct RegSample {
+    float v[kPctPer];
+    template <class F>
+    __device__ __forceinline__ void for_each(unsigned int ns, F f) const {
+#pragma unroll
+        for (int j = 0; j < kPctPer; ++j)
+            if ((unsigned int)(j * 1024) < ns) f(v[j]);  // block-uniform; slots past ns hold NaN
+    }
+};
+__global__ __launch_bounds__(1024) void percentiles_reg_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out,
+                                                                FrameDev *__restrict__ fd) {
+    RegSample s;
+#pragma unroll
+    for (int j = 0; j < kPctPer; ++j) {
+        const unsigned int i = (unsigned int)(j * 1024) + threadIdx.x;
+        s.v[j] = i < ns ? sub[i] : __builtin_nanf("");
+    }
+    percentiles_body(s, ns, out, fd);
+}
+
+// larger subsamples (planes of 100 000 .. 200 000 pixels are sampled at step 1): swept from a buffer
+struct MemSample {
+    const float *s;
+    template <class F>
+    __device__ __forceinline__ void for_each(unsigned int ns, F f) const {
+        for (unsigned int i0 = 0; i0 < ns; i0 += 1024) {
+            const unsigned int i = i0 + threadIdx.x;
+            f(i < ns ? s[i] : __builtin_nanf(""));
+        }
+    }
+};
+__global__ __launch_bounds__(1024) void percentiles_mem_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out,
+                                                                FrameDev *__restrict__ fd) {
+    percentiles_body(MemSample{sub}, ns, out, fd);
+}
+
+
+// estimate_background's reduction of the tiles (star_detection.rs:70-83) on the device: the upper median of the valid tiles'
+// medians and of their sigmas (sorted[len / 2]; any order of equal values gives the same element), then detect_stars'
+// threshold (:103).  One workgroup; a tile's rank is counted against all others (<= kBgTiles tiles: 256 for a 4096^2 frame).
+constexpr int kBgTiles = 2048;
+struct BgOut {
+    double bg_median, bg_sigma;
+};
+__global__ __launch_bounds__(1024) void bg_threshold_kernel(const TileOut *__restrict__ tiles, int ntiles, double sigma_threshold,
+                                                            FrameDev *__restrict__ fd, BgOut *__restrict__ out) {
+    __shared__ double med[kBgTiles], sig[kBgTiles];
+    __shared__ unsigned int nv_s;
+    __shared__ double res[2];
+    if (threadIdx.x == 0) {
+        nv_s = 0;
+        res[0] = 0.0;  // no valid tile: (0, 1) (:70-72)
+        res[1] = 1.0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntiles; i += 1024) {
+        const TileOut t = tiles[i];
+        if (t.valid) {
+            const unsigned int at = atomicAdd(&nv_s, 1u);
+            med[at] = t.median;
+            sig[at] = t.sigma;
+        }
+    }
+    __syncthreads();
+    const unsigned int nv = nv_s, want = nv / 2;
+    for (unsigned int i = threadIdx.x; i < nv; i += 1024) {
+        const double mi = med[i], si = sig[i];
+        unsigned int rm = 0, rs = 0;
+        for (unsigned int j = 0; j < nv; ++j) {
+            const double mj = med[j], sj = sig[j];
+            rm += (mj < mi || (mj == mi && j < i)) ? 1u : 0u;
+            rs += (sj < si || (sj == si && j < i)) ? 1u : 0u;
+        }
+        if (rm == want) res[0] = mi;
+        if (rs == want) res[1] = si;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double bg_median = res[0], bg_sigma = nv ? fmax(res[1], 1e-10) : 1.0;  // :81
+        fd->bg_median = bg_median;
+        fd->bg_sigma = bg_sigma;
+        fd->threshold = bg_median + sigma_threshold * bg_sigma;  // :103
+        out->bg_median = bg_median;
+        out->bg_sigma = bg_sigma;
+    }
+}
+
 int f64_cmp(double a, double b) {  // math/median.rs:15-25
     if (a < b) return -1;
     if (a > b) return 1;
@@ -536,7 +787,7 @@ static int tile_stats_host(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
                            ntx, xf, (TileOut *)pin);
     else
         hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(ntiles), dim3(tb::kThreads), 0, ctx->stream, img, (int)rows, (int)cols, ld,
-                           step, ntx, xf, (TileOut *)pin);
+                           step, ntx, xf, (TileOut *)pin, (const FrameDev *)nullptr);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->assign((const TileOut *)pin, (const TileOut *)pin + ntiles);
@@ -569,7 +820,8 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
 
 // detect_stars (star_detection.rs:86-258) on a device plane; stars sorted by flux, deduplicated
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
-                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out, ab_pixel_xf xf, size_t max_keep) {
+                           std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out, ab_pixel_xf xf, size_t max_keep,
+                           bool normalize_first) {
     stars->clear();
     *bg_median_out = 0.0;
     *bg_sigma_out = 1.0;
@@ -579,14 +831,52 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     ab_trace trace("detect_stars");
     const int64_t m = std::min(rows, cols);
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // :100
-    double bg_median, bg_sigma;
-    AB_TRY(ab_estimate_background_device(ctx, img, rows, cols, ld, tile_size, &bg_median, &bg_sigma, xf));
-    trace.mark("background");
-    *bg_median_out = bg_median;
-    *bg_sigma_out = bg_sigma;
-    const double threshold = bg_median + sigma_threshold * bg_sigma;  // :103
-
     const int64_t P = rows * cols;
+    // The chained form (normalize_first: the registration path): percentiles -> tiles -> background -> threshold -> labels are
+    // enqueued back to back, every parameter travelling through FrameDev; the host joins at the component count.
+    const int step = (int)std::max<int64_t>(tile_size, 16);
+    const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
+    static const bool legacy_tiles = getenv("AB_TILE_LEGACY") != nullptr;
+    // OFF by default (AB_DETECT_CHAIN=1 turns it on): measured on the bench, same box, three runs each -- registration stage 18.4 /
+    // 18.6 / 18.7 ms with the two host joins against 21.0 / 21.9 / 22.2 ms chained, although one frame alone gets faster (0.39 ->
+    // 0.37 ms).  Sixteen streams share four in-order hardware queues; a stream that enqueues nine packets in one go holds its
+    // queue until they have all run, and the three streams behind it wait -- the host joins were what interleaved them.
+    static const bool want_chain = getenv("AB_DETECT_CHAIN") != nullptr;
+    const bool chained = normalize_first && ld == cols && ntiles <= kBgTiles && !legacy_tiles && want_chain;
+    double bg_median = 0.0, bg_sigma = 1.0, threshold = 0.0;
+    FrameDev *fd = nullptr;
+    struct Joined {  // what the host reads at the first synchronisation of the chained form (pinned)
+        PercentileOut po;
+        BgOut bg;
+        unsigned int ncomp;
+    };
+    void *pin = nullptr;
+    if (chained) {
+        char *dv = nullptr;
+        AB_TRY(ab_workspace(ctx, AB_WS_DETECT_DEV, sizeof(FrameDev) + (size_t)ntiles * sizeof(TileOut), (void **)&dv));
+        fd = (FrameDev *)dv;
+        TileOut *tiles = (TileOut *)(dv + sizeof(FrameDev));
+        AB_TRY(ab_pinned(ctx, sizeof(Joined), &pin));
+        Joined *jn = (Joined *)pin;
+        const int64_t sstep = std::max<int64_t>(P / 100000, 1), ns = (P + sstep - 1) / sstep;
+        float *sub = nullptr;
+        AB_TRY(ab_workspace(ctx, AB_WS_SUBSAMPLE, (size_t)ns * sizeof(float), (void **)&sub));
+        hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, P, sstep, sub, ns);
+        if (ns <= (int64_t)kPctPer * 1024)
+            hipLaunchKernelGGL(percentiles_reg_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, &jn->po, fd);
+        else
+            hipLaunchKernelGGL(percentiles_mem_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, &jn->po, fd);
+        hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(ntiles), dim3(tb::kThreads), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
+                           ntx, ab_pixel_xf(), tiles, (const FrameDev *)fd);
+        hipLaunchKernelGGL(bg_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const TileOut *)tiles, ntiles, sigma_threshold, fd, &jn->bg);
+        AB_HIP(ctx, hipGetLastError());
+    } else {
+        if (normalize_first) AB_TRY(ab_normalize_params_device(ctx, img, P, &xf));
+        AB_TRY(ab_estimate_background_device(ctx, img, rows, cols, ld, tile_size, &bg_median, &bg_sigma, xf));
+        trace.mark("background");
+        threshold = bg_median + sigma_threshold * bg_sigma;  // :103
+    }
+
     const unsigned int root_cap = (unsigned int)(P / 4 + 1);  // 8-connected components cannot be denser
     int *parent = nullptr, *cid = nullptr, *roots = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_PARENT, (size_t)P * sizeof(int), (void **)&parent));
@@ -601,16 +891,27 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     AB_HIP(ctx, hipMemsetAsync(nroots, 0, 2 * sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(label_init_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds))), dim3(kInitBlock), 0, ctx->stream, img, (int)rows,
                        (int)cols, ld, threshold, xf, parent, mask, plist, nlab,
-                       (int)(ld == cols && (P & 3) == 0 && ((uintptr_t)img & 15) == 0));
+                       (int)(ld == cols && (P & 3) == 0 && ((uintptr_t)img & 15) == 0), (const FrameDev *)fd);
     hipLaunchKernelGGL(label_merge_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, mask, plist, nlab);
     hipLaunchKernelGGL(roots_kernel, dim3(gl / 4), dim3(kRootsBlock), 0, ctx->stream, parent, plist, nlab, roots, cid, nroots, root_cap);
     AB_HIP(ctx, hipGetLastError());
-    void *pin = nullptr;
-    AB_TRY(ab_pinned(ctx, 64, &pin));
-    AB_HIP(ctx, hipMemcpyAsync(pin, nroots, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const unsigned int ncomp = *(const unsigned int *)pin;
-    trace.mark("label+roots");
+    unsigned int ncomp = 0;
+    if (chained) {
+        Joined *jn = (Joined *)pin;
+        AB_HIP(ctx, hipMemcpyAsync(&jn->ncomp, nroots, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ncomp = jn->ncomp;
+        bg_median = jn->bg.bg_median;
+        bg_sigma = jn->bg.bg_sigma;
+    } else {
+        AB_TRY(ab_pinned(ctx, 64, &pin));
+        AB_HIP(ctx, hipMemcpyAsync(pin, nroots, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ncomp = *(const unsigned int *)pin;
+    }
+    *bg_median_out = bg_median;
+    *bg_sigma_out = bg_sigma;
+    trace.mark(chained ? "percentiles+background+label+roots" : "label+roots");
     AB_CHECK(ctx, ncomp <= root_cap, "detect_stars: %u components exceed the table capacity", ncomp);
     if (ncomp == 0) return AB_OK;
     void *cbuf = nullptr;
@@ -621,7 +922,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     hipLaunchKernelGGL(comp_init_kernel, dim3((ncomp + 255) / 256), dim3(256), 0, ctx->stream, dstat, ncomp);
     hipLaunchKernelGGL(comp_stats_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, cid, dstat, plist, nlab);
     hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, mask, roots, dstat, ncomp,
-                       bg_median, xf, drec);
+                       bg_median, xf, drec, (const FrameDev *)fd);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipMemcpyAsync(pin, drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -719,168 +1020,6 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     return AB_OK;
 }
 
-// normalize_for_detection's parameters (affine.rs:24-47): the 1st and 99.9th percentile of an every-step subsample.
-// xf->on = 0 when the reference returns image.clone() (too few finite samples / flat range).
-// The 1 % / 99.9 % order statistics of the finite subsample values (affine.rs:33-42 sorts the subsample; only these two
-// elements of the sorted list are read), by ONE 1024-thread workgroup: an 11 / 11 / 10-bit radix select on the monotone image
-// of the float bit patterns (any sign), both ranks descending together -- three sweeps over ~100 000 values in L2.  The first
-// version copied the subsample to the host and ran std::nth_element twice: 0.7 .. 1.2 ms of a worker thread per frame, the
-// largest single item of the registration stage's per-frame host time.
-namespace {
-struct PercentileOut {
-    float lo, hi;
-    unsigned int finite;  // count of finite subsample values
-    unsigned int pad;
-};
-__device__ __forceinline__ uint32_t ordered_key(float v) {  // monotone for every finite float (-0.0 sorts just below +0.0)
-    const uint32_t b = __float_as_uint(v);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float ordered_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
-
-// histogram update with the wave's first bin tallied by ballot: sky pixels share their top bits, and 64 lanes adding to one LDS
-// address serialise
-__device__ __forceinline__ void tally(unsigned int *hist, bool on, uint32_t bin) {
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(on);
-    if (!act) return;
-    const uint32_t mode = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)__builtin_ctzll(act));
-    const unsigned long long same = __builtin_amdgcn_ballot_w64(on && bin == mode);
-    if ((threadIdx.x & 63) == (int)__builtin_ctzll(act)) atomicAdd(&hist[mode], (unsigned int)__builtin_popcountll(same));
-    if (on && bin != mode) atomicAdd(&hist[bin], 1u);
-}
-
-// the bin of `hist[0 .. 2048)` that holds 0-based rank r, and r's rank inside it; every thread gets the answer (block of 1024)
-__device__ __forceinline__ void find_rank_2048(const unsigned int *hist, unsigned int *wave_tot /* 16 */, unsigned int *bcast /* 2 */,
-                                               unsigned int r, unsigned int *bin, unsigned int *within) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const unsigned int h0 = hist[2 * t], h1 = hist[2 * t + 1], mine = h0 + h1;
-    unsigned int inc = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned int u = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += u;
-    }
-    __syncthreads();  // (wave_tot / bcast may still be read from the previous call)
-    if (lane == 63) wave_tot[wv] = inc;
-    __syncthreads();
-    unsigned int base = 0;
-    for (int i = 0; i < wv; ++i) base += wave_tot[i];
-    const unsigned int excl = base + inc - mine;
-    if (r >= excl && r < excl + mine) {  // exactly one thread
-        const bool second = r - excl >= h0;
-        bcast[0] = 2u * t + (second ? 1u : 0u);
-        bcast[1] = r - excl - (second ? h0 : 0u);
-    }
-    __syncthreads();
-    *bin = bcast[0];
-    *within = bcast[1];
-}
-
-// SRC supplies sample i; the sweeps are written once for both sources below
-template <class SRC>
-__device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns, PercentileOut *__restrict__ out) {
-    __shared__ unsigned int hist[2][2048];
-    __shared__ unsigned int wave_tot[16], bcast[2];
-    const int t = threadIdx.x;
-    for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
-    __syncthreads();
-    // level 0: key bits 31..21 of every finite value; the total is the finite count
-    src.for_each(ns, [&](float v) {
-        const bool ok = fabsf(v) <= 3.4028234663852886e38f;  // finite (NaN fails)
-        tally(hist[0], ok, ordered_key(v) >> 21);
-    });
-    __syncthreads();
-    unsigned int m = 0;
-    {
-        const unsigned int mine = hist[0][2 * t] + hist[0][2 * t + 1];
-        unsigned int x = mine;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
-        if ((t & 63) == 0) wave_tot[t >> 6] = x;
-        __syncthreads();
-        for (int i = 0; i < 16; ++i) m += wave_tot[i];
-    }
-    if (m < 100u) {  // affine.rs:34-36: too few samples, the frame is used as it is
-        if (t == 0) *out = PercentileOut{0.0f, 0.0f, m, 0u};
-        return;
-    }
-    unsigned int r[2] = {m / 100u, (unsigned int)((uint64_t)m * 999u / 1000u)};  // affine.rs:41-42
-    uint32_t prefix[2];
-    {
-        unsigned int b0, w0, b1, w1;
-        find_rank_2048(hist[0], wave_tot, bcast, r[0], &b0, &w0);
-        find_rank_2048(hist[0], wave_tot, bcast, r[1], &b1, &w1);
-        prefix[0] = b0 << 21;
-        prefix[1] = b1 << 21;
-        r[0] = w0;
-        r[1] = w1;
-    }
-    // levels 1 (bits 20..10) and 2 (bits 9..0): both ranks in the same sweep, one histogram each
-    for (int level = 1; level <= 2; ++level) {
-        const int shift = level == 1 ? 10 : 0;
-        const uint32_t digit_mask = level == 1 ? 2047u : 1023u, prefix_mask = level == 1 ? 0xffe00000u : 0xfffffc00u;
-        __syncthreads();
-        for (int i = t; i < 2 * 2048; i += 1024) (&hist[0][0])[i] = 0;
-        __syncthreads();
-        const uint32_t p0 = prefix[0], p1 = prefix[1];
-        src.for_each(ns, [&](float v) {
-            const bool ok = fabsf(v) <= 3.4028234663852886e38f;
-            const uint32_t k = ordered_key(v), d = (k >> shift) & digit_mask;
-            if (ok && (k & prefix_mask) == p0) atomicAdd(&hist[0][d], 1u);
-            if (ok && (k & prefix_mask) == p1) atomicAdd(&hist[1][d], 1u);
-        });
-        __syncthreads();
-        for (int q = 0; q < 2; ++q) {
-            unsigned int b, w;
-            find_rank_2048(hist[q], wave_tot, bcast, r[q], &b, &w);
-            prefix[q] |= b << shift;
-            r[q] = w;
-        }
-    }
-    if (t == 0) *out = PercentileOut{ordered_value(prefix[0]), ordered_value(prefix[1]), m, 0u};
-}
-
-// the subsample held in registers: <= kPctPer values per thread, all loads in flight at once; the three sweeps then read
-// registers.  (Sweeping the buffer in memory cost one dependent L2 round trip per value and sweep -- the LDS atomics keep the
-// compiler from pipelining the loads: 92 us for the workgroup.  Gathering every `step`-th pixel of the plane in this kernel,
-// without subsample_kernel, was worse still: 100 000 scattered cache lines through ONE compute unit, 0.3 ms.)
-constexpr int kPctPer = 100;
-struct RegSample {
-    float v[kPctPer];
-    template <class F>
-    __device__ __forceinline__ void for_each(unsigned int ns, F f) const {
-#pragma unroll
-        for (int j = 0; j < kPctPer; ++j)
-            if ((unsigned int)(j * 1024) < ns) f(v[j]);  // block-uniform; slots past ns hold NaN
-    }
-};
-__global__ __launch_bounds__(1024) void percentiles_reg_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
-    RegSample s;
-#pragma unroll
-    for (int j = 0; j < kPctPer; ++j) {
-        const unsigned int i = (unsigned int)(j * 1024) + threadIdx.x;
-        s.v[j] = i < ns ? sub[i] : __builtin_nanf("");
-    }
-    percentiles_body(s, ns, out);
-}
-
-// larger subsamples (planes of 100 000 .. 200 000 pixels are sampled at step 1): swept from a buffer
-struct MemSample {
-    const float *s;
-    template <class F>
-    __device__ __forceinline__ void for_each(unsigned int ns, F f) const {
-        for (unsigned int i0 = 0; i0 < ns; i0 += 1024) {
-            const unsigned int i = i0 + threadIdx.x;
-            f(i < ns ? s[i] : __builtin_nanf(""));
-        }
-    }
-};
-__global__ __launch_bounds__(1024) void percentiles_mem_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
-    percentiles_body(MemSample{sub}, ns, out);
-}
-
-}  // namespace
-
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     *xf = ab_pixel_xf();
@@ -894,9 +1033,9 @@ int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pi
     AB_TRY(ab_workspace(ctx, AB_WS_SUBSAMPLE, (size_t)ns * sizeof(float), (void **)&sub));
     hipLaunchKernelGGL(subsample_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, ctx->stream, img, len, step, sub, ns);
     if (ns <= (int64_t)kPctPer * 1024)
-        hipLaunchKernelGGL(percentiles_reg_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin);
+        hipLaunchKernelGGL(percentiles_reg_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin, (FrameDev *)nullptr);
     else
-        hipLaunchKernelGGL(percentiles_mem_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin);
+        hipLaunchKernelGGL(percentiles_mem_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, (PercentileOut *)pin, (FrameDev *)nullptr);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     trace.mark("subsample+percentiles+sync");

@@ -219,3 +219,37 @@ def test_align_pairs_affine_equals_estimate_then_warp(ctx, oracle):
         assert (r.method, r.transform, r.inliers) == (a.method, a.transform, a.inliers)
         want = oracle.warp_image(t.cpu().numpy(), r.transform, rows, cols)
         assert np.array_equal(o.cpu().numpy(), want)
+
+
+def test_chained_detection_gives_the_same_transform():
+    """AB_DETECT_CHAIN=1 (read once per process): percentiles -> tiles -> background -> threshold -> labels enqueued back to back
+    with the parameters travelling through device memory.  Same registration result as the default path, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "import astroburst_amd as ab\n"
+        "from astroburst_amd import synth\n"
+        "ctx = ab.Context(0)\n"
+        "y, x, flux = synth.star_catalog(1024, 1024, 400, seed=3)\n"
+        "cat = (y, x, flux * 25.0)\n"
+        "ref = synth.make_frame(1024, 1024, 0, cat=cat, device='cuda')\n"
+        "tgt = synth.make_frame(1024, 1024, 1, cat=cat, device='cuda', shift=(3.3, -5.1))\n"
+        "r = ctx.align_channel_affine(ref, tgt, 8)\n"
+        "print('RESULT', json.dumps([float(v).hex() for v in r.transform] + [str(r.method), int(r.inliers)]))\n"
+    ) % root
+    out = []
+    for chain in (False, True):
+        env = dict(os.environ)
+        env.pop("AB_DETECT_CHAIN", None)
+        if chain:
+            env["AB_DETECT_CHAIN"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-3000:]
+        out.append(line[0])
+    assert out[0] == out[1]
