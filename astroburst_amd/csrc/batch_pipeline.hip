@@ -45,10 +45,10 @@
         const T x0_ = v[a], x1_ = v[b], x2_ = v[c], x3_ = v[d];                      \
         const T s0_ = fminf(fminf(x0_, x1_), x2_), s1_ = __builtin_amdgcn_fmed3f(x0_, x1_, x2_), \
                 s2_ = fmaxf(fmaxf(x0_, x1_), x2_);                                   \
-        v[a] = fminf(s0_, x3_);                                                      \
+        v[a] = __builtin_amdgcn_fmed3f(-__builtin_inff(), s0_, x3_); /* = min: no canonicalising v_max of x3 first */ \
         v[b] = __builtin_amdgcn_fmed3f(s0_, s1_, x3_);                               \
         v[c] = __builtin_amdgcn_fmed3f(s1_, s2_, x3_);                               \
-        v[d] = fmaxf(s2_, x3_);                                                      \
+        v[d] = __builtin_amdgcn_fmed3f(__builtin_inff(), s2_, x3_);  /* = max */          \
     }
 #include "sortnet_gen.hpp"
 

@@ -47,10 +47,10 @@
         const T x0_ = v[a], x1_ = v[b], x2_ = v[c], x3_ = v[d];                      \
         const T s0_ = fminf(fminf(x0_, x1_), x2_), s1_ = __builtin_amdgcn_fmed3f(x0_, x1_, x2_), \
                 s2_ = fmaxf(fmaxf(x0_, x1_), x2_);                                   \
-        v[a] = fminf(s0_, x3_);                                                      \
+        v[a] = __builtin_amdgcn_fmed3f(-__builtin_inff(), s0_, x3_); /* = min: no canonicalising v_max of x3 first */ \
         v[b] = __builtin_amdgcn_fmed3f(s0_, s1_, x3_);                               \
         v[c] = __builtin_amdgcn_fmed3f(s1_, s2_, x3_);                               \
-        v[d] = fmaxf(s2_, x3_);                                                      \
+        v[d] = __builtin_amdgcn_fmed3f(__builtin_inff(), s2_, x3_);  /* = max */          \
     }
 #endif
 #include "sortnet_gen.hpp"
@@ -282,17 +282,27 @@ __device__ __forceinline__ ClipResult clip_exact(float (&v)[NP], int n, float me
 // variance differs from the two-pass value by a few ulp(f64), i.e. the f32 sigma is identical
 // except with probability ~1e-8 per pixel -- far inside the 1e-5 contract, and measured in
 // tests/ against engine A and the oracle.
+// wave reductions on DPP moves (row_shr 1/2/4/8, row_bcast 15 / 31; lanes without a source take the identity) and one v_readlane:
+// VALU only, where the __shfl_xor butterfly is six dependent ds_bpermute round trips
+template <int OP>  // 0 sum, 1 min, 2 max (signed)
+__device__ __forceinline__ int wave_reduce_i32(int x) {
+    constexpr int id = OP == 1 ? 0x7fffffff : (OP == 2 ? (int)0x80000000 : 0);
+    auto op = [](int a, int b) { return OP == 0 ? a + b : (OP == 1 ? min(a, b) : max(a, b)); };
+    x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x111, 0xf, 0xf, false));
+    x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x112, 0xf, 0xf, false));
+    x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x114, 0xf, 0xf, false));
+    x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x118, 0xf, 0xf, false));
+    x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x142, 0xa, 0xf, false));
+    x = op(x, __builtin_amdgcn_update_dpp(id, x, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(x, 63);
+}
 template <int NP>
 __device__ __forceinline__ int wave_max_i32(int x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = max(x, __shfl_xor(x, off, 64));
-    return __builtin_amdgcn_readfirstlane(x);
+    return wave_reduce_i32<2>(x);
 }
 template <int NP>
 __device__ __forceinline__ int wave_min_i32(int x) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = min(x, __shfl_xor(x, off, 64));
-    return __builtin_amdgcn_readfirstlane(x);
+    return wave_reduce_i32<1>(x);
 }
 
 // One clipping pass over the two ends.  UPDATE: also fold the shaved samples into s_rem/q_rem.
@@ -776,8 +786,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
     // counters (summed by the host).  All 262 144 waves of a 4096^2 stack adding to a single
     // address serialise at ~12 ns per atomic = 3 ms, more than the whole kernel; a workgroup-level
     // LDS reduction would need a barrier that makes the 4 waves of a group wait for the slowest.
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) rej += __shfl_xor(rej, off, 64);
+    rej = (uint32_t)wave_reduce_i32<0>((int)rej);
     if ((threadIdx.x & 63) == 0 && rej != 0)
         atomicAdd(&args.rejected[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kRejSlots - 1)], (unsigned long long)rej);
 }
