@@ -559,6 +559,39 @@ __device__ __forceinline__ double lane_f64(double x, int lane) {  // wave-unifor
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+// Per group of 64 consecutive reference triangles: the ratio windows and the bucket range a candidate must fall into to match
+// ANY triangle of the group.  The reference table is the same for every target of a batch, so these are computed once per batch
+// (one wave per group) instead of by four 64-lane f64 shuffle reductions per work item in every vote kernel -- 48 dependent
+// ds_bpermute round trips per item in a kernel of 1024 lone waves that has nothing to hide them behind.
+struct RefGroup {
+    double lmin, lmax, mmin, mmax;
+    int bmin, bmax;
+};
+__global__ __launch_bounds__(64) void tri_group_windows_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
+                                                               RefGroup *__restrict__ out) {
+    const unsigned int nr = *nr_p, first = blockIdx.x * 64u, lane = threadIdx.x;
+    if (first >= nr) return;
+    const DTri a = rt_sorted[first + lane < nr ? first + lane : nr - 1];  // tail lanes replicate the last triangle
+    double lmin = a.lng, lmax = a.lng, mmin = a.mid, mmax = a.mid;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lmin = fmin(lmin, __shfl_xor(lmin, off, 64));
+        lmax = fmax(lmax, __shfl_xor(lmax, off, 64));
+        mmin = fmin(mmin, __shfl_xor(mmin, off, 64));
+        mmax = fmax(mmax, __shfl_xor(mmax, off, 64));
+    }
+    if (lane == 0) {
+        RefGroup g;
+        g.lmin = lmin;
+        g.lmax = lmax;
+        g.mmin = mmin;
+        g.mmax = mmax;
+        g.bmin = tri_bin(rt_sorted[first].mid);
+        g.bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
+        out[blockIdx.x] = g;
+    }
+}
+
 // slices of a ref group's candidate range (dense buckets would otherwise leave a few very long waves) x persistent one-wave
 // blocks, each flushing its LDS votes once.  Measured (blocks, slices) -> us per frame: (1024, 8) 62, (2048, 8) 74,
 // (2048, 16) 69, (1024, 4) 79, (4096, 8) 79: more blocks pay for more flushes, fewer slices for imbalance.
@@ -566,7 +599,8 @@ constexpr int kVoteSlices = 8;
 constexpr int kVoteBlocks = 1024;
 __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
-                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */) {
+                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */,
+                                                      const RefGroup *__restrict__ groups) {
     // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and with a stride of 64
     // (a multiple of the bank count) all of those atomics would land in one bank
     constexpr int kLdsStride = kVoteDim + 1;
@@ -580,18 +614,11 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
         const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
         const bool have = r < nr;
         const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
-        double lmin = a.lng, lmax = a.lng, mmin = a.mid, mmax = a.mid;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            lmin = fmin(lmin, __shfl_xor(lmin, off, 64));
-            lmax = fmax(lmax, __shfl_xor(lmax, off, 64));
-            mmin = fmin(mmin, __shfl_xor(mmin, off, 64));
-            mmax = fmax(mmax, __shfl_xor(mmax, off, 64));
-        }
+        const RefGroup grp = groups[item / kVoteSlices];  // (uniform: scalar loads)
         // a candidate can match SOME triangle of the group only inside the group's ratio windows (widened by the tolerance)
-        const double win_lo = lmin - kTriangleTolerance * 1.0001, win_hi = lmax + kTriangleTolerance * 1.0001;
-        const double mwin_lo = mmin - kTriangleTolerance * 1.0001, mwin_hi = mmax + kTriangleTolerance * 1.0001;
-        const int bmin = tri_bin(rt_sorted[first].mid), bmax = tri_bin(rt_sorted[min(first + 63u, nr - 1u)].mid);
+        const double win_lo = grp.lmin - kTriangleTolerance * 1.0001, win_hi = grp.lmax + kTriangleTolerance * 1.0001;
+        const double mwin_lo = grp.mmin - kTriangleTolerance * 1.0001, mwin_hi = grp.mmax + kTriangleTolerance * 1.0001;
+        const int bmin = grp.bmin, bmax = grp.bmax;
         unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
         {
             const unsigned int per = (q1 - q0 + kVoteSlices - 1) / kVoteSlices;
@@ -634,12 +661,14 @@ struct MatchWs {
     unsigned int *counts;  // [0] ref, [1] tgt
     unsigned int *bin_hist, *bin_off, *cursor;
     unsigned int *votes;
+    RefGroup *groups;  // per 64 reference triangles (tri_group_windows_kernel)
 };
 
 int match_ws(ab_ctx *ctx, MatchWs *w) {
     const size_t tri_bytes = (size_t)kMaxTris * sizeof(DTri), vote_bytes = kVoteDim * kVoteDim * sizeof(unsigned int);
     const size_t bin_words = 64 + 3 * (size_t)kTriBins + 64;
-    const size_t total = 4 * tri_bytes + bin_words * sizeof(unsigned int) + vote_bytes;
+    const size_t group_bytes = (size_t)((kMaxTris + 63) / 64) * sizeof(RefGroup);
+    const size_t total = 4 * tri_bytes + bin_words * sizeof(unsigned int) + vote_bytes + group_bytes;
     char *p = nullptr;
     const void *before = ctx->ws[AB_WS_REGISTER];
     AB_TRY(ab_workspace(ctx, AB_WS_REGISTER, total, (void **)&p));
@@ -655,6 +684,7 @@ int match_ws(ab_ctx *ctx, MatchWs *w) {
     w->bin_off = w->bin_hist + kTriBins;  // kTriBins + 1 entries
     w->cursor = w->bin_off + kTriBins + 32;
     w->votes = u + bin_words;
+    w->groups = (RefGroup *)((char *)w->votes + vote_bytes);
     return AB_OK;
 }
 
@@ -678,7 +708,11 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
     // (the scan leaves bin_hist zeroed again)
     hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
     hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 1023) / 1024), dim3(1024), 0, ctx->stream, raw, w.counts + which, w.cursor, sorted);
-    if (!which) hipLaunchKernelGGL(tri_bucket_sort_kernel, dim3(kTriBins), dim3(256), 0, ctx->stream, sorted, w.bin_off);
+    if (!which) {
+        hipLaunchKernelGGL(tri_bucket_sort_kernel, dim3(kTriBins), dim3(256), 0, ctx->stream, sorted, w.bin_off);
+        hipLaunchKernelGGL(tri_group_windows_kernel, dim3((kMaxTris + 63) / 64), dim3(64), 0, ctx->stream, (const DTri *)sorted, (const unsigned int *)w.counts,
+                           w.groups);
+    }
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -686,7 +720,7 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
 // votes of the current ref / tgt triangle tables -> host (kVoteDim x kVoteDim)
 int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std::vector<uint32_t> *votes) {
     AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes);
+    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, (const RefGroup *)w.groups);
     AB_HIP(ctx, hipGetLastError());
     votes->resize(kVoteDim * kVoteDim);
     AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -751,6 +785,7 @@ static int register_one(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const f
         AB_TRY(gpu_build_triangles(wc, w, ts, 1));
         MatchWs mixed = w;  // tgt table and votes of this worker; ref table of the caller
         mixed.ref_sorted = ref_ws.ref_sorted;
+        mixed.groups = ref_ws.groups;
         std::vector<uint32_t> votes;
         AB_TRY(gpu_votes(wc, mixed, ref_ws.counts, &votes));
         trace.mark("triangles+votes");
