@@ -126,6 +126,26 @@ __device__ __forceinline__ void gather(float (&u)[NP], const uint32_t (&plo_in)[
     }
 }
 
+// The same gather with the plane pointers through the SCALAR cache (<= 64 slots): the table is the first member of the kernel
+// argument block, `s_load_dwordx16` fetches eight pointers at a time and every sample is `global_load_dword v, voffset,
+// s[base:base+1]` -- no v_readlane pair, no descriptor, no s_nop per sample (that was 15 % of the chunk loop's instructions).
+// The kernarg pointer goes through an opaque copy on every call: hoisted out of the chunk loop, the 64 bases would overflow
+// the SGPR file and be spilled lane by lane, which is how the VGPR-resident table above came about.  gi < npix (clamped by
+// the callers), so nothing is out of range without the descriptor's bounds check.
+template <int NP>
+__device__ __forceinline__ void gather_scalar(float (&u)[NP], uint32_t gi) {
+    static_assert(NP <= 64, "the 128-slot kernel keeps its table in two VGPRs");
+    const uint32_t off = gi * 4u;
+    // (explicit address spaces: behind the opaque copy the compiler no longer knows that this is the kernarg segment -- constant,
+    // uniform -- nor that what it holds are global pointers, and would fall back to 64-bit flat loads for both)
+    typedef const uint64_t __attribute__((address_space(4))) *KernargTable;
+    typedef const float __attribute__((address_space(1))) *GlobalF32;
+    KernargTable kp = (KernargTable)__builtin_amdgcn_kernarg_segment_ptr();  // BatchArgs::p is at offset 0
+    asm volatile("" : "+s"(kp));
+#pragma unroll
+    for (int f = 0; f < NP; ++f) u[f] = *(GlobalF32)(kp[f] + off);
+}
+
 // slot f of a ragged stack (n < NP) is a pad.  The frame count goes through an opaque scalar copy at every use: left to
 // itself LLVM evaluates all NP `f >= n` up front as 64-bit lane masks, keeps them for the whole chunk loop and spills the
 // SGPR file (157 spills, one wave per SIMD, 2x the time of the full kernel).
@@ -167,7 +187,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
     if constexpr (PF) {
         if (first < end) {
             const uint32_t g0 = first * kWave + lane, gi0 = g0 < a.npix ? g0 : a.npix - 1;
-            gather<NP>(nxt, plo, phi, gi0, a.npix * 4u);
+            if constexpr (NP <= 64) gather_scalar<NP>(nxt, gi0); else gather<NP>(nxt, plo, phi, gi0, a.npix * 4u);
             if constexpr (CAL) cnxt = cal_load(a.m, gi0);
         }
     }
@@ -185,12 +205,12 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
             c = cnxt;
             if (chunk + step < end) {
                 const uint32_t g1 = (chunk + step) * kWave + lane, gi1 = g1 < a.npix ? g1 : a.npix - 1;
-                gather<NP>(nxt, plo, phi, gi1, a.npix * 4u);
+                if constexpr (NP <= 64) gather_scalar<NP>(nxt, gi1); else gather<NP>(nxt, plo, phi, gi1, a.npix * 4u);
                 if constexpr (CAL) cnxt = cal_load(a.m, gi1);
             }
         } else {
             const uint32_t gi = valid ? g : a.npix - 1;
-            gather<NP>(u, plo, phi, gi, a.npix * 4u);
+            if constexpr (NP <= 64) gather_scalar<NP>(u, gi); else gather<NP>(u, plo, phi, gi, a.npix * 4u);
             if constexpr (CAL) c = cal_load(a.m, gi);
         }
         if constexpr (CAL) {
