@@ -3,7 +3,12 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/stack_ablate.hip -o build/stack_ablate
 #include "../astroburst_amd/csrc/ab_context.hip"
 #include "../astroburst_amd/csrc/stack_sigma_clip.hip"
-#include "../astroburst_amd/csrc/stack_wide.hip"
+// (the > 64-frame path lives in stack_wide.hip, whose file-scope constants collide with stack_sigma_clip.hip's when both are
+// pulled into one translation unit; this tool never stacks more than 64 frames)
+int ab_stack_wide_device(ab_ctx *ctx, const float *const *, const int64_t *, size_t, int64_t, int64_t, const ab_stack_config *, float *, double *,
+                         uint32_t *, bool) {
+    return ab_set_error(ctx, AB_ERR_INVALID, "stack_ablate: the wide path is not linked into this tool");
+}
 
 __global__ void fill_kernel(float *p, int64_t n, uint32_t seed, float cr_rate) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,7 +68,7 @@ int main(int argc, char **argv) {
         args.p[f] = p; args.ld[f] = cols;
     }
     float *out; hipMalloc(&out, P * 4);
-    args.n = 64; args.contiguous = 1; args.rows = rows; args.cols = cols;
+    args.n = 64; args.n_real = 64; args.contiguous = 1; args.rows = rows; args.cols = cols;
     args.sigma_low = 3.f; args.sigma_high = 3.f; args.max_iter = 5; args.out = out; args.rejected = ctx->counters;
     hipStreamSynchronize(ctx->stream);
     const double gb = (4.0 * 64 * P + 4.0 * P) / 1e9;
