@@ -154,3 +154,28 @@ def test_allocation_failure_is_a_status_code_not_an_abort():
     assert rc == _lib.AB_ERR_NOMEM            # std::bad_alloc: 2^48 bytes exceed the address space
     rc = L.ab_affine_from_stars(xy, 4, xy, 4, 100, 100, 8, ctypes.byref(res), ctypes.byref(found))
     assert rc == _lib.AB_OK                   # and the library still works
+
+
+def test_sorting_networks_are_current_and_sort():
+    """astroburst_amd/csrc/sortnet_gen.hpp is what tools/gen_sortnet.py writes (the generator checks every network with the
+    0-1 principle before it emits it), and its AB_SORT4 base case -- sort three with min3 / med3 / max3, then place the fourth
+    with min, med3, med3, max -- sorts every arrangement of four values, ties and infinities included."""
+    import importlib.util
+    import itertools
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_sortnet", os.path.join(root, "tools", "gen_sortnet.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(gen.PATH).read() == gen.render()
+
+    def med3(a, b, c):
+        return sorted((a, b, c))[1]
+
+    def sort4(x0, x1, x2, x3):  # the macro in stack_sigma_clip.hip / batch_pipeline.hip, operation for operation
+        s0, s1, s2 = min(x0, x1, x2), med3(x0, x1, x2), max(x0, x1, x2)
+        return [med3(float("-inf"), s0, x3), med3(s0, s1, x3), med3(s1, s2, x3), med3(float("inf"), s2, x3)]
+
+    vals = [0.0, 1.0, 1.0, 2.5, float("inf"), float("-inf")]
+    for combo in itertools.product(vals, repeat=4):
+        assert sort4(*combo) == sorted(combo)
