@@ -285,6 +285,26 @@ __device__ __forceinline__ unsigned int gather_sweep(const Keys &K, Shared &sh, 
             ++cnt;
         }
     };
+    if constexpr (!DEV) {
+        // a value gather wants one bucket's keys -- one key in a thousand: four keys share a wave-wide test, and only the one
+        // group in five that holds a hit anywhere in the wave goes on to the stores (6 instructions per key instead of 10)
+#pragma unroll 1
+        for (int j = 0; j < 32; ++j) {
+            uint32_t k[kVecs];
+            unsigned long long any = 0;
+#pragma unroll
+            for (int c = 0; c < kVecs; ++c) {
+                k[c] = K.v[c][j];
+                any |= __builtin_amdgcn_ballot_w64(k[c] - l1 <= w1);
+            }
+            if (any) {
+#pragma unroll
+                for (int c = 0; c < kVecs; ++c) put(k[c], k[c] - l1 <= w1);
+                cnt = cnt < (unsigned int)(kOwn + 1) ? cnt : (unsigned int)(kOwn + 1);
+            }
+        }
+        return cnt;
+    }
 #pragma unroll 1
     for (int j = 0; j < 32; ++j) {
 #pragma unroll
@@ -576,7 +596,7 @@ __device__ __forceinline__ Bounds dev_bounds(const Shared &sh, const Window &w, 
 
 // ranks r_lo <= r_hi (adjacent or equal, 0-based) of the deviation keys of the window's candidates
 __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Frame &f, const Window &w, double median, unsigned int r_lo,
-                                            unsigned int r_hi, uint32_t *d_lo, uint32_t *d_hi) {
+                                            unsigned int r_hi, float mad_guess, uint32_t *d_lo, uint32_t *d_hi) {
     DevCtx c;
     c.f = f;
     c.median = median;
@@ -610,15 +630,34 @@ __device__ __forceinline__ void select_devs(const Keys &K, Shared &sh, const Fra
             *br = r > c.bm ? r : c.bm;
         };
         unsigned int first = 0xffffffffu, z0 = 0, z1 = 0, z2 = 0;
-#pragma unroll
-        for (int j = 0; j < PERT; ++j) {
-            const unsigned int i = (unsigned int)(j * kThreads) + threadIdx.x;
+        // where to look first: one threshold per thread in a window of 512 around the expected MAD (the sample's, then the
+        // previous iteration's).  The window's answer is THE first threshold iff it lies strictly inside the window (F~ is
+        // monotone: below the window's start it is smaller still); otherwise all 4096 thresholds are evaluated, 8 per thread.
+        bool windowed = false;
+        if (mad_guess > 0.0f && delta > 0.0f) {
+            const float gi = mad_guess / delta;
+            const unsigned int guess = gi < 3500.0f ? (unsigned int)gi : 3500u, i_lo = guess > 256u ? guess - 256u : 0u;
+            const unsigned int i = i_lo + threadIdx.x;
             int bl, br;
             ring_of((float)(i + 1u) * delta, &bl, &br);
             const unsigned int F = wprefix(sh, w, br + 1) - wprefix(sh, w, bl);
-            if (F >= r_hi + 1u) first = first < i ? first : i;
+            if (F >= r_hi + 1u) first = i;
+            block_reduce4<OP_MIN, OP_SUM, OP_SUM, OP_SUM>(sh, first, z0, z1, z2);
+            windowed = first != 0xffffffffu && (first > i_lo || i_lo == 0u);
         }
-        block_reduce4<OP_MIN, OP_SUM, OP_SUM, OP_SUM>(sh, first, z0, z1, z2);
+        if (!windowed) {
+            first = 0xffffffffu;
+            z0 = z1 = z2 = 0;
+#pragma unroll
+            for (int j = 0; j < PERT; ++j) {
+                const unsigned int i = (unsigned int)(j * kThreads) + threadIdx.x;
+                int bl, br;
+                ring_of((float)(i + 1u) * delta, &bl, &br);
+                const unsigned int F = wprefix(sh, w, br + 1) - wprefix(sh, w, bl);
+                if (F >= r_hi + 1u) first = first < i ? first : i;
+            }
+            block_reduce4<OP_MIN, OP_SUM, OP_SUM, OP_SUM>(sh, first, z0, z1, z2);
+        }
         TB_MARK(sh, 4);
         if (first != 0xffffffffu && delta > 0.0f) {
             int bLo, bRo, bLi = 0, bRi = 0;
@@ -849,6 +888,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh, cons
     Frame f;
     f.kmin = kmin;
     f.kmax = kmax;
+    float mad_guess = 0.0f;
     {
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const uint32_t sorted = wave_sort64(sample_key(K));
@@ -877,6 +917,7 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh, cons
         if (sn > 0.0f) {
             const float Q1 = s1 / sn, Q2 = s2 / sn, Q3 = s3 / sn;
             const float sig = (Q3 - Q1) * (1.0f / 1.349f);
+            mad_guess = 0.6745f * sig;  // where select_devs looks first
             uint32_t kc = __float_as_uint(Q2);
             kc = kc < kmin ? kmin : (kc > kmax ? kmax : kc);
             const float up = Q2 + sig;
@@ -898,9 +939,27 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh, cons
     // ---- the one histogram sweep ----
     for (int i = threadIdx.x; i < kBuckets; i += kThreads) sh.prefix[i] = 0;
     __syncthreads();
-    for_each_key(K, [&](uint32_t k) {
-        if (k) atomicAdd(&sh.prefix[f.bucket_of(k)], 1u);
-    });
+    // Straight-line bucket index for the sweep: with base = zlo - 2^shift, min((key -sat base) >> shift, ..) is 0 below zlo and
+    // 1 + ((key - zlo) >> shift) from zlo on; only "above zhi" keeps its compare (a key just above zhi may share the last
+    // central bucket's granule).  Non-candidates (key 0) simply land in bucket 0 and are taken out again afterwards -- no
+    // predicate, no nested exec regions: 9 instructions per key instead of ~20.  Not when most of the tile is empty (64 lanes
+    // adding to one LDS address serialise) or when base would underflow: then the plain form.
+    const uint32_t gran = 1u << f.shift;
+    if (f.zlo >= gran && cnt * 2u >= (unsigned int)(kThreads * kSlots)) {
+        const uint32_t base = f.zlo - gran, zhi = f.zhi, top = (uint32_t)(f.nb - 1);
+        const int shift = f.shift;
+        for_each_key(K, [&](uint32_t k) {
+            const uint32_t t = k > base ? k - base : 0u;
+            const uint32_t b = k > zhi ? top : (t >> shift);
+            atomicAdd(&sh.prefix[b], 1u);
+        });
+        __syncthreads();
+        if (threadIdx.x == 0) sh.prefix[0] -= (unsigned int)(kThreads * kSlots) - cnt;  // the non-candidates
+    } else {
+        for_each_key(K, [&](uint32_t k) {
+            if (k) atomicAdd(&sh.prefix[f.bucket_of(k)], 1u);
+        });
+    }
     __syncthreads();
     TB_MARK(sh, 11);
     {  // inclusive prefix sum over 4096 buckets: PER per thread + a scan of the thread totals in sh.tmp
@@ -949,8 +1008,9 @@ __device__ __forceinline__ TileResult tile_stats(const Keys &K, Shared &sh, cons
         median = w.n % 2 == 0 ? ((double)__uint_as_float(ka) + (double)__uint_as_float(kb)) / 2.0 : (double)__uint_as_float(kb);
         // median_f32_mut of the deviations (median.rs:46-63): f32 average for even n
         uint32_t da, db;
-        select_devs(K, sh, f, w, median, w.n % 2 == 0 ? mid - 1 : mid, mid, &da, &db);
+        select_devs(K, sh, f, w, median, w.n % 2 == 0 ? mid - 1 : mid, mid, mad_guess, &da, &db);
         const float mad_f32 = w.n % 2 == 0 ? (__uint_as_float(da) + __uint_as_float(db)) / 2.0f : __uint_as_float(db);
+        mad_guess = mad_f32;
         const double sig = fmax((double)mad_f32 * kMadToSigma, 1e-30);
         if (it == 2) {
             sigma = sig;
