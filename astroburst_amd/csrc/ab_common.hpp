@@ -192,6 +192,8 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
                            bool normalize_first = false /* normalize_for_detection's transform is derived and applied on the device */);
 // the percentile normalisation's parameters (xf->on = 0 where the reference returns image.clone())
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf);
+// the same for n equally sized planes in two launches and one synchronisation
+int ab_normalize_params_many_device(ab_ctx *ctx, const float *const *planes, size_t n, int64_t len, ab_pixel_xf *xf);
 
 int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, int64_t ref_cols, int64_t ref_ld, const float *tgt,
                               int64_t tgt_rows, int64_t tgt_cols, int64_t tgt_ld, double *dx, double *dy, double *confidence);

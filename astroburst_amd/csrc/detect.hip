@@ -707,6 +707,31 @@ __global__ __launch_bounds__(1024) void percentiles_mem_kernel(const float *__re
     percentiles_body(MemSample{sub}, ns, out, fd);
 }
 
+// The same for MANY planes of one size in two launches (the registration batch: the percentiles of all 64 frames before any
+// worker starts).  One percentile workgroup per plane -- 64 of them side by side take what one takes, where each used to sit in
+// its frame's chain: 60 .. 100 us of ONE compute unit during which the three other streams of its hardware queue waited.
+constexpr int kManyPlanes = 128;
+struct PlaneList {
+    const float *p[kManyPlanes];
+};
+__global__ __launch_bounds__(256) void subsample_many_kernel(const PlaneList pl, int64_t len, int64_t step, float *__restrict__ out, int64_t nout) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nout) out[(int64_t)blockIdx.y * nout + i] = pl.p[blockIdx.y][i * step];
+}
+__global__ __launch_bounds__(1024) void percentiles_many_reg_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
+    const float *mine = sub + (size_t)blockIdx.x * ns;
+    RegSample s;
+#pragma unroll
+    for (int j = 0; j < kPctPer; ++j) {
+        const unsigned int i = (unsigned int)(j * 1024) + threadIdx.x;
+        s.v[j] = i < ns ? mine[i] : __builtin_nanf("");
+    }
+    percentiles_body(s, ns, out + blockIdx.x, (FrameDev *)nullptr);
+}
+__global__ __launch_bounds__(1024) void percentiles_many_mem_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
+    percentiles_body(MemSample{sub + (size_t)blockIdx.x * ns}, ns, out + blockIdx.x, (FrameDev *)nullptr);
+}
+
 
 // estimate_background's reduction of the tiles (star_detection.rs:70-83) on the device: the upper median of the valid tiles'
 // medians and of their sigmas (sorted[len / 2]; any order of equal values gives the same element), then detect_stars'
@@ -756,6 +781,19 @@ __global__ __launch_bounds__(1024) void bg_threshold_kernel(const TileOut *__res
         out->bg_median = bg_median;
         out->bg_sigma = bg_sigma;
     }
+}
+
+// affine.rs:34-47 from the two order statistics: unchanged frame for < 100 finite samples or a flat range
+ab_pixel_xf xf_from_percentiles(const PercentileOut &po) {
+    ab_pixel_xf xf;
+    if (po.finite < 100) return xf;
+    const double lo = (double)po.lo, hi = (double)po.hi;
+    const double range = hi - lo;
+    if (range < 1e-15) return xf;
+    xf.lo = lo;
+    xf.inv = 1.0 / range;
+    xf.on = 1;
+    return xf;
 }
 
 int f64_cmp(double a, double b) {  // math/median.rs:15-25
@@ -1039,14 +1077,34 @@ int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pi
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     trace.mark("subsample+percentiles+sync");
-    const PercentileOut po = *(const PercentileOut *)pin;
-    if (po.finite < 100) return AB_OK;
-    const double lo = (double)po.lo, hi = (double)po.hi;
-    const double range = hi - lo;
-    if (range < 1e-15) return AB_OK;
-    xf->lo = lo;
-    xf->inv = 1.0 / range;
-    xf->on = 1;
+    *xf = xf_from_percentiles(*(const PercentileOut *)pin);
+    return AB_OK;
+}
+
+// the same for n planes of `len` pixels each (device pointers), two launches and one synchronisation for all of them
+int ab_normalize_params_many_device(ab_ctx *ctx, const float *const *planes, size_t n, int64_t len, ab_pixel_xf *xf) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    for (size_t i = 0; i < n; ++i) xf[i] = ab_pixel_xf();
+    if (len == 0 || n == 0) return AB_OK;
+    const int64_t step = std::max<int64_t>(len / 100000, 1);
+    const int64_t ns = (len + step - 1) / step;
+    for (size_t first = 0; first < n; first += kManyPlanes) {
+        const size_t m = std::min<size_t>(kManyPlanes, n - first);
+        PlaneList pl;
+        for (size_t i = 0; i < (size_t)kManyPlanes; ++i) pl.p[i] = planes[first + (i < m ? i : 0)];
+        void *pin = nullptr;
+        AB_TRY(ab_pinned(ctx, m * sizeof(PercentileOut), &pin));
+        float *sub = nullptr;
+        AB_TRY(ab_workspace(ctx, AB_WS_SUBSAMPLE, m * (size_t)ns * sizeof(float), (void **)&sub));
+        hipLaunchKernelGGL(subsample_many_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, pl, len, step, sub, ns);
+        if (ns <= (int64_t)kPctPer * 1024)
+            hipLaunchKernelGGL(percentiles_many_reg_kernel, dim3((unsigned)m), dim3(1024), 0, ctx->stream, (const float *)sub, (unsigned int)ns, (PercentileOut *)pin);
+        else
+            hipLaunchKernelGGL(percentiles_many_mem_kernel, dim3((unsigned)m), dim3(1024), 0, ctx->stream, (const float *)sub, (unsigned int)ns, (PercentileOut *)pin);
+        AB_HIP(ctx, hipGetLastError());
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < m; ++i) xf[first + i] = xf_from_percentiles(((const PercentileOut *)pin)[i]);
+    }
     return AB_OK;
 }
 
