@@ -84,6 +84,12 @@ struct ab_ctx {
     hipEvent_t stack_ev[2] = {nullptr, nullptr};
     bool stack_ev_valid = false;
     hipEvent_t switch_ev = nullptr;  // orders the stream being left before the one switched to (ab_ctx_set_stream)
+    // the background-tile pipeline of a registration batch (detect.hip: ab_bg_pipeline_*): its own stream, one event per chunk
+    // of frames, its own pinned result buffer (the context's general one may be reallocated by the reference's detection)
+    hipStream_t aux_stream = nullptr;
+    std::vector<hipEvent_t> aux_events;
+    void *aux_pinned = nullptr;
+    size_t aux_pinned_bytes = 0;
     // progress / cancel (infra/progress.rs:39-74): the callback is serialised by progress_mu (frame workers tick it too);
     // worker contexts forward to their parent
     ab_progress_cb progress_cb = nullptr;
@@ -189,7 +195,21 @@ int ab_stf_u8_device_tx(ab_ctx *ctx, const float *in, int64_t n, const void *tx_
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out,
                            ab_pixel_xf xf = ab_pixel_xf(), size_t max_keep = (size_t)-1 /* only the brightest max_keep stars are wanted */,
-                           bool normalize_first = false /* normalize_for_detection's transform is derived and applied on the device */);
+                           bool normalize_first = false /* normalize_for_detection's transform is derived and applied on the device */,
+                           const double *bg_known = nullptr /* {bg_median, bg_sigma} of estimate_background, if the caller has them */);
+// estimate_background of a batch of equally sized planes as a pipeline: the tile kernel of `chunk` planes at a time on the
+// context's auxiliary stream, an event after each chunk; ab_bg_pipeline_get blocks until plane i's chunk has run and reduces
+// its tiles (any thread)
+struct ab_bg_pipeline {
+    bool on = false;
+    const void *tiles = nullptr;  // pinned TileOut[n][ntiles]
+    const hipEvent_t *events = nullptr;
+    int ntiles = 0, chunk = 1;
+    size_t n = 0;
+};
+int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, const ab_pixel_xf *xf, int chunk,
+                         ab_bg_pipeline *p);
+int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *bg /* [2] */);
 // the percentile normalisation's parameters (xf->on = 0 where the reference returns image.clone())
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf);
 // the same for n equally sized planes in two launches and one synchronisation

@@ -729,13 +729,14 @@ int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std:
 }
 
 // normalize_for_detection + detect_stars(3.5 sigma) + top_n_stars of one frame (:134-160)
-int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::vector<Pt> *out, const ab_pixel_xf *xf = nullptr) {
+int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::vector<Pt> *out, const ab_pixel_xf *xf = nullptr,
+                const double *bg = nullptr) {
     std::vector<ab_detected_star> stars;
     double m, s;
     // the normalised frame is never materialised: detection applies the transform on load.  xf: the frame's transform if the
     // caller has it already (a batch takes all its frames' percentiles in one go); otherwise detection derives it first
     AB_TRY(ab_detect_stars_device(ctx, img, rows, cols, cols, kDetectionSigma, &stars, &m, &s, xf ? *xf : ab_pixel_xf(), kMaxStars,
-                                  /*normalize_first=*/xf == nullptr));  // top_n_stars (:272-277)
+                                  /*normalize_first=*/xf == nullptr, xf ? bg : nullptr));  // top_n_stars (:272-277)
     out->clear();
     for (const auto &st : stars) {
         if (out->size() >= kMaxStars) break;  // top_n_stars (:272-277): detections are already sorted by flux
@@ -773,13 +774,13 @@ struct RefTable {
 
 // one target against the reference being prepared (stars + triangle table in rt / ref_ws); all device work on wc's stream
 static int register_one(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const float *ref, const float *tgt, int64_t rows, int64_t cols,
-                        int num_threads, ab_affine_align_result *out, const ab_pixel_xf *tgt_xf) {
+                        int num_threads, ab_affine_align_result *out, const ab_pixel_xf *tgt_xf, const double *tgt_bg) {
     MatchWs w;
     AB_TRY(match_ws(wc, &w));
     std::vector<Pt> ts;
     bool found = false;
     ab_trace trace("register_one");
-    AB_TRY(frame_stars(wc, tgt, rows, cols, &ts, tgt_xf));
+    AB_TRY(frame_stars(wc, tgt, rows, cols, &ts, tgt_xf, tgt_bg));
     trace.mark("frame_stars");
     if (rt.wait() != AB_OK) return ab_set_error(wc, rt.rc, "the reference frame's detection failed");
     const std::vector<Pt> &rs = rt.stars;
@@ -828,15 +829,32 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     // normalize_for_detection's percentiles of every frame of the batch (targets, then the reference) up front: two launches, 64
     // percentile workgroups side by side (see ab_normalize_params_many_device)
     std::vector<ab_pixel_xf> xfs;
+    ab_bg_pipeline pipe;  // plane 0 = the reference, plane 1 + f = target f
     const bool have_xf = n >= 4;
     if (have_xf) {
         std::vector<const float *> planes(targets, targets + n);
         planes.push_back(ref);
         xfs.resize(n + 1);
         AB_TRY(ab_normalize_params_many_device(ctx, planes.data(), n + 1, rows * cols, xfs.data()));
+        // ... and their background tiles: the tile kernel runs on its own stream, a few frames per launch, the reference first,
+        // while the workers already label the frames whose tiles are done (register_one blocks on its frame's chunk)
+        static const int chunk = getenv("AB_TILE_CHUNK") ? atoi(getenv("AB_TILE_CHUNK")) : 8;  // frames per launch (0: every frame's tiles in its own chain); measured 0 / 2 / 4 / 8 / 16 -> 17.6 / 17.5 / 17.2 / 17.0 / 17.4 ms for the stage
+        if (chunk > 0) {
+            std::vector<const float *> order;  // reference first
+            std::vector<ab_pixel_xf> oxf;
+            order.push_back(ref);
+            oxf.push_back(xfs[n]);
+            for (size_t i = 0; i < n; ++i) {
+                order.push_back(targets[i]);
+                oxf.push_back(xfs[i]);
+            }
+            AB_TRY(ab_bg_pipeline_begin(ctx, order.data(), n + 1, rows, cols, oxf.data(), chunk, &pipe));
+        }
     }
     auto prepare_reference = [&]() -> int {
-        AB_TRY(frame_stars(ctx, ref, rows, cols, &rt.stars, have_xf ? &xfs[n] : nullptr));
+        double bg[2];
+        if (pipe.on) AB_TRY(ab_bg_pipeline_get(ctx, &pipe, 0, bg));
+        AB_TRY(frame_stars(ctx, ref, rows, cols, &rt.stars, have_xf ? &xfs[n] : nullptr, pipe.on ? bg : nullptr));
         if (rt.stars.size() < kMinMatchesRigid) return AB_OK;
         // reference table: built, bucketed by ratio_mid and ordered by ratio_long inside the buckets on the GPU
         AB_TRY(gpu_build_triangles(ctx, w, rt.stars, 0));
@@ -845,7 +863,9 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     };
     // the warp of a frame (f64 VALU) overlaps the other workers' latency-bound detection passes
     auto one = [&](ab_ctx *wc, size_t f) -> int {
-        AB_TRY(register_one(wc, w, rt, ref, targets[f], rows, cols, num_threads, &out[f], have_xf ? &xfs[f] : nullptr));
+        double bg[2];
+        if (pipe.on) AB_TRY(ab_bg_pipeline_get(wc, &pipe, f + 1, bg));
+        AB_TRY(register_one(wc, w, rt, ref, targets[f], rows, cols, num_threads, &out[f], have_xf ? &xfs[f] : nullptr, pipe.on ? bg : nullptr));
         if (aligned) AB_TRY(ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]));  // pair.rs:59-61
         return AB_OK;
     };

@@ -158,11 +158,20 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
 // the round-1 radix-select version, kept behind AB_TILE_LEGACY=1 as an in-library cross-check (tests/test_gpu_tile_stats.py runs both).
 // (capping the registers at 168 so that another kernel's wave fits beside a tile on every SIMD -- amdgpu_waves_per_eu(3, 3) --
 // spills 65 registers: 104 -> 130 us alone and the registration stage 19.8 -> 21.4 ms)
-__global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
+__global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(const float *__restrict__ img_arg, int rows, int cols, int64_t ld,
                                                                               int step, int ntx, const ab_pixel_xf xf_arg, TileOut *__restrict__ out,
-                                                                              const FrameDev *__restrict__ fd) {
+                                                                              const FrameDev *__restrict__ fd,
+                                                                              const float *const *__restrict__ many_planes = nullptr,
+                                                                              const ab_pixel_xf *__restrict__ many_xf = nullptr) {
     __shared__ tb::Shared sh;
-    const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
+    const float *__restrict__ img = img_arg;
+    // many_planes: blockIdx.y names the plane (all of one size), its transform and its row of `out` -- the tiles of a whole
+    // registration batch in ONE launch
+    if (many_planes) {
+        img = many_planes[blockIdx.y];
+        out += (size_t)blockIdx.y * gridDim.x;
+    }
+    const ab_pixel_xf xf = many_planes ? many_xf[blockIdx.y] : (fd ? fd->xf : xf_arg);
     const int ty0 = (blockIdx.x / ntx) * step, tx0 = (blockIdx.x % ntx) * step;
     const int y1 = min(ty0 + step, rows), x1 = min(tx0 + step, cols);
     // thread (tx, ty) of the 256 x 2 layout walks column tx0 + tx downwards, two rows per slot: consecutive lanes read
@@ -833,6 +842,92 @@ static int tile_stats_host(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     return AB_OK;
 }
 
+// (median, sigma) of estimate_background's tiles (star_detection.rs:70-83)
+static void background_from_tiles(const TileOut *t, int ntiles, double *out_median, double *out_sigma) {
+    std::vector<double> med, sig;
+    for (int i = 0; i < ntiles; ++i)
+        if (t[i].valid) {
+            med.push_back(t[i].median);
+            sig.push_back(t[i].sigma);
+        }
+    if (med.empty()) {  // :70-72
+        *out_median = 0.0;
+        *out_sigma = 1.0;
+        return;
+    }
+    auto lt = [](double a, double b) { return f64_cmp(a, b) < 0; };
+    std::sort(med.begin(), med.end(), lt);
+    std::sort(sig.begin(), sig.end(), lt);
+    *out_median = med[med.size() / 2];
+    *out_sigma = std::fmax(sig[sig.size() / 2], 1e-10);
+}
+
+// estimate_background of the n contiguous planes of a registration batch, each with its own load transform, as a PIPELINE: the
+// tile kernel runs on the context's auxiliary stream, `chunk` planes per launch (grid: tiles x planes), an event after every
+// launch, results in a pinned buffer of its own; ab_bg_pipeline_get blocks on a plane's event and reduces its tiles.  Inside a
+// batch the tile kernel owns every compute unit while it runs; launched per frame from sixteen worker streams it kept pushing
+// the other frames' small kernels aside and shared their in-order queues.  (One launch for all 64 frames followed by a
+// synchronisation was slower than the per-frame form -- 5.9 ms during which nothing else runs: 19.0 against 18.0 ms for the
+// stage; the pipeline measures 17.1.)
+int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, const ab_pixel_xf *xf, int chunk,
+                         ab_bg_pipeline *p) {
+    *p = ab_bg_pipeline();
+    static const bool legacy = getenv("AB_TILE_LEGACY") != nullptr;
+    if (legacy || n == 0 || rows < 3 || cols < 3 || chunk < 1) return AB_OK;
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t m = std::min(rows, cols);
+    const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // detect_stars' choice (:100)
+    const int step = (int)std::max<int64_t>(tile_size, 16);
+    const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
+    if (!ctx->aux_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    const size_t nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
+    while (ctx->aux_events.size() < nchunks) {
+        hipEvent_t e;
+        AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->aux_events.push_back(e);
+    }
+    const size_t need = n * (size_t)ntiles * sizeof(TileOut);
+    if (need > ctx->aux_pinned_bytes) {
+        if (ctx->aux_pinned) {
+            AB_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+            AB_HIP(ctx, hipHostFree(ctx->aux_pinned));
+            ctx->aux_pinned = nullptr;
+            ctx->aux_pinned_bytes = 0;
+        }
+        AB_HIP(ctx, hipHostMalloc(&ctx->aux_pinned, need, hipHostMallocDefault));
+        ctx->aux_pinned_bytes = need;
+    }
+    char *dv = nullptr;  // device copies of the plane pointers and transforms
+    const size_t ptr_bytes = n * sizeof(const float *), xf_bytes = n * sizeof(ab_pixel_xf);
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_DEV, ptr_bytes + xf_bytes + 64, (void **)&dv));
+    const float **dplanes = (const float **)dv;
+    ab_pixel_xf *dxf = (ab_pixel_xf *)(dv + ((ptr_bytes + 15) & ~(size_t)15));
+    AB_HIP(ctx, hipMemcpyAsync(dplanes, planes, ptr_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
+    AB_HIP(ctx, hipMemcpyAsync(dxf, xf, xf_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
+    for (size_t c = 0; c < nchunks; ++c) {
+        const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
+        hipLaunchKernelGGL(tile_background_bucket_kernel, dim3((unsigned)ntiles, (unsigned)cnt), dim3(tb::kThreads), 0, ctx->aux_stream, (const float *)nullptr,
+                           (int)rows, (int)cols, cols, step, ntx, ab_pixel_xf(), (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, (const FrameDev *)nullptr,
+                           (const float *const *)(dplanes + first), (const ab_pixel_xf *)(dxf + first));
+        AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
+    }
+    AB_HIP(ctx, hipGetLastError());
+    p->on = true;
+    p->tiles = ctx->aux_pinned;
+    p->events = ctx->aux_events.data();
+    p->ntiles = ntiles;
+    p->chunk = chunk;
+    p->n = n;
+    return AB_OK;
+}
+
+int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *bg) {
+    AB_CHECK(ctx, p && p->on && i < p->n, "background pipeline: no such plane");
+    AB_HIP(ctx, hipEventSynchronize(p->events[i / (size_t)p->chunk]));
+    background_from_tiles((const TileOut *)p->tiles + i * (size_t)p->ntiles, p->ntiles, &bg[0], &bg[1]);
+    return AB_OK;
+}
+
 int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, int64_t tile_size,
                                   double *out_median, double *out_sigma, ab_pixel_xf xf = ab_pixel_xf()) {
     std::vector<TileOut> h;
@@ -859,7 +954,7 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
 // detect_stars (star_detection.rs:86-258) on a device plane; stars sorted by flux, deduplicated
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out, ab_pixel_xf xf, size_t max_keep,
-                           bool normalize_first) {
+                           bool normalize_first, const double *bg_known) {
     stars->clear();
     *bg_median_out = 0.0;
     *bg_sigma_out = 1.0;
@@ -880,7 +975,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     // 0.37 ms).  Sixteen streams share four in-order hardware queues; a stream that enqueues nine packets in one go holds its
     // queue until they have all run, and the three streams behind it wait -- the host joins were what interleaved them.
     static const bool want_chain = getenv("AB_DETECT_CHAIN") != nullptr;
-    const bool chained = normalize_first && ld == cols && ntiles <= kBgTiles && !legacy_tiles && want_chain;
+    const bool chained = normalize_first && !bg_known && ld == cols && ntiles <= kBgTiles && !legacy_tiles && want_chain;
     double bg_median = 0.0, bg_sigma = 1.0, threshold = 0.0;
     FrameDev *fd = nullptr;
     struct Joined {  // what the host reads at the first synchronisation of the chained form (pinned)
@@ -908,6 +1003,10 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
                            ntx, ab_pixel_xf(), tiles, (const FrameDev *)fd);
         hipLaunchKernelGGL(bg_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const TileOut *)tiles, ntiles, sigma_threshold, fd, &jn->bg);
         AB_HIP(ctx, hipGetLastError());
+    } else if (bg_known) {  // the caller has estimate_background's result for this plane and transform already
+        bg_median = bg_known[0];
+        bg_sigma = bg_known[1];
+        threshold = bg_median + sigma_threshold * bg_sigma;  // :103
     } else {
         if (normalize_first) AB_TRY(ab_normalize_params_device(ctx, img, P, &xf));
         AB_TRY(ab_estimate_background_device(ctx, img, rows, cols, ld, tile_size, &bg_median, &bg_sigma, xf));
