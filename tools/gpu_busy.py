@@ -9,9 +9,13 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 win = float(sys.argv[2]) if len(sys.argv) > 2 else 28.0
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "")[:60], r.get("Queue_Id", "")) for r in rows)
-tiles = [e for e in ev if "tile_background" in e[2]][-63:]            # the last step's 63 target frames
-t_beg = min(e[0] for e in tiles) - 300_000                             # (the percentile kernels come first)
-t_end = min(e[0] for e in ev if "stack_sigma_clip_kernel" in e[2] and e[0] > max(t[1] for t in tiles))
+starts = [e for e in ev if "subsample_many_kernel" in e[2]]      # a registration batch begins with its frames' subsamples
+if starts:
+    t_beg = starts[-1][0]
+else:                                                             # (older builds: one tile launch per frame)
+    tiles = [e for e in ev if "tile_background" in e[2]][-63:]
+    t_beg = min(e[0] for e in tiles) - 300_000
+t_end = min(e[0] for e in ev if "stack_sigma_clip_kernel" in e[2] and e[0] > t_beg)
 win = (t_end - t_beg) / 1e6
 seg = [e for e in ev if e[0] >= t_beg and e[1] <= t_end]
 busy, cur_s, cur_e = 0, None, None
