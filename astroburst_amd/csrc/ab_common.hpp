@@ -87,6 +87,7 @@ struct ab_ctx {
     // the background-tile pipeline of a registration batch (detect.hip: ab_bg_pipeline_*): its own stream, one event per chunk
     // of frames, its own pinned result buffer (the context's general one may be reallocated by the reference's detection)
     hipStream_t aux_stream = nullptr;
+    hipStream_t warp_stream = nullptr;  // the warps of a registration batch (affine.hip): off the workers' own streams
     std::vector<hipEvent_t> aux_events;
     void *aux_pinned = nullptr;
     size_t aux_pinned_bytes = 0;

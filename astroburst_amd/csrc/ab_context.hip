@@ -131,6 +131,7 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
     if (ctx->aux_pinned) (void)hipHostFree(ctx->aux_pinned);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->warp_stream) (void)hipStreamDestroy(ctx->warp_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

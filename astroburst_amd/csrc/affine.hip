@@ -861,15 +861,29 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the workers' vote kernels read it from their own streams
         return AB_OK;
     };
+    hipStream_t warp_stream = nullptr;
     // the warp of a frame (f64 VALU) overlaps the other workers' latency-bound detection passes
     auto one = [&](ab_ctx *wc, size_t f) -> int {
         double bg[2];
         if (pipe.on) AB_TRY(ab_bg_pipeline_get(wc, &pipe, f + 1, bg));
         AB_TRY(register_one(wc, w, rt, ref, targets[f], rows, cols, num_threads, &out[f], have_xf ? &xfs[f] : nullptr, pipe.on ? bg : nullptr));
-        if (aligned) AB_TRY(ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]));  // pair.rs:59-61
+        if (aligned) {  // pair.rs:59-61
+            // the warp needs nothing from the GPU but the frame: it goes to the batch's warp stream, so that this worker's
+            // next frame does not queue up behind it on the worker's own stream
+            hipStream_t keep = wc->stream;
+            if (warp_stream) wc->stream = warp_stream;
+            const int rc = ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]);
+            wc->stream = keep;
+            if (rc != AB_OK) return rc;
+        }
         return AB_OK;
     };
     const bool inline_run = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1)) <= 1;
+    static const bool own_warp_stream = getenv("AB_NO_WARP_STREAM") == nullptr;
+    if (!inline_run && aligned && own_warp_stream) {
+        if (!ctx->warp_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->warp_stream, hipStreamNonBlocking));
+        warp_stream = ctx->warp_stream;
+    }
     if (inline_run) {  // the reference first, on ctx
         const int rc = prepare_reference();
         rt.publish(rc, rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
@@ -884,6 +898,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     });
     const int rc = ab_parallel_frames(ctx, n, "registration", one, /*drain_caller_stream=*/false);
     prep.join();
+    if (warp_stream) (void)hipStreamSynchronize(warp_stream);  // the aligned frames are complete when this call returns
     return prep_rc != AB_OK ? prep_rc : rc;
 }
 
