@@ -74,10 +74,11 @@ struct ab_ctx {
     void *ws[AB_WS_SLOTS] = {};
     size_t ws_bytes[AB_WS_SLOTS] = {};
     // frame-parallel registration (affine.hip): child contexts (own stream + workspaces), one per host worker;
-    // AB_REGISTER_WORKERS overrides the default of 12.  The stage is GPU-throughput-bound, so past ~12 workers nothing is gained and
-    // the step time only gets noisier (MI355X, 63 frames, median of 8: 6 -> 49.5 ms, 8 -> 45.9, 12 -> 41.0, 16 -> 41.5, 24 -> 44-55, 32 -> 70)
+    // AB_REGISTER_WORKERS overrides the default.  The stage is bound by the four in-order hardware queues the worker streams
+    // share; end of round 2, whole stage, three runs each: 6 -> 17.7 ms, 8 -> 16.9, 10 -> 17.0, 12 -> 16.8,
+    // 14 -> 17.2, 16 -> 17.3, 20 -> 17.9, 24 -> 18.2
     std::vector<ab_ctx *> workers;
-    int register_workers = 16;
+    int register_workers = 12;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
     // HIP events recorded on ctx->stream right around the stack kernels of the last ab_stack_* call (ab_stack_last_kernel_ms)
