@@ -392,7 +392,10 @@ struct StarXY {
 };
 
 __global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
-                                                         unsigned int *__restrict__ bin_hist /* nullable; zero on entry */) {
+                                                         unsigned int *__restrict__ bin_hist /* nullable; zero on entry */,
+                                                         unsigned int *__restrict__ votes_to_clear /* nullable: the vote matrix of the frame */) {
+    // (the vote kernel of this frame runs later on the same stream: clearing its matrix here saves a fill command per frame)
+    if (votes_to_clear && blockIdx.x * 1024 + threadIdx.x < kVoteDim * kVoteDim) votes_to_clear[blockIdx.x * 1024 + threadIdx.x] = 0;
     __shared__ unsigned int lhist[kTriBins];  // this block's share of the bucket histogram: one global atomic per touched bucket
     if (bin_hist) {
         for (int b = threadIdx.x; b < kTriBins; b += 1024) lhist[b] = 0;
@@ -600,7 +603,8 @@ constexpr int kVoteBlocks = 1024;
 __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
                                                       unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */,
-                                                      const RefGroup *__restrict__ groups) {
+                                                      const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tgt_count_to_clear = 0;  // tri_scatter_kernel was its last reader
     // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and with a stride of 64
     // (a multiple of the bank count) all of those atomics would land in one bank
     constexpr int kLdsStride = kVoteDim + 1;
@@ -700,11 +704,15 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
         xy.xy[2 * i + 1] = stars[i][1];
     }
     DTri *raw = which ? w.tgt_tris : w.ref_tris, *sorted = which ? w.tgt_sorted : w.ref_sorted;
-    AB_HIP(ctx, hipMemsetAsync(w.counts + which, 0, sizeof(unsigned int), ctx->stream));
-    if (limit >= 3) {
-        const int total = limit * limit * limit;
-        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 1023) / 1024), dim3(1024), 0, ctx->stream, xy, limit, raw, w.counts + which, w.bin_hist);
-    }
+    // the target table's counter is left at zero by the previous frame's vote kernel (and by the fresh workspace's memset); the
+    // reference table is built once per batch
+    if (!which) AB_HIP(ctx, hipMemsetAsync(w.counts, 0, sizeof(unsigned int), ctx->stream));
+    const int total = limit * limit * limit;
+    const bool clears = which && limit >= 3 && (total + 1023) / 1024 * 1024 >= kVoteDim * kVoteDim;  // enough threads to clear the votes
+    if (limit >= 3)
+        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 1023) / 1024), dim3(1024), 0, ctx->stream, xy, limit, raw, w.counts + which, w.bin_hist,
+                           clears ? w.votes : (unsigned int *)nullptr);
+    if (which && !clears) AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
     // (the scan leaves bin_hist zeroed again)
     hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
     hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 1023) / 1024), dim3(1024), 0, ctx->stream, raw, w.counts + which, w.cursor, sorted);
@@ -719,8 +727,10 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
 
 // votes of the current ref / tgt triangle tables -> host (kVoteDim x kVoteDim)
 int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std::vector<uint32_t> *votes) {
-    AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, (const RefGroup *)w.groups);
+    // (w.votes was cleared by this frame's tri_build_kernel or the memset beside it; the kernel resets the target table's counter
+    // for the next frame)
+    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, (const RefGroup *)w.groups,
+                       w.counts + 1);
     AB_HIP(ctx, hipGetLastError());
     votes->resize(kVoteDim * kVoteDim);
     AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
