@@ -35,12 +35,12 @@ double compute_weight(double fwhm, double ecc, double snr, double noise, const a
     return std::fmax(raw / total, 0.0);
 }
 
-int analyze_one(ab_ctx *ctx, const ab_plane *img, const ab_subframe_weight_config &c, ab_subframe_metrics *out) {  // :51-121
+int analyze_one(ab_ctx *ctx, const ab_plane *img, const ab_subframe_weight_config &c, ab_subframe_metrics *out, const double *bg = nullptr) {  // :51-121
     StagedPlane in;
     AB_TRY(ab_stage_in(ctx, img, &in));
     std::vector<ab_detected_star> stars;
     double bm = 0.0, bs = 1.0;
-    const int rc = ab_detect_stars_device(ctx, in.dptr, in.rows, in.cols, in.cols, kDetectionSigma, &stars, &bm, &bs);
+    const int rc = ab_detect_stars_device(ctx, in.dptr, in.rows, in.cols, in.cols, kDetectionSigma, &stars, &bm, &bs, ab_pixel_xf(), (size_t)-1, false, bg);
     ab_stage_release(ctx, &in);
     if (rc != AB_OK) return rc;
     *out = ab_subframe_metrics{};
@@ -76,7 +76,24 @@ int ab_analyze_subframes(ab_ctx *ctx, const ab_plane *images, size_t n, const ab
     for (size_t i = 0; i < n; ++i)
         AB_CHECK(ctx, images[i].data && images[i].rows > 0 && images[i].cols > 0, "subframe %zu is null or has a zero dimension", i);
     AB_HIP(ctx, hipSetDevice(ctx->device));
-    return ab_parallel_frames(ctx, n, "subframe", [&](ab_ctx *wc, size_t f) { return analyze_one(wc, &images[f], c, &out[f]); });
+    // device-resident subframes of one size: their background tiles as a pipeline on the auxiliary stream, as in a registration
+    // batch (detect.hip: ab_bg_pipeline_*), instead of one tile kernel inside every frame's chain
+    ab_bg_pipeline pipe;
+    bool uniform = n >= 4;
+    for (size_t i = 0; i < n && uniform; ++i)
+        uniform = images[i].on_device && images[i].rows == images[0].rows && images[i].cols == images[0].cols;
+    if (uniform) {
+        std::vector<const float *> planes(n);
+        for (size_t i = 0; i < n; ++i) planes[i] = (const float *)images[i].data;
+        const std::vector<ab_pixel_xf> xf(n);  // no load transform: subframes are measured as they are
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's frames are complete before another stream reads them
+        AB_TRY(ab_bg_pipeline_begin(ctx, planes.data(), n, images[0].rows, images[0].cols, xf.data(), 8, &pipe));
+    }
+    return ab_parallel_frames(ctx, n, "subframe", [&](ab_ctx *wc, size_t f) {
+        double bg[2];
+        if (pipe.on) AB_TRY(ab_bg_pipeline_get(wc, &pipe, f, bg));
+        return analyze_one(wc, &images[f], c, &out[f], pipe.on ? bg : nullptr);
+    });
 } AB_CATCH(ctx)
 
 int ab_analyze_subframe(ab_ctx *ctx, const ab_plane *image, const ab_subframe_weight_config *config, ab_subframe_metrics *out) try {

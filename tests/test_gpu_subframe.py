@@ -50,6 +50,8 @@ def test_device_frames_and_normalised_weights(ctx, oracle):
     assert max(g.weight for g in got) == 1.0
     for g, w, n in zip(got, want, wn):
         assert g.star_count == w["star_count"] and g.weight == pytest.approx(n, rel=1e-12)
+        # (>= 4 device frames of one size: their background tiles came through the pipeline on the auxiliary stream)
+        assert (g.background_median, g.background_sigma) == (w["background_median"], w["background_sigma"])
     assert ctx.analyze_subframes([]) == []
 
 
