@@ -895,10 +895,11 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         warp_stream = ctx->warp_stream;
     }
     if (inline_run) {  // the reference first, on ctx
-        const int rc = prepare_reference();
+        int rc = prepare_reference();
         rt.publish(rc, rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
-        if (rc != AB_OK) return rc;
-        return ab_parallel_frames(ctx, n, "registration", one);
+        if (rc == AB_OK) rc = ab_parallel_frames(ctx, n, "registration", one);
+        if (pipe.on) (void)hipStreamSynchronize(ctx->aux_stream);  // (an error or a cancel may leave tile launches in flight: they read the caller's frames)
+        return rc;
     }
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's frames are complete before any other stream reads them
     int prep_rc = AB_OK;
@@ -909,6 +910,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     const int rc = ab_parallel_frames(ctx, n, "registration", one, /*drain_caller_stream=*/false);
     prep.join();
     if (warp_stream) (void)hipStreamSynchronize(warp_stream);  // the aligned frames are complete when this call returns
+    if (pipe.on) (void)hipStreamSynchronize(ctx->aux_stream);  // (an error or a cancel may leave tile launches in flight: they read the caller's frames)
     return prep_rc != AB_OK ? prep_rc : rc;
 }
 

@@ -89,11 +89,13 @@ int ab_analyze_subframes(ab_ctx *ctx, const ab_plane *images, size_t n, const ab
         AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's frames are complete before another stream reads them
         AB_TRY(ab_bg_pipeline_begin(ctx, planes.data(), n, images[0].rows, images[0].cols, xf.data(), 8, &pipe));
     }
-    return ab_parallel_frames(ctx, n, "subframe", [&](ab_ctx *wc, size_t f) {
+    const int rc = ab_parallel_frames(ctx, n, "subframe", [&](ab_ctx *wc, size_t f) {
         double bg[2];
         if (pipe.on) AB_TRY(ab_bg_pipeline_get(wc, &pipe, f, bg));
         return analyze_one(wc, &images[f], c, &out[f], pipe.on ? bg : nullptr);
     });
+    if (pipe.on) (void)hipStreamSynchronize(ctx->aux_stream);  // (an error or a cancel may leave tile launches in flight: they read the caller's frames)
+    return rc;
 } AB_CATCH(ctx)
 
 int ab_analyze_subframe(ab_ctx *ctx, const ab_plane *image, const ab_subframe_weight_config *config, ab_subframe_metrics *out) try {
