@@ -327,6 +327,11 @@ def lib() -> C.CDLL:
     L.ab_comm_get_unique_id.argtypes = [u8p]
     L.ab_comm_init_rank.argtypes = [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]
     L.ab_comm_init_all.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+    L.ab_comm_init_rank_host.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.ab_comm_is_host.argtypes = [vp]
+    L.ab_comm_agree.argtypes = [vp, vp, C.c_int]
+    L.ab_comm_abort.argtypes = [vp]
+    L.ab_comm_set_timeout_ms.argtypes = [vp, C.c_int64]
     L.ab_comm_destroy.argtypes = [vp]
     L.ab_comm_destroy.restype = None
     L.ab_comm_rank.argtypes = [vp]

@@ -215,6 +215,34 @@ class Comm:
         ctx._check(self._L.ab_comm_init_rank(ctx._h, buf, nranks, rank, C.byref(h)))
         self._h = h
 
+    @classmethod
+    def host(cls, ctx: "Context", name: str, nranks: int, rank: int) -> "Comm":
+        """ab_comm_init_rank_host: host-staged collectives through the shared segment /abcomm_<name> (ranks may share a GPU)."""
+        self = cls.__new__(cls)
+        self._ctx = ctx
+        self._L = ctx._L
+        h = C.c_void_p()
+        ctx._check(self._L.ab_comm_init_rank_host(ctx._h, name.encode(), nranks, rank, C.byref(h)))
+        self._h = h
+        return self
+
+    @property
+    def is_host(self) -> bool:
+        return bool(self._L.ab_comm_is_host(self._h))
+
+    def agree(self, local_status: int = 0) -> int:
+        """ab_comm_agree: AB_OK only if every rank passed AB_OK (raises otherwise)"""
+        self._ctx.use_torch_stream()
+        rc = self._L.ab_comm_agree(self._ctx._h, self._h, int(local_status))
+        self._ctx._check(rc)
+        return rc
+
+    def abort(self):
+        self._L.ab_comm_abort(self._h)
+
+    def set_timeout_ms(self, ms: int):
+        self._ctx._check(self._L.ab_comm_set_timeout_ms(self._h, int(ms)))
+
     @property
     def rank(self) -> int:
         return self._L.ab_comm_rank(self._h)

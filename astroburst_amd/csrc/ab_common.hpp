@@ -229,6 +229,11 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
 int ab_resample_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, int64_t out_rows, int64_t out_cols,
                        float *out);
 
+// comm.hip: wait for ctx->stream while a collective of `comm` may be in flight -- bounded (AB_COMM_TIMEOUT_MS) and watching
+// RCCL's asynchronous error state; on failure the communicator is aborted and AB_ERR_COMM returned.  NULL / host-staged
+// communicators: a plain hipStreamSynchronize.
+int ab_comm_stream_wait(ab_ctx *ctx, ab_comm *comm);
+
 // stack_wide.hip: 65 .. 512 frames, one wave per pixel (host tables of n plane pointers / strides; counters pre-cleared)
 int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
                          const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only);

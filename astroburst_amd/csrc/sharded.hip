@@ -37,7 +37,7 @@ int total_rejected(ab_ctx *ctx, ab_comm *comm, uint64_t *out) {
     void *pin = nullptr;
     AB_TRY(ab_pinned(ctx, sizeof(unsigned long long), &pin));
     AB_HIP(ctx, hipMemcpyAsync(pin, slot, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AB_TRY(ab_comm_stream_wait(ctx, comm));
     *out = *(const unsigned long long *)pin;
     return AB_OK;
 }
@@ -71,13 +71,15 @@ int ab_stack_sigma_clip_rows(ab_ctx *ctx, const ab_plane *planes, size_t n, cons
                              ab_plane_mut *out_band, uint64_t *out_rejected) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");
-    AB_CHECK(ctx, cfg && out_band && out_band->data && out_band->on_device, "null config or output (device band expected)");
+    AB_CHECK(ctx, cfg && out_band, "null config or output");
     AB_CHECK(ctx, row0 >= 0 && out_band->rows >= 0 && out_band->cols > 0, "bad row band");
-    if (out_band->rows == 0) {  // an empty band (more ranks than rows): nothing to stack, nothing rejected
+    if (out_band->rows == 0) {  // an empty band (more ranks than rows; its data pointer may be NULL): nothing to stack, nothing rejected
         if (out_rejected) *out_rejected = 0;
+        AB_HIP(ctx, hipSetDevice(ctx->device));
         AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, AB_REJ_SLOTS * sizeof(unsigned long long), ctx->stream));
         return AB_OK;
     }
+    AB_CHECK(ctx, out_band->data && out_band->on_device, "device band expected");
     std::vector<const float *> dp(n);
     std::vector<int64_t> ld(n);
     for (size_t i = 0; i < n; ++i) {
@@ -95,20 +97,26 @@ int ab_stack_sigma_clip_rows(ab_ctx *ctx, const ab_plane *planes, size_t n, cons
 int ab_stack_sigma_clip_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
                                 ab_plane_mut *out_band, uint64_t *out_rejected_total) try {
     if (!ctx) return AB_ERR_INVALID;
-    AB_CHECK(ctx, planes && n >= 1, "No images to stack");
-    AB_CHECK(ctx, cfg && out_band, "null config or output");
-    int64_t min_rows = planes[0].rows, min_cols = planes[0].cols;
-    for (size_t i = 1; i < n; ++i) {
-        min_rows = std::min(min_rows, planes[i].rows);
-        min_cols = std::min(min_cols, planes[i].cols);
-    }
-    int64_t row0 = 0, nrows = 0;
-    AB_CHECK(ctx, ab_shard_rows(min_rows, ab_comm_size(comm), ab_comm_rank(comm), &row0, &nrows) == AB_OK, "bad communicator");
-    AB_CHECK(ctx, out_band->rows == nrows && out_band->cols == min_cols, "this rank's band is %lld x %lld (got %lld x %lld)", (long long)nrows,
-             (long long)min_cols, (long long)out_band->rows, (long long)out_band->cols);
-    AB_TRY(ab_stack_sigma_clip_rows(ctx, planes, n, cfg, row0, out_band, nullptr));
-    if (out_rejected_total) AB_TRY(total_rejected(ctx, comm, out_rejected_total));
-    return AB_OK;
+    // the local part: argument checks + this rank's band.  Its status is agreed on before the count is exchanged, so a rank
+    // that fails here (bad band, out of memory, cancelled) fails the call on every rank instead of leaving them in RCCL
+    auto local = [&]() -> int {
+        AB_CHECK(ctx, planes && n >= 1, "No images to stack");
+        AB_CHECK(ctx, cfg && out_band, "null config or output");
+        int64_t min_rows = planes[0].rows, min_cols = planes[0].cols;
+        for (size_t i = 1; i < n; ++i) {
+            min_rows = std::min(min_rows, planes[i].rows);
+            min_cols = std::min(min_cols, planes[i].cols);
+        }
+        int64_t row0 = 0, nrows = 0;
+        AB_CHECK(ctx, ab_shard_rows(min_rows, ab_comm_size(comm), ab_comm_rank(comm), &row0, &nrows) == AB_OK, "bad communicator");
+        AB_CHECK(ctx, out_band->rows == nrows && out_band->cols == min_cols, "this rank's band is %lld x %lld (got %lld x %lld)", (long long)nrows,
+                 (long long)min_cols, (long long)out_band->rows, (long long)out_band->cols);
+        return ab_stack_sigma_clip_rows(ctx, planes, n, cfg, row0, out_band, nullptr);
+    };
+    const int rc = local();
+    if (!out_rejected_total) return rc;  // no collective in this call: nothing to agree on
+    AB_TRY(ab_comm_agree(ctx, comm, rc));
+    return total_rejected(ctx, comm, out_rejected_total);
 } AB_CATCH(ctx)
 
 // Frame-sharded two-level stack (BASELINE configs[3]): per-GPU partial over THIS rank's frames -> all-reduce of the
@@ -118,16 +126,24 @@ int ab_stack_sigma_clip_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plane *plan
 int ab_stack_sigma_clip_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *local_planes, size_t n_local, const ab_stack_config *cfg,
                                 ab_plane_mut *out, uint64_t *out_rejected_total) try {
     if (!ctx) return AB_ERR_INVALID;
-    AB_CHECK(ctx, local_planes && n_local >= 1, "every rank needs at least one frame (No images to stack)");
-    AB_CHECK(ctx, cfg && out && out->data && out->on_device, "null config or output (device plane expected)");
-    const int64_t total = out->rows * out->cols;
-    AB_CHECK(ctx, total > 0, "stack output has a zero dimension");
-    char *ws = nullptr;
-    const size_t sum_bytes = (size_t)total * sizeof(double);
-    AB_TRY(ab_workspace(ctx, AB_WS_SHARD, sum_bytes + (size_t)total * sizeof(uint32_t), (void **)&ws));
-    double *psum = (double *)ws;
-    uint32_t *pcnt = (uint32_t *)(ws + sum_bytes);
-    AB_TRY(ab_stack_sigma_clip_partial(ctx, local_planes, n_local, cfg, out->rows, out->cols, psum, pcnt, nullptr));
+    double *psum = nullptr;
+    uint32_t *pcnt = nullptr;
+    int64_t total = 0;
+    // local part first, then ONE agreement: a rank with an empty shard, a failed allocation or a cancel fails the call on
+    // every rank before anybody enters the 12-bytes-per-pixel all-reduces
+    auto local = [&]() -> int {
+        AB_CHECK(ctx, local_planes && n_local >= 1, "every rank needs at least one frame (No images to stack)");
+        AB_CHECK(ctx, cfg && out && out->data && out->on_device, "null config or output (device plane expected)");
+        total = out->rows * out->cols;
+        AB_CHECK(ctx, total > 0, "stack output has a zero dimension");
+        char *ws = nullptr;
+        const size_t sum_bytes = (size_t)total * sizeof(double);
+        AB_TRY(ab_workspace(ctx, AB_WS_SHARD, sum_bytes + (size_t)total * sizeof(uint32_t), (void **)&ws));
+        psum = (double *)ws;
+        pcnt = (uint32_t *)(ws + sum_bytes);
+        return ab_stack_sigma_clip_partial(ctx, local_planes, n_local, cfg, out->rows, out->cols, psum, pcnt, nullptr);
+    };
+    AB_TRY(ab_comm_agree(ctx, comm, local()));
     AB_TRY(ab_comm_allreduce(ctx, comm, psum, (size_t)total, AB_DT_F64, AB_RED_SUM));
     AB_TRY(ab_comm_allreduce(ctx, comm, pcnt, (size_t)total, AB_DT_U32, AB_RED_SUM));
     AB_TRY(ab_stack_finalize_partial(ctx, psum, pcnt, total, out->data));
@@ -139,14 +155,19 @@ int ab_stack_sigma_clip_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *loca
 // rows [row0_r, row0_r + nrows_r) (ab_shard_rows).  One broadcast per rank inside one RCCL group; bands may be unequal.
 int ab_allgather_rows(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, ab_plane_mut *full) try {
     if (!ctx) return AB_ERR_INVALID;
-    AB_CHECK(ctx, band && full && full->data && full->on_device && (band->rows == 0 || (band->data && band->on_device)), "device planes expected");
     const int size = ab_comm_size(comm), rank = ab_comm_rank(comm);
-    int64_t row0 = 0, nrows = 0;
-    AB_CHECK(ctx, ab_shard_rows(full->rows, size, rank, &row0, &nrows) == AB_OK && nrows == band->rows && (nrows == 0 || band->cols == full->cols),
-             "band does not match this rank's share of the image");
-    float *mine = full->data + row0 * full->cols;
-    if (nrows > 0 && band->data != mine)
-        AB_HIP(ctx, hipMemcpyAsync(mine, band->data, (size_t)nrows * full->cols * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    auto local = [&]() -> int {
+        AB_CHECK(ctx, band && full && full->data && full->on_device && (band->rows == 0 || (band->data && band->on_device)), "device planes expected");
+        int64_t row0 = 0, nrows = 0;
+        AB_CHECK(ctx, ab_shard_rows(full->rows, size, rank, &row0, &nrows) == AB_OK && nrows == band->rows && (nrows == 0 || band->cols == full->cols),
+                 "band does not match this rank's share of the image");
+        float *mine = full->data + row0 * full->cols;
+        AB_HIP(ctx, hipSetDevice(ctx->device));
+        if (nrows > 0 && band->data != mine)
+            AB_HIP(ctx, hipMemcpyAsync(mine, band->data, (size_t)nrows * full->cols * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        return AB_OK;
+    };
+    AB_TRY(ab_comm_agree(ctx, comm, local()));
     if (!comm || size == 1) return AB_OK;
     AB_TRY(ab_comm_group_start());
     int rc = AB_OK;
@@ -177,18 +198,24 @@ int ab_register_frames_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *refer
         idx.push_back(i);
     }
     std::vector<ab_affine_align_result> res(mine.size());
-    if (!mine.empty()) AB_TRY(ab_register_frames(ctx, reference, mine.data(), mine.size(), num_threads, res.data()));
+    void *dev = nullptr;
+    const size_t bytes = n * sizeof *out;
+    // this rank's estimates (a frame that cannot be read, a cancel, an allocation may fail here) and the exchange buffer; the
+    // status is agreed on before the exchange, so a rank that failed or was cancelled fails the call on EVERY rank
+    auto local = [&]() -> int {
+        if (!mine.empty()) AB_TRY(ab_register_frames(ctx, reference, mine.data(), mine.size(), num_threads, res.data()));
+        if (comm && size > 1 && n > 0) AB_TRY(ab_scratch(ctx, bytes, &dev));
+        return AB_OK;
+    };
+    AB_TRY(ab_comm_agree(ctx, comm, local()));
     static_assert(sizeof(ab_affine_align_result) % 8 == 0, "results travel as u64 words");
     memset(out, 0, n * sizeof *out);
     for (size_t k = 0; k < idx.size(); ++k) out[idx[k]] = res[k];
     if (!comm || size == 1 || n == 0) return AB_OK;
-    void *dev = nullptr;
-    const size_t bytes = n * sizeof *out;
-    AB_TRY(ab_scratch(ctx, bytes, &dev));
     AB_HIP(ctx, hipMemcpyAsync(dev, out, bytes, hipMemcpyHostToDevice, ctx->stream));
     AB_TRY(ab_comm_allreduce(ctx, comm, dev, bytes / 8, AB_DT_U64, AB_RED_SUM));
     AB_HIP(ctx, hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AB_TRY(ab_comm_stream_wait(ctx, comm));
     return AB_OK;
 } AB_CATCH(ctx)
 

@@ -30,6 +30,32 @@
 
 #include <cmath>
 
+// -inf / +inf the optimiser cannot see through (one SGPR each): v_med3_f32(x, y, -inf) IS min(x, y), but spelled fminf() -- or as
+// a med3 with a literal infinity, which instcombine folds back to fminf() -- it is preceded by a canonicalising v_max_f32 x, x, x
+// whenever the compiler cannot prove an operand is not a signalling NaN (a freshly loaded sample, the result of an integer
+// operation).  No NaN reaches the network (non-finite samples are replaced by +inf above it).
+__device__ __forceinline__ float ab_ninf() {
+    float x = -__builtin_inff();
+    asm("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ float ab_pinf() {
+    float x = __builtin_inff();
+    asm("" : "+s"(x));
+    return x;
+}
+// Compare-exchange.  v_min_f32 / v_max_f32 / v_med3_f32 are half-rate on gfx950 (4.3 cycles per wave64 instruction,
+// tools/valu_rate.hip), and a sorting network is nothing else.  AB_STACK_CE_XOR: the larger element is not compared for a second
+// time -- the minimum is one of the two inputs bit for bit (no NaN reaches the network, denormals are not flushed), so the other
+// one is a ^ b ^ min, a single v_bitop3_b32.
+#ifdef AB_STACK_CE_XOR
+#define AB_CE(a, b)                                                                                                   \
+    {                                                                                                                 \
+        const T lo_ = __builtin_amdgcn_fmed3f(v[a], v[b], ab_ninf());                                                 \
+        v[b] = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(v[a]), __float_as_uint(v[b]), __float_as_uint(lo_), 0x96)); \
+        v[a] = lo_;                                                                                                   \
+    }
+#else
 #define AB_CE(a, b)                         \
     {                                       \
         T lo_ = fminf(v[a], v[b]);          \
@@ -37,21 +63,29 @@
         v[a] = lo_;                         \
         v[b] = hi_;                         \
     }
+#endif
 // The base case of the network on four unsorted samples with the three-input operations: sort three (min3 / med3 / max3), then
 // place the fourth (min, med3, med3, max) -- 7 instructions where Batcher's five compare-exchanges take 10, all of them at the
 // same half rate as a two-input min / max (tools/valu_rate.hip): 48 of the sort's 1086 instructions, 1.18 -> 1.14 ms on the bench
-// stack (same box, AB_LIB_PATH A/B).  No NaN reaches the network (non-finite samples are replaced by +inf above it).
+// stack (same box, AB_LIB_PATH A/B).
 #ifndef AB_STACK_NO_SORT4  // (A/B switch for tools/time_stack_bench_data.py)
 #define AB_SORT4(a, b, c, d)                                                         \
     {                                                                                \
         const T x0_ = v[a], x1_ = v[b], x2_ = v[c], x3_ = v[d];                      \
         const T s0_ = fminf(fminf(x0_, x1_), x2_), s1_ = __builtin_amdgcn_fmed3f(x0_, x1_, x2_), \
                 s2_ = fmaxf(fmaxf(x0_, x1_), x2_);                                   \
-        v[a] = __builtin_amdgcn_fmed3f(-__builtin_inff(), s0_, x3_); /* = min: no canonicalising v_max of x3 first */ \
+        v[a] = __builtin_amdgcn_fmed3f(AB_SORT4_NINF, s0_, x3_); /* = min */         \
         v[b] = __builtin_amdgcn_fmed3f(s0_, s1_, x3_);                               \
         v[c] = __builtin_amdgcn_fmed3f(s1_, s2_, x3_);                               \
-        v[d] = __builtin_amdgcn_fmed3f(__builtin_inff(), s2_, x3_);  /* = max */          \
+        v[d] = __builtin_amdgcn_fmed3f(AB_SORT4_PINF, s2_, x3_); /* = max */         \
     }
+#endif
+#ifdef AB_STACK_LITERAL_INF  // (A/B: round 2's form -- the compiler turns these two into v_min / v_max + one canonicalising v_max per base case)
+#define AB_SORT4_NINF (-__builtin_inff())
+#define AB_SORT4_PINF (__builtin_inff())
+#else
+#define AB_SORT4_NINF ab_ninf()
+#define AB_SORT4_PINF ab_pinf()
 #endif
 #include "sortnet_gen.hpp"
 
@@ -401,8 +435,18 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
     uint32_t rej = 0;
     float last_center = __builtin_nanf("");
     bool active = (n >= 2);
+    // The running sums are moments about c0.  AB_STACK_RAW_MOMENTS: c0 = 0 -- the conversion f32 -> f64 IS the deviation, one f64
+    // subtraction per sample less (3 instructions per sample instead of 4 in the E/Q pass), and sum (x - mean)^2 = Q - n mean^2
+    // cancels log2(mean^2 / variance) bits of an f64: a relative error of ~1e-12 on the variance at mean / sigma = 40.
+#ifdef AB_STACK_RAW_MOMENTS
+    constexpr bool kRaw = true;
+    const float c0 = 0.0f;
+    const double c0d = 0.0;
+#else
+    constexpr bool kRaw = false;
     const float c0 = med;
     const double c0d = (double)med;
+#endif
     double e_rem = 0.0, q_rem = 0.0;
 
     // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
@@ -483,7 +527,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         launder<NP>(v);  // stop LICM from hoisting 64 f32->f64 conversions out of this loop
         const double nn = (double)len;
         // sum x_i = n c0 + sum e_i: exact whenever the direct f64 sum is (one rounding otherwise)
-        const double mean = __builtin_fma(nn, c0d, E1 - e_rem) / nn;
+        const double mean = (kRaw ? E1 - e_rem : __builtin_fma(nn, c0d, E1 - e_rem)) / nn;
         const double dlt = mean - c0d;
         double ss = (Q1 - q_rem) - nn * (dlt * dlt);
         ss = ss > 0.0 ? ss : 0.0;
@@ -527,7 +571,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         active = go && (removed != 0) && !defer;
     }
 
-    const double S = __builtin_fma((double)len, c0d, E1 - e_rem);
+    const double S = kRaw ? E1 - e_rem : __builtin_fma((double)len, c0d, E1 - e_rem);
     ClipResult r;
     if (n == 0) {
         r.value = 0.0f;

@@ -649,7 +649,7 @@ int carve(ab_ctx *ctx, Ws *w) {
 // CUs made 17 workgroups do double duty: the pass took twice one chunk's time)
 void hist_launch_shape(ab_ctx *ctx, int64_t n, int *grid, int64_t *chunk) {
     const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-    int64_t nchunks = (n + kHistChunkMax - 1) / kHistChunkMax;
+    int64_t nchunks = std::max<int64_t>(1, (n + kHistChunkMax - 1) / kHistChunkMax);  // (n == 0: an empty row band of a sharded image)
     const int g = (int)std::max<int64_t>(1, std::min<int64_t>(nchunks, cus));
     nchunks = ((nchunks + g - 1) / g) * g;
     int64_t c = (n + nchunks - 1) / nchunks;
@@ -771,12 +771,12 @@ int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, i
     return AB_OK;
 }
 
-static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_stats *out, ab_stf_params *stf_out) {
+static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_stats *out, ab_stf_params *stf_out, ab_comm *comm = nullptr) {
     void *pin = nullptr;
     AB_TRY(ab_pinned(ctx, sizeof(ab_image_stats) + sizeof(ab_stf_params), &pin));
     static_assert(offsetof(StatsDev, stf) == offsetof(StatsDev, result) + sizeof(ab_image_stats), "result and stf are adjacent");
     AB_HIP(ctx, hipMemcpyAsync(pin, result_dev, sizeof(ab_image_stats) + sizeof(ab_stf_params), hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AB_TRY(ab_comm_stream_wait(ctx, comm));  // (a plain hipStreamSynchronize without a communicator)
     if (out) memcpy(out, pin, sizeof *out);
     if (stf_out) memcpy(stf_out, (char *)pin + sizeof(ab_image_stats), sizeof *stf_out);
     return AB_OK;
@@ -816,12 +816,21 @@ int ab_compute_image_stats_with_known_range(ab_ctx *ctx, const ab_plane *img, do
 // rows, total_rows the whole image's.  Every rank receives the statistics of the WHOLE image.
 int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, int64_t total_rows, ab_image_stats *out) try {
     if (!ctx) return AB_ERR_INVALID;
-    AB_CHECK(ctx, band && out && band->on_device, "sharded statistics take a device-resident row band");
-    AB_CHECK(ctx, total_rows >= band->rows && band->cols > 0, "total_rows (%lld) is smaller than the band (%lld rows)", (long long)total_rows,
-             (long long)band->rows);
+    // arguments + workspace first, agreed on across the ranks: the chain below interleaves kernels and all-reduces, a rank that
+    // bailed out before it would leave its peers inside the first of them
+    auto local = [&]() -> int {
+        AB_CHECK(ctx, band && out && band->on_device, "sharded statistics take a device-resident row band");
+        AB_CHECK(ctx, band->rows >= 0 && (band->rows == 0 || band->data), "null band data");
+        AB_CHECK(ctx, total_rows >= band->rows && band->cols > 0, "total_rows (%lld) is smaller than the band (%lld rows)", (long long)total_rows,
+                 (long long)band->rows);
+        AB_HIP(ctx, hipSetDevice(ctx->device));
+        Ws w;
+        return carve(ctx, &w);
+    };
+    AB_TRY(ab_comm_agree(ctx, comm, local()));
     const ab_image_stats *res = nullptr;
     AB_TRY(ab_stats_enqueue(ctx, comm, band->data, band->rows * band->cols, total_rows * band->cols, 0, 0.0, 0.0, nullptr, &res, nullptr, nullptr));
-    return fetch_result(ctx, res, out, nullptr);
+    return fetch_result(ctx, res, out, nullptr, comm);
 } AB_CATCH(ctx)
 
 // auto_stretch_preview (cmd/common.rs:18-22): compute_image_stats -> auto_stf(default config) -> apply_stf, as one
@@ -832,15 +841,22 @@ int ab_compute_image_stats_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *b
 int ab_auto_stretch_preview(ab_ctx *ctx, ab_comm *comm, const ab_plane *img, int64_t total_rows, const ab_auto_stf_config *cfg,
                             uint8_t *out_u8_dev, ab_image_stats *out_stats, ab_stf_params *out_stf) try {
     if (!ctx) return AB_ERR_INVALID;
-    AB_CHECK(ctx, img && img->data && img->on_device && out_u8_dev, "auto_stretch_preview takes a device plane and a device output");
-    AB_CHECK(ctx, img->rows > 0 && img->cols > 0, "plane has a zero dimension");
-    if (total_rows <= 0) total_rows = img->rows;
-    AB_CHECK(ctx, total_rows >= img->rows, "total_rows is smaller than the band");
+    auto local = [&]() -> int {
+        AB_CHECK(ctx, img && img->on_device && img->rows >= 0 && img->cols > 0, "auto_stretch_preview takes a device plane");
+        AB_CHECK(ctx, comm ? (img->rows == 0 || (img->data && out_u8_dev)) : (img->rows > 0 && img->data && out_u8_dev),
+                 "auto_stretch_preview takes a non-empty device plane and a device output (an empty row band only with a communicator)");
+        if (total_rows <= 0) total_rows = img->rows;
+        AB_CHECK(ctx, total_rows >= img->rows && total_rows > 0, "total_rows is smaller than the band");
+        AB_HIP(ctx, hipSetDevice(ctx->device));
+        Ws w;
+        return carve(ctx, &w);
+    };
+    AB_TRY(ab_comm_agree(ctx, comm, local()));  // (no communicator: returns the local status)
     const ab_image_stats *res = nullptr;
     const void *tx = nullptr;
     AB_TRY(ab_stats_enqueue(ctx, comm, img->data, img->rows * img->cols, total_rows * img->cols, 0, 0.0, 0.0, cfg, &res, &tx, nullptr));
-    AB_TRY(ab_stf_u8_device_tx(ctx, img->data, img->rows * img->cols, tx, out_u8_dev));
-    if (out_stats || out_stf) return fetch_result(ctx, res, out_stats, out_stf);
+    if (img->rows > 0) AB_TRY(ab_stf_u8_device_tx(ctx, img->data, img->rows * img->cols, tx, out_u8_dev));
+    if (out_stats || out_stf) return fetch_result(ctx, res, out_stats, out_stf, comm);
     return AB_OK;
 } AB_CATCH(ctx)
 

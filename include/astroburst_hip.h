@@ -590,13 +590,30 @@ AB_API int ab_comm_init_rank(ab_ctx *ctx, const uint8_t id[AB_COMM_ID_BYTES], in
 /* single process, n contexts on n distinct devices: out_comms[i] is rank i, bound to ctxs[i]'s device.  Drive each
  * context from its own host thread, or bracket the per-device calls with ab_comm_group_start / _end. */
 AB_API int ab_comm_init_all(ab_ctx *const *ctxs, int n, ab_comm **out_comms);
+/* HOST-STAGED transport (no RCCL, ranks may share a device): collectives go through the POSIX shared-memory segment
+ * /abcomm_<name> -- every rank of the job passes the same name; blocks until all nranks joined.  The same entry points
+ * work on it; a collective then returns when its result is in device memory.  What a one-GPU box runs the N > 1 paths
+ * on (tests/test_gpu_multirank.py) and a host without librccl falls back to.  AB_COMM_HOST_SLOT_MB (default 4) = the
+ * per-rank staging window. */
+AB_API int ab_comm_init_rank_host(ab_ctx *ctx, const char *name, int nranks, int rank, ab_comm **out);
+AB_API int ab_comm_is_host(const ab_comm *comm);
+/* Failure handling.  ab_comm_agree: every rank passes the status of its local work; AB_OK comes back only if every rank
+ * passed AB_OK -- a failed rank gets its own status, the others AB_ERR_CANCELLED (a peer was cancelled) or AB_ERR_COMM.
+ * Every sharded entry point below calls it BEFORE its data collectives, so one failing rank fails the call everywhere and
+ * the communicator stays usable.  Waits on collectives are bounded by ab_comm_set_timeout_ms (default: AB_COMM_TIMEOUT_MS
+ * or 300 000): a peer that died turns into AB_ERR_COMM and a dead communicator, not a hang.  ab_comm_abort gives up at
+ * once (host transport: peers blocked in a collective return AB_ERR_COMM immediately; RCCL: ncclCommAbort); afterwards
+ * every collective on the handle fails with AB_ERR_COMM and only ab_comm_destroy is useful. */
+AB_API int ab_comm_agree(ab_ctx *ctx, ab_comm *comm, int local_status);
+AB_API int ab_comm_abort(ab_comm *comm);
+AB_API int ab_comm_set_timeout_ms(ab_comm *comm, int64_t ms);
 AB_API void ab_comm_destroy(ab_comm *comm);
 AB_API int ab_comm_rank(const ab_comm *comm);  /* a NULL communicator is a world of one: rank 0 */
 AB_API int ab_comm_size(const ab_comm *comm);  /* ... of size 1 */
 AB_API uint64_t ab_comm_collectives_issued(const ab_comm *comm);
 AB_API int ab_comm_group_start(void);
 AB_API int ab_comm_group_end(void);
-/* in-place all-reduce of `count` elements on the context's stream (asynchronous) */
+/* in-place all-reduce of `count` elements on the context's stream (RCCL: asynchronous; host-staged: done on return) */
 AB_API int ab_comm_allreduce(ab_ctx *ctx, ab_comm *comm, void *buf_dev, size_t count, int dtype /* ab_dtype */, int op /* ab_redop */);
 /* recv_dev = size x bytes_per_rank bytes, rank r's block at r * bytes_per_rank */
 AB_API int ab_comm_allgather(ab_ctx *ctx, ab_comm *comm, const void *send_dev, void *recv_dev, size_t bytes_per_rank);

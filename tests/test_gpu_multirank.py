@@ -1,0 +1,144 @@
+"""csrc/sharded.hip + csrc/comm.hip with MORE THAN ONE RANK, on one MI355X.
+
+RCCL refuses two ranks on one device, so the ranks join the library's host-staged communicator
+(ab_comm_init_rank_host: collectives through a POSIX shared-memory segment); everything above the transport -- the
+rank-strided target assignment and u64-SUM exchange of ab_register_frames_sharded, the unequal / empty bands of
+ab_stack_sigma_clip_rowband + ab_allgather_rows, the in-chain histogram all-reduces of ab_compute_image_stats_sharded,
+the (sum f64, count u32) all-reduces of ab_stack_sigma_clip_sharded, the status agreement before every data collective --
+is the code a multi-GPU host runs.  Each rank is its own process (tests/multirank_worker.py); this file spawns them and
+holds their results against the oracle and against the single-context entry points.
+"""
+import os
+import subprocess
+import sys
+import time
+import uuid
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import multirank_worker as mw  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def spawn(nranks, scenario, tmp_path, timeout=300, expect_exit=None):
+    name = f"t{uuid.uuid4().hex[:12]}"
+    env = dict(os.environ)
+    env.setdefault("AB_COMM_TIMEOUT_MS", "60000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), name, str(nranks), str(r), scenario, str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(nranks)]
+    t0 = time.time()
+    outs = []
+    for r, p in enumerate(procs):
+        try:
+            o, _ = p.communicate(timeout=max(1.0, timeout - (time.time() - t0)))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail(f"rank {r} of the {scenario!r} scenario hung for {timeout} s")
+        outs.append(o.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        want = 0 if expect_exit is None else expect_exit.get(r, 0)
+        assert p.returncode == want, f"rank {r} exited with {p.returncode}:\n{outs[r][-3000:]}"
+    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) if os.path.exists(os.path.join(tmp_path, f"rank{r}.npz")) else None
+            for r in range(nranks)]
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_sharded_entry_points_with_n_ranks(ctx, oracle, tmp_path, nranks):
+    res = spawn(nranks, "all", tmp_path)
+    # every rank holds the same answers
+    for r in res[1:]:
+        for k in res[0].files:
+            if k.endswith("_rows") or k == "collectives":
+                continue
+            a, b = res[0][k], r[k]
+            if k.startswith("u8_"):   # each rank stretches ITS band
+                continue
+            assert a.shape == b.shape and (np.array_equal(a, b, equal_nan=True) if a.dtype.kind != "U" else (a == b).all()), k
+    r0 = res[0]
+
+    # ab_register_frames_sharded == ab_register_frames on one context == the oracle, frame by frame
+    ref, tgts = mw.star_frames()
+    single = ctx.register_frames(ref.cuda(), [t.cuda() for t in tgts], num_threads=8)
+    for i, s in enumerate(single):
+        assert tuple(r0["reg_transform"][i]) == tuple(s.transform), i       # bit for bit through the u64-SUM exchange
+        assert tuple(r0["reg_counts"][i]) == (s.matched_stars, s.inliers)
+        assert r0["reg_residual"][i] == s.residual_px and str(r0["reg_method"][i]) == s.method
+        want = oracle.align_channel_affine(ref.numpy(), tgts[i].numpy(), num_threads=8)
+        assert want.method == s.method and want.inliers == s.inliers
+        assert np.allclose(s.transform, want.transform, rtol=0, atol=1e-8)
+
+    # row bands: unequal bands (50 rows over 3 ranks: 17 + 17 + 16) and empty ones (2 rows over 3 ranks) reassemble the
+    # reference's single-level stack bit for bit; the rejected count is the sum over the bands
+    for tag, (n, rows, cols) in {"band": (16, 50, 96), "thin": (8, 2, 70)}.items():
+        host = mw.stack_frames(n, rows, cols)
+        want, want_rej = oracle.stack_images([f.numpy() for f in host])
+        assert np.array_equal(r0[f"{tag}_full"], want, equal_nan=True), tag
+        assert int(r0[f"{tag}_rej"][0]) == want_rej
+        covered = sorted((int(r[f"{tag}_rows"][0]), int(r[f"{tag}_rows"][1])) for r in res)
+        assert sum(nr for _, nr in covered) == rows
+    if nranks == 3:
+        assert min(int(r["thin_rows"][1]) for r in res) == 0   # an empty band took part
+
+    # statistics of an image spread over the ranks == compute_image_stats of the whole image: integers exact
+    for tag, img in {"hist": mw.big_image(), "exact": mw.big_image(300, 500, seed=6), "tiny": mw.big_image(2, 700, seed=8)}.items():
+        want = oracle.compute_image_stats(img)
+        got = r0[f"stats_{tag}"]
+        assert int(got[6]) == want.valid_count, tag
+        assert got[0] == want.min and got[1] == want.max
+        for g, w in zip(got[2:6], (want.median, want.mad, want.sigma, want.mean)):
+            assert abs(g - w) <= 1e-12 * max(1.0, abs(w)), (tag, g, w)
+        # and of the library on one context
+        one = ctx.compute_image_stats(torch.from_numpy(img).cuda())
+        assert (one.median, one.mad, one.valid_count) == (got[2], got[3], int(got[6])), tag
+        # the stretch of the bands, put together, is the stretch of the whole image
+        p = oracle.auto_stf(want)
+        assert np.allclose(r0[f"stf_{tag}"], [p.shadow, p.midtone, p.highlight], rtol=1e-12, atol=0)
+        whole = oracle.apply_stf(img, p, want)
+        row = 0
+        for r in range(nranks):
+            _, nr = ctx.shard_rows(img.shape[0], nranks, r)
+            assert np.array_equal(res[r][f"u8_{tag}"], whole[row:row + nr]), (tag, r)
+            row += nr
+
+    # frame shards: partial per rank -> all-reduce -> divide == the two-level checker run shard by shard
+    host = mw.stack_frames(24, 97, 160)
+    s = np.zeros((97, 160)); c = np.zeros((97, 160), dtype=np.uint64); rej = 0
+    for r in range(nranks):
+        f0, nf = ctx.shard_frames(24, nranks, r)
+        ps, pc, pr = oracle.stack_partial([f.numpy() for f in host[f0:f0 + nf]])
+        s, c, rej = s + ps, c + pc, rej + pr   # (two or three addends: the f64 sum in rank order, as the transport forms it)
+    want = np.where(c > 0, (s / np.maximum(c, 1)).astype(np.float32), np.float32(0))
+    assert np.array_equal(r0["frames_out"], want)
+    assert int(r0["frames_rej"][0]) == rej
+    assert all(int(r["collectives"][0]) == int(r0["collectives"][0]) for r in res)   # every rank issued the same sequence
+
+
+def test_a_failing_rank_fails_every_rank_and_nobody_hangs(tmp_path):
+    from astroburst_amd._lib import AB_ERR_CANCELLED
+    res = spawn(2, "fail", tmp_path, timeout=120)
+    for r in res:
+        assert list(r["codes"]) == list(r["want"]), (list(r["codes"]), list(r["want"]))
+        assert bool(r["ok"][0])
+    assert int(res[0]["codes"][0]) == AB_ERR_CANCELLED            # the peer of a cancelled rank is cancelled too
+    assert int(res[0]["rej"][0]) == int(res[1]["rej"][0])         # and the communicator was still in step afterwards
+
+
+def test_a_dead_rank_times_out_as_err_comm(tmp_path):
+    from astroburst_amd._lib import AB_ERR_COMM
+    res = spawn(2, "die", tmp_path, timeout=120, expect_exit={1: 17})
+    r = res[0]
+    assert int(r["code"][0]) == AB_ERR_COMM and 2.0 < float(r["seconds"][0]) < 20.0
+    assert int(r["code2"][0]) == AB_ERR_COMM and float(r["seconds2"][0]) < 1.0   # dead communicator: fails at once
+
+
+def test_abort_releases_blocked_peers(tmp_path):
+    from astroburst_amd._lib import AB_ERR_COMM
+    res = spawn(3, "abort", tmp_path, timeout=120)
+    for r in res[:2]:
+        assert int(r["code"][0]) == AB_ERR_COMM and float(r["seconds"][0]) < 10.0

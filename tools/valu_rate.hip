@@ -104,6 +104,56 @@ __global__ __launch_bounds__(256) void k(float *out, float seed) {
                 if (OP == 65) CHAIN3("v_max3_u32");
                 if (OP == 66) CHAIN2("v_max_u16");
                 if (OP == 67) CHAIN3("v_med3_f32");
+            } else if (OP >= 80 && OP < 100) {
+#define CHAIN3S(OPN, SUF) asm volatile(OPN " %0, %0, %1, %2" SUF "\n " OPN " %1, %1, %2, %3" SUF "\n " OPN " %2, %2, %3, %4" SUF "\n " OPN " %3, %3, %4, %5" SUF "\n " \
+                                 OPN " %4, %4, %5, %6" SUF "\n " OPN " %5, %5, %6, %7" SUF "\n " OPN " %6, %6, %7, %0" SUF "\n " OPN " %7, %7, %0, %1" SUF "\n"     \
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+#define CHAIN2D(OPN) asm volatile(OPN " %0, %0, %1\n " OPN " %1, %1, %2\n " OPN " %2, %2, %3\n " OPN " %3, %3, %4\n " \
+                                 OPN " %4, %4, %5\n " OPN " %5, %5, %6\n " OPN " %6, %6, %7\n " OPN " %7, %7, %0\n"     \
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7))
+#define CHAIN1D(OPN) asm volatile(OPN " %0, %1\n " OPN " %1, %2\n " OPN " %2, %3\n " OPN " %3, %4\n " \
+                                 OPN " %4, %5\n " OPN " %5, %6\n " OPN " %6, %7\n " OPN " %7, %0\n"     \
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7))
+#define CHAIN1(OPN) asm volatile(OPN " %0, %1\n " OPN " %1, %2\n " OPN " %2, %3\n " OPN " %3, %4\n " \
+                                 OPN " %4, %5\n " OPN " %5, %6\n " OPN " %6, %7\n " OPN " %7, %0\n"     \
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7))
+#define CHAIN3D(OPN) asm volatile(OPN " %0, %0, %1, %2\n " OPN " %1, %1, %2, %3\n " OPN " %2, %2, %3, %4\n " OPN " %3, %3, %4, %5\n " \
+                                 OPN " %4, %4, %5, %6\n " OPN " %5, %5, %6, %7\n " OPN " %6, %6, %7, %0\n " OPN " %7, %7, %0, %1\n"     \
+                                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7))
+                if (OP == 80) CHAIN3S("v_bitop3_b32", " bitop3:0x96");
+                if (OP == 81) CHAIN2D("v_min_f64");
+                if (OP == 82) CHAIN1D("v_rcp_f64");
+                if (OP == 83) CHAIN1D("v_rsq_f64");
+                if (OP == 84) CHAIN1D("v_sqrt_f64");
+                if (OP == 85) CHAIN3D("v_div_fixup_f64");
+                if (OP == 86) CHAIN1("v_mov_b32");
+                if (OP == 87) CHAIN1("v_rcp_f32");
+                if (OP == 88) CHAIN1("v_sqrt_f32");
+                if (OP == 89) {  // the compare-exchange as the sorter would issue it: v_min_f32 + v_bitop3_b32 (a ^ b ^ min)  (4 CEs = 8 instr)
+                    float t0, t1, t2, t3;
+                    asm volatile("v_min_f32 %8, %0, %1\n v_min_f32 %9, %2, %3\n v_min_f32 %10, %4, %5\n v_min_f32 %11, %6, %7\n"
+                                 "v_bitop3_b32 %1, %0, %1, %8 bitop3:0x96\n v_bitop3_b32 %3, %2, %3, %9 bitop3:0x96\n"
+                                 "v_bitop3_b32 %5, %4, %5, %10 bitop3:0x96\n v_bitop3_b32 %7, %6, %7, %11 bitop3:0x96\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+                }
+                if (OP == 90) {  // the same with the two-input xor twice (12 instr per 4 CEs; normalised to 8 by the caller's REP)
+                    float t0, t1, t2, t3;
+                    asm volatile("v_min_f32 %8, %0, %1\n v_min_f32 %9, %2, %3\n v_xor_b32 %1, %0, %1\n v_xor_b32 %3, %2, %3\n"
+                                 "v_xor_b32 %1, %1, %8\n v_xor_b32 %3, %3, %9\n v_mov_b32 %0, %8\n v_mov_b32 %2, %9\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3));
+                }
+                if (OP == 91)
+                    asm volatile("v_cvt_f32_f64 %0, %8\n v_cvt_f32_f64 %1, %9\n v_cvt_f32_f64 %2, %10\n v_cvt_f32_f64 %3, %11\n"
+                                 "v_cvt_f32_f64 %4, %12\n v_cvt_f32_f64 %5, %13\n v_cvt_f32_f64 %6, %14\n v_cvt_f32_f64 %7, %15\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                                 : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7));
+                if (OP == 92) CHAIN3D("v_pk_fma_f32");
+                if (OP == 93) {  // v_cmp -> sgpr pair, v_addc with that carry-in (per-lane counting: 2 instr per element)
+                    unsigned long long m0, m1, m2, m3;
+                    asm volatile("v_cmp_lt_f32 %8, %0, %1\n v_cmp_lt_f32 %9, %1, %2\n v_cmp_lt_f32 %10, %2, %3\n v_cmp_lt_f32 %11, %3, %0\n"
+                                 "v_addc_co_u32 %4, vcc, 0, %4, %8\n v_addc_co_u32 %5, vcc, 0, %5, %9\n v_addc_co_u32 %6, vcc, 0, %6, %10\n v_addc_co_u32 %7, vcc, 0, %7, %11\n"
+                                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3) : : "vcc");
+                }
             } else if (OP == 70) {  // integer compare-exchange: v_sub_co_u32 -> vcc ; 2 x v_cndmask (3 instr per CE, 4 CEs)
                 float t0, t1, t2, t3;
                 asm volatile("v_sub_co_u32 %8, vcc, %0, %1\n v_cndmask_b32 %8, %0, %1, vcc\n v_cndmask_b32 %1, %1, %0, vcc\n v_mov_b32 %0, %8\n"
@@ -189,6 +239,12 @@ int main() {
             run<66>("v_max_u16", out, 4, cus, clk); run<67>("v_med3_f32", out, 4, cus, clk);
             run<70>("CE int: sub_co+2cndmask+mov (8 instr/blk)", out, 4, cus, clk); run<71>("CE: cmp_u32->sgpr,2cndmask (8/blk)", out, 4, cus, clk);
             run<72>("CE: sub_co->sgpr,2cndmask (8/blk)", out, 4, cus, clk);
+            run<80>("v_bitop3_b32", out, 4, cus, clk); run<81>("v_min_f64", out, 4, cus, clk); run<82>("v_rcp_f64", out, 4, cus, clk);
+            run<83>("v_rsq_f64", out, 4, cus, clk); run<84>("v_sqrt_f64", out, 4, cus, clk); run<85>("v_div_fixup_f64", out, 4, cus, clk);
+            run<86>("v_mov_b32", out, 4, cus, clk); run<87>("v_rcp_f32", out, 4, cus, clk); run<88>("v_sqrt_f32", out, 4, cus, clk);
+            run<89>("CE: v_min_f32 + v_bitop3 (8/blk)", out, 4, cus, clk); run<90>("CE: v_min_f32 + 2 v_xor + mov (8/blk)", out, 4, cus, clk);
+            run<91>("v_cvt_f32_f64", out, 4, cus, clk); run<92>("v_pk_fma_f32", out, 4, cus, clk);
+            run<93>("count: v_cmp->sgpr + v_addc (8/blk)", out, 4, cus, clk);
         }
     }
     return 0;
