@@ -48,6 +48,9 @@ __device__ __forceinline__ float ab_pinf() {
 // tools/valu_rate.hip), and a sorting network is nothing else.  AB_STACK_CE_XOR: the larger element is not compared for a second
 // time -- the minimum is one of the two inputs bit for bit (no NaN reaches the network, denormals are not flushed), so the other
 // one is a ^ b ^ min, a single v_bitop3_b32.
+#if !defined(AB_STACK_NO_CE_XOR) && !defined(AB_STACK_CE_XOR)
+#define AB_STACK_CE_XOR 1
+#endif
 #ifdef AB_STACK_CE_XOR
 #define AB_CE(a, b)                                                                                                   \
     {                                                                                                                 \
@@ -86,6 +89,48 @@ __device__ __forceinline__ float ab_pinf() {
 #else
 #define AB_SORT4_NINF ab_ninf()
 #define AB_SORT4_PINF ab_pinf()
+#endif
+// The rewritten network (SortNet<NP>::sort_fused, tools/gen_sortnet.py): 789 instructions for 64 samples instead of 1038.  Its
+// operations are spelled as inline assembly: fminf() on a freshly loaded sample is preceded by a canonicalising v_max_f32 x, x, x,
+// a med3 with a literal infinity is folded back to fminf(), and a chain of two fminf() is only sometimes selected as v_min3_f32.
+// No NaN reaches the network (non-finite samples are replaced by +inf above it) and denormals are not flushed, so each of these
+// returns one of its inputs bit for bit.
+__device__ __forceinline__ float ab_v_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float ab_v_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float ab_v_min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float ab_v_max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float ab_v_med3(float a, float b, float c) {
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define AB_SN_MIN2(a, b) ab_v_min(a, b)
+#define AB_SN_MAX2(a, b) ab_v_max(a, b)
+#define AB_SN_MIN3(a, b, c) ab_v_min3(a, b, c)
+#define AB_SN_MAX3(a, b, c) ab_v_max3(a, b, c)
+#define AB_SN_MED3(a, b, c) ab_v_med3(a, b, c)
+#ifdef AB_STACK_CE_XOR  // a plain exchange (both outputs kept): the maximum is x ^ y ^ min, one full-rate v_bitop3_b32
+#define AB_SN_CE(lo, hi, x, y)                                                                                          \
+    {                                                                                                                   \
+        lo = ab_v_min(x, y);                                                                                            \
+        hi = __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(x), __float_as_uint(y), __float_as_uint(lo), 0x96)); \
+    }
 #endif
 #include "sortnet_gen.hpp"
 
@@ -438,15 +483,19 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
     // The running sums are moments about c0.  AB_STACK_RAW_MOMENTS: c0 = 0 -- the conversion f32 -> f64 IS the deviation, one f64
     // subtraction per sample less (3 instructions per sample instead of 4 in the E/Q pass), and sum (x - mean)^2 = Q - n mean^2
     // cancels log2(mean^2 / variance) bits of an f64: a relative error of ~1e-12 on the variance at mean / sigma = 40.
-#ifdef AB_STACK_RAW_MOMENTS
-    constexpr bool kRaw = true;
-    const float c0 = 0.0f;
-    const double c0d = 0.0;
+    // The DEFAULT decides per wave: raw moments when every lane has |median| <= 1024 sigma (the relative error of the variance is
+    // then below 64 * 2^-53 * 2^20 = 7e-9 in the worst case, ~1e-9 typically, a thousandth of what one f32 ulp of sigma means),
+    // moments about the median otherwise (a flat field at 30 000 +- 5, a saturated core).  The formulas below are the same in
+    // both cases: c0 = 0 makes fma(n, c0, E) = E and mean - c0 = mean.
+#if defined(AB_STACK_RAW_MOMENTS)
+    const bool raw = true;
+#elif defined(AB_STACK_CENTRED_MOMENTS)
+    const bool raw = false;
 #else
-    constexpr bool kRaw = false;
-    const float c0 = med;
-    const double c0d = (double)med;
+    const bool raw = __all(__builtin_fabsf(med) <= 1024.0f * sigma);
 #endif
+    const float c0 = raw ? 0.0f : med;
+    const double c0d = (double)c0;
     double e_rem = 0.0, q_rem = 0.0;
 
     // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
@@ -492,10 +541,26 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
                 if (CH * c > top) continue;  // pads only: every lane would add e = c0 - c0
             }
             const bool interior = (CH * c >= a_hi) && (CH * c + CH - 1 <= b_lo);  // wave-uniform
-            if (interior) {
+            if (interior && raw) {  // 3 instructions per sample: cvt, add, fma
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const double e = (double)v[CH * c + j];
+                    E1 += e;
+                    Q1 = __builtin_fma(e, e, Q1);
+                }
+            } else if (interior) {
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const double e = (double)v[CH * c + j] - c0d;
+                    E1 += e;
+                    Q1 = __builtin_fma(e, e, Q1);
+                }
+            } else if (raw) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int i = CH * c + j;
+                    const bool in = (i >= a) && (i <= b);
+                    const double e = (double)(in ? v[i] : 0.0f);
                     E1 += e;
                     Q1 = __builtin_fma(e, e, Q1);
                 }
@@ -527,7 +592,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         launder<NP>(v);  // stop LICM from hoisting 64 f32->f64 conversions out of this loop
         const double nn = (double)len;
         // sum x_i = n c0 + sum e_i: exact whenever the direct f64 sum is (one rounding otherwise)
-        const double mean = (kRaw ? E1 - e_rem : __builtin_fma(nn, c0d, E1 - e_rem)) / nn;
+        const double mean = __builtin_fma(nn, c0d, E1 - e_rem) / nn;
         const double dlt = mean - c0d;
         double ss = (Q1 - q_rem) - nn * (dlt * dlt);
         ss = ss > 0.0 ? ss : 0.0;
@@ -571,7 +636,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         active = go && (removed != 0) && !defer;
     }
 
-    const double S = kRaw ? E1 - e_rem : __builtin_fma((double)len, c0d, E1 - e_rem);
+    const double S = __builtin_fma((double)len, c0d, E1 - e_rem);
     ClipResult r;
     if (n == 0) {
         r.value = 0.0f;
@@ -615,6 +680,11 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
     // n finite samples end up on sorted positions [0, n).
     float v[NP];
     float nf = 0.0f;  // fma(x, 0, nf) stays 0 for finite x and turns NaN for inf / NaN
+#if defined(AB_STACK_PLAIN_SORT) || defined(AB_STACK_NO_HOOKS)
+    constexpr bool kHooked = false;
+#else
+    constexpr bool kHooked = DIRECT && INPUT == kInNative && NP >= 8 && NP <= 64 && STAGE != 1;
+#endif
     if constexpr (DIRECT && INPUT == kInNative && NP <= 64) {
         // All NP frames present, contiguous, < 2^30 px.  The plane pointers come through the scalar cache (s_load_dwordx16 of the
         // kernarg table, 8 pointers per load) and every sample is `global_load_dword v, voffset, s[base:base+1]` with one shared
@@ -625,7 +695,9 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         const uint32_t boff = (uint32_t)g * 4u;
 #pragma unroll
         for (int f = 0; f < NP; ++f) v[f] = *(const float *)((const char *)args.p[f] + boff);
-        if constexpr (MODE == kPlain) {
+        if constexpr (kHooked) {
+            // (tested quarter by quarter from inside the network, below)
+        } else if constexpr (MODE == kPlain) {
             constexpr int CH = NP >= 8 ? 8 : NP;
 #pragma unroll
             for (int c = 0; c < NP / CH; ++c) {
@@ -729,13 +801,15 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         }
     }
     int n = DIRECT ? (MODE == kPlain ? args.n_real : NP) : args.n;
-    if (__any(nf != nf)) {  // rare: some lane of this wave met a non-finite sample
-        n = 0;
+    if constexpr (!kHooked) {
+        if (__any(nf != nf)) {  // rare: some lane of this wave met a non-finite sample
+            n = 0;
 #pragma unroll
-        for (int f = 0; f < NP; ++f) {
-            const bool fin = __builtin_isfinite(v[f]);
-            v[f] = fin ? v[f] : __builtin_inff();
-            n += fin ? 1 : 0;
+            for (int f = 0; f < NP; ++f) {
+                const bool fin = __builtin_isfinite(v[f]);
+                v[f] = fin ? v[f] : __builtin_inff();
+                n += fin ? 1 : 0;
+            }
         }
     }
     if constexpr (STAGE == 1) {
@@ -746,7 +820,59 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         return;
     }
 
+#ifdef AB_STACK_PLAIN_SORT  // (A/B: Batcher's network as written)
     SortNet<NP>::sort(v);
+#else
+    if constexpr (kHooked) {
+        // The finiteness test runs QUARTER BY QUARTER, from inside the network, right before the first operation that reads a
+        // sample of that quarter: the wave sorts frames 0 .. 15 while the loads of frames 16 .. 63 are still in flight (one test
+        // over all 64 samples in front of the network made every wave wait for its last load before its first exchange).
+        constexpr int Q = NP / 4 >= 4 ? NP / 4 : 4, CH = Q < 8 ? Q : 8;
+        int lost = 0;  // non-finite samples among the n real ones
+        auto hook = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            float nq = 0.0f;  // fma(x, 0, nq) stays 0 for finite x and turns NaN for inf / NaN
+            int t = n;
+            if constexpr (MODE == kPlain) {
+                // a padded stack: the pads must not trip the non-finite path for every wave.  Wave-uniform chunk tests on an
+                // opaque scalar copy of the count (or all the `f < n_real` become lane masks held across the kernel)
+                asm volatile("" : "+s"(t));
+#pragma unroll
+                for (int c = 0; c < Q / CH; ++c) {
+                    const int lo = Q * q + CH * c;
+                    if (lo + CH <= t) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) nq = __builtin_fmaf(v[lo + j], 0.0f, nq);
+                    } else if (lo < t) {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j)
+                            if (lo + j < t) nq = __builtin_fmaf(v[lo + j], 0.0f, nq);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < Q; ++j) nq = __builtin_fmaf(v[Q * q + j], 0.0f, nq);
+            }
+            if (__any(nq != nq)) {  // rare: some lane of this wave met a non-finite sample in this quarter
+                int fin_here = 0;
+#pragma unroll
+                for (int j = 0; j < Q; ++j) {
+                    const bool fin = __builtin_isfinite(v[Q * q + j]);
+                    v[Q * q + j] = fin ? v[Q * q + j] : __builtin_inff();
+                    fin_here += fin ? 1 : 0;
+                }
+                const int real = t - Q * q < 0 ? 0 : (t - Q * q > Q ? Q : t - Q * q);  // pads are +inf: never counted as finite
+                lost += real - fin_here;
+            }
+        };
+        SortNet<NP>::sort_fused(v, hook);
+        n -= lost;
+    } else if constexpr (NP >= 8 && NP <= 64) {
+        SortNet<NP>::sort_fused(v);
+    } else {
+        SortNet<NP>::sort(v);
+    }
+#endif
 
     if constexpr (STAGE == 2) {
         float t = 0.0f;
@@ -766,11 +892,16 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         // 128 / 256-sample kernels lose ~4 ms per 4096^2 launch to register shuffling
         med_mad_dispatch<NP, 0, NP / 2>(v, m, __builtin_amdgcn_readfirstlane(m), med, mad);
     } else {
+        // (on a COPY of the samples: launder() makes the vector look rewritten, and if that were v itself the common path
+        // above would pay for it with one register move per sample where the three paths join)
+        float w[NP];
+#pragma unroll
+        for (int f = 0; f < NP; ++f) w[f] = v[f];
         unsigned long long todo = __ballot(1);
         while (todo) {
-            launder<NP>(v);  // or LICM evaluates all NP/2+1 candidate positions up front and spills
+            launder<NP>(w);  // or LICM evaluates all NP/2+1 candidate positions up front and spills
             const int cur = __builtin_amdgcn_readlane(m, (int)__builtin_ctzll(todo));
-            med_mad_dispatch<NP, 0, NP / 2>(v, m, cur, med, mad);
+            med_mad_dispatch<NP, 0, NP / 2>(w, m, cur, med, mad);
             todo &= ~__ballot(m == cur);
         }
     }

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/sq; mkdir -p $OUT
+OUT=/tmp/sq_out; rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VMEM_RD --kernel-trace -d $OUT -o a -- python tools/time_stack_bench_data.py > $OUT/a.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT -o b -- python tools/time_stack_bench_data.py > $OUT/b.log 2>&1
