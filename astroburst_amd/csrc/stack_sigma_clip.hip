@@ -384,7 +384,7 @@ __device__ __forceinline__ int wave_min_i32(int x) {
     return wave_reduce_i32<1>(x);
 }
 
-// One clipping pass over the two ends.  UPDATE: also fold the shaved samples into s_rem/q_rem.
+// One clipping pass over the two ends.  UPDATE: also fold the shaved samples into e_rem / q_rem (RAW: moments about 0).
 // DEFER (fast pass): look at the outermost chunk of each end, and at a second one only if some lane of the wave asks for it;
 // a lane that would have to walk further still is flagged for the general pass instead of making its whole wave walk with
 // it.  (Round 1 stopped after ONE chunk: every pixel with 5 .. 8 rejected samples at one end -- the bands where a few frames
@@ -392,7 +392,11 @@ __device__ __forceinline__ int wave_min_i32(int x) {
 // waves that need it ~40 instructions and everybody else one scalar branch.)
 // SKIP (single-pass kernel): the high-end walk starts at the chunk that holds the wave's largest b instead of stepping
 // over the pads of a ragged / padded stack four registers at a time (129 frames in 256 slots: 32 chunks per pass).
-template <int NP, bool UPDATE, bool DEFER = false, bool SKIP = false>
+// The UPDATE of a chunk sits behind a wave-uniform BRANCH that the compiler must not turn into selects (round 2's form --
+// `if (__any(r)) { ... }` per sample -- was if-converted: every examined sample paid a conversion, three f64 operations and
+// four 32-bit selects whether or not any lane had shaved it, ~120 instructions per iteration; the asm volatile in the block
+// is what keeps it a branch).
+template <int NP, bool UPDATE, bool DEFER = false, bool SKIP = false, bool RAW = false>
 __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, int b, float center, float lo, float hi,
                                           double c0d, float c0, int &cl_out, int &ch_out, double &e_rem, double &q_rem,
                                           bool *defer = nullptr, int skip_hi = 0) {
@@ -401,19 +405,26 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
     bool found_lo = false, found_hi = false;
 #pragma unroll
     for (int c = 0; c < NP / CH; ++c) {
+        bool r[CH];
+        bool any_r = false;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int i = CH * c + j;
             const bool in = (i >= a) && (i <= b);
             const float dev = v[i] - center;
             const bool ok = dev >= lo;
-            const bool r = go && in && !ok;
+            r[j] = go && in && !ok;
             found_lo = found_lo || (in && ok);
-            cl += r ? 1 : 0;
-            if (UPDATE) {
-                if (__any(r)) {
-                    const float xm = r ? v[i] : c0;
-                    const double e = (double)xm - c0d;  // 0 for lanes that keep the sample
+            cl += r[j] ? 1 : 0;
+            any_r = any_r || r[j];
+        }
+        if constexpr (UPDATE) {
+            if (__any(any_r)) {
+                asm volatile("" ::: "memory");  // keeps this a branch (see above)
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float xm = r[j] ? v[CH * c + j] : c0;
+                    const double e = RAW ? (double)xm : (double)xm - c0d;  // 0 for lanes that keep the sample
                     e_rem += e;
                     q_rem = __builtin_fma(e, e, q_rem);
                 }
@@ -433,19 +444,26 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
         if constexpr (SKIP) {
             if (c < skip_hi) continue;  // wave-uniform: every slot of this chunk lies above every lane's b
         }
+        bool r[CH];
+        bool any_r = false;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             const int i = NP - 1 - (CH * c + j);
             const bool in = (i >= a) && (i <= b);
             const float dev = v[i] - center;
             const bool ok = dev <= hi;
-            const bool r = go && in && !ok;
+            r[j] = go && in && !ok;
             found_hi = found_hi || (in && ok);
-            ch += r ? 1 : 0;
-            if (UPDATE) {
-                if (__any(r)) {
-                    const float xm = r ? v[i] : c0;
-                    const double e = (double)xm - c0d;  // 0 for lanes that keep the sample
+            ch += r[j] ? 1 : 0;
+            any_r = any_r || r[j];
+        }
+        if constexpr (UPDATE) {
+            if (__any(any_r)) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const float xm = r[j] ? v[NP - 1 - (CH * c + j)] : c0;
+                    const double e = RAW ? (double)xm : (double)xm - c0d;
                     e_rem += e;
                     q_rem = __builtin_fma(e, e, q_rem);
                 }
@@ -464,103 +482,97 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
     ch_out = ch;
 }
 
-// (Tried: the two divisions of an iteration and the final mean as Markstein steps -- q = x r, rem = fma(-q, d, x), fma(rem, r, q)
-// with r = RN(1 / d) from a 65-entry LDS table, correctly rounded for divisors < 2^7 and bit-identical in every test -- three
-// FMAs instead of the ~11-instruction IEEE sequence.  The per-lane LDS look-ups and the workgroup barrier that fills the table
-// cost more than the divisions: 1.10 -> 1.18 ms.)
-template <int NP, int STAGE = 99, bool DEFER = false, bool SKIP = false>
-__device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med, float mad, float sigma_low,
-                                                float sigma_high, uint32_t max_iter) {
-    bool defer = false;
-    const int top = SKIP ? wave_max_i32<NP>(n - 1) : NP - 1;      // no lane's interval reaches past this slot
-    const int skip_hi = SKIP ? (NP - 1 - top) / (NP >= 4 ? 4 : NP) : 0;  // whole clip_ends chunks above it
-    float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
-    float center = med;
-    int a = 0, b = n - 1, len = n;
-    uint32_t rej = 0;
-    float last_center = __builtin_nanf("");
-    bool active = (n >= 2);
-    // The running sums are moments about c0.  AB_STACK_RAW_MOMENTS: c0 = 0 -- the conversion f32 -> f64 IS the deviation, one f64
-    // subtraction per sample less (3 instructions per sample instead of 4 in the E/Q pass), and sum (x - mean)^2 = Q - n mean^2
-    // cancels log2(mean^2 / variance) bits of an f64: a relative error of ~1e-12 on the variance at mean / sigma = 40.
-    // The DEFAULT decides per wave: raw moments when every lane has |median| <= 1024 sigma (the relative error of the variance is
-    // then below 64 * 2^-53 * 2^20 = 7e-9 in the worst case, ~1e-9 typically, a thousandth of what one f32 ulp of sigma means),
-    // moments about the median otherwise (a flat field at 30 000 +- 5, a saturated core).  The formulas below are the same in
-    // both cases: c0 = 0 makes fma(n, c0, E) = E and mean - c0 = mean.
-#if defined(AB_STACK_RAW_MOMENTS)
-    const bool raw = true;
-#elif defined(AB_STACK_CENTRED_MOMENTS)
-    const bool raw = false;
-#else
-    const bool raw = __all(__builtin_fabsf(med) <= 1024.0f * sigma);
-#endif
-    const float c0 = raw ? 0.0f : med;
+// x / n for a sample count n = 1 .. 64 without the IEEE division sequence (v_div_scale x 2, v_rcp_f64 = 4 issue slots, 5 FMAs, v_div_fmas,
+// v_div_fixup: ~14 slots; an iteration divides twice and the result once more).  With r = RN(1 / n):
+//     q0 = RN(x r),   rem = x - q0 n  (one FMA; exact: q0 is within 2 ulp of x / n, so rem is a multiple of ulp(q0) / 2 below 2^8 ulp),
+//     q  = RN(q0 + rem r)
+// and q0 + rem r differs from x / n by rem (r - 1 / n), less than 2^-45 ulp(q).  That can only change the rounding if x / n lies
+// within 2^-45 ulp of a rounding boundary (k + 1/2) ulp(q); but n (k + 1/2 + eps) ulp(q) = x is a multiple of ulp(x) >= ulp(q), so
+// n eps is a multiple of 1/2 and eps = 0 or |eps| >= 1 / (2 n) = 2^-7 -- and eps = 0 (an exact tie) needs 2 ulp(x) / ulp(q) to divide
+// n, which only a power of two n allows, where the division is exact anyway.  So q = RN(x / n), for every finite x (no overflow:
+// a sum of 64 squares of f32 values stays below 2^262).
+// The reciprocals live in ONE register per wave: lane k holds RN(1 / k) (lane 0: RN(1 / 64)), loaded once from a constant table,
+// and a lane reads the entry of ITS count with two ds_bpermute_b32 (no LDS allocation, no barrier: round 2's LDS table was slower
+// than the divisions because of the barrier that filled it).
+struct RecipTable {
+    double r[64];
+    constexpr RecipTable() : r() {
+        for (int k = 0; k < 64; ++k) r[k] = 1.0 / (double)(k ? k : 64);  // constant-folded: correctly rounded
+    }
+};
+__device__ const RecipTable kRecip{};
+
+__device__ __forceinline__ double recip_of_count(double table, int n) {  // n = 1 .. 64
+    const int idx = (n & 63) << 2;
+    const long long t = __double_as_longlong(table);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)(unsigned)t);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(idx, (int)(unsigned)(t >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int NP>
+__device__ __forceinline__ double div_by_count(double x, double nn, int n, double table) {
+    if constexpr (NP <= 64) {
+        const double r = recip_of_count(table, n);
+        const double q0 = x * r;
+        const double rem = __builtin_fma(-q0, nn, x);
+        return __builtin_fma(rem, r, q0);
+    } else {
+        return x / nn;
+    }
+}
+
+// Per-lane state of the fast engine between the median/MAD clip and the iterations on running sums.
+struct FastState {
+    int a, b, len;
+    uint32_t rej;
+    float last_center;
+    bool active, defer;
+};
+
+// ---- E/Q pass + iterations >= 1 + result, on moments about c0 (RAW: c0 = 0, one f64 subtraction per sample less) ----
+template <int NP, int STAGE, bool DEFER, bool SKIP, bool RAW>
+__device__ __forceinline__ ClipResult clip_fast_tail(float (&v)[NP], int n, float med, float sigma_low, float sigma_high,
+                                                     uint32_t max_iter, FastState s, int top, int skip_hi) {
+    int a = s.a, b = s.b, len = s.len;
+    uint32_t rej = s.rej;
+    float last_center = s.last_center;
+    bool active = s.active, defer = s.defer;
+    const float c0 = RAW ? 0.0f : med;
     const double c0d = (double)c0;
     double e_rem = 0.0, q_rem = 0.0;
+    const double rtab = NP <= 64 ? kRecip.r[threadIdx.x & 63] : 0.0;
 
-    // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
-    if (max_iter >= 1) {
-        const bool go = active;
-        if (go) last_center = center;
-        const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
-        int cl, ch;
-        clip_ends<NP, false, DEFER, SKIP>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer, skip_hi);
-        const int removed = (cl + ch > len) ? len : (cl + ch);
-        if (go) {
-            rej += (uint32_t)removed;
-            len -= removed;
-            if (len > 0) {
-                a += cl;
-                b -= ch;
-            } else {
-                a = 1;
-                b = 0;
-            }
-        }
-        active = go && (removed != 0) && !defer;
-    }
-
-    if constexpr (STAGE == 4) {
-        ClipResult r;
-        r.value = (float)(a + b + len) + center;
-        r.sum = 0.0;
-        r.len = len;
-        r.rej = rej;
-        return r;
-    }
     // ---- one pass over the survivors: E1 = sum e_i, Q1 = sum e_i^2 with e_i = x_i - c0 (f64) ----
-    // (masked only in the 8-register chunks the interval ends can reach; the rest is 4
-    // instructions per sample: cvt, sub, add, fma)
+    // (masked only in the 4-register chunks the interval ends can reach -- the mask is applied to the f32 sample, one select; the
+    // rest is 3 (RAW) or 4 instructions per sample: cvt, [sub,] add, fma)
     double E1 = 0.0, Q1 = 0.0;
     {
-        constexpr int CH = NP >= 8 ? 8 : NP;
-        const int a_hi = wave_max_i32<NP>(defer ? 0 : a), b_lo = wave_min_i32<NP>(defer ? NP - 1 : b);
+        constexpr int CH = NP >= 4 ? 4 : NP;
+        int a_hi = 0, b_lo = NP - 1;
+        if constexpr (!DEFER) {
+            a_hi = wave_max_i32<NP>(a);
+            b_lo = wave_min_i32<NP>(b);
+        }
 #pragma unroll
         for (int c = 0; c < NP / CH; ++c) {
             if constexpr (SKIP) {
                 if (CH * c > top) continue;  // pads only: every lane would add e = c0 - c0
             }
-            const bool interior = (CH * c >= a_hi) && (CH * c + CH - 1 <= b_lo);  // wave-uniform
-            if (interior && raw) {  // 3 instructions per sample: cvt, add, fma
+            bool interior;  // wave-uniform: every lane keeps all CH samples of this chunk
+            if constexpr (DEFER) {
+                // the fast pass shaves at most kDeferChunks chunks off either end (a lane that wanted more is deferred and its
+                // sums are never used): only those chunks can hold an interval end -- one ballot each instead of two wave reductions
+                if (c >= kDeferChunks && c < NP / CH - kDeferChunks)
+                    interior = true;
+                else
+                    interior = !__any(!defer && (a > CH * c || b < CH * c + CH - 1));
+            } else {
+                interior = (CH * c >= a_hi) && (CH * c + CH - 1 <= b_lo);
+            }
+            if (interior) {
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    const double e = (double)v[CH * c + j];
-                    E1 += e;
-                    Q1 = __builtin_fma(e, e, Q1);
-                }
-            } else if (interior) {
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const double e = (double)v[CH * c + j] - c0d;
-                    E1 += e;
-                    Q1 = __builtin_fma(e, e, Q1);
-                }
-            } else if (raw) {
-#pragma unroll
-                for (int j = 0; j < CH; ++j) {
-                    const int i = CH * c + j;
-                    const bool in = (i >= a) && (i <= b);
-                    const double e = (double)(in ? v[i] : 0.0f);
+                    const double e = RAW ? (double)v[CH * c + j] : (double)v[CH * c + j] - c0d;
                     E1 += e;
                     Q1 = __builtin_fma(e, e, Q1);
                 }
@@ -569,8 +581,9 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
                 for (int j = 0; j < CH; ++j) {
                     const int i = CH * c + j;
                     const bool in = (i >= a) && (i <= b);
-                    const float xm = in ? v[i] : c0;
-                    const double e = (double)xm - c0d;
+                    float xm = in ? v[i] : c0;
+                    asm volatile("" : "+v"(xm));  // select the f32 sample (or the compiler selects the two halves of the f64)
+                    const double e = RAW ? (double)xm : (double)xm - c0d;
                     E1 += e;
                     Q1 = __builtin_fma(e, e, Q1);
                 }
@@ -592,13 +605,16 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         launder<NP>(v);  // stop LICM from hoisting 64 f32->f64 conversions out of this loop
         const double nn = (double)len;
         // sum x_i = n c0 + sum e_i: exact whenever the direct f64 sum is (one rounding otherwise)
-        const double mean = __builtin_fma(nn, c0d, E1 - e_rem) / nn;
-        const double dlt = mean - c0d;
+        const int nd = len > 0 ? len : 1;  // (len == 0 only on lanes that are no longer active: their mean is never used)
+        const double sum = RAW ? E1 - e_rem : __builtin_fma(nn, c0d, E1 - e_rem);
+        const double mean = div_by_count<NP>(sum, (double)nd, nd, rtab);
+        const double dlt = RAW ? mean : mean - c0d;
         double ss = (Q1 - q_rem) - nn * (dlt * dlt);
         ss = ss > 0.0 ? ss : 0.0;
-        const double variance = ss / fmax(nn - 1.0, 1.0);
-        center = (float)mean;
-        sigma = (float)fmax(sqrt(variance), 1e-10);
+        const int n1 = len > 1 ? len - 1 : 1;
+        const double variance = div_by_count<NP>(ss, (double)n1, n1, rtab);  // ss / max(n - 1, 1)
+        float center = (float)mean;
+        float sigma = (float)fmax(sqrt(variance), 1e-10);
         if constexpr (STAGE == 6) {  // ablation: iteration 1's mean / sigma only
             ClipResult r;
             r.value = center + sigma;
@@ -612,7 +628,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         if (go) last_center = center;
         const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
         int cl, ch;
-        clip_ends<NP, true, DEFER, SKIP>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer, skip_hi);
+        clip_ends<NP, true, DEFER, SKIP, RAW>(v, go, a, b, center, lo, hi, c0d, c0, cl, ch, e_rem, q_rem, &defer, skip_hi);
         if constexpr (STAGE == 7) {  // ablation: + iteration 1's end walk
             ClipResult r;
             r.value = center + sigma + (float)(cl + ch) + (float)(e_rem + q_rem);
@@ -636,7 +652,10 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         active = go && (removed != 0) && !defer;
     }
 
-    const double S = __builtin_fma((double)len, c0d, E1 - e_rem);
+    const double S = RAW ? E1 - e_rem : __builtin_fma((double)len, c0d, E1 - e_rem);
+    // (outside the per-lane branches below: the table look-up is a cross-lane read, and a lane that sits out a branch returns 0)
+    const int nl = len > 0 ? len : 1;
+    const float mean_f = (float)div_by_count<NP>(S, (double)nl, nl, rtab);
     ClipResult r;
     if (n == 0) {
         r.value = 0.0f;
@@ -645,7 +664,7 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
     } else if (len == 0) {
         r.value = __builtin_isfinite(last_center) ? last_center : 0.0f;
     } else {
-        r.value = (float)(S / (double)len);
+        r.value = mean_f;
     }
     r.sum = (len > 0) ? S : 0.0;
     r.len = len > 0 ? len : 0;
@@ -653,6 +672,71 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
     r.defer = defer;
     return r;
 }
+
+template <int NP, int STAGE = 99, bool DEFER = false, bool SKIP = false>
+__device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med, float mad, float sigma_low,
+                                                float sigma_high, uint32_t max_iter) {
+    bool defer = false;
+    const int top = SKIP ? wave_max_i32<NP>(n - 1) : NP - 1;      // no lane's interval reaches past this slot
+    const int skip_hi = SKIP ? (NP - 1 - top) / (NP >= 4 ? 4 : NP) : 0;  // whole clip_ends chunks above it
+    const float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
+    FastState s;
+    s.a = 0;
+    s.b = n - 1;
+    s.len = n;
+    s.rej = 0;
+    s.last_center = __builtin_nanf("");
+    s.active = (n >= 2);
+
+    // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
+    if (max_iter >= 1) {
+        const bool go = s.active;
+        if (go) s.last_center = med;
+        const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
+        int cl, ch;
+        double unused_e = 0.0, unused_q = 0.0;
+        clip_ends<NP, false, DEFER, SKIP>(v, go, s.a, s.b, med, lo, hi, 0.0, 0.0f, cl, ch, unused_e, unused_q, &defer, skip_hi);
+        const int removed = (cl + ch > s.len) ? s.len : (cl + ch);
+        if (go) {
+            s.rej += (uint32_t)removed;
+            s.len -= removed;
+            if (s.len > 0) {
+                s.a += cl;
+                s.b -= ch;
+            } else {
+                s.a = 1;
+                s.b = 0;
+            }
+        }
+        s.active = go && (removed != 0) && !defer;
+    }
+    s.defer = defer;
+
+    if constexpr (STAGE == 4) {
+        ClipResult r;
+        r.value = (float)(s.a + s.b + s.len) + med;
+        r.sum = 0.0;
+        r.len = s.len;
+        r.rej = s.rej;
+        return r;
+    }
+    // The running sums are moments about c0: E = sum (x - c0), Q = sum (x - c0)^2 (f64, ascending), and iteration k gets
+    // mean = (n c0 + E) / n and sum (x - mean)^2 = Q - n (mean - c0)^2.  RAW MOMENTS (c0 = 0): the conversion f32 -> f64 IS the
+    // deviation, one f64 subtraction per sample less, and Q - n mean^2 cancels log2(mean^2 / variance) bits of an f64.  The wave
+    // decides: raw moments when every lane has |median| <= 1024 sigma (the relative error of the variance is then below
+    // 64 * 2^-53 * 2^20 = 7e-9 in the worst case, ~1e-9 typically, a thousandth of what one f32 ulp of sigma means), moments
+    // about the median otherwise (a flat field at 30 000 +- 5, a saturated core).  Two instances of the tail, one branch.
+#if defined(AB_STACK_RAW_MOMENTS)
+    const bool raw = true;
+#elif defined(AB_STACK_CENTRED_MOMENTS)
+    const bool raw = false;
+#else
+    const bool raw = __all(__builtin_fabsf(med) <= 1024.0f * sigma);
+#endif
+    if (raw) return clip_fast_tail<NP, STAGE, DEFER, SKIP, true>(v, n, med, sigma_low, sigma_high, max_iter, s, top, skip_hi);
+    return clip_fast_tail<NP, STAGE, DEFER, SKIP, false>(v, n, med, sigma_low, sigma_high, max_iter, s, top, skip_hi);
+}
+
 
 // STAGE < 99 cuts the kernel short for the ablation bench (tools/stack_ablate.hip):
 //   1 = loads only, 2 = + pads + sort, 3 = + median/MAD, 99 = everything (the product).
