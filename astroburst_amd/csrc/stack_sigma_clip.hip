@@ -144,6 +144,7 @@ constexpr int kMaxFrames = 256;  // 65 .. 256: 2 / 4 registers of plane pointers
 constexpr int kMaxStrided = 64;  // ragged row strides only exist for the <= 64-frame kernels (deeper stacks are DIRECT or wide)
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
+constexpr unsigned int kGenWaves = 2;    // general pass: single-wave workgroups per deferred-pixel list (a list holds ~65 pixels on the bench stack, 109 at most)
 constexpr int kDeferChunks = 2;          // chunks of 4 samples the fast pass may examine at either end before it defers a pixel (3: 1.165 ms against 1.116, every wave pays for the larger code)
 enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
 enum { kInNative = 0, kInF32BE = 1, kInI16BE = 2 };  // sample encodings the gather understands
@@ -165,6 +166,7 @@ struct StackArgs {
     // two-pass mode (see stack_sigma_clip_kernel): per-slot lists of the pixels the fast pass hands to the general pass
     int *defer_list;                 // kDeferSlots x defer_cap pixel indices
     unsigned int *defer_count;       // kDeferSlots counters
+    unsigned int *defer_ticket;      // kDeferSlots arrival counters of the general pass's workgroups
     unsigned int defer_cap;
     int keep_counts;                 // AB_TRACE: leave the counters for the host to read
     // raw FITS input (INPUT != kInNative): p[] point at big-endian data units, decoded on load as decode_pixels does
@@ -1053,16 +1055,26 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
 template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain, int INPUT = kInNative>
 __global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : AB_STACK_WAVES_PER_SIMD) void stack_sigma_clip_kernel(const StackArgs args) {
     if constexpr (MODE == kGeneralPass) {
-        const unsigned int cnt = args.defer_count[blockIdx.x];  // one block per list
-        const int *list = args.defer_list + (size_t)blockIdx.x * args.defer_cap;
-        for (unsigned int base = 0; base < cnt; base += 256) {
-            if (base + (threadIdx.x & ~63u) >= cnt) break;  // this wave has no pixel left (no barriers in the body)
+        // ONE wave per workgroup, kGenWaves workgroups per list (launched with 64 threads).  With one 4-wave workgroup per list
+        // (round 2) a list of ~65 pixels kept one wave busy and three wave slots empty until it finished: 2048 workgroups went
+        // through the chip three at a time per CU and the pass took 60 us for 2100 waves' worth of work.
+        const unsigned int slot = blockIdx.x / kGenWaves, sub = blockIdx.x % kGenWaves;
+        const unsigned int cnt = args.defer_count[slot];
+        const int *list = args.defer_list + (size_t)slot * args.defer_cap;
+        for (unsigned int base = sub * 64u; base < cnt; base += 64u * kGenWaves) {
             const unsigned int k = base + threadIdx.x;
             const bool valid = k < cnt;
             stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE, INPUT>(args, (int64_t)list[valid ? k : cnt - 1], valid);
         }
-        __syncthreads();  // every wave has read its count
-        if (!args.keep_counts && threadIdx.x == 0) args.defer_count[blockIdx.x] = 0;  // ready for the next launch
+        // the last of the list's workgroups to get here leaves the list empty for the next launch.  (No fence: each workgroup's
+        // own read of the count has returned before its ticket is taken -- the loop bound depends on it -- and a device-scope
+        // release here is an L2 write-back per workgroup on this chip: 4096 of them made the pass 2.4x slower.)
+        if (!args.keep_counts && threadIdx.x == 0) {
+            if (atomicAdd(&args.defer_ticket[slot], 1u) == kGenWaves - 1) {
+                args.defer_ticket[slot] = 0;
+                args.defer_count[slot] = 0;
+            }
+        }
     } else {
         const int64_t total = args.rows * args.cols;
         int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1099,7 +1111,7 @@ __global__ void finalize_partial_kernel(const double *sum, const uint32_t *cnt, 
 template <int NP, int INPUT>
 void launch_raw(ab_ctx *ctx, const StackArgs &args, dim3 grid, dim3 block) {
     hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, false, false, 99, true, kFastPass, INPUT>), grid, block, 0, ctx->stream, args);
-    hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, false, false, 99, true, kGeneralPass, INPUT>), dim3(kDeferSlots), block, 0, ctx->stream, args);
+    hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, false, false, 99, true, kGeneralPass, INPUT>), dim3(kDeferSlots * kGenWaves), dim3(64), 0, ctx->stream, args);
 }
 
 template <int NP, bool PARTIAL, bool EXACT, int STAGE>
@@ -1109,7 +1121,7 @@ void launch_np(ab_ctx *ctx, const StackArgs &args, dim3 grid, dim3 block) {
     if constexpr (!EXACT && STAGE == 99 && NP >= 8) {
         if (direct && args.defer_list) {  // two-pass mode: fast pass over every pixel, general pass over the deferred ones
             hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, true, kFastPass>), grid, block, 0, ctx->stream, args);
-            hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, true, kGeneralPass>), dim3(kDeferSlots), block, 0,
+            hipLaunchKernelGGL((stack_sigma_clip_kernel<NP, PARTIAL, EXACT, STAGE, true, kGeneralPass>), dim3(kDeferSlots * kGenWaves), dim3(64), 0,
                                ctx->stream, args);
             return;
         }
@@ -1157,13 +1169,14 @@ static int setup_defer(ab_ctx *ctx, StackArgs *args, int64_t total) {
     const unsigned int cap = (unsigned int)(((waves + kDeferSlots - 1) / kDeferSlots) * 64);
     char *ws = nullptr;
     const void *before = ctx->ws[AB_WS_STACK_DEFER];
-    AB_TRY(ab_workspace(ctx, AB_WS_STACK_DEFER, (size_t)kDeferSlots * sizeof(unsigned int) + (size_t)kDeferSlots * cap * sizeof(int), (void **)&ws));
+    AB_TRY(ab_workspace(ctx, AB_WS_STACK_DEFER, (size_t)2 * kDeferSlots * sizeof(unsigned int) + (size_t)kDeferSlots * cap * sizeof(int), (void **)&ws));
     args->defer_count = (unsigned int *)ws;
-    args->defer_list = (int *)(ws + (size_t)kDeferSlots * sizeof(unsigned int));
+    args->defer_ticket = args->defer_count + kDeferSlots;
+    args->defer_list = (int *)(ws + (size_t)2 * kDeferSlots * sizeof(unsigned int));
     args->defer_cap = cap;
     // the general pass leaves every counter at zero again, so only a fresh workspace needs clearing
     args->keep_counts = getenv("AB_TRACE") ? 1 : 0;
-    if (ws != before || args->keep_counts) AB_HIP(ctx, hipMemsetAsync(args->defer_count, 0, kDeferSlots * sizeof(unsigned int), ctx->stream));
+    if (ws != before || args->keep_counts) AB_HIP(ctx, hipMemsetAsync(args->defer_count, 0, 2 * kDeferSlots * sizeof(unsigned int), ctx->stream));
     return AB_OK;
 }
 
@@ -1267,7 +1280,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
                 hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 10, true>), grid, block, 0, ctx->stream, args);
             } else if (args.defer_list) {
                 hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kFastPass>), grid, block, 0, ctx->stream, args);
-                hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kGeneralPass>), dim3(kDeferSlots), block, 0, ctx->stream, args);
+                hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true, kGeneralPass>), dim3(kDeferSlots * kGenWaves), dim3(64), 0, ctx->stream, args);
             } else {
                 hipLaunchKernelGGL((stack_sigma_clip_kernel<128, false, false, 99, true>), grid, block, 0, ctx->stream, args);
             }

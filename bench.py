@@ -280,16 +280,24 @@ def main():
     # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs; FETCH_SIZE doubled per the gfx950
     # calibration in profiles/: a loads-only kernel with this access pattern reads exactly 1/2)
     traffic = None
+    profile_avg_ms = None
     try:
         with open(os.path.join(ROOT, "profiles", "stack_pmc.json")) as f:
             pmc = json.load(f)
         # only a counter taken from THIS kernel source counts: the profile script stores the hash of the stack kernel's sources
         if pmc.get("frames") == N and pmc.get("pixels") == P and pmc.get("kernel_source_sha256") == stack_source_hash() and not sharded:
             traffic = pmc["hbm_bytes_per_launch"]
+            profile_avg_ms = pmc.get("profile_avg_ms")
     except Exception:
         pass
+    # `frac` = `frac_in_step`: the kernels' duration between the library's HIP events inside the timed steps (the contract's
+    # definition).  `frac_sustained`: the same launch repeated back to back (a VALU-bound kernel clocks lower when nothing idles
+    # the chip between launches).  `frac_profile`: from the average under rocprofv3 in the committed profile of this source.
     roofline = {"bound": "hbm", "kernel": "stack_sigma_clip_kernel<64> (fast pass + general pass over the deferred pixels = one stack launch)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_in_step": round(achieved / HBM_PEAK_GBS, 4), "frac_sustained": None,
+                "frac_profile": None if not profile_avg_ms else round(algo_bytes / (profile_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "profile_avg_ms": profile_avg_ms,
                 "algorithmic_bytes": algo_bytes, "avg_kernel_ms": round(stack_avg_ms, 4), "traffic": traffic,
                 "back_to_back_ms": None}
     warp_avg_ms = (sum(warp_ms) / len(warp_ms)) if register else 0.0
@@ -337,6 +345,7 @@ def main():
         iso_ms = i0.elapsed_time(i1) / 5
 
     roofline["back_to_back_ms"] = None if iso_ms is None else round(iso_ms, 4)
+    roofline["frac_sustained"] = None if iso_ms is None else round(algo_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     # measured streaming ceiling of this GPU (float4 copy), for context
     a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)
     b = torch.empty_like(a)

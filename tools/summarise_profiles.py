@@ -52,6 +52,13 @@ def main(tag, outdir=None, frames=64, pixels=4096 * 4096):
            "hbm_bytes_per_launch": int((2.0 * fk + wk) * 1024),
            "algorithmic_bytes": 4 * frames * pixels + 4 * pixels}
     out["traffic_over_algorithmic"] = round(out["hbm_bytes_per_launch"] / out["algorithmic_bytes"], 4)
+    # the AVERAGE duration of one stack launch under `rocprofv3 --kernel-trace --stats` (fast pass + general pass): the figure a
+    # reader of profiles/<tag>_kernel_stats.txt recomputes; bench.py prints it beside its own live measurements
+    con = sqlite3.connect(os.path.join(d, "trace_results.db"))
+    rows = con.execute("select name, count(*), avg(duration) from kernels where name like ? group by name", ("%stack_sigma_clip_kernel<64%",)).fetchall()
+    out["profile_avg_ms"] = round(sum(r[2] for r in rows) / 1e6, 4)
+    out["profile_kernels"] = [{"name": r[0][:90], "calls": r[1], "avg_us": round(r[2] / 1e3, 2)} for r in rows]
+    out["profile_source"] = f"profiles/{tag}_kernel_stats.txt"
     # ties the counters to the kernel source they were taken from: bench.py reports `traffic` only while this still matches
     import hashlib
     h = hashlib.sha256()
