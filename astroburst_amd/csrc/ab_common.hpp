@@ -78,6 +78,7 @@ struct ab_ctx {
     // share; end of round 2, whole stage, three runs each: 6 -> 17.7 ms, 8 -> 16.9, 10 -> 17.0, 12 -> 16.8,
     // 14 -> 17.2, 16 -> 17.3, 20 -> 17.9, 24 -> 18.2
     std::vector<ab_ctx *> workers;
+    struct ab_worker_pool *pool = nullptr;  // the persistent host threads that drive `workers` (ab_parallel_frames)
     int register_workers = 12;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
@@ -142,7 +143,10 @@ int ab_workspace(ab_ctx *ctx, int slot, size_t bytes, void **out);
 // (own non-blocking stream + workspaces, cached in ctx->workers).  ctx->stream is drained first (unless the caller did and keeps
 // using it concurrently); each worker's stream is drained
 // before return.  With one worker fn runs inline on ctx.
-int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn, bool drain_caller_stream = true);
+// prologue (nullable): run once, on one more pool thread, concurrently with the frame loop -- work on the caller's context that
+// overlaps the workers' frames (the reference frame's detection in a registration batch)
+int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn, bool drain_caller_stream = true,
+                       const std::function<void()> *prologue = nullptr);
 
 // RAII staging of an input plane: host planes are uploaded to a temporary device buffer.
 struct StagedPlane {

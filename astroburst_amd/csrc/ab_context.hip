@@ -1,6 +1,8 @@
 // Context, error reporting, HBM scratch and host<->device staging.
 #include "ab_common.hpp"
 
+#include <condition_variable>
+
 #include <algorithm>
 #include <atomic>
 #include <exception>
@@ -48,12 +50,17 @@ int ab_progress(ab_ctx *ctx, const char *stage, uint64_t current, uint64_t total
     ab_ctx *root = ctx;
     while (root->parent) root = root->parent;
     if (root->cancel.load(std::memory_order_relaxed)) return ab_set_error(ctx, AB_ERR_CANCELLED, "Operation cancelled");
-    if (root->progress_cb) {
-        std::lock_guard<std::mutex> lk(root->progress_mu);
-        root->progress_cb(stage, current, total, root->progress_user);
+    {
+        std::lock_guard<std::mutex> lk(root->progress_mu);  // the callback and its user pointer are read under the lock that sets them
+        if (root->progress_cb) root->progress_cb(stage, current, total, root->progress_user);
     }
+    // a host that learns of a cancel while it is being ticked (bindings/mod.rs forwards ProgressHandle::is_cancelled() from the tick)
+    // stops at THIS stage boundary, as the reference's `if p.is_cancelled()` after each tick does (background.rs:80-91)
+    if (root->cancel.load(std::memory_order_relaxed)) return ab_set_error(ctx, AB_ERR_CANCELLED, "Operation cancelled");
     return AB_OK;
 }
+
+void ab_worker_pool_destroy(ab_ctx *ctx);
 
 extern "C" {
 
@@ -117,6 +124,7 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ab_worker_pool_destroy(ctx);  // (the threads index ctx->workers)
     for (ab_ctx *w : ctx->workers) ab_ctx_destroy(w);
     ctx->workers.clear();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -136,7 +144,17 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     delete ctx;
 }
 
-const char *ab_last_error(const ab_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+// (a copy per calling thread, taken under the lock ab_set_error writes under: a frame worker may be recording an error while the
+// caller reads the previous one; the pointer stays valid until this thread's next ab_last_error)
+const char *ab_last_error(const ab_ctx *ctx) {
+    if (!ctx) return "null context";
+    thread_local std::string copy;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<ab_ctx *>(ctx)->err_mu);
+        copy = ctx->err;
+    }
+    return copy.c_str();
+}
 
 // State the context owns (rejection counters, scratch arena, defer lists, statistics block) may still be in use by asynchronous
 // work queued on the stream being left: the new stream waits for an event recorded there, so calls stay ordered across a switch.
@@ -321,9 +339,75 @@ void ab_stage_out_abort(ab_ctx *ctx, StagedOut *o) {
     }
 }
 
-int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn, bool drain_caller_stream) {
+// The host threads behind ab_parallel_frames live as long as their context: a registration call used to create and join 12 + 1
+// std::threads (~0.5 ms of a 17 ms stage); now a call publishes a job and the parked threads pick it up.
+struct ab_worker_pool {
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    std::vector<std::thread> threads;
+    uint64_t generation = 0;
+    bool stop = false;
+    // the job in flight (valid while remaining > 0)
+    const std::function<int(ab_ctx *, size_t)> *fn = nullptr;
+    const std::function<void()> *prologue = nullptr;
+    const char *what = "";
+    size_t n = 0, active = 0, remaining = 0;
+    std::atomic<size_t> next{0};
+    std::vector<int> rcs;
+};
+
+static void pool_thread(ab_ctx *ctx, ab_worker_pool *p, size_t t) {
+    uint64_t seen = 0;
+    bool device_ok = hipSetDevice(ctx->device) == hipSuccess;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv_start.wait(lk, [&] { return p->stop || p->generation != seen; });
+            if (p->stop) return;
+            seen = p->generation;
+            if (t >= p->active) continue;  // this job uses fewer workers
+        }
+        int rc = device_ok ? AB_OK : AB_ERR_HIP;
+        if (p->prologue && t == p->active - 1) {  // the extra thread of a job with a prologue runs that and nothing else
+            if (rc == AB_OK) (*p->prologue)();
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->rcs[t] = rc;
+            if (--p->remaining == 0) p->cv_done.notify_all();
+            continue;
+        }
+        ab_ctx *wc = ctx->workers[t];
+        if (rc == AB_OK) {
+            for (size_t f = p->next.fetch_add(1); f < p->n; f = p->next.fetch_add(1)) {
+                rc = ab_progress(wc, p->what, f + 1, p->n);  // per-frame tick; a cancel request stops the fan-out here
+                if (rc == AB_OK) rc = (*p->fn)(wc, f);
+                if (rc != AB_OK) break;  // (the stream is still drained below: nothing of this worker may be in flight when the caller cleans up)
+            }
+            if (hipStreamSynchronize(wc->stream) != hipSuccess && rc == AB_OK) rc = AB_ERR_HIP;
+        }
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->rcs[t] = rc;
+        if (--p->remaining == 0) p->cv_done.notify_all();
+    }
+}
+
+void ab_worker_pool_destroy(ab_ctx *ctx) {
+    ab_worker_pool *p = ctx->pool;
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+    }
+    p->cv_start.notify_all();
+    for (std::thread &th : p->threads) th.join();
+    delete p;
+    ctx->pool = nullptr;
+}
+
+int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::function<int(ab_ctx *, size_t)> &fn, bool drain_caller_stream,
+                       const std::function<void()> *prologue) {
     const size_t workers = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1));
     if (workers <= 1) {
+        if (prologue) (*prologue)();
         for (size_t f = 0; f < n; ++f) {
             AB_TRY(ab_progress(ctx, what, f + 1, n));
             AB_TRY(fn(ctx, f));
@@ -338,28 +422,29 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
         ctx->workers.push_back(wc);
     }
     if (drain_caller_stream) AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // whatever the caller queued on ctx (its frames, shared tables) is complete
-    std::atomic<size_t> next{0};
-    std::vector<int> rcs(workers, AB_OK);
-    std::vector<std::thread> pool;
+    if (!ctx->pool) ctx->pool = new ab_worker_pool();
+    ab_worker_pool *p = ctx->pool;
+    const size_t active = workers + (prologue ? 1 : 0);
+    while (p->threads.size() < active) {  // (only ever grows; the worker contexts it indexes exist above)
+        const size_t t = p->threads.size();
+        p->threads.emplace_back(pool_thread, ctx, p, t);
+    }
+    {
+        std::unique_lock<std::mutex> lk(p->mu);
+        p->fn = &fn;
+        p->prologue = prologue;
+        p->what = what;
+        p->n = n;
+        p->active = active;
+        p->remaining = active;
+        p->next.store(0);
+        p->rcs.assign(p->threads.size(), AB_OK);
+        ++p->generation;
+        p->cv_start.notify_all();
+        p->cv_done.wait(lk, [&] { return p->remaining == 0; });
+    }
     for (size_t t = 0; t < workers; ++t)
-        pool.emplace_back([&, t]() {
-            ab_ctx *wc = ctx->workers[t];
-            if (hipSetDevice(wc->device) != hipSuccess) {
-                rcs[t] = AB_ERR_HIP;
-                return;
-            }
-            for (size_t f = next.fetch_add(1); f < n; f = next.fetch_add(1)) {
-                int rc = ab_progress(wc, what, f + 1, n);  // per-frame tick; a cancel request stops the fan-out here
-                if (rc == AB_OK) rc = fn(wc, f);
-                if (rc != AB_OK) {
-                    rcs[t] = rc;
-                    break;  // (the stream is still drained below: nothing of this worker may be in flight when the caller cleans up)
-                }
-            }
-            if (hipStreamSynchronize(wc->stream) != hipSuccess && rcs[t] == AB_OK) rcs[t] = AB_ERR_HIP;
-        });
-    for (std::thread &th : pool) th.join();
-    for (size_t t = 0; t < workers; ++t)
-        if (rcs[t] != AB_OK) return ab_set_error(ctx, rcs[t], "%s worker %zu: %s", what, t, ctx->workers[t]->err.c_str());
+        if (p->rcs[t] != AB_OK) return ab_set_error(ctx, p->rcs[t], "%s worker %zu: %s", what, t, ctx->workers[t]->err.c_str());
+    if (prologue && p->rcs[workers] != AB_OK) return ab_set_error(ctx, p->rcs[workers], "%s: no device for the prologue thread", what);
     return AB_OK;
 }

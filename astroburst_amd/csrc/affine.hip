@@ -840,6 +840,15 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     // percentile workgroups side by side (see ab_normalize_params_many_device)
     std::vector<ab_pixel_xf> xfs;
     ab_bg_pipeline pipe;  // plane 0 = the reference, plane 1 + f = target f
+    // whatever path leaves this function, tile launches still in flight on the auxiliary stream (they read the caller's frames)
+    // are drained first
+    struct AuxDrain {
+        ab_ctx *c;
+        ab_bg_pipeline *p;
+        ~AuxDrain() {
+            if (p->on && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+        }
+    } aux_drain{ctx, &pipe};
     const bool have_xf = n >= 4;
     if (have_xf) {
         std::vector<const float *> planes(targets, targets + n);
@@ -902,13 +911,14 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         return rc;
     }
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's frames are complete before any other stream reads them
+    // the reference frame's detection and triangle table run on the caller's context, on one more thread of the pool, while the
+    // workers already detect their targets (they block on the table only before matching)
     int prep_rc = AB_OK;
-    std::thread prep([&]() {
-        prep_rc = hipSetDevice(ctx->device) == hipSuccess ? prepare_reference() : AB_ERR_HIP;
+    const std::function<void()> prep = [&]() {
+        prep_rc = prepare_reference();
         rt.publish(prep_rc, prep_rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
-    });
-    const int rc = ab_parallel_frames(ctx, n, "registration", one, /*drain_caller_stream=*/false);
-    prep.join();
+    };
+    const int rc = ab_parallel_frames(ctx, n, "registration", one, /*drain_caller_stream=*/false, &prep);
     if (warp_stream) (void)hipStreamSynchronize(warp_stream);  // the aligned frames are complete when this call returns
     if (pipe.on) (void)hipStreamSynchronize(ctx->aux_stream);  // (an error or a cancel may leave tile launches in flight: they read the caller's frames)
     return prep_rc != AB_OK ? prep_rc : rc;

@@ -886,7 +886,11 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
         AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->aux_events.push_back(e);
     }
-    const size_t need = n * (size_t)ntiles * sizeof(TileOut);
+    // the tile results, and behind them the staging copy of the plane-pointer and transform tables: the callers' tables are locals
+    // in pageable memory, and an asynchronous copy out of those is only safe while the runtime happens to stage it synchronously
+    const size_t ptr_bytes = n * sizeof(const float *), xf_bytes = n * sizeof(ab_pixel_xf);
+    const size_t tiles_bytes = (n * (size_t)ntiles * sizeof(TileOut) + 63) & ~(size_t)63;
+    const size_t need = tiles_bytes + ((ptr_bytes + 15) & ~(size_t)15) + xf_bytes;
     if (need > ctx->aux_pinned_bytes) {
         if (ctx->aux_pinned) {
             AB_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
@@ -898,20 +902,31 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
         ctx->aux_pinned_bytes = need;
     }
     char *dv = nullptr;  // device copies of the plane pointers and transforms
-    const size_t ptr_bytes = n * sizeof(const float *), xf_bytes = n * sizeof(ab_pixel_xf);
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_DEV, ptr_bytes + xf_bytes + 64, (void **)&dv));
     const float **dplanes = (const float **)dv;
     ab_pixel_xf *dxf = (ab_pixel_xf *)(dv + ((ptr_bytes + 15) & ~(size_t)15));
-    AB_HIP(ctx, hipMemcpyAsync(dplanes, planes, ptr_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
-    AB_HIP(ctx, hipMemcpyAsync(dxf, xf, xf_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
-    for (size_t c = 0; c < nchunks; ++c) {
-        const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
-        hipLaunchKernelGGL(tile_background_bucket_kernel, dim3((unsigned)ntiles, (unsigned)cnt), dim3(tb::kThreads), 0, ctx->aux_stream, (const float *)nullptr,
-                           (int)rows, (int)cols, cols, step, ntx, ab_pixel_xf(), (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, (const FrameDev *)nullptr,
-                           (const float *const *)(dplanes + first), (const ab_pixel_xf *)(dxf + first));
-        AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
+    char *stage = (char *)ctx->aux_pinned + tiles_bytes;
+    memcpy(stage, planes, ptr_bytes);
+    memcpy(stage + ((ptr_bytes + 15) & ~(size_t)15), xf, xf_bytes);
+    // from the first enqueue on, a failure drains the auxiliary stream before it returns: the launches read the caller's frames
+    auto enqueue = [&]() -> int {
+        AB_HIP(ctx, hipMemcpyAsync(dplanes, stage, ptr_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
+        AB_HIP(ctx, hipMemcpyAsync(dxf, stage + ((ptr_bytes + 15) & ~(size_t)15), xf_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
+        for (size_t c = 0; c < nchunks; ++c) {
+            const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
+            hipLaunchKernelGGL(tile_background_bucket_kernel, dim3((unsigned)ntiles, (unsigned)cnt), dim3(tb::kThreads), 0, ctx->aux_stream, (const float *)nullptr,
+                               (int)rows, (int)cols, cols, step, ntx, ab_pixel_xf(), (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, (const FrameDev *)nullptr,
+                               (const float *const *)(dplanes + first), (const ab_pixel_xf *)(dxf + first));
+            AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
+        }
+        AB_HIP(ctx, hipGetLastError());
+        return AB_OK;
+    };
+    const int rc = enqueue();
+    if (rc != AB_OK) {
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        return rc;
     }
-    AB_HIP(ctx, hipGetLastError());
     p->on = true;
     p->tiles = ctx->aux_pinned;
     p->events = ctx->aux_events.data();

@@ -79,6 +79,15 @@ int ab_analyze_subframes(ab_ctx *ctx, const ab_plane *images, size_t n, const ab
     // device-resident subframes of one size: their background tiles as a pipeline on the auxiliary stream, as in a registration
     // batch (detect.hip: ab_bg_pipeline_*), instead of one tile kernel inside every frame's chain
     ab_bg_pipeline pipe;
+    // whatever path leaves this function, tile launches still in flight on the auxiliary stream (they read the caller's frames)
+    // are drained first
+    struct AuxDrain {
+        ab_ctx *c;
+        ab_bg_pipeline *p;
+        ~AuxDrain() {
+            if (p->on && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+        }
+    } aux_drain{ctx, &pipe};
     bool uniform = n >= 4;
     for (size_t i = 0; i < n && uniform; ++i)
         uniform = images[i].on_device && images[i].rows == images[0].rows && images[i].cols == images[0].cols;

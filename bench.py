@@ -57,6 +57,10 @@ def parse():
                     help="1 GPU: run the N > 1 code path (partial -> RCCL all-reduce on a one-rank communicator -> finalize)")
     ap.add_argument("--mode", choices=("frames", "rowband"), default="frames",
                     help="N > 1: 'frames' = BASELINE configs[3] (frame shards, two-level, weak scaling); 'rowband' = exact row bands (strong scaling)")
+    ap.add_argument("--config", choices=("C1", "C3", "C5"), default=None,
+                    help="a BASELINE.json configuration other than the headline C2: one secondary JSON line (bench_configs.py)")
+    ap.add_argument("--host-planes", action="store_true",
+                    help="also time the step with the 64 frames starting in pinned HOST memory (uploads pipelined with registration): config.host_resident_mpix_s")
     return ap.parse_args()
 
 
@@ -116,6 +120,10 @@ def rigid_transforms(n, rows, cols, seed=7):
 
 def main():
     args = parse()
+    if args.config:
+        import bench_configs
+        bench_configs.run(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
     # stdout carries ONE JSON line: everything else that lands on fd 1 (RCCL prints a version banner there, at communicator
@@ -344,6 +352,59 @@ def main():
         torch.cuda.synchronize()
         iso_ms = i0.elapsed_time(i1) / 5
 
+    # ---- the same step with the frames starting in HOST memory, as a command of the application would hold them (Array2<f32> in
+    # GLOBAL_IMAGE_CACHE): 64 x 67 MB cross PCIe once.  The uploads run on their own stream, four chunks of 16 frames, and the
+    # registration of a chunk starts when its frames have landed, so the link is busy from the first byte to (almost) the last.
+    host_info = None
+    if args.host_planes and world == 1 and not sharded and register and not args.known_transforms:
+        hosts = [torch.empty((R, Cc), dtype=torch.float32, pin_memory=True) for _ in range(N)]
+        for k in range(N):
+            hosts[k].copy_(raw[k])
+        up = [torch.empty_like(raw[0]) for _ in range(N)]
+        hw = [up[0]] + [torch.empty_like(raw[0]) for _ in range(1, N)]
+        copy_stream = torch.cuda.Stream()
+        chunks = [list(range(c, min(c + 16, N))) for c in range(0, N, 16)]
+        torch.cuda.synchronize()
+
+        def upload_all():
+            evs = []
+            with torch.cuda.stream(copy_stream):
+                for ch in chunks:
+                    for k in ch:
+                        up[k].copy_(hosts[k], non_blocking=True)
+                    e_ = torch.cuda.Event()
+                    e_.record(copy_stream)
+                    evs.append(e_)
+            return evs
+
+        def host_step():
+            evs = upload_all()
+            main_s = torch.cuda.current_stream()
+            for ci, ch in enumerate(chunks):
+                main_s.wait_event(evs[ci])
+                tg = [k for k in ch if k != 0]
+                ctx.align_pairs_affine(up[0], [up[k] for k in tg], [hw[k] for k in tg], num_threads=8)
+            ctx.stack_sigma_clip(hw, 3.0, 3.0, 5, out=stacked, want_rejected=False)
+            ctx.auto_stretch_preview(stacked, out=u8)
+
+        host_step()
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        for _ in range(3):
+            host_step()
+        torch.cuda.synchronize()
+        host_ms = (time.perf_counter() - t_h) / 3 * 1e3
+        t_u = time.perf_counter()
+        for _ in range(3):
+            upload_all()
+        torch.cuda.synchronize()
+        up_ms = (time.perf_counter() - t_u) / 3 * 1e3
+        same = all(torch.equal(hw[k], warped[k]) for k in (1, N // 2, N - 1))
+        host_info = {"host_resident_ms_per_step": round(host_ms, 3), "host_resident_mpix_s": round(N * P / 1e6 / (host_ms * 1e-3), 1),
+                     "pcie_upload_only_ms": round(up_ms, 3), "pcie_GBs": round(4 * N * P / (up_ms * 1e-3) / 1e9, 1),
+                     "over_pcie_bound": round(host_ms / up_ms, 3), "registered_frames_equal_device_resident_run": bool(same)}
+        del hosts, up, hw
+
     roofline["back_to_back_ms"] = None if iso_ms is None else round(iso_ms, 4)
     roofline["frac_sustained"] = None if iso_ms is None else round(algo_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     # measured streaming ceiling of this GPU (float4 copy), for context
@@ -469,7 +530,8 @@ def main():
                        "devices": dev_names, "mode": ("rowband" if rowband else "frames") if sharded else "single",
                        "output_mpix_per_s": round((1 if rowband else world) * P / 1e6 / (elapsed / args.steps), 1),
                        "rejected_pixels": rejected, "median": st.median,
-                       "measured_copy_GBs": round(copy_gbs, 1), "stage_ms": stage_ms, "registration": reg_info},
+                       "measured_copy_GBs": round(copy_gbs, 1), "stage_ms": stage_ms, "registration": reg_info,
+                       **({"host_resident_mpix_s": host_info["host_resident_mpix_s"], "host_planes": host_info} if host_info else {})},
             "roofline": roofline,
             "roofline_step": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                               "frac": round(step_gbs / (HBM_PEAK_GBS * world), 4), "algorithmic_bytes": step_bytes,

@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""bench.py --config C1|C3|C5: the BASELINE.json configurations other than the headline one (C2 = bench.py's default; C4 = the
+8-GPU leg, `bench.py --gpus 8`), each as ONE JSON line with its own `roofline` and `cpu_baseline`, one GPU.
+
+  C1  exampleFits shape, 4 x 1600 x 1600 f32: stack_images(align = true: phase correlation + bicubic shift + kappa-sigma stack) +
+      compute_image_stats (exact select, <= 4 000 000 px) + auto_stf + apply_stf
+  C3  JWST NIRCam shape, 16 x 13759 x 12451 f32: 15 x align_pair(Affine) (estimate + bicubic warp) + 16-frame kappa-sigma stack +
+      tone curve (apply_curve) + SHO blend-matrix compose (blend_channels, 3 channels -> r, g, b)
+  C5  3 x 8192 x 8192 f32 narrowband: masked_stretch_rgb_shared (star mask from the luminance) + apply_scnr_inplace +
+      spcc_calibrate_rgb
+
+The reference publishes no throughput for these shapes; docs/code/astroburst_technical_document.tex:611-619 quotes
+per-operation times of the CPU / WebGPU paths on the authors' machine, kept in `config.reference_published` as context only.
+`cpu_baseline` is the oracle (C restatement, OpenMP, all host cores) on a bounded sample, scaled to the configuration.
+"""
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0
+
+
+def _events(torch):
+    return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+
+def _time_steps(torch, step, steps, warmup):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def _time_kernel(torch, fn, reps=5):
+    fn()
+    e0, e1 = _events(torch)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def config_c1(args, torch, ab, synth, pyoracle, ctx):
+    import numpy as np
+    n, rows, cols = 4, 1600, 1600
+    P = rows * cols
+    y, x, flux = synth.star_catalog(rows, cols, 900, seed=11)
+    cat = (y, x, flux * 30.0)
+    shifts = [(0.0, 0.0), (2.25, -1.5), (-3.5, 4.0), (1.0, 2.75)]
+    frames = [synth.make_frame(rows, cols, k, cat=cat, device="cuda", shift=shifts[k], bad_patch_rate=0.0) for k in range(n)]
+    u8 = torch.empty((rows, cols), dtype=torch.uint8, device="cuda")
+    state = {}
+
+    def step():
+        res = ctx.stack_images(frames, 3.0, 3.0, 5, align=True)
+        _, st, _ = ctx.auto_stretch_preview(res.image, out=u8)
+        state["res"], state["st"] = res, st
+
+    sec = _time_steps(torch, step, args.steps, args.warmup)
+    res = state["res"]
+    stack_only = _time_kernel(torch, lambda: ctx.stack_sigma_clip(frames, 3.0, 3.0, 5, want_rejected=False))
+    # algorithmic bytes of the step: phase correlation reads the reference + each target once at <= 512^2 after area-averaging the
+    # frames (2 x 4P per pair), the 3 shifts read + write a frame (8P each), the stack reads 4 frames and writes one, stats + STF 21P
+    step_bytes = 3 * 8 * P + 3 * 8 * P + (4 * n * P + 4 * P) + 21 * P
+    stack_bytes = 4 * n * P + 4 * P
+    cpu = None
+    if not args.no_cpu_baseline:
+        host = [f.cpu().numpy() for f in frames]
+        t0 = time.perf_counter()
+        ref_img, _, ref_offs = pyoracle.stack_images_align(host, 3.0, 3.0, 5)
+        cst = pyoracle.compute_image_stats(ref_img)
+        pyoracle.apply_stf(ref_img, pyoracle.auto_stf(cst), cst)
+        dt = time.perf_counter() - t0
+        got = res.image.cpu().numpy()
+        cpu = {"value": round(n * P / 1e6 / dt, 2), "unit": "MPix/s", "cores": pyoracle.max_threads(), "kind": "port",
+               "sample": f"oracle/liboracle.so: stack_images(align) + exact stats + auto-STF on the whole {n}x{rows}x{cols} configuration ({dt:.2f} s)",
+               "parity_vs_gpu": {"offsets_equal": [tuple(o) for o in res.offsets] == [tuple(o) for o in ref_offs],
+                                 "bit_mismatches": int((~((got == ref_img) | (np.isnan(got) & np.isnan(ref_img)))).sum())}}
+    return {
+        "metric": "MPix/s align + sigma-clipped stack + stretch, 4x1600x1600 f32 (BASELINE configs[0])", "value": round(n * P / 1e6 / sec, 1),
+        "ms_per_step": round(sec * 1e3, 4),
+        "config": {"workload": f"C1: {n}x{rows}x{cols} f32 synthetic WFPC2-shape frames: stack_images(align=true) = 3 x phase_correlate + 3 x bicubic shift + "
+                               "kappa-sigma stack (3/3/5) + exact image stats + auto-STF u8", "offsets": [list(o) for o in res.offsets]},
+        "roofline": {"bound": "hbm", "kernel": "stack_sigma_clip_kernel<4> (the stack of the 4 shifted frames alone)", "achieved": round(stack_bytes / (stack_only * 1e-3) / 1e9, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(stack_bytes / (stack_only * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(stack_only, 4),
+                     "algorithmic_bytes": stack_bytes, "traffic": None,
+                     "note": "a 10 MB plane: every kernel of this configuration is launch- and latency-bound, the step is 14 launches and 3 host joins (the correlation peaks)"},
+        "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes": step_bytes},
+        "cpu_baseline": cpu,
+    }
+
+
+def config_c3(args, torch, ab, synth, pyoracle, ctx):
+    import numpy as np
+    from bench import rigid_transforms
+    n, rows, cols = 16, 13759, 12451
+    P = rows * cols
+    cy, cx, cf = synth.star_catalog(rows, cols, int(120.0 * P / 1e6), seed=21)
+    cf = cf * 25.0
+    T = rigid_transforms(n, rows, cols)
+    raw = []
+    for k in range(n):
+        a_, b_, tx_, c_, d_, ty_ = T[k]
+        truth = torch.full((rows, cols), 200.0, device="cuda") + synth.render_stars(rows, cols, (c_ * cx + d_ * cy + ty_, a_ * cx + b_ * cy + tx_, cf), device="cuda")
+        raw.append(synth.make_frame(rows, cols, k, device="cuda", truth=truth, border=0))
+    del truth
+    warped = [raw[0]] + [torch.empty_like(raw[0]) for _ in range(1, n)]
+    stacked = torch.empty((rows, cols), device="cuda")
+    toned = torch.empty_like(stacked)
+    lut = ctx.spline_lut_from_points([(0.0, 0.0), (0.25, 0.4), (0.6, 0.8), (1.0, 1.0)])
+    # SHO palette: S -> red, H -> green (with a little red), O -> blue; the stacked frame stands for H, two registered frames for S and O
+    weights = [(0, 1.0, 0.0, 0.0), (1, 0.3, 1.0, 0.0), (2, 0.0, 0.1, 1.0)]
+    norm = torch.empty_like(stacked)
+    state = {}
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps + args.warmup)]
+    it = [0]
+
+    def step():
+        e = ev[it[0]]
+        it[0] += 1
+        e[0].record()
+        state["est"] = ctx.align_pairs_affine(raw[0], raw[1:], warped[1:], num_threads=8)
+        e[1].record()
+        ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
+        e[2].record()
+        torch.div(stacked, 65535.0, out=norm)        # the [0, 1] plane a tone curve takes (the app normalises on load)
+        ctx.apply_curve(norm, lut, out=toned)
+        e[3].record()
+        state["rgb"] = ctx.blend_channels([warped[1], toned, warped[2]], weights, rows, cols)
+        e[4].record()
+
+    sec = _time_steps(torch, step, args.steps, args.warmup)
+    stages = {k: 0.0 for k in ("register_15_frames_estimate_and_warp", "stack_16", "tone_curve", "sho_blend")}
+    for e in ev[args.warmup:]:
+        for name, a, b in (("register_15_frames_estimate_and_warp", 0, 1), ("stack_16", 1, 2), ("tone_curve", 2, 3), ("sho_blend", 3, 4)):
+            stages[name] += e[a].elapsed_time(e[b]) / args.steps
+    kern_ms = ctx.stack_last_kernel_ms()
+    stack_bytes = 4 * n * P + 4 * P
+    step_bytes = 8 * P * (n - 1) + stack_bytes + 12 * P + (12 * P + 12 * P)   # warps + stack + (div, curve) + blend (3 in, 3 out)
+    est = state["est"]
+    errs = []
+    for k, r in enumerate(est, start=1):
+        t, g = r.transform, T[k]
+        for (x, y) in ((0.0, 0.0), (cols - 1.0, rows - 1.0), ((cols - 1) / 2.0, (rows - 1) / 2.0)):
+            errs.append(math.hypot((t[0] - g[0]) * x + (t[1] - g[1]) * y + (t[2] - g[2]), (t[3] - g[3]) * x + (t[4] - g[4]) * y + (t[5] - g[5])))
+    cpu = None
+    if not args.no_cpu_baseline:
+        threads = pyoracle.max_threads()
+        rows_s = 16 * threads if 16 * threads < rows else rows
+        crop = [w[:rows_s].cpu().numpy() for w in warped]
+        t0 = time.perf_counter()
+        img, _ = pyoracle.stack_images(crop, 3.0, 3.0, 5, order=pyoracle.ORDER_SELECT)
+        tn = pyoracle.apply_curve((img / np.float32(65535.0)).astype(np.float32), lut)
+        pyoracle.blend_channels([crop[1], tn, crop[2]], weights, rows_s, cols)
+        dt = time.perf_counter() - t0
+        got = stacked[:rows_s].cpu().numpy()
+        ref_h, tgt_h = raw[0].cpu().numpy(), raw[1].cpu().numpy()
+        t1 = time.perf_counter()
+        want = pyoracle.align_channel_affine(ref_h, tgt_h, num_threads=8)
+        pyoracle.warp_image(tgt_h, want.transform, rows, cols)
+        t_reg = time.perf_counter() - t1
+        t_full = dt * rows / rows_s + t_reg * (n - 1)
+        cpu = {"value": round(n * P / 1e6 / t_full, 2), "unit": "MPix/s", "cores": threads, "kind": "port",
+               "sample": f"oracle/liboracle.so: kappa-sigma stack + tone curve + blend on a {n}x{rows_s}x{cols} crop ({dt:.1f} s, scaled to {rows} rows) + "
+                         f"align_channel_affine + warp_image of one {rows}x{cols} pair ({t_reg:.1f} s, scaled to {n - 1})",
+               "parity_vs_gpu": {"stack_bit_mismatches_on_crop": int((~((got == img) | (np.isnan(got) & np.isnan(img)))).sum()),
+                                 "registration_frame1_max_abs_coeff_diff": float(max(abs(a - b) for a, b in zip(est[0].transform, want.transform)))}}
+    return {
+        "metric": "MPix/s star-align + sigma-clipped stack + tone curve + SHO compose, 16x13759x12451 f32 (BASELINE configs[2])",
+        "value": round(n * P / 1e6 / sec, 1), "ms_per_step": round(sec * 1e3, 3),
+        "config": {"workload": f"C3: {n}x{rows}x{cols} f32 synthetic NIRCam-shape frames: 15 x align_pair(Affine) + kappa-sigma stack (3/3/5) + apply_curve + "
+                               "blend_channels (SHO matrix)", "stage_ms": {k: round(v, 3) for k, v in stages.items()},
+                   "registration": {"methods": sorted(set(r.method for r in est)), "max_err_px_vs_generating_transform": round(max(errs), 4)},
+                   "reference_published": "technical_document.tex:611-619 quotes channel blend / affine / masked stretch on the authors' machine; no figure for this shape"},
+        "roofline": {"bound": "hbm", "kernel": "stack_sigma_clip_kernel<16> (fast pass + general pass)", "achieved": round(stack_bytes / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(stack_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(kern_ms, 4), "algorithmic_bytes": stack_bytes,
+                     "traffic": None},
+        "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes": step_bytes},
+        "cpu_baseline": cpu,
+    }
+
+
+def config_c5(args, torch, ab, synth, pyoracle, ctx):
+    import numpy as np
+    rows = cols = 8192
+    P = rows * cols
+    y, x, flux = synth.star_catalog(rows, cols, 20000, seed=5)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    planes = []
+    for gain in (1.0, 0.8, 1.25):
+        stars = synth.render_stars(rows, cols, (y, x, flux * 6.0e-4 * gain), device="cuda")
+        planes.append((0.02 + stars + 0.002 * torch.randn((rows, cols), device="cuda", generator=g)).clamp_(1e-5, None))
+    red, green, blue = planes
+    state = {}
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps + args.warmup)]
+    it = [0]
+
+    def step():
+        e = ev[it[0]]
+        it[0] += 1
+        e[0].record()
+        rgb = ctx.masked_stretch_rgb_shared(red, green, blue)
+        e[1].record()
+        sr, sg, sb = rgb[0].image, rgb[1].image, rgb[2].image
+        ctx.apply_scnr_inplace(sr, sg, sb, "average", 1.0, True)
+        e[2].record()
+        state["spcc"] = ctx.spcc_calibrate_rgb(red, green, blue, 0.3)
+        e[3].record()
+        state["rgb"] = rgb
+
+    sec = _time_steps(torch, step, args.steps, args.warmup)
+    stages = {"masked_stretch_rgb_shared": 0.0, "scnr": 0.0, "spcc": 0.0}
+    for e in ev[args.warmup:]:
+        for name, a, b in (("masked_stretch_rgb_shared", 0, 1), ("scnr", 1, 2), ("spcc", 2, 3)):
+            stages[name] += e[a].elapsed_time(e[b]) / args.steps
+    a_, b_, c_ = (p.clone() for p in planes)
+    scnr_ms = _time_kernel(torch, lambda: ctx.apply_scnr_inplace(a_, b_, c_, "average", 1.0, True))
+    scnr_bytes = 24 * P   # three planes read, three written (preserve_luminance rescales all of them)
+    iters = [r.iterations_run for r in state["rgb"][:3]]
+    # masked stretch per channel: stats (16P) + normalise (8P) + per iteration { masked median = 2 histogram passes over image + mask
+    # (16P), MTF blend (12P) } + luminance and mask once (16P + 4P); SCNR 24P; SPCC: luminance + detection (~3 passes) + photometry
+    step_bytes = sum(24 * P + it_ * 28 * P for it_ in iters) + 20 * P + scnr_bytes + 24 * P
+    cpu = None
+    if not args.no_cpu_baseline:
+        rs = 2048   # a 2048 x 2048 corner: the oracle's masked stretch is iterative and serial in parts
+        hr, hg, hb = (p[:rs, :rs].contiguous().cpu().numpy() for p in planes)
+        t0 = time.perf_counter()
+        ref = pyoracle.masked_stretch_rgb_shared(hr, hg, hb)
+        sr, sg, sb = pyoracle.apply_scnr(ref[0].image, ref[1].image, ref[2].image, "average", 1.0, True)
+        sp = pyoracle.spcc_calibrate_rgb(hr, hg, hb, 0.3)
+        dt = time.perf_counter() - t0
+        got = ctx.masked_stretch_rgb_shared(*(p[:rs, :rs].contiguous() for p in planes))
+        worst = max(float(np.max(np.abs(got[i].image.cpu().numpy() - ref[i].image))) for i in range(3))
+        cpu = {"value": round(3 * P / 1e6 / (dt * (P / (rs * rs))), 2), "unit": "MPix/s", "cores": pyoracle.max_threads(), "kind": "port",
+               "sample": f"oracle/liboracle.so: masked_stretch_rgb_shared + SCNR + SPCC on a 3x{rs}x{rs} corner ({dt:.1f} s, scaled by area to 3x{rows}x{cols})",
+               "parity_vs_gpu": {"masked_stretch_max_abs_diff_on_corner": worst, "spcc_factors_oracle": [sp.r_factor, sp.g_factor, sp.b_factor]}}
+    sp = state["spcc"]
+    return {
+        "metric": "MPix/s masked stretch + SCNR + SPCC, 3x8192x8192 f32 (BASELINE configs[4])", "value": round(3 * P / 1e6 / sec, 1), "ms_per_step": round(sec * 1e3, 3),
+        "config": {"workload": f"C5: 3x{rows}x{cols} f32 synthetic narrowband planes (20 000 stars): masked_stretch_rgb_shared (10 iterations max, star mask from "
+                               "the luminance) + apply_scnr_inplace (average neutral, preserve luminance) + spcc_calibrate_rgb",
+                   "stage_ms": {k: round(v, 3) for k, v in stages.items()}, "masked_stretch_iterations": iters,
+                   "spcc": {"r": sp.r_factor, "g": sp.g_factor, "b": sp.b_factor, "stars_matched": sp.stars_matched},
+                   "reference_published": "technical_document.tex:611-619: masked stretch / SCNR rows of the authors' CPU / WebGPU paths; other hardware, other sizes"},
+        "roofline": {"bound": "hbm", "kernel": "scnr_kernel (the streaming kernel of the configuration: 3 planes in, 3 out)", "achieved": round(scnr_bytes / (scnr_ms * 1e-3) / 1e9, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(scnr_bytes / (scnr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_kernel_ms": round(scnr_ms, 4),
+                     "algorithmic_bytes": scnr_bytes, "traffic": None},
+        "roofline_step": {"bound": "hbm", "achieved": round(step_bytes / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_bytes / sec / 1e9 / HBM_PEAK_GBS, 4),
+                          "algorithmic_bytes": step_bytes, "note": "the masked median of each iteration is a select (histogram passes + a host join), not a stream"},
+        "cpu_baseline": cpu,
+    }
+
+
+def run(args):
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import astroburst_amd as ab
+    from astroburst_amd import synth
+    from oracle import pyoracle
+    assert args.gpus == 1, "--config runs on one GPU"
+    torch.cuda.set_device(0)
+    ctx = ab.Context(0)
+    ctx.use_torch_stream()
+    name = ctx.device_info()[0]
+    fn = {"C1": config_c1, "C3": config_c3, "C5": config_c5}[args.config]
+    out = fn(args, torch, ab, synth, pyoracle, ctx)
+    line = {"metric": out["metric"], "value": out["value"], "unit": "MPix/s (input pixels)", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": out["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    out["config"]["device"] = name
+    line.update({k: out[k] for k in ("config", "roofline", "roofline_step", "cpu_baseline")})
+    os.write(json_fd, (json.dumps(line) + "\n").encode())
