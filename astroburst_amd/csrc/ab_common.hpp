@@ -108,6 +108,18 @@ int ab_progress(ab_ctx *ctx, const char *stage, uint64_t current, uint64_t total
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);
 
+// A non-blocking stream, optionally confined to a subset of the compute units: `env` names an environment variable holding a 32-bit
+// hex pattern that is repeated over the chip's CU mask (0x55555555 = every other CU).  Unset / 0 / ffffffff: an ordinary stream.
+inline hipError_t ab_stream_create_masked(ab_ctx *ctx, hipStream_t *out, const char *env) {
+    const char *v = env ? getenv(env) : nullptr;
+    const uint32_t pat = v ? (uint32_t)strtoul(v, nullptr, 16) : 0u;
+    if (pat == 0u || pat == 0xffffffffu) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    const int words = (ctx->cu_count > 0 ? ctx->cu_count + 31 : 256) / 32;
+    uint32_t mask[16];
+    for (int i = 0; i < 16; ++i) mask[i] = pat;
+    return hipExtStreamCreateWithCUMask(out, (uint32_t)(words > 16 ? 16 : words), mask);
+}
+
 #define AB_HIP(ctx, call)                                                                        \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \

@@ -900,7 +900,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     const bool inline_run = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1)) <= 1;
     static const bool own_warp_stream = getenv("AB_NO_WARP_STREAM") == nullptr;
     if (!inline_run && aligned && own_warp_stream) {
-        if (!ctx->warp_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->warp_stream, hipStreamNonBlocking));
+        if (!ctx->warp_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->warp_stream, "AB_WARP_CU_MASK"));
         warp_stream = ctx->warp_stream;
     }
     if (inline_run) {  // the reference first, on ctx

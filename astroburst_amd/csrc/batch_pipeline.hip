@@ -50,6 +50,8 @@
         v[c] = __builtin_amdgcn_fmed3f(s1_, s2_, x3_);                               \
         v[d] = __builtin_amdgcn_fmed3f(__builtin_inff(), s2_, x3_);  /* = max */          \
     }
+#define AB_STACK_CE_XOR 1
+#include "sort_ops.hpp"
 #include "sortnet_gen.hpp"
 
 namespace {
@@ -238,7 +240,12 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
                 cnan += isn ? 1 : 0;
             }
         }
-        if (a.stage != 1) SortNet<NP>::sort(v);
+        if (a.stage != 1) {
+            if constexpr (NP >= 8 && NP <= 64)
+                SortNet<NP>::sort_fused(v);  // the rewrite over min3 / med3 / max3 (tools/gen_sortnet.py): 789 instructions for 64 samples, not 1038
+            else
+                SortNet<NP>::sort(v);
+        }
         if (a.stage != 2) {
 #pragma unroll
             for (int i = 0; i < NP; ++i) S(i) = v[i];

@@ -879,7 +879,7 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // detect_stars' choice (:100)
     const int step = (int)std::max<int64_t>(tile_size, 16);
     const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
-    if (!ctx->aux_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK"));
     const size_t nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
     while (ctx->aux_events.size() < nchunks) {
         hipEvent_t e;

@@ -399,7 +399,7 @@ def main():
             upload_all()
         torch.cuda.synchronize()
         up_ms = (time.perf_counter() - t_u) / 3 * 1e3
-        same = all(torch.equal(hw[k], warped[k]) for k in (1, N // 2, N - 1))
+        same = all(bool(((hw[k] == warped[k]) | (hw[k].isnan() & warped[k].isnan())).all()) for k in (1, N // 2, N - 1))   # (NaN patches warp to NaN)
         host_info = {"host_resident_ms_per_step": round(host_ms, 3), "host_resident_mpix_s": round(N * P / 1e6 / (host_ms * 1e-3), 1),
                      "pcie_upload_only_ms": round(up_ms, 3), "pcie_GBs": round(4 * N * P / (up_ms * 1e-3) / 1e9, 1),
                      "over_pcie_bound": round(host_ms / up_ms, 3), "registered_frames_equal_device_resident_run": bool(same)}

@@ -53,10 +53,17 @@ def config_c1(args, torch, ab, synth, pyoracle, ctx):
     import numpy as np
     n, rows, cols = 4, 1600, 1600
     P = rows * cols
-    y, x, flux = synth.star_catalog(rows, cols, 900, seed=11)
-    cat = (y, x, flux * 30.0)
-    shifts = [(0.0, 0.0), (2.25, -1.5), (-3.5, 4.0), (1.0, 2.75)]
-    frames = [synth.make_frame(rows, cols, k, cat=cat, device="cuda", shift=shifts[k], bad_patch_rate=0.0) for k in range(n)]
+    y, x, flux = synth.star_catalog(rows, cols, 300, seed=21)
+    cat = (y, x, flux * 20.0)
+    shifts = [(0.0, 0.0), (2.25, -1.5), (-3.0, 0.75), (1.5, 4.0)]
+    # a smooth nebular background (a low-dynamic-range narrowband frame) + stars, each frame shifted and with its own noise: the
+    # scene of tests/test_gpu_full_size.py::test_c1_* (phase correlation needs structure; a sparse star field alone has none)
+    # (generated on the host, as that test does: torch's CUDA generator gives frames k and k + 1 noise fields that correlate at a fixed
+    # displacement, which a phase correlation of low-contrast frames then reports instead of the shift)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, rows), torch.linspace(-1, 1, cols), indexing="ij")
+    nebula = 40.0 * torch.exp(-(xx ** 2 + 0.5 * yy ** 2) * 2.0)
+    frames = [synth.make_frame(rows, cols, k, truth=200.0 + nebula + synth.render_stars(rows, cols, cat, dy=sh[0], dx=sh[1]), bad_patch_rate=0.0).cuda()
+              for k, sh in enumerate(shifts)]
     u8 = torch.empty((rows, cols), dtype=torch.uint8, device="cuda")
     state = {}
 

@@ -233,7 +233,7 @@ def test_c3_sixteen_distinct_frames_clip_at_size(tctx, oracle):
     assert rej == rej2 and torch.equal(out, out2)                       # order of the frames cannot matter
     del out2, perm
     assert torch.isfinite(out).all()
-    assert abs(float(out.mean()) - 900.0) < 0.05                        # 54 000 hits of ~22 000 ADU would move the mean by 0.4 if averaged in
+    assert abs(float(out.mean()) - 900.0) < 0.15                        # the hits would move the mean by 0.43 if averaged in (clipping itself: +0.07)
     assert float(out.max()) < 1000.0                                    # no pixel keeps a cosmic ray (900 + 25 x 900 / 16 = 2300 if one survived)
     assert 3.4 < float(out[100:-100].std()) < 4.2                       # sigma / sqrt(16) = 3.75
     assert 0.05 * r * c < rej < 1.2 * r * c
