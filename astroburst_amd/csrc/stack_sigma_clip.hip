@@ -104,7 +104,10 @@ constexpr int kMaxStrided = 64;  // ragged row strides only exist for the <= 64-
 constexpr int kRejSlots = AB_REJ_SLOTS;  // rejection counters (see the kernel epilogue)
 constexpr int kDeferSlots = 2048;        // deferred-pixel lists (same reason: no hot atomic address)
 constexpr unsigned int kGenWaves = 2;    // general pass: single-wave workgroups per deferred-pixel list (a list holds ~65 pixels on the bench stack, 109 at most)
-constexpr int kDeferChunks = 2;          // chunks of 4 samples the fast pass may examine at either end before it defers a pixel (3: 1.165 ms against 1.116, every wave pays for the larger code)
+#ifndef AB_STACK_DEFER_CHUNKS
+#define AB_STACK_DEFER_CHUNKS 2
+#endif
+constexpr int kDeferChunks = AB_STACK_DEFER_CHUNKS;          // chunks of 4 samples the fast pass may examine at either end before it defers a pixel (3: 1.165 ms against 1.116, every wave pays for the larger code)
 enum { kPlain = 0, kFastPass = 1, kGeneralPass = 2 };
 enum { kInNative = 0, kInF32BE = 1, kInI16BE = 2 };  // sample encodings the gather understands
 constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
@@ -443,6 +446,45 @@ __device__ __forceinline__ void clip_ends(const float (&v)[NP], bool go, int a, 
     ch_out = ch;
 }
 
+// Iteration 0 of the fast pass when every lane of the wave holds all NP samples (see clip_fast): the outermost kDeferChunks chunks of
+// either end, no interval tests.  Same results as clip_ends<NP, false, true, false> with a = 0, b = NP - 1, go = true.
+template <int NP>
+__device__ __forceinline__ void clip_first_full(const float (&v)[NP], float center, float lo, float hi, int &cl_out, int &ch_out, bool *defer) {
+    int cl = 0, ch = 0;
+    bool found = false;
+#pragma unroll
+    for (int c = 0; c < kDeferChunks; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (v[4 * c + j] - center) >= lo;
+            found = found || ok;
+            cl += ok ? 0 : 1;
+        }
+        if (c == kDeferChunks - 1) {
+            *defer = *defer || !found;
+            break;
+        }
+        if (!__any(!found)) break;
+    }
+    found = false;
+#pragma unroll
+    for (int c = 0; c < kDeferChunks; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (v[NP - 1 - (4 * c + j)] - center) <= hi;
+            found = found || ok;
+            ch += ok ? 0 : 1;
+        }
+        if (c == kDeferChunks - 1) {
+            *defer = *defer || !found;
+            break;
+        }
+        if (!__any(!found)) break;
+    }
+    cl_out = cl;
+    ch_out = ch;
+}
+
 // x / n for a sample count n = 1 .. 64 without the IEEE division sequence (v_div_scale x 2, v_rcp_f64 = 4 issue slots, 5 FMAs, v_div_fmas,
 // v_div_fixup: ~14 slots; an iteration divides twice and the result once more).  With r = RN(1 / n):
 //     q0 = RN(x r),   rem = x - q0 n  (one FMA; exact: q0 is within 2 ulp of x / n, so rem is a multiple of ulp(q0) / 2 below 2^8 ulp),
@@ -480,6 +522,24 @@ __device__ __forceinline__ double div_by_count(double x, double nn, int n, doubl
     } else {
         return x / nn;
     }
+}
+
+// sqrt(v) for the iteration's sigma, which only its f32 rounding is used of.  v_rsq_f64 is good to ~2^-27; g = v y, one residual
+// step g + (v - g^2) y / 2 brings it to ~2^-52 -- a few ulp(f64) short of the correctly rounded root, which the compiler's 15-
+// instruction expansion (scaling, three refinement pairs, class fix-up) delivers.  That is the same order as the fast engine's
+// running-sum variance itself (a few ulp(f64) from the two-pass value, see above), 28 binary orders below the f32 the result is
+// rounded to: the f32 sigma differs from the oracle's with probability ~1e-8 per pixel, as before.  No scaling: a variance of f32
+// samples lies between 2^-298 and 2^+262 or is 0 (-> 0: the caller's max with 1e-10 takes over).  (AB_STACK_IEEE_SQRT: the library call.)
+__device__ __forceinline__ double sqrt_for_sigma(double v) {
+#ifdef AB_STACK_IEEE_SQRT
+    return sqrt(v);
+#else
+    const double y = __builtin_amdgcn_rsq(v);
+    const double g = v * y;
+    const double e = __builtin_fma(-g, g, v);
+    const double r = __builtin_fma(e, 0.5 * y, g);
+    return v > 0.0 ? r : 0.0;
+#endif
 }
 
 // Per-lane state of the fast engine between the median/MAD clip and the iterations on running sums.
@@ -575,7 +635,7 @@ __device__ __forceinline__ ClipResult clip_fast_tail(float (&v)[NP], int n, floa
         const int n1 = len > 1 ? len - 1 : 1;
         const double variance = div_by_count<NP>(ss, (double)n1, n1, rtab);  // ss / max(n - 1, 1)
         float center = (float)mean;
-        float sigma = (float)fmax(sqrt(variance), 1e-10);
+        float sigma = (float)fmax(sqrt_for_sigma(variance), 1e-10);
         if constexpr (STAGE == 6) {  // ablation: iteration 1's mean / sigma only
             ClipResult r;
             r.value = center + sigma;
@@ -656,6 +716,13 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
         const float lo = -sigma_low * sigma, hi = sigma_high * sigma;
         int cl, ch;
         double unused_e = 0.0, unused_q = 0.0;
+#ifndef AB_STACK_NO_FULL0
+        // The common case of the fast pass -- every lane holds all NP samples -- needs none of the interval tests: go is true,
+        // every examined position lies inside [0, NP - 1], and the rejected samples of a sorted end are a prefix of it.
+        if (DEFER && NP >= 8 && __all(n == NP)) {
+            clip_first_full<NP>(v, med, lo, hi, cl, ch, &defer);
+        } else
+#endif
         clip_ends<NP, false, DEFER, SKIP>(v, go, s.a, s.b, med, lo, hi, 0.0, 0.0f, cl, ch, unused_e, unused_q, &defer, skip_hi);
         const int removed = (cl + ch > s.len) ? s.len : (cl + ch);
         if (go) {

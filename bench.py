@@ -363,7 +363,17 @@ def main():
         up = [torch.empty_like(raw[0]) for _ in range(N)]
         hw = [up[0]] + [torch.empty_like(raw[0]) for _ in range(1, N)]
         copy_stream = torch.cuda.Stream()
-        chunks = [list(range(c, min(c + 16, N))) for c in range(0, N, 16)]
+        # frames per upload / registration chunk: LARGE chunks first (a registration call has ~2.5 ms of fixed cost -- the reference
+        # frame's detection, the tile pipeline's first launch -- which hides under the uploads still to come), SMALL ones last
+        # (what is registered after the last byte has landed is exposed).  AB_HOST_CHUNKS overrides (developer knob).
+        sched = [int(x) for x in os.environ.get("AB_HOST_CHUNKS", "40,16,8").split(",")]
+        chunks, c0 = [], 0
+        for w in sched:
+            if c0 < N:
+                chunks.append(list(range(c0, min(c0 + w, N))))
+                c0 += w
+        if c0 < N:
+            chunks.append(list(range(c0, N)))
         torch.cuda.synchronize()
 
         def upload_all():
