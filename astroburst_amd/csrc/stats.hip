@@ -33,6 +33,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <mutex>
 
 namespace {
 
@@ -81,6 +82,16 @@ struct StatsDev {
     StfTx tx;
 };
 
+// the resident kernel's part of the workspace (stats_resident.hpp)
+constexpr int kResMaxGrid = 512;   // workgroups (one per CU)
+constexpr int kResLevels = 6;      // grid-wide histogram reductions per call
+constexpr int kSlabRow = 512;      // u32 per workgroup and level: histogram A [0, 256), histogram B / a count [256, 512)
+struct ResWs {
+    unsigned int *slab;       // kResLevels x kResMaxGrid x kSlabRow: every workgroup's 256-bin counts, written whole each call
+    ScanPartial *p1, *p2, *p3;  // per-workgroup partials (range / sum and count / count below the MAD region), 128 bytes apart
+    unsigned int *bar;        // kResMaxGrid arrival flags, the abort flag, timing stamps (4 KiB, cleared per call)
+};
+
 // workspace carved from AB_WS_STATS
 struct Ws {
     StatsDev *st;
@@ -88,6 +99,7 @@ struct Ws {
     ScanPartial *partials;   // kMaxPartials
     unsigned int *sel;       // 2 x 2048
     unsigned int *gsum;      // 2 x 1024 group totals (64 bins each) of h0 / h1
+    ResWs res;
 };
 
 __device__ __forceinline__ double shfl_xor_f64(double v, int off) { return __shfl_xor(v, off, 64); }
@@ -173,15 +185,17 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const float *__restric
 }
 
 // one workgroup: fixed-shape reduction of the per-workgroup partials (thread t folds partials t, t + 1024, ...)
+// (stride: in units of ScanPartial; the resident kernel keeps every workgroup's partial on a cache line of its own)
 __device__ __forceinline__ void reduce_partials(const ScanPartial *p, int np, double *mn, double *mx, double *sum,
-                                                unsigned long long *cnt) {
+                                                unsigned long long *cnt, int stride = 1) {
     double a = DBL_MAX, b = -DBL_MAX, s = 0.0;
     unsigned long long c = 0;
     for (int i = threadIdx.x; i < np; i += blockDim.x) {
-        a = fmin(a, p[i].mn);
-        b = fmax(b, p[i].mx);
-        s += p[i].sum;
-        c += p[i].cnt;
+        const ScanPartial q = p[(size_t)i * stride];
+        a = fmin(a, q.mn);
+        b = fmax(b, q.mx);
+        s += q.sum;
+        c += q.cnt;
     }
     __shared__ ScanPartial tot;
     block_reduce_scan(a, b, s, c, &tot);
@@ -382,14 +396,16 @@ __device__ __forceinline__ RankHit block_find_rank(const unsigned long long *his
 }
 
 // resolve_rank_in_hist (stats.rs:333-353)
-__device__ __forceinline__ double resolve_rank(const unsigned long long *hist, const unsigned int *gsum, unsigned long long rank, double region_lo,
-                                               double sub_bw) {
-    if (rank == 0) return region_lo;  // uniform
-    const RankHit h = block_find_rank(hist, gsum, rank);
+__device__ __forceinline__ double resolve_from_hit(const RankHit &h, unsigned long long rank, double region_lo, double sub_bw) {
     if (!h.found) return region_lo + (double)kHistBins * sub_bw;
     const unsigned long long overshoot = h.cum - rank;
     const double frac = h.count > 0 ? 1.0 - ((double)overshoot / (double)h.count) : 0.5;
     return region_lo + ((double)h.bin + frac) * sub_bw;
+}
+__device__ __forceinline__ double resolve_rank(const unsigned long long *hist, const unsigned int *gsum, unsigned long long rank, double region_lo,
+                                               double sub_bw) {
+    if (rank == 0) return region_lo;  // uniform
+    return resolve_from_hit(block_find_rank(hist, gsum, rank), rank, region_lo, sub_bw);
 }
 
 __device__ __forceinline__ void write_zero_result(StatsDev *st) {
@@ -398,8 +414,10 @@ __device__ __forceinline__ void write_zero_result(StatsDev *st) {
     st->result.valid_count = 0;
 }
 
-// before the VALUE pass: the histogram's origin and scale from the (all-reduced) range
-__global__ void book_range_kernel(StatsDev *st) {
+// The bookkeeping bodies below are shared by the one-workgroup kernels of the chain and by the resident kernel
+// (stats_resident.hpp), where every workgroup runs them on its own LDS copy of the state: `st` is a generic pointer.
+// before the VALUE pass: the histogram's origin and scale from the (all-reduced) range; one thread
+__device__ void book_range_body(StatsDev *st) {
     const double gmin = -st->negmin_max[0], gmax = st->negmin_max[1];
     st->empty = 0;
     st->two = 0;
@@ -415,23 +433,15 @@ __global__ void book_range_kernel(StatsDev *st) {
     st->result.min = gmin;
     st->result.max = gmax;
 }
+__global__ void book_range_kernel(StatsDev *st) { book_range_body(st); }
 
 // after the VALUE pass (stats.rs:94-117): mean, the median's coarse bin, parameters of the DEV pass
-__global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, const unsigned long long *H, const unsigned int *G) {
-    if (st->empty) return;
-    const unsigned long long total = H[0];
-    if (total == 0) {  // stats.rs:95-97
-        __syncthreads();
-        if (threadIdx.x == 0) write_zero_result(st);
-        return;
-    }
-    const unsigned long long half = f64_to_u64_sat(ceil((double)total * 0.5));  // :100 (== find_percentile_bin's target)
-    const RankHit h = block_find_rank(H + 1, G, half);
-    if (threadIdx.x != 0) return;
+// one thread: `h` = where the value histogram's cumulative count reaches `half`; last_count = the count of its last bin
+__device__ void book_value_apply(StatsDev *st, unsigned long long total, unsigned long long half, const RankHit &h, unsigned long long last_count) {
     const double gmin = st->gmin, bw = st->bin_width, range = st->range;
     const uint32_t median_bin = h.found ? h.bin : (uint32_t)(kHistBins - 1);  // find_percentile_bin (:302-311)
     // count_before_median = sum of the bins below the median bin (:103)
-    const unsigned long long before = h.found ? h.cum - h.count : total - H[1 + kHistBins - 1];
+    const unsigned long long before = h.found ? h.cum - h.count : total - last_count;
     double coarse;  // interpolate_percentile (:313-331)
     if (h.found) {
         const unsigned long long overshoot = h.cum - half;
@@ -453,15 +463,28 @@ __global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, co
     st->result.mean = st->sum / (double)total;  // :98
     st->result.valid_count = total;
 }
+__device__ __forceinline__ unsigned long long half_of(unsigned long long total) {
+    return f64_to_u64_sat(ceil((double)total * 0.5));  // :100 (== find_percentile_bin's target)
+}
+// (a workgroup of kBookBlock threads; `total` = the valid count, `hist` = the value histogram, G its group totals)
+__device__ void book_value_body(StatsDev *st, unsigned long long total, const unsigned long long *hist, const unsigned int *G) {
+    if (st->empty) return;
+    if (total == 0) {  // stats.rs:95-97
+        __syncthreads();
+        if (threadIdx.x == 0) write_zero_result(st);
+        return;
+    }
+    const unsigned long long half = half_of(total);
+    const RankHit h = block_find_rank(hist, G, half);
+    if (threadIdx.x == 0) book_value_apply(st, total, half, h, hist[kHistBins - 1]);
+}
+__global__ __launch_bounds__(kBookBlock) void book_value_kernel(StatsDev *st, const unsigned long long *H, const unsigned int *G) {
+    book_value_body(st, H[0], H + 1, G);
+}
 
 // after the DEV pass (stats.rs:148-164): the exact median from the refined bin, the MAD's coarse region
-__global__ __launch_bounds__(kBookBlock) void book_dev_kernel(StatsDev *st, const unsigned long long *H, const unsigned int *G) {
-    if (st->empty) return;
-    const unsigned long long half = st->half_count, before = st->count_before_median;
-    const unsigned long long rank_in_bin = half > before ? half - before : 0;  // saturating_sub (:148)
-    const double median = resolve_rank(H + 1 + kHistBins, G + 1024, rank_in_bin, st->median_bin_lo, st->refine_range / (double)kHistBins);
-    const RankHit h = block_find_rank(H + 1, G, half);  // find_percentile_bin(dev_hist, total, 0.5) (:154)
-    if (threadIdx.x != 0) return;
+// one thread: the refined median and `h` = where the deviation histogram's cumulative count reaches half
+__device__ void book_dev_apply(StatsDev *st, double median, const RankHit &h) {
     const uint32_t mad_bin = h.found ? h.bin : (uint32_t)(kHistBins - 1);
     const uint32_t expand_lo = mad_bin > 0 ? mad_bin - 1 : 0;                                         // :155
     const uint32_t expand_hi = (mad_bin + 2 < (uint32_t)kHistBins) ? mad_bin + 2 : (uint32_t)kHistBins;  // :156
@@ -474,6 +497,18 @@ __global__ __launch_bounds__(kBookBlock) void book_dev_kernel(StatsDev *st, cons
     st->mad_lo_f32 = (float)lo;  // :163-164
     st->mad_hi_f32 = (float)hi;
     st->result.median = median;
+}
+// (dev = the deviation histogram, refine = the 65 536 sub-bins of the median's bin; Gd / Gr their group totals)
+__device__ void book_dev_body(StatsDev *st, const unsigned long long *dev, const unsigned long long *refine, const unsigned int *Gd, const unsigned int *Gr) {
+    if (st->empty) return;
+    const unsigned long long half = st->half_count, before = st->count_before_median;
+    const unsigned long long rank_in_bin = half > before ? half - before : 0;  // saturating_sub (:148)
+    const double median = resolve_rank(refine, Gr, rank_in_bin, st->median_bin_lo, st->refine_range / (double)kHistBins);
+    const RankHit h = block_find_rank(dev, Gd, half);  // find_percentile_bin(dev_hist, total, 0.5) (:154)
+    if (threadIdx.x == 0) book_dev_apply(st, median, h);
+}
+__global__ __launch_bounds__(kBookBlock) void book_dev_kernel(StatsDev *st, const unsigned long long *H, const unsigned int *G) {
+    book_dev_body(st, H + 1, H + 1 + kHistBins, G, G + 1024);
 }
 
 __device__ __forceinline__ void finish_result(StatsDev *st, double mad, const ab_auto_stf_config cfg) {
@@ -621,6 +656,8 @@ __global__ void exact_end_kernel(StatsDev *st, ab_auto_stf_config cfg) {
     finish_result(st, (double)mad_f32, cfg);
 }
 
+#include "stats_resident.hpp"
+
 // ---------------------------------------------------------------------------------------------
 int grid_for(ab_ctx *ctx, int64_t n, int block, int per_cu) {
     int64_t want = (n + block - 1) / block;
@@ -629,10 +666,11 @@ int grid_for(ab_ctx *ctx, int64_t n, int block, int per_cu) {
 }
 
 int carve(ab_ctx *ctx, Ws *w) {
-    const size_t bytes = 1024 + (size_t)(1 + 2 * kHistBins) * sizeof(unsigned long long) + kMaxPartials * sizeof(ScanPartial) + 4096 * 4 + 2048 * 4;
     static_assert(sizeof(StatsDev) <= 1024, "StatsDev outgrew its slot");
+    constexpr size_t kChain = 1024 + (size_t)(1 + 2 * kHistBins) * sizeof(unsigned long long) + kMaxPartials * sizeof(ScanPartial) + 4096 * 4 + 2048 * 4;
+    constexpr size_t kRes = 256 + 4096 + 3 * kResMaxGrid * 128 + (size_t)kResLevels * kResMaxGrid * kSlabRow * 4;
     char *c = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_STATS, bytes, (void **)&c));
+    AB_TRY(ab_workspace(ctx, AB_WS_STATS, kChain + kRes, (void **)&c));
     w->st = (StatsDev *)c;
     c += 1024;
     w->H = (unsigned long long *)c;
@@ -642,6 +680,16 @@ int carve(ab_ctx *ctx, Ws *w) {
     w->sel = (unsigned int *)c;
     c += 4096 * sizeof(unsigned int);
     w->gsum = (unsigned int *)c;
+    c += 2048 * sizeof(unsigned int);
+    c = (char *)(((uintptr_t)c + 255) & ~(uintptr_t)255);  // (rows and flags on cache lines of their own)
+    w->res.bar = (unsigned int *)c;
+    c += 4096;
+    static_assert(sizeof(ScanPartial) == 32, "the partials are spaced 4 apart = one 128-byte line each");
+    w->res.p1 = (ScanPartial *)c;
+    w->res.p2 = w->res.p1 + 4 * kResMaxGrid;
+    w->res.p3 = w->res.p2 + 4 * kResMaxGrid;
+    c += 3 * kResMaxGrid * 128;
+    w->res.slab = (unsigned int *)c;
     return AB_OK;
 }
 
@@ -741,6 +789,73 @@ int enqueue_exact_path(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n,
     return AB_OK;
 }
 
+// The resident kernel (stats_resident.hpp) takes the histogram path of one unsharded, 16-byte aligned plane that one
+// workgroup per CU can hold; AB_STATS_CHAIN=1 keeps the chain (the GPU tests run both).
+bool resident_takes(ab_ctx *ctx, const float *data, int64_t n, const uint8_t *u8) {
+    const char *e = getenv("AB_STATS_CHAIN");
+    if (e && *e && *e != '0') return false;
+    const int64_t cus = ctx->cu_count;
+    return cus > 0 && n > 0 && (((uintptr_t)data) & 15) == 0 && (((uintptr_t)u8) & 3) == 0 &&
+           (n + kResTile - 1) / kResTile <= std::min<int64_t>(cus, kResMaxGrid);
+}
+
+int enqueue_resident(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int known, double kmin, double kmax, const ab_auto_stf_config &cfg,
+                     uint8_t *u8) {
+    AB_HIP(ctx, hipMemsetAsync(w.res.bar, 0, 4096, ctx->stream));
+    const unsigned grid = (unsigned)((n + kResTile - 1) / kResTile);
+    hipLaunchKernelGGL(stats_resident_kernel, dim3(grid), dim3(kResBlock), 0, ctx->stream, data, n, w.st, w.res, known, kmin, kmax, cfg, u8);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+// One resident kernel at a time per device: a workgroup needs a whole CU (16 waves x 128 registers), so two of them launched
+// together would each hold part of the chip and wait for the rest until the barrier times out.  A caller that finds the lock
+// taken uses the chain.
+std::mutex &resident_lock(int device) {
+    static std::mutex m[64];
+    return m[device & 63];
+}
+
+// `resident` (nullable): the caller will look at the abort flag after its synchronisation and can re-run the chain, so the
+// resident kernel may be used; it then also writes the stretched plane to `u8` (nullable).  *resident = whether it was.
+int stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, int64_t n_total, int use_known, double known_min, double known_max,
+                  const ab_auto_stf_config *stf_cfg, const ab_image_stats **result_dev, const void **tx_dev, const ab_stf_params **stf_dev,
+                  uint8_t *u8, bool *resident) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    Ws w;
+    AB_TRY(carve(ctx, &w));
+    const ab_auto_stf_config cfg = stf_cfg ? *stf_cfg : kDefaultStf;
+    if (resident) *resident = false;
+    if (n_total <= kExactLimit) {  // stats.rs:18-22,32-34
+        AB_TRY(enqueue_exact_path(ctx, comm, data, n, w, cfg));
+    } else {
+        const bool known = use_known && std::isfinite(known_min) && std::isfinite(known_max) && known_min < known_max;  // stats.rs:36-38
+        if (resident && !comm && resident_takes(ctx, data, n, u8) && resident_lock(ctx->device).try_lock()) {
+            *resident = true;  // (the caller unlocks after its synchronisation: ResidentGuard)
+            AB_TRY(enqueue_resident(ctx, data, n, w, known ? 1 : 0, known_min, known_max, cfg, u8));
+        } else {
+            if (known) {
+                hipLaunchKernelGGL(set_range_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st, known_min, known_max);
+            } else {
+                AB_TRY(enqueue_scan(ctx, comm, data, n, w, false));
+            }
+            AB_TRY(enqueue_hist_path(ctx, comm, data, n, w, cfg));
+        }
+    }
+    if (result_dev) *result_dev = &w.st->result;
+    if (tx_dev) *tx_dev = &w.st->tx;
+    if (stf_dev) *stf_dev = &w.st->stf;
+    return AB_OK;
+}
+
+struct ResidentGuard {  // releases the device's resident-kernel lock when the call that may have taken it returns
+    ab_ctx *ctx;
+    bool *held;
+    ~ResidentGuard() {
+        if (*held) resident_lock(ctx->device).unlock();
+    }
+};
+
 }  // namespace
 
 // The asynchronous form: enqueues compute_image_stats (+ auto_stf with `stf_cfg`, default config if null) of `data` on the
@@ -750,33 +865,33 @@ int enqueue_exact_path(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n,
 int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, int64_t n_total, int use_known, double known_min,
                      double known_max, const ab_auto_stf_config *stf_cfg, const ab_image_stats **result_dev, const void **tx_dev,
                      const ab_stf_params **stf_dev) {
-    AB_HIP(ctx, hipSetDevice(ctx->device));
-    Ws w;
-    AB_TRY(carve(ctx, &w));
-    const ab_auto_stf_config cfg = stf_cfg ? *stf_cfg : kDefaultStf;
-    if (n_total <= kExactLimit) {  // stats.rs:18-22,32-34
-        AB_TRY(enqueue_exact_path(ctx, comm, data, n, w, cfg));
-    } else {
-        const bool known = use_known && std::isfinite(known_min) && std::isfinite(known_max) && known_min < known_max;  // stats.rs:36-38
-        if (known) {
-            hipLaunchKernelGGL(set_range_kernel, dim3(1), dim3(1), 0, ctx->stream, w.st, known_min, known_max);
-        } else {
-            AB_TRY(enqueue_scan(ctx, comm, data, n, w, false));
-        }
-        AB_TRY(enqueue_hist_path(ctx, comm, data, n, w, cfg));
-    }
-    if (result_dev) *result_dev = &w.st->result;
-    if (tx_dev) *tx_dev = &w.st->tx;
-    if (stf_dev) *stf_dev = &w.st->stf;
-    return AB_OK;
+    return stats_enqueue(ctx, comm, data, n, n_total, use_known, known_min, known_max, stf_cfg, result_dev, tx_dev, stf_dev, nullptr, nullptr);
 }
 
-static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_stats *out, ab_stf_params *stf_out, ab_comm *comm = nullptr) {
+// *aborted (nullable): the resident kernel's abort flag, fetched with the result
+static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_stats *out, ab_stf_params *stf_out, ab_comm *comm = nullptr,
+                        bool *aborted = nullptr) {
     void *pin = nullptr;
-    AB_TRY(ab_pinned(ctx, sizeof(ab_image_stats) + sizeof(ab_stf_params), &pin));
+    constexpr size_t kFlagAt = (sizeof(ab_image_stats) + sizeof(ab_stf_params) + 7) & ~(size_t)7;
+    AB_TRY(ab_pinned(ctx, kFlagAt + 8, &pin));
+    if (aborted) {
+        Ws w;
+        AB_TRY(carve(ctx, &w));
+        AB_HIP(ctx, hipMemcpyAsync((char *)pin + kFlagAt, w.res.bar + kBarAbort, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    }
     static_assert(offsetof(StatsDev, stf) == offsetof(StatsDev, result) + sizeof(ab_image_stats), "result and stf are adjacent");
     AB_HIP(ctx, hipMemcpyAsync(pin, result_dev, sizeof(ab_image_stats) + sizeof(ab_stf_params), hipMemcpyDeviceToHost, ctx->stream));
     AB_TRY(ab_comm_stream_wait(ctx, comm));  // (a plain hipStreamSynchronize without a communicator)
+    if (aborted) *aborted = *(const unsigned int *)((const char *)pin + kFlagAt) != 0;
+    if (aborted && getenv("AB_STATS_TIMING")) {  // workgroup 0's phase stamps (s_memtime: shader clock cycles)
+        Ws w;
+        AB_TRY(carve(ctx, &w));
+        unsigned long long st[24];
+        AB_HIP(ctx, hipMemcpy(st, w.res.bar + kBarStamps, sizeof st, hipMemcpyDeviceToHost));
+        fprintf(stderr, "stats_resident phases (100 cycles):");
+        for (int i = 1; i < 23; ++i) fprintf(stderr, " %d:%.1f", i, st[i] > st[0] ? (double)(st[i] - st[0]) / 100.0 : -1.0);
+        fprintf(stderr, "\n");
+    }
     if (out) memcpy(out, pin, sizeof *out);
     if (stf_out) memcpy(stf_out, (char *)pin + sizeof(ab_image_stats), sizeof *stf_out);
     return AB_OK;
@@ -785,6 +900,12 @@ static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_
 int ab_stats_device(ab_ctx *ctx, const float *data, int64_t n, int use_known, double known_min, double known_max,
                     ab_image_stats *out) {
     const ab_image_stats *res = nullptr;
+    bool resident = false, aborted = false;
+    ResidentGuard guard{ctx, &resident};
+    AB_TRY(stats_enqueue(ctx, nullptr, data, n, n, use_known, known_min, known_max, nullptr, &res, nullptr, nullptr, nullptr, &resident));
+    AB_TRY(fetch_result(ctx, res, out, nullptr, nullptr, resident ? &aborted : nullptr));
+    if (!aborted) return AB_OK;
+    // a grid barrier of the resident kernel timed out (its workgroups were not all resident): the chain takes the plane
     AB_TRY(ab_stats_enqueue(ctx, nullptr, data, n, n, use_known, known_min, known_max, nullptr, &res, nullptr, nullptr));
     return fetch_result(ctx, res, out, nullptr);
 }
@@ -854,10 +975,19 @@ int ab_auto_stretch_preview(ab_ctx *ctx, ab_comm *comm, const ab_plane *img, int
     AB_TRY(ab_comm_agree(ctx, comm, local()));  // (no communicator: returns the local status)
     const ab_image_stats *res = nullptr;
     const void *tx = nullptr;
+    // (a caller that does not fetch gets the chain: nobody would see the resident kernel's abort flag)
+    const bool fetch = out_stats || out_stf;
+    bool resident = false, aborted = false;
+    ResidentGuard guard{ctx, &resident};
+    AB_TRY(stats_enqueue(ctx, comm, img->data, img->rows * img->cols, total_rows * img->cols, 0, 0.0, 0.0, cfg, &res, &tx, nullptr, out_u8_dev,
+                         fetch ? &resident : nullptr));
+    if (!resident && img->rows > 0) AB_TRY(ab_stf_u8_device_tx(ctx, img->data, img->rows * img->cols, tx, out_u8_dev));
+    if (!fetch) return AB_OK;
+    AB_TRY(fetch_result(ctx, res, out_stats, out_stf, comm, resident ? &aborted : nullptr));
+    if (!aborted) return AB_OK;
     AB_TRY(ab_stats_enqueue(ctx, comm, img->data, img->rows * img->cols, total_rows * img->cols, 0, 0.0, 0.0, cfg, &res, &tx, nullptr));
-    if (img->rows > 0) AB_TRY(ab_stf_u8_device_tx(ctx, img->data, img->rows * img->cols, tx, out_u8_dev));
-    if (out_stats || out_stf) return fetch_result(ctx, res, out_stats, out_stf, comm);
-    return AB_OK;
+    AB_TRY(ab_stf_u8_device_tx(ctx, img->data, img->rows * img->cols, tx, out_u8_dev));
+    return fetch_result(ctx, res, out_stats, out_stf, comm);
 } AB_CATCH(ctx)
 
 int ab_stats_value_hist(ab_ctx *ctx, const ab_plane *img, double gmin, double gmax, uint64_t *hist65536_host,

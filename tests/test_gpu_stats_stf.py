@@ -3,10 +3,26 @@
 Bar: integer results (valid_count, every histogram bin, u8 STF output) bit-exact; min/max/median/
 mad/sigma exact (same f64 scalar code on identical integer histograms / exact order statistics);
 mean within 1e-12 relative (f64 summation order is unspecified in the reference, stats.rs:252-257)."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["resident", "chain"])
+def hist_engine(request):
+    """The histogram path has two engines in the library: one kernel that holds the plane in the register file
+    (csrc/stats_resident.hpp, the default where it fits) and the five-pass chain (AB_STATS_CHAIN=1; also what sharded, very
+    large and fetch-less calls use).  The library reads the variable per call."""
+    old = os.environ.get("AB_STATS_CHAIN")
+    os.environ["AB_STATS_CHAIN"] = "1" if request.param == "chain" else "0"
+    yield request.param
+    if old is None:
+        os.environ.pop("AB_STATS_CHAIN", None)
+    else:
+        os.environ["AB_STATS_CHAIN"] = old
 
 
 def sky_image(rng, rows, cols, pad=True):
@@ -51,7 +67,7 @@ def test_stats_all_invalid(ctx, oracle):
 
 
 @pytest.mark.parametrize("shape", [(2048, 2051), (2100, 2300)])
-def test_stats_hist_path(ctx, oracle, shape):                   # stats.rs:75-210 (> 4 000 000 px)
+def test_stats_hist_path(ctx, oracle, shape, hist_engine):      # stats.rs:75-210 (> 4 000 000 px)
     rng = np.random.default_rng(9)
     img = sky_image(rng, *shape)
     ref = oracle.compute_image_stats(img)
@@ -67,11 +83,52 @@ def test_stats_hist_path(ctx, oracle, shape):                   # stats.rs:75-21
                 oracle.compute_image_stats_with_known_range(img, float("nan"), 1.0))
 
 
-def test_stats_hist_path_constant_and_tiny_range(ctx, oracle):
+def test_stats_hist_path_constant_and_tiny_range(ctx, oracle, hist_engine):
     img = np.full((2048, 2049), 7.25, np.float32)
     check_stats(ctx.compute_image_stats(img), oracle.compute_image_stats(img))
     img[0, 0] = np.float32(7.2500005)
     check_stats(ctx.compute_image_stats(img), oracle.compute_image_stats(img))
+
+
+def test_stats_hist_path_shapes_of_the_resident_kernel(ctx, oracle, hist_engine):
+    """What the one-kernel engine has to get right beyond the sky image: a pixel count that is not a multiple of four or of a
+    workgroup's 65 536 pixels, exactly 256 full workgroups (4096 x 4096), a plane with no valid pixel, a plane whose valid
+    pixels all sit in one workgroup, two-valued data (the MAD's rank falls on a bin edge), heavy tails."""
+    rng = np.random.default_rng(31)
+    cases = {
+        "odd count": sky_image(rng, 2049, 2051),
+        "4096 x 4096": sky_image(rng, 4096, 4096),
+        "no valid pixel": np.zeros((2048, 2050), np.float32),
+        "valid pixels in one workgroup": np.zeros((2048, 2050), np.float32),
+        "two values": np.where(rng.random((2048, 2050)) < 0.5, np.float32(3.0), np.float32(5.0)).astype(np.float32),
+        "heavy tails": (rng.standard_cauchy((2048, 2050)) * 10.0 + 500.0).astype(np.float32),
+        "ramp": np.linspace(1.0, 2.0, 2048 * 2050, dtype=np.float32).reshape(2048, 2050),
+    }
+    cases["valid pixels in one workgroup"][700, :1500] = (100.0 + rng.standard_normal(1500)).astype(np.float32)
+    for name, img in cases.items():
+        got, ref = ctx.compute_image_stats(img), oracle.compute_image_stats(img)
+        try:
+            check_stats(got, ref)
+        except AssertionError as e:
+            raise AssertionError(f"{name} [{hist_engine}]: {got} != {ref}") from e
+
+
+@pytest.mark.parametrize("shape", [(2048, 2051), (2049, 2051), (4096, 4096)])
+def test_auto_stretch_preview_hist_path(ctx, oracle, shape, hist_engine):   # cmd/common.rs:18-22 on > 4 000 000 px
+    import torch
+    rng = np.random.default_rng(shape[1])
+    img = sky_image(rng, *shape)
+    st = oracle.compute_image_stats(img)
+    p = oracle.auto_stf(st)
+    want = oracle.apply_stf(img, p, st)
+    u8, gst, gp = ctx.auto_stretch_preview(torch.from_numpy(img).cuda())
+    check_stats(gst, st)
+    assert (gp.shadow, gp.midtone, gp.highlight) == (p.shadow, p.midtone, p.highlight)
+    assert np.array_equal(u8.cpu().numpy(), want)
+    # the fetch-less form (always the chain) leaves the same bytes
+    u8b, _, _ = ctx.auto_stretch_preview(torch.from_numpy(img).cuda(), fetch=False)
+    ctx.synchronize()
+    assert np.array_equal(u8b.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("bins", [512, 65536, 100000])
@@ -123,3 +180,32 @@ def test_stf_inplace_device(ctx, oracle):                       # stf.rs:147-155
     gst = ctx.compute_image_stats(d)
     ctx.apply_stf_f32(d, ctx.auto_stf(gst), gst, out=d)
     assert np.array_equal(d.cpu().numpy(), oracle.apply_stf_f32(img, p, st))
+
+
+def test_stats_hist_path_from_two_threads(oracle):
+    """The one-kernel engine needs the whole chip; two contexts calling at once must not wait for each other's workgroups (the
+    library lets one of them through and gives the other the chain).  Results stay exact either way."""
+    import threading
+    import astroburst_amd as ab
+    rng = np.random.default_rng(77)
+    imgs = [sky_image(rng, 2048, 2100 + 8 * i) for i in range(2)]
+    refs = [oracle.compute_image_stats(im) for im in imgs]
+    ctxs = [ab.Context(0) for _ in imgs]
+    out, errs = [[] for _ in imgs], []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                out[i].append(ctxs[i].compute_image_stats(imgs[i]))
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(imgs))]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    [c.close() for c in ctxs]
+    assert not errs, errs
+    for i, ref in enumerate(refs):
+        assert len(out[i]) == 20
+        for got in out[i]:
+            check_stats(got, ref)
