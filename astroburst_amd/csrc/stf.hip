@@ -79,9 +79,27 @@ __global__ __launch_bounds__(256) void stf_f32_kernel(const float *in, int64_t n
     }
 }
 
-__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, int64_t n4) {
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+// the streaming ceiling probe behind bench.py's `measured_copy_GBs`: four 16-byte loads in flight per lane (a workgroup moves 16 KiB
+// per iteration), streaming loads and stores (nothing of a 2 x 256 MB copy is worth keeping in L2)
+typedef float copy_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_kernel(const float4 *__restrict__ src4, float4 *__restrict__ dst4, int64_t n4) {
+    const copy_f4 *src = reinterpret_cast<const copy_f4 *>(src4);
+    copy_f4 *dst = reinterpret_cast<copy_f4 *>(dst4);
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t base = (int64_t)blockIdx.x * 1024; base < n4; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        if (base + 1024 <= n4) {
+            const copy_f4 a = __builtin_nontemporal_load(&src[i]), b = __builtin_nontemporal_load(&src[i + 256]),
+                          c = __builtin_nontemporal_load(&src[i + 512]), d = __builtin_nontemporal_load(&src[i + 768]);
+            __builtin_nontemporal_store(a, &dst[i]);
+            __builtin_nontemporal_store(b, &dst[i + 256]);
+            __builtin_nontemporal_store(c, &dst[i + 512]);
+            __builtin_nontemporal_store(d, &dst[i + 768]);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (i + 256 * k < n4) dst[i + 256 * k] = src[i + 256 * k];
+        }
+    }
 }
 
 int stream_grid(ab_ctx *ctx, int64_t n4) {
@@ -181,7 +199,7 @@ int ab_bench_copy(ab_ctx *ctx, const float *src_dev, float *dst_dev, size_t n_fl
     AB_CHECK(ctx, src_dev && dst_dev && (n_floats % 4) == 0, "copy needs 16-byte multiples");
     AB_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t n4 = (int64_t)(n_floats / 4);
-    hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(ctx, n4)), dim3(256), 0, ctx->stream, (const float4 *)src_dev,
+    hipLaunchKernelGGL(copy_kernel, dim3(stream_grid(ctx, (n4 + 3) / 4)), dim3(256), 0, ctx->stream, (const float4 *)src_dev,
                        (float4 *)dst_dev, n4);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;

@@ -515,7 +515,9 @@ def main():
 
     if rank == 0:
         # the whole step against HBM: every byte the step's stages must move at least once, over the step's wall time
-        step_bytes = (4 * N * P + 4 * P) + 21 * P + (8 * P * (N - 1) if register else 0)   # stack + stats(16P) + STF(5P) + unfused warps
+        # stack + statistics and stretch (one kernel that reads the plane once and writes the u8 plane: 5 P; the row-band chain makes
+        # five passes: 16 P + 5 P) + unfused warps
+        step_bytes = (4 * N * P + 4 * P) + (21 if rowband else 5) * P + (8 * P * (N - 1) if register else 0)
         step_gbs = step_bytes / (ms_per_step * 1e-3) / 1e9 * (1 if rowband else world)
         out = {
             "metric": "MPix/s sigma-clipped stack+stretch, 64x4096x4096 f32",

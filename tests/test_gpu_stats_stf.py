@@ -209,3 +209,14 @@ def test_stats_hist_path_from_two_threads(oracle):
         assert len(out[i]) == 20
         for got in out[i]:
             check_stats(got, ref)
+
+
+@pytest.mark.parametrize("n", [4, 1020, 4096, 4100, 1 << 22, (1 << 22) + 12])
+def test_bench_copy_probe_copies(ctx, n):
+    """bench.py's streaming probe is a real copy (whole 16 KiB workgroup steps and the ragged end)"""
+    import torch
+    a = torch.arange(n, dtype=torch.float32, device="cuda")
+    b = torch.full((n + 8,), -1.0, dtype=torch.float32, device="cuda")
+    ctx.bench_copy(a, b[:n])
+    ctx.synchronize()
+    assert torch.equal(b[:n], a) and bool((b[n:] == -1.0).all())
