@@ -802,6 +802,8 @@ bool resident_takes(ab_ctx *ctx, const float *data, int64_t n, const uint8_t *u8
 int enqueue_resident(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int known, double kmin, double kmax, const ab_auto_stf_config &cfg,
                      uint8_t *u8) {
     AB_HIP(ctx, hipMemsetAsync(w.res.bar, 0, 4096, ctx->stream));
+    if (const char *e = getenv("AB_STATS_FORCE_ABORT"); e && *e == '1')  // test hook: the kernel finds the abort flag raised at its first barrier
+        AB_HIP(ctx, hipMemsetAsync(w.res.bar + kBarAbort, 1, 1, ctx->stream));
     const unsigned grid = (unsigned)((n + kResTile - 1) / kResTile);
     hipLaunchKernelGGL(stats_resident_kernel, dim3(grid), dim3(kResBlock), 0, ctx->stream, data, n, w.st, w.res, known, kmin, kmax, cfg, u8);
     AB_HIP(ctx, hipGetLastError());

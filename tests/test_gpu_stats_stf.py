@@ -220,3 +220,27 @@ def test_bench_copy_probe_copies(ctx, n):
     ctx.bench_copy(a, b[:n])
     ctx.synchronize()
     assert torch.equal(b[:n], a) and bool((b[n:] == -1.0).all())
+
+
+def test_stats_resident_abort_falls_back_to_the_chain(ctx, oracle):
+    """A grid barrier of the one-kernel engine that cannot complete raises an abort flag; the host then runs the chain.  The test
+    hook raises the flag before the launch: statistics and stretched bytes must still be the oracle's."""
+    import torch
+    rng = np.random.default_rng(5)
+    img = sky_image(rng, 2048, 2052)
+    st = oracle.compute_image_stats(img)
+    want = oracle.apply_stf(img, oracle.auto_stf(st), st)
+    old = {k: os.environ.get(k) for k in ("AB_STATS_FORCE_ABORT", "AB_STATS_CHAIN")}
+    os.environ["AB_STATS_FORCE_ABORT"] = "1"
+    os.environ["AB_STATS_CHAIN"] = "0"
+    try:
+        check_stats(ctx.compute_image_stats(img), st)
+        u8, gst, _ = ctx.auto_stretch_preview(torch.from_numpy(img).cuda())
+        check_stats(gst, st)
+        assert np.array_equal(u8.cpu().numpy(), want)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
