@@ -87,13 +87,41 @@ constexpr int kVecs = kSlots / 32;
 struct Keys {
     u32x32 v[kVecs];  // key of slot s = v[s >> 5][s & 31]; 0 = not a candidate
 };
+// k[c] = v[c][j] for the four vectors inside ONE index-register window.  The compiler opens a window (s_set_gpr_idx_on / _off, two
+// SALU instructions with their hazards: ~20 cycles) around every indexed move it emits, four per iteration of a sweep -- 40 % of a
+// sweep (tools/sweep_bench.hip).  Inline assembly cannot name "element j of this operand", but it can name a register: the four
+// vectors are tied to v[104:231] by the operand constraints (the allocator then keeps them there for good: no copies appear), and
+// the window's moves address v104 / v136 / v168 / v200 + j.  The rest of the kernel lives below and just above them (the kernel
+// must stay at 240 registers: at two waves per SIMD that leaves 32 per SIMD for a wave of the f64 warp beside a tile workgroup).
+#ifndef AB_TILE_NO_PINNED_KEYS
+static_assert(kVecs == 4, "read_keys names four register ranges");
+__device__ __forceinline__ void read_keys(const Keys &K, int j, uint32_t (&k)[kVecs]) {
+    asm volatile(
+        "s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+        "v_mov_b32 %0, v104\n\t"
+        "v_mov_b32 %1, v136\n\t"
+        "v_mov_b32 %2, v168\n\t"
+        "v_mov_b32 %3, v200\n\t"
+        "s_set_gpr_idx_off"
+        : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3])
+        : "s"(j), "{v[104:135]}"(K.v[0]), "{v[136:167]}"(K.v[1]), "{v[168:199]}"(K.v[2]), "{v[200:231]}"(K.v[3])
+        );  // (M0 is written: the compiler never keeps a value in it across an asm statement)
+}
+#else
+__device__ __forceinline__ void read_keys(const Keys &K, int j, uint32_t (&k)[kVecs]) {
+#pragma unroll
+    for (int c = 0; c < kVecs; ++c) k[c] = K.v[c][j];
+}
+#endif
 // f(key) for every key of the thread
 template <class F>
 __device__ __forceinline__ void for_each_key(const Keys &K, F f) {
 #pragma unroll 1
     for (int j = 0; j < 32; ++j) {
+        uint32_t k[kVecs];
+        read_keys(K, j, k);
 #pragma unroll
-        for (int c = 0; c < kVecs; ++c) f(K.v[c][j]);
+        for (int c = 0; c < kVecs; ++c) f(k[c]);
     }
 }
 
@@ -292,11 +320,9 @@ __device__ __forceinline__ unsigned int gather_sweep(const Keys &K, Shared &sh, 
         for (int j = 0; j < 32; ++j) {
             uint32_t k[kVecs];
             unsigned long long any = 0;
+            read_keys(K, j, k);
 #pragma unroll
-            for (int c = 0; c < kVecs; ++c) {
-                k[c] = K.v[c][j];
-                any |= __builtin_amdgcn_ballot_w64(k[c] - l1 <= w1);
-            }
+            for (int c = 0; c < kVecs; ++c) any |= __builtin_amdgcn_ballot_w64(k[c] - l1 <= w1);
             if (any) {
 #pragma unroll
                 for (int c = 0; c < kVecs; ++c) put(k[c], k[c] - l1 <= w1);
@@ -307,9 +333,11 @@ __device__ __forceinline__ unsigned int gather_sweep(const Keys &K, Shared &sh, 
     }
 #pragma unroll 1
     for (int j = 0; j < 32; ++j) {
+        uint32_t kk[kVecs];
+        read_keys(K, j, kk);
 #pragma unroll
         for (int c = 0; c < kVecs; ++c) {
-            const uint32_t k = K.v[c][j];
+            const uint32_t k = kk[c];
             bool in = (k - l1 <= w1) | (DEV & (k - l2 <= w2));  // lo <= k <= hi in one unsigned compare
             if (two_excl) in = in & !((k >= g.x1_lo) & (k <= g.x1_hi)) & !((k >= g.x2_lo) & (k <= g.x2_hi));
             put(k, in);

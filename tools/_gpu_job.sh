@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-bash tools/profile_bench.sh r03u 5 > gpurun_out/r03u_profile.log 2>&1
-timeout 600 python bench.py > gpurun_out/r03u_bench.json 2> gpurun_out/r03u_bench.err
+timeout 120 build/tile_bench 0 2>&1 | cut -c1-330 | head -5 > gpurun_out/r03v_tile_bench.txt
+timeout 900 python -m pytest tests/test_gpu_tile_stats.py tests/test_gpu_detect_affine.py -m gpu -x -q 2>&1 | tail -n 5 > gpurun_out/r03v_pytest.log
+timeout 300 python tools/time_register.py > gpurun_out/r03v_time_register.txt 2>&1
