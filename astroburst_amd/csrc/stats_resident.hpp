@@ -34,8 +34,10 @@ constexpr int kResPer = 4 * kResVec;            // pixels per thread
 constexpr int kResTile = kResBlock * kResPer;   // 65 536 pixels per workgroup
 constexpr int kResWaves = kResBlock / 64;
 // A thread's 64 pixels are two 32-element register vectors, and every sweep is a REAL loop of 32 iterations that reads a[j] and
-// b[j] through the VGPR index register (cf. tile_bucket.hpp): ~20 cycles per indexed read, a third of a sweep.  Unrolled sweeps
-// would not pay that, but every attempt spilled 130 .. 630 registers (the optimiser shares sub-expressions between the sweeps and
+// b[j] through the VGPR index register (cf. tile_bucket.hpp).  Four reads per index window (the vectors tied to fixed registers,
+// as tile_bucket.hpp's read_keys does) measured 365 000 cycles against 374 000 for the kernel: not worth the assembly here -- a
+// sweep is 17 VALU and ~10 SALU instructions per pixel, and the scalar unit serves a SIMD once in four cycles.  Unrolled sweeps
+// would need neither index windows nor loop control, but every attempt spilled 130 .. 630 registers (the optimiser shares sub-expressions between the sweeps and
 // parks their ballot masks; laundering the values and pinning the counts brought it to 133, not to 0), and 25 000 instructions
 // of straight-line code run at the instruction-fetch rate.
 // a scalar count is final where it is written (the optimiser otherwise collects ballot masks and counts them later)
