@@ -393,9 +393,10 @@ struct StarXY {
 
 __global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
                                                          unsigned int *__restrict__ bin_hist /* nullable; zero on entry */,
-                                                         unsigned int *__restrict__ votes_to_clear /* nullable: the vote matrix of the frame */) {
-    // (the vote kernel of this frame runs later on the same stream: clearing its matrix here saves a fill command per frame)
-    if (votes_to_clear && blockIdx.x * 1024 + threadIdx.x < kVoteDim * kVoteDim) votes_to_clear[blockIdx.x * 1024 + threadIdx.x] = 0;
+                                                         unsigned int *__restrict__ votes_to_clear /* nullable: the vote matrices of the frame */,
+                                                         int vote_words) {
+    // (the vote kernel of this frame runs later on the same stream: clearing its matrices here saves a fill command per frame)
+    if (votes_to_clear && (int)(blockIdx.x * 1024 + threadIdx.x) < vote_words) votes_to_clear[blockIdx.x * 1024 + threadIdx.x] = 0;
     __shared__ unsigned int lhist[kTriBins];  // this block's share of the bucket histogram: one global atomic per touched bucket
     if (bin_hist) {
         for (int b = threadIdx.x; b < kTriBins; b += 1024) lhist[b] = 0;
@@ -600,9 +601,22 @@ __global__ __launch_bounds__(64) void tri_group_windows_kernel(const DTri *__res
 // (2048, 16) 69, (1024, 4) 79, (4096, 8) 79: more blocks pay for more flushes, fewer slices for imbalance.
 constexpr int kVoteSlices = 8;
 constexpr int kVoteBlocks = 1024;
+// The blocks flush their LDS votes into one of `copies` copies of the matrix (block b -> copy b % copies) and the host adds the
+// copies up: same-address device-scope atomics retire one per 15 .. 50 ns (stats_resident.hpp), and the pairs that collect votes
+// collect them from hundreds of blocks.  Measured (AB_VOTE_COPIES = 1 / 4 / 16): kernel 83 / 80 / 80 us on average inside the batch
+// (56.7 / 56.0 alone), stage median 16.3-16.6 / 15.8-15.9 / 15.7-16.3 ms: the flush is a small part of the kernel, 4 copies kept.
+constexpr int kVoteCopiesMax = 16;
+int vote_copies() {
+    static const int c = [] {
+        const char *e = getenv("AB_VOTE_COPIES");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > kVoteCopiesMax ? kVoteCopiesMax : v);
+    }();
+    return c;
+}
 __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
-                                                      unsigned int *__restrict__ votes_out /* 64 x 64, zeroed */,
+                                                      unsigned int *__restrict__ votes_out /* copies x 64 x 64, zeroed */, int copies,
                                                       const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *tgt_count_to_clear = 0;  // tri_scatter_kernel was its last reader
     // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and with a stride of 64
@@ -653,9 +667,10 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
         }
     }
     __syncthreads();
+    unsigned int *mine = votes_out + (size_t)(blockIdx.x % (unsigned int)copies) * (kVoteDim * kVoteDim);
     for (int row = 0; row < kVoteDim; ++row) {  // lane = column
         const unsigned int v = votes[row * kLdsStride + lane];
-        if (v) atomicAdd(&votes_out[row * kVoteDim + lane], v);
+        if (v) atomicAdd(&mine[row * kVoteDim + lane], v);
     }
 }
 
@@ -669,7 +684,7 @@ struct MatchWs {
 };
 
 int match_ws(ab_ctx *ctx, MatchWs *w) {
-    const size_t tri_bytes = (size_t)kMaxTris * sizeof(DTri), vote_bytes = kVoteDim * kVoteDim * sizeof(unsigned int);
+    const size_t tri_bytes = (size_t)kMaxTris * sizeof(DTri), vote_bytes = (size_t)kVoteCopiesMax * kVoteDim * kVoteDim * sizeof(unsigned int);
     const size_t bin_words = 64 + 3 * (size_t)kTriBins + 64;
     const size_t group_bytes = (size_t)((kMaxTris + 63) / 64) * sizeof(RefGroup);
     const size_t total = 4 * tri_bytes + bin_words * sizeof(unsigned int) + vote_bytes + group_bytes;
@@ -708,11 +723,12 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
     // reference table is built once per batch
     if (!which) AB_HIP(ctx, hipMemsetAsync(w.counts, 0, sizeof(unsigned int), ctx->stream));
     const int total = limit * limit * limit;
-    const bool clears = which && limit >= 3 && (total + 1023) / 1024 * 1024 >= kVoteDim * kVoteDim;  // enough threads to clear the votes
+    const int vote_words = vote_copies() * kVoteDim * kVoteDim;
+    const bool clears = which && limit >= 3 && (total + 1023) / 1024 * 1024 >= vote_words;  // enough threads to clear the votes
     if (limit >= 3)
         hipLaunchKernelGGL(tri_build_kernel, dim3((total + 1023) / 1024), dim3(1024), 0, ctx->stream, xy, limit, raw, w.counts + which, w.bin_hist,
-                           clears ? w.votes : (unsigned int *)nullptr);
-    if (which && !clears) AB_HIP(ctx, hipMemsetAsync(w.votes, 0, kVoteDim * kVoteDim * sizeof(unsigned int), ctx->stream));
+                           clears ? w.votes : (unsigned int *)nullptr, vote_words);
+    if (which && !clears) AB_HIP(ctx, hipMemsetAsync(w.votes, 0, (size_t)vote_words * sizeof(unsigned int), ctx->stream));
     // (the scan leaves bin_hist zeroed again)
     hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
     hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 1023) / 1024), dim3(1024), 0, ctx->stream, raw, w.counts + which, w.cursor, sorted);
@@ -729,12 +745,16 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
 int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std::vector<uint32_t> *votes) {
     // (w.votes was cleared by this frame's tri_build_kernel or the memset beside it; the kernel resets the target table's counter
     // for the next frame)
-    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, (const RefGroup *)w.groups,
-                       w.counts + 1);
+    const int copies = vote_copies();
+    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, copies,
+                       (const RefGroup *)w.groups, w.counts + 1);
     AB_HIP(ctx, hipGetLastError());
-    votes->resize(kVoteDim * kVoteDim);
+    votes->resize((size_t)copies * kVoteDim * kVoteDim);
     AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int c = 1; c < copies; ++c)
+        for (int i = 0; i < kVoteDim * kVoteDim; ++i) (*votes)[i] += (*votes)[(size_t)c * kVoteDim * kVoteDim + i];
+    votes->resize(kVoteDim * kVoteDim);
     return AB_OK;
 }
 
