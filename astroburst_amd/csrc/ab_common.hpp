@@ -101,6 +101,11 @@ struct ab_ctx {
     std::mutex progress_mu;
     std::mutex err_mu;  // ab_set_error may be reached from the reference-preparation thread and the caller at once (affine.hip)
     ab_ctx *parent = nullptr;
+    // the register-resident statistics kernel (stats_resident.hpp): its barrier flags carry epochs that grow from call to call, so
+    // they are cleared only when the workspace is new, after an abort, or before the 32-bit epoch wraps
+    const void *stats_bar = nullptr;
+    unsigned int stats_epoch = 0;
+    unsigned long long stats_expect = 0;  // the completion marker the last resident launch writes beside its result
 };
 
 // stage boundary: AB_ERR_CANCELLED ("Operation cancelled") if the host asked to stop, else ticks the callback (if any)

@@ -79,6 +79,7 @@ struct StatsDev {
     float center;
     ab_image_stats result;
     ab_stf_params stf;
+    unsigned long long done;    // the resident kernel's completion marker (fetched with result and stf: one copy)
     StfTx tx;
 };
 
@@ -801,11 +802,19 @@ bool resident_takes(ab_ctx *ctx, const float *data, int64_t n, const uint8_t *u8
 
 int enqueue_resident(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int known, double kmin, double kmax, const ab_auto_stf_config &cfg,
                      uint8_t *u8) {
-    AB_HIP(ctx, hipMemsetAsync(w.res.bar, 0, 4096, ctx->stream));
+    if (ctx->stats_bar != (const void *)w.res.bar || ctx->stats_epoch > 0xffff0000u) {  // new workspace / after an abort / epoch about to wrap
+        AB_HIP(ctx, hipMemsetAsync(w.res.bar, 0, 4096, ctx->stream));
+        AB_HIP(ctx, hipMemsetAsync(&w.st->done, 0, sizeof w.st->done, ctx->stream));
+        ctx->stats_bar = w.res.bar;
+        ctx->stats_epoch = 0;
+    }
+    const unsigned int epoch_base = ctx->stats_epoch;
+    ctx->stats_epoch += 8;  // (seven barriers per launch)
+    ctx->stats_expect = (unsigned long long)epoch_base + 8u;
     if (const char *e = getenv("AB_STATS_FORCE_ABORT"); e && *e == '1')  // test hook: the kernel finds the abort flag raised at its first barrier
         AB_HIP(ctx, hipMemsetAsync(w.res.bar + kBarAbort, 1, 1, ctx->stream));
     const unsigned grid = (unsigned)((n + kResTile - 1) / kResTile);
-    hipLaunchKernelGGL(stats_resident_kernel, dim3(grid), dim3(kResBlock), 0, ctx->stream, data, n, w.st, w.res, known, kmin, kmax, cfg, u8);
+    hipLaunchKernelGGL(stats_resident_kernel, dim3(grid), dim3(kResBlock), 0, ctx->stream, data, n, w.st, w.res, epoch_base, known, kmin, kmax, cfg, u8);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -870,21 +879,23 @@ int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, i
     return stats_enqueue(ctx, comm, data, n, n_total, use_known, known_min, known_max, stf_cfg, result_dev, tx_dev, stf_dev, nullptr, nullptr);
 }
 
-// *aborted (nullable): the resident kernel's abort flag, fetched with the result
+// *aborted (nullable; after a resident launch): whether the completion marker beside the result is NOT this launch's -- a grid
+// barrier timed out and the workgroups left.  The barrier flags are then cleared before the next launch.
 static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_stats *out, ab_stf_params *stf_out, ab_comm *comm = nullptr,
                         bool *aborted = nullptr) {
     void *pin = nullptr;
-    constexpr size_t kFlagAt = (sizeof(ab_image_stats) + sizeof(ab_stf_params) + 7) & ~(size_t)7;
-    AB_TRY(ab_pinned(ctx, kFlagAt + 8, &pin));
-    if (aborted) {
-        Ws w;
-        AB_TRY(carve(ctx, &w));
-        AB_HIP(ctx, hipMemcpyAsync((char *)pin + kFlagAt, w.res.bar + kBarAbort, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-    }
+    constexpr size_t kDoneAt = sizeof(ab_image_stats) + sizeof(ab_stf_params);
+    static_assert(offsetof(StatsDev, done) == offsetof(StatsDev, result) + kDoneAt, "result, stf and the marker are adjacent");
+    AB_TRY(ab_pinned(ctx, kDoneAt + 8, &pin));
     static_assert(offsetof(StatsDev, stf) == offsetof(StatsDev, result) + sizeof(ab_image_stats), "result and stf are adjacent");
-    AB_HIP(ctx, hipMemcpyAsync(pin, result_dev, sizeof(ab_image_stats) + sizeof(ab_stf_params), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipMemcpyAsync(pin, result_dev, kDoneAt + 8, hipMemcpyDeviceToHost, ctx->stream));
     AB_TRY(ab_comm_stream_wait(ctx, comm));  // (a plain hipStreamSynchronize without a communicator)
-    if (aborted) *aborted = *(const unsigned int *)((const char *)pin + kFlagAt) != 0;
+    if (aborted) {
+        unsigned long long done;
+        memcpy(&done, (const char *)pin + kDoneAt, sizeof done);
+        *aborted = done != ctx->stats_expect;
+        if (*aborted) ctx->stats_bar = nullptr;
+    }
     if (aborted && getenv("AB_STATS_TIMING")) {  // workgroup 0's phase stamps (s_memtime: shader clock cycles)
         Ws w;
         AB_TRY(carve(ctx, &w));

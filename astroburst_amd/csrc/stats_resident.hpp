@@ -232,7 +232,7 @@ __device__ __forceinline__ RankHit join_levels(const RankHit &coarse, const Rank
 }
 
 __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *__restrict__ data, int64_t n, StatsDev *st_out, const ResWs w,
-                                                                   int known, double kmin, double kmax, ab_auto_stf_config cfg,
+                                                                   unsigned int epoch_base, int known, double kmin, double kmax, ab_auto_stf_config cfg,
                                                                    unsigned char *__restrict__ u8) {
     __shared__ unsigned int lds[kResWaves * kWaveLds];  // the waves' counting regions
     __shared__ unsigned long long s_tot[512];
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
     __shared__ StatsDev s_st;
     const int t = threadIdx.x;
     const unsigned int G = gridDim.x;
-    unsigned int nbar = 0;
+    unsigned int nbar = epoch_base;  // the barrier flags keep the previous launch's epochs: this launch's are all larger
     int level = 0;
     auto my_row = [&](int lv) { return w.slab + ((size_t)lv * kResMaxGrid + blockIdx.x) * kSlabRow; };
     auto rows_of = [&](int lv) { return w.slab + (size_t)lv * kResMaxGrid * kSlabRow; };
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
     } else if (t == 0) {
         finish_result(&s_st, 0.0, cfg);
     }
+    if (t == 0) s_st.done = (unsigned long long)epoch_base + 8u;  // the host's proof that this launch ran to the end
     __syncthreads();
     if (blockIdx.x == 0)
         for (int i = t; i < (int)(sizeof(StatsDev) / 4); i += kResBlock) reinterpret_cast<unsigned int *>(st_out)[i] = reinterpret_cast<const unsigned int *>(&s_st)[i];
