@@ -1,9 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-: > gpurun_out/r03ad_sweep.txt
-timeout 120 python tools/time_register.py < /dev/null 2>&1 | tail -n 1 >> gpurun_out/r03ad_sweep.txt
-AB_DETECT_CHAIN=1 timeout 120 python tools/time_register.py < /dev/null 2>&1 | tail -n 1 >> gpurun_out/r03ad_sweep.txt
-AB_NO_WARP_STREAM=1 timeout 120 python tools/time_register.py < /dev/null 2>&1 | tail -n 1 >> gpurun_out/r03ad_sweep.txt
-GPU_MAX_HW_QUEUES=8 timeout 120 python tools/time_register.py < /dev/null 2>&1 | tail -n 1 >> gpurun_out/r03ad_sweep.txt
-GPU_MAX_HW_QUEUES=2 timeout 120 python tools/time_register.py < /dev/null 2>&1 | tail -n 1 >> gpurun_out/r03ad_sweep.txt
-timeout 120 python tools/time_register.py < /dev/null 2>&1 | tail -n 1 >> gpurun_out/r03ad_sweep.txt
+timeout 1500 python -m pytest tests/test_gpu_background.py tests/test_gpu_masked.py tests/test_gpu_compose.py tests/test_gpu_extras.py tests/test_gpu_full_size.py -m gpu -x -q < /dev/null 2>&1 | head -n 4 > gpurun_out/r03ag_pytest.log
+timeout 300 python tools/time_c5.py < /dev/null > gpurun_out/r03ag_c5.txt 2>&1
