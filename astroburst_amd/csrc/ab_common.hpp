@@ -37,6 +37,7 @@ enum {
     AB_WS_SHARD,              // (sum f64, count u32) partial planes of the frame-sharded stack (sharded.hip)
     AB_WS_SUBSAMPLE,          // the <= ~100 000-pixel subsample normalize_for_detection takes its percentiles from
     AB_WS_DETECT_DEV,         // FrameDev + the tile statistics of the chained detection (detect.hip)
+    AB_WS_PHASE_TABLES,       // two sets of Hann windows + FFT twiddles of the phase correlation, kept between calls (phase_corr.hip)
     AB_WS_SLOTS
 };
 
@@ -106,6 +107,9 @@ struct ab_ctx {
     const void *stats_bar = nullptr;
     unsigned int stats_epoch = 0;
     unsigned long long stats_expect = 0;  // the completion marker the last resident launch writes beside its result
+    // phase_corr.hip: the (rows, cols) the two table sets in AB_WS_PHASE_TABLES were built for, and the workspace they live in
+    int pc_tab_dims[2][2] = {{0, 0}, {0, 0}};
+    const void *pc_tab_ws = nullptr;
 };
 
 // stage boundary: AB_ERR_CANCELLED ("Operation cancelled") if the host asked to stop, else ticks the callback (if any)

@@ -217,7 +217,47 @@ __global__ __launch_bounds__(kBlock) void scale_peak_kernel(const double2 *__res
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
 }
 
-__global__ __launch_bounds__(kBlock) void var_kernel(const double *__restrict__ corr, int n, double mean, double *__restrict__ partials) {
+// What the host used to do between the kernels of a correlation -- pick the peak among the workgroups' partials, form the mean,
+// add up the variance partials, read the peak's four neighbours -- in the host's own (sequential) order, by one thread each, so
+// that a correlation ends in ONE read-back and one synchronisation instead of four (a 4 x 1600 x 1600 stack_images(align) spent
+// more time in its 30 host joins than in its kernels).
+struct PcFin {
+    int best_idx, pad;
+    double mean, count, var_sum;
+    double sv[5];
+};
+__global__ void peak_finish_kernel(const PeakPartial *__restrict__ pp, int pg, PcFin *fin) {
+    double best = -DBL_MAX, sum = 0.0, count = 0.0;
+    int best_idx = 0x7fffffff;
+    for (int i = 0; i < pg; ++i) {
+        const PeakPartial p = pp[i];
+        if (p.best_idx != 0x7fffffff && (best_idx == 0x7fffffff || p.best > best || (p.best == best && p.best_idx < best_idx))) {
+            best = p.best;
+            best_idx = p.best_idx;
+        }
+        sum += p.sum;
+        count += p.count;
+    }
+    fin->best_idx = best_idx == 0x7fffffff ? 0 : best_idx;
+    fin->count = count;
+    fin->mean = count >= 1.0 ? sum / count : 0.0;  // normalization.rs:128-161
+}
+__global__ void var_finish_kernel(const double *__restrict__ vp, int pg, const double *__restrict__ corr, int fr, int fc, PcFin *fin) {
+    double var_sum = 0.0;
+    if (fin->count >= 1.0)
+        for (int i = 0; i < pg; ++i) var_sum += vp[i];
+    fin->var_sum = var_sum;
+    const int py = fin->best_idx / fc, px = fin->best_idx % fc;
+    // the 5 surface samples of the 3-point refinements (subpixel.rs:27-62), wrap-around neighbours
+    fin->sv[0] = corr[py * fc + px];
+    fin->sv[1] = corr[(py == 0 ? fr - 1 : py - 1) * fc + px];
+    fin->sv[2] = corr[(py == fr - 1 ? 0 : py + 1) * fc + px];
+    fin->sv[3] = corr[py * fc + (px == 0 ? fc - 1 : px - 1)];
+    fin->sv[4] = corr[py * fc + (px == fc - 1 ? 0 : px + 1)];
+}
+
+__global__ __launch_bounds__(kBlock) void var_kernel(const double *__restrict__ corr, int n, const PcFin *__restrict__ fin, double *__restrict__ partials) {
+    const double mean = fin->mean;
     double vs = 0.0;
     const int stride = gridDim.x * kBlock;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
@@ -264,13 +304,18 @@ struct PcScratch {
     double *hann_y, *hann_x;
     double2 *tw_r, *tw_c;  // 256 each
     float *ds_a, *ds_b;    // 512 x 512 downsampled planes
-    void *partials;        // kMinMaxPartials x 32 B
+    void *partials;        // kMinMaxPartials x 32 B (min / max partials of two planes; peak partials)
+    double *var_partials;  // kPartials
+    PcFin *fin;
 };
+
+void hann_periodic(int n, std::vector<double> &w);
+void twiddles(int n, std::vector<double> &tw);
 
 int pc_carve(ab_ctx *ctx, PcScratch *s) {
     const size_t n = 512 * 512;
     const size_t bytes = 2 * n * sizeof(double2) + n * sizeof(double) + 2 * 512 * sizeof(double) + 2 * 256 * sizeof(double2) +
-                         2 * n * sizeof(float) + kMinMaxPartials * 32 + 256;
+                         2 * n * sizeof(float) + 2 * kMinMaxPartials * 32 + kPartials * 8 + sizeof(PcFin) + 512;
     void *p = nullptr;
     AB_TRY(ab_scratch(ctx, bytes, &p));
     char *c = (char *)p;
@@ -283,7 +328,41 @@ int pc_carve(ab_ctx *ctx, PcScratch *s) {
     s->tw_c = (double2 *)c; c += 256 * sizeof(double2);
     s->ds_a = (float *)c; c += n * sizeof(float);
     s->ds_b = (float *)c; c += n * sizeof(float);
-    s->partials = (void *)c;
+    s->partials = (void *)c; c += 2 * kMinMaxPartials * 32;
+    s->var_partials = (double *)c; c += kPartials * 8;
+    s->fin = (PcFin *)c;
+    return AB_OK;
+}
+
+// Hann windows and twiddles for (rows, cols) in table set `set` (0: the coarse / only correlation, 1: the refinement crop): kept
+// in a workspace of their own between calls, uploaded only when the dimensions change (every call used to upload four tables from
+// pageable memory and wait for them)
+int pc_tables(ab_ctx *ctx, PcScratch *s, int set, int rows, int cols, int fr, int fc) {
+    const size_t per = 2 * 512 * sizeof(double) + 2 * 256 * sizeof(double2);
+    char *t = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_PHASE_TABLES, 2 * per, (void **)&t));
+    if (ctx->pc_tab_ws != (const void *)t) {
+        ctx->pc_tab_ws = t;
+        ctx->pc_tab_dims[0][0] = ctx->pc_tab_dims[1][0] = 0;
+    }
+    t += (size_t)set * per;
+    s->hann_y = (double *)t;
+    s->hann_x = s->hann_y + 512;
+    s->tw_r = (double2 *)(s->hann_x + 512);
+    s->tw_c = s->tw_r + 256;
+    if (ctx->pc_tab_dims[set][0] == rows && ctx->pc_tab_dims[set][1] == cols) return AB_OK;
+    std::vector<double> hy, hx, twr, twc;
+    hann_periodic(rows, hy);
+    hann_periodic(cols, hx);
+    twiddles(fr, twr);
+    twiddles(fc, twc);
+    AB_HIP(ctx, hipMemcpyAsync(s->hann_y, hy.data(), rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipMemcpyAsync(s->hann_x, hx.data(), cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipMemcpyAsync(s->tw_r, twr.data(), twr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipMemcpyAsync(s->tw_c, twc.data(), twc.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host tables are locals
+    ctx->pc_tab_dims[set][0] = rows;
+    ctx->pc_tab_dims[set][1] = cols;
     return AB_OK;
 }
 
@@ -315,40 +394,45 @@ int fft2d(ab_ctx *ctx, double2 *buf, int fr, int fc, const PcScratch &s, int inv
     return AB_OK;
 }
 
-int is_constant_or_zero(ab_ctx *ctx, const View &v, const PcScratch &s, bool *out) {
-    const int grid = (int)std::min<int64_t>(kMinMaxPartials, v.rows);
-    hipLaunchKernelGGL(minmax_finite_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, v.p, v.rows, v.cols, v.ld,
-                       (MinMaxPartial *)s.partials);
-    AB_HIP(ctx, hipGetLastError());
-    std::vector<MinMaxPartial> h(grid);
-    AB_HIP(ctx, hipMemcpyAsync(h.data(), s.partials, grid * sizeof(MinMaxPartial), hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    float mn = INFINITY, mx = -INFINITY;
-    unsigned long long cnt = 0;
-    for (const auto &p : h) {
-        mn = std::fmin(mn, p.mn);
-        mx = std::fmax(mx, p.mx);
-        cnt += p.finite;
+// is_constant_or_zero (:143-160) of both planes with one read-back (the reference tests the target only if the reference passes:
+// the result is the same)
+int constant_or_zero2(ab_ctx *ctx, const View &r, const View &t, const PcScratch &s, bool *cr, bool *ct) {
+    const View *v[2] = {&r, &t};
+    int grid[2];
+    MinMaxPartial *part = (MinMaxPartial *)s.partials;
+    for (int k = 0; k < 2; ++k) {
+        grid[k] = (int)std::min<int64_t>(kMinMaxPartials, v[k]->rows);
+        hipLaunchKernelGGL(minmax_finite_kernel, dim3(grid[k]), dim3(kBlock), 0, ctx->stream, v[k]->p, v[k]->rows, v[k]->cols, v[k]->ld,
+                           part + (size_t)k * kMinMaxPartials);
     }
-    *out = cnt < 16 || std::fabs(mx - mn) < 1e-10f;
+    AB_HIP(ctx, hipGetLastError());
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, 2 * kMinMaxPartials * sizeof(MinMaxPartial), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, part, (size_t)(kMinMaxPartials + grid[1]) * sizeof(MinMaxPartial), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bool out[2];
+    for (int k = 0; k < 2; ++k) {
+        const MinMaxPartial *h = (const MinMaxPartial *)pin + (size_t)k * kMinMaxPartials;
+        float mn = INFINITY, mx = -INFINITY;
+        unsigned long long cnt = 0;
+        for (int i = 0; i < grid[k]; ++i) {
+            mn = std::fmin(mn, h[i].mn);
+            mx = std::fmax(mx, h[i].mx);
+            cnt += h[i].finite;
+        }
+        out[k] = cnt < 16 || std::fabs(mx - mn) < 1e-10f;
+    }
+    *cr = out[0];
+    *ct = out[1];
     return AB_OK;
 }
 
 // phase_correlation.rs:105-141
-int correlate_single(ab_ctx *ctx, const View &a, const View &b, const PcScratch &s, double *dx, double *dy, double *conf,
+int correlate_single(ab_ctx *ctx, const View &a, const View &b, PcScratch s, int table_set, double *dx, double *dy, double *conf,
                      double *surface_host) {
     const int rows = a.rows, cols = a.cols;
     const int fr = next_pow2(rows), fc = next_pow2(cols), n = fr * fc;
-    std::vector<double> hy, hx, twr, twc;
-    hann_periodic(rows, hy);
-    hann_periodic(cols, hx);
-    twiddles(fr, twr);
-    twiddles(fc, twc);
-    AB_HIP(ctx, hipMemcpyAsync(s.hann_y, hy.data(), rows * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    AB_HIP(ctx, hipMemcpyAsync(s.hann_x, hx.data(), cols * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    AB_HIP(ctx, hipMemcpyAsync(s.tw_r, twr.data(), twr.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    AB_HIP(ctx, hipMemcpyAsync(s.tw_c, twc.data(), twc.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host tables are locals
+    AB_TRY(pc_tables(ctx, &s, table_set, rows, cols, fr, fc));
     const int g = (n + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(window_pad_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, a.p, rows, cols, a.ld, s.hann_y, s.hann_x, fr, fc, s.fa);
     hipLaunchKernelGGL(window_pad_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, b.p, rows, cols, b.ld, s.hann_y, s.hann_x, fr, fc, s.fb);
@@ -359,42 +443,21 @@ int correlate_single(ab_ctx *ctx, const View &a, const View &b, const PcScratch 
     const int pg = std::min(kPartials, g);
     hipLaunchKernelGGL(scale_peak_kernel, dim3(pg), dim3(kBlock), 0, ctx->stream, s.fa, n, 1.0 / (double)((size_t)fr * fc), s.corr,
                        (PeakPartial *)s.partials);
+    hipLaunchKernelGGL(peak_finish_kernel, dim3(1), dim3(1), 0, ctx->stream, (const PeakPartial *)s.partials, pg, s.fin);
+    hipLaunchKernelGGL(var_kernel, dim3(pg), dim3(kBlock), 0, ctx->stream, s.corr, n, (const PcFin *)s.fin, s.var_partials);
+    hipLaunchKernelGGL(var_finish_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double *)s.var_partials, pg, (const double *)s.corr, fr, fc, s.fin);
     AB_HIP(ctx, hipGetLastError());
-    std::vector<PeakPartial> pp(pg);
-    AB_HIP(ctx, hipMemcpyAsync(pp.data(), s.partials, pg * sizeof(PeakPartial), hipMemcpyDeviceToHost, ctx->stream));
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    double best = -DBL_MAX, sum = 0.0, count = 0.0;
-    int best_idx = 0x7fffffff;
-    for (const auto &p : pp) {
-        if (p.best_idx != 0x7fffffff && (best_idx == 0x7fffffff || p.best > best || (p.best == best && p.best_idx < best_idx))) {
-            best = p.best;
-            best_idx = p.best_idx;
-        }
-        sum += p.sum;
-        count += p.count;
-    }
-    if (best_idx == 0x7fffffff) best_idx = 0;
-    double mean = 0.0, sigma = 0.0;  // normalization.rs:128-161
-    if (count >= 1.0) {
-        mean = sum / count;
-        hipLaunchKernelGGL(var_kernel, dim3(pg), dim3(kBlock), 0, ctx->stream, s.corr, n, mean, (double *)s.partials);
-        AB_HIP(ctx, hipGetLastError());
-        std::vector<double> vp(pg);
-        AB_HIP(ctx, hipMemcpyAsync(vp.data(), s.partials, pg * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        double var_sum = 0.0;
-        for (double v : vp) var_sum += v;
-        sigma = std::sqrt(var_sum / (count > 1.0 ? count - 1.0 : 1.0));
-    }
-    const int py = best_idx / fc, px = best_idx % fc;
-    // the 5 surface samples of the 3-point refinements (subpixel.rs:27-62), wrap-around neighbours
-    const int nb[5] = {py * fc + px, (py == 0 ? fr - 1 : py - 1) * fc + px, (py == fr - 1 ? 0 : py + 1) * fc + px,
-                       py * fc + (px == 0 ? fc - 1 : px - 1), py * fc + (px == fc - 1 ? 0 : px + 1)};
-    double sv[5];
-    for (int i = 0; i < 5; ++i)
-        AB_HIP(ctx, hipMemcpyAsync(&sv[i], s.corr + nb[i], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, sizeof(PcFin), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, s.fin, sizeof(PcFin), hipMemcpyDeviceToHost, ctx->stream));
     if (surface_host) AB_HIP(ctx, hipMemcpyAsync(surface_host, s.corr, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PcFin fin;
+    memcpy(&fin, pin, sizeof fin);
+    const double mean = fin.mean, count = fin.count;
+    const double sigma = count >= 1.0 ? std::sqrt(fin.var_sum / (count > 1.0 ? count - 1.0 : 1.0)) : 0.0;
+    const int py = fin.best_idx / fc, px = fin.best_idx % fc;
+    const double *sv = fin.sv;
     auto refine = [](double center, double prev, double next) {
         const double denom = 2.0 * (2.0 * center - prev - next);
         if (std::fabs(denom) < 1e-15) return 0.0;  // FftFloat::epsilon_val() for f64 is 1e-15 (math/fft.rs)
@@ -431,10 +494,9 @@ int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, i
     AB_TRY(pc_carve(ctx, &s));
     const View r{ref, (int)rows, (int)cols, ref_ld}, t{tgt, (int)rows, (int)cols, tgt_ld};
     bool cr = false, ct = false;
-    AB_TRY(is_constant_or_zero(ctx, r, s, &cr));
-    if (!cr) AB_TRY(is_constant_or_zero(ctx, t, s, &ct));
+    AB_TRY(constant_or_zero2(ctx, r, t, s, &cr, &ct));
     if (cr || ct) return AB_OK;                                                    // :42-48
-    if (rows <= kCoarseMaxDim && cols <= kCoarseMaxDim) return correlate_single(ctx, r, t, s, dx, dy, confidence, nullptr);  // :50-52
+    if (rows <= kCoarseMaxDim && cols <= kCoarseMaxDim) return correlate_single(ctx, r, t, s, 0, dx, dy, confidence, nullptr);  // :50-52
     const double scale_y = (double)rows / (double)kCoarseMaxDim, scale_x = (double)cols / (double)kCoarseMaxDim;
     const int ds_rows = (int)std::min<int64_t>(kCoarseMaxDim, rows), ds_cols = (int)std::min<int64_t>(kCoarseMaxDim, cols);
     // area_downsample's own scale (downsample.rs:13-14) is in/out, which differs from scale_y when a dim <= 512
@@ -446,7 +508,7 @@ int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, i
                        dsy, dsx, s.ds_b);
     AB_HIP(ctx, hipGetLastError());
     double cdx, cdy, cconf;
-    AB_TRY(correlate_single(ctx, View{s.ds_a, ds_rows, ds_cols, ds_cols}, View{s.ds_b, ds_rows, ds_cols, ds_cols}, s, &cdx, &cdy,
+    AB_TRY(correlate_single(ctx, View{s.ds_a, ds_rows, ds_cols, ds_cols}, View{s.ds_b, ds_rows, ds_cols, ds_cols}, s, 0, &cdx, &cdy,
                             &cconf, nullptr));
     const double coarse_dx = cdx * scale_x, coarse_dy = cdy * scale_y;            // :62-64
     const int64_t half = kRefineCropSize / 2, ref_cy = rows / 2, ref_cx = cols / 2;
@@ -465,7 +527,7 @@ int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, i
         return AB_OK;
     }
     double rdx, rdy, rconf;
-    AB_TRY(correlate_single(ctx, rc, tc, s, &rdx, &rdy, &rconf, nullptr));
+    AB_TRY(correlate_single(ctx, rc, tc, s, 1, &rdx, &rdy, &rconf, nullptr));
     *dx = coarse_dx + rdx;
     *dy = coarse_dy + rdy;
     *confidence = rconf;
@@ -504,7 +566,7 @@ int ab_correlate_single(ab_ctx *ctx, const ab_plane *a, const ab_plane *b, ab_ph
         rc = pc_carve(ctx, &s);
         if (rc == AB_OK)
             rc = correlate_single(ctx, View{sa.dptr, (int)sa.rows, (int)sa.cols, sa.cols}, View{sb.dptr, (int)sb.rows, (int)sb.cols, sb.cols},
-                                  s, &out->dx, &out->dy, &out->confidence, surface_host);
+                                  s, 0, &out->dx, &out->dy, &out->confidence, surface_host);
         ab_stage_release(ctx, &sb);
     }
     ab_stage_release(ctx, &sa);
