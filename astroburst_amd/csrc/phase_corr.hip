@@ -226,11 +226,16 @@ struct PcFin {
     double mean, count, var_sum;
     double sv[5];
 };
-__global__ void peak_finish_kernel(const PeakPartial *__restrict__ pp, int pg, PcFin *fin) {
+// (a workgroup fetches the partials into LDS together; one thread then walks them in order: 256 dependent global loads took 60 us)
+__global__ __launch_bounds__(256) void peak_finish_kernel(const PeakPartial *__restrict__ pp, int pg, PcFin *fin) {
+    __shared__ PeakPartial sh[256];
+    if ((int)threadIdx.x < pg) sh[threadIdx.x] = pp[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double best = -DBL_MAX, sum = 0.0, count = 0.0;
     int best_idx = 0x7fffffff;
     for (int i = 0; i < pg; ++i) {
-        const PeakPartial p = pp[i];
+        const PeakPartial p = sh[i];
         if (p.best_idx != 0x7fffffff && (best_idx == 0x7fffffff || p.best > best || (p.best == best && p.best_idx < best_idx))) {
             best = p.best;
             best_idx = p.best_idx;
@@ -242,10 +247,14 @@ __global__ void peak_finish_kernel(const PeakPartial *__restrict__ pp, int pg, P
     fin->count = count;
     fin->mean = count >= 1.0 ? sum / count : 0.0;  // normalization.rs:128-161
 }
-__global__ void var_finish_kernel(const double *__restrict__ vp, int pg, const double *__restrict__ corr, int fr, int fc, PcFin *fin) {
+__global__ __launch_bounds__(256) void var_finish_kernel(const double *__restrict__ vp, int pg, const double *__restrict__ corr, int fr, int fc, PcFin *fin) {
+    __shared__ double sh[256];
+    if ((int)threadIdx.x < pg) sh[threadIdx.x] = vp[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double var_sum = 0.0;
     if (fin->count >= 1.0)
-        for (int i = 0; i < pg; ++i) var_sum += vp[i];
+        for (int i = 0; i < pg; ++i) var_sum += sh[i];
     fin->var_sum = var_sum;
     const int py = fin->best_idx / fc, px = fin->best_idx % fc;
     // the 5 surface samples of the 3-point refinements (subpixel.rs:27-62), wrap-around neighbours
@@ -443,9 +452,10 @@ int correlate_single(ab_ctx *ctx, const View &a, const View &b, PcScratch s, int
     const int pg = std::min(kPartials, g);
     hipLaunchKernelGGL(scale_peak_kernel, dim3(pg), dim3(kBlock), 0, ctx->stream, s.fa, n, 1.0 / (double)((size_t)fr * fc), s.corr,
                        (PeakPartial *)s.partials);
-    hipLaunchKernelGGL(peak_finish_kernel, dim3(1), dim3(1), 0, ctx->stream, (const PeakPartial *)s.partials, pg, s.fin);
+    static_assert(kPartials <= 256, "the finish kernels stage the partials in 256 LDS slots");
+    hipLaunchKernelGGL(peak_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const PeakPartial *)s.partials, pg, s.fin);
     hipLaunchKernelGGL(var_kernel, dim3(pg), dim3(kBlock), 0, ctx->stream, s.corr, n, (const PcFin *)s.fin, s.var_partials);
-    hipLaunchKernelGGL(var_finish_kernel, dim3(1), dim3(1), 0, ctx->stream, (const double *)s.var_partials, pg, (const double *)s.corr, fr, fc, s.fin);
+    hipLaunchKernelGGL(var_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double *)s.var_partials, pg, (const double *)s.corr, fr, fc, s.fin);
     AB_HIP(ctx, hipGetLastError());
     void *pin = nullptr;
     AB_TRY(ab_pinned(ctx, sizeof(PcFin), &pin));
