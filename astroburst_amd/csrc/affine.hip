@@ -749,12 +749,15 @@ int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std:
     hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, copies,
                        (const RefGroup *)w.groups, w.counts + 1);
     AB_HIP(ctx, hipGetLastError());
-    votes->resize((size_t)copies * kVoteDim * kVoteDim);
-    AB_HIP(ctx, hipMemcpyAsync(votes->data(), w.votes, votes->size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    const size_t words = (size_t)copies * kVoteDim * kVoteDim;
+    void *pin = nullptr;  // (read back into pinned memory: a copy into a std::vector is staged and synchronised by the runtime)
+    AB_TRY(ab_pinned(ctx, words * sizeof(uint32_t), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, w.votes, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t *h = (const uint32_t *)pin;
+    votes->assign(h, h + kVoteDim * kVoteDim);
     for (int c = 1; c < copies; ++c)
-        for (int i = 0; i < kVoteDim * kVoteDim; ++i) (*votes)[i] += (*votes)[(size_t)c * kVoteDim * kVoteDim + i];
-    votes->resize(kVoteDim * kVoteDim);
+        for (int i = 0; i < kVoteDim * kVoteDim; ++i) (*votes)[i] += h[(size_t)c * kVoteDim * kVoteDim + i];
     return AB_OK;
 }
 
