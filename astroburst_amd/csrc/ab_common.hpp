@@ -107,6 +107,7 @@ struct ab_ctx {
     const void *stats_bar = nullptr;
     unsigned int stats_epoch = 0;
     unsigned long long stats_expect = 0;  // the completion marker the last resident launch writes beside its result
+    int stats_aborts = 0;                 // consecutive aborted resident launches: three in a row switch this context to the chain for good
     // phase_corr.hip: the (rows, cols) the two table sets in AB_WS_PHASE_TABLES were built for, and the workspace they live in
     int pc_tab_dims[2][2] = {{0, 0}, {0, 0}};
     const void *pc_tab_ws = nullptr;

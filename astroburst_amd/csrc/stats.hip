@@ -828,6 +828,7 @@ int enqueue_exact_path(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n,
 bool resident_takes(ab_ctx *ctx, const float *data, int64_t n, const uint8_t *u8) {
     const char *e = getenv("AB_STATS_CHAIN");
     if (e && *e && *e != '0') return false;
+    if (ctx->stats_aborts >= 3) return false;  // (fewer CUs than it reports, e.g. a CU mask: every launch would wait out its barrier first)
     const int64_t cus = ctx->cu_count;
     return cus > 0 && n > 0 && (((uintptr_t)data) & 15) == 0 && (((uintptr_t)u8) & 3) == 0 &&
            (n + kResTile - 1) / kResTile <= std::min<int64_t>(cus, kResMaxGrid);
@@ -928,6 +929,7 @@ static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_
         memcpy(&done, (const char *)pin + kDoneAt, sizeof done);
         *aborted = done != ctx->stats_expect;
         if (*aborted) ctx->stats_bar = nullptr;
+        ctx->stats_aborts = *aborted ? ctx->stats_aborts + 1 : 0;
     }
     if (aborted && getenv("AB_STATS_TIMING")) {  // workgroup 0's phase stamps (s_memtime: shader clock cycles)
         Ws w;
