@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_stats_stf.py -m gpu -x -q < /dev/null 2>&1 | grep -E "passed|failed|error" | tail -n 2 > gpurun_out/r03at.txt
-timeout 300 python tools/time_stats.py < /dev/null 2>&1 | tail -n 3 | cut -c1-120 >> gpurun_out/r03at.txt
+timeout 900 python bench.py --host-planes --no-cpu-baseline --steps 5 < /dev/null 2>gpurun_out/r03au.err | tail -n 1 > gpurun_out/r03au_host.json
+timeout 600 python bench.py --mode rowband --force-sharded --no-cpu-baseline --steps 5 < /dev/null 2>>gpurun_out/r03au.err | tail -n 1 > gpurun_out/r03au_rowband.json
+timeout 600 python bench.py --force-sharded --no-cpu-baseline --steps 5 < /dev/null 2>>gpurun_out/r03au.err | tail -n 1 > gpurun_out/r03au_frames.json
