@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python bench.py --host-planes --no-cpu-baseline --steps 5 < /dev/null 2>gpurun_out/r03au.err | tail -n 1 > gpurun_out/r03au_host.json
-timeout 600 python bench.py --mode rowband --force-sharded --no-cpu-baseline --steps 5 < /dev/null 2>>gpurun_out/r03au.err | tail -n 1 > gpurun_out/r03au_rowband.json
-timeout 600 python bench.py --force-sharded --no-cpu-baseline --steps 5 < /dev/null 2>>gpurun_out/r03au.err | tail -n 1 > gpurun_out/r03au_frames.json
+timeout 2400 python -m pytest tests -m gpu -x -q < /dev/null 2>&1 | grep -E "passed|failed|error" | tail -n 3 > gpurun_out/r03x_pytest_gpu.log
+timeout 600 python bench.py > gpurun_out/r03x_bench.json 2> gpurun_out/r03x_bench.err < /dev/null
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r03x_smoke.txt 2>&1 < /dev/null
