@@ -94,6 +94,10 @@ struct ab_ctx {
     std::vector<hipEvent_t> aux_events;
     void *aux_pinned = nullptr;
     size_t aux_pinned_bytes = 0;
+    // the tiles the streaming tile kernel declined (detect.hip): {count, finished blocks, tile ids ...} per stream it is launched
+    // on ([0] the context's stream, [1] the auxiliary one); zeroed once, the fallback kernel leaves it zeroed
+    unsigned int *tile_fail[2] = {nullptr, nullptr};
+    size_t tile_fail_cap[2] = {0, 0};
     // progress / cancel (infra/progress.rs:39-74): the callback is serialised by progress_mu (frame workers tick it too);
     // worker contexts forward to their parent
     ab_progress_cb progress_cb = nullptr;

@@ -138,6 +138,8 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
     for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
     if (ctx->aux_pinned) (void)hipHostFree(ctx->aux_pinned);
+    for (int i = 0; i < 2; ++i)
+        if (ctx->tile_fail[i]) (void)hipFree(ctx->tile_fail[i]);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->warp_stream) (void)hipStreamDestroy(ctx->warp_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

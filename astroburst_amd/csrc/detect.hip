@@ -26,6 +26,7 @@
 #include "ab_common.hpp"
 #include "block_select.hpp"
 #include "tile_bucket.hpp"
+#include "tile_stream.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -154,59 +155,122 @@ __global__ __launch_bounds__(absel::kBlock) void tile_background_kernel(const fl
     if (threadIdx.x == 0) out[blockIdx.x] = res;
 }
 
-// The same statistics from ONE histogram of the tile (tile_bucket.hpp): the product kernel.  tile_background_kernel above is
-// the round-1 radix-select version, kept behind AB_TILE_LEGACY=1 as an in-library cross-check (tests/test_gpu_tile_stats.py runs both).
+// The same statistics from ONE histogram of the tile with the tile's keys held in registers (tile_bucket.hpp): round 2's product
+// kernel, now the FALLBACK of the streaming kernel below (and the whole job behind AB_TILE_RESIDENT=1).  tile_background_kernel
+// above is the round-1 radix-select version, kept behind AB_TILE_LEGACY=1 as an in-library cross-check
+// (tests/test_gpu_tile_stats.py runs all three).
 // (capping the registers at 168 so that another kernel's wave fits beside a tile on every SIMD -- amdgpu_waves_per_eu(3, 3) --
 // spills 65 registers: 104 -> 130 us alone and the registration stage 19.8 -> 21.4 ms)
+// `fail` given: the launch works off the list of tiles the streaming kernel declined ({count, finished blocks, ids ...}; id =
+// plane * tiles-per-plane + tile) with however many blocks it has, and the last block to finish leaves the list empty again.
 __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(const float *__restrict__ img_arg, int rows, int cols, int64_t ld,
-                                                                              int step, int ntx, const ab_pixel_xf xf_arg, TileOut *__restrict__ out,
+                                                                              int step, int ntx, const ab_pixel_xf xf_arg, TileOut *__restrict__ out_arg,
                                                                               const FrameDev *__restrict__ fd,
                                                                               const float *const *__restrict__ many_planes = nullptr,
-                                                                              const ab_pixel_xf *__restrict__ many_xf = nullptr) {
+                                                                              const ab_pixel_xf *__restrict__ many_xf = nullptr,
+                                                                              unsigned int *__restrict__ fail = nullptr, int tiles_per_plane = 0) {
     __shared__ tb::Shared sh;
+    const unsigned int nwork = fail ? fail[0] : 1u;
+#pragma unroll 1
+    for (unsigned int wi = fail ? blockIdx.x : 0u; wi < nwork; wi += gridDim.x) {
+        const float *__restrict__ img = img_arg;
+        TileOut *__restrict__ out = out_arg;
+        unsigned int tile = blockIdx.x, plane = blockIdx.y, per_plane = gridDim.x;
+        if (fail) {
+            const unsigned int id = fail[2 + wi];
+            per_plane = (unsigned int)tiles_per_plane;
+            plane = id / per_plane;
+            tile = id % per_plane;
+        }
+        // many_planes: `plane` names the plane (all of one size), its transform and its row of `out` -- the tiles of a whole
+        // registration batch in ONE launch
+        if (many_planes) {
+            img = many_planes[plane];
+            out += (size_t)plane * per_plane;
+        }
+        const ab_pixel_xf xf = many_planes ? many_xf[plane] : (fd ? fd->xf : xf_arg);
+        const int ty0 = (int)(tile / (unsigned int)ntx) * step, tx0 = (int)(tile % (unsigned int)ntx) * step;
+        const int y1 = min(ty0 + step, rows), x1 = min(tx0 + step, cols);
+        // thread (tx, ty) of the 256 x 2 layout walks column tx0 + tx downwards, two rows per slot: consecutive lanes read
+        // consecutive pixels; 32 loads are in flight before the first key is formed
+        constexpr int kRowPhases = tb::kThreads / 256;
+        const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
+        const int c = tx0 + tx;
+        const bool col_ok = c < x1;
+        tb::Keys K;
+        tb::KeyRange kr;
+        constexpr int kBatch = 32;
+#pragma unroll
+        for (int h = 0; h < tb::kSlots / kBatch; ++h) {
+            float raw[kBatch];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const int r = ty0 + ty + kRowPhases * (h * kBatch + i);
+                raw[i] = (col_ok && r < y1) ? img[(int64_t)r * ld + c] : __builtin_nanf("");
+            }
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+                const float v = ab_px(xf, raw[i]);
+                const uint32_t key = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
+                K.v[(h * kBatch + i) >> 5][(h * kBatch + i) & 31] = key;
+                kr.add(key);
+            }
+        }
+        const tb::TileResult r = tb::tile_stats(K, sh, kr);
+        if (threadIdx.x == 0) {
+            TileOut o;
+            o.median = r.median;
+            o.sigma = r.sigma;
+            o.valid = r.valid;
+            o.pad = 0;
+            out[tile] = o;
+        }
+        __syncthreads();  // (the next tile reuses the shared block)
+    }
+    if (fail && threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&fail[1], 1u) == gridDim.x - 1u) {  // the last block: everything has been read
+            fail[0] = 0u;
+            fail[1] = 0u;
+        }
+    }
+}
+
+// The product kernel (round 4, tile_stream.hpp): nothing per pixel stays on chip -- histogram pass, a plan of the buckets the
+// three clipping rounds will need, a second pass that collects those buckets' keys, the rounds on that list.  Three tiles per
+// CU in flight at ~100 VGPRs each; a tile it cannot settle exactly is appended to `fail` for the kernel above.
+__global__ __launch_bounds__(ts::kThreads) void tile_background_stream_kernel(const float *__restrict__ img_arg, int rows, int cols, int64_t ld, int step,
+                                                                              int ntx, const ab_pixel_xf xf_arg, TileOut *__restrict__ out,
+                                                                              const FrameDev *__restrict__ fd, const float *const *__restrict__ many_planes,
+                                                                              const ab_pixel_xf *__restrict__ many_xf, unsigned int *__restrict__ fail) {
+    __shared__ ts::Shared sh;
     const float *__restrict__ img = img_arg;
-    // many_planes: blockIdx.y names the plane (all of one size), its transform and its row of `out` -- the tiles of a whole
-    // registration batch in ONE launch
     if (many_planes) {
         img = many_planes[blockIdx.y];
         out += (size_t)blockIdx.y * gridDim.x;
     }
     const ab_pixel_xf xf = many_planes ? many_xf[blockIdx.y] : (fd ? fd->xf : xf_arg);
-    const int ty0 = (blockIdx.x / ntx) * step, tx0 = (blockIdx.x % ntx) * step;
-    const int y1 = min(ty0 + step, rows), x1 = min(tx0 + step, cols);
-    // thread (tx, ty) of the 256 x 2 layout walks column tx0 + tx downwards, two rows per slot: consecutive lanes read
-    // consecutive pixels; 32 loads are in flight before the first key is formed
-    constexpr int kRowPhases = tb::kThreads / 256;
-    const int tx = threadIdx.x & 255, ty = threadIdx.x >> 8;
-    const int c = tx0 + tx;
-    const bool col_ok = c < x1;
-    tb::Keys K;
-    tb::KeyRange kr;
-    constexpr int kBatch = 32;
-#pragma unroll
-    for (int h = 0; h < tb::kSlots / kBatch; ++h) {
-        float raw[kBatch];
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            const int r = ty0 + ty + kRowPhases * (h * kBatch + i);
-            raw[i] = (col_ok && r < y1) ? img[(int64_t)r * ld + c] : __builtin_nanf("");
-        }
-#pragma unroll
-        for (int i = 0; i < kBatch; ++i) {
-            const float v = ab_px(xf, raw[i]);
-            const uint32_t key = (__builtin_isfinite(v) && v > 1e-7f) ? __float_as_uint(v) : 0u;  // star_detection.rs:56
-            K.v[(h * kBatch + i) >> 5][(h * kBatch + i) & 31] = key;
-            kr.add(key);
-        }
-    }
-    const tb::TileResult r = tb::tile_stats(K, sh, kr);
+    ts::TileRect r;
+    r.img = img;
+    r.ld = ld;
+    r.y0 = (int)(blockIdx.x / (unsigned int)ntx) * step;
+    r.x0 = (int)(blockIdx.x % (unsigned int)ntx) * step;
+    r.y1 = min(r.y0 + step, rows);
+    r.x1 = min(r.x0 + step, cols);
+    r.vec = ((ld | (int64_t)step | (int64_t)cols) & 3) == 0 && ((uintptr_t)img & 15) == 0;
+    const ts::TileResult res = ts::tile_stats(sh, r, xf);
     if (threadIdx.x == 0) {
-        TileOut o;
-        o.median = r.median;
-        o.sigma = r.sigma;
-        o.valid = r.valid;
-        o.pad = 0;
-        out[blockIdx.x] = o;
+        if (res.declined) {
+            const unsigned int at = atomicAdd(&fail[0], 1u);
+            fail[2 + at] = blockIdx.y * gridDim.x + blockIdx.x;
+        } else {
+            TileOut o;
+            o.median = res.median;
+            o.sigma = res.sigma;
+            o.valid = res.valid;
+            o.pad = 0;
+            out[blockIdx.x] = o;
+        }
     }
 }
 
@@ -815,6 +879,46 @@ int f64_cmp(double a, double b) {  // math/median.rs:15-25
 
 }  // namespace
 
+// {count, finished blocks, ids[tiles]} of the tiles the streaming kernel declines, one per stream the tile kernels run on
+static int tile_fail_buffer(ab_ctx *ctx, int which, size_t tiles, unsigned int **out) {
+    if (tiles + 2 > ctx->tile_fail_cap[which]) {
+        if (ctx->tile_fail[which]) {
+            AB_HIP(ctx, hipDeviceSynchronize());
+            AB_HIP(ctx, hipFree(ctx->tile_fail[which]));
+            ctx->tile_fail[which] = nullptr;
+            ctx->tile_fail_cap[which] = 0;
+        }
+        const size_t cap = tiles + 2 + (tiles >> 1);
+        AB_HIP(ctx, hipMalloc((void **)&ctx->tile_fail[which], cap * sizeof(unsigned int)));
+        AB_HIP(ctx, hipMemset(ctx->tile_fail[which], 0, 2 * sizeof(unsigned int)));  // (synchronous, once: the kernels keep it zeroed)
+        ctx->tile_fail_cap[which] = cap;
+    }
+    *out = ctx->tile_fail[which];
+    return AB_OK;
+}
+
+// The per-tile statistics of `nplanes` planes (grid: tiles x planes) on `stream`: the streaming kernel, then the resident one
+// over whatever it declined (a launch of a few hundred blocks that find an empty list and leave).  AB_TILE_RESIDENT=1: the
+// resident kernel alone (round 2 / 3's arrangement).  which: 0 = the context's stream, 1 = its auxiliary stream.
+static int launch_tile_kernels(ab_ctx *ctx, hipStream_t stream, int which, const float *img, int64_t rows, int64_t cols, int64_t ld, int step, int ntx,
+                               int ntiles, int nplanes, const ab_pixel_xf &xf, TileOut *out, const FrameDev *fd, const float *const *many_planes,
+                               const ab_pixel_xf *many_xf) {
+    static const bool resident = getenv("AB_TILE_RESIDENT") != nullptr;
+    if (resident) {
+        hipLaunchKernelGGL(tile_background_bucket_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(tb::kThreads), 0, stream, img, (int)rows, (int)cols,
+                           ld, step, ntx, xf, out, fd, many_planes, many_xf, (unsigned int *)nullptr, 0);
+        return AB_OK;
+    }
+    unsigned int *fail = nullptr;
+    AB_TRY(tile_fail_buffer(ctx, which, (size_t)ntiles * (size_t)nplanes, &fail));
+    hipLaunchKernelGGL(tile_background_stream_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(ts::kThreads), 0, stream, img, (int)rows, (int)cols, ld,
+                       step, ntx, xf, out, fd, many_planes, many_xf, fail);
+    const unsigned int blocks = (unsigned int)std::min<int64_t>((int64_t)ntiles * nplanes, 256);
+    hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(blocks), dim3(tb::kThreads), 0, stream, img, (int)rows, (int)cols, ld, step, ntx, xf, out, fd,
+                       many_planes, many_xf, fail, ntiles);
+    return AB_OK;
+}
+
 // estimate_background (star_detection.rs:32-84) on a device plane
 // per-tile sigma-clipped (median, sigma, valid) of estimate_background's tiling (star_detection.rs:36-68), row-major tiles
 static int tile_stats_host(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, int64_t tile_size, ab_pixel_xf xf,
@@ -833,8 +937,7 @@ static int tile_stats_host(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
         hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(absel::kBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
                            ntx, xf, (TileOut *)pin);
     else
-        hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(ntiles), dim3(tb::kThreads), 0, ctx->stream, img, (int)rows, (int)cols, ld,
-                           step, ntx, xf, (TileOut *)pin, (const FrameDev *)nullptr);
+        AB_TRY(launch_tile_kernels(ctx, ctx->stream, 0, img, rows, cols, ld, step, ntx, ntiles, 1, xf, (TileOut *)pin, nullptr, nullptr, nullptr));
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     out->assign((const TileOut *)pin, (const TileOut *)pin + ntiles);
@@ -914,9 +1017,9 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
         AB_HIP(ctx, hipMemcpyAsync(dxf, stage + ((ptr_bytes + 15) & ~(size_t)15), xf_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
         for (size_t c = 0; c < nchunks; ++c) {
             const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
-            hipLaunchKernelGGL(tile_background_bucket_kernel, dim3((unsigned)ntiles, (unsigned)cnt), dim3(tb::kThreads), 0, ctx->aux_stream, (const float *)nullptr,
-                               (int)rows, (int)cols, cols, step, ntx, ab_pixel_xf(), (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, (const FrameDev *)nullptr,
-                               (const float *const *)(dplanes + first), (const ab_pixel_xf *)(dxf + first));
+            AB_TRY(launch_tile_kernels(ctx, ctx->aux_stream, 1, nullptr, rows, cols, cols, step, ntx, ntiles, (int)cnt, ab_pixel_xf(),
+                                       (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, nullptr, (const float *const *)(dplanes + first),
+                                       (const ab_pixel_xf *)(dxf + first)));
             AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
         }
         AB_HIP(ctx, hipGetLastError());
@@ -1014,8 +1117,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
             hipLaunchKernelGGL(percentiles_reg_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, &jn->po, fd);
         else
             hipLaunchKernelGGL(percentiles_mem_kernel, dim3(1), dim3(1024), 0, ctx->stream, sub, (unsigned int)ns, &jn->po, fd);
-        hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(ntiles), dim3(tb::kThreads), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
-                           ntx, ab_pixel_xf(), tiles, (const FrameDev *)fd);
+        AB_TRY(launch_tile_kernels(ctx, ctx->stream, 0, img, rows, cols, ld, step, ntx, ntiles, 1, ab_pixel_xf(), tiles, fd, nullptr, nullptr));
         hipLaunchKernelGGL(bg_threshold_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const TileOut *)tiles, ntiles, sigma_threshold, fd, &jn->bg);
         AB_HIP(ctx, hipGetLastError());
     } else if (bg_known) {  // the caller has estimate_background's result for this plane and transform already
