@@ -56,7 +56,7 @@ __global__ __launch_bounds__(ts::kThreads) void k_stream(const float *img, int c
         out[3 * blockIdx.x + 2] = res.valid;
         declined[blockIdx.x] = res.declined;
 #ifdef AB_TILE_TIMING
-        for (int i = 0; i < 8; ++i) phases[8 * blockIdx.x + i] = sh.t_phase[i];
+        for (int i = 0; i < 16; ++i) phases[16 * blockIdx.x + i] = sh.t_phase[i];
 #endif
     }
 }
@@ -97,7 +97,7 @@ int main(int argc, char **argv) {
     hipMalloc(&o_res, ntiles * 3 * 8);
     hipMalloc(&o_str, ntiles * 3 * 8);
     hipMalloc(&decl, ntiles * 4);
-    hipMalloc(&ph, ntiles * 8 * 8);
+    hipMalloc(&ph, ntiles * 16 * 8);
     hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -124,7 +124,7 @@ int main(int argc, char **argv) {
            ms_str * 1000.0f / reps / frames);
     std::vector<double> a(ntiles * 3), b(ntiles * 3);
     std::vector<int> dc(ntiles);
-    std::vector<long long> p(ntiles * 8);
+    std::vector<long long> p(ntiles * 16);
     hipMemcpy(a.data(), o_res, a.size() * 8, hipMemcpyDeviceToHost);
     hipMemcpy(b.data(), o_str, b.size() * 8, hipMemcpyDeviceToHost);
     hipMemcpy(dc.data(), decl, dc.size() * 4, hipMemcpyDeviceToHost);
@@ -145,13 +145,13 @@ int main(int argc, char **argv) {
     for (int i = 1; i < 16; ++i)
         if (why[i]) printf(" [%d]=%d", i, why[i]);
     printf("\n");
-    const char *names[8] = {"sample", "pass1", "scan", "plan", "zones", "pass2", "rounds", "-"};
+    const char *names[16] = {"sample", "pass1", "scan", "plan", "zones", "pass2", "r:rest", "-", "v:gather", "v:select", "d:geo", "d:first", "d:gather", "d:select", "d:proof", "edges"};
     for (int t = 0; t < 3; ++t) {
         printf("tile %d: median %.6g sigma %.6g |", t, b[3 * t], b[3 * t + 1]);
         long long tot = 0;
-        for (int i = 0; i < 7; ++i) {
-            printf(" %s %lld;", names[i], p[8 * t + i]);
-            tot += p[8 * t + i];
+        for (int i = 0; i < 16; ++i) {
+            printf(" %s %lld;", names[i], p[16 * t + i]);
+            tot += p[16 * t + i];
         }
         printf(" TOTAL %lld\n", tot);
     }
