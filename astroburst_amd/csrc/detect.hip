@@ -283,11 +283,15 @@ __device__ __forceinline__ bool above(float v, double threshold) { return __buil
 // a -1 in the 64 MiB forest: the threshold pass writes P/8 bytes, not 4 P, and `parent` is only defined at labelled pixels
 __device__ __forceinline__ bool labelled(const unsigned int *__restrict__ mask, int j) { return (mask[j >> 5] >> (j & 31)) & 1u; }
 
-// A 1024-thread block owns kInitRounds consecutive sub-spans of 4096 pixels, collects their labelled indices in LDS and
+// A 256-thread block owns kInitRounds consecutive sub-spans of 1024 pixels, collects their labelled indices in LDS and
 // reserves list space with ONE global atomic at the end (or whenever the LDS list could overflow, which needs > 75 % of
 // the pixels above threshold).  With one reservation per 8192 pixels the 2048 same-address atomics-with-return of a
 // 4096^2 frame took 25 of the kernel's 36 us.
-constexpr int kInitBlock = 1024, kInitSub = 4 * kInitBlock, kInitRounds = 8, kInitCap = 4 * kInitSub;
+// Round 4: 256 threads and 16 KB of LDS per block (was 1024 threads, 64 KB).  Alone the kernel takes the same 22 us, but inside a
+// registration batch a 16-wave workgroup waited for a CU with sixteen free wave slots and 64 KB of LDS while the warp's and the
+// tile kernel's small workgroups kept slipping in ahead of it: 110 us on average.  Same-box A/B of the stage: 12.9 -> 12.4 ms;
+// roots_kernel likewise (kRootsBlock 1024 -> 256): another 0.5 - 0.8 ms.
+constexpr int kInitBlock = 256, kInitSub = 4 * kInitBlock, kInitRounds = 16, kInitCap = 4 * kInitSub;
 __global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
                                                                 double threshold_arg, const ab_pixel_xf xf_arg, int *__restrict__ parent,
                                                                 unsigned int *__restrict__ mask, int *__restrict__ plist, unsigned int *nlab,
@@ -415,7 +419,7 @@ struct CompRec {  // what the host needs to finish one star (star_detection.rs:1
 
 // number the component roots (parent[i] == i) among the labelled pixels; one atomic per 1024-thread block and round on the
 // tail (one per WAVE serialised on that single counter: ~2500 x 12 ns per frame)
-constexpr int kRootsBlock = 1024;
+constexpr int kRootsBlock = 256;
 __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist,
                                                             const unsigned int *__restrict__ nlab, int *__restrict__ roots, int *__restrict__ cid,
                                                             unsigned int *nroots, unsigned int cap) {
