@@ -33,7 +33,7 @@ def test_reference_cases(ctx):                                  # phase_correlat
     dx, dy, _ = ctx.phase_correlate(img, img)
     assert abs(dx) < 0.5 and abs(dy) < 0.5
     big = make_pattern(256, 256)
-    dx, dy, _ = ctx.phase_correlate(big, shift_array(big, 4, -5))   # sign per the reference CODE (see the oracle test)
+    dx, dy, _ = ctx.phase_correlate(big, shift_array(big, 4, -5))   # (not the reference's (10, -5): see test_hip_against_the_independent_restatement)
     assert abs(dx - 5.0) < 1.0 and abs(dy + 4.0) < 1.0
     nan = make_pattern(64, 64)
     nan[10, 10], nan[20, 30], nan[5, 5] = np.nan, np.inf, -np.inf
@@ -41,6 +41,26 @@ def test_reference_cases(ctx):                                  # phase_correlat
     assert np.isfinite(dx) and np.isfinite(dy)
     const = np.full((64, 64), 100.0, np.float32)
     assert ctx.phase_correlate(const, const) == (0.0, 0.0, 0.0)
+
+
+def test_hip_against_the_independent_restatement(ctx):
+    """The HIP path held to tests/phasecorr_restatement.py (numpy, written from the Rust, nothing shared with the oracle) to 1e-6 px:
+    the reference's three test inputs VERBATIM (phase_correlation.rs:205-220, align.rs:216-223, pair.rs:126-156 -- whose asserted
+    values the reference's own code does not produce, tests/test_oracle_phasecorr_cases.py), and aperiodic fields on either side of
+    the 512 px switch to the coarse-to-fine driver."""
+    import phasecorr_restatement as R
+    from scipy.ndimage import gaussian_filter
+    cases = []
+    for n, (sy, sx) in ((256, (10, -5)), (128, (5, -3)), (128, (6, -4))):
+        p = make_pattern(n, n)
+        cases.append((p, shift_array(p, sy, sx)))
+    base = gaussian_filter(np.random.default_rng(1).standard_normal((1300, 1300)), 2.0).astype(np.float32) * 1000
+    for (r, c), (sy, sx) in [((400, 500), (7, -11)), ((512, 512), (3, 4)), ((520, 300), (2, -3)), ((600, 800), (7, -11)), ((1030, 1030), (-9, 13))]:
+        cases.append((base[40:40 + r, 50:50 + c].copy(), base[40 - sy:40 - sy + r, 50 - sx:50 - sx + c].copy()))
+    for ref, tgt in cases:
+        got, want = ctx.phase_correlate(ref, tgt), R.phase_correlate(ref, tgt)
+        assert abs(got[0] - want[0]) <= 1e-6 and abs(got[1] - want[1]) <= 1e-6, (ref.shape, got, want)
+        assert abs(got[2] - want[2]) <= 1e-6 * max(1.0, abs(want[2])), (ref.shape, got, want)
 
 
 @pytest.mark.parametrize("dims", [((600, 800), (600, 800)), ((520, 300), (520, 300)), ((700, 900), (650, 1000)),

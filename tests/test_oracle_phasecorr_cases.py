@@ -1,13 +1,23 @@
-"""Pin the phase-correlation oracle: its FFT against numpy's (an independent exact DFT), and the
-reference's unit tests (phase_correlation.rs:197-240, downsample.rs:52-67, align.rs:187-223).
+"""Pin the phase-correlation oracle.
 
-SIGN CONVENTION.  The reference computes ifft2(A * conj(B)) with A = fft2(reference),
-B = fft2(target) (complex.rs:27-33, phase_correlation.rs:124-126).  For target(y, x) =
-reference(y - sy, x - sx) that surface peaks at (-sy, -sx) -- checked below against numpy's FFT.
-Three reference tests assert the OPPOSITE sign (phase_correlation.rs:205-220 expects dy = +10 for
-shift_array(img, 10, -5); align.rs:187-223 likewise); by the code's own arithmetic they cannot
-pass, and the reference CI never runs `cargo test`.  As with warp_image, the oracle
-follows the CODE: magnitudes and tolerances are taken from those tests, the sign from the code."""
+WHAT THE REFERENCE HOLDS FOR THIS FUNCTION, AND WHY IT CANNOT PIN IT.  The reference has three tests that feed a shifted copy of
+`make_pattern` to the phase correlation: phase_correlation.rs:205-220 (256 px, shift_array(img, 10, -5), asserts dx = -5 +- 1 and
+dy = +10 +- 1), align.rs:216-223 (128 px, (5, -3), asserts dy = 5 +- 1.5, dx = -3 +- 1.5) and pair.rs:126-156 (128 px, (6, -4),
+asserts an RMSE after alignment).  The reference's CODE does not produce those values, for two reasons that add up:
+  * sign: the code computes ifft2(A conj(B)) with A = fft2(reference), B = fft2(target) (complex.rs:27-33,
+    phase_correlation.rs:124-126), and for target(y, x) = reference(y - sy, x - sx) that surface peaks at (-sy, -sx), minus the
+    applied shift (test_sign_convention_is_the_codes checks this against numpy's FFT);
+  * the pattern: sin(0.3 y) cos(0.2 x) repeats every 20.9 px in y and 31.4 px in x, so a shift of 10 px in y is half a period and
+    the correlation surface of a 128 / 256 px window has several peaks of nearly the same height.
+With the VERBATIM inputs the code returns (dx, dy) = (1.986, -8.309), (0.065, -3.261) and (1.155, -4.355): neither the asserted
+values nor their negation.  The reference's CI never runs `cargo test`, so these tests fail upstream unnoticed.
+
+So the pin is built the only way left: tests/phasecorr_restatement.py is a second, independent restatement of the Rust (numpy,
+numpy's FFT, no code shared with oracle/orc_phasecorr.c), and the oracle -- and in tests/test_gpu_phasecorr.py the HIP path --
+must agree with it to 1e-6 px on the reference's verbatim inputs, on fields up to 512 px (one correlation) and above (the
+coarse-to-fine driver, which returns about -3x the shift: its refinement crop is centred at ref_centre + coarse, i.e. moved AWAY
+from the match, phase_correlation.rs:68-72).  The measured values are asserted too, so that a change of either restatement shows.
+The cases further down that use other inputs than the reference's are labelled as such: they are not transcriptions."""
 import numpy as np
 
 
@@ -57,10 +67,61 @@ def test_sign_convention_is_the_codes(oracle):
     assert abs(dy + 5.0) < 0.5 and abs(dx - 3.0) < 0.5
 
 
-def test_known_integer_shift(oracle):                          # :205-220 (tolerance 1.0; sign per the code)
+def _both(oracle, ref, tgt):
+    """the oracle's (dx, dy, confidence), after holding it to the independent restatement"""
+    import phasecorr_restatement as R
+    got, want = oracle.phase_correlate(ref, tgt), R.phase_correlate(ref, tgt)
+    assert abs(got[0] - want[0]) <= 1e-6 and abs(got[1] - want[1]) <= 1e-6, (got, want)
+    assert abs(got[2] - want[2]) <= 1e-6 * max(1.0, abs(want[2])), (got, want)
+    return got
+
+
+def test_reference_inputs_verbatim_known_integer_shift(oracle):
+    """phase_correlation.rs:205-220, inputs verbatim (256 px, shift_array(img, 10, -5)).  The reference asserts dx = -5 +- 1 and
+    dy = +10 +- 1; its code returns what is asserted here (see the module docstring) -- the upstream test fails."""
     img = make_pattern(256, 256)
-    dx, dy, _ = oracle.phase_correlate(img, shift_array(img, 4, -5))
+    dx, dy, conf = _both(oracle, img, shift_array(img, 10, -5))
+    assert abs(dx - 1.9863165) < 1e-5 and abs(dy + 8.3091065) < 1e-5 and abs(conf - 17.775382) < 1e-4
+    assert not (abs(dx + 5.0) < 1.0 and abs(dy - 10.0) < 1.0)     # the reference's own assertion does not hold for its code
+
+
+def test_reference_inputs_verbatim_estimate_offset(oracle):
+    """align.rs:216-223, inputs verbatim (128 px, shift_array(ref, 5, -3)); the reference asserts dy = 5 +- 1.5, dx = -3 +- 1.5."""
+    ref = make_pattern(128, 128)
+    dx, dy, conf = _both(oracle, ref, shift_array(ref, 5, -3))
+    assert abs(dx - 0.0648178) < 1e-5 and abs(dy + 3.2612459) < 1e-5 and abs(conf - 13.678022) < 1e-4
+    assert not (abs(dy - 5.0) < 1.5 and abs(dx + 3.0) < 1.5)
+
+
+def test_reference_inputs_verbatim_align_pair(oracle):
+    """pair.rs:126-156, inputs verbatim (128 px, shift_array(reference, 6, -4)): the offset align_pair(PhaseCorrelation) would
+    apply.  (The reference then asserts an RMSE < 50 between the reference and the re-shifted target over 20..108; with this
+    offset the frames end up 10 px apart in y instead of aligned.)"""
+    ref = make_pattern(128, 128)
+    dx, dy, conf = _both(oracle, ref, shift_array(ref, 6, -4))
+    assert abs(dx - 1.1547875) < 1e-5 and abs(dy + 4.3546455) < 1e-5 and abs(conf - 9.577215) < 1e-4
+
+
+def test_not_a_transcription_small_shift_on_the_pattern(oracle):
+    """NOT one of the reference's cases: a shift well below half a period of the pattern ((4, -5) at 256 px), where the peak is
+    unambiguous and the code's answer is minus the shift."""
+    img = make_pattern(256, 256)
+    dx, dy, _ = _both(oracle, img, shift_array(img, 4, -5))
     assert abs(dx - 5.0) < 1.0 and abs(dy + 4.0) < 1.0
+
+
+def test_aperiodic_fields_against_the_restatement(oracle):
+    """NOT the reference's inputs: smoothed noise (no periodicity), crops of one field so that the shift is exact.  Up to 512 px
+    the code returns minus the shift; above, about minus three times the shift."""
+    from scipy.ndimage import gaussian_filter
+    base = gaussian_filter(np.random.default_rng(1).standard_normal((1300, 1300)), 2.0).astype(np.float32) * 1000
+    for (r, c), (sy, sx), factor in [((400, 500), (7, -11), 1.0), ((512, 512), (3, 4), 1.0), ((520, 300), (2, -3), None),
+                                     ((600, 800), (7, -11), 3.0), ((1030, 1030), (-9, 13), None)]:
+        ref, tgt = base[40:40 + r, 50:50 + c], base[40 - sy:40 - sy + r, 50 - sx:50 - sx + c]   # tgt(y, x) = ref(y - sy, x - sx)
+        dx, dy, conf = _both(oracle, ref, tgt)
+        assert conf > 100.0
+        if factor is not None:
+            assert abs(dx + factor * sx) < 0.3 * factor and abs(dy + factor * sy) < 0.3 * factor, (dx, dy)
 
 
 def test_nan_no_panic(oracle):                                 # :222-231
@@ -75,9 +136,11 @@ def test_constant_image(oracle):                               # :233-240
     assert oracle.phase_correlate(img, img) == (0.0, 0.0, 0.0)
 
 
-def test_estimate_offset(oracle):                              # align.rs:216-223 (tolerance 1.5; sign per the code)
-    ref = make_pattern(256, 256)            # (the 128 px pattern is too periodic: sin(0.3 y) repeats every 21 px)
-    dx, dy, _ = oracle.phase_correlate(ref, shift_array(ref, 5, -3))
+def test_not_a_transcription_estimate_offset_at_256(oracle):
+    """NOT align.rs:216-223 (that one, verbatim, is above): the same shift (5, -3) on a 256 px pattern, where the window holds
+    enough periods for the true peak to win; the code's answer is minus the shift."""
+    ref = make_pattern(256, 256)
+    dx, dy, _ = _both(oracle, ref, shift_array(ref, 5, -3))
     assert abs(dy + 5.0) < 1.5 and abs(dx - 3.0) < 1.5
 
 
