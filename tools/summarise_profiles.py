@@ -62,7 +62,7 @@ def main(tag, outdir=None, frames=64, pixels=4096 * 4096):
     # ties the counters to the kernel source they were taken from: bench.py reports `traffic` only while this still matches
     import hashlib
     h = hashlib.sha256()
-    for fn in ("stack_sigma_clip.hip", "sortnet_gen.hpp"):
+    for fn in ("stack_sigma_clip.hip", "sortnet_gen.hpp", "sort_ops.hpp"):
         with open(os.path.join(ROOT, "astroburst_amd", "csrc", fn), "rb") as fh:
             h.update(fh.read())
     out["kernel_source_sha256"] = h.hexdigest()
