@@ -28,6 +28,10 @@
 //   * f64 sums: per-thread sequential over a strided slice, then a fixed-shape tree; the
 //     reference's own order is rayon's unspecified reduce tree (stats.rs:252-257).
 #include "ab_common.hpp"
+
+#include <fcntl.h>
+#include <sys/file.h>
+#include <unistd.h>
 #include "stf_device.hpp"
 
 #include <algorithm>
@@ -187,12 +191,25 @@ __global__ __launch_bounds__(kScanBlock) void scan_kernel(const float *__restric
 
 // one workgroup: fixed-shape reduction of the per-workgroup partials (thread t folds partials t, t + 1024, ...)
 // (stride: in units of ScanPartial; the resident kernel keeps every workgroup's partial on a cache line of its own)
+// AGENT: the partials were written by other workgroups of THIS launch (the resident kernel): they are read with device-scope
+// (sc1) loads, the pair of the producers' sc1 stores -- a plain load may be served a line this XCD's L2 kept from an earlier launch
+template <bool AGENT = false>
 __device__ __forceinline__ void reduce_partials(const ScanPartial *p, int np, double *mn, double *mx, double *sum,
                                                 unsigned long long *cnt, int stride = 1) {
     double a = DBL_MAX, b = -DBL_MAX, s = 0.0;
     unsigned long long c = 0;
     for (int i = threadIdx.x; i < np; i += blockDim.x) {
-        const ScanPartial q = p[(size_t)i * stride];
+        ScanPartial q;
+        if constexpr (AGENT) {
+            unsigned long long *src = reinterpret_cast<unsigned long long *>(const_cast<ScanPartial *>(p + (size_t)i * stride));
+            static_assert(sizeof(ScanPartial) == 32, "four 8-byte words");
+            q.mn = __longlong_as_double((long long)__hip_atomic_load(&src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            q.mx = __longlong_as_double((long long)__hip_atomic_load(&src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            q.sum = __longlong_as_double((long long)__hip_atomic_load(&src[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            q.cnt = __hip_atomic_load(&src[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            q = p[(size_t)i * stride];
+        }
         a = fmin(a, q.mn);
         b = fmax(b, q.mx);
         s += q.sum;
@@ -845,20 +862,51 @@ int enqueue_resident(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int
     const unsigned int epoch_base = ctx->stats_epoch;
     ctx->stats_epoch += 8;  // (seven barriers per launch)
     ctx->stats_expect = (unsigned long long)epoch_base + 8u;
-    if (const char *e = getenv("AB_STATS_FORCE_ABORT"); e && *e == '1')  // test hook: the kernel finds the abort flag raised at its first barrier
-        AB_HIP(ctx, hipMemsetAsync(w.res.bar + kBarAbort, 1, 1, ctx->stream));
+    // test hooks.  AB_STATS_FORCE_ABORT=1: the kernel finds the abort flag raised at its first barrier.  =b<k> (k = 1 .. 7): the
+    // LAST workgroup behaves at its k-th barrier as if it had timed out AFTER publishing its arrival -- its peers pass that barrier
+    // and run to the end without it (what a real time-out at the final barrier does)
+    int abort_at = 0;
+    if (const char *e = getenv("AB_STATS_FORCE_ABORT"); e && *e) {
+        if (*e == '1') AB_HIP(ctx, hipMemsetAsync(w.res.bar + kBarAbort, 1, 1, ctx->stream));
+        if (*e == 'b') abort_at = atoi(e + 1);
+    }
     const unsigned grid = (unsigned)((n + kResTile - 1) / kResTile);
-    hipLaunchKernelGGL(stats_resident_kernel, dim3(grid), dim3(kResBlock), 0, ctx->stream, data, n, w.st, w.res, epoch_base, known, kmin, kmax, cfg, u8);
+    hipLaunchKernelGGL(stats_resident_kernel, dim3(grid), dim3(kResBlock), 0, ctx->stream, data, n, w.st, w.res, epoch_base, known, kmin, kmax, cfg, u8, abort_at);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
 
 // One resident kernel at a time per device: a workgroup needs a whole CU (16 waves x 128 registers), so two of them launched
 // together would each hold part of the chip and wait for the rest until the barrier times out.  A caller that finds the lock
-// taken uses the chain.
-std::mutex &resident_lock(int device) {
-    static std::mutex m[64];
-    return m[device & 63];
+// taken uses the chain.  The lock has two halves: a mutex for the threads of this process, and an advisory file lock
+// (flock on /dev/shm/astroburst_resident_<uid>_<device>.lock, non-blocking) for OTHER processes on the same GPU -- several ranks
+// may share one device (tests/multirank_worker.py does).  Where the file cannot be opened the process half alone decides; two
+// processes colliding then costs each a timed-out barrier (0.5 s), the abort flag, the chain's (exact) result, and after three in
+// a row the context stays on the chain (resident_takes): slow, never wrong.
+struct ResidentLock {
+    std::mutex m;
+    int fd = -2;  // -2: not opened yet, -1: unavailable
+    bool try_lock(int device) {
+        if (!m.try_lock()) return false;
+        if (fd == -2) {
+            char path[96];
+            snprintf(path, sizeof path, "/dev/shm/astroburst_resident_%u_%d.lock", (unsigned)getuid(), device);
+            fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+        }
+        if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) {
+            m.unlock();
+            return false;
+        }
+        return true;
+    }
+    void unlock() {
+        if (fd >= 0) (void)flock(fd, LOCK_UN);
+        m.unlock();
+    }
+};
+ResidentLock &resident_lock(int device) {
+    static ResidentLock l[64];
+    return l[device & 63];
 }
 
 // `resident` (nullable): the caller will look at the abort flag after its synchronisation and can re-run the chain, so the
@@ -875,7 +923,7 @@ int stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, int6
         AB_TRY(enqueue_exact_path(ctx, comm, data, n, w, cfg));
     } else {
         const bool known = use_known && std::isfinite(known_min) && std::isfinite(known_max) && known_min < known_max;  // stats.rs:36-38
-        if (resident && !comm && resident_takes(ctx, data, n, u8) && resident_lock(ctx->device).try_lock()) {
+        if (resident && !comm && resident_takes(ctx, data, n, u8) && resident_lock(ctx->device).try_lock(ctx->device)) {
             *resident = true;  // (the caller unlocks after its synchronisation: ResidentGuard)
             AB_TRY(enqueue_resident(ctx, data, n, w, known ? 1 : 0, known_min, known_max, cfg, u8));
         } else {

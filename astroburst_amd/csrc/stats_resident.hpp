@@ -70,7 +70,7 @@ static_assert(kResBlock == kBookBlock, "the resident kernel shares the chain's b
 // before the flag, acquire = L2 invalidate after the poll) measured 2 + 2 us per barrier and workgroup on top of the poll.
 constexpr int kBarAbort = kResMaxGrid;        // u32 index of the abort flag in `bar`
 constexpr int kBarStamps = kResMaxGrid + 32;  // u32 index of the timing stamps (8-byte aligned)
-__device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int epoch, unsigned long long *dbg = nullptr) {
+__device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int epoch, unsigned long long *dbg = nullptr, bool fake_timeout = false) {
     __shared__ int s_ok;
     __builtin_amdgcn_s_waitcnt(0);  // this wave's published stores have been written through
     __syncthreads();
@@ -80,11 +80,11 @@ __device__ __forceinline__ bool grid_barrier(unsigned int *bar, unsigned int epo
         if (t == 0) __hip_atomic_store(&bar[blockIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (dbg && t == 0) dbg[1] = __builtin_amdgcn_s_memtime();
         int ok = 1;
-        unsigned int spins = 0;
+        unsigned int spins = fake_timeout ? 0xfffffff0u : 0u;  // (test hook: this workgroup has arrived -- and gives up at once)
         for (;;) {
             unsigned int m = 0xffffffffu;
             for (unsigned int b = t; b < gridDim.x; b += 64) m = min(m, __hip_atomic_load(&bar[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (__builtin_amdgcn_ballot_w64(m < epoch) == 0) break;
+            if (!fake_timeout && __builtin_amdgcn_ballot_w64(m < epoch) == 0) break;
             if (++spins > 300000u || __hip_atomic_load(&bar[kBarAbort], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                 __hip_atomic_store(&bar[kBarAbort], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
@@ -174,8 +174,13 @@ __device__ __forceinline__ void grid_columns(const unsigned int *slab, unsigned 
         const uint4 *p = reinterpret_cast<const uint4 *>(slab) + 64 * h + l;
 #pragma unroll 8
         for (unsigned int r = q; r < G; r += kResWaves) {
-            const uint4 x = p[(size_t)r * (kSlabRow / 4)];
-            a.x += x.x, a.y += x.y, a.z += x.z, a.w += x.w;
+            // device-scope (sc1) loads, the pair of publish_counts' sc1 stores: the rows are rewritten by every launch, and a plain
+            // load may be served a line this XCD's L2 kept from the launch before (two 8-byte halves: an agent-scope atomic load is
+            // sc1 only up to 8 bytes)
+            unsigned long long *src = reinterpret_cast<unsigned long long *>(const_cast<uint4 *>(p + (size_t)r * (kSlabRow / 4)));
+            const unsigned long long lo = __hip_atomic_load(&src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long hi = __hip_atomic_load(&src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.x += (unsigned int)lo, a.y += (unsigned int)(lo >> 32), a.z += (unsigned int)hi, a.w += (unsigned int)(hi >> 32);
         }
         reinterpret_cast<uint4 *>(s_red)[q * 128 + 64 * h + l] = a;
     }
@@ -233,7 +238,7 @@ __device__ __forceinline__ RankHit join_levels(const RankHit &coarse, const Rank
 
 __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *__restrict__ data, int64_t n, StatsDev *st_out, const ResWs w,
                                                                    unsigned int epoch_base, int known, double kmin, double kmax, ab_auto_stf_config cfg,
-                                                                   unsigned char *__restrict__ u8) {
+                                                                   unsigned char *__restrict__ u8, int abort_at) {
     __shared__ unsigned int lds[kResWaves * kWaveLds];  // the waves' counting regions
     __shared__ unsigned long long s_tot[512];
     __shared__ __attribute__((aligned(16))) unsigned int s_red[kResWaves * 512];
@@ -252,6 +257,10 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
         ++nstamp;
     };
     stamp();
+    auto barrier = [&](unsigned long long *dbg = nullptr) {
+        ++nbar;
+        return grid_barrier(w.bar, nbar, dbg, abort_at != 0 && blockIdx.x == G - 1u && nbar - epoch_base == (unsigned int)abort_at);
+    };
 
     // ---- the workgroup's 65 536 pixels, all loads in flight at once; beyond the plane: NaN (not a valid pixel) ----
     Pix P;
@@ -299,11 +308,11 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
         const bool any = mnf <= mxf;
         publish_partial(any ? (double)mnf : DBL_MAX, any ? (double)mxf : -DBL_MAX, 0.0, 0ull, &w.p1[4 * blockIdx.x]);
         stamp();  // 2: plane in registers, range swept
-        if (!grid_barrier(w.bar, ++nbar)) return;
+        if (!barrier()) return;
         stamp();  // 3: barrier
         double mn, mx, sum;
         unsigned long long cnt;
-        reduce_partials(w.p1, (int)G, &mn, &mx, &sum, &cnt, 4);
+        reduce_partials<true>(w.p1, (int)G, &mn, &mx, &sum, &cnt, 4);
         if (t == 0) {
             s_st.negmin_max[0] = -mn;
             s_st.negmin_max[1] = mx;
@@ -339,12 +348,12 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
             publish_counts(lds, my_row(level), 1);
         }
         stamp();  // 4: VALUE coarse sweep
-        if (!grid_barrier(w.bar, ++nbar, blockIdx.x == 0 ? stamps + 19 : nullptr)) return;  // (+ the barrier's own stamps: 19 .. 22)
+        if (!barrier(blockIdx.x == 0 ? stamps + 19 : nullptr)) return;  // (+ the barrier's own stamps: 19 .. 22)
         stamp();  // 5: barrier
         unsigned long long total;
         {
             double mn, mx, sum;
-            reduce_partials(w.p2, (int)G, &mn, &mx, &sum, &total, 4);
+            reduce_partials<true>(w.p2, (int)G, &mn, &mx, &sum, &total, 4);
             if (t == 0) s_st.sum = sum;
         }
         grid_columns(rows_of(level++), G, 1, s_tot, s_red);
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
                 publish_counts(lds, my_row(level), 1);
             }
             stamp();  // 7: VALUE fine sweep
-            if (!grid_barrier(w.bar, ++nbar)) return;
+            if (!barrier()) return;
             stamp();  // 8: barrier
             grid_columns(rows_of(level++), G, 1, s_tot, s_red);
             const RankHit fv = find_in_256(t < 256 ? s_tot[t] : 0ull, cv.cum - cv.count, half);
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
             publish_counts(lds, my_row(level), 2);
         }
         stamp();  // 9: DEV coarse sweep
-        if (!grid_barrier(w.bar, ++nbar)) return;
+        if (!barrier()) return;
         stamp();  // 10: barrier
         grid_columns(rows_of(level++), G, 2, s_tot, s_red);
         const RankHit cd = find_in_256(t < 256 ? s_tot[t] : 0ull, 0ull, half);  // every valid pixel has a deviation bin: found
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
             publish_counts(lds, my_row(level), 2);
         }
         stamp();  // 11: DEV fine sweep
-        if (!grid_barrier(w.bar, ++nbar)) return;
+        if (!barrier()) return;
         stamp();  // 12: barrier
         grid_columns(rows_of(level++), G, 2, s_tot, s_red);
         const RankHit fd = find_in_256(t < 256 ? s_tot[t] : 0ull, cd.cum - cd.count, half);
@@ -455,13 +464,13 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
             publish_counts(lds, my_row(level), 1);
         }
         stamp();  // 13: MAD coarse sweep
-        if (!grid_barrier(w.bar, ++nbar)) return;
+        if (!barrier()) return;
         stamp();  // 14: barrier
         grid_columns(rows_of(level++), G, 1, s_tot, s_red);
         unsigned long long nbelow;
         {
             double mn, mx, sum;
-            reduce_partials(w.p3, (int)G, &mn, &mx, &sum, &nbelow, 4);
+            reduce_partials<true>(w.p3, (int)G, &mn, &mx, &sum, &nbelow, 4);
         }
         const unsigned long long rank = half > nbelow ? half - nbelow : 0;
         double mad = region_lo;  // rank 0
@@ -483,7 +492,7 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
                     publish_counts(lds, my_row(level), 1);
                 }
                 stamp();  // 15: MAD fine sweep
-                if (!grid_barrier(w.bar, ++nbar)) return;
+                if (!barrier()) return;
                 stamp();  // 16: barrier
                 grid_columns(rows_of(level++), G, 1, s_tot, s_red);
                 const RankHit fm = find_in_256(t < 256 ? s_tot[t] : 0ull, cm.cum - cm.count, rank);
@@ -494,9 +503,8 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
     } else if (t == 0) {
         finish_result(&s_st, 0.0, cfg);
     }
-    if (t == 0) s_st.done = (unsigned long long)epoch_base + 8u;  // the host's proof that this launch ran to the end
     __syncthreads();
-    if (blockIdx.x == 0)
+    if (blockIdx.x == 0)  // (without the completion marker: that is written last, below)
         for (int i = t; i < (int)(sizeof(StatsDev) / 4); i += kResBlock) reinterpret_cast<unsigned int *>(st_out)[i] = reinterpret_cast<const unsigned int *>(&s_st)[i];
     nstamp = 17;
     stamp();  // 17: result written
@@ -524,4 +532,27 @@ __global__ __launch_bounds__(kResBlock) void stats_resident_kernel(const float *
         }
     }
     stamp();  // 18: stretched
+    // ---- completion is a fact about the GRID.  Every workgroup publishes "finished" (epoch base + 8: above this launch's barriers,
+    // below the next launch's) once its part of the u8 plane is stored; workgroup 0 writes the host's completion marker only when it
+    // has seen all of them.  A workgroup that timed out at the LAST barrier after publishing its arrival there lets its peers pass
+    // and finish -- with the marker written by workgroup 0 alone (round 3) the host then took a preview with an unwritten tile for
+    // complete.  Now the marker stays away (the abort flag is up, or workgroup 0's wait runs out) and the host re-runs the chain.
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const unsigned int fin = epoch_base + 8u;
+    if (t == 0) __hip_atomic_store(&w.bar[blockIdx.x], fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && t < 64) {
+        bool all = false;
+        for (unsigned int spins = 0; spins < 300000u; ++spins) {
+            unsigned int m = 0xffffffffu;
+            for (unsigned int b = t; b < G; b += 64) m = min(m, __hip_atomic_load(&w.bar[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (__builtin_amdgcn_ballot_w64(m < fin) == 0) {
+                all = true;
+                break;
+            }
+            if (__hip_atomic_load(&w.bar[kBarAbort], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (all && t == 0) st_out->done = (unsigned long long)fin;  // the host's proof that EVERY workgroup of this launch ran to the end
+    }
 }

@@ -244,3 +244,94 @@ def test_stats_resident_abort_falls_back_to_the_chain(ctx, oracle):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+@pytest.mark.parametrize("barrier", [1, 2, 3, 4, 5, 6, 7])
+def test_stats_resident_timeout_after_arrival_at_any_barrier(ctx, oracle, barrier):
+    """A workgroup that times out at a barrier AFTER publishing its arrival there lets its peers pass.  At the LAST barrier of a
+    launch they then run to the end without it, and with the completion marker written by workgroup 0 alone (round 3) the host took
+    a preview with an unwritten tile for complete.  The hook makes the last workgroup do exactly that at its `barrier`-th barrier
+    (a launch has five to seven; a hook beyond the last one does nothing): statistics and EVERY stretched byte must be the oracle's.
+    The output buffer is poisoned first, so that a tile nobody wrote cannot pass by luck."""
+    import torch
+    rng = np.random.default_rng(50 + barrier)
+    img = sky_image(rng, 2048, 2052)
+    st = oracle.compute_image_stats(img)
+    want = oracle.apply_stf(img, oracle.auto_stf(st), st)
+    old = {k: os.environ.get(k) for k in ("AB_STATS_FORCE_ABORT", "AB_STATS_CHAIN")}
+    os.environ["AB_STATS_FORCE_ABORT"] = f"b{barrier}"
+    os.environ["AB_STATS_CHAIN"] = "0"
+    try:
+        dev = torch.from_numpy(img).cuda()
+        out = torch.full(img.shape, 0x5a, dtype=torch.uint8, device="cuda")
+        u8, gst, _ = ctx.auto_stretch_preview(dev, out=out)
+        check_stats(gst, st)
+        assert np.array_equal(u8.cpu().numpy(), want)
+        os.environ["AB_STATS_FORCE_ABORT"] = "0"               # and the context recovers: the next launch is a clean resident one
+        out.fill_(0x5a)
+        u8, gst, _ = ctx.auto_stretch_preview(dev, out=out)
+        check_stats(gst, st)
+        assert np.array_equal(u8.cpu().numpy(), want)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_stats_resident_soak_alternating_images_under_load(oracle):
+    """The resident engine's grid barrier carries data between workgroups of different XCDs through device-scope stores and
+    loads at addresses that every launch reuses.  500 previews on ONE context, alternating two images whose statistics differ
+    (a stale slab row or partial from the launch before would be the OTHER image's), while a second context keeps the chip busy
+    with warps on its own stream: every result must equal the chain's."""
+    import threading
+    import torch
+    import astroburst_amd as ab
+    rng = np.random.default_rng(123)
+    imgs = [sky_image(rng, 2048, 2052), (sky_image(rng, 2048, 2052, pad=False) * np.float32(1.7) + np.float32(333.0))]
+    old = os.environ.get("AB_STATS_CHAIN")
+    main, load = ab.Context(0), ab.Context(0)
+    try:
+        devs = [torch.from_numpy(im).cuda() for im in imgs]
+        os.environ["AB_STATS_CHAIN"] = "1"
+        want = []
+        for d in devs:
+            u8, st, _ = main.auto_stretch_preview(d)
+            want.append((u8.cpu().numpy().copy(), st))
+        assert want[0][1].median != want[1][1].median
+        os.environ["AB_STATS_CHAIN"] = "0"
+        stop, errs = threading.Event(), []
+
+        def churn():
+            try:
+                src = torch.from_numpy(imgs[0]).cuda()
+                dst = torch.empty_like(src)
+                while not stop.is_set():
+                    load.warp_image(src, (1.0, 0.0005, 0.3, -0.0005, 1.0, -0.2), src.shape[0], src.shape[1], out=dst)
+                    load.synchronize()
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+
+        th = threading.Thread(target=churn)
+        th.start()
+        try:
+            out = torch.empty(imgs[0].shape, dtype=torch.uint8, device="cuda")
+            for it in range(500):
+                k = it & 1
+                u8, st, _ = main.auto_stretch_preview(devs[k], out=out)
+                check_stats(st, want[k][1], exact_mean=True)
+                assert st.mean == want[k][1].mean
+                if it % 25 == 0 or it >= 490:
+                    assert np.array_equal(u8.cpu().numpy(), want[k][0]), it
+        finally:
+            stop.set()
+            th.join()
+        assert not errs, errs
+    finally:
+        main.close()
+        load.close()
+        if old is None:
+            os.environ.pop("AB_STATS_CHAIN", None)
+        else:
+            os.environ["AB_STATS_CHAIN"] = old
