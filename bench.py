@@ -59,6 +59,9 @@ def parse():
                     help="N > 1: 'frames' = BASELINE configs[3] (frame shards, two-level, weak scaling); 'rowband' = exact row bands (strong scaling)")
     ap.add_argument("--config", choices=("C1", "C3", "C5"), default=None,
                     help="a BASELINE.json configuration other than the headline C2: one secondary JSON line (bench_configs.py)")
+    ap.add_argument("--host-staged", action="store_true",
+                    help="DRY RUN of the N > 1 launch line on ONE GPU: every rank on cuda:0, torch.distributed over gloo, the library's host-staged "
+                         "communicator instead of RCCL (which refuses two ranks per device).  The line says so (config.transport); not a scaling figure")
     ap.add_argument("--host-planes", action="store_true",
                     help="also time the step with the 64 frames starting in pinned HOST memory (uploads pipelined with registration): config.host_resident_mpix_s")
     return ap.parse_args()
@@ -147,14 +150,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-GPU run as {args.gpus} GPUs")
-    if torch.cuda.device_count() < 1 or local_rank >= torch.cuda.device_count():
+    if torch.cuda.device_count() < 1 or (local_rank >= torch.cuda.device_count() and not args.host_staged):
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but {torch.cuda.device_count()} device(s) are visible")
+    if args.host_staged:
+        local_rank = 0   # every rank shares the one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if args.host_staged:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
@@ -166,7 +174,12 @@ def main():
     rowband = sharded and args.mode == "rowband"   # (with --force-sharded: one band = the whole image, the same code path)
     # the library's own communicator (RCCL behind the C ABI): rank 0 makes the id, torch.distributed carries it
     comm = None
-    if sharded:
+    if sharded and args.host_staged:
+        comm = ab.Comm.host(ctx, f"bench{os.environ.get('MASTER_PORT', '0')}", world, rank)
+        comm.allreduce(torch.zeros(8, dtype=torch.float32, device=dev))
+        torch.cuda.synchronize()
+        assert comm.size == world and comm.rank == rank and comm.is_host
+    elif sharded:
         uid = torch.zeros(128, dtype=torch.uint8, device=dev)
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(ab.Comm.unique_id()), dtype=torch.uint8))
@@ -269,7 +282,7 @@ def main():
     elapsed = time.perf_counter() - t0
     wall_mark("timed_steps_s")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.host_staged else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     for i in range(args.warmup, args.warmup + args.steps):
@@ -559,6 +572,8 @@ def main():
                        "frames_per_gpu": N, "rows": R, "cols": Cc, "device": name, "cus": cus,
                        "rccl_ranks": (comm.size if comm else 0), "rccl_collectives_per_step": (comm.collectives_issued // nsteps if comm else 0),
                        "devices": dev_names, "mode": ("rowband" if rowband else "frames") if sharded else "single",
+                       **({"transport": f"HOST-STAGED DRY RUN: {world} ranks share ONE GPU (cuda:0), collectives through shared memory, not RCCL / xGMI: "
+                                        "the launch line and the sharded code path executed end to end, not a scaling measurement"} if args.host_staged else {}),
                        "output_mpix_per_s": round((1 if rowband else world) * P / 1e6 / (elapsed / args.steps), 1),
                        "rejected_pixels": rejected, "median": st.median,
                        "measured_copy_GBs": round(copy_gbs, 1), "stage_ms": stage_ms, "registration": reg_info,
