@@ -371,7 +371,10 @@ static void pool_thread(ab_ctx *ctx, ab_worker_pool *p, size_t t) {
         }
         int rc = device_ok ? AB_OK : AB_ERR_HIP;
         if (p->prologue && t == p->active - 1) {  // the extra thread of a job with a prologue runs that and nothing else
-            if (rc == AB_OK) (*p->prologue)();
+            // ALWAYS run it, a thread without a device included: the prologue is what publishes the reference table the job's
+            // workers block on (affine.hip: rt.publish), and its own first HIP call reports the device failure -- skipping it left
+            // them waiting for ever
+            (*p->prologue)();
             std::lock_guard<std::mutex> lk(p->mu);
             p->rcs[t] = rc;
             if (--p->remaining == 0) p->cv_done.notify_all();

@@ -28,6 +28,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -127,6 +128,7 @@ struct HostShm {  // lives at the start of the segment; lock-free atomics on pla
     std::atomic<uint32_t> arrived;  // barrier: arrivals of the current generation
     std::atomic<uint32_t> generation;
     int32_t status[64];             // ab_comm_agree: one word per rank
+    int32_t owner_pid;              // rank 0's process: a segment whose owner is gone is a dead job's, not this one's
 };
 constexpr uint32_t kShmMagic = 0x41424d43u;  // "ABMC"
 constexpr size_t kShmHeader = 4096;
@@ -225,18 +227,31 @@ void reduce_slots(ab_comm *c, void *out, size_t bytes, int dtype, int op) {
     }
 }
 
+// a HIP call inside a host collective that fails on THIS rank: the peers are (or will be) waiting in the collective's barrier for a
+// rank that has left -- raise the segment's abort flag first, so that they return AB_ERR_COMM at once instead of after the time-out
+#define AB_HIP_COMM(ctx, c, call)                                                                       \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) {                                                                       \
+            (c)->dead = true;                                                                         \
+            if ((c)->shm) (c)->shm->aborted.store(1, std::memory_order_release);                      \
+            return ab_set_error((ctx), AB_ERR_HIP, "%s failed inside a host-staged collective: %s (%s:%d); communicator aborted", #call, \
+                                hipGetErrorString(e_), __FILE__, __LINE__);                           \
+        }                                                                                             \
+    } while (0)
+
 int host_allreduce(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t count, size_t elem, int dtype, int op) {
     const size_t slot = (size_t)c->shm->slot_bytes, total = count * elem;
     for (size_t off = 0; off < total; off += slot) {
         const size_t n = std::min(slot, total - off);
-        AB_HIP(ctx, hipMemcpyAsync(c->slot(c->rank), (char *)buf_dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
-        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (also: the previous chunk has left c->tmp)
+        AB_HIP_COMM(ctx, c, hipMemcpyAsync(c->slot(c->rank), (char *)buf_dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP_COMM(ctx, c, hipStreamSynchronize(ctx->stream));  // (also: the previous chunk has left c->tmp)
         AB_TRY(host_barrier(ctx, c, "all-reduce"));
         reduce_slots(c, c->tmp, n, dtype, op);
         AB_TRY(host_barrier(ctx, c, "all-reduce"));  // every rank has read every slot: they may be overwritten
-        AB_HIP(ctx, hipMemcpyAsync((char *)buf_dev + off, c->tmp, n, hipMemcpyHostToDevice, ctx->stream));
+        AB_HIP_COMM(ctx, c, hipMemcpyAsync((char *)buf_dev + off, c->tmp, n, hipMemcpyHostToDevice, ctx->stream));
     }
-    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // c->tmp is free again when the call returns
+    AB_HIP_COMM(ctx, c, hipStreamSynchronize(ctx->stream));  // c->tmp is free again when the call returns
     return AB_OK;
 }
 
@@ -245,13 +260,13 @@ int host_broadcast(ab_ctx *ctx, ab_comm *c, void *buf_dev, size_t bytes, int roo
     for (size_t off = 0; off < bytes; off += slot) {
         const size_t n = std::min(slot, bytes - off);
         if (c->rank == root) {
-            AB_HIP(ctx, hipMemcpyAsync(c->slot(root), (char *)buf_dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
-            AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            AB_HIP_COMM(ctx, c, hipMemcpyAsync(c->slot(root), (char *)buf_dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
+            AB_HIP_COMM(ctx, c, hipStreamSynchronize(ctx->stream));
         }
         AB_TRY(host_barrier(ctx, c, "broadcast"));
         if (c->rank != root) {
-            AB_HIP(ctx, hipMemcpyAsync((char *)buf_dev + off, c->slot(root), n, hipMemcpyHostToDevice, ctx->stream));
-            AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            AB_HIP_COMM(ctx, c, hipMemcpyAsync((char *)buf_dev + off, c->slot(root), n, hipMemcpyHostToDevice, ctx->stream));
+            AB_HIP_COMM(ctx, c, hipStreamSynchronize(ctx->stream));
         }
         AB_TRY(host_barrier(ctx, c, "broadcast"));
     }
@@ -262,12 +277,12 @@ int host_allgather(ab_ctx *ctx, ab_comm *c, const void *send_dev, void *recv_dev
     const size_t slot = (size_t)c->shm->slot_bytes;
     for (size_t off = 0; off < bytes_per_rank; off += slot) {
         const size_t n = std::min(slot, bytes_per_rank - off);
-        AB_HIP(ctx, hipMemcpyAsync(c->slot(c->rank), (const char *)send_dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
-        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AB_HIP_COMM(ctx, c, hipMemcpyAsync(c->slot(c->rank), (const char *)send_dev + off, n, hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP_COMM(ctx, c, hipStreamSynchronize(ctx->stream));
         AB_TRY(host_barrier(ctx, c, "all-gather"));
         for (int r = 0; r < c->size; ++r)
-            AB_HIP(ctx, hipMemcpyAsync((char *)recv_dev + (size_t)r * bytes_per_rank + off, c->slot(r), n, hipMemcpyHostToDevice, ctx->stream));
-        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            AB_HIP_COMM(ctx, c, hipMemcpyAsync((char *)recv_dev + (size_t)r * bytes_per_rank + off, c->slot(r), n, hipMemcpyHostToDevice, ctx->stream));
+        AB_HIP_COMM(ctx, c, hipStreamSynchronize(ctx->stream));
         AB_TRY(host_barrier(ctx, c, "all-gather"));
     }
     return AB_OK;
@@ -435,6 +450,7 @@ int ab_comm_init_rank_host(ab_ctx *ctx, const char *name, int nranks, int rank, 
     if (rank == 0) {  // a fresh segment is zero-filled
         h->nranks = nranks;
         h->slot_bytes = slot;
+        h->owner_pid = (int32_t)getpid();
         h->magic.store(kShmMagic, std::memory_order_release);
     } else {
         while (h->magic.load(std::memory_order_acquire) != kShmMagic) {
@@ -444,6 +460,19 @@ int ab_comm_init_rank_host(ab_ctx *ctx, const char *name, int nranks, int rank, 
                 return ab_set_error(ctx, AB_ERR_COMM, "rank %d: the shared segment was never initialised", rank);
             }
             sched_yield();
+        }
+        // A segment of this name whose rank 0 no longer exists was left by a job that died (before all its ranks had joined, or it
+        // would have been unlinked).  This job's rank 0 has not got to replacing it yet: leave it and look again.  (Joining it --
+        // its `joined` count may even make the communicator look complete -- would put this rank in a different segment from its
+        // own rank 0 for good.)
+        if (h->owner_pid <= 0 || (kill((pid_t)h->owner_pid, 0) != 0 && errno == ESRCH)) {
+            host_detach(c);
+            delete c;
+            if (now_ms() - t0 > default_timeout_ms())
+                return ab_set_error(ctx, AB_ERR_COMM, "rank %d: only a dead job's segment %s%s to join", rank, "/dev/shm/abcomm_", name);
+            timespec ts = {0, 5000000};
+            nanosleep(&ts, nullptr);
+            return ab_comm_init_rank_host(ctx, name, nranks, rank, out);
         }
         if (h->nranks != nranks || h->slot_bytes != slot) {
             const int hn = h->nranks;

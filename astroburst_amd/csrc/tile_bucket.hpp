@@ -96,16 +96,21 @@ struct Keys {
 #ifndef AB_TILE_NO_PINNED_KEYS
 static_assert(kVecs == 4, "read_keys names four register ranges");
 __device__ __forceinline__ void read_keys(const Keys &K, int j, uint32_t (&k)[kVecs]) {
+    // s_set_gpr_idx_on writes M0 (and MODE.gpr_idx_en, which _off restores).  M0 cannot be named in the clobber list (a reserved
+    // register: the compiler only warns and ignores it), so the statement saves and restores it itself: whatever the compiler keeps
+    // in M0 -- LDS-direct bases, readlane selectors, its own indirect indexing -- survives.
+    uint32_t m0_save;
     asm volatile(
-        "s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\t"
+        "s_mov_b32 %4, m0\n\t"
+        "s_set_gpr_idx_on %5, gpr_idx(SRC0)\n\t"
         "v_mov_b32 %0, v104\n\t"
         "v_mov_b32 %1, v136\n\t"
         "v_mov_b32 %2, v168\n\t"
         "v_mov_b32 %3, v200\n\t"
-        "s_set_gpr_idx_off"
-        : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3])
-        : "s"(j), "{v[104:135]}"(K.v[0]), "{v[136:167]}"(K.v[1]), "{v[168:199]}"(K.v[2]), "{v[200:231]}"(K.v[3])
-        );  // (M0 is written: the compiler never keeps a value in it across an asm statement)
+        "s_set_gpr_idx_off\n\t"
+        "s_mov_b32 m0, %4"
+        : "=&v"(k[0]), "=&v"(k[1]), "=&v"(k[2]), "=&v"(k[3]), "=&s"(m0_save)
+        : "s"(j), "{v[104:135]}"(K.v[0]), "{v[136:167]}"(K.v[1]), "{v[168:199]}"(K.v[2]), "{v[200:231]}"(K.v[3]));
 }
 #else
 __device__ __forceinline__ void read_keys(const Keys &K, int j, uint32_t (&k)[kVecs]) {

@@ -232,6 +232,14 @@ def scenario_abort(ab, ctx, comm, rank, nranks, out):
     np.savez(os.path.join(out, f"rank{rank}.npz"), code=np.array([code]), seconds=np.array([time.time() - t0]))
 
 
+def scenario_sum(ab, ctx, comm, rank, nranks, out):
+    """one all-reduce: proves that every rank of the job sits in the same segment"""
+    import torch
+    t = torch.full((1000,), float(rank + 1), dtype=torch.float64, device="cuda")
+    comm.allreduce(t, "sum")
+    np.savez(os.path.join(out, f"rank{rank}.npz"), total=np.array([float(t[0].item())]))
+
+
 def main():
     name, nranks, rank, scenario, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     import astroburst_amd as ab
@@ -239,7 +247,7 @@ def main():
     ctx.use_torch_stream()
     comm = ab.Comm.host(ctx, name, nranks, rank)
     assert comm.is_host and (comm.rank, comm.size) == (rank, nranks)
-    {"all": scenario_all, "fail": scenario_fail, "die": scenario_die, "abort": scenario_abort}[scenario](ab, ctx, comm, rank, nranks, out)
+    {"all": scenario_all, "fail": scenario_fail, "die": scenario_die, "abort": scenario_abort, "sum": scenario_sum}[scenario](ab, ctx, comm, rank, nranks, out)
     comm.close()
     ctx.close()
 

@@ -165,3 +165,41 @@ def test_abort_releases_blocked_peers(tmp_path):
     res = spawn(3, "abort", tmp_path, timeout=120)
     for r in res[:2]:
         assert int(r["code"][0]) == AB_ERR_COMM and float(r["seconds"][0]) < 10.0
+
+
+def test_a_stale_segment_of_the_same_name_does_not_split_the_job(tmp_path):
+    """A job that died before all its ranks had joined leaves /dev/shm/abcomm_<name> behind, initialised.  A non-zero rank of the
+    NEXT job of that name that starts before its rank 0 attaches the stale segment; rank 0 then unlinks it and creates the job's own.
+    The early rank must notice that the name no longer leads to what it mapped and move over (it used to wait out the time-out)."""
+    import signal
+    name = f"s{uuid.uuid4().hex[:12]}"
+    env = dict(os.environ, AB_COMM_TIMEOUT_MS="60000")
+
+    def start(rank, scenario="sum"):
+        return subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), name, "2", str(rank), scenario, str(tmp_path)],
+                                env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    # job A: rank 0 alone; killed while it waits for rank 1 -> a stale, initialised segment with joined = 1
+    a0 = start(0)
+    path = f"/dev/shm/abcomm_{name}"
+    t0 = time.time()
+    while not os.path.exists(path) and time.time() - t0 < 120:
+        time.sleep(0.05)
+    assert os.path.exists(path), "job A's rank 0 never created its segment"
+    time.sleep(1.0)                                   # (past ftruncate + the header's initialisation)
+    a0.send_signal(signal.SIGKILL)
+    a0.wait()
+    assert os.path.exists(path)                       # the stale segment is there
+    # job B: rank 1 FIRST (it finds the stale segment), rank 0 three seconds later
+    b1 = start(1)
+    time.sleep(3.0)
+    b0 = start(0)
+    t0 = time.time()
+    for r, p in ((0, b0), (1, b1)):
+        try:
+            o, _ = p.communicate(timeout=max(1.0, 50.0 - (time.time() - t0)))   # well inside the 60 s communicator time-out
+        except subprocess.TimeoutExpired:
+            b0.kill(), b1.kill()
+            pytest.fail(f"job B's rank {r} still waits: it sits in the stale segment")
+        assert p.returncode == 0, o.decode(errors="replace")[-3000:]
+    for r in (0, 1):
+        assert float(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["total"][0]) == 3.0
