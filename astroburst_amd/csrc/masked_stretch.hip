@@ -217,69 +217,329 @@ int detect_discs(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, doub
     return AB_OK;
 }
 
-double mtf_balance(double median, double target) {  // masked_stretch.rs:232-238
+__host__ __device__ inline double mtf_balance(double median, double target) {  // masked_stretch.rs:232-238
     const double denom = 2.0 * target * median - target - median;
-    if (std::fabs(denom) < 1e-15) return 0.5;
+    if (fabs(denom) < 1e-15) return 0.5;
     const double v = median * (target - 1.0) / denom;
     return v < 0.0001 ? 0.0001 : (v > 0.9999 ? 0.9999 : v);
 }
 
+// ---- masked_stretch_with_mask (:60-118) as ONE device-resident chain -----------------------------------------------------------
+// Round 3 joined the host after every pass of every masked median (three passes per median, four medians per channel) and ran
+// the three channels of masked_stretch_rgb_shared one after another: 9.85 ms for 3 x 8192^2.  Here the loop's scalar state lives
+// in device memory (MsState): a median is three histogram passes (11 / 11 / 10 bits of the f32 pattern of the unmasked positive
+// pixels) each followed by a one-workgroup kernel that picks the rank's bin and narrows the prefix; the last of them also DECIDES
+// the iteration (at_target / stagnated / mtf_balance, the reference's f64 arithmetic); the blend reads the midtone from the state
+// and histograms the first level of the NEXT median on its way out (one pass over the plane less per iteration); every kernel
+// of an iteration that the decision cancelled returns at once.  The host enqueues the whole chain for the configured number of
+// iterations, joins ONCE, and the three channels run on three streams.
+struct MsState {
+    float dmin, inv;  // normalize_to_01's transform (:195-212)
+    int zero_all;
+    uint32_t kmin, kmax;  // ordered keys of the valid pixels' minimum / maximum (range pass)
+    uint32_t prefix_mask, prefix_val;
+    unsigned long long rank, count;
+    double bg, prev_bg;
+    float m;
+    int done, converged;
+    unsigned long long iterations_run;
+};
+constexpr int kPickBlock = 1024;
+
+__device__ __forceinline__ uint32_t ord_key(float v) {  // floats of either sign as monotone unsigned integers
+    const uint32_t b = __float_as_uint(v);
+    return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+__device__ __forceinline__ float from_ord_key(uint32_t u) { return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xffffffffu)); }
+__device__ __forceinline__ bool ms_candidate(float v, float mk) { return mk < 0.5f && __builtin_isfinite(v) && v > 0.0f; }  // :217-221
+
+__global__ void ms_init_kernel(MsState *st, unsigned int *hist) {
+    hist[blockIdx.x * 1024 + threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        MsState z = {};
+        z.kmin = 0xffffffffu;
+        *st = z;
+    }
+}
+
+// minimum / maximum of the valid pixels (compute_image_stats' range: finite and above the padding threshold, stats.rs:10-13)
+__global__ __launch_bounds__(kBlock) void ms_range_kernel(const float *__restrict__ in, int64_t n, MsState *st) {
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float v = in[i];
+        if (__builtin_isfinite(v) && v > 1e-7f) {
+            const uint32_t k = ord_key(v);
+            lo = min(lo, k);
+            hi = max(hi, k);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+    }
+    __shared__ uint32_t s_lo[kBlock / 64], s_hi[kBlock / 64];
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) {
+            lo = min(lo, s_lo[w]);
+            hi = max(hi, s_hi[w]);
+        }
+        if (lo <= hi) {
+            atomicMin(&st->kmin, lo);
+            atomicMax(&st->kmax, hi);
+        }
+    }
+}
+__global__ void ms_range_finish_kernel(MsState *st) {
+    // stats.min / stats.max as f64 of the f32 extremes (0 / 0 without a valid pixel, stats.rs:95-97), then :196-201 in f32
+    const bool any = st->kmin <= st->kmax;
+    const double mn = any ? (double)from_ord_key(st->kmin) : 0.0, mx = any ? (double)from_ord_key(st->kmax) : 0.0;
+    const float range = (float)(mx - mn);
+    st->zero_all = range < 1e-10f;
+    st->dmin = (float)mn;
+    st->inv = st->zero_all ? 0.0f : 1.0f / range;
+}
+
+// a block's share of one level of the select: LDS histogram of the candidates under the current prefix, flushed to `hist`
+struct LevelHist {
+    unsigned int *lds;
+    uint32_t nb, pmask, pval;
+    int shift;
+    __device__ __forceinline__ void begin(unsigned int *l, int nbits, int sh, uint32_t m, uint32_t v) {
+        lds = l;
+        nb = 1u << nbits;
+        shift = sh;
+        pmask = m;
+        pval = v;
+        for (uint32_t i = threadIdx.x; i < nb; i += kBlock) lds[i] = 0;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void add(float v) {
+        const uint32_t key = __float_as_uint(v);
+        if ((key & pmask) == pval) atomicAdd(&lds[(key >> shift) & (nb - 1)], 1u);
+    }
+    __device__ __forceinline__ void end(unsigned int *hist) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nb; i += kBlock)
+            if (lds[i]) atomicAdd(&hist[i], lds[i]);
+    }
+};
+
+// normalize_to_01 (:195-212) + level 0 of the first median
+__global__ __launch_bounds__(kBlock) void ms_normalize_hist0_kernel(const float *__restrict__ in, const float *__restrict__ mask, int64_t n,
+                                                                    const MsState *__restrict__ st, float *__restrict__ out, unsigned int *hist) {
+    __shared__ unsigned int lds[2048];
+    LevelHist H;
+    H.begin(lds, 11, 21, 0u, 0u);
+    const int zero_all = st->zero_all;
+    const float dmin = st->dmin, inv = st->inv;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float v = in[i];
+        float r = 0.0f;
+        if (!zero_all && __builtin_isfinite(v) && !(v <= 0.0f)) {  // masked_stretch.rs:204-210
+            const float t = (v - dmin) * inv;
+            r = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+        }
+        out[i] = r;
+        if (ms_candidate(r, mask[i])) H.add(r);
+    }
+    H.end(hist);
+}
+
+// levels 1 and 2 of a median
+__global__ __launch_bounds__(kBlock) void ms_hist_kernel(const float *__restrict__ work, const float *__restrict__ mask, int64_t n,
+                                                         const MsState *__restrict__ st, unsigned int *hist, int level) {
+    if (st->done || st->count == 0) return;
+    __shared__ unsigned int lds[2048];
+    LevelHist H;
+    H.begin(lds, level == 1 ? 11 : 10, level == 1 ? 10 : 0, st->prefix_mask, st->prefix_val);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float v = work[i];
+        if (ms_candidate(v, mask[i])) H.add(v);
+    }
+    H.end(hist);
+}
+
+// apply_mtf (:240-255) + the mask-weighted blend (:93-100) in place, + level 0 of the next median
+__global__ __launch_bounds__(kBlock) void ms_blend_hist0_kernel(float *__restrict__ work, const float *__restrict__ mask, int64_t n,
+                                                                const MsState *__restrict__ st, float protection, unsigned int *hist) {
+    if (st->done) return;
+    __shared__ unsigned int lds[2048];
+    LevelHist H;
+    H.begin(lds, 11, 21, 0u, 0u);
+    const float m = st->m;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float x = work[i], mk = mask[i];
+        float stretched;
+        if (x <= 0.0f) {
+            stretched = 0.0f;
+        } else if (x >= 1.0f) {
+            stretched = 1.0f;
+        } else {
+            const float denom = (2.0f * m - 1.0f) * x - m;
+            if (fabsf(denom) < 1e-10f) {
+                stretched = x;
+            } else {
+                const float v = (m - 1.0f) * x / denom;
+                stretched = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            }
+        }
+        const float blend = mk * protection;
+        const float r = x * blend + stretched * (1.0f - blend);
+        work[i] = r;
+        if (ms_candidate(r, mk)) H.add(r);
+    }
+    H.end(hist);
+}
+
+// One workgroup after every histogram pass: the bin of the wanted rank, the narrowed prefix, the histogram cleared for the next
+// pass.  Level 0 also takes the candidate count (rank = count / 2: the [len / 2] element, :226-229).  Level 2 completes a median
+// and runs the loop's head for iteration `it` (:78-92): it = -1: the median before the loop (:71); it = iterations: the loop has run out.
+__global__ __launch_bounds__(kPickBlock) void ms_pick_kernel(unsigned int *hist, MsState *st, int level, int it, int iterations, double target, double threshold) {
+    if (st->done) return;
+    __shared__ unsigned long long s_wave[kPickBlock / 64];
+    __shared__ uint32_t s_bin;
+    __shared__ unsigned long long s_before;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const uint32_t nb = level == 2 ? 1024u : 2048u;
+    // thread t owns bins 2t, 2t + 1 (levels 0, 1) or bin t (level 2)
+    const unsigned int c0 = level == 2 ? (t < 1024 ? hist[t] : 0u) : hist[2 * t], c1 = level == 2 ? 0u : hist[2 * t + 1];
+    if (level == 2) {
+        if (t < 1024) hist[t] = 0;
+    } else {
+        hist[2 * t] = 0;
+        hist[2 * t + 1] = 0;
+    }
+    unsigned long long own = (unsigned long long)c0 + c1, incl = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    if (t == 0) s_bin = 0xffffffffu;
+    __syncthreads();
+    unsigned long long before = incl - own, total = 0;
+    for (int w = 0; w < kPickBlock / 64; ++w) {
+        if (w < wv) before += s_wave[w];
+        total += s_wave[w];
+    }
+    if (level == 0 && t == 0) {
+        st->count = total;
+        st->rank = total / 2;
+    }
+    __syncthreads();
+    if (level == 0 && total == 0) {  // no candidate: the median is 0.0 (:222-224)
+        if (t == 0) {
+            st->prefix_mask = st->prefix_val = 0u;
+            st->rank = 0;
+        }
+    } else {
+        const unsigned long long rank = level == 0 ? total / 2 : st->rank;
+        if (own && rank >= before && rank < before + own) {  // exactly one thread
+            const bool second = level != 2 && rank >= before + c0;
+            s_bin = (level == 2 ? (uint32_t)t : 2u * t) + (second ? 1u : 0u);
+            s_before = before + (second ? c0 : 0u);
+        }
+        __syncthreads();
+        if (t == 0) {
+            const uint32_t bin = s_bin == 0xffffffffu ? nb - 1 : s_bin;
+            const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+            const uint32_t bits = level == 2 ? 0x3ffu : 0x7ffu;
+            const uint32_t pm = level == 0 ? 0u : st->prefix_mask, pv = level == 0 ? 0u : st->prefix_val;
+            st->prefix_mask = pm | (bits << shift);
+            st->prefix_val = pv | (bin << shift);
+            st->rank = s_bin == 0xffffffffu ? 0ull : rank - s_before;
+        }
+    }
+    if (level != 2) return;
+    __syncthreads();
+    if (t == 0) {
+        const double bg = st->count == 0 ? 0.0 : (double)__uint_as_float(st->prefix_val);
+        if (it < 0) {  // :71
+            st->prev_bg = bg;
+            st->bg = bg;
+            it = 0;
+        } else {
+            st->prev_bg = st->bg;  // (:103 after the blend of the iteration that just ended)
+            st->bg = bg;
+        }
+        if (it >= iterations) {  // the loop has run its course (:77)
+            st->done = 1;
+            return;
+        }
+        // the head of iteration `it` (:78-92)
+        st->iterations_run = (unsigned long long)it + 1ull;
+        const bool at_target = fabs(bg - target) < threshold;
+        const bool stagnated = it > 0 && fabs(bg - st->prev_bg) < threshold * 0.1;
+        if (at_target) {
+            st->converged = 1;
+            st->done = 1;
+        } else if (stagnated) {
+            st->done = 1;
+        } else {
+            st->m = (float)mtf_balance(bg, target);
+        }
+    }
+}
+
+// the whole chain of one channel on `stream`; nothing is synchronised.  scratch: sizeof(MsState) + 2048 words, device memory.
+int masked_stretch_enqueue(ab_ctx *ctx, hipStream_t stream, const float *img, const float *mask, int64_t n, const ab_masked_stretch_config &cfg, float *work,
+                           void *scratch) {
+    MsState *st = (MsState *)scratch;
+    unsigned int *hist = (unsigned int *)((char *)scratch + ((sizeof(MsState) + 63) & ~(size_t)63));
+    hipLaunchKernelGGL(ms_init_kernel, dim3(2), dim3(1024), 0, stream, st, hist);  // (no fill, no copy: the chain's state starts on the device)
+    if (n <= 0) return AB_OK;
+    const int grid = stream_grid(ctx, n);
+    const int iterations = (int)std::min<size_t>(cfg.iterations, 1000000);
+    const float protection = (float)cfg.protection_amount;
+    hipLaunchKernelGGL(ms_range_kernel, dim3(grid), dim3(kBlock), 0, stream, img, n, st);
+    hipLaunchKernelGGL(ms_range_finish_kernel, dim3(1), dim3(1), 0, stream, st);
+    hipLaunchKernelGGL(ms_normalize_hist0_kernel, dim3(grid), dim3(kBlock), 0, stream, img, mask, n, (const MsState *)st, work, hist);
+    auto finish_median = [&](int it) {
+        hipLaunchKernelGGL(ms_pick_kernel, dim3(1), dim3(kPickBlock), 0, stream, hist, st, 0, it, iterations, cfg.target_background, cfg.convergence_threshold);
+        hipLaunchKernelGGL(ms_hist_kernel, dim3(grid), dim3(kBlock), 0, stream, (const float *)work, mask, n, (const MsState *)st, hist, 1);
+        hipLaunchKernelGGL(ms_pick_kernel, dim3(1), dim3(kPickBlock), 0, stream, hist, st, 1, it, iterations, cfg.target_background, cfg.convergence_threshold);
+        hipLaunchKernelGGL(ms_hist_kernel, dim3(grid), dim3(kBlock), 0, stream, (const float *)work, mask, n, (const MsState *)st, hist, 2);
+        hipLaunchKernelGGL(ms_pick_kernel, dim3(1), dim3(kPickBlock), 0, stream, hist, st, 2, it, iterations, cfg.target_background, cfg.convergence_threshold);
+    };
+    finish_median(-1);
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(ms_blend_hist0_kernel, dim3(grid), dim3(kBlock), 0, stream, work, mask, n, (const MsState *)st, protection, hist);
+        finish_median(it + 1);
+    }
+    hipLaunchKernelGGL(clamp01_kernel, dim3(grid), dim3(kBlock), 0, stream, work, n);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+// after the stream has been joined: the loop's outcome (host copy of the state)
+void masked_stretch_result_of(const MsState &st, ab_masked_stretch_result *res) {
+    res->iterations_run = (size_t)st.iterations_run;
+    res->final_background = st.bg;
+    res->converged = st.converged;
+}
+constexpr size_t kMsScratch = ((sizeof(MsState) + 63) & ~(size_t)63) + 2048 * sizeof(unsigned int);
+
 // masked_stretch_with_mask (:60-118) on device planes; `work` receives the result
 int masked_stretch_device(ab_ctx *ctx, const float *img, const float *mask, int64_t n, const ab_masked_stretch_config &cfg, float *work,
-                          ab_masked_stretch_result *res) {
-    const int grid = stream_grid(ctx, n);
-    ab_image_stats st;
-    memset(&st, 0, sizeof st);
-    if (n > 0) AB_TRY(ab_stats_device(ctx, img, n, 0, 0.0, 0.0, &st));
-    const float range = (float)(st.max - st.min);
-    const int zero_all = range < 1e-10f;
-    if (n > 0) {
-        hipLaunchKernelGGL(normalize01_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, img, n, zero_all, (float)st.min,
-                           zero_all ? 0.0f : 1.0f / range, work);
-        AB_HIP(ctx, hipGetLastError());
-    }
-    ab_plane_sel sel;
-    sel.data = work;
-    sel.mask = mask;
-    sel.n = n;
-    auto masked_median = [&](double *out) -> int {  // :214-230 ([len/2] element, 0.0 when empty)
-        uint64_t cnt;
-        float mid;
-        AB_TRY(ab_plane_order_stats(ctx, sel, 0, &cnt, &mid, nullptr));
-        *out = cnt == 0 ? 0.0 : (double)mid;
-        return AB_OK;
-    };
-    const float protection = (float)cfg.protection_amount;
-    double current_bg;  // median of `work` as it stands (the reference recomputes it at :71, :79 and :107)
-    AB_TRY(masked_median(&current_bg));
-    double prev_bg = current_bg;
-    size_t iterations_run = 0;
-    int converged = 0;
-    for (size_t it = 0; it < cfg.iterations; ++it) {
-        iterations_run = it + 1;
-        const double bg = current_bg;
-        const bool at_target = std::fabs(bg - cfg.target_background) < cfg.convergence_threshold;
-        const bool stagnated = it > 0 && std::fabs(bg - prev_bg) < cfg.convergence_threshold * 0.1;
-        if (at_target) {
-            converged = 1;
-            break;
-        }
-        if (stagnated) break;
-        const float m = (float)mtf_balance(bg, cfg.target_background);
-        if (n > 0) {
-            hipLaunchKernelGGL(mtf_blend_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, work, mask, n, m, protection);
-            AB_HIP(ctx, hipGetLastError());
-        }
-        prev_bg = bg;
-        AB_TRY(masked_median(&current_bg));
-    }
-    res->iterations_run = iterations_run;
-    res->final_background = current_bg;
-    res->converged = converged;
-    if (n > 0) {
-        hipLaunchKernelGGL(clamp01_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, work, n);
-        AB_HIP(ctx, hipGetLastError());
-    }
+                          ab_masked_stretch_result *res, Scope &sc) {
+    void *scratch = nullptr;
+    AB_TRY(sc.alloc(&scratch, kMsScratch));
+    AB_TRY(masked_stretch_enqueue(ctx, ctx->stream, img, mask, n, cfg, work, scratch));
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, sizeof(MsState), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, scratch, sizeof(MsState), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    masked_stretch_result_of(*(const MsState *)pin, res);
     return AB_OK;
 }
 
@@ -357,7 +617,7 @@ int ab_masked_stretch_with_mask(ab_ctx *ctx, const ab_plane *img, const ab_plane
     AB_TRY(ab_stage_out_begin(ctx, out, &so));
     sc.outs.push_back(&so);
     memset(res, 0, sizeof *res);
-    AB_TRY(masked_stretch_device(ctx, in.dptr, mk.dptr, in.rows * in.cols, *cfg, so.dptr, res));
+    AB_TRY(masked_stretch_device(ctx, in.dptr, mk.dptr, in.rows * in.cols, *cfg, so.dptr, res, sc));
     if (mask_info) {
         res->stars_masked = mask_info->stars_masked;
         res->mask_coverage = mask_info->coverage_fraction;
@@ -387,7 +647,7 @@ int ab_masked_stretch(ab_ctx *ctx, const ab_plane *img, const ab_masked_stretch_
     AB_TRY(detect_discs(ctx, in.dptr, in.rows, in.cols, mc.detection_sigma, &discs));
     AB_TRY(star_mask_device(ctx, in.dptr, in.rows, in.cols, discs, mc, mask, &mi, sc));
     memset(res, 0, sizeof *res);
-    AB_TRY(masked_stretch_device(ctx, in.dptr, mask, n, *cfg, so.dptr, res));
+    AB_TRY(masked_stretch_device(ctx, in.dptr, mask, n, *cfg, so.dptr, res, sc));
     res->stars_masked = mi.stars_masked;
     res->mask_coverage = mi.coverage_fraction;
     return ab_stage_out_finish(ctx, &so);
@@ -427,11 +687,38 @@ int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab_plane 
     AB_TRY(detect_discs(ctx, lum, rows, cols, mc.detection_sigma, &discs));
     AB_TRY(star_mask_device(ctx, lum, rows, cols, discs, mc, mask, &mi, sc));
     if (shared) *shared = mi;
+    // the three channels as the reference's three-way join (:175-181): one chain each, on the context's stream and its two
+    // auxiliary streams, ordered after the mask by an event and joined by two more
+    char *scratch = nullptr;
+    AB_TRY(sc.alloc((void **)&scratch, 3 * kMsScratch));
+    if (!ctx->aux_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (!ctx->warp_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->warp_stream, hipStreamNonBlocking));
+    hipStream_t streams[3] = {ctx->stream, ctx->aux_stream, ctx->warp_stream};
+    if (!ctx->switch_ev) AB_HIP(ctx, hipEventCreateWithFlags(&ctx->switch_ev, hipEventDisableTiming));
     for (int c = 0; c < 3; ++c) {
         AB_TRY(ab_stage_out_begin(ctx, outs[c], &so[c]));
         sc.outs.push_back(&so[c]);
         memset(&res3[c], 0, sizeof res3[c]);
-        AB_TRY(masked_stretch_device(ctx, in[c].dptr, mask, n, *cfg, so[c].dptr, &res3[c]));
+    }
+    AB_HIP(ctx, hipEventRecord(ctx->switch_ev, ctx->stream));  // mask, staged inputs and outputs are in place
+    int rc = AB_OK;
+    for (int c = 0; c < 3 && rc == AB_OK; ++c) {
+        if (c > 0 && hipStreamWaitEvent(streams[c], ctx->switch_ev, 0) != hipSuccess) rc = ab_set_error(ctx, AB_ERR_HIP, "hipStreamWaitEvent failed");
+        if (rc == AB_OK) rc = masked_stretch_enqueue(ctx, streams[c], in[c].dptr, mask, n, *cfg, so[c].dptr, scratch + (size_t)c * kMsScratch);
+    }
+    // (whatever was enqueued is drained before anything is released, also on an error path)
+    for (int c = 1; c < 3; ++c)
+        if (hipStreamSynchronize(streams[c]) != hipSuccess && rc == AB_OK) rc = ab_set_error(ctx, AB_ERR_HIP, "hipStreamSynchronize failed");
+    void *pin = nullptr;
+    if (rc == AB_OK) rc = ab_pinned(ctx, 3 * sizeof(MsState), &pin);
+    if (rc == AB_OK)
+        for (int c = 0; c < 3; ++c)
+            if (hipMemcpyAsync((char *)pin + (size_t)c * sizeof(MsState), scratch + (size_t)c * kMsScratch, sizeof(MsState), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                rc = ab_set_error(ctx, AB_ERR_HIP, "hipMemcpyAsync failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == AB_OK) rc = ab_set_error(ctx, AB_ERR_HIP, "hipStreamSynchronize failed");
+    if (rc != AB_OK) return rc;
+    for (int c = 0; c < 3; ++c) {
+        masked_stretch_result_of(((const MsState *)pin)[c], &res3[c]);
         res3[c].stars_masked = mi.stars_masked;
         res3[c].mask_coverage = mi.coverage_fraction;
     }
