@@ -37,6 +37,7 @@ enum {
     AB_WS_SHARD,              // (sum f64, count u32) partial planes of the frame-sharded stack (sharded.hip)
     AB_WS_SUBSAMPLE,          // the <= ~100 000-pixel subsample normalize_for_detection takes its percentiles from
     AB_WS_DETECT_DEV,         // FrameDev + the tile statistics of the chained detection (detect.hip)
+    AB_WS_REGISTER_GROUP,     // the target-side matcher workspaces of a group of frames (affine.hip)
     AB_WS_PHASE_TABLES,       // two sets of Hann windows + FFT twiddles of the phase correlation, kept between calls (phase_corr.hip)
     AB_WS_SLOTS
 };
@@ -96,6 +97,7 @@ struct ab_ctx {
     size_t aux_pinned_bytes = 0;
     // the tiles the streaming tile kernel declined (detect.hip): {count, finished blocks, tile ids ...} per stream it is launched
     // on ([0] the context's stream, [1] the auxiliary one); zeroed once, the fallback kernel leaves it zeroed
+    bool det_group_ws = false;  // detect.hip: the detection workspaces were last carved for a group of frames
     unsigned int *tile_fail[2] = {nullptr, nullptr};
     size_t tile_fail_cap[2] = {0, 0};
     // progress / cancel (infra/progress.rs:39-74): the callback is serialised by progress_mu (frame workers tick it too);
@@ -224,6 +226,9 @@ int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, i
                      const ab_stf_params **stf_dev);
 // apply_stf -> u8 with the transform (StfTx) read from device memory
 int ab_stf_u8_device_tx(ab_ctx *ctx, const float *in, int64_t n, const void *tx_dev, uint8_t *out);
+// detect_stars of G frames of one size in lockstep (one launch per step for all of them); bg[f] = {median, sigma} of frame f's background
+int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, int64_t rows, int64_t cols, double sigma_threshold, const ab_pixel_xf *xf,
+                                 const double (*bg)[2], size_t max_keep, std::vector<ab_detected_star> *stars /* [G] */);
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out,
                            ab_pixel_xf xf = ab_pixel_xf(), size_t max_keep = (size_t)-1 /* only the brightest max_keep stars are wanted */,

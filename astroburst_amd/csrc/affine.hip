@@ -391,7 +391,7 @@ struct StarXY {
     double xy[kTriLimit * 2];
 };
 
-__global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
+__device__ __forceinline__ void tri_build_body(const double *__restrict__ xy, int limit, DTri *__restrict__ out, unsigned int *count,
                                                          unsigned int *__restrict__ bin_hist /* nullable; zero on entry */,
                                                          unsigned int *__restrict__ votes_to_clear /* nullable: the vote matrices of the frame */,
                                                          int vote_words) {
@@ -402,10 +402,10 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int
         for (int b = threadIdx.x; b < kTriBins; b += 1024) lhist[b] = 0;
         __syncthreads();
     }
-    const double *xy = stars.xy;
     const int t = blockIdx.x * 1024 + threadIdx.x;
-    const int i = t / (limit * limit), j = (t / limit) % limit, k = t % limit;
-    bool ok = i < limit && i < j && j < k;
+    const int lim = limit >= 3 ? limit : 3;  // (a frame of a group without enough stars: no triangle, no division by zero)
+    const int i = t / (lim * lim), j = (t / lim) % lim, k = t % lim;
+    bool ok = limit >= 3 && i < limit && i < j && j < k;
     DTri tri = {0.0, 0.0, 0u, 0u};
     if (ok) {
         const double xi = xy[2 * i], yi = xy[2 * i + 1], xj = xy[2 * j], yj = xy[2 * j + 1], xk = xy[2 * k], yk = xy[2 * k + 1];
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int
 
 // exclusive scan of the 4096 bucket counts (one 1024-thread block); sets the scatter cursors and re-zeroes the
 // histogram for the next table
-__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ off /* kTriBins + 1 */,
+__device__ __forceinline__ void tri_bin_scan_body(unsigned int *__restrict__ hist, unsigned int *__restrict__ off /* kTriBins + 1 */,
                                                             unsigned int *__restrict__ cursor) {
     __shared__ unsigned int wave_tot[16];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(1024) void tri_bin_scan_kernel(unsigned int *__rest
 // Bucket scatter.  A block ranks its 1024 triangles inside their buckets with LDS atomics and reserves each touched
 // bucket's range with ONE global atomic (per-triangle global cursor atomics-with-return serialised on the dense buckets:
 // 845 triangles in the fullest one, ~12 ns each, 41 us for the kernel).
-__global__ __launch_bounds__(1024) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
+__device__ __forceinline__ void tri_scatter_body(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
                                                            DTri *__restrict__ sorted) {
     __shared__ unsigned int cnt[kTriBins];  // per-bucket count of this block, then the bucket's reserved base
     const unsigned int n = *n_p, i = blockIdx.x * 1024 + threadIdx.x;
@@ -614,7 +614,7 @@ int vote_copies() {
     }();
     return c;
 }
-__global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
+__device__ __forceinline__ void tri_vote_body(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
                                                       unsigned int *__restrict__ votes_out /* copies x 64 x 64, zeroed */, int copies,
                                                       const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
@@ -672,6 +672,48 @@ __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ r
         const unsigned int v = votes[row * kLdsStride + lane];
         if (v) atomicAdd(&mine[row * kVoteDim + lane], v);
     }
+}
+
+// ---- the kernels above as launches: one table, or the target tables of a GROUP of frames (blockIdx.y = frame; see detect.hip) ---
+constexpr int kTriGroupMax = 8;
+struct TriGroup {
+    int n;
+    int limit[kTriGroupMax];
+    DTri *raw[kTriGroupMax], *sorted[kTriGroupMax];
+    unsigned int *count[kTriGroupMax], *bin_hist[kTriGroupMax], *bin_off[kTriGroupMax], *cursor[kTriGroupMax], *votes[kTriGroupMax];
+};
+__global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
+                                                         unsigned int *__restrict__ bin_hist, unsigned int *__restrict__ votes_to_clear, int vote_words) {
+    tri_build_body(stars.xy, limit, out, count, bin_hist, votes_to_clear, vote_words);
+}
+__global__ __launch_bounds__(1024) void tri_build_many_kernel(const TriGroup g, const StarXY *__restrict__ stars, int vote_words) {
+    const int f = blockIdx.y;
+    tri_build_body(stars[f].xy, g.limit[f], g.raw[f], g.count[f], g.bin_hist[f], g.votes[f], vote_words);
+}
+__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ off, unsigned int *__restrict__ cursor) {
+    tri_bin_scan_body(hist, off, cursor);
+}
+__global__ __launch_bounds__(1024) void tri_bin_scan_many_kernel(const TriGroup g) {
+    const int f = blockIdx.y;
+    tri_bin_scan_body(g.bin_hist[f], g.bin_off[f], g.cursor[f]);
+}
+__global__ __launch_bounds__(1024) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
+                                                           DTri *__restrict__ sorted) {
+    tri_scatter_body(in, n_p, cursor, sorted);
+}
+__global__ __launch_bounds__(1024) void tri_scatter_many_kernel(const TriGroup g) {
+    const int f = blockIdx.y;
+    tri_scatter_body(g.raw[f], g.count[f], g.cursor[f], g.sorted[f]);
+}
+__global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, const DTri *__restrict__ tt_sorted,
+                                                      const unsigned int *__restrict__ bin_off, unsigned int *__restrict__ votes_out, int copies,
+                                                      const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
+    tri_vote_body(rt_sorted, nr_p, tt_sorted, bin_off, votes_out, copies, groups, tgt_count_to_clear);
+}
+__global__ __launch_bounds__(64) void tri_vote_many_kernel(const TriGroup g, const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, int copies,
+                                                           const RefGroup *__restrict__ groups) {
+    const int f = blockIdx.y;
+    tri_vote_body(rt_sorted, nr_p, g.sorted[f], g.bin_off[f], g.votes[f], copies, groups, g.count[f]);
 }
 
 // device-side layout of the matcher's workspace (AB_WS_REGISTER)
@@ -758,6 +800,84 @@ int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std:
     votes->assign(h, h + kVoteDim * kVoteDim);
     for (int c = 1; c < copies; ++c)
         for (int i = 0; i < kVoteDim * kVoteDim; ++i) (*votes)[i] += h[(size_t)c * kVoteDim * kVoteDim + i];
+    return AB_OK;
+}
+
+// The target-side matcher state of a group of frames: G x {raw table, bucketed table, counter, bucket arrays, vote matrices}, the
+// frames' star coordinates, kept in AB_WS_REGISTER_GROUP.  Zero where the kernels expect zero (counters, bucket histograms) when the
+// workspace is new; they leave it that way.
+struct MatchGroupWs {
+    TriGroup g;
+    StarXY *stars;
+    unsigned int *votes_all;  // G x copies x 64 x 64, contiguous: one copy brings all of them back
+};
+int match_group_ws(ab_ctx *ctx, int G, MatchGroupWs *w) {
+    const size_t tri_bytes = (size_t)kMaxTris * sizeof(DTri), vote_bytes = (size_t)kVoteCopiesMax * kVoteDim * kVoteDim * sizeof(unsigned int);
+    const size_t word_block = (64 + 3 * (size_t)kTriBins + 64) * sizeof(unsigned int);
+    const size_t per = 2 * tri_bytes + word_block, stars_bytes = (size_t)kTriGroupMax * sizeof(StarXY);
+    const size_t total = (size_t)kTriGroupMax * (per + vote_bytes) + stars_bytes;
+    char *p = nullptr;
+    const void *before = ctx->ws[AB_WS_REGISTER_GROUP];
+    AB_TRY(ab_workspace(ctx, AB_WS_REGISTER_GROUP, total, (void **)&p));
+    if (p != before) AB_HIP(ctx, hipMemsetAsync(p, 0, total, ctx->stream));
+    memset(&w->g, 0, sizeof w->g);
+    w->g.n = G;
+    w->votes_all = (unsigned int *)(p + (size_t)kTriGroupMax * per);
+    w->stars = (StarXY *)(p + (size_t)kTriGroupMax * (per + vote_bytes));
+    for (int f = 0; f < kTriGroupMax; ++f) {
+        char *q = p + (size_t)f * per;
+        w->g.raw[f] = (DTri *)q;
+        w->g.sorted[f] = (DTri *)(q + tri_bytes);
+        unsigned int *u = (unsigned int *)(q + 2 * tri_bytes);
+        w->g.count[f] = u;
+        w->g.bin_hist[f] = u + 64;
+        w->g.bin_off[f] = u + 64 + kTriBins;
+        w->g.cursor[f] = u + 64 + 2 * kTriBins + 32;
+        w->g.votes[f] = w->votes_all + (size_t)f * (vote_bytes / sizeof(unsigned int));
+    }
+    return AB_OK;
+}
+
+// the vote matrices of G targets' star lists against the reference table of `ref_ws`: four launches, one copy in, one copy out
+int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *stars /* [G] */, int G, std::vector<uint32_t> *votes /* [G] */) {
+    MatchGroupWs w;
+    AB_TRY(match_group_ws(ctx, G, &w));
+    const int copies = vote_copies(), vote_words = copies * kVoteDim * kVoteDim;
+    const size_t per_frame_words = (size_t)kVoteCopiesMax * kVoteDim * kVoteDim;
+    void *pin = nullptr;
+    const size_t stars_bytes = (size_t)G * sizeof(StarXY), votes_bytes = (size_t)G * per_frame_words * sizeof(uint32_t);
+    AB_TRY(ab_pinned(ctx, stars_bytes + votes_bytes, &pin));
+    StarXY *hs = (StarXY *)pin;
+    memset(hs, 0, stars_bytes);
+    int max_limit = 0;
+    for (int f = 0; f < G; ++f) {
+        const int limit = (int)std::min<size_t>(stars[f].size(), kTriLimit);
+        w.g.limit[f] = limit;
+        max_limit = std::max(max_limit, limit);
+        for (int i = 0; i < limit; ++i) {
+            hs[f].xy[2 * i] = stars[f][i][0];
+            hs[f].xy[2 * i + 1] = stars[f][i][1];
+        }
+    }
+    for (int f = 0; f < G; ++f) votes[f].assign((size_t)kVoteDim * kVoteDim, 0u);
+    if (max_limit < 3) return AB_OK;
+    AB_HIP(ctx, hipMemcpyAsync(w.stars, hs, stars_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // every table's builder clears that frame's vote matrices (its grid must have the threads: 1024-thread blocks over limit^3 >= 27)
+    const int total = max_limit * max_limit * max_limit, blocks = std::max((total + 1023) / 1024, (vote_words + 1023) / 1024);
+    hipLaunchKernelGGL(tri_build_many_kernel, dim3(blocks, G), dim3(1024), 0, ctx->stream, w.g, (const StarXY *)w.stars, vote_words);
+    hipLaunchKernelGGL(tri_bin_scan_many_kernel, dim3(1, G), dim3(1024), 0, ctx->stream, w.g);
+    hipLaunchKernelGGL(tri_scatter_many_kernel, dim3((kMaxTris + 1023) / 1024, G), dim3(1024), 0, ctx->stream, w.g);
+    hipLaunchKernelGGL(tri_vote_many_kernel, dim3(kVoteBlocks, G), dim3(64), 0, ctx->stream, w.g, (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts,
+                       copies, (const RefGroup *)ref_ws.groups);
+    AB_HIP(ctx, hipGetLastError());
+    uint32_t *hv = (uint32_t *)((char *)pin + stars_bytes);
+    AB_HIP(ctx, hipMemcpyAsync(hv, w.votes_all, votes_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < G; ++f) {
+        const uint32_t *h = hv + (size_t)f * per_frame_words;
+        for (int c = 0; c < copies; ++c)
+            for (int i = 0; i < kVoteDim * kVoteDim; ++i) votes[f][i] += h[(size_t)c * kVoteDim * kVoteDim + i];
+    }
     return AB_OK;
 }
 
@@ -848,6 +968,68 @@ static int register_one(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const f
     return AB_OK;
 }
 
+// G targets against the reference in lockstep (round 4): one launch per step of the detection and of the matcher for all of them,
+// the host geometry frame by frame in between.  out / xf are indexed by frame, bg by position in the group.
+static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const float *ref, const float *const *targets, const size_t *frames, int G,
+                          int64_t rows, int64_t cols, int num_threads, ab_affine_align_result *out, const ab_pixel_xf *xfs, const double (*bg)[2],
+                          const std::function<int(size_t)> &frame_done /* called with a frame's index as soon as out[frame] is final */) {
+    const float *imgs[kTriGroupMax];
+    ab_pixel_xf xf[kTriGroupMax];
+    for (int k = 0; k < G; ++k) {
+        imgs[k] = targets[frames[k]];
+        xf[k] = xfs[frames[k]];
+    }
+    std::vector<ab_detected_star> det[kTriGroupMax];
+    AB_TRY(ab_detect_stars_group_device(wc, imgs, G, rows, cols, kDetectionSigma, xf, bg, kMaxStars, det));
+    std::vector<Pt> ts[kTriGroupMax];
+    for (int k = 0; k < G; ++k)
+        for (const auto &st : det[k]) {
+            if (ts[k].size() >= kMaxStars) break;  // top_n_stars (:272-277): detections are already sorted by flux
+            ts[k].push_back({st.x, st.y});
+        }
+    if (rt.wait() != AB_OK) return ab_set_error(wc, rt.rc, "the reference frame's detection failed");
+    const std::vector<Pt> &rs = rt.stars;
+    bool found[kTriGroupMax] = {};
+    if (rt.ok) {
+        std::vector<Pt> live[kTriGroupMax];  // a frame with too few stars takes no part in the matching (:166-168): an empty list
+        bool any = false;
+        for (int k = 0; k < G; ++k)
+            if (ts[k].size() >= kMinMatchesRigid) {
+                live[k] = ts[k];
+                any = true;
+            }
+        if (any) {
+            std::vector<uint32_t> votes[kTriGroupMax];
+            AB_TRY(gpu_match_group(wc, ref_ws, live, G, votes));
+            for (int k = 0; k < G; ++k) {
+                if (live[k].empty()) continue;
+                const auto matches = matches_from_votes(rs, ts[k], votes[k].data(), kVoteDim);
+                found[k] = transform_from_matches(matches, rows, cols, num_threads, &out[frames[k]]);
+                if (found[k]) AB_TRY(frame_done(frames[k]));  // (its warp starts while the next frame's RANSAC runs)
+            }
+        }
+    }
+    for (int k = 0; k < G; ++k) {
+        if (found[k]) continue;
+        // fallback_phase_correlation (:243-270) on the ORIGINAL planes
+        ab_affine_align_result *o = &out[frames[k]];
+        double dx, dy, conf;
+        AB_TRY(ab_phase_correlate_device(wc, ref, rows, cols, cols, imgs[k], rows, cols, cols, &dx, &dy, &conf));
+        memset(o, 0, sizeof *o);
+        o->transform[0] = 1.0;
+        o->transform[4] = 1.0;
+        if (std::fabs(dx) > (double)cols * kMaxOffsetFraction || std::fabs(dy) > (double)rows * kMaxOffsetFraction || conf < 1.5) {
+            o->method = kIdentity;
+        } else {
+            o->transform[2] = dx;
+            o->transform[5] = dy;
+            o->method = kPhaseCorr;
+        }
+        AB_TRY(frame_done(frames[k]));
+    }
+    return AB_OK;
+}
+
 // align_channel_affine (affine.rs:129-212) of n targets against ONE reference.  The reference's normalisation,
 // detection and triangle table are computed once.  Targets are independent, so they are spread over up to
 // ctx->register_workers host threads, each driving its own HIP stream and workspaces (child contexts cached in
@@ -920,7 +1102,37 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         }
         return AB_OK;
     };
-    const bool inline_run = std::min<size_t>(n, (size_t)std::max(ctx->register_workers, 1)) <= 1;
+    // Round 4: the targets go through detection and matching in GROUPS of kGroup (AB_REGISTER_GROUP, default 4; 1 = frame by frame as
+    // in rounds 2 / 3): the stage was bound by the number of launches the four hardware queues serialise, not by their work.
+    static const int kGroup = [] {
+        const char *e = getenv("AB_REGISTER_GROUP");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > kTriGroupMax ? kTriGroupMax : v);
+    }();
+    const bool grouped = kGroup > 1 && pipe.on && have_xf;
+    const size_t n_groups = grouped ? (n + (size_t)kGroup - 1) / (size_t)kGroup : 0;
+    auto one_group = [&](ab_ctx *wc, size_t gi) -> int {
+        size_t frames[kTriGroupMax];
+        double bgs[kTriGroupMax][2];
+        const size_t f0 = gi * (size_t)kGroup;
+        const int G = (int)std::min<size_t>((size_t)kGroup, n - f0);
+        for (int k = 0; k < G; ++k) {
+            frames[k] = f0 + (size_t)k;
+            AB_TRY(ab_bg_pipeline_get(wc, &pipe, frames[k] + 1, bgs[k]));
+        }
+        const std::function<int(size_t)> warp_frame = [&](size_t f) -> int {
+            if (!aligned) return AB_OK;  // pair.rs:59-61
+            hipStream_t keep = wc->stream;
+            if (warp_stream) wc->stream = warp_stream;
+            const int rc = ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]);
+            wc->stream = keep;
+            return rc;
+        };
+        return register_group(wc, w, rt, ref, targets, frames, G, rows, cols, num_threads, out, xfs.data(), bgs, warp_frame);
+    };
+    const size_t n_jobs = grouped ? n_groups : n;
+    const std::function<int(ab_ctx *, size_t)> job = grouped ? std::function<int(ab_ctx *, size_t)>(one_group) : std::function<int(ab_ctx *, size_t)>(one);
+    const bool inline_run = std::min<size_t>(n_jobs, (size_t)std::max(ctx->register_workers, 1)) <= 1;
     static const bool own_warp_stream = getenv("AB_NO_WARP_STREAM") == nullptr;
     if (!inline_run && aligned && own_warp_stream) {
         if (!ctx->warp_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->warp_stream, "AB_WARP_CU_MASK"));
@@ -929,7 +1141,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     if (inline_run) {  // the reference first, on ctx
         int rc = prepare_reference();
         rt.publish(rc, rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
-        if (rc == AB_OK) rc = ab_parallel_frames(ctx, n, "registration", one);
+        if (rc == AB_OK) rc = ab_parallel_frames(ctx, n_jobs, "registration", job);
         if (pipe.on) (void)hipStreamSynchronize(ctx->aux_stream);  // (an error or a cancel may leave tile launches in flight: they read the caller's frames)
         return rc;
     }
@@ -941,7 +1153,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         prep_rc = prepare_reference();
         rt.publish(prep_rc, prep_rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
     };
-    const int rc = ab_parallel_frames(ctx, n, "registration", one, /*drain_caller_stream=*/false, &prep);
+    const int rc = ab_parallel_frames(ctx, n_jobs, "registration", job, /*drain_caller_stream=*/false, &prep);
     if (warp_stream) (void)hipStreamSynchronize(warp_stream);  // the aligned frames are complete when this call returns
     if (pipe.on) (void)hipStreamSynchronize(ctx->aux_stream);  // (an error or a cancel may leave tile launches in flight: they read the caller's frames)
     return prep_rc != AB_OK ? prep_rc : rc;

@@ -292,7 +292,7 @@ __device__ __forceinline__ bool labelled(const unsigned int *__restrict__ mask, 
 // tile kernel's small workgroups kept slipping in ahead of it: 110 us on average.  Same-box A/B of the stage: 12.9 -> 12.4 ms;
 // roots_kernel likewise (kRootsBlock 1024 -> 256): another 0.5 - 0.8 ms.
 constexpr int kInitBlock = 256, kInitSub = 4 * kInitBlock, kInitRounds = 16, kInitCap = 4 * kInitSub;
-__global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld,
+__device__ __forceinline__ void label_init_body(const float *__restrict__ img, int rows, int cols, int64_t ld,
                                                                 double threshold_arg, const ab_pixel_xf xf_arg, int *__restrict__ parent,
                                                                 unsigned int *__restrict__ mask, int *__restrict__ plist, unsigned int *nlab,
                                                                 int vec_ok, const FrameDev *__restrict__ fd) {
@@ -390,7 +390,7 @@ __device__ __forceinline__ void uf_union(int *parent, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void label_merge_kernel(int rows, int cols, int *parent, const unsigned int *__restrict__ mask,
+__device__ __forceinline__ void label_merge_body(int rows, int cols, int *parent, const unsigned int *__restrict__ mask,
                                                           const int *__restrict__ plist, const unsigned int *__restrict__ nlab) {
     const unsigned int n = *nlab;
     for (unsigned int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
@@ -420,7 +420,7 @@ struct CompRec {  // what the host needs to finish one star (star_detection.rs:1
 // number the component roots (parent[i] == i) among the labelled pixels; one atomic per 1024-thread block and round on the
 // tail (one per WAVE serialised on that single counter: ~2500 x 12 ns per frame)
 constexpr int kRootsBlock = 256;
-__global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist,
+__device__ __forceinline__ void roots_body(const int *__restrict__ parent, const int *__restrict__ plist,
                                                             const unsigned int *__restrict__ nlab, int *__restrict__ roots, int *__restrict__ cid,
                                                             unsigned int *nroots, unsigned int cap) {
     __shared__ unsigned int wave_cnt[kRootsBlock / 64], block_base;
@@ -456,13 +456,13 @@ __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restric
     }
 }
 
-__global__ __launch_bounds__(256) void comp_init_kernel(CompStat *st, unsigned int n) {
+__device__ __forceinline__ void comp_init_body(CompStat *st, unsigned int n) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) st[i] = CompStat{0, 0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff};
 }
 
 // flatten the forest and gather size / bounding box / first interior pixel of every component
-__global__ __launch_bounds__(256) void comp_stats_kernel(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st,
+__device__ __forceinline__ void comp_stats_body(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st,
                                                          const int *__restrict__ plist, const unsigned int *__restrict__ nlab) {
     const unsigned int n = *nlab;
     const int lane = threadIdx.x & 63;
@@ -526,7 +526,7 @@ __device__ __forceinline__ double wave_max(double x) {
 // one wave per component: flux-weighted moments over the bounding box (star_detection.rs:147-189).  Lane l owns
 // the columns x0 + l + 64 k; lane partials are combined by a fixed butterfly, so results are reproducible
 // (the reference accumulates in BFS order: the two agree to ~1e-15 relative).
-__global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
+__device__ __forceinline__ void comp_moments_body(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
                                                            double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
                                                            const FrameDev *__restrict__ fd) {
@@ -584,6 +584,73 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
         }
     }
     if (lane == 0) rec[comp] = out;
+}
+
+// ---- the kernels above as launches: one frame, or a GROUP of frames of one size (blockIdx.y = frame) ------------------------------
+// Round 4: inside a registration batch every frame used to bring its own six small launches, two copies and a fill; four hardware
+// queues serialise them, so the stage was the sum of ~1000 launch durations over four.  A worker now takes kGroup frames through
+// the chain in lockstep: one launch per step for all of them (their blocks side by side), one copy of their counters, one of
+// their records.  The per-frame arguments travel by value in DetGroup.
+constexpr int kGroupMax = 8;
+struct DetGroup {
+    int n;
+    const float *img[kGroupMax];
+    double threshold[kGroupMax], bg_median[kGroupMax];
+    ab_pixel_xf xf[kGroupMax];
+    int *parent[kGroupMax], *cid[kGroupMax], *plist[kGroupMax], *roots[kGroupMax];
+    unsigned int *mask[kGroupMax], *counters[kGroupMax];  // counters[f][0] = components, [1] = labelled pixels
+    CompStat *st[kGroupMax];
+    CompRec *rec[kGroupMax];
+    unsigned int ncomp[kGroupMax];
+};
+__global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld, double threshold_arg,
+                                                                const ab_pixel_xf xf_arg, int *__restrict__ parent, unsigned int *__restrict__ mask,
+                                                                int *__restrict__ plist, unsigned int *nlab, int vec_ok, const FrameDev *__restrict__ fd) {
+    label_init_body(img, rows, cols, ld, threshold_arg, xf_arg, parent, mask, plist, nlab, vec_ok, fd);
+}
+__global__ __launch_bounds__(kInitBlock) void label_init_many_kernel(const DetGroup g, int rows, int cols, int64_t ld, int vec_ok) {
+    const int f = blockIdx.y;
+    label_init_body(g.img[f], rows, cols, ld, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1, vec_ok, nullptr);
+}
+__global__ __launch_bounds__(256) void label_merge_kernel(int rows, int cols, int *parent, const unsigned int *__restrict__ mask, const int *__restrict__ plist,
+                                                          const unsigned int *__restrict__ nlab) {
+    label_merge_body(rows, cols, parent, mask, plist, nlab);
+}
+__global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g, int rows, int cols) {
+    const int f = blockIdx.y;
+    label_merge_body(rows, cols, g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1);
+}
+__global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
+                                                            int *__restrict__ roots, int *__restrict__ cid, unsigned int *nroots, unsigned int cap) {
+    roots_body(parent, plist, nlab, roots, cid, nroots, cap);
+}
+__global__ __launch_bounds__(kRootsBlock) void roots_many_kernel(const DetGroup g, unsigned int cap) {
+    const int f = blockIdx.y;
+    roots_body(g.parent[f], g.plist[f], g.counters[f] + 1, g.roots[f], g.cid[f], g.counters[f], cap);
+}
+__global__ __launch_bounds__(256) void comp_init_kernel(CompStat *st, unsigned int n) { comp_init_body(st, n); }
+__global__ __launch_bounds__(256) void comp_init_many_kernel(const DetGroup g) {
+    const int f = blockIdx.y;
+    comp_init_body(g.st[f], g.ncomp[f]);
+}
+__global__ __launch_bounds__(256) void comp_stats_kernel(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st, const int *__restrict__ plist,
+                                                         const unsigned int *__restrict__ nlab) {
+    comp_stats_body(rows, cols, parent, cid, st, plist, nlab);
+}
+__global__ __launch_bounds__(256) void comp_stats_many_kernel(const DetGroup g, int rows, int cols) {
+    const int f = blockIdx.y;
+    if (g.ncomp[f] == 0) return;
+    comp_stats_body(rows, cols, g.parent[f], g.cid[f], g.st[f], g.plist[f], g.counters[f] + 1);
+}
+__global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
+                                                           const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st,
+                                                           unsigned int ncomp, double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
+                                                           const FrameDev *__restrict__ fd) {
+    comp_moments_body(img, cols, ld, parent, mask, roots, st, ncomp, bg_median_arg, xf_arg, rec, fd);
+}
+__global__ __launch_bounds__(256) void comp_moments_many_kernel(const DetGroup g, int cols, int64_t ld) {
+    const int f = blockIdx.y;
+    comp_moments_body(g.img[f], cols, ld, g.parent[f], g.mask[f], g.roots[f], g.st[f], g.ncomp[f], g.bg_median[f], g.xf[f], g.rec[f], nullptr);
 }
 
 // ---- normalize_for_detection (affine.rs:24-53) ------------------------------------------------------
@@ -1073,6 +1140,97 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
     return AB_OK;
 }
 
+// The host's share of detect_stars (star_detection.rs:147-248) on the components' records: star parameters in discovery order,
+// the stable sort by descending flux, the 3 px dedup, at most max_keep survivors.
+static void finish_stars(const CompRec *recs_begin, unsigned int ncomp, double bg_sigma, size_t max_keep, std::vector<ab_detected_star> *stars) {
+    const CompRec *recs_end = recs_begin + ncomp;
+    // ---- host: the reference finishes the stars in discovery order (ascending first interior pixel = BFS seed order) and then
+    // sorts them stably by descending flux (:215).  The two orders are one: (flux descending, first interior pixel ascending).
+    struct Cand {
+        ab_detected_star s;
+        int first;
+    };
+    std::vector<Cand> cand;
+    cand.reserve(ncomp);
+    for (const CompRec *pc = recs_begin; pc != recs_end; ++pc) {
+        const CompRec *c = pc;
+        if (!(c->first_interior != 0x7fffffff && c->npix >= 3 && c->npix <= 5000 && c->sum_flux > 0.0)) continue;
+        const double sum_flux = c->sum_flux;
+        const double cx = c->sum_x / sum_flux, cy = c->sum_y / sum_flux;
+        const double sigma_star = std::sqrt(c->sum_r2 / (2.0 * sum_flux));
+        const double fwhm = sigma_star * 2.3548200450309493;
+        if (fwhm < 0.5 || fwhm > 30.0) continue;
+        const double ixx = c->sum_xx / sum_flux, iyy = c->sum_yy / sum_flux, ixy = c->sum_xy / sum_flux;
+        const double trace = ixx + iyy;
+        const double det = std::fmax(ixx * iyy - ixy * ixy, 0.0);
+        const double disc = std::sqrt(std::fmax((trace * trace / 4.0) - det, 0.0));
+        const double l1 = trace / 2.0 + disc, l2 = std::fmax(trace / 2.0 - disc, 0.0);
+        double ecc = 0.0;
+        if (l1 > 1e-15) {
+            ecc = std::sqrt(1.0 - l2 / l1);
+            ecc = ecc < 0.0 ? 0.0 : (ecc > 1.0 ? 1.0 : ecc);
+        }
+        Cand k;
+        k.s.x = cx;
+        k.s.y = cy;
+        k.s.flux = sum_flux;
+        k.s.fwhm = fwhm;
+        k.s.eccentricity = ecc;
+        k.s.peak = c->peak;
+        k.s.npix = (uint64_t)c->npix;
+        k.s.snr = bg_sigma <= DBL_EPSILON ? 0.0 : c->peak / bg_sigma;  // confidence.rs:3-8
+        k.first = c->first_interior;
+        cand.push_back(k);
+    }
+    auto before = [](const Cand &a, const Cand &b) { return a.s.flux != b.s.flux ? b.s.flux < a.s.flux : a.first < b.first; };
+    // a caller that wants only the max_keep brightest survivors of the 3 px dedup (registration: 120) does not need the faint
+    // thousands in order: the dedup only ever compares a star with brighter ones, so the brightest 4 max_keep are split off and
+    // sorted first, and the rest only if the dedup ate so many that they are needed after all
+    size_t sorted_upto = cand.size();
+    if (max_keep < cand.size() / 4) {
+        sorted_upto = 4 * max_keep;
+        std::nth_element(cand.begin(), cand.begin() + sorted_upto, cand.end(), before);
+    }
+    std::sort(cand.begin(), cand.begin() + sorted_upto, before);
+    // dedup within 3 px, comparing only against kept stars in the 3 x 3 neighbourhood of 3 px grid cells (:217-248)
+    // (kept stars live in a chained hash table over the 3 px cells: no per-cell allocations)
+    size_t nbuckets = 64;
+    while (nbuckets < 2 * std::min(cand.size(), std::max<size_t>(4 * std::min(max_keep, cand.size()), 64))) nbuckets <<= 1;
+    std::vector<int> head(nbuckets, -1), next(cand.size(), -1);
+    std::vector<uint64_t> cell_of(cand.size());
+    auto key = [](uint64_t gy, uint64_t gx) { return (gy << 32) | gx; };
+    auto bucket = [&](uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 32) & (nbuckets - 1); };
+    stars->reserve(std::min(cand.size(), max_keep));
+    for (size_t i = 0; i < cand.size() && stars->size() < max_keep; ++i) {
+        if (i == sorted_upto) {  // the brightest block did not yield max_keep survivors: order the rest too
+            std::sort(cand.begin() + sorted_upto, cand.end(), before);
+            sorted_upto = cand.size();
+        }
+        const ab_detected_star &fi = cand[i].s;
+        const uint64_t gx = (uint64_t)(fi.x / 3.0), gy = (uint64_t)(fi.y / 3.0);
+        bool too_close = false;
+        for (uint64_t ny = gy ? gy - 1 : 0; ny <= gy + 1 && !too_close; ++ny)
+            for (uint64_t nx = gx ? gx - 1 : 0; nx <= gx + 1 && !too_close; ++nx) {
+                const uint64_t k = key(ny, nx);
+                for (int j = head[bucket(k)]; j >= 0; j = next[j]) {
+                    if (cell_of[j] != k) continue;
+                    const double dx = fi.x - cand[j].s.x, dy = fi.y - cand[j].s.y;
+                    if (dx * dx + dy * dy < 9.0) {
+                        too_close = true;
+                        break;
+                    }
+                }
+            }
+        if (!too_close) {
+            const uint64_t k = key(gy, gx);
+            cell_of[i] = k;
+            next[i] = head[bucket(k)];
+            head[bucket(k)] = (int)i;
+            stars->push_back(fi);
+        }
+    }
+}
+
 // detect_stars (star_detection.rs:86-258) on a device plane; stars sorted by flux, deduplicated
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out, ab_pixel_xf xf, size_t max_keep,
@@ -1184,97 +1342,94 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipMemcpyAsync(pin, drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const CompRec *recs_begin = (const CompRec *)pin, *recs_end = recs_begin + ncomp;
+    const CompRec *recs_begin = (const CompRec *)pin;
 
     trace.mark("moments+D2H");
     if (trace.on) fprintf(stderr, " (%u components)", ncomp);
-    // ---- host: the reference finishes the stars in discovery order (ascending first interior pixel = BFS seed order) and then
-    // sorts them stably by descending flux (:215).  The two orders are one: (flux descending, first interior pixel ascending).
-    struct Cand {
-        ab_detected_star s;
-        int first;
-    };
-    std::vector<Cand> cand;
-    cand.reserve(ncomp);
-    for (const CompRec *pc = recs_begin; pc != recs_end; ++pc) {
-        const CompRec *c = pc;
-        if (!(c->first_interior != 0x7fffffff && c->npix >= 3 && c->npix <= 5000 && c->sum_flux > 0.0)) continue;
-        const double sum_flux = c->sum_flux;
-        const double cx = c->sum_x / sum_flux, cy = c->sum_y / sum_flux;
-        const double sigma_star = std::sqrt(c->sum_r2 / (2.0 * sum_flux));
-        const double fwhm = sigma_star * 2.3548200450309493;
-        if (fwhm < 0.5 || fwhm > 30.0) continue;
-        const double ixx = c->sum_xx / sum_flux, iyy = c->sum_yy / sum_flux, ixy = c->sum_xy / sum_flux;
-        const double trace = ixx + iyy;
-        const double det = std::fmax(ixx * iyy - ixy * ixy, 0.0);
-        const double disc = std::sqrt(std::fmax((trace * trace / 4.0) - det, 0.0));
-        const double l1 = trace / 2.0 + disc, l2 = std::fmax(trace / 2.0 - disc, 0.0);
-        double ecc = 0.0;
-        if (l1 > 1e-15) {
-            ecc = std::sqrt(1.0 - l2 / l1);
-            ecc = ecc < 0.0 ? 0.0 : (ecc > 1.0 ? 1.0 : ecc);
-        }
-        Cand k;
-        k.s.x = cx;
-        k.s.y = cy;
-        k.s.flux = sum_flux;
-        k.s.fwhm = fwhm;
-        k.s.eccentricity = ecc;
-        k.s.peak = c->peak;
-        k.s.npix = (uint64_t)c->npix;
-        k.s.snr = bg_sigma <= DBL_EPSILON ? 0.0 : c->peak / bg_sigma;  // confidence.rs:3-8
-        k.first = c->first_interior;
-        cand.push_back(k);
-    }
-    trace.mark("finish");
-    auto before = [](const Cand &a, const Cand &b) { return a.s.flux != b.s.flux ? b.s.flux < a.s.flux : a.first < b.first; };
-    // a caller that wants only the max_keep brightest survivors of the 3 px dedup (registration: 120) does not need the faint
-    // thousands in order: the dedup only ever compares a star with brighter ones, so the brightest 4 max_keep are split off and
-    // sorted first, and the rest only if the dedup ate so many that they are needed after all
-    size_t sorted_upto = cand.size();
-    if (max_keep < cand.size() / 4) {
-        sorted_upto = 4 * max_keep;
-        std::nth_element(cand.begin(), cand.begin() + sorted_upto, cand.end(), before);
-    }
-    std::sort(cand.begin(), cand.begin() + sorted_upto, before);
-    // dedup within 3 px, comparing only against kept stars in the 3 x 3 neighbourhood of 3 px grid cells (:217-248)
-    // (kept stars live in a chained hash table over the 3 px cells: no per-cell allocations)
-    size_t nbuckets = 64;
-    while (nbuckets < 2 * std::min(cand.size(), std::max<size_t>(4 * std::min(max_keep, cand.size()), 64))) nbuckets <<= 1;
-    std::vector<int> head(nbuckets, -1), next(cand.size(), -1);
-    std::vector<uint64_t> cell_of(cand.size());
-    auto key = [](uint64_t gy, uint64_t gx) { return (gy << 32) | gx; };
-    auto bucket = [&](uint64_t k) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 32) & (nbuckets - 1); };
-    stars->reserve(std::min(cand.size(), max_keep));
-    for (size_t i = 0; i < cand.size() && stars->size() < max_keep; ++i) {
-        if (i == sorted_upto) {  // the brightest block did not yield max_keep survivors: order the rest too
-            std::sort(cand.begin() + sorted_upto, cand.end(), before);
-            sorted_upto = cand.size();
-        }
-        const ab_detected_star &fi = cand[i].s;
-        const uint64_t gx = (uint64_t)(fi.x / 3.0), gy = (uint64_t)(fi.y / 3.0);
-        bool too_close = false;
-        for (uint64_t ny = gy ? gy - 1 : 0; ny <= gy + 1 && !too_close; ++ny)
-            for (uint64_t nx = gx ? gx - 1 : 0; nx <= gx + 1 && !too_close; ++nx) {
-                const uint64_t k = key(ny, nx);
-                for (int j = head[bucket(k)]; j >= 0; j = next[j]) {
-                    if (cell_of[j] != k) continue;
-                    const double dx = fi.x - cand[j].s.x, dy = fi.y - cand[j].s.y;
-                    if (dx * dx + dy * dy < 9.0) {
-                        too_close = true;
-                        break;
-                    }
-                }
-            }
-        if (!too_close) {
-            const uint64_t k = key(gy, gx);
-            cell_of[i] = k;
-            next[i] = head[bucket(k)];
-            head[bucket(k)] = (int)i;
-            stars->push_back(fi);
-        }
-    }
+    finish_stars(recs_begin, ncomp, bg_sigma, max_keep, stars);
     trace.mark("sort+dedup");
+    return AB_OK;
+}
+
+// detect_stars (star_detection.rs:86-258) of G <= kGroupMax frames of ONE size in lockstep: the registration batch's form.  The
+// frames' background (estimate_background's median and sigma under their load transform xf[f]) comes from the tile pipeline; every
+// step of the chain is ONE launch for all of them (blockIdx.y = frame), the counters and the component records come back in one
+// copy each.  Results equal G calls of ab_detect_stars_device.
+int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, int64_t rows, int64_t cols, double sigma_threshold, const ab_pixel_xf *xf,
+                                 const double (*bg)[2], size_t max_keep, std::vector<ab_detected_star> *stars /* [G] */) {
+    for (int f = 0; f < G; ++f) stars[f].clear();
+    if (rows < 3 || cols < 3 || G <= 0) return AB_OK;  // :89-98
+    AB_CHECK(ctx, G <= kGroupMax, "detect_stars: groups of at most %d frames", kGroupMax);
+    AB_CHECK(ctx, rows * cols < (int64_t(1) << 31), "detect_stars: image too large for 32-bit labels");
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t P = rows * cols;
+    const unsigned int root_cap = (unsigned int)(P / 4 + 1);
+    int *parent = nullptr, *cid = nullptr, *roots = nullptr, *plist = nullptr;
+    unsigned int *mask = nullptr;
+    const size_t mask_words = (size_t)P / 32 + 2, roots_words = (size_t)root_cap + 4;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_PARENT, (size_t)G * P * sizeof(int), (void **)&parent));
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_CID, (size_t)G * P * sizeof(int), (void **)&cid));
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_ROOTS, (size_t)G * roots_words * sizeof(int), (void **)&roots));
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)G * P * sizeof(int), (void **)&plist));
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_MASK, (size_t)G * mask_words * sizeof(unsigned int), (void **)&mask));
+    ctx->det_group_ws = true;  // (the single-frame path carves the same workspaces differently: nothing of it survives a call)
+    DetGroup g;
+    memset(&g, 0, sizeof g);
+    g.n = G;
+    bool vec_ok = (P & 3) == 0;
+    unsigned int *counters = (unsigned int *)(roots + (size_t)G * root_cap);  // G x 4 words behind the G root tables
+    for (int f = 0; f < G; ++f) {
+        g.img[f] = imgs[f];
+        g.bg_median[f] = bg[f][0];
+        g.threshold[f] = bg[f][0] + sigma_threshold * bg[f][1];  // :103
+        g.xf[f] = xf[f];
+        g.parent[f] = parent + (size_t)f * P;
+        g.cid[f] = cid + (size_t)f * P;
+        g.plist[f] = plist + (size_t)f * P;
+        g.roots[f] = roots + (size_t)f * root_cap;
+        g.mask[f] = mask + (size_t)f * mask_words;
+        g.counters[f] = counters + 4 * f;
+        vec_ok = vec_ok && ((uintptr_t)imgs[f] & 15) == 0;
+    }
+    const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
+    const int gl = cus * 2;  // list kernels: grid-stride over the frame's labelled pixels (a fraction of a percent of the frame)
+    AB_HIP(ctx, hipMemsetAsync(counters, 0, (size_t)G * 4 * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(label_init_many_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds)), (unsigned)G), dim3(kInitBlock), 0, ctx->stream, g,
+                       (int)rows, (int)cols, cols, (int)vec_ok);
+    hipLaunchKernelGGL(label_merge_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
+    hipLaunchKernelGGL(roots_many_kernel, dim3(gl, G), dim3(kRootsBlock), 0, ctx->stream, g, root_cap);
+    AB_HIP(ctx, hipGetLastError());
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, (size_t)G * 4 * sizeof(unsigned int), &pin));
+    AB_HIP(ctx, hipMemcpyAsync(pin, counters, (size_t)G * 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t total = 0, off[kGroupMax + 1];
+    unsigned int max_nc = 0;
+    for (int f = 0; f < G; ++f) {
+        g.ncomp[f] = ((const unsigned int *)pin)[4 * f];
+        AB_CHECK(ctx, g.ncomp[f] <= root_cap, "detect_stars: %u components exceed the table capacity", g.ncomp[f]);
+        off[f] = total;
+        total += g.ncomp[f];
+        max_nc = std::max(max_nc, g.ncomp[f]);
+    }
+    off[G] = total;
+    if (total == 0) return AB_OK;
+    void *cbuf = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, total * (sizeof(CompStat) + sizeof(CompRec)), &cbuf));
+    CompRec *drec = (CompRec *)cbuf;
+    CompStat *dstat = (CompStat *)(drec + total);
+    for (int f = 0; f < G; ++f) {
+        g.rec[f] = drec + off[f];
+        g.st[f] = dstat + off[f];
+    }
+    AB_TRY(ab_pinned(ctx, total * sizeof(CompRec), &pin));
+    hipLaunchKernelGGL(comp_init_many_kernel, dim3((max_nc + 255) / 256, G), dim3(256), 0, ctx->stream, g);
+    hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
+    hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 3) / 4, G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
+    AB_HIP(ctx, hipGetLastError());
+    AB_HIP(ctx, hipMemcpyAsync(pin, drec, total * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < G; ++f) finish_stars((const CompRec *)pin + off[f], g.ncomp[f], bg[f][1], max_keep, &stars[f]);
     return AB_OK;
 }
 
