@@ -391,18 +391,21 @@ struct StarXY {
     double xy[kTriLimit * 2];
 };
 
+// (round 4: 256-thread blocks -- a 1024-thread workgroup with 16 KB of LDS waited for a CU with sixteen free wave slots inside a
+// registration batch: 157 us on average for a kernel that takes 11 alone)
+constexpr int kTriBlock = 256;
 __device__ __forceinline__ void tri_build_body(const double *__restrict__ xy, int limit, DTri *__restrict__ out, unsigned int *count,
                                                          unsigned int *__restrict__ bin_hist /* nullable; zero on entry */,
                                                          unsigned int *__restrict__ votes_to_clear /* nullable: the vote matrices of the frame */,
                                                          int vote_words) {
     // (the vote kernel of this frame runs later on the same stream: clearing its matrices here saves a fill command per frame)
-    if (votes_to_clear && (int)(blockIdx.x * 1024 + threadIdx.x) < vote_words) votes_to_clear[blockIdx.x * 1024 + threadIdx.x] = 0;
+    if (votes_to_clear && (int)(blockIdx.x * kTriBlock + threadIdx.x) < vote_words) votes_to_clear[blockIdx.x * kTriBlock + threadIdx.x] = 0;
     __shared__ unsigned int lhist[kTriBins];  // this block's share of the bucket histogram: one global atomic per touched bucket
     if (bin_hist) {
-        for (int b = threadIdx.x; b < kTriBins; b += 1024) lhist[b] = 0;
+        for (int b = threadIdx.x; b < kTriBins; b += kTriBlock) lhist[b] = 0;
         __syncthreads();
     }
-    const int t = blockIdx.x * 1024 + threadIdx.x;
+    const int t = blockIdx.x * kTriBlock + threadIdx.x;
     const int lim = limit >= 3 ? limit : 3;  // (a frame of a group without enough stars: no triangle, no division by zero)
     const int i = t / (lim * lim), j = (t / lim) % lim, k = t % lim;
     bool ok = limit >= 3 && i < limit && i < j && j < k;
@@ -431,14 +434,14 @@ __device__ __forceinline__ void tri_build_body(const double *__restrict__ xy, in
         tri.bin = ok ? (uint32_t)tri_bin(tri.mid) : 0u;
     }
     // slots: one global atomic per BLOCK (a same-address atomic with return costs ~12 ns; 3375 per-wave ones were 40 us)
-    __shared__ unsigned int wave_cnt[16], block_base;
+    __shared__ unsigned int wave_cnt[kTriBlock / 64], block_base;
     const unsigned long long m = __ballot(ok);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) wave_cnt[wv] = (unsigned int)__builtin_popcountll(m);
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned int tot = 0;
-        for (int w = 0; w < 16; ++w) tot += wave_cnt[w];
+        for (int w = 0; w < kTriBlock / 64; ++w) tot += wave_cnt[w];
         block_base = tot ? atomicAdd(count, tot) : 0u;
     }
     __syncthreads();
@@ -450,7 +453,7 @@ __device__ __forceinline__ void tri_build_body(const double *__restrict__ xy, in
     }
     if (bin_hist) {
         __syncthreads();
-        for (int b = threadIdx.x; b < kTriBins; b += 1024)
+        for (int b = threadIdx.x; b < kTriBins; b += kTriBlock)
             if (lhist[b]) atomicAdd(&bin_hist[b], lhist[b]);
     }
 }
@@ -490,9 +493,9 @@ __device__ __forceinline__ void tri_bin_scan_body(unsigned int *__restrict__ his
 __device__ __forceinline__ void tri_scatter_body(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
                                                            DTri *__restrict__ sorted) {
     __shared__ unsigned int cnt[kTriBins];  // per-bucket count of this block, then the bucket's reserved base
-    const unsigned int n = *n_p, i = blockIdx.x * 1024 + threadIdx.x;
-    if (blockIdx.x * 1024 >= n) return;
-    for (int b = threadIdx.x; b < kTriBins; b += 1024) cnt[b] = 0;
+    const unsigned int n = *n_p, i = blockIdx.x * kTriBlock + threadIdx.x;
+    if (blockIdx.x * kTriBlock >= n) return;
+    for (int b = threadIdx.x; b < kTriBins; b += kTriBlock) cnt[b] = 0;
     __syncthreads();
     DTri t = {0.0, 0.0, 0u, 0u};
     unsigned int rank = 0;
@@ -501,7 +504,7 @@ __device__ __forceinline__ void tri_scatter_body(const DTri *__restrict__ in, co
         rank = atomicAdd(&cnt[t.bin], 1u);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < kTriBins; b += 1024) {
+    for (int b = threadIdx.x; b < kTriBins; b += kTriBlock) {
         const unsigned int c = cnt[b];
         if (c) cnt[b] = atomicAdd(&cursor[b], c);
     }
@@ -682,11 +685,11 @@ struct TriGroup {
     DTri *raw[kTriGroupMax], *sorted[kTriGroupMax];
     unsigned int *count[kTriGroupMax], *bin_hist[kTriGroupMax], *bin_off[kTriGroupMax], *cursor[kTriGroupMax], *votes[kTriGroupMax];
 };
-__global__ __launch_bounds__(1024) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
+__global__ __launch_bounds__(kTriBlock) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
                                                          unsigned int *__restrict__ bin_hist, unsigned int *__restrict__ votes_to_clear, int vote_words) {
     tri_build_body(stars.xy, limit, out, count, bin_hist, votes_to_clear, vote_words);
 }
-__global__ __launch_bounds__(1024) void tri_build_many_kernel(const TriGroup g, const StarXY *__restrict__ stars, int vote_words) {
+__global__ __launch_bounds__(kTriBlock) void tri_build_many_kernel(const TriGroup g, const StarXY *__restrict__ stars, int vote_words) {
     const int f = blockIdx.y;
     tri_build_body(stars[f].xy, g.limit[f], g.raw[f], g.count[f], g.bin_hist[f], g.votes[f], vote_words);
 }
@@ -697,11 +700,11 @@ __global__ __launch_bounds__(1024) void tri_bin_scan_many_kernel(const TriGroup 
     const int f = blockIdx.y;
     tri_bin_scan_body(g.bin_hist[f], g.bin_off[f], g.cursor[f]);
 }
-__global__ __launch_bounds__(1024) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
+__global__ __launch_bounds__(kTriBlock) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
                                                            DTri *__restrict__ sorted) {
     tri_scatter_body(in, n_p, cursor, sorted);
 }
-__global__ __launch_bounds__(1024) void tri_scatter_many_kernel(const TriGroup g) {
+__global__ __launch_bounds__(kTriBlock) void tri_scatter_many_kernel(const TriGroup g) {
     const int f = blockIdx.y;
     tri_scatter_body(g.raw[f], g.count[f], g.cursor[f], g.sorted[f]);
 }
@@ -766,14 +769,14 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
     if (!which) AB_HIP(ctx, hipMemsetAsync(w.counts, 0, sizeof(unsigned int), ctx->stream));
     const int total = limit * limit * limit;
     const int vote_words = vote_copies() * kVoteDim * kVoteDim;
-    const bool clears = which && limit >= 3 && (total + 1023) / 1024 * 1024 >= vote_words;  // enough threads to clear the votes
+    const bool clears = which && limit >= 3 && (total + kTriBlock - 1) / kTriBlock * kTriBlock >= vote_words;  // enough threads to clear the votes
     if (limit >= 3)
-        hipLaunchKernelGGL(tri_build_kernel, dim3((total + 1023) / 1024), dim3(1024), 0, ctx->stream, xy, limit, raw, w.counts + which, w.bin_hist,
+        hipLaunchKernelGGL(tri_build_kernel, dim3((total + kTriBlock - 1) / kTriBlock), dim3(kTriBlock), 0, ctx->stream, xy, limit, raw, w.counts + which, w.bin_hist,
                            clears ? w.votes : (unsigned int *)nullptr, vote_words);
     if (which && !clears) AB_HIP(ctx, hipMemsetAsync(w.votes, 0, (size_t)vote_words * sizeof(unsigned int), ctx->stream));
     // (the scan leaves bin_hist zeroed again)
     hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
-    hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + 1023) / 1024), dim3(1024), 0, ctx->stream, raw, w.counts + which, w.cursor, sorted);
+    hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + kTriBlock - 1) / kTriBlock), dim3(kTriBlock), 0, ctx->stream, raw, w.counts + which, w.cursor, sorted);
     if (!which) {
         hipLaunchKernelGGL(tri_bucket_sort_kernel, dim3(kTriBins), dim3(256), 0, ctx->stream, sorted, w.bin_off);
         hipLaunchKernelGGL(tri_group_windows_kernel, dim3((kMaxTris + 63) / 64), dim3(64), 0, ctx->stream, (const DTri *)sorted, (const unsigned int *)w.counts,
@@ -863,10 +866,10 @@ int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *s
     if (max_limit < 3) return AB_OK;
     AB_HIP(ctx, hipMemcpyAsync(w.stars, hs, stars_bytes, hipMemcpyHostToDevice, ctx->stream));
     // every table's builder clears that frame's vote matrices (its grid must have the threads: 1024-thread blocks over limit^3 >= 27)
-    const int total = max_limit * max_limit * max_limit, blocks = std::max((total + 1023) / 1024, (vote_words + 1023) / 1024);
-    hipLaunchKernelGGL(tri_build_many_kernel, dim3(blocks, G), dim3(1024), 0, ctx->stream, w.g, (const StarXY *)w.stars, vote_words);
+    const int total = max_limit * max_limit * max_limit, blocks = std::max((total + kTriBlock - 1) / kTriBlock, (vote_words + kTriBlock - 1) / kTriBlock);
+    hipLaunchKernelGGL(tri_build_many_kernel, dim3(blocks, G), dim3(kTriBlock), 0, ctx->stream, w.g, (const StarXY *)w.stars, vote_words);
     hipLaunchKernelGGL(tri_bin_scan_many_kernel, dim3(1, G), dim3(1024), 0, ctx->stream, w.g);
-    hipLaunchKernelGGL(tri_scatter_many_kernel, dim3((kMaxTris + 1023) / 1024, G), dim3(1024), 0, ctx->stream, w.g);
+    hipLaunchKernelGGL(tri_scatter_many_kernel, dim3((kMaxTris + kTriBlock - 1) / kTriBlock, G), dim3(kTriBlock), 0, ctx->stream, w.g);
     hipLaunchKernelGGL(tri_vote_many_kernel, dim3(kVoteBlocks, G), dim3(64), 0, ctx->stream, w.g, (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts,
                        copies, (const RefGroup *)ref_ws.groups);
     AB_HIP(ctx, hipGetLastError());
