@@ -167,16 +167,37 @@ __device__ __forceinline__ void publish_partial(double mn, double mx, double sum
 // after the barrier: column totals over the grid's rows for `nh` (1 or 2) histograms, into s_tot (LDS, 512 x u64).  Thread
 // (q, l) = (t >> 6, t & 63) reads columns 4 l .. 4 l + 3 (uint4) of the rows q, q + 16, ...: for 256 workgroups 16 (32) independent
 // loads per thread, all in flight together (four at a time, the first version spent 10 us here on 32 dependent round trips).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void grid_columns(const unsigned int *slab, unsigned int G, int nh, unsigned long long *s_tot, unsigned int *s_red) {
     const int t = threadIdx.x, l = t & 63, q = t >> 6;
     for (int h = 0; h < nh; ++h) {
         uint4 a = {0, 0, 0, 0};  // (a plane has fewer than 2^31 pixels)
         const uint4 *p = reinterpret_cast<const uint4 *>(slab) + 64 * h + l;
-#pragma unroll 8
-        for (unsigned int r = q; r < G; r += kResWaves) {
-            // device-scope (sc1) loads, the pair of publish_counts' sc1 stores: the rows are rewritten by every launch, and a plain
-            // load may be served a line this XCD's L2 kept from the launch before (two 8-byte halves: an agent-scope atomic load is
-            // sc1 only up to 8 bytes)
+        // device-scope (sc1) loads, the pair of publish_counts' sc1 stores: the rows are rewritten by every launch, and a plain load
+        // may be served a line this XCD's L2 kept from the launch before.  An agent-scope atomic load is sc1 only up to 8 bytes (two
+        // per 16-byte piece: +25 us per launch), so the 16-byte loads are written out, eight in flight per wait.
+        unsigned int r = q;
+        for (; r + 7u * kResWaves < G; r += 8u * kResWaves) {
+            u32x4 x0, x1, x2, x3, x4, x5, x6, x7;
+            const uint4 *b = p + (size_t)r * (kSlabRow / 4);
+            constexpr size_t S = (size_t)kResWaves * (kSlabRow / 4);
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off sc1\n\t"
+                "global_load_dwordx4 %1, %9, off sc1\n\t"
+                "global_load_dwordx4 %2, %10, off sc1\n\t"
+                "global_load_dwordx4 %3, %11, off sc1\n\t"
+                "global_load_dwordx4 %4, %12, off sc1\n\t"
+                "global_load_dwordx4 %5, %13, off sc1\n\t"
+                "global_load_dwordx4 %6, %14, off sc1\n\t"
+                "global_load_dwordx4 %7, %15, off sc1\n\t"
+                "s_waitcnt vmcnt(0)"
+                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7)
+                : "v"(b), "v"(b + S), "v"(b + 2 * S), "v"(b + 3 * S), "v"(b + 4 * S), "v"(b + 5 * S), "v"(b + 6 * S), "v"(b + 7 * S)
+                : "memory");
+            const u32x4 t = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7;
+            a.x += t.x, a.y += t.y, a.z += t.z, a.w += t.w;
+        }
+        for (; r < G; r += kResWaves) {
             unsigned long long *src = reinterpret_cast<unsigned long long *>(const_cast<uint4 *>(p + (size_t)r * (kSlabRow / 4)));
             const unsigned long long lo = __hip_atomic_load(&src[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long hi = __hip_atomic_load(&src[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
