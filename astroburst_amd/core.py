@@ -332,6 +332,10 @@ class Context:
 
     # ---- plane marshalling -----------------------------------------------------------------
     def _plane(self, x, keep):
+        if _is_torch(x) and not x.is_cuda:  # a host plane held by torch (pinned memory keeps the library's uploads asynchronous)
+            assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous(), "host planes are contiguous 2-D float32 tensors"
+            keep.append(x)
+            return Plane(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], 0)
         if _is_torch(x):
             assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous(), \
                 "device planes are contiguous 2-D float32 CUDA tensors"
@@ -919,8 +923,9 @@ class Context:
                 for r in res[:len(targets)]]
 
     def align_pairs_affine(self, reference, targets, outs, num_threads: int = 8):
-        """align_pair(reference, t, AlignMethod::Affine) for every t (pair.rs:41-77): estimate + warp_image into outs[i];
-        device planes only.  -> [AffineAlignResult]"""
+        """align_pair(reference, t, AlignMethod::Affine) for every t (pair.rs:41-77): estimate + warp_image into outs[i]
+        (device planes).  The reference and the targets may be HOST planes (numpy arrays / CPU tensors, pinned for asynchronous
+        copies): the library uploads them on its own stream and registers every frame as it lands.  -> [AffineAlignResult]"""
         keep = []
         pr = self._plane(reference, keep)
         planes = (Plane * max(len(targets), 1))(*[self._plane(t, keep) for t in targets])

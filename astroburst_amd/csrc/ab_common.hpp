@@ -39,6 +39,8 @@ enum {
     AB_WS_DETECT_DEV,         // FrameDev + the tile statistics of the chained detection (detect.hip)
     AB_WS_REGISTER_GROUP,     // the target-side matcher workspaces of a group of frames (affine.hip)
     AB_WS_PHASE_TABLES,       // two sets of Hann windows + FFT twiddles of the phase correlation, kept between calls (phase_corr.hip)
+    AB_WS_PIPE_TABLES,        // plane pointers + transforms of the fed background pipeline (detect.hip: ab_bg_pipeline_begin_fed)
+    AB_WS_PIPE_SUBSAMPLE,     // its subsamples (one per plane: the chunks' percentile launches overlap)
     AB_WS_SLOTS
 };
 
@@ -93,6 +95,14 @@ struct ab_ctx {
     hipStream_t aux_stream = nullptr;
     hipStream_t warp_stream = nullptr;  // the warps of a registration batch (affine.hip): off the workers' own streams
     std::vector<hipEvent_t> aux_events;
+    hipStream_t pct_stream = nullptr;  // the fed pipeline's percentile launches (ab_bg_pipeline_begin_fed)
+    std::vector<hipEvent_t> pct_events;
+    // frames that arrive from the host inside a registration call (ab_align_pairs_affine with on_device = 0 targets): the copy
+    // stream, one event per frame, the HBM staging area
+    hipStream_t upload_stream = nullptr;
+    std::vector<hipEvent_t> upload_events;
+    void *upload_buf = nullptr;
+    size_t upload_bytes = 0;
     void *aux_pinned = nullptr;
     size_t aux_pinned_bytes = 0;
     // the tiles the streaming tile kernel declined (detect.hip): {count, finished blocks, tile ids ...} per stream it is launched
@@ -243,7 +253,12 @@ struct ab_bg_pipeline {
     const hipEvent_t *events = nullptr;
     int ntiles = 0, chunk = 1;
     size_t n = 0;
+    const ab_pixel_xf *xf_host = nullptr;  // fed pipeline: plane i's transform, valid once ab_bg_pipeline_get(i) has returned
 };
+// the pipeline fed chunk by chunk: the percentiles run per chunk on the device (no host join before the first tile launch), and a
+// chunk waits for its planes' `landed` events (nullable; a null entry = the plane is complete already)
+int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, int chunk, const hipEvent_t *landed,
+                             ab_bg_pipeline *p);
 int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, const ab_pixel_xf *xf, int chunk,
                          ab_bg_pipeline *p);
 int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *bg /* [2] */);
@@ -272,6 +287,9 @@ int ab_comm_stream_wait(ab_ctx *ctx, ab_comm *comm);
 // stack_wide.hip: 65 .. 512 frames, one wave per pixel (host tables of n plane pointers / strides; counters pre-cleared)
 int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
                          const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only);
+// 257 .. 512 contiguous frames, two lanes per pixel (stack_pair.hip); dplanes is a HOST array of n device pointers
+int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg,
+                         float *out_dev, bool median_only);
 
 static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -137,6 +137,11 @@ void ab_ctx_destroy(ab_ctx *ctx) {
         if (e) (void)hipEventDestroy(e);
     if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
     for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->pct_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->upload_events) (void)hipEventDestroy(e);
+    if (ctx->pct_stream) (void)hipStreamDestroy(ctx->pct_stream);
+    if (ctx->upload_stream) (void)hipStreamDestroy(ctx->upload_stream);
+    if (ctx->upload_buf) (void)hipFree(ctx->upload_buf);
     if (ctx->aux_pinned) (void)hipHostFree(ctx->aux_pinned);
     for (int i = 0; i < 2; ++i)
         if (ctx->tile_fail[i]) (void)hipFree(ctx->tile_fail[i]);

@@ -26,6 +26,7 @@
 #include <thread>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <thread>
 
@@ -1039,7 +1040,8 @@ static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const
 // ctx): one frame's host geometry overlaps the other frames' GPU passes.  Results do not depend on the worker
 // count (each out[i] equals a stand-alone align_channel_affine(reference, targets[i])).
 int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const *targets, size_t n, int64_t rows, int64_t cols, int num_threads,
-                              ab_affine_align_result *out, float *const *aligned /* nullable: warp_image(target, transform) per target */) {
+                              ab_affine_align_result *out, float *const *aligned /* nullable: warp_image(target, transform) per target */,
+                              const hipEvent_t *landed /* nullable: per target, the event after which its pixels are in HBM (an upload in flight) */) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     MatchWs w;
     AB_TRY(match_ws(ctx, &w));
@@ -1054,11 +1056,37 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         ab_ctx *c;
         ab_bg_pipeline *p;
         ~AuxDrain() {
+            if (p->on && c->pct_stream) (void)hipStreamSynchronize(c->pct_stream);
             if (p->on && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
         }
     } aux_drain{ctx, &pipe};
-    const bool have_xf = n >= 4;
-    if (have_xf) {
+    const bool have_xf = n >= 4 || landed != nullptr;
+    // Round 4: frames that are still on the PCIe link (`landed`) go through the FED pipeline (ab_bg_pipeline_begin_fed): a chunk's
+    // percentiles run on the device right before its tiles and wait for the chunk's upload events, so nothing is joined on the host
+    // before the first tile launch.  Device-resident frames keep the percentiles of all frames up front (two launches + a join):
+    // measured on the bench stack, same box, 12.99 ms for the stage against 13.34 fed (sixteen more launches in the tile stream's
+    // way).  AB_PIPE_FED=1 feeds them too (the GPU tests hold the two orders to the same transforms).
+    static const bool force_fed = getenv("AB_PIPE_FED") != nullptr;
+    const bool fed = have_xf && (landed != nullptr || force_fed);
+    if (fed) {
+        static const int chunk = getenv("AB_TILE_CHUNK") ? std::max(atoi(getenv("AB_TILE_CHUNK")), 1) : 8;
+        static const int fed_chunk = getenv("AB_FEED_CHUNK") ? std::max(atoi(getenv("AB_FEED_CHUNK")), 1) : 4;  // frames per launch while frames are still arriving
+        std::vector<const float *> order;  // reference first
+        std::vector<hipEvent_t> ev;
+        order.push_back(ref);
+        ev.push_back(nullptr);
+        for (size_t i = 0; i < n; ++i) {
+            order.push_back(targets[i]);
+            ev.push_back(landed ? landed[i] : nullptr);
+        }
+        xfs.resize(n + 1);
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's frames are complete before any other stream reads them
+        AB_TRY(ab_bg_pipeline_begin_fed(ctx, order.data(), n + 1, rows, cols, landed ? fed_chunk : chunk, landed ? ev.data() : nullptr, &pipe));
+        if (!pipe.on && landed)  // (planes too small for tiles, AB_TILE_LEGACY: the frames are waited for and the batch takes the path below)
+            for (size_t i = 0; i < n; ++i)
+                if (landed[i]) AB_HIP(ctx, hipEventSynchronize(landed[i]));
+    }
+    if (have_xf && !pipe.on) {
         std::vector<const float *> planes(targets, targets + n);
         planes.push_back(ref);
         xfs.resize(n + 1);
@@ -1081,6 +1109,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     auto prepare_reference = [&]() -> int {
         double bg[2];
         if (pipe.on) AB_TRY(ab_bg_pipeline_get(ctx, &pipe, 0, bg));
+        if (pipe.xf_host) xfs[n] = pipe.xf_host[0];
         AB_TRY(frame_stars(ctx, ref, rows, cols, &rt.stars, have_xf ? &xfs[n] : nullptr, pipe.on ? bg : nullptr));
         if (rt.stars.size() < kMinMatchesRigid) return AB_OK;
         // reference table: built, bucketed by ratio_mid and ordered by ratio_long inside the buckets on the GPU
@@ -1093,6 +1122,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     auto one = [&](ab_ctx *wc, size_t f) -> int {
         double bg[2];
         if (pipe.on) AB_TRY(ab_bg_pipeline_get(wc, &pipe, f + 1, bg));
+        if (pipe.xf_host) xfs[f] = pipe.xf_host[f + 1];  // (each worker writes its own frames' entries)
         AB_TRY(register_one(wc, w, rt, ref, targets[f], rows, cols, num_threads, &out[f], have_xf ? &xfs[f] : nullptr, pipe.on ? bg : nullptr));
         if (aligned) {  // pair.rs:59-61
             // the warp needs nothing from the GPU but the frame: it goes to the batch's warp stream, so that this worker's
@@ -1122,6 +1152,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         for (int k = 0; k < G; ++k) {
             frames[k] = f0 + (size_t)k;
             AB_TRY(ab_bg_pipeline_get(wc, &pipe, frames[k] + 1, bgs[k]));
+            if (pipe.xf_host) xfs[frames[k]] = pipe.xf_host[frames[k] + 1];  // (each worker writes its own frames' entries)
         }
         const std::function<int(size_t)> warp_frame = [&](size_t f) -> int {
             if (!aligned) return AB_OK;  // pair.rs:59-61
@@ -1164,7 +1195,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
 
 int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
                                    ab_affine_align_result *out) {
-    return ab_register_frames_device(ctx, ref, &tgt, 1, rows, cols, num_threads, out, nullptr);
+    return ab_register_frames_device(ctx, ref, &tgt, 1, rows, cols, num_threads, out, nullptr, nullptr);
 }
 
 extern "C" {
@@ -1206,7 +1237,7 @@ int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *t
         if (rc != AB_OK) break;
         ptrs[staged] = st[staged].dptr;
     }
-    if (rc == AB_OK) rc = ab_register_frames_device(ctx, r.dptr, ptrs.data(), n, r.rows, r.cols, num_threads, out, nullptr);
+    if (rc == AB_OK) rc = ab_register_frames_device(ctx, r.dptr, ptrs.data(), n, r.rows, r.cols, num_threads, out, nullptr, nullptr);
     for (size_t i = 0; i < staged && i < n; ++i) ab_stage_release(ctx, &st[i]);
     ab_stage_release(ctx, &r);
     return rc;
@@ -1216,19 +1247,94 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
                           ab_affine_align_result *out, ab_plane_mut *aligned) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, reference && out && aligned && (targets || n == 0), "null argument");
-    AB_CHECK(ctx, reference->on_device, "align_pairs takes device-resident planes");
     std::vector<const float *> ptrs(n);
     std::vector<float *> outs(n);
+    size_t n_host = 0;
     for (size_t i = 0; i < n; ++i) {
-        AB_CHECK(ctx, targets[i].on_device && aligned[i].on_device, "align_pairs takes device-resident planes");
+        AB_CHECK(ctx, aligned[i].on_device, "align_pairs writes device-resident planes");
         AB_CHECK(ctx, targets[i].rows == reference->rows && targets[i].cols == reference->cols && aligned[i].rows == reference->rows &&
                           aligned[i].cols == reference->cols,
                  "align_pairs: target %zu / its output differ from the reference's dims", i);
         AB_CHECK(ctx, targets[i].data != aligned[i].data, "warp_image cannot run in place");
         ptrs[i] = targets[i].data;
         outs[i] = aligned[i].data;
+        if (!targets[i].on_device) ++n_host;
     }
-    return ab_register_frames_device(ctx, reference->data, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data());
+    if (n_host == 0 && reference->on_device)
+        return ab_register_frames_device(ctx, reference->data, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data(), nullptr);
+    // Frames held by the HOST (as the application holds them: Array2<f32> in the image cache, calibration.rs:306-315): every host
+    // frame is copied into an HBM staging area on the context's upload stream, an event behind each, all enqueued before anything
+    // else; the registration's pipeline waits for a frame's event, not for the batch, so the link is busy from the first byte to the
+    // last and what remains after the last byte is one group's registration.  (Pinned host memory keeps the copies asynchronous;
+    // pageable memory is staged by the runtime copy by copy -- same result, the call then waits in the enqueue loop.)
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t plane_bytes = (size_t)reference->rows * (size_t)reference->cols * sizeof(float);
+    const size_t slots = n_host + (reference->on_device ? 0 : 1);
+    const size_t stride = (plane_bytes + 255) & ~(size_t)255;
+    if (slots * stride > ctx->upload_bytes) {
+        if (ctx->upload_buf) {
+            AB_HIP(ctx, hipDeviceSynchronize());
+            AB_HIP(ctx, hipFree(ctx->upload_buf));
+            ctx->upload_buf = nullptr;
+            ctx->upload_bytes = 0;
+        }
+        AB_HIP(ctx, hipMalloc(&ctx->upload_buf, slots * stride));
+        ctx->upload_bytes = slots * stride;
+    }
+    if (!ctx->upload_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    while (ctx->upload_events.size() < slots) {
+        hipEvent_t e;
+        AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->upload_events.push_back(e);
+    }
+    // whatever leaves this function, the copies (they read the caller's memory) have drained first
+    struct UploadDrain {
+        ab_ctx *c;
+        ~UploadDrain() { (void)hipStreamSynchronize(c->upload_stream); }
+    } upload_drain{ctx};
+    size_t slot = 0;
+    const float *ref_dev = reference->data;
+    if (!reference->on_device) {  // the reference first: every frame's matching needs it
+        float *d = (float *)((char *)ctx->upload_buf + slot * stride);
+        if (plane_bytes) AB_HIP(ctx, hipMemcpyAsync(d, reference->data, plane_bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->upload_stream));
+        ref_dev = d;
+        ++slot;
+    }
+    // AB_UPLOAD_TRACE=1 (developer knob): how long the copies took under the registration's load, and what was left after the last
+    static const bool up_trace = getenv("AB_UPLOAD_TRACE") != nullptr;
+    hipEvent_t tr0 = nullptr, tr1 = nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    if (up_trace) {
+        AB_HIP(ctx, hipEventCreate(&tr0));
+        AB_HIP(ctx, hipEventCreate(&tr1));
+        AB_HIP(ctx, hipEventRecord(tr0, ctx->upload_stream));
+    }
+    std::vector<hipEvent_t> landed(n, nullptr);
+    for (size_t i = 0; i < n; ++i) {
+        if (targets[i].on_device) continue;
+        float *d = (float *)((char *)ctx->upload_buf + slot * stride);
+        if (plane_bytes) AB_HIP(ctx, hipMemcpyAsync(d, targets[i].data, plane_bytes, hipMemcpyHostToDevice, ctx->upload_stream));
+        AB_HIP(ctx, hipEventRecord(ctx->upload_events[slot], ctx->upload_stream));
+        landed[i] = ctx->upload_events[slot];
+        ptrs[i] = d;
+        ++slot;
+    }
+    if (up_trace) AB_HIP(ctx, hipEventRecord(tr1, ctx->upload_stream));
+    const double enq_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+    const int rc = ab_register_frames_device(ctx, ref_dev, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data(),
+                                             n_host ? landed.data() : nullptr);
+    if (up_trace) {
+        const double call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
+        float up_ms = 0.0f;
+        (void)hipEventSynchronize(tr1);
+        (void)hipEventElapsedTime(&up_ms, tr0, tr1);
+        fprintf(stderr, "[ab upload] %zu host frames: enqueue %.2f ms, copies %.2f ms (%.1f GB/s), call %.2f ms\n", n_host, enq_ms, up_ms,
+                (double)n_host * (double)plane_bytes / (up_ms * 1e-3) / 1e9, call_ms);
+        (void)hipEventDestroy(tr0);
+        (void)hipEventDestroy(tr1);
+    }
+    return rc;
 } AB_CATCH(ctx)
 
 // the host geometry alone, on given centroids (x, y pairs): returns AB_OK and *found = 0/1

@@ -728,7 +728,9 @@ __device__ __forceinline__ void find_rank_2048(const unsigned int *hist, unsigne
 
 // SRC supplies sample i; the sweeps are written once for both sources below
 template <class SRC>
-__device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns, PercentileOut *__restrict__ out, FrameDev *__restrict__ fd) {
+__device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns, PercentileOut *__restrict__ out, FrameDev *__restrict__ fd,
+                                                 ab_pixel_xf *__restrict__ dxf = nullptr /* the transform itself, into a device table ... */,
+                                                 ab_pixel_xf *__restrict__ hxf = nullptr /* ... and into its pinned host mirror (fed pipeline) */) {
     __shared__ unsigned int hist[2][2048];
     __shared__ unsigned int wave_tot[16], bcast[2];
     const int t = threadIdx.x;
@@ -757,6 +759,8 @@ __device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns
                 fd->xf = ab_pixel_xf();
                 fd->finite = m;
             }
+            if (dxf) *dxf = ab_pixel_xf();
+            if (hxf) *hxf = ab_pixel_xf();
         }
         return;
     }
@@ -796,7 +800,7 @@ __device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns
     if (t == 0) {
         const float lo = ordered_value(prefix[0]), hi = ordered_value(prefix[1]);
         *out = PercentileOut{lo, hi, m, 0u};
-        if (fd) {  // the host's arithmetic (ab_normalize_params_device), on the device
+        if (fd || dxf || hxf) {  // the host's arithmetic (xf_from_percentiles), on the device
             ab_pixel_xf xf;
             const double range = (double)hi - (double)lo;
             if (!(range < 1e-15)) {
@@ -804,8 +808,12 @@ __device__ __forceinline__ void percentiles_body(const SRC &src, unsigned int ns
                 xf.inv = 1.0 / range;
                 xf.on = 1;
             }
-            fd->xf = xf;
-            fd->finite = m;
+            if (fd) {
+                fd->xf = xf;
+                fd->finite = m;
+            }
+            if (dxf) *dxf = xf;
+            if (hxf) *hxf = xf;
         }
     }
 }
@@ -862,7 +870,8 @@ __global__ __launch_bounds__(256) void subsample_many_kernel(const PlaneList pl,
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nout) out[(int64_t)blockIdx.y * nout + i] = pl.p[blockIdx.y][i * step];
 }
-__global__ __launch_bounds__(1024) void percentiles_many_reg_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
+__global__ __launch_bounds__(1024) void percentiles_many_reg_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out,
+                                                                     ab_pixel_xf *__restrict__ dxf, ab_pixel_xf *__restrict__ hxf) {
     const float *mine = sub + (size_t)blockIdx.x * ns;
     RegSample s;
 #pragma unroll
@@ -870,10 +879,12 @@ __global__ __launch_bounds__(1024) void percentiles_many_reg_kernel(const float 
         const unsigned int i = (unsigned int)(j * 1024) + threadIdx.x;
         s.v[j] = i < ns ? mine[i] : __builtin_nanf("");
     }
-    percentiles_body(s, ns, out + blockIdx.x, (FrameDev *)nullptr);
+    percentiles_body(s, ns, out + blockIdx.x, (FrameDev *)nullptr, dxf ? dxf + blockIdx.x : nullptr, hxf ? hxf + blockIdx.x : nullptr);
 }
-__global__ __launch_bounds__(1024) void percentiles_many_mem_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out) {
-    percentiles_body(MemSample{sub + (size_t)blockIdx.x * ns}, ns, out + blockIdx.x, (FrameDev *)nullptr);
+__global__ __launch_bounds__(1024) void percentiles_many_mem_kernel(const float *__restrict__ sub, unsigned int ns, PercentileOut *__restrict__ out,
+                                                                     ab_pixel_xf *__restrict__ dxf, ab_pixel_xf *__restrict__ hxf) {
+    percentiles_body(MemSample{sub + (size_t)blockIdx.x * ns}, ns, out + blockIdx.x, (FrameDev *)nullptr, dxf ? dxf + blockIdx.x : nullptr,
+                     hxf ? hxf + blockIdx.x : nullptr);
 }
 
 
@@ -1107,6 +1118,108 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     p->ntiles = ntiles;
     p->chunk = chunk;
     p->n = n;
+    return AB_OK;
+}
+
+// The same pipeline FED chunk by chunk (round 4): nothing is known about a plane on the host before its chunk has run.  The
+// percentiles of normalize_for_detection (subsample + radix select, one workgroup per plane) run per chunk on a third stream and
+// leave each plane's transform in a device table (read by the tile kernel) and in a pinned mirror (read by the workers after
+// ab_bg_pipeline_get); a chunk's tile launch waits for its percentiles by event.  `landed` (nullable): one event per plane that is
+// still being written when this returns (an upload from the host in flight) -- a chunk's percentiles wait for its planes' events,
+// so the registration of frame k starts when frame k has landed, whatever is still on the link.
+int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, int chunk, const hipEvent_t *landed,
+                             ab_bg_pipeline *p) {
+    *p = ab_bg_pipeline();
+    static const bool legacy = getenv("AB_TILE_LEGACY") != nullptr;
+    if (legacy || n == 0 || rows < 3 || cols < 3 || chunk < 1) return AB_OK;
+    if (chunk > kManyPlanes) chunk = kManyPlanes;
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t m = std::min(rows, cols);
+    const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // detect_stars' choice (:100)
+    const int step = (int)std::max<int64_t>(tile_size, 16);
+    const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
+    const int64_t len = rows * cols;
+    const int64_t sstep = std::max<int64_t>(len / 100000, 1);  // affine.rs:28-30
+    const int64_t ns = (len + sstep - 1) / sstep;
+    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK"));
+    if (!ctx->pct_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->pct_stream, hipStreamNonBlocking));
+    const size_t nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
+    while (ctx->aux_events.size() < nchunks) {
+        hipEvent_t e;
+        AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->aux_events.push_back(e);
+    }
+    while (ctx->pct_events.size() < nchunks) {
+        hipEvent_t e;
+        AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->pct_events.push_back(e);
+    }
+    // pinned: tile results | plane pointers (staging copy) | transforms (the mirror the workers read) | percentile records
+    const size_t ptr_bytes = (n * sizeof(const float *) + 15) & ~(size_t)15, xf_bytes = (n * sizeof(ab_pixel_xf) + 15) & ~(size_t)15;
+    const size_t tiles_bytes = (n * (size_t)ntiles * sizeof(TileOut) + 63) & ~(size_t)63;
+    const size_t need = tiles_bytes + ptr_bytes + xf_bytes + n * sizeof(PercentileOut);
+    if (need > ctx->aux_pinned_bytes) {
+        if (ctx->aux_pinned) {
+            AB_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+            AB_HIP(ctx, hipStreamSynchronize(ctx->pct_stream));
+            AB_HIP(ctx, hipHostFree(ctx->aux_pinned));
+            ctx->aux_pinned = nullptr;
+            ctx->aux_pinned_bytes = 0;
+        }
+        AB_HIP(ctx, hipHostMalloc(&ctx->aux_pinned, need, hipHostMallocDefault));
+        ctx->aux_pinned_bytes = need;
+    }
+    char *dv = nullptr;  // device: plane pointers | transforms
+    AB_TRY(ab_workspace(ctx, AB_WS_PIPE_TABLES, ptr_bytes + xf_bytes + 64, (void **)&dv));
+    float *sub = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_PIPE_SUBSAMPLE, n * (size_t)ns * sizeof(float), (void **)&sub));
+    const float **dplanes = (const float **)dv;
+    ab_pixel_xf *dxf = (ab_pixel_xf *)(dv + ptr_bytes);
+    char *stage = (char *)ctx->aux_pinned + tiles_bytes;
+    ab_pixel_xf *hxf = (ab_pixel_xf *)(stage + ptr_bytes);
+    PercentileOut *hpo = (PercentileOut *)(stage + ptr_bytes + xf_bytes);
+    memcpy(stage, planes, n * sizeof(const float *));
+    // from the first enqueue on, a failure drains both streams before it returns: the launches read the caller's frames
+    auto enqueue = [&]() -> int {
+        AB_HIP(ctx, hipMemcpyAsync(dplanes, stage, n * sizeof(const float *), hipMemcpyHostToDevice, ctx->aux_stream));
+        for (size_t c = 0; c < nchunks; ++c) {
+            const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
+            if (landed)
+                for (size_t i = 0; i < cnt; ++i)
+                    if (landed[first + i]) AB_HIP(ctx, hipStreamWaitEvent(ctx->pct_stream, landed[first + i], 0));
+            PlaneList pl;
+            for (size_t i = 0; i < (size_t)kManyPlanes; ++i) pl.p[i] = planes[first + (i < cnt ? i : 0)];
+            float *csub = sub + first * (size_t)ns;
+            hipLaunchKernelGGL(subsample_many_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->pct_stream, pl, len, sstep, csub, ns);
+            if (ns <= (int64_t)kPctPer * 1024)
+                hipLaunchKernelGGL(percentiles_many_reg_kernel, dim3((unsigned)cnt), dim3(1024), 0, ctx->pct_stream, (const float *)csub, (unsigned int)ns,
+                                   hpo + first, dxf + first, hxf + first);
+            else
+                hipLaunchKernelGGL(percentiles_many_mem_kernel, dim3((unsigned)cnt), dim3(1024), 0, ctx->pct_stream, (const float *)csub, (unsigned int)ns,
+                                   hpo + first, dxf + first, hxf + first);
+            AB_HIP(ctx, hipEventRecord(ctx->pct_events[c], ctx->pct_stream));
+            AB_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->pct_events[c], 0));
+            AB_TRY(launch_tile_kernels(ctx, ctx->aux_stream, 1, nullptr, rows, cols, cols, step, ntx, ntiles, (int)cnt, ab_pixel_xf(),
+                                       (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, nullptr, (const float *const *)(dplanes + first),
+                                       (const ab_pixel_xf *)(dxf + first)));
+            AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
+        }
+        AB_HIP(ctx, hipGetLastError());
+        return AB_OK;
+    };
+    const int rc = enqueue();
+    if (rc != AB_OK) {
+        (void)hipStreamSynchronize(ctx->pct_stream);
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        return rc;
+    }
+    p->on = true;
+    p->tiles = ctx->aux_pinned;
+    p->events = ctx->aux_events.data();
+    p->ntiles = ntiles;
+    p->chunk = chunk;
+    p->n = n;
+    p->xf_host = hxf;
     return AB_OK;
 }
 
@@ -1473,9 +1586,11 @@ int ab_normalize_params_many_device(ab_ctx *ctx, const float *const *planes, siz
         AB_TRY(ab_workspace(ctx, AB_WS_SUBSAMPLE, m * (size_t)ns * sizeof(float), (void **)&sub));
         hipLaunchKernelGGL(subsample_many_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)m), dim3(256), 0, ctx->stream, pl, len, step, sub, ns);
         if (ns <= (int64_t)kPctPer * 1024)
-            hipLaunchKernelGGL(percentiles_many_reg_kernel, dim3((unsigned)m), dim3(1024), 0, ctx->stream, (const float *)sub, (unsigned int)ns, (PercentileOut *)pin);
+            hipLaunchKernelGGL(percentiles_many_reg_kernel, dim3((unsigned)m), dim3(1024), 0, ctx->stream, (const float *)sub, (unsigned int)ns, (PercentileOut *)pin,
+                               (ab_pixel_xf *)nullptr, (ab_pixel_xf *)nullptr);
         else
-            hipLaunchKernelGGL(percentiles_many_mem_kernel, dim3((unsigned)m), dim3(1024), 0, ctx->stream, (const float *)sub, (unsigned int)ns, (PercentileOut *)pin);
+            hipLaunchKernelGGL(percentiles_many_mem_kernel, dim3((unsigned)m), dim3(1024), 0, ctx->stream, (const float *)sub, (unsigned int)ns, (PercentileOut *)pin,
+                               (ab_pixel_xf *)nullptr, (ab_pixel_xf *)nullptr);
         AB_HIP(ctx, hipGetLastError());
         AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i < m; ++i) xf[first + i] = xf_from_percentiles(((const PercentileOut *)pin)[i]);

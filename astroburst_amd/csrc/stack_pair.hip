@@ -1,0 +1,407 @@
+// Per-pixel kappa-sigma stacking of 257 .. 512 contiguous frames on gfx950: TWO LANES PER PIXEL.
+//
+// sigma_clip_combine (core/stacking/combine.rs:14-92) and median_combine_row_major (core/stacking/calibration.rs:84-125) for the
+// frame counts of master calibration stacks (calibration.rs:47-125).  stack_sigma_clip.hip keeps a pixel's samples in ONE lane
+// (up to 256: the whole unified register file); stack_wide.hip gives a pixel a whole wave (3000 instructions per pixel, 180 ms
+// for 4096^2 x 512).  Here lanes 2k and 2k+1 share pixel k of the wave's 32:
+//   * the even lane gathers frames 0 .. 255, the odd lane frames 256 .. 511 (non-finite samples and absent frames become
+//     +inf pads), and each sorts its 256 samples in registers with the same network as the one-lane kernel (SortNet<256>);
+//   * one cross step -- v[i] against the partner's v[255 - i], fetched by DPP quad_perm [1,0,3,2] -- leaves the 256 smallest
+//     in the even lane and the 256 largest in the odd lane, each a bitonic sequence, and an in-lane bitonic merge (8 half-
+//     cleaner stages on constant register indices) sorts them: the pair now holds sorted ranks 0 .. 511, pads on top;
+//   * the median and the MAD pairing (term(p) = max(med - V[p], V[p + n/2] - med), the k-th element of the merge of the
+//     two deviation runs, as in stack_sigma_clip.hip) read ranks at a per-pixel offset: with all 512 samples finite the
+//     offset is 256 and the partner's register p IS V[p + 256] (DPP); otherwise the ranks travel through LDS, one half at
+//     a time (32 KB per wave);
+//   * the clipping iterations are the oracle's arithmetic word for word (two-pass mean / squared deviations, f64, ascending):
+//     the survivors are a rank interval, a sum runs over the even lane's part first and is handed to the odd lane, which
+//     continues it -- the same sequence of f64 additions as one lane walking all 512 ranks, so the result is BIT-IDENTICAL to
+//     the wave-per-pixel kernel and to the CPU restatement (ORC_ORDER_ASCENDING), not merely within the 1e-5 contract.
+// ~25 000 instructions per wave of 32 pixels, 512 load instructions of 128 B each; one wave per SIMD (the samples fill the
+// register file), 32 KB of LDS per wave.
+#include "ab_common.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+#include "sort_ops.hpp"
+#define AB_CE(a, b)                       \
+    {                                     \
+        T lo_ = ab_v_min(v[a], v[b]);     \
+        T hi_ = ab_v_max(v[a], v[b]);     \
+        v[a] = lo_;                       \
+        v[b] = hi_;                       \
+    }
+#define AB_SORT4(a, b, c, d)                                                                          \
+    {                                                                                                 \
+        const T x0_ = v[a], x1_ = v[b], x2_ = v[c], x3_ = v[d];                                       \
+        const T s0_ = ab_v_min3(x0_, x1_, x2_), s1_ = ab_v_med3(x0_, x1_, x2_), s2_ = ab_v_max3(x0_, x1_, x2_); \
+        v[a] = ab_v_min(s0_, x3_);                                                                    \
+        v[b] = ab_v_med3(s0_, s1_, x3_);                                                              \
+        v[c] = ab_v_med3(s1_, s2_, x3_);                                                              \
+        v[d] = ab_v_max(s2_, x3_);                                                                    \
+    }
+#include "sortnet_gen.hpp"
+
+namespace {
+
+constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
+constexpr int kRejSlots = AB_REJ_SLOTS;
+constexpr int H = 256;  // samples per lane
+
+struct PairArgs {
+    const float *const *p;  // n plane pointers (device array), n in (256, 512]
+    int n;
+    int64_t total;  // pixels
+    float sigma_low, sigma_high;
+    uint32_t max_iter;
+    float *out;
+    unsigned long long *rejected;
+    int median_only;  // median_combine_row_major (calibration.rs:84-125): [len/2] of the finite samples
+};
+
+// the partner lane's value (lanes 2k <-> 2k+1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ float swapf(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int swapi(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); }
+__device__ __forceinline__ double swapd(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned int lo = (unsigned int)swapi((int)(unsigned int)u), hi = (unsigned int)swapi((int)(unsigned int)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// The network's min / max are inline assembly, and the compiler's hazard recogniser does not see a VALU write inside an asm
+// statement: a DPP read of such a register within two wait states returns the OLD value.  Every sample therefore passes through
+// one of these (volatile, `s_nop 1` inside, the sample an in/out operand) between the network that wrote it and the first DPP
+// that reads it.
+__device__ __forceinline__ void dpp_fence(float (&v)[256]) {
+#pragma unroll
+    for (int i = 0; i < 256; i += 8)
+        asm volatile("s_nop 1" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]),
+                     "+v"(v[i + 7]));
+}
+
+// Compiler fence (no instructions): the sample vector looks rewritten, so LLVM does not hoist 256 f32->f64 conversions out of
+// the clipping loop (stack_sigma_clip.hip: launder)
+__device__ __forceinline__ void launder(float (&v)[H]) {
+#pragma unroll
+    for (int i = 0; i < H; i += 8)
+        asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]),
+                     "+v"(v[i + 7]));
+}
+__device__ __forceinline__ void opaque(int &a, int &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
+// in-lane bitonic merge of a bitonic sequence of 256 (ascending result): eight half-cleaner stages.  (One function per stage: as
+// two nested `#pragma unroll` loops the body exceeds the pragma's size limit, the outer loop stays a loop, and the samples live
+// in scratch memory.)
+template <int D>
+__device__ __forceinline__ void half_cleaner(float (&v)[H]) {
+    using T = float;
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+        if ((i & D) == 0) AB_CE(i, i + D)
+}
+__device__ __forceinline__ void bitonic_merge_256(float (&v)[H]) {
+    half_cleaner<128>(v);
+    half_cleaner<64>(v);
+    half_cleaner<32>(v);
+    half_cleaner<16>(v);
+    half_cleaner<8>(v);
+    half_cleaner<4>(v);
+    half_cleaner<2>(v);
+    half_cleaner<1>(v);
+}
+
+// One f64 accumulation over the global rank interval [a, b] (ranks 0 .. 511 over the pair), ascending: the even lane's part
+// first, then the odd lane continues from the even lane's sum.  la / lb: this lane's part of the interval in local indices
+// (la = lb = -1: none).  MODE 0: sum of v; MODE 1: sum of (v - mean)^2.  Both lanes return the pair's total.
+template <int MODE>
+__device__ __forceinline__ double pair_sum(float (&v)[H], int la, int lb, bool odd, double mean) {
+    double S = 0.0;
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        launder(v);  // (or the 256 conversions, the same in both phases, are hoisted out of this loop: 512 registers, all spilled)
+        // phase 0: even lanes add their samples, odd lanes add zeros; phase 1: the odd lane continues the even lane's sum
+        if (phase == 1) {
+            const double from_even = swapd(S);  // (evaluated by ALL lanes: a DPP read of a lane that is switched off returns nothing)
+            S = odd ? from_even : S;
+        }
+        const bool mine = odd == (phase == 1);
+        const int pa = mine ? la : -1, pb = mine ? lb : -1;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const bool in = (unsigned)(i - pa) <= (unsigned)(pb - pa);
+            if (MODE == 0) {
+                const float xs = in ? v[i] : 0.0f;  // (x + 0.0 is exact)
+                S += (double)xs;
+            } else {
+                const double dd = (double)v[i] - mean;
+                const double sq = dd * dd;
+                S += in ? sq : 0.0;
+            }
+        }
+    }
+    const double from_odd = swapd(S);
+    return odd ? S : from_odd;
+}
+
+// ranks through LDS: `buf` holds one half (256 ranks) of each of the wave's 32 pixels, rank-major (conflict-free: a wave's
+// accesses to one rank are 32 consecutive words)
+__device__ __forceinline__ void put_half(float *buf, const float (&v)[H], bool writer, int pix) {
+    if (writer) {
+#pragma unroll
+        for (int i = 0; i < H; ++i) buf[i * 32 + pix] = v[i];
+    }
+}
+
+template <bool MEDIAN_ONLY>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stack_pair_kernel(const PairArgs a) {
+    __shared__ float buf[H * 32];
+    const int lane = threadIdx.x;
+    const bool odd = lane & 1;
+    const int pix = lane >> 1;
+    int64_t g = (int64_t)blockIdx.x * 32 + pix;
+    const bool valid = g < a.total;
+    if (!valid) g = a.total - 1;
+
+    // ---- gather (combine.rs:170-175 / calibration.rs:95-104): only finite samples take part; the rest are +inf pads ----
+    // lane-parity halves: two exec-masked load streams of 256 instructions, 32 lanes x 4 B = one 128-byte line each
+    // Every load instruction has a wave-uniform plane (scalar base + one shared 32-bit byte offset, no vector address work): BOTH
+    // lanes of a pair fetch their pixel from frame f and from frame f + 256 (the two lanes read the same word: one 128-byte
+    // line per instruction either way) and each keeps its half's sample.
+    float v[H];
+    const int have = odd ? a.n - H : H;  // frames of this half (n > 256: the even half is full)
+    const uint32_t boff = (uint32_t)g * 4u;
+#pragma unroll
+    for (int f = 0; f < H; ++f) {
+        const float xe = *(const float *)((const char *)a.p[f] + boff);
+        const float xo = *(const float *)((const char *)a.p[f + H] + boff);  // (table entries past n point at a plane of +inf: pads)
+        v[f] = odd ? xo : xe;
+    }
+    float nf = 0.0f;  // fma(x, 0, nf) stays 0 for finite x and turns NaN for inf / NaN
+#pragma unroll
+    for (int f = 0; f < H; ++f) nf = __builtin_fmaf(f < have ? v[f] : 0.0f, 0.0f, nf);
+    int n_lane = have;
+    if (__any(nf != nf)) {  // rare: some lane of this wave met a non-finite sample
+        n_lane = 0;
+#pragma unroll
+        for (int f = 0; f < H; ++f) {
+            const bool fin = __builtin_isfinite(v[f]);
+            v[f] = fin ? v[f] : __builtin_inff();
+            n_lane += fin ? 1 : 0;
+        }
+    }
+    const int n = n_lane + swapi(n_lane);  // the pixel's finite samples: sorted ranks [0, n)
+
+    // ---- sort: 256 per lane, cross step, in-lane bitonic merge ----
+    SortNet<H>::sort(v);
+    dpp_fence(v);
+#pragma unroll
+    for (int i = 0; i < H / 2; ++i) {
+        const float t1 = swapf(v[H - 1 - i]), t2 = swapf(v[i]);
+        const float lo1 = ab_v_min(v[i], t1), hi1 = ab_v_max(v[i], t1);
+        const float lo2 = ab_v_min(v[H - 1 - i], t2), hi2 = ab_v_max(v[H - 1 - i], t2);
+        v[i] = odd ? hi1 : lo1;
+        v[H - 1 - i] = odd ? hi2 : lo2;
+    }
+    if constexpr (MEDIAN_ONLY) {
+        // calibration.rs:106-124: 0 for no finite sample, else sorted[len / 2].  All 512 finite: rank 256 = the smallest of the odd
+        // lane's half, no merge needed
+        if (__all(n == 2 * H)) {
+            float m = v[0];
+#pragma unroll
+            for (int i = 1; i < H; ++i) m = ab_v_min(m, v[i]);
+            if (valid && odd) a.out[g] = m;
+            return;
+        }
+    }
+    bitonic_merge_256(v);
+    dpp_fence(v);
+
+    // ---- median (combine.rs:38-40) and MAD (combine.rs:42-46) ----
+    const int M = n >> 1;
+    float med, mad;
+    if (__all(n == 2 * H)) {
+        const float o0 = swapf(v[0]);
+        med = odd ? v[0] : o0;  // rank 256
+        // term(p) = max(med - V[p], V[p + 256] - med), p = 0 .. 255: V[p] is the even lane's v[p], V[p + 256] the odd lane's
+        float best = __builtin_inff();
+#pragma unroll
+        for (int p = 0; p < H; ++p) {
+            const float d = odd ? v[p] - med : med - v[p];
+            best = ab_v_min(best, ab_v_max(d, swapf(d)));
+        }
+        mad = best;
+    } else {
+        // per-pixel offsets: the ranks travel through LDS, the odd lane's half first.  The even lane evaluates
+        //   med = V[M];  best = med - V[0];  for p = 1 .. M with p + M < 512: best = min(best, max(med - V[p], V[p + M] - med))
+        // (ranks >= n are +inf pads and drop out by themselves; p <= 255 because a term needs p + M <= n - 1 <= 511)
+        float medv = 0.0f, best = __builtin_inff();
+        put_half(buf, v, odd, pix);
+        __syncthreads();
+        if (M >= H && M < 2 * H) medv = buf[(M - H) * 32 + pix];
+        if (__any(M < H)) {  // (wave-uniform) some pixel's median and near partners lie in the EVEN half
+            __syncthreads();
+            put_half(buf, v, !odd, pix);
+            __syncthreads();
+            if (M < H) medv = buf[M * 32 + pix];
+            if constexpr (!MEDIAN_ONLY) {
+                if (!odd) {
+#pragma unroll
+                    for (int p = 1; p < H; ++p) {  // (branch-free: the read is clamped, the term selected)
+                        const int r = p + M;
+                        const float w = buf[min(r, H - 1) * 32 + pix];
+                        const float t = fminf(best, fmaxf(medv - v[p], w - medv));
+                        best = (p <= M && r < H) ? t : best;
+                    }
+                }
+            }
+            __syncthreads();
+            put_half(buf, v, odd, pix);
+            __syncthreads();
+        }
+        if constexpr (!MEDIAN_ONLY) {
+            if (!odd) {  // the terms whose partner rank lies in the ODD half (which is what buf holds now)
+#pragma unroll
+                for (int p = 1; p < H; ++p) {
+                    const int r = p + M - H;
+                    const float w = buf[min(max(r, 0), H - 1) * 32 + pix];
+                    const float t = fminf(best, fmaxf(medv - v[p], w - medv));
+                    best = (p <= M && r >= 0 && r < H) ? t : best;
+                }
+                best = fminf(best, medv - v[0]);
+            }
+        }
+        const float em = swapf(medv), eb = swapf(best);  // (the even lane's)
+        med = odd ? em : medv;
+        mad = odd ? eb : best;
+    }
+
+    if constexpr (MEDIAN_ONLY) {
+        if (valid && !odd) a.out[g] = (n == 0) ? 0.0f : med;
+        return;
+    }
+
+    // ---- clipping iterations (combine.rs:31-83), the oracle's arithmetic: two-pass mean / variance over the rank interval ----
+    const int base = odd ? H : 0;
+    float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
+    float center = med;
+    int ra = 0, rb = n - 1, len = n;  // survivors: global ranks ra .. rb
+    uint32_t rej = 0;
+    float last_center = __builtin_nanf("");
+    bool active = n >= 2;
+    for (uint32_t it = 0; it < a.max_iter; ++it) {
+        if (!__any(active)) break;
+        launder(v);
+        int la = max(ra - base, 0), lb = min(rb - base, H - 1);  // this lane's part of the interval
+        if (ra > rb || la > lb) la = lb = -1;                    // none: (unsigned)(i + 1) <= 0 holds for no i >= 0
+        if (it > 0) {
+            const double S = pair_sum<0>(v, la, lb, odd, 0.0);
+            const double nn = (double)len;
+            const double mean = S / nn;
+            opaque(la, lb);
+            const double Q = pair_sum<1>(v, la, lb, odd, mean);
+            const double variance = Q / fmax(nn - 1.0, 1.0);
+            center = (float)mean;
+            sigma = (float)fmax(sqrt(variance), 1e-10);
+            opaque(la, lb);
+        }
+        const bool go = active && (len >= 2);  // `if len < 2 { break }` (combine.rs:33-35)
+        if (go) last_center = center;          // combine.rs:63
+        const float lo = -a.sigma_low * sigma;  // combine.rs:65-66
+        const float hi = a.sigma_high * sigma;
+        int cl = 0, ch = 0;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const bool in = (unsigned)(i - la) <= (unsigned)(lb - la);
+            const float dev = v[i] - center;
+            cl += (in && !(dev >= lo)) ? 1 : 0;
+            ch += (in && !(dev <= hi)) ? 1 : 0;
+        }
+        cl += swapi(cl);
+        ch += swapi(ch);
+        // a sample can fail both tests only if nothing survives (lo > hi or NaN thresholds)
+        const int removed = (cl + ch > len) ? len : (cl + ch);
+        if (go) {
+            rej += (uint32_t)removed;  // combine.rs:76-78
+            len -= removed;
+            if (len > 0) {
+                ra += cl;
+                rb -= ch;
+            } else {
+                ra = 1;
+                rb = 0;
+            }
+        }
+        active = go && (removed != 0);  // combine.rs:80-82
+    }
+
+    // ---- result (combine.rs:20-26,85-91) ----
+    launder(v);
+    int la = max(ra - base, 0), lb = min(rb - base, H - 1);
+    if (ra > rb || la > lb) la = lb = -1;
+    opaque(la, lb);
+    const double S = pair_sum<0>(v, la, lb, odd, 0.0);  // an empty interval sums to 0
+    float value;
+    if (n == 0)
+        value = 0.0f;
+    else if (n == 1)
+        value = med;  // the single finite sample is V[0] = V[n / 2]
+    else if (len == 0)
+        value = __builtin_isfinite(last_center) ? last_center : 0.0f;
+    else
+        value = (float)(S / (double)len);
+    if (valid && !odd) a.out[g] = value;
+
+    // rejection count: one atomic per wave, spread over kRejSlots counters (summed by the host)
+    int r = (valid && !odd) ? (int)rej : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
+    if (lane == 0 && r != 0) atomicAdd(&a.rejected[blockIdx.x & (kRejSlots - 1)], (unsigned long long)r);
+}
+
+}  // namespace
+
+// dplanes: HOST array of n device pointers (256 < n <= 512), contiguous planes of rows x cols; counters already cleared by the caller
+int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg,
+                         float *out_dev, bool median_only) {
+    AB_CHECK(ctx, n > 256 && n <= 512, "the two-lane stack takes 257 .. 512 frames (got %zu)", n);
+    void *ws = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, 512 * (sizeof(float *) + sizeof(int64_t)), &ws));
+    // the table is tiny; a blocking copy keeps the host array's lifetime out of the picture
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // frames the stack is short of 512: ONE plane of +inf stands in for all of them (a non-finite sample is exactly what the
+    // algorithm ignores, combine.rs:170-175; the pad reads stay in L2) -- every load of the kernel is unconditional
+    const float *table[512];
+    const int64_t total = rows * cols;
+    const float *inf_plane = nullptr;
+    if (n < 512) {
+        float *ip = nullptr;
+        const void *before = ctx->ws[AB_WS_STACK_INF];
+        const size_t had = ctx->ws_bytes[AB_WS_STACK_INF];
+        AB_TRY(ab_workspace(ctx, AB_WS_STACK_INF, (size_t)total * sizeof(float), (void **)&ip));
+        if (ip != before || had < (size_t)total * sizeof(float))
+            AB_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ip, 0x7f800000, ctx->ws_bytes[AB_WS_STACK_INF] / sizeof(float), ctx->stream));
+        inf_plane = ip;
+    }
+    for (size_t i = 0; i < 512; ++i) table[i] = i < n ? dplanes[i] : inf_plane;
+    AB_HIP(ctx, hipMemcpy(ws, table, sizeof table, hipMemcpyHostToDevice));
+    PairArgs a;
+    a.p = (const float *const *)ws;
+    a.n = (int)n;
+    a.total = total;
+    a.sigma_low = cfg->sigma_low;
+    a.sigma_high = cfg->sigma_high;
+    a.max_iter = cfg->max_iterations;
+    a.out = out_dev;
+    a.rejected = ctx->counters;
+    a.median_only = median_only ? 1 : 0;
+    const dim3 grid((unsigned)((a.total + 31) / 32)), block(64);
+    if (median_only)
+        hipLaunchKernelGGL(stack_pair_kernel<true>, grid, block, 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(stack_pair_kernel<false>, grid, block, 0, ctx->stream, a);
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}

@@ -1224,12 +1224,18 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     bool contig_all = total < (int64_t(1) << 30);
     for (size_t i = 0; i < n && contig_all; ++i) contig_all = ld[i] == cols;
     const bool reg128 = n > 64 && n <= 256 && contig_all && !partial && !ctx->stack_exact;  // (and 129 .. 256; median_combine too)
-    if (n > 64 && !reg128) {  // deeper than one lane's registers: one wave per pixel (stack_wide.hip)
+    if (n > 64 && !reg128) {  // deeper than one lane's registers
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
         ctx->stack_ev_valid = false;
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
-        AB_TRY(ab_stack_wide_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
+        // 257 .. 512 contiguous frames, plain full-image stack or median combine: two lanes per pixel (stack_pair.hip), bit-identical
+        // to the wave-per-pixel kernel (AB_STACK_NO_PAIR=1 keeps that one); everything else: one wave per pixel (stack_wide.hip)
+        static const bool no_pair = getenv("AB_STACK_NO_PAIR") != nullptr;
+        if (n > 256 && contig_all && !partial && !no_pair)
+            AB_TRY(ab_stack_pair_device(ctx, dplanes, n, rows, cols, cfg, out_dev, median_only));
+        else
+            AB_TRY(ab_stack_wide_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[1], ctx->stream));
         ctx->stack_ev_valid = true;
         if (out_rejected) AB_TRY(read_rejected(ctx, out_rejected));

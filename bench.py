@@ -384,8 +384,9 @@ def main():
         iso_ms = i0.elapsed_time(i1) / 5
 
     # ---- the same step with the frames starting in HOST memory, as a command of the application would hold them (Array2<f32> in
-    # GLOBAL_IMAGE_CACHE): 64 x 67 MB cross PCIe once.  The uploads run on their own stream, four chunks of 16 frames, and the
-    # registration of a chunk starts when its frames have landed, so the link is busy from the first byte to (almost) the last.
+    # GLOBAL_IMAGE_CACHE): 64 x 67 MB cross PCIe once.  ONE registration call takes the 63 host frames (round 4): the library
+    # uploads them on its own stream, an event behind each frame, and its pipeline registers a frame when it has landed, so the
+    # link is busy from the first byte to the last and what remains after it is one group's registration.
     host_info = None
     if args.host_planes and world == 1 and not sharded and register and not args.known_transforms:
         hosts = [torch.empty((R, Cc), dtype=torch.float32, pin_memory=True) for _ in range(N)]
@@ -394,37 +395,16 @@ def main():
         up = [torch.empty_like(raw[0]) for _ in range(N)]
         hw = [up[0]] + [torch.empty_like(raw[0]) for _ in range(1, N)]
         copy_stream = torch.cuda.Stream()
-        # frames per upload / registration chunk: LARGE chunks first (a registration call has ~2.5 ms of fixed cost -- the reference
-        # frame's detection, the tile pipeline's first launch -- which hides under the uploads still to come), SMALL ones last
-        # (what is registered after the last byte has landed is exposed).  AB_HOST_CHUNKS overrides (developer knob).
-        sched = [int(x) for x in os.environ.get("AB_HOST_CHUNKS", "40,16,8").split(",")]
-        chunks, c0 = [], 0
-        for w in sched:
-            if c0 < N:
-                chunks.append(list(range(c0, min(c0 + w, N))))
-                c0 += w
-        if c0 < N:
-            chunks.append(list(range(c0, N)))
         torch.cuda.synchronize()
 
         def upload_all():
-            evs = []
             with torch.cuda.stream(copy_stream):
-                for ch in chunks:
-                    for k in ch:
-                        up[k].copy_(hosts[k], non_blocking=True)
-                    e_ = torch.cuda.Event()
-                    e_.record(copy_stream)
-                    evs.append(e_)
-            return evs
+                for k in range(N):
+                    up[k].copy_(hosts[k], non_blocking=True)
 
         def host_step():
-            evs = upload_all()
-            main_s = torch.cuda.current_stream()
-            for ci, ch in enumerate(chunks):
-                main_s.wait_event(evs[ci])
-                tg = [k for k in ch if k != 0]
-                ctx.align_pairs_affine(up[0], [up[k] for k in tg], [hw[k] for k in tg], num_threads=8)
+            up[0].copy_(hosts[0], non_blocking=True)   # the reference frame: the stack reads it from HBM as well
+            ctx.align_pairs_affine(up[0], hosts[1:], hw[1:], num_threads=8)
             ctx.stack_sigma_clip(hw, 3.0, 3.0, 5, out=stacked, want_rejected=False)
             ctx.auto_stretch_preview(stacked, out=u8)
 

@@ -390,8 +390,10 @@ pub fn register_frames<P: PlaneSrc>(hip: &Hip, reference: &impl PlaneSrc, target
     hip.check(unsafe { sys::ab_register_frames(hip.ctx, &reference.ab(), planes.as_ptr(), planes.len(), num_threads(), out.as_mut_ptr()) })?;
     Ok(out.iter().map(align_from_sys).collect())
 }
-/// align_pair(reference, targets[i], Affine) for every i (pair.rs:41-77): estimate + warp, frames resident in HBM
-pub fn align_pairs_affine(hip: &Hip, reference: &DevicePlane, targets: &[DevicePlane], aligned: &mut [DevicePlane]) -> Result<Vec<AffineAlignResult>> {
+/// align_pair(reference, targets[i], Affine) for every i (pair.rs:41-77): estimate + warp into HBM.  The reference and the targets
+/// may be host arrays (`&Array2<f32>` as GLOBAL_IMAGE_CACHE holds them) or DevicePlanes: host frames are uploaded by the library
+/// on its own stream and registered as they land (one call for the whole set -- do not chunk it)
+pub fn align_pairs_affine<P: PlaneSrc>(hip: &Hip, reference: &impl PlaneSrc, targets: &[P], aligned: &mut [DevicePlane]) -> Result<Vec<AffineAlignResult>> {
     let planes: Vec<_> = targets.iter().map(|t| t.ab()).collect();
     let mut outs: Vec<_> = aligned.iter_mut().map(|a| a.ab_mut()).collect();
     let mut res: Vec<sys::ab_affine_align_result> = vec![unsafe { std::mem::zeroed() }; targets.len()];

@@ -208,8 +208,12 @@ AB_API int ab_align_channel_affine(ab_ctx *ctx, const ab_plane *reference, const
 AB_API int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
                               ab_affine_align_result *out);
 /* align_pair(reference, targets[i], AlignMethod::Affine) for i < n (core/alignment/pair.rs:41-77): the estimate above
- * followed by warp_image(target, transform) into aligned[i].  Device-resident planes only; each worker warps its
- * frame right after estimating it, so the warps overlap the other frames' detection. */
+ * followed by warp_image(target, transform) into aligned[i] (device planes); each worker warps its frame right after
+ * estimating it, so the warps overlap the other frames' detection.  The reference and any target may be HOST planes
+ * (on_device = 0), as the application holds its frames (core/stacking/calibration.rs:306-315, infra/cache.rs:306-310):
+ * the library copies them into HBM on its own stream, one event per frame, and registers each frame as it lands -- the
+ * call costs the upload plus one group's registration, not upload + registration.  Pinned host memory keeps the copies
+ * asynchronous; results do not depend on where a frame started. */
 AB_API int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane *targets, size_t n, int num_threads,
                                  ab_affine_align_result *out, ab_plane_mut *aligned);
 /* the star-list half (triangles -> votes -> RANSAC -> sanity) on given centroids; host only */

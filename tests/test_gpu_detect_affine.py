@@ -221,6 +221,79 @@ def test_align_pairs_affine_equals_estimate_then_warp(ctx, oracle):
         assert np.array_equal(o.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("n_targets", [2, 7])
+def test_align_pairs_affine_takes_host_frames(ctx, oracle, n_targets):
+    """The application holds its frames on the host (calibration.rs:306-315): ab_align_pairs_affine uploads on_device = 0 frames on
+    its own stream and registers each as it lands.  Transforms and warped planes equal the device-resident call's bit for bit, for
+    pinned tensors, pageable numpy arrays, a mix of both with device frames, and a host reference; 2 targets take the
+    frame-by-frame path, 7 the grouped one (two groups, the second short)."""
+    import torch
+    from astroburst_amd import synth
+    rows, cols = 448, 576
+    y, x, flux = synth.star_catalog(rows, cols, 350, seed=21)
+    cat = (y, x, flux * 30.0)
+    ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=0.0)
+    shifts = [(2.5, -1.0), (-3.0, 4.0), (0.5, 0.25), (6.0, 2.0), (-1.25, -2.5), (0.0, 3.5), (4.0, -4.0)][:n_targets]
+    tgts = [synth.make_frame(rows, cols, k + 1, cat=cat, shift=s, bad_patch_rate=0.0, cosmic_rate=0.0) for k, s in enumerate(shifts)]
+    if n_targets > 2:
+        tgts[2] = torch.full((rows, cols), 1000.0)   # no stars: the phase-correlation fallback reads the staged copy as well
+    dev = [t.cuda() for t in tgts]
+    want_out = [torch.empty_like(t) for t in dev]
+    want = ctx.align_pairs_affine(ref.cuda(), dev, want_out, num_threads=8)
+    o0 = oracle.align_channel_affine(ref.numpy(), tgts[0].numpy(), num_threads=8)
+    assert want[0].method == o0.method and np.allclose(want[0].transform, o0.transform, rtol=0, atol=1e-8)
+    variants = {
+        "pinned": (ref.cuda(), [t.pin_memory() for t in tgts]),
+        "pageable numpy": (ref.cuda(), [t.numpy() for t in tgts]),
+        "mixed": (ref.cuda(), [t.pin_memory() if k % 2 else d for k, (t, d) in enumerate(zip(tgts, dev))]),
+        "host reference": (ref.numpy(), [t.pin_memory() for t in tgts]),
+    }
+    for name, (r, ts) in variants.items():
+        for rep in range(2):   # the second call reuses the staging area and the events
+            outs = [torch.full_like(d, -1.0) for d in dev]
+            got = ctx.align_pairs_affine(r, ts, outs, num_threads=8)
+            for g, w, o, wo in zip(got, want, outs, want_out):
+                assert (g.method, g.transform, g.inliers, g.matched_stars) == (w.method, w.transform, w.inliers, w.matched_stars), name
+                assert torch.equal(o.isnan(), wo.isnan()) and torch.equal(o.nan_to_num(), wo.nan_to_num()), name
+
+
+def test_fed_pipeline_equals_upfront_percentiles(tmp_path):
+    """Round 4: frames arriving from the host go through a pipeline whose percentiles run chunk by chunk on the device
+    (ab_bg_pipeline_begin_fed); AB_PIPE_FED=1 sends device-resident frames the same way.  The default order (all frames'
+    percentiles up front, a host join, then the tiles) and the fed one give the same transforms, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from astroburst_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    y, x, flux = synth.star_catalog(768, 768, 400, seed=5)
+    cat = (y, x, flux * 25.0)
+    frames = [synth.make_frame(768, 768, k, cat=cat, device="cuda", shift=(0.7 * k, -1.1 * k)).cpu().numpy() for k in range(7)]
+    np.save(tmp_path / "frames.npy", np.stack(frames))
+    code = (
+        "import sys, json\n"
+        "sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import astroburst_amd as ab\n"
+        "ctx = ab.Context(0)\n"
+        "f = [torch.from_numpy(a).cuda() for a in np.load(%r)]\n"
+        "res = ctx.register_frames(f[0], f[1:], 8)\n"
+        "print('RESULT', json.dumps([[float(v).hex() for v in r.transform] + [str(r.method), int(r.inliers)] for r in res]))\n"
+    ) % (root, str(tmp_path / "frames.npy"))
+    out = []
+    for fed in (False, True):
+        env = dict(os.environ)
+        env.pop("AB_PIPE_FED", None)
+        if fed:
+            env["AB_PIPE_FED"] = "1"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        assert r.returncode == 0 and line, r.stdout[-2000:] + r.stderr[-3000:]
+        out.append(line[0])
+    assert out[0] == out[1]
+    assert out[0].count("affine") == 6
+
+
 def test_chained_detection_gives_the_same_transform(tmp_path):
     """AB_DETECT_CHAIN=1 (read once per process): percentiles -> tiles -> background -> threshold -> labels enqueued back to back
     with the parameters travelling through device memory.  Same registration result as the default path, bit for bit.  (The two

@@ -183,6 +183,46 @@ def test_deep_median_combine(ctx, oracle, n):
     assert np.array_equal(ctx.median_combine(fr), oracle.median_combine(fr), equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [257, 300, 384, 511, 512])
+def test_two_lanes_per_pixel_stack(ctx, oracle, n):
+    """257 .. 512 contiguous frames: csrc/stack_pair.hip (two lanes per pixel: 256 samples each, cross step + in-lane bitonic
+    merge, ranks through DPP or LDS, the oracle's ascending f64 sums continued from the even lane into the odd one).  Bit for bit
+    the oracle on dirty frames (NaN / inf / ties / constant / empty / single-sample pixels: the LDS paths) and on clean ones (all
+    samples finite: the DPP paths), sigma-clip and median combine; 1500 pixels = 47 waves, the last one partly filled."""
+    fr = deep_frames(n, (30, 50), 7000 + n)
+    rng = np.random.default_rng(n)
+    clean = [rng.normal(500.0, 12.0, (30, 50)).astype(np.float32) for _ in range(n)]
+    for k in range(0, n, 11):
+        clean[k][rng.random((30, 50)) < 0.02] += 300.0                # outliers to clip, still finite
+    for name, frames in (("dirty", fr), ("clean", clean)):
+        for sl, sh, it in ((3.0, 3.0, 5), (2.0, 2.5, 3), (1.0, 1.0, 1), (3.0, 3.0, 0), (0.5, 0.5, 8)):
+            want, wrej = oracle.stack_images(frames, sl, sh, it)
+            got, rej = ctx.stack_sigma_clip(frames, sl, sh, it)
+            assert rej == wrej, (name, sl, sh, it)
+            assert np.array_equal(got, want, equal_nan=True), (name, sl, sh, it)
+        assert np.array_equal(ctx.median_combine(frames), oracle.median_combine(frames), equal_nan=True), name
+
+
+def test_two_lanes_per_pixel_at_scale(ctx, oracle):
+    """512 x 512^2 frames on the device (byte offsets, grid, rejection counters at a real size), one third of the frames with a
+    dead row or a hot column; 320 frames of the same set through the +inf pad plane"""
+    import torch
+    rows = cols = 512
+    g = torch.Generator(device="cuda").manual_seed(512)
+    dev = [1000.0 + 15.0 * torch.randn((rows, cols), device="cuda", generator=g) for _ in range(512)]
+    for k in range(0, 512, 3):
+        dev[k][k % rows, :] = float("nan")
+        dev[k][:, (5 * k) % cols] += 500.0
+    dev[7][100:200, 100:200] = float("inf")
+    fr = [d.cpu().numpy() for d in dev]
+    for n in (512, 320):
+        want, wrej = oracle.stack_images(fr[:n], 3.0, 3.0, 5)
+        got, rej = ctx.stack_sigma_clip(dev[:n], 3.0, 3.0, 5)
+        assert rej == wrej
+        assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)
+        assert np.array_equal(ctx.median_combine(dev[:n]).cpu().numpy(), oracle.median_combine(fr[:n]), equal_nan=True)
+
+
 @pytest.mark.parametrize("n", [100, 200])
 def test_deep_stack_at_scale(ctx, oracle, n):
     """1024^2 x 100 / 200 frames through the 128 / 256-sample register kernels (byte offsets, grid and pad plane at a real size)"""

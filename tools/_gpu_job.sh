@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -x -q < /dev/null 2>&1 | grep -E "passed|failed|error" | tail -n 3 > gpurun_out/r03x_pytest_gpu.log
-timeout 600 python bench.py > gpurun_out/r03x_bench.json 2> gpurun_out/r03x_bench.err < /dev/null
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r03x_smoke.txt 2>&1 < /dev/null
+timeout 900 python -X faulthandler -m pytest tests/test_gpu_stack.py -m gpu -x -q < /dev/null > gpurun_out/r04h_pytest.log 2>&1
+tail -n 12 gpurun_out/r04h_pytest.log
+N_LIST=320,512 timeout 600 python tools/time_stack_deep.py > gpurun_out/r04h_deep.txt 2>&1
+cat gpurun_out/r04h_deep.txt
