@@ -134,12 +134,39 @@ int ab_progress(ab_ctx *ctx, const char *stage, uint64_t current, uint64_t total
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);
 
+// AB_UPLOAD_TRACE=1 (developer knob): a timeline of a host-fed registration call on stderr, milliseconds since the call began
+inline std::chrono::steady_clock::time_point &ab_trace_t0() {
+    static std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    return t;
+}
+inline bool ab_upload_trace_on() {
+    static const bool on = getenv("AB_UPLOAD_TRACE") != nullptr;
+    return on;
+}
+inline void ab_upload_trace(const char *what, long a, long b = -1) {
+    if (!ab_upload_trace_on()) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ab_trace_t0()).count();
+    fprintf(stderr, "[ab timeline] %8.3f ms  %s %ld %ld\n", ms, what, a, b);
+}
+
 // A non-blocking stream, optionally confined to a subset of the compute units: `env` names an environment variable holding a 32-bit
 // hex pattern that is repeated over the chip's CU mask (0x55555555 = every other CU).  Unset / 0 / ffffffff: an ordinary stream.
-inline hipError_t ab_stream_create_masked(ab_ctx *ctx, hipStream_t *out, const char *env) {
+// prio_env / prio_default: the stream's priority (-1 high, 0 normal, 1 low; clamped to the device's range).  The runtime multiplexes
+// all streams of one priority onto four in-order hardware queues; a stream of another priority gets a queue of another pool, so
+// a stream that holds long-running or long-waiting packets (the tile kernels, the upload's copy barriers) no longer stands in
+// front of a quarter of the worker streams' kernels.
+inline hipError_t ab_stream_create_masked(ab_ctx *ctx, hipStream_t *out, const char *env, const char *prio_env = nullptr, int prio_default = 0) {
     const char *v = env ? getenv(env) : nullptr;
     const uint32_t pat = v ? (uint32_t)strtoul(v, nullptr, 16) : 0u;
-    if (pat == 0u || pat == 0xffffffffu) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    if (pat == 0u || pat == 0xffffffffu) {
+        const char *pv = prio_env ? getenv(prio_env) : nullptr;
+        int prio = pv ? atoi(pv) : prio_default;
+        if (prio == 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+        int least = 0, greatest = 0;  // (numerically: greatest priority <= least priority)
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+        prio = prio < greatest ? greatest : (prio > least ? least : prio);
+        return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+    }
     const int words = (ctx->cu_count > 0 ? ctx->cu_count + 31 : 256) / 32;
     uint32_t mask[16];
     for (int i = 0; i < 16; ++i) mask[i] = pat;
@@ -254,9 +281,11 @@ struct ab_bg_pipeline {
     int ntiles = 0, chunk = 1;
     size_t n = 0;
     const ab_pixel_xf *xf_host = nullptr;  // fed pipeline: plane i's transform, valid once ab_bg_pipeline_get(i) has returned
+    struct ab_bg_feed_impl *feed = nullptr;  // the feeder thread of a pipeline whose planes are still landing (detect.hip)
 };
-// the pipeline fed chunk by chunk: the percentiles run per chunk on the device (no host join before the first tile launch), and a
-// chunk waits for its planes' `landed` events (nullable; a null entry = the plane is complete already)
+void ab_bg_pipeline_end(ab_bg_pipeline *p);  // joins the feeder, if any (before the streams are drained / the planes released)
+// the pipeline fed chunk by chunk: the percentiles run per chunk on the device (no host join before the first tile launch); with
+// `landed` events (nullable; a null entry = the plane is complete already) a feeder thread enqueues a chunk when its planes have landed
 int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, int chunk, const hipEvent_t *landed,
                              ab_bg_pipeline *p);
 int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, const ab_pixel_xf *xf, int chunk,

@@ -984,7 +984,9 @@ static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const
         xf[k] = xfs[frames[k]];
     }
     std::vector<ab_detected_star> det[kTriGroupMax];
+    ab_upload_trace("group starts detection, first frame", (long)frames[0]);
     AB_TRY(ab_detect_stars_group_device(wc, imgs, G, rows, cols, kDetectionSigma, xf, bg, kMaxStars, det));
+    ab_upload_trace("group detected, first frame", (long)frames[0]);
     std::vector<Pt> ts[kTriGroupMax];
     for (int k = 0; k < G; ++k)
         for (const auto &st : det[k]) {
@@ -1005,10 +1007,12 @@ static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const
         if (any) {
             std::vector<uint32_t> votes[kTriGroupMax];
             AB_TRY(gpu_match_group(wc, ref_ws, live, G, votes));
+            ab_upload_trace("group votes back, first frame", (long)frames[0]);
             for (int k = 0; k < G; ++k) {
                 if (live[k].empty()) continue;
                 const auto matches = matches_from_votes(rs, ts[k], votes[k].data(), kVoteDim);
                 found[k] = transform_from_matches(matches, rows, cols, num_threads, &out[frames[k]]);
+                ab_upload_trace("frame fitted", (long)frames[k]);
                 if (found[k]) AB_TRY(frame_done(frames[k]));  // (its warp starts while the next frame's RANSAC runs)
             }
         }
@@ -1056,6 +1060,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         ab_ctx *c;
         ab_bg_pipeline *p;
         ~AuxDrain() {
+            ab_bg_pipeline_end(p);
             if (p->on && c->pct_stream) (void)hipStreamSynchronize(c->pct_stream);
             if (p->on && c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
         }
@@ -1169,7 +1174,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     const bool inline_run = std::min<size_t>(n_jobs, (size_t)std::max(ctx->register_workers, 1)) <= 1;
     static const bool own_warp_stream = getenv("AB_NO_WARP_STREAM") == nullptr;
     if (!inline_run && aligned && own_warp_stream) {
-        if (!ctx->warp_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->warp_stream, "AB_WARP_CU_MASK"));
+        if (!ctx->warp_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->warp_stream, "AB_WARP_CU_MASK", "AB_WARP_PRIO", 0));
         warp_stream = ctx->warp_stream;
     }
     if (inline_run) {  // the reference first, on ctx
@@ -1281,7 +1286,9 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
         AB_HIP(ctx, hipMalloc(&ctx->upload_buf, slots * stride));
         ctx->upload_bytes = slots * stride;
     }
-    if (!ctx->upload_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->upload_stream, hipStreamNonBlocking));
+    // (a queue of its own pool: 63 copies are enqueued up front, each a barrier packet that waits for its DMA -- on a queue shared
+    // with worker streams they held a quarter of the groups back until the LAST frame had landed: measured, 8 ms after the last byte)
+    if (!ctx->upload_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->upload_stream, nullptr, "AB_UPLOAD_PRIO", 1));
     while (ctx->upload_events.size() < slots) {
         hipEvent_t e;
         AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1305,6 +1312,7 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
     static const bool up_trace = getenv("AB_UPLOAD_TRACE") != nullptr;
     hipEvent_t tr0 = nullptr, tr1 = nullptr;
     const auto t_call = std::chrono::steady_clock::now();
+    ab_trace_t0() = t_call;
     if (up_trace) {
         AB_HIP(ctx, hipEventCreate(&tr0));
         AB_HIP(ctx, hipEventCreate(&tr1));
@@ -1324,6 +1332,7 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
     const double enq_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     const int rc = ab_register_frames_device(ctx, ref_dev, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data(),
                                              n_host ? landed.data() : nullptr);
+    ab_upload_trace("registration returned", (long)n);
     if (up_trace) {
         const double call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
         float up_ms = 0.0f;

@@ -32,6 +32,8 @@
 #include <cfloat>
 #include <cmath>
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 
 namespace {
 
@@ -1064,7 +1066,7 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // detect_stars' choice (:100)
     const int step = (int)std::max<int64_t>(tile_size, 16);
     const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
-    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK"));
+    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK", "AB_TILE_PRIO", 0));
     const size_t nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
     while (ctx->aux_events.size() < nchunks) {
         hipEvent_t e;
@@ -1124,9 +1126,76 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
 // The same pipeline FED chunk by chunk (round 4): nothing is known about a plane on the host before its chunk has run.  The
 // percentiles of normalize_for_detection (subsample + radix select, one workgroup per plane) run per chunk on a third stream and
 // leave each plane's transform in a device table (read by the tile kernel) and in a pinned mirror (read by the workers after
-// ab_bg_pipeline_get); a chunk's tile launch waits for its percentiles by event.  `landed` (nullable): one event per plane that is
-// still being written when this returns (an upload from the host in flight) -- a chunk's percentiles wait for its planes' events,
-// so the registration of frame k starts when frame k has landed, whatever is still on the link.
+// ab_bg_pipeline_get); a chunk's tile launch waits for its percentiles by event.
+// `landed` (nullable): one event per plane that is still being written when this returns (an upload from the host in flight).
+// A chunk is then enqueued by a FEEDER THREAD once its planes' events have completed on the host.  (Enqueueing every chunk up
+// front behind hipStreamWaitEvent was measured first: the runtime multiplexes all streams onto four hardware queues, a wait
+// packet at the head of a queue holds back every stream that shares it, and a third of the workers' kernels ran only after the
+// LAST frame had landed -- 10 ms of registration behind a 76 ms upload instead of ~2.)
+struct FedPlan {  // everything a chunk's launches need, by value (the feeder outlives ab_bg_pipeline_begin_fed)
+    ab_ctx *ctx = nullptr;
+    std::vector<const float *> planes;
+    std::vector<hipEvent_t> landed;
+    size_t n = 0, nchunks = 0;
+    int chunk = 1, step = 0, ntx = 0, ntiles = 0;
+    int64_t rows = 0, cols = 0, len = 0, sstep = 1, ns = 0;
+    float *sub = nullptr;
+    const float **dplanes = nullptr;
+    ab_pixel_xf *dxf = nullptr, *hxf = nullptr;
+    PercentileOut *hpo = nullptr;
+    int enqueue(size_t c) const {
+        const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
+        PlaneList pl;
+        for (size_t i = 0; i < (size_t)kManyPlanes; ++i) pl.p[i] = planes[first + (i < cnt ? i : 0)];
+        float *csub = sub + first * (size_t)ns;
+        hipLaunchKernelGGL(subsample_many_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->pct_stream, pl, len, sstep, csub, ns);
+        if (ns <= (int64_t)kPctPer * 1024)
+            hipLaunchKernelGGL(percentiles_many_reg_kernel, dim3((unsigned)cnt), dim3(1024), 0, ctx->pct_stream, (const float *)csub, (unsigned int)ns,
+                               hpo + first, dxf + first, hxf + first);
+        else
+            hipLaunchKernelGGL(percentiles_many_mem_kernel, dim3((unsigned)cnt), dim3(1024), 0, ctx->pct_stream, (const float *)csub, (unsigned int)ns,
+                               hpo + first, dxf + first, hxf + first);
+        AB_HIP(ctx, hipEventRecord(ctx->pct_events[c], ctx->pct_stream));
+        AB_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->pct_events[c], 0));
+        AB_TRY(launch_tile_kernels(ctx, ctx->aux_stream, 1, nullptr, rows, cols, cols, step, ntx, ntiles, (int)cnt, ab_pixel_xf(),
+                                   (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, nullptr, (const float *const *)(dplanes + first),
+                                   (const ab_pixel_xf *)(dxf + first)));
+        AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
+        AB_HIP(ctx, hipGetLastError());
+        return AB_OK;
+    }
+};
+struct ab_bg_feed_impl {
+    FedPlan plan;
+    std::mutex m;
+    std::condition_variable cv;
+    size_t enqueued = 0;  // chunks whose launches are in the streams
+    int rc = AB_OK;
+    std::thread th;
+    void run() {
+        (void)hipSetDevice(plan.ctx->device);
+        for (size_t c = 0; c < plan.nchunks; ++c) {
+            int r = AB_OK;
+            const size_t first = c * (size_t)plan.chunk, cnt = std::min<size_t>((size_t)plan.chunk, plan.n - first);
+            for (size_t i = 0; i < cnt && r == AB_OK; ++i)
+                if (plan.landed[first + i] && hipEventSynchronize(plan.landed[first + i]) != hipSuccess)
+                    r = ab_set_error(plan.ctx, AB_ERR_HIP, "waiting for an uploaded frame failed");
+            ab_upload_trace("chunk landed", (long)c);
+            if (r == AB_OK) r = plan.enqueue(c);
+            ab_upload_trace("chunk enqueued", (long)c);
+            {
+                std::lock_guard<std::mutex> g(m);
+                if (r == AB_OK)
+                    enqueued = c + 1;
+                else
+                    rc = r;
+            }
+            cv.notify_all();
+            if (r != AB_OK) return;
+        }
+    }
+};
+
 int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, int chunk, const hipEvent_t *landed,
                              ab_bg_pipeline *p) {
     *p = ab_bg_pipeline();
@@ -1134,29 +1203,37 @@ int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, 
     if (legacy || n == 0 || rows < 3 || cols < 3 || chunk < 1) return AB_OK;
     if (chunk > kManyPlanes) chunk = kManyPlanes;
     AB_HIP(ctx, hipSetDevice(ctx->device));
+    FedPlan f;
+    f.ctx = ctx;
+    f.n = n;
+    f.chunk = chunk;
+    f.rows = rows;
+    f.cols = cols;
     const int64_t m = std::min(rows, cols);
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // detect_stars' choice (:100)
-    const int step = (int)std::max<int64_t>(tile_size, 16);
-    const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
-    const int64_t len = rows * cols;
-    const int64_t sstep = std::max<int64_t>(len / 100000, 1);  // affine.rs:28-30
-    const int64_t ns = (len + sstep - 1) / sstep;
-    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK"));
+    f.step = (int)std::max<int64_t>(tile_size, 16);
+    const int nty = (int)((rows + f.step - 1) / f.step);
+    f.ntx = (int)((cols + f.step - 1) / f.step);
+    f.ntiles = nty * f.ntx;
+    f.len = rows * cols;
+    f.sstep = std::max<int64_t>(f.len / 100000, 1);  // affine.rs:28-30
+    f.ns = (f.len + f.sstep - 1) / f.sstep;
+    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK", "AB_TILE_PRIO", 0));
     if (!ctx->pct_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->pct_stream, hipStreamNonBlocking));
-    const size_t nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
-    while (ctx->aux_events.size() < nchunks) {
+    f.nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
+    while (ctx->aux_events.size() < f.nchunks) {
         hipEvent_t e;
         AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->aux_events.push_back(e);
     }
-    while (ctx->pct_events.size() < nchunks) {
+    while (ctx->pct_events.size() < f.nchunks) {
         hipEvent_t e;
         AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         ctx->pct_events.push_back(e);
     }
     // pinned: tile results | plane pointers (staging copy) | transforms (the mirror the workers read) | percentile records
     const size_t ptr_bytes = (n * sizeof(const float *) + 15) & ~(size_t)15, xf_bytes = (n * sizeof(ab_pixel_xf) + 15) & ~(size_t)15;
-    const size_t tiles_bytes = (n * (size_t)ntiles * sizeof(TileOut) + 63) & ~(size_t)63;
+    const size_t tiles_bytes = (n * (size_t)f.ntiles * sizeof(TileOut) + 63) & ~(size_t)63;
     const size_t need = tiles_bytes + ptr_bytes + xf_bytes + n * sizeof(PercentileOut);
     if (need > ctx->aux_pinned_bytes) {
         if (ctx->aux_pinned) {
@@ -1171,61 +1248,65 @@ int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, 
     }
     char *dv = nullptr;  // device: plane pointers | transforms
     AB_TRY(ab_workspace(ctx, AB_WS_PIPE_TABLES, ptr_bytes + xf_bytes + 64, (void **)&dv));
-    float *sub = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_PIPE_SUBSAMPLE, n * (size_t)ns * sizeof(float), (void **)&sub));
-    const float **dplanes = (const float **)dv;
-    ab_pixel_xf *dxf = (ab_pixel_xf *)(dv + ptr_bytes);
+    AB_TRY(ab_workspace(ctx, AB_WS_PIPE_SUBSAMPLE, n * (size_t)f.ns * sizeof(float), (void **)&f.sub));
+    unsigned int *fail = nullptr;  // (sized once, here: the feeder's launches must not reallocate it)
+    AB_TRY(tile_fail_buffer(ctx, 1, (size_t)f.ntiles * (size_t)chunk, &fail));
+    f.dplanes = (const float **)dv;
+    f.dxf = (ab_pixel_xf *)(dv + ptr_bytes);
     char *stage = (char *)ctx->aux_pinned + tiles_bytes;
-    ab_pixel_xf *hxf = (ab_pixel_xf *)(stage + ptr_bytes);
-    PercentileOut *hpo = (PercentileOut *)(stage + ptr_bytes + xf_bytes);
+    f.hxf = (ab_pixel_xf *)(stage + ptr_bytes);
+    f.hpo = (PercentileOut *)(stage + ptr_bytes + xf_bytes);
     memcpy(stage, planes, n * sizeof(const float *));
-    // from the first enqueue on, a failure drains both streams before it returns: the launches read the caller's frames
-    auto enqueue = [&]() -> int {
-        AB_HIP(ctx, hipMemcpyAsync(dplanes, stage, n * sizeof(const float *), hipMemcpyHostToDevice, ctx->aux_stream));
-        for (size_t c = 0; c < nchunks; ++c) {
-            const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
-            if (landed)
-                for (size_t i = 0; i < cnt; ++i)
-                    if (landed[first + i]) AB_HIP(ctx, hipStreamWaitEvent(ctx->pct_stream, landed[first + i], 0));
-            PlaneList pl;
-            for (size_t i = 0; i < (size_t)kManyPlanes; ++i) pl.p[i] = planes[first + (i < cnt ? i : 0)];
-            float *csub = sub + first * (size_t)ns;
-            hipLaunchKernelGGL(subsample_many_kernel, dim3((unsigned)((ns + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->pct_stream, pl, len, sstep, csub, ns);
-            if (ns <= (int64_t)kPctPer * 1024)
-                hipLaunchKernelGGL(percentiles_many_reg_kernel, dim3((unsigned)cnt), dim3(1024), 0, ctx->pct_stream, (const float *)csub, (unsigned int)ns,
-                                   hpo + first, dxf + first, hxf + first);
-            else
-                hipLaunchKernelGGL(percentiles_many_mem_kernel, dim3((unsigned)cnt), dim3(1024), 0, ctx->pct_stream, (const float *)csub, (unsigned int)ns,
-                                   hpo + first, dxf + first, hxf + first);
-            AB_HIP(ctx, hipEventRecord(ctx->pct_events[c], ctx->pct_stream));
-            AB_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->pct_events[c], 0));
-            AB_TRY(launch_tile_kernels(ctx, ctx->aux_stream, 1, nullptr, rows, cols, cols, step, ntx, ntiles, (int)cnt, ab_pixel_xf(),
-                                       (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, nullptr, (const float *const *)(dplanes + first),
-                                       (const ab_pixel_xf *)(dxf + first)));
-            AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
-        }
-        AB_HIP(ctx, hipGetLastError());
-        return AB_OK;
-    };
-    const int rc = enqueue();
-    if (rc != AB_OK) {
-        (void)hipStreamSynchronize(ctx->pct_stream);
-        (void)hipStreamSynchronize(ctx->aux_stream);
-        return rc;
-    }
-    p->on = true;
+    f.planes.assign(planes, planes + n);
+    if (landed) f.landed.assign(landed, landed + n);
+    AB_HIP(ctx, hipMemcpyAsync(f.dplanes, stage, n * sizeof(const float *), hipMemcpyHostToDevice, ctx->aux_stream));
     p->tiles = ctx->aux_pinned;
     p->events = ctx->aux_events.data();
-    p->ntiles = ntiles;
+    p->ntiles = f.ntiles;
     p->chunk = chunk;
     p->n = n;
-    p->xf_host = hxf;
+    p->xf_host = f.hxf;
+    if (landed) {
+        ab_bg_feed_impl *feed = new ab_bg_feed_impl();
+        feed->plan = std::move(f);
+        p->feed = feed;
+        p->on = true;
+        feed->th = std::thread([feed] { feed->run(); });
+        return AB_OK;
+    }
+    // frames that are complete already: every chunk enqueued here.  From the first enqueue on, a failure drains both streams
+    // before it returns: the launches read the caller's frames
+    for (size_t c = 0; c < f.nchunks; ++c) {
+        const int rc = f.enqueue(c);
+        if (rc != AB_OK) {
+            (void)hipStreamSynchronize(ctx->pct_stream);
+            (void)hipStreamSynchronize(ctx->aux_stream);
+            return rc;
+        }
+    }
+    p->on = true;
     return AB_OK;
+}
+
+// joins the feeder (if any): call before the pipeline's streams are drained and before the planes go away
+void ab_bg_pipeline_end(ab_bg_pipeline *p) {
+    if (p && p->feed) {
+        if (p->feed->th.joinable()) p->feed->th.join();
+        delete p->feed;
+        p->feed = nullptr;
+    }
 }
 
 int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *bg) {
     AB_CHECK(ctx, p && p->on && i < p->n, "background pipeline: no such plane");
-    AB_HIP(ctx, hipEventSynchronize(p->events[i / (size_t)p->chunk]));
+    const size_t c = i / (size_t)p->chunk;
+    if (p->feed) {  // the chunk's launches are in the streams only once its planes have landed
+        std::unique_lock<std::mutex> g(p->feed->m);
+        p->feed->cv.wait(g, [&] { return p->feed->enqueued > c || p->feed->rc != AB_OK; });
+        if (p->feed->enqueued <= c) return ab_set_error(ctx, p->feed->rc, "the background pipeline's feeder failed");
+    }
+    AB_HIP(ctx, hipEventSynchronize(p->events[c]));
+    ab_upload_trace("tiles ready, plane", (long)i);
     background_from_tiles((const TileOut *)p->tiles + i * (size_t)p->ntiles, p->ntiles, &bg[0], &bg[1]);
     return AB_OK;
 }
