@@ -18,7 +18,15 @@
 //     continues it -- the same sequence of f64 additions as one lane walking all 512 ranks, so the result is BIT-IDENTICAL to
 //     the wave-per-pixel kernel and to the CPU restatement (ORC_ORDER_ASCENDING), not merely within the 1e-5 contract.
 // ~25 000 instructions per wave of 32 pixels, 512 load instructions of 128 B each; one wave per SIMD (the samples fill the
-// register file), 32 KB of LDS per wave.
+// register file), 32 KB of LDS per wave.  Measured (4096^2, round 4): 512 frames 59.5 ms, 320 frames 64 ms (the LDS paths), where
+// the wave-per-pixel kernel takes 180 .. 375 ms -- 117 us per wave for ~32 000 executed instructions = 8 .. 9 cycles per
+// instruction: ONE wave per SIMD cannot issue faster (tools/valu_rate.hip's rates need two), so fewer instructions do not buy
+// time here.  Tried and backed out: sums taken eight samples at a time with wave-uniform inside / outside tests and counts that
+// stop at the first surviving sample (-35 % of the clip's instructions: 60.4 ms, and 82 ms for 320 frames -- the uniform masks
+// spill scalar registers); the maximum of an exchange as a ^ b ^ min (v_bitop3_b32, full rate) -- no change; four-wave
+// workgroups kept in step by a barrier every 128 exchanges so that the 60 KB of straight-line sort is fetched once per
+// workgroup (70.7 ms: the instruction cache was not the limit).  What would help is two waves per SIMD: four lanes per pixel
+// with 128 samples each.
 #include "ab_common.hpp"
 
 #include <algorithm>
