@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
             }
         }
         if (a.stage != 1) {
-            if constexpr (NP >= 8 && NP <= 64)
+            if constexpr (NP >= 8 && NP <= 128)
                 SortNet<NP>::sort_fused(v);  // the rewrite over min3 / med3 / max3 (tools/gen_sortnet.py): 789 instructions for 64 samples, not 1038
             else
                 SortNet<NP>::sort(v);

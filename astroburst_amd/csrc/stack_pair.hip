@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int n = n_lane + swapi(n_lane);  // the pixel's finite samples: sorted ranks [0, n)
 
     // ---- sort: 256 per lane, cross step, in-lane bitonic merge ----
-    SortNet<H>::sort(v);
+    SortNet<H>::sort_fused(v);  // the rewrite over min3 / med3 / max3 (tools/gen_sortnet.py): 5493 instructions, not 7486
     dpp_fence(v);
 #pragma unroll
     for (int i = 0; i < H / 2; ++i) {

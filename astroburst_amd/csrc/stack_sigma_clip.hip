@@ -979,7 +979,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         };
         SortNet<NP>::sort_fused(v, hook);
         n -= lost;
-    } else if constexpr (NP >= 8 && NP <= 64) {
+    } else if constexpr (NP >= 8 && NP <= 256) {
         SortNet<NP>::sort_fused(v);
     } else {
         SortNet<NP>::sort(v);

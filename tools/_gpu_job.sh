@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for i in 1 2 3 4 5 6; do
-timeout 900 python -X faulthandler -m pytest tests/test_gpu_background.py tests/test_gpu_batch.py -m gpu -x -q < /dev/null > gpurun_out/r04n_soak_$i.log 2>&1
-echo "run $i rc=$?"; tail -n 2 gpurun_out/r04n_soak_$i.log
-done
-grep -l "Abort\|fault\|Fatal" gpurun_out/r04n_soak_*.log
+timeout 1500 python -X faulthandler -m pytest tests/test_gpu_stack.py tests/test_gpu_batch.py tests/test_gpu_fits.py -m gpu -x -q < /dev/null > gpurun_out/r04r_pytest.log 2>&1
+tail -n 4 gpurun_out/r04r_pytest.log
+N_LIST=100,128,200,256,320,512 timeout 600 python tools/time_stack_deep.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04r_deep.txt
+timeout 600 python tools/time_median_combine.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04r_median.txt

@@ -35,7 +35,7 @@ import sys
 import numpy as np
 
 SIZES = (2, 4, 8, 16, 32, 64, 128, 256)
-FUSED_SIZES = (8, 16, 32, 64)
+FUSED_SIZES = (8, 16, 32, 64, 128, 256)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -131,20 +131,48 @@ def level_states(n, size, rng):
     size == 8: all 256 0-1 inputs of the block; otherwise all (size/4 + 1)^4 states made of four sorted runs (sorted runs pass
     the lower levels unchanged, so they arrive at the block's two child merges as they are).  Block 0 takes the states in
     order; the other blocks take the same set in a random order each.  Returns uint8 [n, S/8] (bit-packed along the states)."""
+    chunks = list(level_state_chunks(n, size, rng))
+    assert len(chunks) == 1
+    return chunks[0]
+
+
+CHUNK = 1 << 20   # states per batch of the top level of the 256-wire network (65^4 = 17.9 M states: 18 batches of 32 MB)
+
+
+QUICK = False   # the test suite's setting: of the 256-wire network's top level, two batches (2 M of 17.9 M states) instead of all
+
+
+def level_state_chunks(n, size, rng):
+    """level_states in batches: one batch for every level but the 256-wire one, whose (64 + 1)^4 states come CHUNK at a time (a
+    single block spans the network there, so no permutation of the set is needed: consecutive ranges of the state index)."""
     if size == 8:
         st = np.array(list(itertools.product((0, 1), repeat=8)), dtype=np.uint8)  # [256, 8]
+        sets = [st]
     else:
         q = size // 4
-        z = np.array(list(itertools.product(range(q + 1), repeat=4)), dtype=np.int16)  # [S, 4]
+        total = (q + 1) ** 4
         pos = np.arange(q, dtype=np.int16)
-        st = (pos[None, None, :] >= z[:, :, None]).reshape(len(z), size).astype(np.uint8)
-    S = len(st)
-    cols = []
-    for b in range(n // size):
-        perm = np.arange(S) if b == 0 else rng.permutation(S)
-        cols.append(st[perm])
-    full = np.concatenate(cols, axis=1)  # [S, n]
-    return np.packbits(full.T, axis=1)   # [n, ceil(S/8)]
+
+        def states(first, last):
+            idx = np.arange(first, last, dtype=np.int64)
+            z = np.stack([(idx // (q + 1) ** (3 - r)) % (q + 1) for r in range(4)], axis=1).astype(np.int16)  # [S, 4], as itertools.product orders them
+            return (pos[None, None, :] >= z[:, :, None]).reshape(len(z), size).astype(np.uint8)
+
+        if total > CHUNK and n == size:
+            firsts = list(range(0, total, CHUNK))
+            if QUICK:
+                firsts = [firsts[0], firsts[len(firsts) // 2]]
+            sets = (states(f, min(f + CHUNK, total)) for f in firsts)
+        else:
+            sets = [states(0, total)]
+    for st in sets:
+        S = len(st)
+        cols = []
+        for b in range(n // size):
+            perm = np.arange(S) if b == 0 else rng.permutation(S)
+            cols.append(st[perm])
+        full = np.concatenate(cols, axis=1)  # [S, n]
+        yield np.packbits(full.T, axis=1)    # [n, ceil(S/8)]
 
 
 def random_states(n, count, rng):
@@ -219,8 +247,13 @@ def candidate_edges(net, rng):
     n = net.n
     cand = {}   # (j, o, k, side) -> still valid
     levels = [s for s in (8, 16, 32, 64, 128, 256) if s <= n]
-    batches = [(s, level_states(n, s, rng)) for s in levels] + [(0, random_states(n, 4096, rng))]
-    for size, st in batches:
+    def batches():
+        for s in levels:
+            for st in level_state_chunks(n, s, rng):
+                yield s, st
+        yield 0, random_states(n, 4096, rng)
+
+    for size, st in batches():
         recs = {}
         uses = {}  # producer -> number of consumers still to come (so the vectors can be freed)
 
@@ -387,8 +420,12 @@ def verify_program(net, ops, out, rng):
             last_use[s] = idx
     for name in out:
         last_use[name] = len(ops)
-    batches = [level_states(n, s, rng) for s in levels] + [random_states(n, 8192, rng)]
-    for st in batches:
+    def batches():
+        for s in levels:
+            yield from level_state_chunks(n, s, rng)
+        yield random_states(n, 8192, rng)
+
+    for st in batches():
         plain = net.simulate(st, lambda *a: None)
         val = {f"i{w}": st[w] for w in range(n)}
         for idx, (dst, op, srcs) in enumerate(ops):
@@ -414,15 +451,46 @@ def verify_program(net, ops, out, rng):
             assert not (plain[w] & ~plain[w + 1]).any()
 
 
+CHOICE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sortnet_choice.json")
+SOLVE = "--solve" in sys.argv   # ignore the stored choices: find the candidates and solve the 0/1 programmes again
+
+
+def stored_choice(n):
+    import json
+    if SOLVE or not os.path.exists(CHOICE_PATH):
+        return None
+    c = json.load(open(CHOICE_PATH)).get(str(n))
+    return None if c is None else (c["candidates"], [tuple(e) for e in c["chosen"]])
+
+
+def store_choice(n, candidates, chosen):
+    import json
+    d = json.load(open(CHOICE_PATH)) if os.path.exists(CHOICE_PATH) else {}
+    d[str(n)] = dict(candidates=candidates, chosen=[list(e) for e in chosen])
+    with open(CHOICE_PATH, "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+        f.write("\n")
+
+
 def fused_network(n, seed=1):
+    """The rewritten programme of the n-wire network.  WHICH exchanges absorb which values (the 0/1 programme's answer: for 256
+    wires a two-minute solve under a time limit, so not reproducible to the bit) is kept in tools/sortnet_choice.json; the header
+    is a deterministic function of that file, and whatever the file says is verified here against the plain network on every
+    0-1 state of every merge level before a line is emitted -- a wrong or stale choice cannot produce a header."""
     rng = np.random.default_rng(seed)
     net = Net(n)
-    edges = candidate_edges(net, rng)
-    chosen = choose(net, edges)
+    stored = stored_choice(n)
+    if stored is None:
+        edges = candidate_edges(net, rng)
+        chosen = choose(net, edges)
+        store_choice(n, len(edges), chosen)
+        n_cand = len(edges)
+    else:
+        n_cand, chosen = stored
     ops, out = build_program(net, chosen)
     verify_program(net, ops, out, np.random.default_rng(seed + 1))
     return ops, out, dict(exchanges=sum(1 for nd in net.nodes if nd["kind"] == "CE"), base=sum(1 for nd in net.nodes if nd["kind"] == "S4"),
-                          candidates=len(edges), absorbed=len(chosen), instructions=count_ops(ops))
+                          candidates=n_cand, absorbed=len(chosen), instructions=count_ops(ops))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
