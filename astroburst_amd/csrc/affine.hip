@@ -720,6 +720,16 @@ __global__ __launch_bounds__(64) void tri_vote_many_kernel(const TriGroup g, con
     tri_vote_body(rt_sorted, nr_p, g.sorted[f], g.bin_off[f], g.votes[f], copies, groups, g.count[f]);
 }
 
+// the `copies` partial vote matrices of every frame of a group added up, straight into pinned host memory (round 4: the group's
+// 16 x 16 KB slots used to come back as one 1 MB blit and the host added them: four launches + this one, no copy out)
+__global__ __launch_bounds__(256) void votes_reduce_many_kernel(const TriGroup g, int copies, uint32_t *__restrict__ out) {
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kVoteDim * kVoteDim) return;
+    uint32_t s = 0;
+    for (int c = 0; c < copies; ++c) s += g.votes[f][(size_t)c * kVoteDim * kVoteDim + i];
+    out[(size_t)f * kVoteDim * kVoteDim + i] = s;
+}
+
 // device-side layout of the matcher's workspace (AB_WS_REGISTER)
 struct MatchWs {
     DTri *ref_tris, *ref_sorted, *tgt_tris, *tgt_sorted;
@@ -842,12 +852,13 @@ int match_group_ws(ab_ctx *ctx, int G, MatchGroupWs *w) {
     return AB_OK;
 }
 
-// the vote matrices of G targets' star lists against the reference table of `ref_ws`: four launches, one copy in, one copy out
+// the vote matrices of G targets' star lists against the reference table of `ref_ws`: five launches, one copy in, the result written
+// straight into pinned memory
 int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *stars /* [G] */, int G, std::vector<uint32_t> *votes /* [G] */) {
     MatchGroupWs w;
     AB_TRY(match_group_ws(ctx, G, &w));
     const int copies = vote_copies(), vote_words = copies * kVoteDim * kVoteDim;
-    const size_t per_frame_words = (size_t)kVoteCopiesMax * kVoteDim * kVoteDim;
+    const size_t per_frame_words = (size_t)kVoteDim * kVoteDim;
     void *pin = nullptr;
     const size_t stars_bytes = (size_t)G * sizeof(StarXY), votes_bytes = (size_t)G * per_frame_words * sizeof(uint32_t);
     AB_TRY(ab_pinned(ctx, stars_bytes + votes_bytes, &pin));
@@ -873,15 +884,11 @@ int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *s
     hipLaunchKernelGGL(tri_scatter_many_kernel, dim3((kMaxTris + kTriBlock - 1) / kTriBlock, G), dim3(kTriBlock), 0, ctx->stream, w.g);
     hipLaunchKernelGGL(tri_vote_many_kernel, dim3(kVoteBlocks, G), dim3(64), 0, ctx->stream, w.g, (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts,
                        copies, (const RefGroup *)ref_ws.groups);
-    AB_HIP(ctx, hipGetLastError());
     uint32_t *hv = (uint32_t *)((char *)pin + stars_bytes);
-    AB_HIP(ctx, hipMemcpyAsync(hv, w.votes_all, votes_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(votes_reduce_many_kernel, dim3((kVoteDim * kVoteDim + 255) / 256, G), dim3(256), 0, ctx->stream, w.g, copies, hv);
+    AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int f = 0; f < G; ++f) {
-        const uint32_t *h = hv + (size_t)f * per_frame_words;
-        for (int c = 0; c < copies; ++c)
-            for (int i = 0; i < kVoteDim * kVoteDim; ++i) votes[f][i] += h[(size_t)c * kVoteDim * kVoteDim + i];
-    }
+    for (int f = 0; f < G; ++f) votes[f].assign(hv + (size_t)f * per_frame_words, hv + (size_t)(f + 1) * per_frame_words);
     return AB_OK;
 }
 

@@ -1609,19 +1609,19 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     off[G] = total;
     if (total == 0) return AB_OK;
     void *cbuf = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, total * (sizeof(CompStat) + sizeof(CompRec)), &cbuf));
-    CompRec *drec = (CompRec *)cbuf;
-    CompStat *dstat = (CompStat *)(drec + total);
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, total * sizeof(CompStat), &cbuf));
+    CompStat *dstat = (CompStat *)cbuf;
+    // the component records (72 B each, written once, by one lane, never read on the device) go STRAIGHT into pinned host memory:
+    // the group's 3 MB used to come back as the stage's largest blit (up to 190 us on a hardware queue shared with other streams)
+    AB_TRY(ab_pinned(ctx, total * sizeof(CompRec), &pin));
     for (int f = 0; f < G; ++f) {
-        g.rec[f] = drec + off[f];
+        g.rec[f] = (CompRec *)pin + off[f];
         g.st[f] = dstat + off[f];
     }
-    AB_TRY(ab_pinned(ctx, total * sizeof(CompRec), &pin));
     hipLaunchKernelGGL(comp_init_many_kernel, dim3((max_nc + 255) / 256, G), dim3(256), 0, ctx->stream, g);
     hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
     hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 3) / 4, G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
     AB_HIP(ctx, hipGetLastError());
-    AB_HIP(ctx, hipMemcpyAsync(pin, drec, total * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int f = 0; f < G; ++f) finish_stars((const CompRec *)pin + off[f], g.ncomp[f], bg[f][1], max_keep, &stars[f]);
     return AB_OK;

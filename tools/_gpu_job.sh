@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -X faulthandler -m pytest tests/test_gpu_stack.py tests/test_gpu_batch.py tests/test_gpu_fits.py -m gpu -x -q < /dev/null > gpurun_out/r04r_pytest.log 2>&1
-tail -n 4 gpurun_out/r04r_pytest.log
-N_LIST=100,128,200,256,320,512 timeout 600 python tools/time_stack_deep.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04r_deep.txt
-timeout 600 python tools/time_median_combine.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04r_median.txt
+timeout 1500 python -X faulthandler -m pytest tests/test_gpu_detect_affine.py tests/test_gpu_subframe.py tests/test_gpu_full_size.py -m gpu -x -q < /dev/null > gpurun_out/r04s_pytest.log 2>&1
+tail -n 4 gpurun_out/r04s_pytest.log
+for i in 1 2 3; do timeout 600 python bench.py --no-cpu-baseline --steps 30 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print(d['ms_per_step'], d['config']['stage_ms'], d['config']['registration'])"; done
