@@ -257,6 +257,43 @@ def test_align_pairs_affine_takes_host_frames(ctx, oracle, n_targets):
                 assert torch.equal(o.isnan(), wo.isnan()) and torch.equal(o.nan_to_num(), wo.nan_to_num()), name
 
 
+def test_host_frames_cancel_errors_and_degenerate_sets(ctx, oracle):
+    """The host-frame path's edges: a cancel requested before the call stops it with the reference's error and leaves nothing in
+    flight (the staging copies read the caller's memory: the call drains them before it returns) and the context usable; planes too
+    small for background tiles take the percentile path after the uploads; a host reference with no target; mismatched dims."""
+    import torch
+    from astroburst_amd import AstroBurstError, _lib, synth
+    rows, cols = 320, 384
+    y, x, flux = synth.star_catalog(rows, cols, 220, seed=5)
+    cat = (y, x, flux * 30.0)
+    ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=0.0)
+    tgts = [synth.make_frame(rows, cols, k + 1, cat=cat, shift=(1.5 * k, -0.75 * k), bad_patch_rate=0.0, cosmic_rate=0.0).pin_memory() for k in range(5)]
+    outs = [torch.empty((rows, cols), device="cuda") for _ in tgts]
+    want = ctx.align_pairs_affine(ref.cuda(), [t.cuda() for t in tgts], [torch.empty_like(o) for o in outs], num_threads=8)
+    ctx.request_cancel()
+    try:
+        with pytest.raises(AstroBurstError) as e:
+            ctx.align_pairs_affine(ref.cuda(), tgts, outs, num_threads=8)
+        assert e.value.code == _lib.AB_ERR_CANCELLED
+    finally:
+        ctx.clear_cancel()
+    for t in tgts:
+        t.zero_()            # nothing may still be reading these ...
+    for t, k in zip(tgts, range(5)):
+        t.copy_(synth.make_frame(rows, cols, k + 1, cat=cat, shift=(1.5 * k, -0.75 * k), bad_patch_rate=0.0, cosmic_rate=0.0))
+    got = ctx.align_pairs_affine(ref.cuda(), tgts, outs, num_threads=8)   # ... and the context works as before
+    assert [(g.method, g.transform) for g in got] == [(w.method, w.transform) for w in want]
+    assert ctx.align_pairs_affine(ref.numpy(), [], [], num_threads=8) == []
+    tiny_ref = np.arange(4, dtype=np.float32).reshape(2, 2)
+    tiny = [np.ones((2, 2), np.float32) * k for k in range(1, 6)]
+    touts = [torch.empty((2, 2), device="cuda") for _ in tiny]
+    res = ctx.align_pairs_affine(torch.from_numpy(tiny_ref).cuda(), tiny, touts, num_threads=8)
+    dres = ctx.align_pairs_affine(torch.from_numpy(tiny_ref).cuda(), [torch.from_numpy(t).cuda() for t in tiny], [torch.empty_like(o) for o in touts], num_threads=8)
+    assert [(r.method, r.transform) for r in res] == [(r.method, r.transform) for r in dres]
+    with pytest.raises(AstroBurstError, match="differ from the reference's dims"):
+        ctx.align_pairs_affine(ref.cuda(), [np.zeros((rows, cols + 1), np.float32)], [torch.empty((rows, cols + 1), device="cuda")], num_threads=8)
+
+
 def test_fed_pipeline_equals_upfront_percentiles(tmp_path):
     """Round 4: frames arriving from the host go through a pipeline whose percentiles run chunk by chunk on the device
     (ab_bg_pipeline_begin_fed); AB_PIPE_FED=1 sends device-resident frames the same way.  The default order (all frames'
