@@ -525,9 +525,17 @@ __device__ __forceinline__ double wave_max(double x) {
     return x;
 }
 
-// one wave per component: flux-weighted moments over the bounding box (star_detection.rs:147-189).  Lane l owns
-// the columns x0 + l + 64 k; lane partials are combined by a fixed butterfly, so results are reproducible
-// (the reference accumulates in BFS order: the two agree to ~1e-15 relative).
+// one wave per component: flux-weighted moments over the bounding box (star_detection.rs:147-189); lane partials are combined
+// by a fixed butterfly, so results are reproducible (the reference accumulates in BFS order: the two agree to ~1e-15 relative;
+// the first-order sums are exact in f64 for normalised pixels, hence order-free).
+// Round 4: the lanes form a PATCH of pw columns x 64 / pw rows (pw = 8, 16, 32 or 64, the smallest that spans the box) instead
+// of one row of 64 columns: a 9 x 9 star was 9 trips with 9 live lanes each, every trip a chain of three dependent loads (mask
+// bit -> parent -> pixel), and the whole walk was taken twice (moments about the centroid need the centroid first).  Now the
+// three loads of a trip are independent (all taken for every pixel of the box: the mask bit decides afterwards), the first
+// four trips are issued together, and boxes of up to eight trips keep their pixel values in registers for the second pass.
+// Inside a registration batch the kernel held a hardware queue for 190-260 us per group of four frames (23 us per frame alone:
+// pure latency, which grows under load).
+constexpr int kMomKeep = 8;
 __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
                                                            double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
@@ -544,45 +552,108 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
     out.npix = s.npix;
     out.sum_flux = out.sum_x = out.sum_y = out.peak = out.sum_r2 = out.sum_xx = out.sum_yy = out.sum_xy = 0.0;
     if (s.npix >= 3 && s.npix <= 5000 && s.first_interior != 0x7fffffff) {  // :142-145
+        const int w = s.x1 - s.x0 + 1, h = s.y1 - s.y0 + 1;
+        const int sh = w <= 8 ? 3 : (w <= 16 ? 4 : (w <= 32 ? 5 : 6)), pw = 1 << sh, rpt = 64 >> sh;  // patch: pw columns x rpt rows
+        const int dc = lane & (pw - 1), dr = lane >> sh;
+        const int nrb = (h + rpt - 1) / rpt;  // trips down the box (per column block)
+        // member pixel's background-subtracted value, 0 for everything else (adding +0.0 changes no sum, max(pk, 0) no peak)
+        auto value = [&](int r, int c, bool valid) -> double {
+            const int rr = valid ? r : s.y0, cc = valid ? c : s.x0, idx = rr * cols + cc;  // invalid lanes re-read the box's corner
+            const unsigned int m = mask[idx >> 5];
+            const int p = parent[idx];  // (defined at labelled pixels only: the bit decides)
+            const float px = img[rr * ld + cc];
+            const bool member = valid && ((m >> (idx & 31)) & 1u) && p == root;
+            return member ? fmax((double)ab_px(xf, px) - bg_median, 0.0) : 0.0;
+        };
         double f = 0.0, sx = 0.0, sy = 0.0, pk = 0.0;
-        for (int r = s.y0; r <= s.y1; ++r)
-            for (int cb = s.x0; cb <= s.x1; cb += 64) {
-                const int c = cb + lane;
-                if (c <= s.x1 && labelled(mask, r * cols + c) && parent[r * cols + c] == root) {
-                    const double v = fmax((double)ab_px(xf, img[r * ld + c]) - bg_median, 0.0);
+        if (w <= 64 && nrb <= kMomKeep) {  // wave-uniform; the usual star
+            const int c = s.x0 + dc;
+            const bool col_ok = dc < w;
+            double v[kMomKeep];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = s.y0 + k * rpt + dr;
+                v[k] = value(r, c, col_ok && r <= s.y1);
+            }
+            if (nrb > 4) {
+#pragma unroll
+                for (int k = 4; k < kMomKeep; ++k) {
+                    const int r = s.y0 + k * rpt + dr;
+                    v[k] = value(r, c, col_ok && r <= s.y1);
+                }
+            } else {
+#pragma unroll
+                for (int k = 4; k < kMomKeep; ++k) v[k] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < kMomKeep; ++k) {
+                const int r = s.y0 + k * rpt + dr;
+                f += v[k];
+                sx += (double)c * v[k];
+                sy += (double)r * v[k];
+                pk = fmax(pk, v[k]);
+            }
+            f = wave_sum(f);
+            sx = wave_sum(sx);
+            sy = wave_sum(sy);
+            pk = wave_max(pk);
+            out.sum_flux = f;
+            out.sum_x = sx;
+            out.sum_y = sy;
+            out.peak = pk;
+            if (f > 0.0) {
+                const double cx = sx / f, cy = sy / f;
+                double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
+                const double dx = (double)c - cx;
+#pragma unroll
+                for (int k = 0; k < kMomKeep; ++k) {
+                    const double dy = (double)(s.y0 + k * rpt + dr) - cy;
+                    r2 += (dx * dx + dy * dy) * v[k];
+                    xx += dx * dx * v[k];
+                    yy += dy * dy * v[k];
+                    xy += dx * dy * v[k];
+                }
+                out.sum_r2 = wave_sum(r2);
+                out.sum_xx = wave_sum(xx);
+                out.sum_yy = wave_sum(yy);
+                out.sum_xy = wave_sum(xy);
+            }
+        } else {  // a large or wide component: walk the box twice
+            for (int r0 = s.y0; r0 <= s.y1; r0 += rpt)
+                for (int cb = s.x0; cb <= s.x1; cb += pw) {
+                    const int r = r0 + dr, c = cb + dc;
+                    const double v = value(r, c, r <= s.y1 && c <= s.x1);
                     f += v;
                     sx += (double)c * v;
                     sy += (double)r * v;
                     pk = fmax(pk, v);
                 }
-            }
-        f = wave_sum(f);
-        sx = wave_sum(sx);
-        sy = wave_sum(sy);
-        pk = wave_max(pk);
-        out.sum_flux = f;
-        out.sum_x = sx;
-        out.sum_y = sy;
-        out.peak = pk;
-        if (f > 0.0) {
-            const double cx = sx / f, cy = sy / f;
-            double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
-            for (int r = s.y0; r <= s.y1; ++r)
-                for (int cb = s.x0; cb <= s.x1; cb += 64) {
-                    const int c = cb + lane;
-                    if (c <= s.x1 && labelled(mask, r * cols + c) && parent[r * cols + c] == root) {
-                        const double v = fmax((double)ab_px(xf, img[r * ld + c]) - bg_median, 0.0);
+            f = wave_sum(f);
+            sx = wave_sum(sx);
+            sy = wave_sum(sy);
+            pk = wave_max(pk);
+            out.sum_flux = f;
+            out.sum_x = sx;
+            out.sum_y = sy;
+            out.peak = pk;
+            if (f > 0.0) {
+                const double cx = sx / f, cy = sy / f;
+                double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
+                for (int r0 = s.y0; r0 <= s.y1; r0 += rpt)
+                    for (int cb = s.x0; cb <= s.x1; cb += pw) {
+                        const int r = r0 + dr, c = cb + dc;
+                        const double v = value(r, c, r <= s.y1 && c <= s.x1);
                         const double dx = (double)c - cx, dy = (double)r - cy;
                         r2 += (dx * dx + dy * dy) * v;
                         xx += dx * dx * v;
                         yy += dy * dy * v;
                         xy += dx * dy * v;
                     }
-                }
-            out.sum_r2 = wave_sum(r2);
-            out.sum_xx = wave_sum(xx);
-            out.sum_yy = wave_sum(yy);
-            out.sum_xy = wave_sum(xy);
+                out.sum_r2 = wave_sum(r2);
+                out.sum_xx = wave_sum(xx);
+                out.sum_yy = wave_sum(yy);
+                out.sum_xy = wave_sum(xy);
+            }
         }
     }
     if (lane == 0) rec[comp] = out;

@@ -12,6 +12,7 @@
 // accumulation are f64 in the reference's evaluation order, so results are bit-identical to the
 // CPU restatement; only the final store is f32.
 #include "ab_common.hpp"
+#include <cmath>
 
 namespace {
 
@@ -109,7 +110,24 @@ __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ sr
     out[(size_t)y * cols + x] = r;
 }
 
-// affine.rs:674-687; map() is affine.rs:74-80
+// The four Catmull-Rom weights of one axis with one operation less per outer weight: 0.5 * t is exact (a power of two), so
+// RN(2.5 - RN(0.5 t)) = RN(2.5 - 0.5 t) = fma(-0.5, t, 2.5) -- the only fusion in this file, and it changes no bit.
+__device__ __forceinline__ double cr_outer_fused(double t) { return t * (t * __builtin_fma(-0.5, t, 2.5) - 4.0) + 2.0; }
+__device__ __forceinline__ void catmull_weights_fused(double f, double &w0, double &w1, double &w2, double &w3) {
+    w0 = cr_outer_fused(fabs(f + 1.0));
+    w1 = cr_inner(fabs(f));
+    w2 = cr_inner(fabs(f - 1.0));
+    w3 = cr_outer_fused(fabs(f - 2.0));
+}
+
+// affine.rs:674-687; map() is affine.rs:74-80.
+// The reference's test `sx >= 0 && sy >= 0 && sx < cols - 1 && sy < rows - 1` is taken on the floors the sampler needs anyway:
+// for finite sx, 0 <= sx < cols - 1  <=>  0 <= floor(sx) <= cols - 2 (cols - 1 is an integer; floor(-0.0) = -0.0 converts to
+// 0 and -0.0 >= 0.0 holds; v_cvt_i32_f64 saturates, so a floor outside the int range fails the unsigned compare like the
+// f64 compare would) -- two integer compares instead of four f64 compares and eight selects on the coordinates.  A NaN
+// coordinate would convert to 0 and pass: GUARD adds the two self-compares, and the host takes that instance whenever the
+// coefficients could overflow (|coefficient| > 1e150 or non-finite), so that products and sums of the plain one are finite.
+template <bool GUARD, bool NOLOAD = false>
 __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src, int src_rows, int src_cols, double a,
                                                    double b, double tx, double c, double d, double ty, int out_rows,
                                                    int out_cols, float *__restrict__ out, int row0) {
@@ -129,8 +147,37 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
         const double xf = (double)x;
         const double sx = a * xf + b * yf + tx;
         const double sy = c * xf + d * yf + ty;
-        const bool in = live[u] && sx >= 0.0 && sy >= 0.0 && sx < (double)(src_cols - 1) && sy < (double)(src_rows - 1);
-        r[u] = bicubic_sample(src, src_rows, src_cols, src_cols, in ? sy : 0.0, in ? sx : 0.0, in);
+        const double fx = floor(sx), fy = floor(sy);
+        int ix, iy;  // the instruction itself (saturating; NaN -> 0): a C++ cast of an out-of-range double is undefined
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(ix) : "v"(fx));
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(iy) : "v"(fy));
+        bool in = live[u] && (unsigned)ix < (unsigned)(src_cols - 1) && (unsigned)iy < (unsigned)(src_rows - 1);
+        if constexpr (GUARD) in = in && sx == sx && sy == sy;
+        double wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3;
+        catmull_weights_fused(sx - fx, wx0, wx1, wx2, wx3);  // (of no consequence where `in` is false)
+        catmull_weights_fused(sy - fy, wy0, wy1, wy2, wy3);
+        const bool interior = ix >= 1 && ix + 2 < src_cols && iy >= 1 && iy + 2 < src_rows;
+        r[u] = 0.0f;
+        if constexpr (NOLOAD) {  // developer timing experiment (AB_ABLATE_WARP=2): the same arithmetic on taps that come from registers
+            double val = 0.0;
+            const double wy[4] = {wy0, wy1, wy2, wy3};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s0 = __int_as_float(0x3f800000 | ((ix + 4 * j) & 0xffff)), s1 = __int_as_float(0x3f800000 | ((ix + 4 * j + 1) & 0xffff)),
+                      s2 = __int_as_float(0x3f800000 | ((iy + 4 * j + 2) & 0xffff)), s3 = __int_as_float(0x3f800000 | ((iy + 4 * j + 3) & 0xffff));
+                double row_val = (double)s0 * wx0;
+                row_val += (double)s1 * wx1;
+                row_val += (double)s2 * wx2;
+                row_val += (double)s3 * wx3;
+                const double t = row_val * wy[j];
+                val = (j == 0) ? t : val + t;
+            }
+            r[u] = in ? (float)val : 0.0f;
+        } else if (__all(interior || !in)) {  // the usual case away from the frame edges
+            if (in) r[u] = bicubic_taps_interior(src, src_cols, ix, iy, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
+        } else if (in) {
+            r[u] = bicubic_taps(src, src_rows, src_cols, src_cols, ix, iy, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
+        }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -206,8 +253,22 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
     AB_CHECK(ctx, out_rows <= 65535 && out_rows * out_cols < (int64_t(1) << 31) && src_rows * src_cols < (int64_t(1) << 31),
              "image of %lld x %lld needs a tiled launch (not in this build)", (long long)out_rows, (long long)out_cols);
     const dim3 grid((unsigned)((out_cols + 511) / 512), (unsigned)nrows), block(256);
-    hipLaunchKernelGGL(warp_kernel, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
-                       t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
+    static const int ablate = getenv("AB_ABLATE_WARP") ? atoi(getenv("AB_ABLATE_WARP")) : 0;  // developer timing experiments
+    if (ablate == 1) return AB_OK;  // what the registration stage takes without the warps
+    if (ablate == 2) {              // what the kernel takes without its loads
+        const dim3 g2((unsigned)((out_cols + 511) / 512), (unsigned)nrows);
+        hipLaunchKernelGGL((warp_kernel<false, true>), g2, dim3(256), 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
+                           t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
+        return AB_OK;
+    }
+    bool tame = true;  // every product and sum of the coordinate arithmetic stays finite (x, y < 2^16)
+    for (int i = 0; i < 6; ++i) tame = tame && std::isfinite(t[i]) && fabs(t[i]) <= 1e150;
+    if (tame)
+        hipLaunchKernelGGL(warp_kernel<false>, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
+                           t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
+    else
+        hipLaunchKernelGGL(warp_kernel<true>, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
+                           t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
