@@ -536,127 +536,199 @@ __device__ __forceinline__ double wave_max(double x) {
 // Inside a registration batch the kernel held a hardware queue for 190-260 us per group of four frames (23 us per frame alone:
 // pure latency, which grows under load).
 constexpr int kMomKeep = 8;
+constexpr int kMomPerWave = 4;  // components per wave: their headers and first four trips are in flight together
+__device__ int g_mom_ablate = 0;  // developer timing experiment (AB_ABLATE_MOMENTS): 1 = no box walk, 2 = no record store either
+
+struct MomGeom {  // the lane patch of one component's box
+    int sh, pw, rpt, dc, dr, nrb, w;
+    bool eligible, small;
+};
+__device__ __forceinline__ MomGeom mom_geom(const CompStat &s, int lane, bool live) {
+    MomGeom g;
+    g.eligible = live && s.npix >= 3 && s.npix <= 5000 && s.first_interior != 0x7fffffff;  // :142-145
+    g.w = s.x1 - s.x0 + 1;
+    const int h = s.y1 - s.y0 + 1;
+    g.sh = g.w <= 8 ? 3 : (g.w <= 16 ? 4 : (g.w <= 32 ? 5 : 6));
+    g.pw = 1 << g.sh;
+    g.rpt = 64 >> g.sh;
+    g.dc = lane & (g.pw - 1);
+    g.dr = lane >> g.sh;
+    g.nrb = (h + g.rpt - 1) / g.rpt;  // trips down the box (per column block)
+    g.small = g.eligible && g.w <= 64 && g.nrb <= kMomKeep;
+    return g;
+}
+
 __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
                                                            double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
                                                            const FrameDev *__restrict__ fd) {
     const double bg_median = fd ? fd->bg_median : bg_median_arg;
     const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
-    const unsigned int comp = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const unsigned int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kMomPerWave;
     const int lane = threadIdx.x & 63;
-    if (comp >= ncomp) return;
-    const CompStat s = st[comp];
-    const int root = roots[comp];
-    CompRec out;
-    out.first_interior = s.first_interior;
-    out.npix = s.npix;
-    out.sum_flux = out.sum_x = out.sum_y = out.peak = out.sum_r2 = out.sum_xx = out.sum_yy = out.sum_xy = 0.0;
-    if (s.npix >= 3 && s.npix <= 5000 && s.first_interior != 0x7fffffff) {  // :142-145
-        const int w = s.x1 - s.x0 + 1, h = s.y1 - s.y0 + 1;
-        const int sh = w <= 8 ? 3 : (w <= 16 ? 4 : (w <= 32 ? 5 : 6)), pw = 1 << sh, rpt = 64 >> sh;  // patch: pw columns x rpt rows
-        const int dc = lane & (pw - 1), dr = lane >> sh;
-        const int nrb = (h + rpt - 1) / rpt;  // trips down the box (per column block)
-        // member pixel's background-subtracted value, 0 for everything else (adding +0.0 changes no sum, max(pk, 0) no peak)
-        auto value = [&](int r, int c, bool valid) -> double {
-            const int rr = valid ? r : s.y0, cc = valid ? c : s.x0, idx = rr * cols + cc;  // invalid lanes re-read the box's corner
-            const unsigned int m = mask[idx >> 5];
-            const int p = parent[idx];  // (defined at labelled pixels only: the bit decides)
-            const float px = img[rr * ld + cc];
-            const bool member = valid && ((m >> (idx & 31)) & 1u) && p == root;
-            return member ? fmax((double)ab_px(xf, px) - bg_median, 0.0) : 0.0;
-        };
-        double f = 0.0, sx = 0.0, sy = 0.0, pk = 0.0;
-        if (w <= 64 && nrb <= kMomKeep) {  // wave-uniform; the usual star
-            const int c = s.x0 + dc;
-            const bool col_ok = dc < w;
-            double v[kMomKeep];
+    if (base >= ncomp) return;
+    const int ablate = g_mom_ablate;
+    // member pixel's background-subtracted value, 0 for everything else (adding +0.0 changes no sum, max(pk, 0) no peak); the
+    // three loads are independent: all are taken for every pixel of the box and the mask bit decides afterwards
+    auto value = [&](const CompStat &s, int root, int r, int c, bool valid) -> double {
+        const int rr = valid ? r : s.y0, cc = valid ? c : s.x0, idx = rr * cols + cc;  // invalid lanes re-read the box's corner
+        const unsigned int m = mask[idx >> 5];
+        const int p = parent[idx];  // (defined at labelled pixels only: the bit decides)
+        const float px = img[rr * ld + cc];
+        const bool member = valid && ((m >> (idx & 31)) & 1u) && p == root;
+        return member ? fmax((double)ab_px(xf, px) - bg_median, 0.0) : 0.0;
+    };
+    CompStat S[kMomPerWave];
+    int root[kMomPerWave];
+    MomGeom G[kMomPerWave];
+    double v[kMomPerWave][kMomKeep];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = s.y0 + k * rpt + dr;
-                v[k] = value(r, c, col_ok && r <= s.y1);
-            }
-            if (nrb > 4) {
+    for (int j = 0; j < kMomPerWave; ++j) {  // headers: independent loads
+        const bool live = base + j < ncomp;
+        S[j] = st[live ? base + j : base];
+        root[j] = roots[live ? base + j : base];
+    }
 #pragma unroll
-                for (int k = 4; k < kMomKeep; ++k) {
-                    const int r = s.y0 + k * rpt + dr;
-                    v[k] = value(r, c, col_ok && r <= s.y1);
-                }
-            } else {
+    for (int j = 0; j < kMomPerWave; ++j) {  // the first four trips of every small box: 48 loads in flight
+        G[j] = mom_geom(S[j], lane, base + j < ncomp);
+        const bool go = G[j].small && ablate == 0;
+        const int c = S[j].x0 + G[j].dc;
 #pragma unroll
-                for (int k = 4; k < kMomKeep; ++k) v[k] = 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < kMomKeep; ++k) {
-                const int r = s.y0 + k * rpt + dr;
-                f += v[k];
-                sx += (double)c * v[k];
-                sy += (double)r * v[k];
-                pk = fmax(pk, v[k]);
-            }
-            f = wave_sum(f);
-            sx = wave_sum(sx);
-            sy = wave_sum(sy);
-            pk = wave_max(pk);
-            out.sum_flux = f;
-            out.sum_x = sx;
-            out.sum_y = sy;
-            out.peak = pk;
-            if (f > 0.0) {
-                const double cx = sx / f, cy = sy / f;
-                double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
-                const double dx = (double)c - cx;
-#pragma unroll
-                for (int k = 0; k < kMomKeep; ++k) {
-                    const double dy = (double)(s.y0 + k * rpt + dr) - cy;
-                    r2 += (dx * dx + dy * dy) * v[k];
-                    xx += dx * dx * v[k];
-                    yy += dy * dy * v[k];
-                    xy += dx * dy * v[k];
-                }
-                out.sum_r2 = wave_sum(r2);
-                out.sum_xx = wave_sum(xx);
-                out.sum_yy = wave_sum(yy);
-                out.sum_xy = wave_sum(xy);
-            }
-        } else {  // a large or wide component: walk the box twice
-            for (int r0 = s.y0; r0 <= s.y1; r0 += rpt)
-                for (int cb = s.x0; cb <= s.x1; cb += pw) {
-                    const int r = r0 + dr, c = cb + dc;
-                    const double v = value(r, c, r <= s.y1 && c <= s.x1);
-                    f += v;
-                    sx += (double)c * v;
-                    sy += (double)r * v;
-                    pk = fmax(pk, v);
-                }
-            f = wave_sum(f);
-            sx = wave_sum(sx);
-            sy = wave_sum(sy);
-            pk = wave_max(pk);
-            out.sum_flux = f;
-            out.sum_x = sx;
-            out.sum_y = sy;
-            out.peak = pk;
-            if (f > 0.0) {
-                const double cx = sx / f, cy = sy / f;
-                double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
-                for (int r0 = s.y0; r0 <= s.y1; r0 += rpt)
-                    for (int cb = s.x0; cb <= s.x1; cb += pw) {
-                        const int r = r0 + dr, c = cb + dc;
-                        const double v = value(r, c, r <= s.y1 && c <= s.x1);
-                        const double dx = (double)c - cx, dy = (double)r - cy;
-                        r2 += (dx * dx + dy * dy) * v;
-                        xx += dx * dx * v;
-                        yy += dy * dy * v;
-                        xy += dx * dy * v;
-                    }
-                out.sum_r2 = wave_sum(r2);
-                out.sum_xx = wave_sum(xx);
-                out.sum_yy = wave_sum(yy);
-                out.sum_xy = wave_sum(xy);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int r = S[j].y0 + k * G[j].rpt + G[j].dr;
+            v[j][k] = value(S[j], root[j], r, c, go && G[j].dc < G[j].w && r <= S[j].y1);
         }
     }
-    if (lane == 0) rec[comp] = out;
+#pragma unroll
+    for (int j = 0; j < kMomPerWave; ++j) {
+        if (base + j >= ncomp) break;  // wave-uniform
+        const CompStat &s = S[j];
+        const MomGeom &g = G[j];
+        CompRec out;
+        out.first_interior = s.first_interior;
+        out.npix = s.npix;
+        out.sum_flux = out.sum_x = out.sum_y = out.peak = out.sum_r2 = out.sum_xx = out.sum_yy = out.sum_xy = 0.0;
+        if (g.eligible && ablate == 0) {
+            double f = 0.0, sx = 0.0, sy = 0.0, pk = 0.0;
+            if (g.small) {  // wave-uniform; the usual star: its values stay in registers for the second pass
+                const int c = s.x0 + g.dc;
+                if (g.nrb > 4) {
+#pragma unroll
+                    for (int k = 4; k < kMomKeep; ++k) {
+                        const int r = s.y0 + k * g.rpt + g.dr;
+                        v[j][k] = value(s, root[j], r, c, g.dc < g.w && r <= s.y1);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 4; k < kMomKeep; ++k) v[j][k] = 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < kMomKeep; ++k) {
+                    const int r = s.y0 + k * g.rpt + g.dr;
+                    f += v[j][k];
+                    sx += (double)c * v[j][k];
+                    sy += (double)r * v[j][k];
+                    pk = fmax(pk, v[j][k]);
+                }
+                f = wave_sum(f);
+                sx = wave_sum(sx);
+                sy = wave_sum(sy);
+                pk = wave_max(pk);
+                out.sum_flux = f;
+                out.sum_x = sx;
+                out.sum_y = sy;
+                out.peak = pk;
+                if (f > 0.0) {
+                    const double cx = sx / f, cy = sy / f;
+                    double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
+                    const double dx = (double)c - cx;
+#pragma unroll
+                    for (int k = 0; k < kMomKeep; ++k) {
+                        const double dy = (double)(s.y0 + k * g.rpt + g.dr) - cy;
+                        r2 += (dx * dx + dy * dy) * v[j][k];
+                        xx += dx * dx * v[j][k];
+                        yy += dy * dy * v[j][k];
+                        xy += dx * dy * v[j][k];
+                    }
+                    out.sum_r2 = wave_sum(r2);
+                    out.sum_xx = wave_sum(xx);
+                    out.sum_yy = wave_sum(yy);
+                    out.sum_xy = wave_sum(xy);
+                }
+            } else {  // a large or wide component: walk the box twice, kMomKeep trips' loads in flight at a time
+                const int ncb = (g.w + g.pw - 1) >> g.sh, ntrips = g.nrb * ncb;
+                auto trip_rc = [&](int t, int &r, int &c) -> bool {
+                    const int rb = t / ncb, cbk = t - rb * ncb;
+                    r = s.y0 + rb * g.rpt + g.dr;
+                    c = s.x0 + (cbk << g.sh) + g.dc;
+                    return t < ntrips && r <= s.y1 && c <= s.x1;
+                };
+                for (int t0 = 0; t0 < ntrips; t0 += kMomKeep) {
+                    double u[kMomKeep];
+                    int rr[kMomKeep], cc[kMomKeep];
+#pragma unroll
+                    for (int k = 0; k < kMomKeep; ++k) {
+                        const bool ok = trip_rc(t0 + k, rr[k], cc[k]);
+                        u[k] = value(s, root[j], rr[k], cc[k], ok);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kMomKeep; ++k) {
+                        f += u[k];
+                        sx += (double)cc[k] * u[k];
+                        sy += (double)rr[k] * u[k];
+                        pk = fmax(pk, u[k]);
+                    }
+                }
+                f = wave_sum(f);
+                sx = wave_sum(sx);
+                sy = wave_sum(sy);
+                pk = wave_max(pk);
+                out.sum_flux = f;
+                out.sum_x = sx;
+                out.sum_y = sy;
+                out.peak = pk;
+                if (f > 0.0) {
+                    const double cx = sx / f, cy = sy / f;
+                    double r2 = 0.0, xx = 0.0, yy = 0.0, xy = 0.0;
+                    for (int t0 = 0; t0 < ntrips; t0 += kMomKeep) {
+                        double u[kMomKeep];
+                        int rr[kMomKeep], cc[kMomKeep];
+#pragma unroll
+                        for (int k = 0; k < kMomKeep; ++k) {
+                            const bool ok = trip_rc(t0 + k, rr[k], cc[k]);
+                            u[k] = value(s, root[j], rr[k], cc[k], ok);
+                        }
+#pragma unroll
+                        for (int k = 0; k < kMomKeep; ++k) {
+                            const double dx = (double)cc[k] - cx, dy = (double)rr[k] - cy;
+                            r2 += (dx * dx + dy * dy) * u[k];
+                            xx += dx * dx * u[k];
+                            yy += dy * dy * u[k];
+                            xy += dx * dy * u[k];
+                        }
+                    }
+                    out.sum_r2 = wave_sum(r2);
+                    out.sum_xx = wave_sum(xx);
+                    out.sum_yy = wave_sum(yy);
+                    out.sum_xy = wave_sum(xy);
+                }
+            }
+        }
+        // the record goes to pinned HOST memory: one 72-byte store by 18 lanes (every lane holds the wave's sums) instead of
+        // five 16-byte stores by lane 0; a component that cannot become a star sends its 8-byte head only (the host reads the
+        // sums behind `npix` and `first_interior` in range, finish_stars) -- PCIe writes are what this kernel's duration is made of
+        static_assert(sizeof(CompRec) == 72, "18 dwords");
+        const double dd[8] = {out.sum_flux, out.sum_x, out.sum_y, out.peak, out.sum_r2, out.sum_xx, out.sum_yy, out.sum_xy};
+        unsigned int word = lane == 0 ? (unsigned int)out.first_interior : (unsigned int)out.npix;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(dd[k]);
+            word = lane == 2 + 2 * k ? (unsigned int)b : word;
+            word = lane == 3 + 2 * k ? (unsigned int)(b >> 32) : word;
+        }
+        const bool head_only = !(s.npix >= 3 && s.npix <= 5000 && s.first_interior != 0x7fffffff);
+        if (lane < (head_only ? 2 : 18) && ablate != 2) reinterpret_cast<unsigned int *>(&rec[base + j])[lane] = word;
+    }
 }
 
 // ---- the kernels above as launches: one frame, or a GROUP of frames of one size (blockIdx.y = frame) ------------------------------
@@ -1602,7 +1674,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     AB_TRY(ab_pinned(ctx, (size_t)ncomp * sizeof(CompRec), &pin));
     hipLaunchKernelGGL(comp_init_kernel, dim3((ncomp + 255) / 256), dim3(256), 0, ctx->stream, dstat, ncomp);
     hipLaunchKernelGGL(comp_stats_kernel, dim3(gl), dim3(256), 0, ctx->stream, (int)rows, (int)cols, parent, cid, dstat, plist, nlab);
-    hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 3) / 4), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, mask, roots, dstat, ncomp,
+    hipLaunchKernelGGL(comp_moments_kernel, dim3((ncomp + 4 * kMomPerWave - 1) / (4 * kMomPerWave)), dim3(256), 0, ctx->stream, img, (int)cols, ld, parent, mask, roots, dstat, ncomp,
                        bg_median, xf, drec, (const FrameDev *)fd);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipMemcpyAsync(pin, drec, (size_t)ncomp * sizeof(CompRec), hipMemcpyDeviceToHost, ctx->stream));
@@ -1691,7 +1763,11 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     }
     hipLaunchKernelGGL(comp_init_many_kernel, dim3((max_nc + 255) / 256, G), dim3(256), 0, ctx->stream, g);
     hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
-    hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 3) / 4, G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
+    if (getenv("AB_ABLATE_MOMENTS")) {
+        const int v = atoi(getenv("AB_ABLATE_MOMENTS"));
+        AB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_mom_ablate), &v, sizeof v));
+    }
+    hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int f = 0; f < G; ++f) finish_stars((const CompRec *)pin + off[f], g.ncomp[f], bg[f][1], max_keep, &stars[f]);
