@@ -51,6 +51,17 @@ struct ab_pixel_xf {
     double lo = 0.0, inv = 1.0;
     int on = 0;
 };
+// Wave priority (s_setprio) of the latency-bound kernels of the registration chain (labelling, component statistics, triangle
+// matcher), which inside a batch share SIMDs with the f64-saturated warp kernel.  MEASURED AND LEFT OFF (round 4, same box,
+// interleaved, tools/time_register.py): priority 3 for these kernels 12.0-12.4 ms min / 13.2-13.8 median against 11.2-11.6 /
+// 12.4-12.7 without; priority 3 for the warp instead (-DAB_WARP_WAVE_PRIO=3) 12.7-15.8 median against 11.9-12.8.  Equal
+// priorities are the best this stage gets; the switches stay for the next person who suspects the arbiter.
+#ifdef AB_LATENCY_PRIO
+#define AB_LATENCY_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define AB_LATENCY_KERNEL_PRIO() ((void)0)
+#endif
+
 __device__ __forceinline__ float ab_px(const ab_pixel_xf &x, float v) {
     if (!x.on) return v;
     double t = ((double)v - x.lo) * x.inv;

@@ -687,42 +687,42 @@ struct TriGroup {
     unsigned int *count[kTriGroupMax], *bin_hist[kTriGroupMax], *bin_off[kTriGroupMax], *cursor[kTriGroupMax], *votes[kTriGroupMax];
 };
 __global__ __launch_bounds__(kTriBlock) void tri_build_kernel(const StarXY stars, int limit, DTri *__restrict__ out, unsigned int *count,
-                                                         unsigned int *__restrict__ bin_hist, unsigned int *__restrict__ votes_to_clear, int vote_words) {
+                                                         unsigned int *__restrict__ bin_hist, unsigned int *__restrict__ votes_to_clear, int vote_words) { AB_LATENCY_KERNEL_PRIO();
     tri_build_body(stars.xy, limit, out, count, bin_hist, votes_to_clear, vote_words);
 }
-__global__ __launch_bounds__(kTriBlock) void tri_build_many_kernel(const TriGroup g, const StarXY *__restrict__ stars, int vote_words) {
+__global__ __launch_bounds__(kTriBlock) void tri_build_many_kernel(const TriGroup g, const StarXY *__restrict__ stars, int vote_words) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     tri_build_body(stars[f].xy, g.limit[f], g.raw[f], g.count[f], g.bin_hist[f], g.votes[f], vote_words);
 }
-__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ off, unsigned int *__restrict__ cursor) {
+__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ off, unsigned int *__restrict__ cursor) { AB_LATENCY_KERNEL_PRIO();
     tri_bin_scan_body(hist, off, cursor);
 }
-__global__ __launch_bounds__(1024) void tri_bin_scan_many_kernel(const TriGroup g) {
+__global__ __launch_bounds__(1024) void tri_bin_scan_many_kernel(const TriGroup g) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     tri_bin_scan_body(g.bin_hist[f], g.bin_off[f], g.cursor[f]);
 }
 __global__ __launch_bounds__(kTriBlock) void tri_scatter_kernel(const DTri *__restrict__ in, const unsigned int *__restrict__ n_p, unsigned int *cursor,
-                                                           DTri *__restrict__ sorted) {
+                                                           DTri *__restrict__ sorted) { AB_LATENCY_KERNEL_PRIO();
     tri_scatter_body(in, n_p, cursor, sorted);
 }
-__global__ __launch_bounds__(kTriBlock) void tri_scatter_many_kernel(const TriGroup g) {
+__global__ __launch_bounds__(kTriBlock) void tri_scatter_many_kernel(const TriGroup g) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     tri_scatter_body(g.raw[f], g.count[f], g.cursor[f], g.sorted[f]);
 }
 __global__ __launch_bounds__(64) void tri_vote_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, const DTri *__restrict__ tt_sorted,
                                                       const unsigned int *__restrict__ bin_off, unsigned int *__restrict__ votes_out, int copies,
-                                                      const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
+                                                      const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) { AB_LATENCY_KERNEL_PRIO();
     tri_vote_body(rt_sorted, nr_p, tt_sorted, bin_off, votes_out, copies, groups, tgt_count_to_clear);
 }
 __global__ __launch_bounds__(64) void tri_vote_many_kernel(const TriGroup g, const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, int copies,
-                                                           const RefGroup *__restrict__ groups) {
+                                                           const RefGroup *__restrict__ groups) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     tri_vote_body(rt_sorted, nr_p, g.sorted[f], g.bin_off[f], g.votes[f], copies, groups, g.count[f]);
 }
 
 // the `copies` partial vote matrices of every frame of a group added up, straight into pinned host memory (round 4: the group's
 // 16 x 16 KB slots used to come back as one 1 MB blit and the host added them: four launches + this one, no copy out)
-__global__ __launch_bounds__(256) void votes_reduce_many_kernel(const TriGroup g, int copies, uint32_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void votes_reduce_many_kernel(const TriGroup g, int copies, uint32_t *__restrict__ out) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kVoteDim * kVoteDim) return;
     uint32_t s = 0;

@@ -750,39 +750,39 @@ struct DetGroup {
 };
 __global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld, double threshold_arg,
                                                                 const ab_pixel_xf xf_arg, int *__restrict__ parent, unsigned int *__restrict__ mask,
-                                                                int *__restrict__ plist, unsigned int *nlab, int vec_ok, const FrameDev *__restrict__ fd) {
+                                                                int *__restrict__ plist, unsigned int *nlab, int vec_ok, const FrameDev *__restrict__ fd) { AB_LATENCY_KERNEL_PRIO();
     label_init_body(img, rows, cols, ld, threshold_arg, xf_arg, parent, mask, plist, nlab, vec_ok, fd);
 }
-__global__ __launch_bounds__(kInitBlock) void label_init_many_kernel(const DetGroup g, int rows, int cols, int64_t ld, int vec_ok) {
+__global__ __launch_bounds__(kInitBlock) void label_init_many_kernel(const DetGroup g, int rows, int cols, int64_t ld, int vec_ok) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     label_init_body(g.img[f], rows, cols, ld, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1, vec_ok, nullptr);
 }
 __global__ __launch_bounds__(256) void label_merge_kernel(int rows, int cols, int *parent, const unsigned int *__restrict__ mask, const int *__restrict__ plist,
-                                                          const unsigned int *__restrict__ nlab) {
+                                                          const unsigned int *__restrict__ nlab) { AB_LATENCY_KERNEL_PRIO();
     label_merge_body(rows, cols, parent, mask, plist, nlab);
 }
-__global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g, int rows, int cols) {
+__global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     label_merge_body(rows, cols, g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1);
 }
 __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
-                                                            int *__restrict__ roots, int *__restrict__ cid, unsigned int *nroots, unsigned int cap) {
+                                                            int *__restrict__ roots, int *__restrict__ cid, unsigned int *nroots, unsigned int cap) { AB_LATENCY_KERNEL_PRIO();
     roots_body(parent, plist, nlab, roots, cid, nroots, cap);
 }
-__global__ __launch_bounds__(kRootsBlock) void roots_many_kernel(const DetGroup g, unsigned int cap) {
+__global__ __launch_bounds__(kRootsBlock) void roots_many_kernel(const DetGroup g, unsigned int cap) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     roots_body(g.parent[f], g.plist[f], g.counters[f] + 1, g.roots[f], g.cid[f], g.counters[f], cap);
 }
-__global__ __launch_bounds__(256) void comp_init_kernel(CompStat *st, unsigned int n) { comp_init_body(st, n); }
-__global__ __launch_bounds__(256) void comp_init_many_kernel(const DetGroup g) {
+__global__ __launch_bounds__(256) void comp_init_kernel(CompStat *st, unsigned int n) { AB_LATENCY_KERNEL_PRIO(); comp_init_body(st, n); }
+__global__ __launch_bounds__(256) void comp_init_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     comp_init_body(g.st[f], g.ncomp[f]);
 }
 __global__ __launch_bounds__(256) void comp_stats_kernel(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st, const int *__restrict__ plist,
-                                                         const unsigned int *__restrict__ nlab) {
+                                                         const unsigned int *__restrict__ nlab) { AB_LATENCY_KERNEL_PRIO();
     comp_stats_body(rows, cols, parent, cid, st, plist, nlab);
 }
-__global__ __launch_bounds__(256) void comp_stats_many_kernel(const DetGroup g, int rows, int cols) {
+__global__ __launch_bounds__(256) void comp_stats_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     if (g.ncomp[f] == 0) return;
     comp_stats_body(rows, cols, g.parent[f], g.cid[f], g.st[f], g.plist[f], g.counters[f] + 1);
@@ -790,10 +790,10 @@ __global__ __launch_bounds__(256) void comp_stats_many_kernel(const DetGroup g, 
 __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st,
                                                            unsigned int ncomp, double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
-                                                           const FrameDev *__restrict__ fd) {
+                                                           const FrameDev *__restrict__ fd) { AB_LATENCY_KERNEL_PRIO();
     comp_moments_body(img, cols, ld, parent, mask, roots, st, ncomp, bg_median_arg, xf_arg, rec, fd);
 }
-__global__ __launch_bounds__(256) void comp_moments_many_kernel(const DetGroup g, int cols, int64_t ld) {
+__global__ __launch_bounds__(256) void comp_moments_many_kernel(const DetGroup g, int cols, int64_t ld) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     comp_moments_body(g.img[f], cols, ld, g.parent[f], g.mask[f], g.roots[f], g.st[f], g.ncomp[f], g.bg_median[f], g.xf[f], g.rec[f], nullptr);
 }

@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
                                                    int out_cols, float *__restrict__ out, int row0) {
     // two output pixels per lane (x and x + 256): their f64 chains are independent, which is the only instruction-level
     // parallelism this f64-bound kernel can get
+#ifdef AB_WARP_WAVE_PRIO
+    __builtin_amdgcn_s_setprio(AB_WARP_WAVE_PRIO);
+#endif
     const int x0 = blockIdx.x * 512 + threadIdx.x;
     // row0: the band of output rows [row0, row0 + gridDim.y) this launch produces (row-band sharding); the
     // coordinate arithmetic uses the row's index in the WHOLE output, so a band is bit-identical to the same rows of a full warp
