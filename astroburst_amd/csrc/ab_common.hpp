@@ -290,6 +290,7 @@ struct ab_bg_pipeline {
     const void *tiles = nullptr;  // pinned TileOut[n][ntiles]
     const hipEvent_t *events = nullptr;
     int ntiles = 0, chunk = 1;
+    int first = 0;  // planes of the FIRST launch when it is smaller than the others (0: `chunk` like every launch): chunk of plane i = i < first ? 0 : 1 + (i - first) / chunk
     size_t n = 0;
     const ab_pixel_xf *xf_host = nullptr;  // fed pipeline: plane i's transform, valid once ab_bg_pipeline_get(i) has returned
     struct ab_bg_feed_impl *feed = nullptr;  // the feeder thread of a pipeline whose planes are still landing (detect.hip)

@@ -1054,6 +1054,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
                               ab_affine_align_result *out, float *const *aligned /* nullable: warp_image(target, transform) per target */,
                               const hipEvent_t *landed /* nullable: per target, the event after which its pixels are in HBM (an upload in flight) */) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
+    if (ab_upload_trace_on() && !landed) ab_trace_t0() = std::chrono::steady_clock::now();  // (a host-fed call has set it)
     MatchWs w;
     AB_TRY(match_ws(ctx, &w));
     RefTable rt;
@@ -1103,6 +1104,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         planes.push_back(ref);
         xfs.resize(n + 1);
         AB_TRY(ab_normalize_params_many_device(ctx, planes.data(), n + 1, rows * cols, xfs.data()));
+        ab_upload_trace("percentiles joined, planes", (long)(n + 1));
         // ... and their background tiles: the tile kernel runs on its own stream, a few frames per launch, the reference first,
         // while the workers already label the frames whose tiles are done (register_one blocks on its frame's chunk)
         static const int chunk = getenv("AB_TILE_CHUNK") ? atoi(getenv("AB_TILE_CHUNK")) : 8;  // frames per launch (0: every frame's tiles in its own chain); measured 0 / 2 / 4 / 8 / 16 -> 17.6 / 17.5 / 17.2 / 17.0 / 17.4 ms for the stage
@@ -1116,6 +1118,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
                 oxf.push_back(xfs[i]);
             }
             AB_TRY(ab_bg_pipeline_begin(ctx, order.data(), n + 1, rows, cols, oxf.data(), chunk, &pipe));
+            ab_upload_trace("tile launches enqueued, planes", (long)(n + 1));
         }
     }
     auto prepare_reference = [&]() -> int {
@@ -1200,7 +1203,10 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         rt.publish(prep_rc, prep_rc == AB_OK && rt.stars.size() >= kMinMatchesRigid);
     };
     const int rc = ab_parallel_frames(ctx, n_jobs, "registration", job, /*drain_caller_stream=*/false, &prep);
-    if (warp_stream) (void)hipStreamSynchronize(warp_stream);  // the aligned frames are complete when this call returns
+    ab_upload_trace("workers joined, jobs", (long)n_jobs);
+    if (warp_stream) (void)hipStreamSynchronize(warp_stream);
+    ab_upload_trace("warp stream drained", 0);
+    if (!landed) ab_upload_trace("registration returns", (long)n);  // the aligned frames are complete when this call returns
     if (pipe.on) (void)hipStreamSynchronize(ctx->aux_stream);  // (an error or a cancel may leave tile launches in flight: they read the caller's frames)
     return prep_rc != AB_OK ? prep_rc : rc;
 }

@@ -1210,7 +1210,11 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     const int step = (int)std::max<int64_t>(tile_size, 16);
     const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
     if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK", "AB_TILE_PRIO", 0));
-    const size_t nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
+    // the first launch holds the reference and the first group's targets only (AB_TILE_FIRST, default 5; 0 = `chunk` like the rest):
+    // nothing else can run until a group's tiles are done, and eight frames' tiles are ~300 us of an otherwise idle chip
+    static const int first_env = getenv("AB_TILE_FIRST") ? atoi(getenv("AB_TILE_FIRST")) : 5;
+    const size_t first = (first_env > 0 && first_env < chunk && (size_t)first_env < n) ? (size_t)first_env : 0;
+    const size_t nchunks = first ? 1 + (n - first + (size_t)chunk - 1) / (size_t)chunk : (n + (size_t)chunk - 1) / (size_t)chunk;
     while (ctx->aux_events.size() < nchunks) {
         hipEvent_t e;
         AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1243,10 +1247,11 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
         AB_HIP(ctx, hipMemcpyAsync(dplanes, stage, ptr_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
         AB_HIP(ctx, hipMemcpyAsync(dxf, stage + ((ptr_bytes + 15) & ~(size_t)15), xf_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
         for (size_t c = 0; c < nchunks; ++c) {
-            const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
+            const size_t begin = first ? (c == 0 ? 0 : first + (c - 1) * (size_t)chunk) : c * (size_t)chunk;
+            const size_t cnt = (first && c == 0) ? first : std::min<size_t>((size_t)chunk, n - begin);
             AB_TRY(launch_tile_kernels(ctx, ctx->aux_stream, 1, nullptr, rows, cols, cols, step, ntx, ntiles, (int)cnt, ab_pixel_xf(),
-                                       (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, nullptr, (const float *const *)(dplanes + first),
-                                       (const ab_pixel_xf *)(dxf + first)));
+                                       (TileOut *)ctx->aux_pinned + begin * (size_t)ntiles, nullptr, (const float *const *)(dplanes + begin),
+                                       (const ab_pixel_xf *)(dxf + begin)));
             AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
         }
         AB_HIP(ctx, hipGetLastError());
@@ -1262,6 +1267,7 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     p->events = ctx->aux_events.data();
     p->ntiles = ntiles;
     p->chunk = chunk;
+    p->first = (int)first;
     p->n = n;
     return AB_OK;
 }
@@ -1442,7 +1448,7 @@ void ab_bg_pipeline_end(ab_bg_pipeline *p) {
 
 int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *bg) {
     AB_CHECK(ctx, p && p->on && i < p->n, "background pipeline: no such plane");
-    const size_t c = i / (size_t)p->chunk;
+    const size_t c = p->first > 0 ? (i < (size_t)p->first ? 0 : 1 + (i - (size_t)p->first) / (size_t)p->chunk) : i / (size_t)p->chunk;
     if (p->feed) {  // the chunk's launches are in the streams only once its planes have landed
         std::unique_lock<std::mutex> g(p->feed->m);
         p->feed->cv.wait(g, [&] { return p->feed->enqueued > c || p->feed->rc != AB_OK; });

@@ -29,6 +29,16 @@ def main(path):
     bursts.append(cur)
     big = [b for b in bursts if any("tile_background_stream" in n for n, _, _ in b)]
     print(f"{len(rows)} kernels, {len(bursts)} bursts, {len(big)} registration calls")
+    for b in big:  # one line per call: where a slow call loses its time (an idle GPU = the host)
+        t0, t1 = min(s for _, s, _ in b), max(e for _, _, e in b)
+        ev = sorted([(s, 1) for _, s, _ in b] + [(e, -1) for _, _, e in b])
+        depth, last, idle, gap = 0, t0, 0, 0
+        for t, d in ev:
+            if depth == 0:
+                idle += t - last
+                gap = max(gap, t - last)
+            last, depth = t, depth + d
+        print(f"call: span {(t1 - t0) / 1e6:7.3f} ms  idle {idle / 1e6:6.3f} ms  longest gap {gap / 1e6:6.3f} ms  kernels {len(b)}")
     for b in big[-3:]:
         t0, t1 = min(s for _, s, _ in b), max(e for _, _, e in b)
         ev = sorted([(s, 1) for _, s, _ in b] + [(e, -1) for _, _, e in b])

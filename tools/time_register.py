@@ -29,10 +29,10 @@ for _ in range(2):
     res = ctx.align_pairs_affine(raw[0], raw[1:], warped, num_threads=8)
 torch.cuda.synchronize()
 ts = []
-for _ in range(8):
+for _ in range(int(os.environ.get('REPS', '8'))):
     t0 = time.perf_counter()
     res = ctx.align_pairs_affine(raw[0], raw[1:], warped, num_threads=8)
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 knobs = {k: v for k, v in os.environ.items() if k.startswith("AB_")}
-print(f"align_pairs_affine x63: min {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms  {knobs}  methods {sorted(set(r.method for r in res))}")
+print(f"align_pairs_affine x63: min {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms  {knobs}  methods {sorted(set(r.method for r in res))}  all " + " ".join(f"{t:.2f}" for t in ts))
