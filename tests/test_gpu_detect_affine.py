@@ -87,6 +87,45 @@ def test_detect_touching_blobs_and_size_limits(ctx, oracle):
     assert sorted(s.npix for s in got) == [3, 17]
 
 
+def test_component_shapes_through_every_moments_path(ctx, oracle):
+    """comp_moments (round 4) walks a component's box as a lane patch of 8 / 16 / 32 / 64 columns, keeps boxes of up to eight trips
+    in registers and walks larger ones eight trips at a time, four components per wave: one frame holding every shape -- a wide
+    thin bar (> 64 columns: several column blocks), a tall one (more than eight trips of an 8-column patch), a 44 x 44 block
+    (44 trips of a 64-column patch) and a 70 x 70 one, an L whose box is mostly empty, a ring (the box's centre is not a member),
+    neighbours whose boxes overlap, and ordinary stars in between"""
+    from astroburst_amd import synth
+    rows, cols = 600, 720
+    y, x, flux = synth.star_catalog(rows, cols, 150, seed=21)
+    img = synth.make_frame(rows, cols, 2, cat=(y, x, flux * 20.0), bad_patch_rate=0.0, cosmic_rate=0.0).numpy()
+    ramp = np.linspace(400.0, 900.0, 200, dtype=np.float32)
+    img[40:43, 100:300] += ramp                                       # 200 x 3: wide, flux gradient along it
+    img[100:260, 30:34] += ramp[:160, None]                           # 4 x 160: tall
+    img[300:344, 400:444] += 600.0 + 3.0 * np.arange(44, dtype=np.float32)[None, :]   # 44 x 44: about the largest box whose FWHM passes (:162)
+    img[380:450, 400:470] += 600.0                                    # 70 x 70 = 4900 px: measured, then dropped by its FWHM
+    img[450:520, 100:104] += 700.0                                    # an L: 70 x 4 ...
+    img[516:520, 100:190] += 700.0                                    # ... and 4 x 90
+    yy, xx = np.mgrid[0:41, 0:41]
+    ring = (np.hypot(yy - 20, xx - 20) > 14) & (np.hypot(yy - 20, xx - 20) < 19)
+    img[200:241, 500:541][ring] += 800.0
+    img[420:426, 600:606] += 500.0                                    # two 6 x 6 blocks one pixel apart on the diagonal:
+    img[427:433, 607:613] += 500.0                                    # separate components with overlapping neighbourhoods
+    for sigma in (5.0, 3.5):
+        got, gm, gs = ctx.detect_stars(img, sigma)
+        ref, rm, rs = oracle.detect_stars(img, sigma)
+        assert (gm, gs) == (rm, rs) and len(ref) > 40
+        compare_stars(got, ref)
+    assert sum(s.npix > 400 for s in got) >= 2   # the block and the ring are stars; the bars and the 70 x 70 block fail the FWHM test
+    # ... and the same frame through the grouped chain of a registration batch (comp_moments_many): every target of a batch of
+    # five equals the pairwise call (the group path's records travel through pinned memory, 72 or 8 bytes each)
+    import torch
+    tgts = [torch.from_numpy(np.roll(img, (k, -k), axis=(0, 1)).copy()).cuda() for k in range(1, 6)]
+    ref_t = torch.from_numpy(img).cuda()
+    batch = ctx.register_frames(ref_t, tgts, num_threads=8)
+    for t, b in zip(tgts, batch):
+        one = ctx.align_channel_affine(ref_t, t, num_threads=8)
+        assert (b.method, b.inliers, b.matched_stars) == (one.method, one.inliers, one.matched_stars) and b.transform == one.transform
+
+
 def test_normalize_for_detection(ctx, oracle):
     rng = np.random.default_rng(2)
     img = rng.normal(1000, 30, (300, 400)).astype(np.float32)

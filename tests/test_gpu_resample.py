@@ -48,6 +48,18 @@ def test_warp_matches_oracle(ctx, oracle, deg, scale, tx, ty):
         assert np.array_equal(got, ref, equal_nan=True), f"max |d| = {np.nanmax(np.abs(got - ref))}"
 
 
+@pytest.mark.parametrize("t", [(1.0, 0.0, float("nan"), 0.0, 1.0, 2.0), (float("inf"), 0.0, 1.0, 0.0, 1.0, 2.0), (1e200, -1e200, 3.0, 0.0, 1.0, 0.5),
+                               (1.0, 0.0, 0.25, 1e-300, 1.0, 1e160), (-0.0, -0.0, -0.0, 0.0, 1.0, 0.0)],
+                         ids=["nan tx", "inf a", "huge a and b cancel to nan", "ty beyond 1e150", "negative zeros"])
+def test_warp_with_untame_coefficients(ctx, oracle, t):
+    """warp_kernel takes the in-bounds test on integer floors; a coordinate that is NaN (or a coefficient that could make one) goes
+    through the guarded instance -- the output equals the oracle's either way (mostly zeros: nothing maps inside the source)"""
+    img = np.random.default_rng(4).normal(100, 10, (96, 130)).astype(np.float32)
+    got = ctx.warp_image(img, t, 96, 130)
+    ref = oracle.warp_image(img, t, 96, 130)
+    assert np.array_equal(got, ref, equal_nan=True)
+
+
 def test_warp_reference_cases(ctx):                             # affine.rs:776-832
     img = np.arange(2500, dtype=np.float32).reshape(50, 50)
     w = ctx.warp_image(img, (1, 0, 0, 0, 1, 0), 50, 50)
