@@ -127,7 +127,7 @@ __device__ __forceinline__ void catmull_weights_fused(double f, double &w0, doub
 // f64 compare would) -- two integer compares instead of four f64 compares and eight selects on the coordinates.  A NaN
 // coordinate would convert to 0 and pass: GUARD adds the two self-compares, and the host takes that instance whenever the
 // coefficients could overflow (|coefficient| > 1e150 or non-finite), so that products and sums of the plain one are finite.
-template <bool GUARD, bool NOLOAD = false>
+template <bool GUARD, bool NOLOAD = false, bool NOCVT = false>
 __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src, int src_rows, int src_cols, double a,
                                                    double b, double tx, double c, double d, double ty, int out_rows,
                                                    int out_cols, float *__restrict__ out, int row0) {
@@ -168,10 +168,17 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
             for (int j = 0; j < 4; ++j) {
                 float s0 = __int_as_float(0x3f800000 | ((ix + 4 * j) & 0xffff)), s1 = __int_as_float(0x3f800000 | ((ix + 4 * j + 1) & 0xffff)),
                       s2 = __int_as_float(0x3f800000 | ((iy + 4 * j + 2) & 0xffff)), s3 = __int_as_float(0x3f800000 | ((iy + 4 * j + 3) & 0xffff));
-                double row_val = (double)s0 * wx0;
-                row_val += (double)s1 * wx1;
-                row_val += (double)s2 * wx2;
-                row_val += (double)s3 * wx3;
+                double d0 = (double)s0, d1 = (double)s1, d2 = (double)s2, d3 = (double)s3;
+                if constexpr (NOCVT) {  // (AB_ABLATE_WARP=3: the upper bound of an LDS-staged f64 tile -- 64-bit words straight from registers)
+                    d0 = __longlong_as_double(0x3ff0000000000000ll | (long long)(unsigned)(ix + 4 * j));
+                    d1 = __longlong_as_double(0x3ff0000000000000ll | (long long)(unsigned)(ix + 4 * j + 1));
+                    d2 = __longlong_as_double(0x3ff0000000000000ll | (long long)(unsigned)(iy + 4 * j + 2));
+                    d3 = __longlong_as_double(0x3ff0000000000000ll | (long long)(unsigned)(iy + 4 * j + 3));
+                }
+                double row_val = d0 * wx0;
+                row_val += d1 * wx1;
+                row_val += d2 * wx2;
+                row_val += d3 * wx3;
                 const double t = row_val * wy[j];
                 val = (j == 0) ? t : val + t;
             }
@@ -258,6 +265,12 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
     const dim3 grid((unsigned)((out_cols + 511) / 512), (unsigned)nrows), block(256);
     static const int ablate = getenv("AB_ABLATE_WARP") ? atoi(getenv("AB_ABLATE_WARP")) : 0;  // developer timing experiments
     if (ablate == 1) return AB_OK;  // what the registration stage takes without the warps
+    if (ablate == 3) {              // ... and without the sixteen conversions and the address arithmetic
+        const dim3 g2((unsigned)((out_cols + 511) / 512), (unsigned)nrows);
+        hipLaunchKernelGGL((warp_kernel<false, true, true>), g2, dim3(256), 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
+                           t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
+        return AB_OK;
+    }
     if (ablate == 2) {              // what the kernel takes without its loads
         const dim3 g2((unsigned)((out_cols + 511) / 512), (unsigned)nrows);
         hipLaunchKernelGGL((warp_kernel<false, true>), g2, dim3(256), 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
