@@ -246,6 +246,13 @@ __global__ __launch_bounds__(ts::kThreads) void tile_background_stream_kernel(co
                                                                               const FrameDev *__restrict__ fd, const float *const *__restrict__ many_planes,
                                                                               const ab_pixel_xf *__restrict__ many_xf, unsigned int *__restrict__ fail) {
     __shared__ ts::Shared sh;
+#ifdef AB_TILE_VGPR_FLOOR
+    // developer experiment: a register floor caps the tile workgroups per CU (four of them take 156 of the 160 KB of LDS, and no
+    // kernel that needs LDS -- label_init, the triangle kernels -- fits beside them)
+#define AB_STR2(x) #x
+#define AB_STR(x) AB_STR2(x)
+    asm volatile("" ::: "v" AB_STR(AB_TILE_VGPR_FLOOR));
+#endif
     const float *__restrict__ img = img_arg;
     if (many_planes) {
         img = many_planes[blockIdx.y];
@@ -536,7 +543,8 @@ __device__ __forceinline__ double wave_max(double x) {
 // Inside a registration batch the kernel held a hardware queue for 190-260 us per group of four frames (23 us per frame alone:
 // pure latency, which grows under load).
 constexpr int kMomKeep = 8;
-constexpr int kMomPerWave = 4;  // components per wave: their headers and first four trips are in flight together
+constexpr int kMomPerWave = 4;  // components per wave: their headers and first trips are in flight together
+constexpr int kMomFirst = 2;    // trips of each of them issued before anything is consumed
 __device__ int g_mom_ablate = 0;  // developer timing experiment (AB_ABLATE_MOMENTS): 1 = no box walk, 2 = no record store either
 
 struct MomGeom {  // the lane patch of one component's box
@@ -589,12 +597,13 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
         root[j] = roots[live ? base + j : base];
     }
 #pragma unroll
-    for (int j = 0; j < kMomPerWave; ++j) {  // the first four trips of every small box: 48 loads in flight
+    for (int j = 0; j < kMomPerWave; ++j) {  // the first kMomFirst trips of every small box together: 24 loads in flight (a 9 x 9 star
+                                             // is two trips of a 16 x 4 patch; four trips each cost 168 registers for the kernel)
         G[j] = mom_geom(S[j], lane, base + j < ncomp);
         const bool go = G[j].small && ablate == 0;
         const int c = S[j].x0 + G[j].dc;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kMomFirst; ++k) {
             const int r = S[j].y0 + k * G[j].rpt + G[j].dr;
             v[j][k] = value(S[j], root[j], r, c, go && G[j].dc < G[j].w && r <= S[j].y1);
         }
@@ -612,6 +621,16 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
             double f = 0.0, sx = 0.0, sy = 0.0, pk = 0.0;
             if (g.small) {  // wave-uniform; the usual star: its values stay in registers for the second pass
                 const int c = s.x0 + g.dc;
+                if (g.nrb > kMomFirst) {
+#pragma unroll
+                    for (int k = kMomFirst; k < 4; ++k) {
+                        const int r = s.y0 + k * g.rpt + g.dr;
+                        v[j][k] = value(s, root[j], r, c, g.dc < g.w && r <= s.y1);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = kMomFirst; k < 4; ++k) v[j][k] = 0.0;
+                }
                 if (g.nrb > 4) {
 #pragma unroll
                     for (int k = 4; k < kMomKeep; ++k) {
