@@ -78,7 +78,30 @@ struct BatchArgs {
     uint32_t *rej;  // [waves][64]
     int stage;           // developer ablation (AB_BATCH_STAGE): 1 no sort, 2 no LDS copy, 3 no epilogue loop
     uint32_t per_block;  // 0: block b takes chunks b, b + grid, ...; else chunks [b * per_block, (b + 1) * per_block)
+    // the retain test without its division (retain_thresholds below): z = RN32(d / sigma) < sigma_high  <=>  d < mid_hi * sigma
+    int retain_fast;
+    int guess_step;  // 0: every MAD search starts from the whole range (AB_BATCH_GUESS: the bracket's half width, default 1)
+    double mid_lo, mid_hi;
 };
+
+// `(x - median) / sigma` is compared with two constants (:359-360), so the IEEE division can be replaced by a comparison of d =
+// RN32(x - median) with a threshold: RN32(q) < h  <=>  q < m, m the midpoint of h and its predecessor, and q < m  <=>  d < m sigma
+// for sigma > 0.  m is an odd 25-bit integer times a power of two, sigma has 24 bits, d 24: m sigma and d are exact doubles and the
+// comparison is exact -- and a tie q = m cannot happen at all (m sigma has at least 25 significant bits, d has 24), so the rounding
+// rule at the midpoint never matters.  Mirror image for the lower bound.  Only for bounds in the normal range (the midpoint must
+// not touch the subnormals) and a finite sigma; everything else keeps the division (tests/test_retain_threshold_math.py restates
+// the claim in numpy on values one ulp either side of every boundary).
+bool retain_thresholds(BatchArgs *a) {
+    const float nsl = -a->sigma_low, sh = a->sigma_high;
+    auto usable = [](float v) { return std::isfinite(v) && std::fabs(v) >= 1e-30f && std::fabs(v) <= 1e30f; };
+    a->retain_fast = 0;
+    a->mid_lo = a->mid_hi = 0.0;
+    if (!usable(nsl) || !usable(sh) || getenv("AB_BATCH_DIVIDE")) return false;
+    a->mid_hi = ((double)std::nextafterf(sh, -INFINITY) + (double)sh) * 0.5;
+    a->mid_lo = ((double)nsl + (double)std::nextafterf(nsl, INFINITY)) * 0.5;
+    a->retain_fast = 1;
+    return true;
+}
 
 // calibrate_light's per-pixel chain (:93-113) in its f32 operation order.  (Tried: sharing the Newton-refined reciprocal
 // of the flat across a pixel's n frames and finishing each quotient with the four fma of the hardware-assisted expansion --
@@ -253,6 +276,7 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
 
         // ---- the clipping loop (:350-367) on the window [lo, hi) of the sorted order ----
         int lo = 0, hi = a.n;
+        int prev_i0 = 0, prev_k = 0;  // the last iteration's MAD split (see the search below)
         for (int it = 0; it < a.max_iter; ++it) {
             const int len = hi - lo;
             if (len < 3) break;
@@ -270,9 +294,20 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
             // independent probes (six reads) per round trip
             const int nA = c - lo + 1, nB = hi - c - 1;
             int i0 = max(0, k + 1 - nB), i1 = min(k + 1, nA);
+            // from the second iteration on the search starts at the previous split, moved by half of what the window lost: a
+            // retain pass shaves a sample or two, the split moves by one or two, and a bracket of three probes around the guess
+            // settles most lanes in ONE round trip instead of three (lanes it does not settle go on with the 4-ary rounds)
+            bool guessed = it > 0 && a.guess_step > 0;
             while (i0 < i1) {
                 const int w = i1 - i0;
-                const int m1 = i0 + (w >> 2), m2 = i0 + (w >> 1), m3 = i0 + ((3 * w) >> 2);  // all within [i0, i1 - 1]
+                int m1 = i0 + (w >> 2), m2 = i0 + (w >> 1), m3 = i0 + ((3 * w) >> 2);  // all within [i0, i1 - 1]
+                if (guessed) {
+                    const int g = prev_i0 + ((k - prev_k) >> 1);
+                    m2 = min(max(g, i0), i1 - 1);
+                    m1 = max(m2 - a.guess_step, i0);
+                    m3 = min(m2 + a.guess_step, i1 - 1);
+                    guessed = false;
+                }
                 const float a1 = S(c - m1), b1 = S(c + k + 1 - m1), a2 = S(c - m2), b2 = S(c + k + 1 - m2), a3 = S(c - m3), b3 = S(c + k + 1 - m3);
                 const bool p1 = (med - a1) < (b1 - med), p2 = (med - a2) < (b2 - med), p3 = (med - a3) < (b3 - med);
                 const int n0 = !p1 ? i0 : (!p2 ? m1 + 1 : (!p3 ? m2 + 1 : m3 + 1));
@@ -280,6 +315,8 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
                 i0 = n0;
                 i1 = n1;
             }
+            prev_i0 = i0;
+            prev_k = k;
             const int j0 = k + 1 - i0;
             const float ma = i0 > 0 ? med - S(c - (i0 - 1)) : -__builtin_inff();
             const float mb = j0 > 0 ? S(c + j0) - med : -__builtin_inff();
@@ -288,24 +325,34 @@ __global__ __launch_bounds__(kWave *kWavesPerBlock) void scms_kernel(const Batch
             const float sigma = (float)((double)mad * kMadToSigma);
             if (sigma < 1e-10f) break;
             const float nsl = -a.sigma_low, sh = a.sigma_high;
-            auto kept = [&](float x) {
-                const float z = (x - med) / sigma;
-                return z > nsl && z < sh;
-            };
             int nlo = lo, nhi = hi;
-            if (!kept(e0)) {
-                nlo = lo + 1;
-                if (!kept(e1)) {
-                    nlo = lo + 2;
-                    while (nlo < nhi && !kept(S(nlo))) ++nlo;
+            auto shave = [&](auto kept) {
+                if (!kept(e0)) {
+                    nlo = lo + 1;
+                    if (!kept(e1)) {
+                        nlo = lo + 2;
+                        while (nlo < nhi && !kept(S(nlo))) ++nlo;
+                    }
                 }
-            }
-            if (nhi > nlo && !kept(f0)) {
-                nhi = hi - 1;
-                if (nhi > nlo && !kept(f1)) {
-                    nhi = hi - 2;
-                    while (nhi > nlo && !kept(S(nhi - 1))) --nhi;
+                if (nhi > nlo && !kept(f0)) {
+                    nhi = hi - 1;
+                    if (nhi > nlo && !kept(f1)) {
+                        nhi = hi - 2;
+                        while (nhi > nlo && !kept(S(nhi - 1))) --nhi;
+                    }
                 }
+            };
+            if (a.retain_fast && !__any(!__builtin_isfinite(sigma))) {  // wave-uniform; see retain_thresholds
+                const double sd = (double)sigma, tlo = a.mid_lo * sd, thi = a.mid_hi * sd;
+                shave([&](float x) {
+                    const double d = (double)(x - med);
+                    return d > tlo && d < thi;
+                });
+            } else {
+                shave([&](float x) {
+                    const float z = (x - med) / sigma;
+                    return z > nsl && z < sh;
+                });
             }
             cnan = 0;  // a retain pass never keeps a NaN
             if (nlo == lo && nhi == hi) break;
@@ -678,6 +725,8 @@ int launch_scms_np(ab_ctx *ctx, const BatchArgs &a, int64_t nchunks, uint32_t **
     void *rej = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)waves + 2) * kMaxFrames * sizeof(unsigned long long), &rej));
     BatchArgs b = a;
+    retain_thresholds(&b);
+    b.guess_step = getenv("AB_BATCH_GUESS") ? atoi(getenv("AB_BATCH_GUESS")) : 1;
     b.stage = getenv("AB_BATCH_STAGE") ? atoi(getenv("AB_BATCH_STAGE")) : 0;
     b.per_block = 0;  // strided chunks; a contiguous range per wave measured the same
     b.rej = (uint32_t *)((unsigned long long *)rej + kMaxFrames);  // [0, 64) u64 totals, then the per-block u32 partials
