@@ -41,6 +41,14 @@ enum {
     AB_WS_PHASE_TABLES,       // two sets of Hann windows + FFT twiddles of the phase correlation, kept between calls (phase_corr.hip)
     AB_WS_PIPE_TABLES,        // plane pointers + transforms of the fed background pipeline (detect.hip: ab_bg_pipeline_begin_fed)
     AB_WS_PIPE_SUBSAMPLE,     // its subsamples (one per plane: the chunks' percentile launches overlap)
+    AB_WS_SCOPE0,             // eight slots for the planes an entry point needs for the length of one call (masked stretch: luminance,
+    AB_WS_SCOPE1,             // mask, disc table, coverage counter, chain state; SPCC: luminance, apertures, fluxes): grow-only like every
+    AB_WS_SCOPE2,             // workspace -- a hipMalloc + hipFree pair per call cost 0.2-0.5 ms each for a 268 MB plane
+    AB_WS_SCOPE3,
+    AB_WS_SCOPE4,
+    AB_WS_SCOPE5,
+    AB_WS_SCOPE6,
+    AB_WS_SCOPE7,
     AB_WS_SLOTS
 };
 

@@ -156,6 +156,7 @@ struct Scope {
     std::vector<StagedPlane *> ins;
     std::vector<StagedOut *> outs;
     std::vector<void *> dev;
+    int next_slot = 0;
     explicit Scope(ab_ctx *c) : ctx(c) {}
     ~Scope() {
         for (StagedOut *o : outs) ab_stage_out_abort(ctx, o);
@@ -163,7 +164,9 @@ struct Scope {
         for (void *p : dev) (void)hipFree(p);
         for (StagedPlane *p : ins) ab_stage_release(ctx, p);
     }
+    // the call's device planes come out of the context's scope slots (kept between calls); a ninth one would be allocated and freed
     int alloc(void **p, size_t bytes) {
+        if (next_slot < 8) return ab_workspace(ctx, AB_WS_SCOPE0 + next_slot++, std::max<size_t>(bytes, 16), p);
         AB_HIP(ctx, hipMalloc(p, bytes));
         dev.push_back(*p);
         return AB_OK;
@@ -243,6 +246,10 @@ struct MsState {
     float m;
     int done, converged;
     unsigned long long iterations_run;
+    // the NEXT median's first level predicted (see ms_blend_hist0_kernel): its level-0 bin, and whether the blend's second histogram
+    // (level 1 under that bin) is the one the median needs
+    uint32_t pred_b0;
+    int l1_ready, pred_valid;  // pred_valid: a blend with a prediction has filled hist + 2048 since the last level-1 pick
 };
 constexpr int kPickBlock = 1024;
 
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(kBlock) void ms_normalize_hist0_kernel(const float 
 // levels 1 and 2 of a median
 __global__ __launch_bounds__(kBlock) void ms_hist_kernel(const float *__restrict__ work, const float *__restrict__ mask, int64_t n,
                                                          const MsState *__restrict__ st, unsigned int *hist, int level) {
-    if (st->done || st->count == 0) return;
+    if (st->done || st->count == 0 || (level == 1 && st->l1_ready)) return;
     __shared__ unsigned int lds[2048];
     LevelHist H;
     H.begin(lds, level == 1 ? 11 : 10, level == 1 ? 10 : 0, st->prefix_mask, st->prefix_val);
@@ -368,37 +375,47 @@ __global__ __launch_bounds__(kBlock) void ms_hist_kernel(const float *__restrict
     H.end(hist);
 }
 
-// apply_mtf (:240-255) + the mask-weighted blend (:93-100) in place, + level 0 of the next median
+// apply_mtf's pixel function (:240-255)
+__device__ __forceinline__ float mtf_pixel(float x, float m) {
+    if (x <= 0.0f) return 0.0f;
+    if (x >= 1.0f) return 1.0f;
+    const float denom = (2.0f * m - 1.0f) * x - m;
+    if (fabsf(denom) < 1e-10f) return x;
+    const float v = (m - 1.0f) * x / denom;
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
+// apply_mtf (:240-255) + the mask-weighted blend (:93-100) in place, + level 0 of the next median -- and, round 4, its LEVEL 1 too
+// when a prediction holds: an unmasked pixel (mask 0, all of the sky) becomes mtf(x) exactly, a monotone function, so the next
+// median would be mtf(this median) if every candidate were unmasked; the few per cent with a soft mask value move it by a few
+// level-1 bins at most, never out of its level-0 bin (a quarter of a binade).  The pass therefore also histograms level 1 of the
+// candidates inside the PREDICTED level-0 bin; the pick after it checks the prediction against the real level-0 histogram and,
+// when it holds, the level-1 pass over the plane returns at once (one of three passes per iteration: 28 -> 20 bytes per pixel).
 __global__ __launch_bounds__(kBlock) void ms_blend_hist0_kernel(float *__restrict__ work, const float *__restrict__ mask, int64_t n,
                                                                 const MsState *__restrict__ st, float protection, unsigned int *hist) {
     if (st->done) return;
-    __shared__ unsigned int lds[2048];
+    __shared__ unsigned int lds[2048], lds1[2048];
     LevelHist H;
+    for (uint32_t i = threadIdx.x; i < 2048u; i += kBlock) lds1[i] = 0;
     H.begin(lds, 11, 21, 0u, 0u);
     const float m = st->m;
+    const uint32_t pred = st->pred_b0;
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const float x = work[i], mk = mask[i];
-        float stretched;
-        if (x <= 0.0f) {
-            stretched = 0.0f;
-        } else if (x >= 1.0f) {
-            stretched = 1.0f;
-        } else {
-            const float denom = (2.0f * m - 1.0f) * x - m;
-            if (fabsf(denom) < 1e-10f) {
-                stretched = x;
-            } else {
-                const float v = (m - 1.0f) * x / denom;
-                stretched = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-            }
-        }
+        const float stretched = mtf_pixel(x, m);
         const float blend = mk * protection;
         const float r = x * blend + stretched * (1.0f - blend);
         work[i] = r;
-        if (ms_candidate(r, mk)) H.add(r);
+        if (ms_candidate(r, mk)) {
+            H.add(r);
+            const uint32_t key = __float_as_uint(r);
+            if ((key >> 21) == pred) atomicAdd(&lds1[(key >> 10) & 0x7ffu], 1u);
+        }
     }
     H.end(hist);
+    for (uint32_t i = threadIdx.x; i < 2048u; i += kBlock)
+        if (lds1[i]) atomicAdd(&hist[2048 + i], lds1[i]);
 }
 
 // One workgroup after every histogram pass: the bin of the wanted rank, the narrowed prefix, the histogram cleared for the next
@@ -411,13 +428,19 @@ __global__ __launch_bounds__(kPickBlock) void ms_pick_kernel(unsigned int *hist,
     __shared__ unsigned long long s_before;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const uint32_t nb = level == 2 ? 1024u : 2048u;
+    // level 1 reads the blend's predicted histogram (hist + 2048) when the level-0 pick found the prediction right; it clears both
+    const unsigned int *src = (level == 1 && st->l1_ready) ? hist + 2048 : hist;
     // thread t owns bins 2t, 2t + 1 (levels 0, 1) or bin t (level 2)
-    const unsigned int c0 = level == 2 ? (t < 1024 ? hist[t] : 0u) : hist[2 * t], c1 = level == 2 ? 0u : hist[2 * t + 1];
+    const unsigned int c0 = level == 2 ? (t < 1024 ? src[t] : 0u) : src[2 * t], c1 = level == 2 ? 0u : src[2 * t + 1];
     if (level == 2) {
         if (t < 1024) hist[t] = 0;
     } else {
         hist[2 * t] = 0;
         hist[2 * t + 1] = 0;
+        if (level == 1) {
+            hist[2048 + 2 * t] = 0;
+            hist[2048 + 2 * t + 1] = 0;
+        }
     }
     unsigned long long own = (unsigned long long)c0 + c1, incl = own;
 #pragma unroll
@@ -442,6 +465,7 @@ __global__ __launch_bounds__(kPickBlock) void ms_pick_kernel(unsigned int *hist,
         if (t == 0) {
             st->prefix_mask = st->prefix_val = 0u;
             st->rank = 0;
+            st->l1_ready = 0;
         }
     } else {
         const unsigned long long rank = level == 0 ? total / 2 : st->rank;
@@ -459,7 +483,12 @@ __global__ __launch_bounds__(kPickBlock) void ms_pick_kernel(unsigned int *hist,
             st->prefix_mask = pm | (bits << shift);
             st->prefix_val = pv | (bin << shift);
             st->rank = s_bin == 0xffffffffu ? 0ull : rank - s_before;
+            if (level == 0) st->l1_ready = (s_bin != 0xffffffffu && bin == st->pred_b0 && st->pred_valid) ? 1 : 0;
         }
+    }
+    if (level == 1) {
+        __syncthreads();
+        if (t == 0) st->pred_valid = 0;  // hist + 2048 has been cleared
     }
     if (level != 2) return;
     __syncthreads();
@@ -487,7 +516,11 @@ __global__ __launch_bounds__(kPickBlock) void ms_pick_kernel(unsigned int *hist,
         } else if (stagnated) {
             st->done = 1;
         } else {
-            st->m = (float)mtf_balance(bg, target);
+            const float mt = (float)mtf_balance(bg, target);
+            st->m = mt;
+            // the blend that follows predicts the next median's level-0 bin from this median (see ms_blend_hist0_kernel)
+            st->pred_b0 = __float_as_uint(mtf_pixel(st->count == 0 ? 0.0f : __uint_as_float(st->prefix_val), mt)) >> 21;
+            st->pred_valid = 1;
         }
     }
 }
@@ -497,7 +530,7 @@ int masked_stretch_enqueue(ab_ctx *ctx, hipStream_t stream, const float *img, co
                            void *scratch) {
     MsState *st = (MsState *)scratch;
     unsigned int *hist = (unsigned int *)((char *)scratch + ((sizeof(MsState) + 63) & ~(size_t)63));
-    hipLaunchKernelGGL(ms_init_kernel, dim3(2), dim3(1024), 0, stream, st, hist);  // (no fill, no copy: the chain's state starts on the device)
+    hipLaunchKernelGGL(ms_init_kernel, dim3(4), dim3(1024), 0, stream, st, hist);  // (no fill, no copy: the chain's state starts on the device)
     if (n <= 0) return AB_OK;
     const int grid = stream_grid(ctx, n);
     const int iterations = (int)std::min<size_t>(cfg.iterations, 1000000);
@@ -527,7 +560,7 @@ void masked_stretch_result_of(const MsState &st, ab_masked_stretch_result *res) 
     res->final_background = st.bg;
     res->converged = st.converged;
 }
-constexpr size_t kMsScratch = ((sizeof(MsState) + 63) & ~(size_t)63) + 2048 * sizeof(unsigned int);
+constexpr size_t kMsScratch = ((sizeof(MsState) + 63) & ~(size_t)63) + 4096 * sizeof(unsigned int);  // the level histogram + the predicted level 1
 
 // masked_stretch_with_mask (:60-118) on device planes; `work` receives the result
 int masked_stretch_device(ab_ctx *ctx, const float *img, const float *mask, int64_t n, const ab_masked_stretch_config &cfg, float *work,

@@ -185,8 +185,9 @@ int spcc_from_detection(ab_ctx *ctx, const float *r, const float *g, const float
         Aperture *daps = nullptr;
         double *dflux = nullptr;
         std::vector<double> flux(aps.size() * 3);
-        AB_HIP(ctx, hipMalloc((void **)&daps, aps.size() * sizeof(Aperture)));
-        hipError_t e = hipMalloc((void **)&dflux, flux.size() * sizeof(double));
+        AB_TRY(ab_workspace(ctx, AB_WS_SCOPE1, aps.size() * sizeof(Aperture), (void **)&daps));  // (kept between calls, see ab_common.hpp)
+        AB_TRY(ab_workspace(ctx, AB_WS_SCOPE2, flux.size() * sizeof(double), (void **)&dflux));
+        hipError_t e = hipSuccess;
         if (e == hipSuccess) e = hipMemcpyAsync(daps, aps.data(), aps.size() * sizeof(Aperture), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             const int lanes = (int)aps.size() * 3;
@@ -196,8 +197,6 @@ int spcc_from_detection(ab_ctx *ctx, const float *r, const float *g, const float
         }
         if (e == hipSuccess) e = hipMemcpyAsync(flux.data(), dflux, flux.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        (void)hipFree(daps);
-        if (dflux) (void)hipFree(dflux);
         if (e != hipSuccess) return ab_set_error(ctx, AB_ERR_HIP, "aperture photometry failed: %s", hipGetErrorString(e));
         for (size_t i = 0; i < good.size(); ++i) {
             const double rf = flux[3 * i], gf = flux[3 * i + 1], bf = flux[3 * i + 2];
@@ -270,7 +269,7 @@ int ab_spcc_calibrate_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, con
     AB_TRY(st.stage(r, g, b));
     const int64_t h = r->rows, w = r->cols, n = h * w;
     float *lum = nullptr;
-    AB_HIP(ctx, hipMalloc((void **)&lum, std::max<size_t>((size_t)n, 1) * sizeof(float)));
+    AB_TRY(ab_workspace(ctx, AB_WS_SCOPE0, std::max<size_t>((size_t)n, 1) * sizeof(float), (void **)&lum));
     int rc = AB_OK;
     std::vector<ab_detected_star> stars;
     ab_image_stats stats;
@@ -284,7 +283,6 @@ int ab_spcc_calibrate_rgb(ab_ctx *ctx, const ab_plane *r, const ab_plane *g, con
     if (rc == AB_OK) rc = ab_detect_stars_device(ctx, lum, h, w, w, 5.0, &stars, &bm, &bs);  // :86
     if (rc == AB_OK && n > 0) rc = ab_stats_device(ctx, lum, n, 0, 0.0, 0.0, &stats);     // :88
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(lum);
     if (rc != AB_OK) return rc;
     return spcc_from_detection(ctx, st.p[0].dptr, st.p[1].dptr, st.p[2].dptr, h, w, stars, stats.max, pixel_scale_arcsec, *cfg, res);
 } AB_CATCH(ctx)
