@@ -203,8 +203,6 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
         if (corr_open) ab_stage_out_abort(ctx, &so_corr);
         if (model_open) ab_stage_out_abort(ctx, &so_model);
         (void)hipStreamSynchronize(ctx->stream);
-        if (model_owned && model) (void)hipFree(model);
-        if (dcells) (void)hipFree(dcells);
         ab_stage_release(ctx, &in);
     };
 #define BG_TRY(expr)          \
@@ -225,7 +223,7 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
         }                                                                                          \
     } while (0)
 
-    BG_HIP(hipMalloc((void **)&dcells, (size_t)grid * grid * sizeof(CellOut)));
+    BG_TRY(ab_workspace(ctx, AB_WS_SCOPE1, (size_t)grid * grid * sizeof(CellOut), (void **)&dcells));  // (kept between calls: ab_common.hpp)
     BG_TRY(ab_progress(ctx, "sampling background", 1, 4));  // background.rs:63-66
 
     // global median / MAD over finite, > 0 pixels (:135-146)
@@ -314,7 +312,7 @@ extern "C" int ab_extract_background(ab_ctx *ctx, const ab_plane *img, const ab_
         model_open = true;
         model = so_model.dptr;
     } else {
-        BG_HIP(hipMalloc((void **)&model, (size_t)npix * sizeof(float)));
+        BG_TRY(ab_workspace(ctx, AB_WS_SCOPE0, (size_t)npix * sizeof(float), (void **)&model));
         model_owned = true;
     }
     hipLaunchKernelGGL(poly_model_kernel, dim3((unsigned)((cols + kBlock - 1) / kBlock), (unsigned)rows), dim3(kBlock), 0, ctx->stream, pa,

@@ -70,6 +70,7 @@ struct Scope {  // frees / aborts everything registered with it when the entry p
     std::vector<StagedPlane *> ins;
     std::vector<StagedOut *> outs;
     std::vector<void *> dev;
+    int next_slot = 0;
     explicit Scope(ab_ctx *c) : ctx(c) {}
     ~Scope() {
         for (StagedOut *o : outs) ab_stage_out_abort(ctx, o);
@@ -77,7 +78,8 @@ struct Scope {  // frees / aborts everything registered with it when the entry p
         for (void *p : dev) (void)hipFree(p);
         for (StagedPlane *p : ins) ab_stage_release(ctx, p);
     }
-    int alloc(float **p, int64_t n) {
+    int alloc(float **p, int64_t n) {  // out of the context's scope slots (kept between calls); a ninth plane is allocated and freed
+        if (next_slot < 8) return ab_workspace(ctx, AB_WS_SCOPE0 + next_slot++, std::max<size_t>((size_t)n, 1) * sizeof(float), (void **)p);
         AB_HIP(ctx, hipMalloc((void **)p, std::max<size_t>((size_t)n, 1) * sizeof(float)));
         dev.push_back(*p);
         return AB_OK;
