@@ -128,24 +128,6 @@ __global__ __launch_bounds__(kBlock) void mtf_blend_kernel(float *__restrict__ w
     }
 }
 
-__global__ __launch_bounds__(kBlock) void clamp01_kernel(float *__restrict__ work, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const float v = work[i];
-        work[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void luminance_kernel(const float *__restrict__ r, const float *__restrict__ g, const float *__restrict__ b,
-                                                           int64_t n, float *__restrict__ out) {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {  // masked_stretch.rs:143-154
-        const float rv = r[i], gv = g[i], bv = b[i];
-        const float rn = __builtin_isfinite(rv) ? rv : 0.0f, gn = __builtin_isfinite(gv) ? gv : 0.0f, bn = __builtin_isfinite(bv) ? bv : 0.0f;
-        out[i] = 0.2126f * rn + 0.7152f * gn + 0.0722f * bn;
-    }
-}
-
 int stream_grid(ab_ctx *ctx, int64_t n) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8));
 }
@@ -249,6 +231,7 @@ struct MsState {
     // the NEXT median's first level predicted (see ms_blend_hist0_kernel): its level-0 bin, and whether the blend's second histogram
     // (level 1 under that bin) is the one the median needs
     uint32_t pred_b0;
+    int need_clamp;  // some pixel left the last blend outside [0, 1] (clamp_inplace, :105, is the identity otherwise and its pass is skipped)
     int l1_ready, pred_valid;  // pred_valid: a blend with a prediction has filled hist + 2048 since the last level-1 pick
 };
 constexpr int kPickBlock = 1024;
@@ -267,6 +250,60 @@ __global__ void ms_init_kernel(MsState *st, unsigned int *hist) {
         z.kmin = 0xffffffffu;
         *st = z;
     }
+}
+
+// masked_stretch_rgb_shared reads the three channels for its luminance anyway: their ranges (ms_range_kernel's minimum / maximum of
+// the valid pixels) are taken in the same pass, into the three chains' states (initialised before it)
+struct RangeWave {
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    __device__ __forceinline__ void add(float v) {
+        if (__builtin_isfinite(v) && v > 1e-7f) {
+            const uint32_t b = __float_as_uint(v);
+            const uint32_t k = b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);  // ord_key
+            lo = min(lo, k);
+            hi = max(hi, k);
+        }
+    }
+    __device__ __forceinline__ void flush(MsState *st, uint32_t *s_lo, uint32_t *s_hi) {  // s_lo / s_hi: kBlock / 64 words each
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = min(lo, (uint32_t)__shfl_xor((int)lo, off, 64));
+            hi = max(hi, (uint32_t)__shfl_xor((int)hi, off, 64));
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+            s_lo[threadIdx.x >> 6] = lo;
+            s_hi[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kBlock / 64; ++w) {
+                lo = min(lo, s_lo[w]);
+                hi = max(hi, s_hi[w]);
+            }
+            if (lo <= hi) {
+                atomicMin(&st->kmin, lo);
+                atomicMax(&st->kmax, hi);
+            }
+        }
+    }
+};
+__global__ __launch_bounds__(kBlock) void luminance_range_kernel(const float *__restrict__ r, const float *__restrict__ g, const float *__restrict__ b,
+                                                                 int64_t n, float *__restrict__ out, MsState *sr, MsState *sg, MsState *sb) {
+    __shared__ uint32_t s_lo[kBlock / 64], s_hi[kBlock / 64];
+    RangeWave wr, wg, wb;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {  // masked_stretch.rs:143-154
+        const float rv = r[i], gv = g[i], bv = b[i];
+        const float rn = __builtin_isfinite(rv) ? rv : 0.0f, gn = __builtin_isfinite(gv) ? gv : 0.0f, bn = __builtin_isfinite(bv) ? bv : 0.0f;
+        out[i] = 0.2126f * rn + 0.7152f * gn + 0.0722f * bn;
+        wr.add(rv);
+        wg.add(gv);
+        wb.add(bv);
+    }
+    wr.flush(sr, s_lo, s_hi);
+    wg.flush(sg, s_lo, s_hi);
+    wb.flush(sb, s_lo, s_hi);
 }
 
 // minimum / maximum of the valid pixels (compute_image_stats' range: finite and above the padding threshold, stats.rs:10-13)
@@ -392,8 +429,9 @@ __device__ __forceinline__ float mtf_pixel(float x, float m) {
 // candidates inside the PREDICTED level-0 bin; the pick after it checks the prediction against the real level-0 histogram and,
 // when it holds, the level-1 pass over the plane returns at once (one of three passes per iteration: 28 -> 20 bytes per pixel).
 __global__ __launch_bounds__(kBlock) void ms_blend_hist0_kernel(float *__restrict__ work, const float *__restrict__ mask, int64_t n,
-                                                                const MsState *__restrict__ st, float protection, unsigned int *hist) {
+                                                                MsState *st, float protection, unsigned int *hist) {
     if (st->done) return;
+    bool outside = false;  // a blend of two values of [0, 1] leaves [0, 1] only by a rounding of 1 - blend (x = stretched = 1)
     __shared__ unsigned int lds[2048], lds1[2048];
     LevelHist H;
     for (uint32_t i = threadIdx.x; i < 2048u; i += kBlock) lds1[i] = 0;
@@ -407,6 +445,7 @@ __global__ __launch_bounds__(kBlock) void ms_blend_hist0_kernel(float *__restric
         const float blend = mk * protection;
         const float r = x * blend + stretched * (1.0f - blend);
         work[i] = r;
+        outside |= r < 0.0f || r > 1.0f;
         if (ms_candidate(r, mk)) {
             H.add(r);
             const uint32_t key = __float_as_uint(r);
@@ -416,6 +455,17 @@ __global__ __launch_bounds__(kBlock) void ms_blend_hist0_kernel(float *__restric
     H.end(hist);
     for (uint32_t i = threadIdx.x; i < 2048u; i += kBlock)
         if (lds1[i]) atomicAdd(&hist[2048 + i], lds1[i]);
+    if (__any(outside) && (threadIdx.x & 63) == 0) atomicOr(&st->need_clamp, 1);
+}
+
+// clamp_inplace (:105, :256-258): the identity on [0, 1], -0.0 and NaN -- the pass runs only when the last blend said it must
+__global__ __launch_bounds__(kBlock) void ms_clamp_kernel(float *__restrict__ work, int64_t n, const MsState *__restrict__ st) {
+    if (!st->need_clamp) return;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float v = work[i];
+        work[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
 }
 
 // One workgroup after every histogram pass: the bin of the wanted rank, the narrowed prefix, the histogram cleared for the next
@@ -518,6 +568,7 @@ __global__ __launch_bounds__(kPickBlock) void ms_pick_kernel(unsigned int *hist,
         } else {
             const float mt = (float)mtf_balance(bg, target);
             st->m = mt;
+            st->need_clamp = 0;  // the blend that follows overwrites every pixel and raises it again if it has to
             // the blend that follows predicts the next median's level-0 bin from this median (see ms_blend_hist0_kernel)
             st->pred_b0 = __float_as_uint(mtf_pixel(st->count == 0 ? 0.0f : __uint_as_float(st->prefix_val), mt)) >> 21;
             st->pred_valid = 1;
@@ -527,15 +578,15 @@ __global__ __launch_bounds__(kPickBlock) void ms_pick_kernel(unsigned int *hist,
 
 // the whole chain of one channel on `stream`; nothing is synchronised.  scratch: sizeof(MsState) + 2048 words, device memory.
 int masked_stretch_enqueue(ab_ctx *ctx, hipStream_t stream, const float *img, const float *mask, int64_t n, const ab_masked_stretch_config &cfg, float *work,
-                           void *scratch) {
+                           void *scratch, bool have_range = false /* the state is initialised and holds the plane's range already */) {
     MsState *st = (MsState *)scratch;
     unsigned int *hist = (unsigned int *)((char *)scratch + ((sizeof(MsState) + 63) & ~(size_t)63));
-    hipLaunchKernelGGL(ms_init_kernel, dim3(4), dim3(1024), 0, stream, st, hist);  // (no fill, no copy: the chain's state starts on the device)
+    if (!have_range) hipLaunchKernelGGL(ms_init_kernel, dim3(4), dim3(1024), 0, stream, st, hist);  // (no fill, no copy: the chain's state starts on the device)
     if (n <= 0) return AB_OK;
     const int grid = stream_grid(ctx, n);
     const int iterations = (int)std::min<size_t>(cfg.iterations, 1000000);
     const float protection = (float)cfg.protection_amount;
-    hipLaunchKernelGGL(ms_range_kernel, dim3(grid), dim3(kBlock), 0, stream, img, n, st);
+    if (!have_range) hipLaunchKernelGGL(ms_range_kernel, dim3(grid), dim3(kBlock), 0, stream, img, n, st);
     hipLaunchKernelGGL(ms_range_finish_kernel, dim3(1), dim3(1), 0, stream, st);
     hipLaunchKernelGGL(ms_normalize_hist0_kernel, dim3(grid), dim3(kBlock), 0, stream, img, mask, n, (const MsState *)st, work, hist);
     auto finish_median = [&](int it) {
@@ -547,10 +598,10 @@ int masked_stretch_enqueue(ab_ctx *ctx, hipStream_t stream, const float *img, co
     };
     finish_median(-1);
     for (int it = 0; it < iterations; ++it) {
-        hipLaunchKernelGGL(ms_blend_hist0_kernel, dim3(grid), dim3(kBlock), 0, stream, work, mask, n, (const MsState *)st, protection, hist);
+        hipLaunchKernelGGL(ms_blend_hist0_kernel, dim3(grid), dim3(kBlock), 0, stream, work, mask, n, st, protection, hist);
         finish_median(it + 1);
     }
-    hipLaunchKernelGGL(clamp01_kernel, dim3(grid), dim3(kBlock), 0, stream, work, n);
+    hipLaunchKernelGGL(ms_clamp_kernel, dim3(grid), dim3(kBlock), 0, stream, work, n, (const MsState *)st);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }
@@ -710,8 +761,17 @@ int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab_plane 
     float *lum = nullptr, *mask = nullptr;
     AB_TRY(sc.alloc((void **)&lum, std::max<size_t>((size_t)n, 1) * sizeof(float)));
     AB_TRY(sc.alloc((void **)&mask, std::max<size_t>((size_t)n, 1) * sizeof(float)));
+    char *scratch = nullptr;
+    AB_TRY(sc.alloc((void **)&scratch, 3 * kMsScratch));
+    MsState *states[3];
+    for (int c = 0; c < 3; ++c) {
+        states[c] = (MsState *)(scratch + (size_t)c * kMsScratch);
+        hipLaunchKernelGGL(ms_init_kernel, dim3(4), dim3(1024), 0, ctx->stream, states[c],
+                           (unsigned int *)(scratch + (size_t)c * kMsScratch + ((sizeof(MsState) + 63) & ~(size_t)63)));
+    }
     if (n > 0) {
-        hipLaunchKernelGGL(luminance_kernel, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, in[0].dptr, in[1].dptr, in[2].dptr, n, lum);
+        hipLaunchKernelGGL(luminance_range_kernel, dim3(stream_grid(ctx, n)), dim3(kBlock), 0, ctx->stream, in[0].dptr, in[1].dptr, in[2].dptr, n, lum,
+                           states[0], states[1], states[2]);
         AB_HIP(ctx, hipGetLastError());
     }
     const ab_star_mask_config mc = mask_config_of(*cfg);
@@ -722,8 +782,6 @@ int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab_plane 
     if (shared) *shared = mi;
     // the three channels as the reference's three-way join (:175-181): one chain each, on the context's stream and its two
     // auxiliary streams, ordered after the mask by an event and joined by two more
-    char *scratch = nullptr;
-    AB_TRY(sc.alloc((void **)&scratch, 3 * kMsScratch));
     if (!ctx->aux_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
     if (!ctx->warp_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->warp_stream, hipStreamNonBlocking));
     hipStream_t streams[3] = {ctx->stream, ctx->aux_stream, ctx->warp_stream};
@@ -737,7 +795,7 @@ int ab_masked_stretch_rgb_shared(ab_ctx *ctx, const ab_plane *r, const ab_plane 
     int rc = AB_OK;
     for (int c = 0; c < 3 && rc == AB_OK; ++c) {
         if (c > 0 && hipStreamWaitEvent(streams[c], ctx->switch_ev, 0) != hipSuccess) rc = ab_set_error(ctx, AB_ERR_HIP, "hipStreamWaitEvent failed");
-        if (rc == AB_OK) rc = masked_stretch_enqueue(ctx, streams[c], in[c].dptr, mask, n, *cfg, so[c].dptr, scratch + (size_t)c * kMsScratch);
+        if (rc == AB_OK) rc = masked_stretch_enqueue(ctx, streams[c], in[c].dptr, mask, n, *cfg, so[c].dptr, scratch + (size_t)c * kMsScratch, /*have_range=*/true);
     }
     // (whatever was enqueued is drained before anything is released, also on an error path)
     for (int c = 1; c < 3; ++c)
