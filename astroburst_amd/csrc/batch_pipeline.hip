@@ -727,7 +727,11 @@ int launch_scms_np(ab_ctx *ctx, const BatchArgs &a, int64_t nchunks, uint32_t **
     BatchArgs b = a;
     retain_thresholds(&b);
     b.guess_step = getenv("AB_BATCH_GUESS") ? atoi(getenv("AB_BATCH_GUESS")) : 1;
+#ifdef AB_DEV_ABLATION  // (stage cuts for tools/time_batch.py: only in a -DAB_DEV_ABLATION build)
     b.stage = getenv("AB_BATCH_STAGE") ? atoi(getenv("AB_BATCH_STAGE")) : 0;
+#else
+    b.stage = 0;
+#endif
     b.per_block = 0;  // strided chunks; a contiguous range per wave measured the same
     b.rej = (uint32_t *)((unsigned long long *)rej + kMaxFrames);  // [0, 64) u64 totals, then the per-block u32 partials
     hipLaunchKernelGGL((scms_kernel<NP, CAL, FULL>), dim3(grid), dim3(kThreads), lds, ctx->stream, b);

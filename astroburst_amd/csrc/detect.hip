@@ -545,7 +545,9 @@ __device__ __forceinline__ double wave_max(double x) {
 constexpr int kMomKeep = 8;
 constexpr int kMomPerWave = 4;  // components per wave: their headers and first trips are in flight together
 constexpr int kMomFirst = 2;    // trips of each of them issued before anything is consumed
-__device__ int g_mom_ablate = 0;  // developer timing experiment (AB_ABLATE_MOMENTS): 1 = no box walk, 2 = no record store either
+#ifdef AB_DEV_ABLATION
+__device__ int g_mom_ablate = 0;  // developer timing experiment (AB_ABLATE_MOMENTS, -DAB_DEV_ABLATION builds only): 1 = no box walk, 2 = no record store either
+#endif
 
 struct MomGeom {  // the lane patch of one component's box
     int sh, pw, rpt, dc, dr, nrb, w;
@@ -575,7 +577,11 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
     const unsigned int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kMomPerWave;
     const int lane = threadIdx.x & 63;
     if (base >= ncomp) return;
+#ifdef AB_DEV_ABLATION
     const int ablate = g_mom_ablate;
+#else
+    constexpr int ablate = 0;
+#endif
     // member pixel's background-subtracted value, 0 for everything else (adding +0.0 changes no sum, max(pk, 0) no peak); the
     // three loads are independent: all are taken for every pixel of the box and the mask bit decides afterwards
     auto value = [&](const CompStat &s, int root, int r, int c, bool valid) -> double {
@@ -1799,10 +1805,12 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     }
     hipLaunchKernelGGL(comp_init_many_kernel, dim3((max_nc + 255) / 256, G), dim3(256), 0, ctx->stream, g);
     hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
+#ifdef AB_DEV_ABLATION
     if (getenv("AB_ABLATE_MOMENTS")) {
         const int v = atoi(getenv("AB_ABLATE_MOMENTS"));
         AB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_mom_ablate), &v, sizeof v));
     }
+#endif
     hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));

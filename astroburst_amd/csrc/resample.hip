@@ -263,6 +263,7 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
     AB_CHECK(ctx, out_rows <= 65535 && out_rows * out_cols < (int64_t(1) << 31) && src_rows * src_cols < (int64_t(1) << 31),
              "image of %lld x %lld needs a tiled launch (not in this build)", (long long)out_rows, (long long)out_cols);
     const dim3 grid((unsigned)((out_cols + 511) / 512), (unsigned)nrows), block(256);
+#ifdef AB_DEV_ABLATION  // developer timing experiments, compiled only into a -DAB_DEV_ABLATION build (profiles/r04_warp_ablation.txt)
     static const int ablate = getenv("AB_ABLATE_WARP") ? atoi(getenv("AB_ABLATE_WARP")) : 0;  // developer timing experiments
     if (ablate == 1) return AB_OK;  // what the registration stage takes without the warps
     if (ablate == 3) {              // ... and without the sixteen conversions and the address arithmetic
@@ -277,6 +278,7 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
                            t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
         return AB_OK;
     }
+#endif
     bool tame = true;  // every product and sum of the coordinate arithmetic stays finite (x, y < 2^16)
     for (int i = 0; i < 6; ++i) tame = tame && std::isfinite(t[i]) && fabs(t[i]) <= 1e150;
     if (tame)
