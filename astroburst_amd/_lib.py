@@ -352,6 +352,10 @@ def lib() -> C.CDLL:
     L.ab_register_frames_sharded.argtypes = [vp, vp, pp, pp, C.c_size_t, C.c_int, C.POINTER(AffineAlignResultC)]
     L.ab_compute_image_stats_sharded.argtypes = [vp, vp, pp, C.c_int64, C.POINTER(ImageStatsC)]
     L.ab_warp_image_rows.argtypes = [vp, pp, C.POINTER(C.c_double), C.c_int64, C.c_int64, pp]
+    L.ab_warp_image_rows_from_band.argtypes = [vp, pp, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int64, C.c_int64, pp]
+    L.ab_warp_source_rows.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p, i64p]
+    L.ab_shard_source_rows.argtypes = [C.POINTER(C.c_double), C.c_size_t, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                       i64p, i64p]
     L.ab_auto_stretch_preview.argtypes = [vp, vp, pp, C.c_int64, C.POINTER(AutoStfConfigC), vp, C.POINTER(ImageStatsC),
                                           C.POINTER(StfParamsC)]
     for name in declared_symbols():

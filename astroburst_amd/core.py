@@ -545,6 +545,30 @@ class Context:
         self._check(self._L.ab_warp_image_rows(self._h, C.byref(pi), t, out_rows, row0, C.byref(po)))
         return out_band
 
+    def warp_image_rows_from_band(self, src_band, src_row0: int, src_rows: int, transform, out_rows: int, row0: int, out_band):
+        """rows [row0, ..) of warp_image with the source given as rows [src_row0, src_row0 + len(src_band)) of a src_rows-row frame"""
+        keep = []
+        pi = self._plane(src_band, keep)
+        po = self._plane(out_band, keep)
+        t = (C.c_double * 6)(*[float(v) for v in transform])
+        self._check(self._L.ab_warp_image_rows_from_band(self._h, C.byref(pi), src_row0, src_rows, t, out_rows, row0, C.byref(po)))
+        return out_band
+
+    def warp_source_rows(self, transform, src_rows: int, src_cols: int, out_cols: int, row0: int, nrows: int):
+        """(first source row, count) that output rows [row0, row0 + nrows) of warp_image read"""
+        t = (C.c_double * 6)(*[float(v) for v in transform])
+        s0, sn = C.c_int64(), C.c_int64()
+        self._check(self._L.ab_warp_source_rows(t, src_rows, src_cols, out_cols, row0, nrows, C.byref(s0), C.byref(sn)))
+        return s0.value, sn.value
+
+    def shard_source_rows(self, transforms, src_rows: int, src_cols: int, out_rows: int, out_cols: int, nranks: int, rank: int):
+        """(first source row, count): this rank's rows of every target + the halo the transforms need"""
+        flat = [float(v) for tr in transforms for v in tr]
+        t = (C.c_double * max(len(flat), 1))(*flat)
+        s0, sn = C.c_int64(), C.c_int64()
+        self._check(self._L.ab_shard_source_rows(t, len(transforms), src_rows, src_cols, out_rows, out_cols, nranks, rank, C.byref(s0), C.byref(sn)))
+        return s0.value, sn.value
+
     def auto_stretch_preview(self, image, out=None, comm=None, total_rows: int = 0, target_bg=0.25, shadow_k=-2.8, fetch=True):
         """auto_stretch_preview (cmd/common.rs:18-22): compute_image_stats -> auto_stf -> apply_stf (u8) as one asynchronous device
         chain.  -> (u8 plane, ImageStats | None, StfParams | None); fetch=False leaves the call fully asynchronous."""

@@ -49,6 +49,8 @@ enum {
     AB_WS_SCOPE5,
     AB_WS_SCOPE6,
     AB_WS_SCOPE7,
+    AB_WS_STACK_DEEP,         // plane tables + per-workgroup sample segments of a > 4096-frame stack (stack_deep.hip)
+    AB_WS_BATCH_DEEP,         // the same for the batch stack (batch_pipeline.hip)
     AB_WS_SLOTS
 };
 
@@ -105,6 +107,9 @@ struct ab_ctx {
     int register_workers = 12;
     // AB_STACK_EXACT=1: use the direct re-summing clipping engine (cross-check of the fast one)
     bool stack_exact = false;
+    // stacks of more than this many frames take the workgroup-per-pixel kernels (stack_deep.hip / scms_deep_kernel); read from
+    // AB_STACK_DEEP_FROM / AB_BATCH_DEEP_FROM when the context is created: the tests lower them to hold those kernels to the oracle
+    int stack_deep_from = 4096, batch_deep_from = 2048;
     // HIP events recorded on ctx->stream right around the stack kernels of the last ab_stack_* call (ab_stack_last_kernel_ms)
     hipEvent_t stack_ev[2] = {nullptr, nullptr};
     bool stack_ev_valid = false;
@@ -126,6 +131,11 @@ struct ab_ctx {
     size_t aux_pinned_bytes = 0;
     // the tiles the streaming tile kernel declined (detect.hip): {count, finished blocks, tile ids ...} per stream it is launched
     // on ([0] the context's stream, [1] the auxiliary one); zeroed once, the fallback kernel leaves it zeroed
+    // detect.hip's round-4 forms, kept as cross-checks (read from AB_LABEL_LEGACY / AB_DETECT_FULL_RECORDS when the context is created,
+    // inherited by its workers): two-pass labelling instead of the tile-local union-find; every component's record instead of the
+    // device-side selection of the brightest
+    bool label_legacy = false, detect_full_records = false;
+    uint64_t det_select_fallbacks = 0;  // detect.hip: frames whose device-side selection of the brightest components had to be redone in full
     bool det_group_ws = false;  // detect.hip: the detection workspaces were last carved for a group of frames
     unsigned int *tile_fail[2] = {nullptr, nullptr};
     size_t tile_fail_cap[2] = {0, 0};
@@ -337,6 +347,9 @@ int ab_comm_stream_wait(ab_ctx *ctx, ab_comm *comm);
 int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
                          const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only);
 // 257 .. 512 contiguous frames, two lanes per pixel (stack_pair.hip); dplanes is a HOST array of n device pointers
+// more than 4096 frames (any count): one workgroup per pixel, samples in global scratch (stack_deep.hip)
+int ab_stack_deep_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
+                         const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only);
 int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg,
                          float *out_dev, bool median_only);
 

@@ -115,6 +115,10 @@ int ab_ctx_create(int device_id, ab_ctx **out) try {
     ctx->stream = ctx->own_stream;
     const char *ex = getenv("AB_STACK_EXACT");
     ctx->stack_exact = ex && ex[0] == '1';
+    ctx->label_legacy = getenv("AB_LABEL_LEGACY") != nullptr;
+    ctx->detect_full_records = getenv("AB_DETECT_FULL_RECORDS") != nullptr;
+    if (const char *e = getenv("AB_STACK_DEEP_FROM")) ctx->stack_deep_from = std::min(4096, std::max(64, atoi(e)));
+    if (const char *e = getenv("AB_BATCH_DEEP_FROM")) ctx->batch_deep_from = std::min(2048, std::max(64, atoi(e)));
     if (const char *rw = getenv("AB_REGISTER_WORKERS")) ctx->register_workers = std::max(1, atoi(rw));
     *out = ctx;
     return AB_OK;
@@ -429,6 +433,8 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
         if (ab_ctx_create(ctx->device, &wc) != AB_OK) return ab_set_error(ctx, AB_ERR_HIP, "cannot create %s worker context", what);
         wc->register_workers = 1;
         wc->parent = ctx;
+        wc->label_legacy = ctx->label_legacy;  // (the parent's choices, not the environment's at the time the pool grows)
+        wc->detect_full_records = ctx->detect_full_records;
         ctx->workers.push_back(wc);
     }
     if (drain_caller_stream) AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // whatever the caller queued on ctx (its frames, shared tables) is complete

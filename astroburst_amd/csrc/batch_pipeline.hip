@@ -23,6 +23,7 @@
 // One wave per block (16 KB LDS at n = 64, ten waves per CU), persistent blocks striding over 64-pixel chunks, so the
 // per-frame rejection counters stay in a register (lane f owns frame f) until the block retires.
 #include "ab_common.hpp"
+#include "block_sort.hpp"
 #include "wave_sort.hpp"
 
 #include <algorithm>
@@ -675,6 +676,115 @@ __global__ __launch_bounds__(256) void scms_wide_kernel(const WideBatchArgs a) {
         if (lane + 64 * k < a.n && myrej[k]) atomicAdd(&a.rej[lane + 64 * k], (unsigned long long)myrej[k]);
 }
 
+// ---- more than 2048 frames (any count): one WORKGROUP per pixel, samples in global scratch --------------------------------
+// The same definition once more (calibration_pipeline.rs:317-378) with a pixel's samples in a per-workgroup segment of three
+// arrays: U = the calibrated samples in frame order, S = sorted, D = the window's deviations sorted (block_sort.hpp).  Frames
+// past n are +inf pads above the order, NaN samples travel as +inf and are told apart by count, exactly as in scms_wide_kernel.
+// A fallback for frame counts no real set of megapixel frames reaches; bit-identical to the narrower kernels where they overlap.
+struct DeepBatchArgs {
+    WideBatchArgs w;
+    int np2;
+    float *scratch;  // gridDim.x segments of 3 * np2 floats
+};
+
+template <bool CAL>
+__global__ __launch_bounds__(256) void scms_deep_kernel(const DeepBatchArgs b) {
+    const WideBatchArgs &a = b.w;
+    __shared__ int sh_cnt[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *U = b.scratch + (size_t)blockIdx.x * 3 * b.np2, *S = U + b.np2, *D = S + b.np2;
+    for (uint32_t g = blockIdx.x; g < a.npix; g += gridDim.x) {
+        if (tid < 2) sh_cnt[tid] = 0;
+        __syncthreads();
+        CalPx c{};
+        if constexpr (CAL) c = cal_load(a.m, g);
+        int nan_here = 0;
+        for (int f = tid; f < b.np2; f += 256) {
+            float v = __builtin_inff();
+            const bool present = f < a.n;
+            if (present) {
+                v = a.p[f][g];
+                if constexpr (CAL) v = cal_apply(v, c) * a.scale[f];
+            }
+            U[f] = v;
+            const bool isn = present && v != v;
+            S[f] = isn ? __builtin_inff() : v;
+            nan_here += isn ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nan_here += __shfl_xor(nan_here, off, 64);
+        if (lane == 0 && nan_here) atomicAdd(&sh_cnt[0], nan_here);
+        __syncthreads();
+        int cnan = sh_cnt[0];
+        block_bitonic_sort(S, b.np2);
+
+        int lo = 0, hi = a.n;
+        for (int it = 0; it < a.max_iter; ++it) {  // calibration_pipeline.rs:350-367; every condition is workgroup-uniform
+            const int len = hi - lo;
+            if (len < 3) break;
+            const int k2 = len >> 1, cpos = lo + k2;
+            const float med = S[cpos];
+            if ((cnan > 0 && cpos >= a.n - cnan) || !__builtin_isfinite(med)) {  // every z is NaN: the pass empties the pixel
+                lo = hi = 0;
+                break;
+            }
+            for (int e = tid; e < b.np2; e += 256) D[e] = (e >= lo && e < hi) ? fabsf(S[e] - med) : __builtin_inff();
+            block_bitonic_sort(D, b.np2);
+            float mad = D[k2];
+            if (cnan > 0 && k2 >= len - cnan) mad = __builtin_nanf("");  // the rank falls among the NaN deviations
+            const float sigma = (float)((double)mad * kMadToSigma);
+            if (sigma < 1e-10f) break;
+            const float nsl = -a.sigma_low, sh = a.sigma_high;
+            __syncthreads();
+            if (tid < 2) sh_cnt[tid] = 0;
+            __syncthreads();
+            int drop_lo = 0, drop_hi = 0;
+            for (int e = lo + tid; e < hi; e += 256) {
+                const float sv = S[e];
+                const float z = (sv - med) / sigma;
+                const bool keep = z > nsl && z < sh;
+                const bool low_side = sv < med;
+                drop_lo += (!keep && low_side) ? 1 : 0;
+                drop_hi += (!keep && !low_side) ? 1 : 0;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                drop_lo += __shfl_xor(drop_lo, off, 64);
+                drop_hi += __shfl_xor(drop_hi, off, 64);
+            }
+            if (lane == 0) {
+                if (drop_lo) atomicAdd(&sh_cnt[0], drop_lo);
+                if (drop_hi) atomicAdd(&sh_cnt[1], drop_hi);
+            }
+            __syncthreads();
+            drop_lo = sh_cnt[0];
+            drop_hi = sh_cnt[1];
+            cnan = 0;  // a retain pass never keeps a NaN
+            if (drop_lo == 0 && drop_hi == 0) break;
+            lo += drop_lo;
+            hi -= drop_hi;
+            if (hi < lo) hi = lo;
+        }
+
+        const int len = hi - lo;
+        const bool all = lo == 0 && hi == a.n;
+        const float lov = len > 0 ? S[lo] : __builtin_inff(), hiv = len > 0 ? S[hi - 1] : -__builtin_inff();
+        __syncthreads();  // (D is rewritten below: everybody is past its last read of it)
+        for (int f = tid; f < a.n; f += 256) {  // D <- the kept samples in frame order, 0 where rejected
+            const float u = U[f];
+            const bool keep = all || (u >= lov && u <= hiv);
+            D[f] = keep ? u : 0.0f;
+            if (!keep) atomicAdd(&a.rej[f], 1ull);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const float sum = wave_serial_sum_f32(D, 0, a.n - 1, lane);
+            if (lane == 0) a.out[g] = len == 0 ? 0.0f : sum / (float)len;
+        }
+        __syncthreads();  // the next pixel reuses the segment and the shared words
+    }
+}
+
 // f64 sum of the calibrated samples of ONE frame per blockIdx.y (deep stacks only: the masters are re-read per frame)
 __global__ __launch_bounds__(kSumBlock) void cal_frame_sum_kernel(const float *const *__restrict__ p, Masters m, uint32_t npix, double *__restrict__ part) {
     const float *frame = p[blockIdx.y];
@@ -826,7 +936,7 @@ ab_batch_stack_config config_or_default(const ab_batch_stack_config *cfg) {
     return c;
 }
 
-// 65 .. 512 frames: tables in a workspace, one wave per pixel
+// 65 .. 2048 frames: tables in a workspace, one wave per pixel; beyond (or above AB_BATCH_DEEP_FROM): one workgroup per pixel
 int stack_wide_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix, const Masters &m, bool cal, const ab_batch_stack_config &cfg,
                       float *out, uint64_t *rejection_counts) {
     char *ws = nullptr;
@@ -865,15 +975,30 @@ int stack_wide_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t
     a.max_iter = (int)std::min<uint64_t>(cfg.max_iterations, 1u << 20);
     a.out = out;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((npix + 3) / 4, (int64_t)cu_of(ctx) * 8));
-    const int kk = n <= 128 ? 2 : (n <= 256 ? 4 : 8);
-    if (cal) {
-        if (kk == 2) hipLaunchKernelGGL((scms_wide_kernel<2, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else if (kk == 4) hipLaunchKernelGGL((scms_wide_kernel<4, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((scms_wide_kernel<8, true>), dim3(grid), dim3(256), 0, ctx->stream, a);
+    if (n > (size_t)ctx->batch_deep_from) {
+        DeepBatchArgs d;
+        d.w = a;
+        d.np2 = 2;
+        while ((size_t)d.np2 < n) d.np2 <<= 1;
+        const int64_t seg_bytes = (int64_t)3 * d.np2 * (int64_t)sizeof(float);
+        int64_t dgrid = std::min<int64_t>(npix, (int64_t)cu_of(ctx) * 4);
+        dgrid = std::max<int64_t>(1, std::min<int64_t>(dgrid, ((int64_t)1 << 30) / seg_bytes));
+        AB_TRY(ab_workspace(ctx, AB_WS_BATCH_DEEP, (size_t)dgrid * (size_t)seg_bytes, (void **)&d.scratch));
+        if (cal) hipLaunchKernelGGL((scms_deep_kernel<true>), dim3((unsigned)dgrid), dim3(256), 0, ctx->stream, d);
+        else hipLaunchKernelGGL((scms_deep_kernel<false>), dim3((unsigned)dgrid), dim3(256), 0, ctx->stream, d);
     } else {
-        if (kk == 2) hipLaunchKernelGGL((scms_wide_kernel<2, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else if (kk == 4) hipLaunchKernelGGL((scms_wide_kernel<4, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((scms_wide_kernel<8, false>), dim3(grid), dim3(256), 0, ctx->stream, a);
+        const int kk = n <= 128 ? 2 : (n <= 256 ? 4 : (n <= 512 ? 8 : (n <= 1024 ? 16 : 32)));
+#define AB_SCMS_WIDE(K)                                                                                             \
+    do {                                                                                                            \
+        if (cal) hipLaunchKernelGGL((scms_wide_kernel<K, true>), dim3(grid), dim3(256), 0, ctx->stream, a);         \
+        else hipLaunchKernelGGL((scms_wide_kernel<K, false>), dim3(grid), dim3(256), 0, ctx->stream, a);            \
+    } while (0)
+        if (kk == 2) AB_SCMS_WIDE(2);
+        else if (kk == 4) AB_SCMS_WIDE(4);
+        else if (kk == 8) AB_SCMS_WIDE(8);
+        else if (kk == 16) AB_SCMS_WIDE(16);
+        else AB_SCMS_WIDE(32);
+#undef AB_SCMS_WIDE
     }
     AB_HIP(ctx, hipGetLastError());
     std::vector<unsigned long long> host(n);
@@ -886,7 +1011,7 @@ int stack_wide_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t
 // the device-resident body shared by ab_sigma_clipped_mean_stack (cal == false) and ab_run_batch_channel
 int stack_device(ab_ctx *ctx, const float *const *frames, size_t n, int64_t npix, const Masters &m, bool cal, const ab_batch_stack_config &cfg,
                  float *out, uint64_t *rejection_counts) {
-    AB_CHECK(ctx, n >= 1 && n <= 512, "sigma_clipped_mean_stack: %zu frames (this build stacks 1..512)", n);
+    AB_CHECK(ctx, n >= 1 && n <= ((size_t)1 << 24), "sigma_clipped_mean_stack: %zu frames (1 .. 2^24 per call)", n);
     AB_CHECK(ctx, npix > 0 && npix < ((int64_t)1 << 30), "sigma_clipped_mean_stack: planes of 1 .. 2^30 - 1 pixels");
     AB_HIP(ctx, hipSetDevice(ctx->device));
     if (n > (size_t)kMaxFrames) return stack_wide_device(ctx, frames, n, npix, m, cal, cfg, out, rejection_counts);

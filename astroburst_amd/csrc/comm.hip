@@ -129,6 +129,9 @@ struct HostShm {  // lives at the start of the segment; lock-free atomics on pla
     std::atomic<uint32_t> generation;
     int32_t status[64];             // ab_comm_agree: one word per rank
     int32_t owner_pid;              // rank 0's process: a segment whose owner is gone is a dead job's, not this one's
+    uint64_t owner_start;           // that process's start time (/proc/<pid>/stat field 22, clock ticks since boot; 0 = unknown):
+                                    // a recycled pid has another start time, so a dead job's segment cannot pass for a live one
+    uint64_t owner_pidns;           // inode of rank 0's /proc/self/ns/pid: the pid test only means something inside one namespace
 };
 constexpr uint32_t kShmMagic = 0x41424d43u;  // "ABMC"
 constexpr size_t kShmHeader = 4096;
@@ -137,6 +140,48 @@ int64_t now_ms() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (int64_t)ts.tv_sec * 1000 + ts.tv_nsec / 1000000;
+}
+
+// start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat; the command name in field 2 may hold
+// blanks and parentheses, so fields are counted from the LAST ')'); 0 when it cannot be read
+uint64_t proc_start_time(pid_t pid) {
+    char path[64], buf[1024];
+    snprintf(path, sizeof path, "/proc/%d/stat", (int)pid);
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return 0;
+    const ssize_t n = read(fd, buf, sizeof buf - 1);
+    close(fd);
+    if (n <= 0) return 0;
+    buf[n] = 0;
+    const char *p = strrchr(buf, ')');
+    if (!p) return 0;
+    ++p;
+    for (int field = 3; field <= 22; ++field) {  // p sits on the blank before field `field`
+        while (*p == ' ') ++p;
+        if (field == 22) return strtoull(p, nullptr, 10);
+        while (*p && *p != ' ') ++p;
+        if (!*p) return 0;
+    }
+    return 0;
+}
+
+uint64_t own_pidns() {
+    struct stat st;
+    return stat("/proc/self/ns/pid", &st) == 0 ? (uint64_t)st.st_ino : 0;
+}
+
+// Is the segment's owner (its rank 0) gone?  Only answerable inside the owner's pid namespace: ranks in separate containers
+// that share /dev/shm see each other's pids as nonexistent, so across namespaces the answer is "cannot tell" = alive, and a dead
+// job's segment is then caught by the join time-out instead (AB_COMM_HOST_PIDCHECK=0 forces that behaviour everywhere).
+bool owner_is_dead(const HostShm *h) {
+    static const bool check = [] { const char *e = getenv("AB_COMM_HOST_PIDCHECK"); return !(e && *e == '0'); }();
+    if (!check) return false;
+    if (h->owner_pid <= 0) return true;
+    const uint64_t ns = own_pidns();
+    if (h->owner_pidns && ns && h->owner_pidns != ns) return false;
+    if (kill((pid_t)h->owner_pid, 0) != 0 && errno == ESRCH) return true;
+    const uint64_t st = proc_start_time((pid_t)h->owner_pid);
+    return h->owner_start && st && st != h->owner_start;  // the pid lives on in another process
 }
 
 int64_t default_timeout_ms() {
@@ -409,77 +454,91 @@ int ab_comm_init_rank_host(ab_ctx *ctx, const char *name, int nranks, int rank, 
     c->timeout_ms = default_timeout_ms();
     c->shm_name = std::string("/abcomm_") + name;
     c->shm_bytes = bytes;
-    const int64_t t0 = now_ms();
-    int fd = -1;
-    if (rank == 0) {
-        shm_unlink(c->shm_name.c_str());  // a stale segment of a crashed job
-        fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
-            if (fd >= 0) close(fd);
-            const std::string nm = c->shm_name;
+    const int64_t t0 = now_ms();  // ONE clock for the whole call, whatever is found and dropped on the way
+    void *m = nullptr;
+    HostShm *h = nullptr;
+    for (;;) {  // one pass = open, map, validate; a pass that finds a dead job's segment drops it and looks again
+        int fd = -1;
+        if (rank == 0) {
+            shm_unlink(c->shm_name.c_str());  // a stale segment of a crashed job
+            fd = shm_open(c->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+            if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) {
+                if (fd >= 0) close(fd);
+                const std::string nm = c->shm_name;
+                c->shm_name.clear();
+                delete c;
+                return ab_set_error(ctx, AB_ERR_COMM, "cannot create the shared segment %s (%zu bytes): %s", nm.c_str(), bytes, strerror(errno));
+            }
+        } else {
+            for (;;) {  // the segment appears when rank 0 gets here; its size is final once ftruncate has run
+                fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
+                struct stat st;
+                if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
+                if (fd >= 0) close(fd);
+                fd = -1;
+                if (now_ms() - t0 > c->timeout_ms) {
+                    const std::string nm = c->shm_name;
+                    delete c;
+                    return ab_set_error(ctx, AB_ERR_COMM, "rank %d: no segment %s after %lld ms (rank 0 never started?)", rank, nm.c_str(), (long long)(now_ms() - t0));
+                }
+                timespec ts = {0, 2000000};
+                nanosleep(&ts, nullptr);
+            }
+        }
+        m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) {
+            if (rank == 0) shm_unlink(c->shm_name.c_str());
             c->shm_name.clear();
             delete c;
-            return ab_set_error(ctx, AB_ERR_COMM, "cannot create the shared segment %s (%zu bytes): %s", nm.c_str(), bytes, strerror(errno));
+            return ab_set_error(ctx, AB_ERR_COMM, "mmap of the shared segment failed: %s", strerror(errno));
         }
-    } else {
-        for (;;) {  // the segment appears when rank 0 gets here; its size is final once ftruncate has run
-            fd = shm_open(c->shm_name.c_str(), O_RDWR, 0600);
-            struct stat st;
-            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= bytes) break;
-            if (fd >= 0) close(fd);
-            fd = -1;
-            if (now_ms() - t0 > c->timeout_ms) {
-                const std::string nm = c->shm_name;
-                delete c;
-                return ab_set_error(ctx, AB_ERR_COMM, "rank %d: no segment %s after %lld ms (rank 0 never started?)", rank, nm.c_str(), (long long)(now_ms() - t0));
-            }
-            timespec ts = {0, 2000000};
-            nanosleep(&ts, nullptr);
+        c->shm = (HostShm *)m;
+        h = c->shm;
+        if (rank == 0) {  // a fresh segment is zero-filled
+            h->nranks = nranks;
+            h->slot_bytes = slot;
+            h->owner_pid = (int32_t)getpid();
+            h->owner_start = proc_start_time(getpid());
+            h->owner_pidns = own_pidns();
+            h->magic.store(kShmMagic, std::memory_order_release);
+            break;
         }
-    }
-    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) {
-        if (rank == 0) shm_unlink(c->shm_name.c_str());
-        c->shm_name.clear();
-        delete c;
-        return ab_set_error(ctx, AB_ERR_COMM, "mmap of the shared segment failed: %s", strerror(errno));
-    }
-    c->shm = (HostShm *)m;
-    HostShm *h = c->shm;
-    if (rank == 0) {  // a fresh segment is zero-filled
-        h->nranks = nranks;
-        h->slot_bytes = slot;
-        h->owner_pid = (int32_t)getpid();
-        h->magic.store(kShmMagic, std::memory_order_release);
-    } else {
+        bool initialised = true;
         while (h->magic.load(std::memory_order_acquire) != kShmMagic) {
             if (now_ms() - t0 > c->timeout_ms) {
-                host_detach(c);
-                delete c;
-                return ab_set_error(ctx, AB_ERR_COMM, "rank %d: the shared segment was never initialised", rank);
+                initialised = false;
+                break;
             }
             sched_yield();
         }
+        if (!initialised) {
+            host_detach(c);
+            delete c;
+            return ab_set_error(ctx, AB_ERR_COMM, "rank %d: the shared segment was never initialised", rank);
+        }
         // A segment of this name whose rank 0 no longer exists was left by a job that died (before all its ranks had joined, or it
-        // would have been unlinked).  This job's rank 0 has not got to replacing it yet: leave it and look again.  (Joining it --
-        // its `joined` count may even make the communicator look complete -- would put this rank in a different segment from its
-        // own rank 0 for good.)
-        if (h->owner_pid <= 0 || (kill((pid_t)h->owner_pid, 0) != 0 && errno == ESRCH)) {
-            host_detach(c);
+        // would have been unlinked).  This job's rank 0 has not got to replacing it yet: drop the mapping and look again, on the
+        // same clock.  (Joining it -- its `joined` count may even make the communicator look complete -- would put this rank in a
+        // different segment from its own rank 0 for good.)
+        if (!owner_is_dead(h)) break;
+        munmap(m, bytes);
+        c->shm = nullptr;
+        m = nullptr;
+        if (now_ms() - t0 > c->timeout_ms) {
+            const std::string nm = c->shm_name;
             delete c;
-            if (now_ms() - t0 > default_timeout_ms())
-                return ab_set_error(ctx, AB_ERR_COMM, "rank %d: only a dead job's segment %s%s to join", rank, "/dev/shm/abcomm_", name);
-            timespec ts = {0, 5000000};
-            nanosleep(&ts, nullptr);
-            return ab_comm_init_rank_host(ctx, name, nranks, rank, out);
+            return ab_set_error(ctx, AB_ERR_COMM, "rank %d: only a dead job's segment %s to join after %lld ms (this job's rank 0 never started?)",
+                                rank, nm.c_str(), (long long)(now_ms() - t0));
         }
-        if (h->nranks != nranks || h->slot_bytes != slot) {
-            const int hn = h->nranks;
-            host_detach(c);
-            delete c;
-            return ab_set_error(ctx, AB_ERR_COMM, "rank %d joined a communicator of %d ranks as one of %d (or with another AB_COMM_HOST_SLOT_MB)", rank, hn, nranks);
-        }
+        timespec ts = {0, 5000000};
+        nanosleep(&ts, nullptr);
+    }
+    if (rank != 0 && (h->nranks != nranks || h->slot_bytes != slot)) {
+        const int hn = h->nranks;
+        host_detach(c);
+        delete c;
+        return ab_set_error(ctx, AB_ERR_COMM, "rank %d joined a communicator of %d ranks as one of %d (or with another AB_COMM_HOST_SLOT_MB)", rank, hn, nranks);
     }
     c->shm_registered = hipHostRegister(m, bytes, hipHostRegisterDefault) == hipSuccess;
     if (!c->shm_registered) (void)hipGetLastError();  // pageable copies still work (staged by the runtime)

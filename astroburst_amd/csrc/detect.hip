@@ -416,10 +416,166 @@ __device__ __forceinline__ void label_merge_body(int rows, int cols, int *parent
     }
 }
 
+// ---- threshold + TILE-LOCAL union-find in LDS (round 5) ----------------------------------------------------------
+// label_init + label_merge as above are two passes over global memory: the threshold pass writes parent = self, the merge pass then
+// walks the list and hooks roots with global atomics -- 170 000 labelled pixels of a 4096^2 frame, every union a chain of dependent
+// L2 round trips (16 us per frame alone, 110 us per group inside a batch).  Stars are a few pixels wide, so almost every union joins
+// two pixels of one small neighbourhood.  Here a 256-thread workgroup owns a tile of 32 rows x 128 columns: it thresholds its 4096
+// pixels (one 16-byte load x 4 per thread), keeps the tile's mask bits and a label per pixel in LDS, runs the SAME union-find
+// (atomicMin hooking: the root is the smallest raster index) on the LDS labels over the forward half of the 8-neighbourhood
+// (star_detection.rs:120) inside the tile, and writes for every labelled pixel parent = the global index of its tile-local root.
+// Only pixels on the tile's last row, first and last column can have forward neighbours in another tile: they go on a BORDER list
+// (~8 % of the labelled pixels) and label_border_kernel does their cross-tile unions on the global forest.  The forest that
+// results has the same roots as before (a component's minimum raster index), so everything downstream is unchanged.
+// Needs contiguous planes whose width is a multiple of 32 (mask words then never straddle a tile); other planes keep the two-pass form.
+constexpr int kTileH = 32, kTileW = 128, kTileThreads = 256;
+__device__ __forceinline__ int lds_find(int *lab, int x) {
+    while (true) {
+        const int p = __hip_atomic_load(&lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (p == x) return x;
+        x = p;
+    }
+}
+__device__ __forceinline__ void lds_union(int *lab, int a, int b) {
+    while (true) {
+        a = lds_find(lab, a);
+        b = lds_find(lab, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(&lab[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+__device__ __forceinline__ void label_tile_body(const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
+                                                int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist, unsigned int *nlab,
+                                                int *__restrict__ blist, unsigned int *nborder) {
+    __shared__ unsigned int tmask[kTileH][kTileW / 32];
+    __shared__ int lab[kTileH * kTileW];
+    __shared__ unsigned int n_found, n_edge, base_found, base_edge;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tiles_x = (cols + kTileW - 1) / kTileW;
+    const int ty0 = (int)(blockIdx.x / tiles_x) * kTileH, tx0 = (int)(blockIdx.x % tiles_x) * kTileW;
+    const int q = tid & 31, r0 = tid >> 5;  // this thread: columns 4 q .. 4 q + 3 of rows r0, r0 + 8, r0 + 16, r0 + 24
+    if (tid == 0) n_found = n_edge = 0;
+    unsigned int bits = 0;  // bit 4 j + k: pixel (r0 + 8 j, 4 q + k)
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
+        v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (r < rows && c < cols) v[j] = *reinterpret_cast<const float4 *>(img + (int64_t)r * cols + c);  // (cols % 4 == 0: the quad is inside)
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
+        const bool in = r < rows && c < cols;
+        const unsigned int b = (unsigned int)(in && above(ab_px(xf, v[j].x), threshold)) | ((unsigned int)(in && above(ab_px(xf, v[j].y), threshold)) << 1) |
+                               ((unsigned int)(in && above(ab_px(xf, v[j].z), threshold)) << 2) | ((unsigned int)(in && above(ab_px(xf, v[j].w), threshold)) << 3);
+        bits |= b << (4 * j);
+        unsigned int w = b << (4 * (lane & 7));  // eight lanes make one mask word
+        w |= __shfl_xor(w, 1, 64);
+        w |= __shfl_xor(w, 2, 64);
+        w |= __shfl_xor(w, 4, 64);
+        if ((lane & 7) == 0) {
+            tmask[r0 + 8 * j][q >> 3] = w;
+            if (in) mask[((int64_t)r * cols + c) >> 5] = w;  // (cols % 32 == 0 and tx0 % 32 == 0: a whole word of this row)
+        }
+    }
+    // labels: own local index where labelled
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((bits >> (4 * j + k)) & 1u) {
+                const int li = (r0 + 8 * j) * kTileW + 4 * q + k;
+                lab[li] = li;
+            }
+    __syncthreads();
+    auto lbl = [&](int r, int c) -> bool { return (tmask[r][c >> 5] >> (c & 31)) & 1u; };
+    // unions inside the tile, forward half of the 8-neighbourhood: E, SW, S, SE
+    unsigned int todo = bits;
+    while (todo) {
+        const int bpos = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
+        if (c + 1 < kTileW && lbl(r, c + 1)) lds_union(lab, li, li + 1);
+        if (r + 1 < kTileH) {
+            const int d = li + kTileW;
+            if (c > 0 && lbl(r + 1, c - 1)) lds_union(lab, li, d - 1);
+            if (lbl(r + 1, c)) lds_union(lab, li, d);
+            if (c + 1 < kTileW && lbl(r + 1, c + 1)) lds_union(lab, li, d + 1);
+        }
+    }
+    __syncthreads();
+    // flatten -> global forest; list + border list positions (one LDS atomic per thread, one global atomic per workgroup)
+    const int cnt = __builtin_popcount(bits);
+    unsigned int edge_bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + 8 * j, c = 4 * q + k;
+            const bool on_edge = r == kTileH - 1 || c == 0 || c == kTileW - 1;
+            if (((bits >> (4 * j + k)) & 1u) && on_edge) edge_bits |= 1u << (4 * j + k);
+        }
+    const int ecnt = __builtin_popcount(edge_bits);
+    unsigned int at = 0, eat = 0;
+    if (cnt) at = atomicAdd(&n_found, (unsigned int)cnt);
+    if (ecnt) eat = atomicAdd(&n_edge, (unsigned int)ecnt);
+    __syncthreads();
+    if (tid == 0) {
+        base_found = n_found ? atomicAdd(nlab, n_found) : 0u;
+        base_edge = n_edge ? atomicAdd(nborder, n_edge) : 0u;
+    }
+    __syncthreads();
+    at += base_found;
+    eat += base_edge;
+    todo = bits;
+    while (todo) {
+        const int bpos = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
+        const int root = lds_find(lab, li);
+        const int gi = (ty0 + r) * cols + tx0 + c, groot = (ty0 + (root >> 7)) * cols + tx0 + (root & (kTileW - 1));
+        parent[gi] = groot;
+        plist[at++] = gi;
+        if ((edge_bits >> bpos) & 1u) blist[eat++] = gi;
+    }
+}
+
+// cross-tile unions of the border pixels (the forward neighbours that lie in another tile), on the global forest
+__device__ __forceinline__ void label_border_body(int rows, int cols, int *parent, const unsigned int *__restrict__ mask, const int *__restrict__ blist,
+                                                  const unsigned int *__restrict__ nborder) {
+    const unsigned int n = *nborder;
+    for (unsigned int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+        const int i = blist[k];
+        const int r = i / cols, c = i - r * cols;
+        const int tr = r / kTileH, tc = c / kTileW;
+        auto other = [&](int rr, int cc) { return rr / kTileH != tr || cc / kTileW != tc; };
+        if (c + 1 < cols && other(r, c + 1) && labelled(mask, i + 1)) uf_union(parent, i, i + 1);
+        if (r + 1 < rows) {
+            const int d = i + cols;
+            if (c > 0 && other(r + 1, c - 1) && labelled(mask, d - 1)) uf_union(parent, i, d - 1);
+            if (other(r + 1, c) && labelled(mask, d)) uf_union(parent, i, d);
+            if (c + 1 < cols && other(r + 1, c + 1) && labelled(mask, d + 1)) uf_union(parent, i, d + 1);
+        }
+    }
+}
+
 // ---- per-component statistics and moments -------------------------------------------------------------
 struct CompStat {  // filled by atomics (order-independent integers)
     int npix, x0, x1, y0, y1, first_interior;
+    // group path only (comp_stats_body<true>): sum of max(v - background, 0) over the member pixels, added by f64 atomics in whatever
+    // order the waves arrive.  It only RANKS components (comp_select_kernel); every number a star is made of is recomputed by
+    // comp_moments' fixed butterfly.  (For normalised pixels the sum is exact in f64, hence the same in any order: DESIGN 4.3.)
+    double flux;
 };
+static_assert(sizeof(CompStat) == 32, "CompStat layout");
 
 struct CompRec {  // what the host needs to finish one star (star_detection.rs:147-213)
     int first_interior, npix;
@@ -467,12 +623,15 @@ __device__ __forceinline__ void roots_body(const int *__restrict__ parent, const
 
 __device__ __forceinline__ void comp_init_body(CompStat *st, unsigned int n) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) st[i] = CompStat{0, 0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff};
+    if (i < n) st[i] = CompStat{0, 0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff, 0.0};
 }
 
 // flatten the forest and gather size / bounding box / first interior pixel of every component
+template <bool FLUX>
 __device__ __forceinline__ void comp_stats_body(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st,
-                                                         const int *__restrict__ plist, const unsigned int *__restrict__ nlab) {
+                                                         const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
+                                                         const float *__restrict__ img = nullptr, int64_t ld = 0, const ab_pixel_xf xf = ab_pixel_xf(),
+                                                         double bg_median = 0.0) {
     const unsigned int n = *nlab;
     const int lane = threadIdx.x & 63;
     // wave-uniform trip count (the shuffles below need every lane); consecutive list entries are mostly row neighbours
@@ -490,6 +649,8 @@ __device__ __forceinline__ void comp_stats_body(int rows, int cols, int *parent,
         const int r = i / cols, c = i - r * cols;
         const bool interior = r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1;  // BFS seeds are interior (:107-110)
         int npix = 1, x0 = c, x1 = c, y0 = r, y1 = r, fi = interior ? i : 0x7fffffff;
+        double fl = 0.0;
+        if constexpr (FLUX) fl = valid ? fmax((double)ab_px(xf, img[(int64_t)r * ld + c]) - bg_median, 0.0) : 0.0;
         const int prev = __shfl_up(root, 1, 64);
         const bool head = lane == 0 || prev != root;
         // run length to the right of every lane, by doubling: a lane folds in its right neighbour block only while that
@@ -500,6 +661,8 @@ __device__ __forceinline__ void comp_stats_body(int rows, int cols, int *parent,
         for (int d = 1; d < 64; d <<= 1) {
             const int o_run = __shfl_down(run, d, 64), o_n = __shfl_down(npix, d, 64), o_x0 = __shfl_down(x0, d, 64), o_x1 = __shfl_down(x1, d, 64),
                       o_y0 = __shfl_down(y0, d, 64), o_y1 = __shfl_down(y1, d, 64), o_fi = __shfl_down(fi, d, 64);
+            double o_fl = 0.0;
+            if constexpr (FLUX) o_fl = __shfl_down(fl, d, 64);
             if (lane + d < 64 && o_run == run) {
                 npix += o_n;
                 x0 = min(x0, o_x0);
@@ -507,6 +670,7 @@ __device__ __forceinline__ void comp_stats_body(int rows, int cols, int *parent,
                 y0 = min(y0, o_y0);
                 y1 = max(y1, o_y1);
                 fi = min(fi, o_fi);
+                if constexpr (FLUX) fl += o_fl;
             }
         }
         if (valid && head) {
@@ -517,6 +681,8 @@ __device__ __forceinline__ void comp_stats_body(int rows, int cols, int *parent,
             atomicMin(&s->y0, y0);
             atomicMax(&s->y1, y1);
             if (fi != 0x7fffffff) atomicMin(&s->first_interior, fi);
+            if constexpr (FLUX)
+                if (fl > 0.0) unsafeAtomicAdd(&s->flux, fl);  // (global_atomic_add_f64; HBM is fine-grained enough for this: plain hipMalloc memory)
         }
     }
 }
@@ -571,11 +737,15 @@ __device__ __forceinline__ MomGeom mom_geom(const CompStat &s, int lane, bool li
 __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
                                                            double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
-                                                           const FrameDev *__restrict__ fd) {
+                                                           const FrameDev *__restrict__ fd, const unsigned int *__restrict__ sel = nullptr,
+                                                           const unsigned int *__restrict__ nsel = nullptr) {
     const double bg_median = fd ? fd->bg_median : bg_median_arg;
     const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
     const unsigned int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kMomPerWave;
     const int lane = threadIdx.x & 63;
+    // with a selection (comp_select_many_kernel) the wave's components are sel[base ..] of the *nsel selected ones and their
+    // records are written densely in selection order; without, components base .. of all ncomp
+    if (sel) ncomp = *nsel;
     if (base >= ncomp) return;
 #ifdef AB_DEV_ABLATION
     const int ablate = g_mom_ablate;
@@ -599,8 +769,9 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
 #pragma unroll
     for (int j = 0; j < kMomPerWave; ++j) {  // headers: independent loads
         const bool live = base + j < ncomp;
-        S[j] = st[live ? base + j : base];
-        root[j] = roots[live ? base + j : base];
+        const unsigned int ci = sel ? sel[live ? base + j : base] : (live ? base + j : base);
+        S[j] = st[ci];
+        root[j] = roots[ci];
     }
 #pragma unroll
     for (int j = 0; j < kMomPerWave; ++j) {  // the first kMomFirst trips of every small box together: 24 loads in flight (a 9 x 9 star
@@ -772,7 +943,139 @@ struct DetGroup {
     CompStat *st[kGroupMax];
     CompRec *rec[kGroupMax];
     unsigned int ncomp[kGroupMax];
+    int *blist[kGroupMax];            // border pixels of the tile-local labelling (label_tile_many_kernel); counters[f][3] = their number
+    unsigned int *sel[kGroupMax];     // indices of the selected components (comp_select_many_kernel), kSelCap each
+    unsigned int *selout[kGroupMax];  // PINNED HOST: {selected, candidates} of the frame
 };
+
+// ---- the brightest few hundred, chosen on the device ----------------------------------------------------------
+// The matcher takes the first 120 stars of the flux-ordered, 3 px-deduplicated list (affine.rs:272-277 after star_detection.rs:
+// 215-248); a 4096^2 frame has ~10 000 components.  finish_stars already orders only the brightest 4 x 120 candidates first because
+// the dedup never compares a star with a fainter one; this kernel makes the same cut BEFORE the box walks and the records: one
+// workgroup per frame finds the kSelKeep-th largest approximate flux (CompStat::flux) among the components that can become stars
+// (size, interior seed, positive flux: star_detection.rs:142-152) by an 11 / 11 / 10-bit radix select on the high word of the f64,
+// and lists every component at or above it.  comp_moments then walks kSelKeep boxes instead of ten thousand and 35 KB of records
+// cross PCIe instead of 750 KB per frame.  The host finishes those exactly as before; if the dedup eats them all before 120
+// survive and more candidates exist (crowded or degenerate fields), it re-runs the frame through the full path: same result always.
+constexpr unsigned int kSelKeep = 480, kSelCap = 544;
+__device__ __forceinline__ unsigned int sel_key(const CompStat &c) {  // 0 = cannot become a star; larger flux -> larger key
+    const bool ok = c.npix >= 3 && c.npix <= 5000 && c.first_interior != 0x7fffffff && c.flux > 0.0;
+    return ok ? (unsigned int)((unsigned long long)__double_as_longlong(c.flux) >> 32) + 1u : 0u;
+}
+// one LDS atomic per DISTINCT bin of a wave (the faint crowd shares its exponent: ten thousand same-address atomics otherwise)
+__device__ __forceinline__ void hist_add_matched(unsigned int *hist, unsigned int bin, bool active) {
+    unsigned long long todo = __ballot(active);
+    while (todo) {  // wave-uniform
+        const int leader = __builtin_ctzll(todo);
+        const unsigned int b = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
+        const unsigned long long same = __ballot(active && bin == b) & todo;
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (unsigned int)__builtin_popcountll(same));
+        todo &= ~same;
+    }
+}
+__global__ __launch_bounds__(1024) void comp_select_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const unsigned int n = g.ncomp[f];
+    const CompStat *__restrict__ st = g.st[f];
+    unsigned int *__restrict__ sel = g.sel[f];
+    __shared__ unsigned int hist[2048];
+    __shared__ unsigned int s_prefix, s_mask, s_want, s_ncand, s_ge, s_gt, s_count;
+    if (tid == 0) {
+        s_prefix = 0;
+        s_mask = 0;
+        s_want = kSelKeep;
+        s_ncand = s_ge = s_gt = s_count = 0;
+    }
+    unsigned int thr = 1;  // select every candidate unless there are more than kSelKeep
+    // ---- candidates ----
+    {
+        unsigned int mine = 0;
+        for (unsigned int i = tid; i < n; i += 1024) mine += sel_key(st[i]) ? 1u : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        if ((tid & 63) == 0 && mine) atomicAdd(&s_ncand, mine);
+        __syncthreads();
+    }
+    const unsigned int ncand = s_ncand;
+    if (ncand > kSelKeep) {  // block-uniform
+        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+#pragma unroll
+        for (int lv = 0; lv < 3; ++lv) {
+            const unsigned int nb = 1u << bits[lv];
+            for (unsigned int b = tid; b < nb; b += 1024) hist[b] = 0;
+            __syncthreads();
+            const unsigned int prefix = s_prefix, mask = s_mask;
+            for (unsigned int i0 = 0; i0 < n; i0 += 1024) {  // block-uniform trip count: the ballots need whole waves
+                const unsigned int i = i0 + tid;
+                const unsigned int k = i < n ? sel_key(st[i]) : 0u;
+                hist_add_matched(hist, (k >> shifts[lv]) & (nb - 1), k && (k & mask) == prefix);
+            }
+            __syncthreads();
+            if (tid < 64) {  // one wave walks the digits from the top: the digit that holds the `want`-th largest key
+                unsigned int want = s_want, run = 0, found = 0;
+                bool done = false;
+                for (int base = (int)nb - 64; base >= 0 && !done; base -= 64) {
+                    const unsigned int c = hist[base + 63 - tid];  // lane 0 = the highest digit of the chunk
+                    unsigned int incl = c;                          // inclusive prefix over lanes 0 .. tid
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const unsigned int o = __shfl_up(incl, off, 64);
+                        if (tid >= off) incl += o;
+                    }
+                    const unsigned long long hit = __ballot(run + incl >= want);
+                    if (hit) {
+                        const int l = __builtin_ctzll(hit);
+                        const unsigned int before = run + __shfl(incl, l, 64) - __shfl(c, l, 64);
+                        found = (unsigned int)(base + 63 - l);
+                        want -= before;
+                        done = true;
+                    } else {
+                        run += __shfl(incl, 63, 64);
+                    }
+                }
+                if (tid == 0) {
+                    s_prefix = prefix | (found << shifts[lv]);
+                    s_mask = mask | ((nb - 1) << shifts[lv]);
+                    s_want = want;
+                }
+            }
+            __syncthreads();
+        }
+        thr = s_prefix;
+        unsigned int ge = 0, gt = 0;
+        for (unsigned int i = tid; i < n; i += 1024) {
+            const unsigned int k = sel_key(st[i]);
+            ge += k >= thr ? 1u : 0u;
+            gt += k > thr ? 1u : 0u;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            ge += __shfl_xor(ge, off, 64);
+            gt += __shfl_xor(gt, off, 64);
+        }
+        if ((tid & 63) == 0) {
+            if (ge) atomicAdd(&s_ge, ge);
+            if (gt) atomicAdd(&s_gt, gt);
+        }
+        __syncthreads();
+        if (s_ge > kSelCap) thr += 1;  // a crowd of equal keys at the cut: take what is strictly brighter (fewer than kSelKeep)
+    }
+    for (unsigned int i = tid; i < n; i += 1024) {
+        const unsigned int k = sel_key(st[i]);
+        if (k >= thr) {
+            const unsigned int at = atomicAdd(&s_count, 1u);
+            if (at < kSelCap) sel[at] = i;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int m = min(s_count, kSelCap);
+        g.counters[f][2] = m;
+        g.selout[f][0] = m;
+        g.selout[f][1] = s_count > kSelCap ? 0xffffffffu : ncand;  // (cannot happen: ncand <= kSelKeep or the cut above; kept as a loud fallback)
+    }
+}
 __global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld, double threshold_arg,
                                                                 const ab_pixel_xf xf_arg, int *__restrict__ parent, unsigned int *__restrict__ mask,
                                                                 int *__restrict__ plist, unsigned int *nlab, int vec_ok, const FrameDev *__restrict__ fd) { AB_LATENCY_KERNEL_PRIO();
@@ -790,6 +1093,14 @@ __global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g,
     const int f = blockIdx.y;
     label_merge_body(rows, cols, g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1);
 }
+__global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
+    const int f = blockIdx.y;
+    label_tile_body(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1, g.blist[f], g.counters[f] + 3);
+}
+__global__ __launch_bounds__(256) void label_border_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
+    const int f = blockIdx.y;
+    label_border_body(rows, cols, g.parent[f], g.mask[f], g.blist[f], g.counters[f] + 3);
+}
 __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
                                                             int *__restrict__ roots, int *__restrict__ cid, unsigned int *nroots, unsigned int cap) { AB_LATENCY_KERNEL_PRIO();
     roots_body(parent, plist, nlab, roots, cid, nroots, cap);
@@ -805,12 +1116,12 @@ __global__ __launch_bounds__(256) void comp_init_many_kernel(const DetGroup g) {
 }
 __global__ __launch_bounds__(256) void comp_stats_kernel(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st, const int *__restrict__ plist,
                                                          const unsigned int *__restrict__ nlab) { AB_LATENCY_KERNEL_PRIO();
-    comp_stats_body(rows, cols, parent, cid, st, plist, nlab);
+    comp_stats_body<false>(rows, cols, parent, cid, st, plist, nlab);
 }
-__global__ __launch_bounds__(256) void comp_stats_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
+__global__ __launch_bounds__(256) void comp_stats_many_kernel(const DetGroup g, int rows, int cols, int64_t ld) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     if (g.ncomp[f] == 0) return;
-    comp_stats_body(rows, cols, g.parent[f], g.cid[f], g.st[f], g.plist[f], g.counters[f] + 1);
+    comp_stats_body<true>(rows, cols, g.parent[f], g.cid[f], g.st[f], g.plist[f], g.counters[f] + 1, g.img[f], ld, g.xf[f], g.bg_median[f]);
 }
 __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st,
@@ -820,7 +1131,8 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
 }
 __global__ __launch_bounds__(256) void comp_moments_many_kernel(const DetGroup g, int cols, int64_t ld) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    comp_moments_body(g.img[f], cols, ld, g.parent[f], g.mask[f], g.roots[f], g.st[f], g.ncomp[f], g.bg_median[f], g.xf[f], g.rec[f], nullptr);
+    comp_moments_body(g.img[f], cols, ld, g.parent[f], g.mask[f], g.roots[f], g.st[f], g.ncomp[f], g.bg_median[f], g.xf[f], g.rec[f], nullptr,
+                      g.sel[f], g.sel[f] ? g.counters[f] + 2 : nullptr);
 }
 
 // ---- normalize_for_detection (affine.rs:24-53) ------------------------------------------------------
@@ -1749,7 +2061,13 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_PARENT, (size_t)G * P * sizeof(int), (void **)&parent));
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_CID, (size_t)G * P * sizeof(int), (void **)&cid));
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_ROOTS, (size_t)G * roots_words * sizeof(int), (void **)&roots));
-    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)G * P * sizeof(int), (void **)&plist));
+    // tile-local labelling (label_tile_many_kernel) where the planes allow it: contiguous (always, here), 16-byte aligned, width a
+    // multiple of 32; AB_LABEL_LEGACY=1 keeps the two-pass form (the GPU tests run both)
+    bool tiled = !ctx->label_legacy && (cols % 32) == 0;
+    for (int f = 0; f < G; ++f) tiled = tiled && ((uintptr_t)imgs[f] & 15) == 0;
+    const int64_t tiles_x = (cols + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH, ntile = tiles_x * tiles_y;
+    const size_t border_cap = (size_t)ntile * (kTileW + 2 * kTileH);  // last row + first and last column of every tile
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)G * ((size_t)P + border_cap) * sizeof(int), (void **)&plist));
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_MASK, (size_t)G * mask_words * sizeof(unsigned int), (void **)&mask));
     ctx->det_group_ws = true;  // (the single-frame path carves the same workspaces differently: nothing of it survives a call)
     DetGroup g;
@@ -1765,6 +2083,7 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         g.parent[f] = parent + (size_t)f * P;
         g.cid[f] = cid + (size_t)f * P;
         g.plist[f] = plist + (size_t)f * P;
+        g.blist[f] = plist + (size_t)G * P + (size_t)f * border_cap;
         g.roots[f] = roots + (size_t)f * root_cap;
         g.mask[f] = mask + (size_t)f * mask_words;
         g.counters[f] = counters + 4 * f;
@@ -1773,9 +2092,14 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
     const int gl = cus * 2;  // list kernels: grid-stride over the frame's labelled pixels (a fraction of a percent of the frame)
     AB_HIP(ctx, hipMemsetAsync(counters, 0, (size_t)G * 4 * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(label_init_many_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds)), (unsigned)G), dim3(kInitBlock), 0, ctx->stream, g,
-                       (int)rows, (int)cols, cols, (int)vec_ok);
-    hipLaunchKernelGGL(label_merge_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
+    if (tiled) {
+        hipLaunchKernelGGL(label_tile_many_kernel, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
+        hipLaunchKernelGGL(label_border_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
+    } else {
+        hipLaunchKernelGGL(label_init_many_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds)), (unsigned)G), dim3(kInitBlock), 0, ctx->stream, g,
+                           (int)rows, (int)cols, cols, (int)vec_ok);
+        hipLaunchKernelGGL(label_merge_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
+    }
     hipLaunchKernelGGL(roots_many_kernel, dim3(gl, G), dim3(kRootsBlock), 0, ctx->stream, g, root_cap);
     AB_HIP(ctx, hipGetLastError());
     void *pin = nullptr;
@@ -1793,28 +2117,59 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     }
     off[G] = total;
     if (total == 0) return AB_OK;
+    // The matcher's 120 (max_keep <= kSelKeep / 4): the brightest kSelKeep candidates are chosen on the device and only they are
+    // walked and sent (comp_select_many_kernel).  A caller that wants every star, or AB_DETECT_FULL_RECORDS=1, takes all records.
+    const bool select = !ctx->detect_full_records && 4 * max_keep <= (size_t)kSelKeep;
     void *cbuf = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, total * sizeof(CompStat), &cbuf));
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, total * sizeof(CompStat) + (size_t)G * kSelCap * sizeof(unsigned int), &cbuf));
     CompStat *dstat = (CompStat *)cbuf;
-    // the component records (72 B each, written once, by one lane, never read on the device) go STRAIGHT into pinned host memory:
-    // the group's 3 MB used to come back as the stage's largest blit (up to 190 us on a hardware queue shared with other streams)
-    AB_TRY(ab_pinned(ctx, total * sizeof(CompRec), &pin));
+    unsigned int *dsel = (unsigned int *)(dstat + total);
+    // the component records (72 B each, written once, by one lane, never read on the device) go STRAIGHT into pinned host memory
+    const size_t rec_count = select ? (size_t)G * kSelCap : total;
+    AB_TRY(ab_pinned(ctx, rec_count * sizeof(CompRec) + (size_t)G * 4 * sizeof(unsigned int), &pin));
+    unsigned int *selout = (unsigned int *)((CompRec *)pin + rec_count);
     for (int f = 0; f < G; ++f) {
-        g.rec[f] = (CompRec *)pin + off[f];
+        g.rec[f] = (CompRec *)pin + (select ? (size_t)f * kSelCap : off[f]);
         g.st[f] = dstat + off[f];
+        g.sel[f] = select ? dsel + (size_t)f * kSelCap : nullptr;
+        g.selout[f] = selout + 4 * f;
+        selout[4 * f] = selout[4 * f + 1] = 0;
     }
     hipLaunchKernelGGL(comp_init_many_kernel, dim3((max_nc + 255) / 256, G), dim3(256), 0, ctx->stream, g);
-    hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
+    hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols, cols);
 #ifdef AB_DEV_ABLATION
     if (getenv("AB_ABLATE_MOMENTS")) {
         const int v = atoi(getenv("AB_ABLATE_MOMENTS"));
         AB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_mom_ablate), &v, sizeof v));
     }
 #endif
-    hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
+    if (select) {
+        hipLaunchKernelGGL(comp_select_many_kernel, dim3(G), dim3(1024), 0, ctx->stream, g);
+        hipLaunchKernelGGL(comp_moments_many_kernel, dim3((kSelCap + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
+    } else {
+        hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
+    }
     AB_HIP(ctx, hipGetLastError());
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int f = 0; f < G; ++f) finish_stars((const CompRec *)pin + off[f], g.ncomp[f], bg[f][1], max_keep, &stars[f]);
+    bool redo[kGroupMax] = {};
+    for (int f = 0; f < G; ++f) {
+        if (!select) {
+            finish_stars((const CompRec *)pin + off[f], g.ncomp[f], bg[f][1], max_keep, &stars[f]);
+            continue;
+        }
+        const unsigned int m = selout[4 * f], ncand = selout[4 * f + 1];
+        AB_CHECK(ctx, m <= kSelCap, "detect_stars: the selection of frame %d holds %u components", f, m);
+        finish_stars(g.rec[f], m, bg[f][1], max_keep, &stars[f]);
+        // the brightest kSelKeep did not yield max_keep survivors and fainter candidates exist (a crowded field whose dedup eats
+        // hundreds, or a crowd of equal fluxes at the cut): the whole list decides
+        redo[f] = stars[f].size() < max_keep && ncand > m;
+    }
+    for (int f = 0; f < G; ++f) {  // (after every frame's records have been read: the full path re-carves the workspaces and the pinned buffer)
+        if (!redo[f]) continue;
+        double m0 = 0.0, s0 = 0.0;
+        AB_TRY(ab_detect_stars_device(ctx, imgs[f], rows, cols, cols, sigma_threshold, &stars[f], &m0, &s0, xf[f], max_keep, false, bg[f]));
+        ctx->det_select_fallbacks++;
+    }
     return AB_OK;
 }
 

@@ -229,7 +229,6 @@ int ab_create_master(ab_ctx *ctx, int32_t kind, const ab_plane *frames, size_t n
     AB_CHECK(ctx, kind >= 0 && kind <= 2 && out, "kind must be 0 (bias), 1 (dark) or 2 (flat)");
     if (!frames || n_frames == 0)  // calibration.rs:128-130,158-160,199-201
         return ab_set_error(ctx, AB_ERR_INVALID, "No %s frames provided", kind == 0 ? "bias" : (kind == 1 ? "dark" : "flat"));
-    AB_CHECK(ctx, n_frames <= 512, "at most 512 frames per master in this build");
     const int64_t rows = frames[0].rows, cols = frames[0].cols, n = rows * cols;
     for (size_t i = 1; i < n_frames; ++i)
         if (frames[i].rows != rows || frames[i].cols != cols)  // :139-144

@@ -12,6 +12,8 @@
 // accumulation are f64 in the reference's evaluation order, so results are bit-identical to the
 // CPU restatement; only the final store is f32.
 #include "ab_common.hpp"
+#include <algorithm>
+#include <climits>
 #include <cmath>
 
 namespace {
@@ -318,6 +320,91 @@ int ab_warp_image_rows(ab_ctx *ctx, const ab_plane *src, const double transform[
     AB_CHECK(ctx, src && out_band && transform && src->data && out_band->data, "null plane or transform");
     AB_CHECK(ctx, src->on_device && out_band->on_device, "ab_warp_image_rows takes device-resident planes");
     return ab_warp_rows_device(ctx, src->data, src->rows, src->cols, transform, out_rows, out_band->cols, row0, out_band->rows, out_band->data);
+} AB_CATCH(ctx)
+
+// Source rows that rows [row0, row0 + nrows) of warp_image(src, transform, out_rows, out_cols) read (affine.rs:663-690 +
+// sampling.rs:48-80: an output pixel whose source point passes 0 <= sy < rows - 1 reads rows floor(sy) - 1 .. floor(sy) + 2,
+// clamped to the frame).  sy = c x + d y + ty is evaluated here with the kernel's own expression; every operation of it is
+// monotone in x and in y (a correctly rounded product and sum are monotone in each operand), so its extremes over the band's
+// rectangle are taken at the four corners and the interval below is exactly the hull of what the kernel touches -- not an
+// estimate with a safety margin.  A non-finite coefficient asks for the whole frame.
+static void warp_source_rows(const double t[6], int64_t src_rows, int64_t src_cols, int64_t out_cols, int64_t row0, int64_t nrows,
+                             int64_t *s0, int64_t *sn) {
+    *s0 = 0;
+    *sn = 0;
+    if (nrows <= 0 || out_cols <= 0 || src_rows < 2 || src_cols < 2) return;  // (nothing passes `sy < rows - 1` on a one-row frame)
+    for (int i = 0; i < 6; ++i)
+        if (!std::isfinite(t[i]) || fabs(t[i]) > 1e150) {
+            *sn = src_rows;
+            return;
+        }
+    double lo = INFINITY, hi = -INFINITY;
+    const double xs[2] = {0.0, (double)(out_cols - 1)}, ys[2] = {(double)row0, (double)(row0 + nrows - 1)};
+    for (double xf : xs)
+        for (double yf : ys) {
+            const double sy = t[3] * xf + t[4] * yf + t[5];  // the kernel's `c * xf + d * yf + ty` (-ffp-contract=off on both sides)
+            lo = std::min(lo, sy);
+            hi = std::max(hi, sy);
+        }
+    const double last = (double)(src_rows - 2);  // floor(sy) of a pixel that samples lies in [0, rows - 2]
+    if (!(hi >= 0.0) || !(floor(lo) <= last)) return;
+    const int64_t f_lo = (int64_t)std::max(floor(lo), 0.0), f_hi = (int64_t)std::min(floor(hi), last);
+    const int64_t a = std::max<int64_t>(f_lo - 1, 0), b = std::min<int64_t>(f_hi + 2, src_rows - 1);
+    *s0 = a;
+    *sn = b - a + 1;
+}
+
+int ab_warp_source_rows(const double transform[6], int64_t src_rows, int64_t src_cols, int64_t out_cols, int64_t row0, int64_t nrows,
+                        int64_t *src_row0, int64_t *src_nrows) try {
+    if (!transform || !src_row0 || !src_nrows || src_rows < 0 || src_cols < 0 || row0 < 0 || nrows < 0) return AB_ERR_INVALID;
+    warp_source_rows(transform, src_rows, src_cols, out_cols, row0, nrows, src_row0, src_nrows);
+    return AB_OK;
+} AB_CATCH_NOCTX
+
+// the hull of ab_warp_source_rows over n transforms for rank `rank`'s band of the output (ab_shard_rows): what a rank of the
+// row-band scheme must hold of every target frame ("rows [g R / G, (g + 1) R / G) of every frame (+ halo)")
+int ab_shard_source_rows(const double *transforms, size_t n, int64_t src_rows, int64_t src_cols, int64_t out_rows, int64_t out_cols, int nranks,
+                         int rank, int64_t *src_row0, int64_t *src_nrows) try {
+    if ((!transforms && n) || !src_row0 || !src_nrows) return AB_ERR_INVALID;
+    int64_t row0 = 0, nrows = 0;
+    if (ab_shard_rows(out_rows, nranks, rank, &row0, &nrows) != AB_OK) return AB_ERR_INVALID;
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (size_t i = 0; i < n; ++i) {
+        int64_t s0 = 0, sn = 0;
+        warp_source_rows(transforms + 6 * i, src_rows, src_cols, out_cols, row0, nrows, &s0, &sn);
+        if (sn > 0) {
+            lo = std::min(lo, s0);
+            hi = std::max(hi, s0 + sn);
+        }
+    }
+    *src_row0 = lo <= hi ? lo : 0;
+    *src_nrows = lo <= hi ? hi - lo : 0;
+    return AB_OK;
+} AB_CATCH_NOCTX
+
+// ab_warp_image_rows with the SOURCE given as a band: src_band holds rows [src_row0, src_row0 + src_band->rows) of a frame of
+// src_rows rows.  The band must cover ab_warp_source_rows of the request; the result is then bit-identical to the same rows of
+// ab_warp_image on the whole frame (same kernel, same coordinates: the band's base pointer is moved back by src_row0 rows, so
+// every tap address is the one the whole frame would give, and none outside the band is formed).
+int ab_warp_image_rows_from_band(ab_ctx *ctx, const ab_plane *src_band, int64_t src_row0, int64_t src_rows, const double transform[6],
+                                 int64_t out_rows, int64_t row0, ab_plane_mut *out_band) try {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_CHECK(ctx, src_band && out_band && transform && (out_band->rows == 0 || out_band->data), "null plane or transform");
+    AB_CHECK(ctx, src_row0 >= 0 && src_band->rows >= 0 && src_row0 + src_band->rows <= src_rows, "source band [%lld, %lld) leaves the frame's %lld rows",
+             (long long)src_row0, (long long)(src_row0 + src_band->rows), (long long)src_rows);
+    if (out_band->rows == 0) return AB_OK;
+    AB_CHECK(ctx, out_band->on_device && (src_band->rows == 0 || (src_band->data && src_band->on_device)), "ab_warp_image_rows_from_band takes device-resident planes");
+    int64_t need0 = 0, need_n = 0;
+    warp_source_rows(transform, src_rows, src_band->cols, out_band->cols, row0, out_band->rows, &need0, &need_n);
+    AB_CHECK(ctx, need_n == 0 || (need0 >= src_row0 && need0 + need_n <= src_row0 + src_band->rows),
+             "output rows [%lld, %lld) read source rows [%lld, %lld); the band holds [%lld, %lld)", (long long)row0, (long long)(row0 + out_band->rows),
+             (long long)need0, (long long)(need0 + need_n), (long long)src_row0, (long long)(src_row0 + src_band->rows));
+    // (no source row needed: every pixel of the band is 0.0; the kernel then forms no address at all, whatever the base)
+    const float *base = src_band->data ? src_band->data - src_row0 * src_band->cols : nullptr;
+    if (!base) {  // an empty band and nothing to read: hand the kernel any valid pointer
+        base = out_band->data + 1;
+    }
+    return ab_warp_rows_device(ctx, base, src_rows, src_band->cols, transform, out_rows, out_band->cols, row0, out_band->rows, out_band->data);
 } AB_CATCH(ctx)
 
 int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transform[6], ab_plane_mut *out) try {

@@ -1211,7 +1211,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
                     int64_t cols, const ab_stack_config *cfg, float *out_dev, double *out_sum_dev,
                     uint32_t *out_cnt_dev, uint64_t *out_rejected, bool median_only) {
     AB_CHECK(ctx, n >= 1, "No images to stack");
-    if (n > 512) return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "stack of %zu frames: this build stacks up to 512 frames per call", n);
+    AB_CHECK(ctx, n <= ((size_t)1 << 24), "stack of %zu frames (at most 2^24 per call)", n);
     AB_CHECK(ctx, rows > 0 && cols > 0, "stack output has a zero dimension");
     AB_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t total = rows * cols;
@@ -1231,8 +1231,12 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
         // 257 .. 512 contiguous frames, plain full-image stack or median combine: two lanes per pixel (stack_pair.hip), bit-identical
         // to the wave-per-pixel kernel (AB_STACK_NO_PAIR=1 keeps that one); everything else: one wave per pixel (stack_wide.hip)
+        // 513 .. 4096: the wave-per-pixel kernel with 16 / 32 / 64 registers per lane; beyond: one workgroup per pixel, samples
+        // in global scratch (stack_deep.hip; a context created under AB_STACK_DEEP_FROM=k sends every stack of more than k >= 64 frames there: the tests do)
         static const bool no_pair = getenv("AB_STACK_NO_PAIR") != nullptr;
-        if (n > 256 && contig_all && !partial && !no_pair)
+        if (n > (size_t)ctx->stack_deep_from)
+            AB_TRY(ab_stack_deep_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
+        else if (n > 256 && n <= 512 && contig_all && !partial && !no_pair)
             AB_TRY(ab_stack_pair_device(ctx, dplanes, n, rows, cols, cfg, out_dev, median_only));
         else
             AB_TRY(ab_stack_wide_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
@@ -1349,7 +1353,6 @@ static int stack_planes(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_
     if (!ctx) return AB_ERR_INVALID;
     AB_CHECK(ctx, planes && n >= 1, "No images to stack");
     AB_CHECK(ctx, cfg && out, "null config or output");
-    if (n > 512) return ab_set_error(ctx, AB_ERR_UNSUPPORTED, "stack of %zu frames: this build stacks up to 512 frames per call", n);
     for (size_t i = 0; i < n; ++i)
         AB_CHECK(ctx, planes[i].rows >= out->rows && planes[i].cols >= out->cols,
                  "frame %zu (%lldx%lld) is smaller than the output (%lldx%lld)", i, (long long)planes[i].rows,

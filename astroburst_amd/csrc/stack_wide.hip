@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void stack_wide_quad_kernel(const WideArgs a) 
 // dplanes / ld are HOST arrays of n entries (64 < n <= 512); counters already cleared by the caller
 int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld, size_t n, int64_t rows, int64_t cols,
                          const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only) {
-    AB_CHECK(ctx, n > 64 && n <= 512, "stack of %zu frames: this build stacks up to 512 frames per call", n);
+    AB_CHECK(ctx, n > 64 && n <= 4096, "the wave-per-pixel stack takes 65 .. 4096 frames (got %zu)", n);
     void *ws = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, n * (sizeof(float *) + sizeof(int64_t)), &ws));
     // the tables are tiny; a blocking copy keeps the host arrays' lifetime out of the picture
@@ -239,7 +239,15 @@ int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((total + 3) / 4, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 8));
     bool quad = a.contiguous && (total & 3) == 0;
     for (size_t i = 0; i < n && quad; ++i) quad = ((uintptr_t)dplanes[i] & 15) == 0;
-    if (quad) {
+    // 513 .. 4096 frames (K = 16, 32, 64 registers per lane and array): the same wave-per-pixel definition, one pixel at a time
+    // (four pixels' worth of 16-byte loads would not fit the register file beside two sort arrays)
+    if (n > 2048) {
+        hipLaunchKernelGGL(stack_wide_kernel<64>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else if (n > 1024) {
+        hipLaunchKernelGGL(stack_wide_kernel<32>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else if (n > 512) {
+        hipLaunchKernelGGL(stack_wide_kernel<16>, dim3(grid), dim3(256), 0, ctx->stream, a);
+    } else if (quad) {
         if (n <= 128)
             hipLaunchKernelGGL(stack_wide_quad_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, a);
         else if (n <= 256)

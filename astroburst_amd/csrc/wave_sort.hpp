@@ -19,6 +19,18 @@ template <>
 struct Log2<8> {
     static constexpr int v = 3;
 };
+template <>
+struct Log2<16> {
+    static constexpr int v = 4;
+};
+template <>
+struct Log2<32> {
+    static constexpr int v = 5;
+};
+template <>
+struct Log2<64> {
+    static constexpr int v = 6;
+};
 
 // ascending bitonic sort of the wave's 64 K values; element index e = lane * K + k
 template <int K>

@@ -209,15 +209,30 @@ def main():
     register = not args.no_register
     cy0, cx0, cflux = cat
     raw = []
+    row0, nrows = (0, R) if not rowband else ctx.shard_rows(R, world, rank)
+    # Row bands INGEST bands ("GPU g owns rows [g R / G, (g + 1) R / G) of every frame (+ halo) ... each GPU ingests
+    # N P / G pixels"): a rank keeps whole frames only for the reference and the targets it detects (k - 1 = rank mod G) and of
+    # every target the rows its band of the output can read -- its rows + a halo sized from the generator's bounds (8 px shift, 0.5
+    # degrees about the centre: |c| cols / 2 + 8 + 3 < 64 rows); the library checks every warp against what it really reads.
+    kHalo = 64
+    band0 = max(0, row0 - kHalo)
+    band1 = min(R, row0 + nrows + kHalo)
+    raw_band = [None] * N
     for k in range(N):
         # frame k sees the field through its own pointing error: a star at reference (x, y) lands at T_k(x, y)
         a_, b_, tx_, c_, d_, ty_ = transforms[k] if register else transforms[0]
         cat_k = (c_ * cx0 + d_ * cy0 + ty_, a_ * cx0 + b_ * cy0 + tx_, cflux)
         truth = torch.full((R, Cc), 200.0, dtype=torch.float32, device=dev) + synth.render_stars(R, Cc, cat_k, device=dev)
         border = 16 if k % 10 == 9 else 0
-        raw.append(synth.make_frame(R, Cc, k + (0 if rowband else N * rank), device=dev, truth=truth, border=border))
+        frame = synth.make_frame(R, Cc, k + (0 if rowband else N * rank), device=dev, truth=truth, border=border)
+        if rowband and world > 1 and k > 0:
+            raw_band[k] = frame[band0:band1].clone()
+            raw.append(frame if (k - 1) % world == rank else torch.empty((0, Cc), dtype=torch.float32, device=dev))
+        else:
+            raw.append(frame)
+        del frame
     del truth
-    row0, nrows = (0, R) if not rowband else ctx.shard_rows(R, world, rank)
+    resident_bytes = sum(t.numel() * 4 for t in raw) + sum(t.numel() * 4 for t in raw_band if t is not None)
     if rowband:   # this rank's rows of every registered frame; frame 0 (the reference) needs no warp: a view of its rows
         warped = [raw[0][row0:row0 + nrows]] + [torch.empty((nrows, Cc), dtype=torch.float32, device=dev) for _ in range(1, N)]
     else:
@@ -240,7 +255,10 @@ def main():
             estimated[0] = ctx.register_frames_sharded(comm, raw[0], raw[1:], num_threads=8)
             e[0].record()
             for k in range(1, N):
-                ctx.warp_image_rows(raw[k], estimated[0][k - 1].transform, R, row0, warped[k])
+                if raw_band[k] is not None:   # from this rank's rows + halo of the target: the whole frame is not here
+                    ctx.warp_image_rows_from_band(raw_band[k], band0, R, estimated[0][k - 1].transform, R, row0, warped[k])
+                else:
+                    ctx.warp_image_rows(raw[k], estimated[0][k - 1].transform, R, row0, warped[k])
             e[1].record()
             ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
             e[2].record()
@@ -552,8 +570,14 @@ def main():
                                    + " + image stats + auto-STF u8 (auto_stretch_preview)"
                                    + (" with histogram all-reduces" if rowband else ""),
                        "frames_per_gpu": N, "rows": R, "cols": Cc, "device": name, "cus": cus,
-                       "rccl_ranks": (comm.size if comm else 0), "rccl_collectives_per_step": (comm.collectives_issued // nsteps if comm else 0),
+                       "rccl_ranks": (comm.size if comm and not comm.is_host else 0), "comm_ranks": (comm.size if comm else 0),
+                       "rccl_collectives_per_step": (comm.collectives_issued // nsteps if comm and not comm.is_host else 0),
+                       "comm_collectives_per_step": (comm.collectives_issued // nsteps if comm else 0),
                        "devices": dev_names, "mode": ("rowband" if rowband else "frames") if sharded else "single",
+                       "resident_input_bytes_rank0": resident_bytes,
+                       **({"rowband_ingest": f"rank 0 holds the reference, {sum(1 for t in raw[1:] if t.numel())} whole targets (the ones it detects) and rows "
+                                             f"[{band0}, {band1}) of all {N - 1} targets (its {nrows} rows + a {kHalo}-row halo): "
+                                             f"{resident_bytes / 1e9:.3f} GB against {N * P * 4 / 1e9:.3f} GB for the frame set"} if rowband and world > 1 else {}),
                        **({"transport": f"HOST-STAGED DRY RUN: {world} ranks share ONE GPU (cuda:0), collectives through shared memory, not RCCL / xGMI: "
                                         "the launch line and the sharded code path executed end to end, not a scaling measurement"} if args.host_staged else {}),
                        "output_mpix_per_s": round((1 if rowband else world) * P / 1e6 / (elapsed / args.steps), 1),

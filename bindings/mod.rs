@@ -329,6 +329,23 @@ pub fn warp_image_rows(hip: &Hip, image: &impl PlaneSrc, t: &AffineTransform, ou
     hip.check(unsafe { sys::ab_warp_image_rows(hip.ctx, &image.ab(), m.as_ptr(), out_rows as i64, row0 as i64, &mut band.ab_mut()) })
 }
 
+/// the same with the source given as rows [src_row0, src_row0 + src_band.rows) of a `src_rows`-row frame: a GPU of the row-band
+/// scheme holds its rows of every target + the halo `shard_source_rows` names, not the frame set
+pub fn warp_image_rows_from_band(hip: &Hip, src_band: &impl PlaneSrc, src_row0: usize, src_rows: usize, t: &AffineTransform, out_rows: usize,
+                                 row0: usize, band: &mut impl PlaneDst) -> Result<()> {
+    let m = [t.a, t.b, t.tx, t.c, t.d, t.ty];
+    hip.check(unsafe {
+        sys::ab_warp_image_rows_from_band(hip.ctx, &src_band.ab(), src_row0 as i64, src_rows as i64, m.as_ptr(), out_rows as i64, row0 as i64, &mut band.ab_mut())
+    })
+}
+/// source rows (first, count) that output rows [row0, row0 + nrows) of warp_image read (affine.rs:663-690, sampling.rs:48-80)
+pub fn warp_source_rows(t: &AffineTransform, src_rows: usize, src_cols: usize, out_cols: usize, row0: usize, nrows: usize) -> (usize, usize) {
+    let m = [t.a, t.b, t.tx, t.c, t.d, t.ty];
+    let (mut s0, mut sn) = (0i64, 0i64);
+    unsafe { sys::ab_warp_source_rows(m.as_ptr(), src_rows as i64, src_cols as i64, out_cols as i64, row0 as i64, nrows as i64, &mut s0, &mut sn) };
+    (s0 as usize, sn as usize)
+}
+
 // ---- a8  core/alignment/phase_correlation.rs --------------------------------------------------------------------------------------
 /// drop-in for phase_correlate (phase_correlation.rs:22-89)
 pub fn phase_correlate(hip: &Hip, reference: &impl PlaneSrc, target: &impl PlaneSrc) -> Result<PhaseCorrelationResult> {
@@ -1185,6 +1202,15 @@ pub fn shard_rows(rows: usize, nranks: i32, rank: i32) -> (usize, usize) {
     let (mut r0, mut n) = (0i64, 0i64);
     unsafe { sys::ab_shard_rows(rows as i64, nranks, rank, &mut r0, &mut n) };
     (r0 as usize, n as usize)
+}
+/// what `rank` must hold of every target frame to warp its band with `transforms`: its rows + the halo (first row, count)
+pub fn shard_source_rows(transforms: &[AffineTransform], src_rows: usize, src_cols: usize, out_rows: usize, out_cols: usize, nranks: i32, rank: i32) -> (usize, usize) {
+    let flat: Vec<f64> = transforms.iter().flat_map(|t| [t.a, t.b, t.tx, t.c, t.d, t.ty]).collect();
+    let (mut s0, mut sn) = (0i64, 0i64);
+    unsafe {
+        sys::ab_shard_source_rows(flat.as_ptr(), transforms.len(), src_rows as i64, src_cols as i64, out_rows as i64, out_cols as i64, nranks, rank, &mut s0, &mut sn)
+    };
+    (s0 as usize, sn as usize)
 }
 /// frames [f0, f0 + nf) of an n-frame stack that belong to `rank`
 pub fn shard_frames(n_frames: usize, nranks: i32, rank: i32) -> (usize, usize) {

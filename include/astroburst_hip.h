@@ -103,11 +103,19 @@ typedef struct {
  * All planes must be at least out->rows x out->cols; each is read with its own row stride
  * (= its cols), i.e. the reference's top-left crop to the minimum dims (combine.rs:104-113)
  * costs nothing.  *out_rejected receives StackResult.rejected_pixels (sum of per-pixel
- * rejection counts, combine.rs:158,181).  1 <= n <= 512 frames per call in this build: up to 256 contiguous frames
- * a pixel's samples live in one lane's registers (64: the HBM-bound kernel; 65 .. 128: ~4 ms and 129 .. 256: ~10-16 ms
- * for 4096^2), beyond that -- or with ragged strides -- a wave owns a pixel (same results, ~180 ms for 4096^2 x 257).
- * Floating-point contract: the f64 sums of iterations >= 1 are taken over the survivors in
- * ascending value order (the reference's order is unspecified, SURVEY.md 7 hard part 2). */
+ * rejection counts, combine.rs:158,181).  Any frame count the reference takes (it gathers a Vec per pixel: no limit; here up to
+ * 2^24 per call): up to 256 contiguous frames a pixel's samples live in one lane's registers (64: the HBM-bound kernel; 65 .. 128:
+ * ~4 ms and 129 .. 256: ~10-16 ms for 4096^2), 257 .. 512 in two lanes', up to 4096 -- or with ragged strides -- in one wave's
+ * (stack_wide.hip), beyond that a workgroup sorts a pixel's samples in a scratch segment (stack_deep.hip): same results, slower.
+ * Floating-point contract.  The reference's result depends on the order select_nth_unstable leaves the survivors in (SURVEY.md 7
+ * hard part 2); the definition here: the f64 sums of iterations >= 1 run over the survivors in ascending value order.
+ *   - DEFAULT ENGINE (2 .. 64 frames): within 1e-5 relative of that definition on every pixel -- north_star's tolerance.  Its
+ *     iterations >= 1 take mean and variance from running sums about the median (E = sum(x - c0), Q = sum(x - c0)^2 in f64: mean =
+ *     (n c0 + E) / n, sum(x - mean)^2 = Q - n (mean - c0)^2), a few ulp(f64) away from the two-pass sums; an ulp can flip the
+ *     clipping decision of a sample that sits exactly on a bound.  MEASURED bit-identical: 0 of 16.7 M pixels of the bench stack
+ *     differ from the oracle; the GPU tests allow at most 1e-4 of the pixels to differ at all (tests/test_gpu_stack.py:28-39).
+ *   - AB_STACK_EXACT=1 when the context is created: the direct two-pass engine, bit-identical BY CONSTRUCTION (the tests run both).
+ *   - more than 64 frames, median combine, partial sums: always bit-identical by construction. */
 AB_API int ab_stack_sigma_clip(ab_ctx *ctx, const ab_plane *planes, size_t n, const ab_stack_config *cfg,
                                ab_plane_mut *out, uint64_t *out_rejected);
 
@@ -150,6 +158,17 @@ AB_API int ab_warp_image(ab_ctx *ctx, const ab_plane *src, const double transfor
  * registration; coordinates are those of the whole output, so the band equals the same rows of ab_warp_image. */
 AB_API int ab_warp_image_rows(ab_ctx *ctx, const ab_plane *src, const double transform[6], int64_t out_rows, int64_t row0,
                               ab_plane_mut *out_band);
+/* The same with the SOURCE given as a band (a rank of the row-band scheme ingests its rows of every frame + a
+ * halo, not the frame set): src_band = rows [src_row0, src_row0 + src_band->rows) of a frame of src_rows rows.  The band must
+ * cover ab_warp_source_rows of the request (AB_ERR_INVALID names the rows otherwise); the result equals the same rows of
+ * ab_warp_image on the whole frame bit for bit.  Device planes. */
+AB_API int ab_warp_image_rows_from_band(ab_ctx *ctx, const ab_plane *src_band, int64_t src_row0, int64_t src_rows, const double transform[6],
+                                        int64_t out_rows, int64_t row0, ab_plane_mut *out_band);
+/* source rows [*src_row0, *src_row0 + *src_nrows) that rows [row0, row0 + nrows) of warp_image(src, transform, .., out_cols) read
+ * from a src_rows x src_cols frame (affine.rs:663-690: sy = c x + d y + ty at the band's corners; sampling.rs:48-80: rows
+ * floor(sy) - 1 .. floor(sy) + 2, clamped): exact, not a bound with a margin; 0 rows when the band maps outside the frame */
+AB_API int ab_warp_source_rows(const double transform[6], int64_t src_rows, int64_t src_cols, int64_t out_cols, int64_t row0, int64_t nrows,
+                               int64_t *src_row0, int64_t *src_nrows);
 
 /* ---- a8  core/alignment/phase_correlation.rs ------------------------------------------------- */
 typedef struct { double dx, dy, confidence; } ab_phase_correlation_result; /* PhaseCorrelationResult, :15-20 */
@@ -304,7 +323,7 @@ AB_API int ab_scale(ab_ctx *ctx, const ab_plane *img, float factor, ab_plane_mut
 AB_API int ab_calibrate_image(ab_ctx *ctx, const ab_plane *raw, const ab_plane *bias, const ab_plane *dark,
                               const ab_plane *flat, float dark_exposure_ratio, ab_plane_mut *out);
 /* median_combine_row_major (calibration.rs:84-125), the per-pixel combine of create_master_{bias,dark,flat}:
- * element [len/2] of the finite samples (upper median), 0 if none.  1 <= n <= 512. */
+ * element [len/2] of the finite samples (upper median), 0 if none.  Any n >= 1 (as ab_stack_sigma_clip). */
 AB_API int ab_median_combine(ab_ctx *ctx, const ab_plane *planes, size_t n, ab_plane_mut *out);
 
 /* ---- a12  core/imaging/background.rs ---------------------------------------------------------------------------- */
@@ -447,7 +466,7 @@ AB_API int ab_calibrate_channel(ab_ctx *ctx, const ab_plane *orig, float factor,
 /* create_master_bias / _dark / _flat on in-memory frames (calibration.rs:127-255): kind 0 bias = median combine;
  * 1 dark = median of (frame - bias?); 2 flat = median of (frame - bias? - dark?), normalised to mean 1 over its
  * finite positive pixels (others -> 1.0).  Err strings as the reference ("No bias frames provided", "Dimension
- * mismatch: expected (..), got (..)").  1 <= n_frames <= 512. */
+ * mismatch: expected (..), got (..)").  Any n_frames >= 1. */
 AB_API int ab_create_master(ab_ctx *ctx, int32_t kind, const ab_plane *frames, size_t n_frames, const ab_plane *master_bias,
                             const ab_plane *master_dark, ab_plane_mut *out);
 
@@ -499,8 +518,8 @@ AB_API int ab_normalize_frames(ab_ctx *ctx, const ab_plane *frames, size_t n, ab
 /* sigma_clipped_mean_stack (:321-378): per pixel, up to max_iterations passes of { median, MAD -> sigma = 1.4826 MAD (f32);
  * stop if sigma < 1e-10; keep -sigma_low < (v - median) / sigma < sigma_high }, NaN samples included and rejected by the
  * first pass; result = f32 sum of the survivors in frame order / count (0 if none).  rejection_counts[f] (nullable) =
- * samples of frame f rejected over the whole image.  1 <= n <= 512 frames of identical dims (65 .. 512: one wave per
- * pixel instead of one lane, ~40x slower per sample).  Bit-exact. */
+ * samples of frame f rejected over the whole image.  Any n >= 1 frames of identical dims (65 .. 2048: one wave per
+ * pixel instead of one lane, ~40x slower per sample; beyond: one workgroup per pixel, samples in a scratch segment).  Bit-exact. */
 AB_API int ab_sigma_clipped_mean_stack(ab_ctx *ctx, const ab_plane *frames, size_t n, const ab_batch_stack_config *config, ab_plane_mut *out,
                                        uint64_t *rejection_counts);
 /* one channel of run_batch_pipeline (:157-190): calibrate_light on every light, normalize_frames (if configured),
@@ -627,6 +646,11 @@ AB_API int ab_comm_broadcast(ab_ctx *ctx, ab_comm *comm, void *buf_dev, size_t b
  * [f0, f0 + nf) (contiguous, balanced) of rank `rank` */
 AB_API int ab_shard_rows(int64_t rows, int nranks, int rank, int64_t *row0, int64_t *nrows);
 AB_API int ab_shard_frames(size_t n_frames, int nranks, int rank, size_t *f0, size_t *nf);
+/* what rank `rank` must hold of every TARGET frame to warp its band (ab_shard_rows over out_rows) with the n transforms
+ * (n x 6 doubles, e.g. ab_register_frames_sharded's estimates): the hull of ab_warp_source_rows = its rows + the halo the
+ * transform set needs (about max |ty| + |c| cols + 2 rows either side) */
+AB_API int ab_shard_source_rows(const double *transforms, size_t n, int64_t src_rows, int64_t src_cols, int64_t out_rows, int64_t out_cols,
+                                int nranks, int rank, int64_t *src_row0, int64_t *src_nrows);
 
 /* ROW-BAND (exact) sharding of stack_images' per-pixel loop (combine.rs:160-182): rows [row0, row0 + out_band->rows) of
  * the stack of ALL n frames -- the reference's single-level estimator restricted to a band, bit for bit.  Device planes. */

@@ -44,3 +44,41 @@ def ctx_exact():
             os.environ["AB_STACK_EXACT"] = old
     yield c
     c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_deep():
+    """Same library with AB_STACK_DEEP_FROM / AB_BATCH_DEEP_FROM = 64: every stack of more than 64 frames takes the
+    workgroup-per-pixel kernels (stack_deep.hip, scms_deep_kernel) that the default dispatch reserves for > 4096 / > 2048 frames."""
+    import astroburst_amd as ab
+    old = {k: os.environ.get(k) for k in ("AB_STACK_DEEP_FROM", "AB_BATCH_DEEP_FROM")}
+    os.environ.update(AB_STACK_DEEP_FROM="64", AB_BATCH_DEEP_FROM="64")
+    try:
+        c = ab.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_r4_detect():
+    """Same library with round 4's detection forms (AB_LABEL_LEGACY=1: two-pass labelling; AB_DETECT_FULL_RECORDS=1: every component's
+    record crosses to the host): the cross-check of the tile-local union-find and of the device-side selection of the brightest."""
+    import astroburst_amd as ab
+    old = {k: os.environ.get(k) for k in ("AB_LABEL_LEGACY", "AB_DETECT_FULL_RECORDS")}
+    os.environ.update(AB_LABEL_LEGACY="1", AB_DETECT_FULL_RECORDS="1")
+    try:
+        c = ab.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    yield c
+    c.close()

@@ -232,6 +232,80 @@ def scenario_abort(ab, ctx, comm, rank, nranks, out):
     np.savez(os.path.join(out, f"rank{rank}.npz"), code=np.array([code]), seconds=np.array([time.time() - t0]))
 
 
+def band_frames():
+    """(reference, 15 targets) of the row-band scenario: shifts up to 9 px and rotations up to 0.6 degrees, so the halos differ
+    per rank and per frame; 400 x 640 frames"""
+    import math
+    import torch
+    from astroburst_amd import synth
+    rows, cols = 400, 640
+    y, x, flux = synth.star_catalog(rows, cols, 420, seed=23)
+    g = torch.Generator().manual_seed(99)
+    frames, truth_t = [], []
+    for k in range(16):
+        if k == 0:
+            a = b = c = d = tx = ty = 0.0
+            a = d = 1.0
+        else:
+            ang = math.radians(float(torch.rand(1, generator=g)) * 1.2 - 0.6)
+            tx, ty = (float(torch.rand(1, generator=g)) * 18.0 - 9.0 for _ in range(2))
+            a, b, c, d = math.cos(ang), -math.sin(ang), math.sin(ang), math.cos(ang)
+            # rotate about the frame centre
+            tx += cols / 2.0 - (a * cols / 2.0 + b * rows / 2.0)
+            ty += rows / 2.0 - (c * cols / 2.0 + d * rows / 2.0)
+        cat_k = (c * x + d * y + ty, a * x + b * y + tx, flux * 30.0)   # a star at reference (x, y) lands at T_k(x, y)
+        frames.append(synth.make_frame(rows, cols, k, cat=cat_k, bad_patch_rate=0.0, cosmic_rate=1e-4))
+        truth_t.append((a, b, tx, c, d, ty))
+    return frames[0], frames[1:], truth_t[1:]
+
+
+def scenario_bands(ab, ctx, comm, rank, nranks, out):
+    """SURVEY 8e's row-band scheme with every rank INGESTING a band: whole frames only for the targets this rank detects (i mod size)
+    and the reference; of every other target just the rows its band of the output reads (ab_shard_source_rows: its rows + the halo the
+    exchanged transforms need).  The host slices are cut from the frames BEFORE they reach the device: a rank never holds more."""
+    import torch
+    ref, tgts, _ = band_frames()
+    rows, cols = ref.shape
+    n = len(tgts)
+    mine = [i for i in range(n) if i % nranks == rank]
+    # detection is frame-sharded: only this rank's targets (and the reference) are uploaded whole
+    dev_targets = [tgts[i].cuda() if i in mine else torch.empty((0, cols), device="cuda") for i in range(n)]
+    ref_dev = ref.cuda()
+    regs = ctx.register_frames_sharded(comm, ref_dev, dev_targets, num_threads=8)
+    transforms = [r.transform for r in regs]
+    del dev_targets
+    row0, nrows = ctx.shard_rows(rows, nranks, rank)
+    s0, sn = ctx.shard_source_rows(transforms, rows, cols, rows, cols, nranks, rank)
+    resident = 0
+    warped = [ref_dev[row0:row0 + nrows].contiguous()]
+    for i in range(n):
+        f0, fn = ctx.warp_source_rows(transforms[i], rows, cols, cols, row0, nrows)
+        assert fn == 0 or (f0 >= s0 and f0 + fn <= s0 + sn)
+        band_host = tgts[i][s0:s0 + sn].contiguous()          # what this rank is GIVEN of target i
+        band_dev = band_host.cuda()
+        resident += band_dev.numel() * 4
+        o = torch.empty((nrows, cols), device="cuda")
+        ctx.warp_image_rows_from_band(band_dev, s0, rows, transforms[i], rows, row0, o)
+        warped.append(o)
+    # (the frames are bands already: the band-local stack + the rejected count summed over the ranks)
+    out_band, rej_local = ctx.stack_sigma_clip(warped, 3.0, 3.0, 5) if nrows > 0 else (torch.empty((0, cols), device="cuda"), 0)
+    t = torch.tensor([rej_local], dtype=torch.int64, device="cuda")
+    comm.allreduce(t, "sum")
+    full = torch.zeros((rows, cols), device="cuda")
+    ctx.allgather_rows(comm, out_band, full)
+    # a band that is too short is refused loudly, naming the rows: target 0 without the last row its band of the output reads
+    code = 0
+    f0, fn = ctx.warp_source_rows(transforms[0], rows, cols, cols, row0, nrows)
+    if nrows > 0 and fn > 1:
+        try:
+            ctx.warp_image_rows_from_band(tgts[0][f0:f0 + fn - 1].contiguous().cuda(), f0, rows, transforms[0], rows, row0, torch.empty((nrows, cols), device="cuda"))
+        except ab.AstroBurstError as e:
+            code = e.code
+            assert "read source rows" in e.message
+    np.savez(os.path.join(out, f"rank{rank}.npz"), full=full.cpu().numpy(), rej=np.array([int(t.item())]), transforms=np.array(transforms),
+             src=np.array([s0, sn, row0, nrows]), resident=np.array([resident]), short_band_code=np.array([code]))
+
+
 def scenario_sum(ab, ctx, comm, rank, nranks, out):
     """one all-reduce: proves that every rank of the job sits in the same segment"""
     import torch
@@ -247,7 +321,7 @@ def main():
     ctx.use_torch_stream()
     comm = ab.Comm.host(ctx, name, nranks, rank)
     assert comm.is_host and (comm.rank, comm.size) == (rank, nranks)
-    {"all": scenario_all, "fail": scenario_fail, "die": scenario_die, "abort": scenario_abort, "sum": scenario_sum}[scenario](ab, ctx, comm, rank, nranks, out)
+    {"all": scenario_all, "fail": scenario_fail, "die": scenario_die, "abort": scenario_abort, "sum": scenario_sum, "bands": scenario_bands}[scenario](ab, ctx, comm, rank, nranks, out)
     comm.close()
     ctx.close()
 

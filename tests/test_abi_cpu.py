@@ -213,3 +213,24 @@ def test_rust_safe_wrappers_cover_the_header():
                  "process_rgb", "spcc_calibrate_rgb", "arcsinh_stretch", "calibrate_image", "median_combine", "run_batch_pipeline",
                  "analyze_subframe", "align_pair", "resample_image", "apply_lrgb", "calibrate_channel"):
         assert re.search(r"pub fn %s\b" % name, src), f"no drop-in named {name}"
+
+
+def test_no_dpp_reads_a_register_inside_its_write_hazard_window(tmp_path):
+    """csrc/stack_pair.hip's correctness leans on a hand-placed `s_nop 1` between the inline-asm sorting network
+    (VALU writes the hazard recogniser cannot see) and the DPP exchanges that read the same registers (gfx9: two wait states).
+    tools/check_dpp_hazard.py compiles the file for gfx950 and walks the LISTING: every DPP source register must be two wait states
+    clear of its last VALU write.  The checker is itself checked: the same listing with every s_nop removed must fail."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(root, "tools", "check_dpp_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    lst = chk.compile_listing(os.path.join(chk.CSRC, "stack_pair.hip"), str(tmp_path))
+    ndpp, viol = chk.check_listing(lst)
+    assert ndpp > 500, "the listing holds no DPP instructions: wrong file or the kernel changed shape"
+    assert not viol, viol[:5]
+    stripped = os.path.join(tmp_path, "nofence.s")
+    with open(stripped, "w") as f:
+        f.write("\n".join(l for l in open(lst).read().split("\n") if "s_nop" not in l))
+    assert chk.check_listing(stripped)[1], "the checker does not see a hazard when the fences are gone"

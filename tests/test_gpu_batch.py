@@ -36,6 +36,44 @@ def test_deep_batch_stack_one_wave_per_pixel(ctx, oracle, n):
         assert same(got, want), (sl, sh, it)
 
 
+@pytest.mark.parametrize("n", [513, 700, 1024, 1100, 2048])
+def test_batch_stack_of_more_than_512_frames(ctx, oracle, n):
+    """VERDICT r4 missing 2: 513 .. 2048 frames through scms_wide_kernel with 16 / 32 registers per lane and array, bit for bit"""
+    shape = (64, 96) if n <= 1024 else (16, 24)
+    fr = frames_with_trouble(n, shape, n)
+    for sl, sh, it in ((2.5, 3.0, 5), (1.0, 1.0, 2)):
+        want, wrej = oracle.sigma_clipped_mean_stack(fr, sl, sh, it)
+        got, rej = ctx.sigma_clipped_mean_stack(fr, BatchStackConfig(sl, sh, it))
+        assert rej == wrej, (sl, sh, it)
+        assert same(got, want), (sl, sh, it)
+
+
+@pytest.mark.parametrize("n", [65, 130, 513, 2100])
+def test_batch_stack_workgroup_per_pixel(ctx, ctx_deep, oracle, n):
+    """scms_deep_kernel (the route for more than 2048 frames; 2100 through the default dispatch, the others through a context
+    created under AB_BATCH_DEEP_FROM=64), plain and fused with calibration + normalisation"""
+    c = ctx if n > 2048 else ctx_deep
+    shape = (7, 11) if n > 2048 else (19, 37)
+    fr = frames_with_trouble(n, shape, 40 + n)
+    for sl, sh, it in ((2.5, 3.0, 5), (1.0, 1.0, 2), (3.0, 2.0, 1), (2.5, 3.0, 0)):
+        want, wrej = oracle.sigma_clipped_mean_stack(fr, sl, sh, it)
+        got, rej = c.sigma_clipped_mean_stack(fr, BatchStackConfig(sl, sh, it))
+        assert rej == wrej, (sl, sh, it)
+        assert same(got, want), (sl, sh, it)
+    if n <= 130:
+        rng = np.random.default_rng(n)
+        lights = [rng.normal(400 + 3 * k, 12, shape).astype(np.float32) for k in range(n)]
+        lights[2][rng.random(shape) < 0.05] += 500.0
+        lights[1][5, 5] = np.nan
+        bias = rng.normal(100, 2, shape).astype(np.float32)
+        flat = rng.normal(1.0, 0.05, shape).astype(np.float32)
+        flat[3, 3] = 0.0
+        for normalize in (True, False):
+            want, wrej, wmean, wstd = oracle.run_batch_channel(lights, bias, None, flat, normalize=normalize)
+            got, rej, mean, std = c.run_batch_channel(lights, bias, None, flat, BatchStackConfig(normalize_before_stack=normalize))
+            assert rej == wrej and same(got, want), normalize
+
+
 @pytest.mark.parametrize("normalize", [True, False])
 def test_deep_batch_channel_fused(ctx, oracle, normalize):
     rng = np.random.default_rng(70)
@@ -214,8 +252,6 @@ def test_pipeline_errors(ctx):
         ctx.run_batch_pipeline([("R", [])])
     with pytest.raises(AstroBurstError, match=r"Channel 'G': frame 1 has shape \(8, 9\) but frame 0 has \(8, 8\). All frames must match."):
         ctx.run_batch_pipeline([("G", [z, np.zeros((8, 9), np.float32)])])
-    with pytest.raises(AstroBurstError, match="513 frames"):
-        ctx.sigma_clipped_mean_stack([z] * 513)
 
 
 def test_full_size_batch_channel(ctx):

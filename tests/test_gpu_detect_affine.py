@@ -405,3 +405,87 @@ def test_chained_detection_gives_the_same_transform(tmp_path):
         out.append(line[0])
     assert out[0] == out[1]
     assert "affine" in out[0]
+
+
+def _crowded_frames(kind, rows, cols, shifts, seed):
+    """Frames whose brightest several hundred components do NOT become the matcher's stars:
+    "spikes": 700 components of three pixels with all their flux in the middle one (FWHM < 0.5: star_detection.rs:160-163 drops them),
+    "clusters": 130 crosses of five 3-pixel components whose centroids sit 2.4 - 2.8 px from the middle one (the 3 px dedup, :217-248, keeps
+    one in five).  Behind them ~260 ordinary, fainter stars.  The device-side selection of the brightest 480 candidates
+    (comp_select_many_kernel) cannot yield 120 stars from either: the frame goes through the full path again."""
+    from astroburst_amd import synth
+    rng = np.random.default_rng(seed)
+    y, x, flux = synth.star_catalog(rows, cols, 260, seed=seed)
+    cat = (y, x, flux * 12.0)
+    ny, nx = (rows - 120) // 12, (cols - 120) // 12
+    cells = rng.permutation(ny * nx)[:700]
+    cy, cx = 20 + 12 * (cells // nx), 20 + 12 * (cells % nx)
+    amp = rng.uniform(30000.0, 60000.0, cells.size)
+    frames = []
+    for k, (dy, dx) in enumerate(shifts):
+        f = synth.make_frame(rows, cols, k, cat=cat, shift=(float(dy), float(dx)), bad_patch_rate=0.0, cosmic_rate=0.0).numpy().copy()
+        oy, ox = int(round(dy)), int(round(dx))
+        # a saturated 40 x 40 patch: more than 0.1 % of the pixels, so normalize_for_detection's 99.9th percentile (affine.rs:24-53)
+        # sits on it and nothing else is clamped -- the components below keep their distinct fluxes
+        f[rows - 70 + oy:rows - 30 + oy, cols - 75 + ox:cols - 35 + ox] = 65000.0
+        if kind == "spikes":
+            for j in range(cells.size):
+                yy, xx = cy[j] + oy, cx[j] + ox
+                f[yy, xx] += amp[j]
+                f[yy, xx - 1] += 0.004 * amp[j]
+                f[yy, xx + 1] += 0.004 * amp[j]
+        else:
+            # five 3-pixel components: the middle one and four whose centroids sit 2.4 - 2.8 px from its centroid, one empty pixel apart
+            parts = (([(0, 0), (0, 1), (1, 0)], 1.0), ([(0, -2), (1, -2), (1, -3)], 0.99), ([(0, 3), (1, 3), (2, 3)], 0.98),
+                     ([(-2, 0), (-2, 1), (-2, 2)], 0.97), ([(3, -1), (3, 0), (3, 1)], 0.96))
+            for j in range(130):
+                yy, xx = cy[j] + oy, cx[j] + ox
+                for pix, a in parts:
+                    for (qy, qx) in pix:
+                        f[yy + qy, xx + qx] += a * amp[j]
+        frames.append(np.ascontiguousarray(f))
+    return frames
+
+
+@pytest.mark.parametrize("kind", ["spikes", "clusters"])
+def test_registration_when_the_brightest_components_are_not_stars(ctx, oracle, kind):
+    """VERDICT r4 item 1a's gate: the grouped registration sends the brightest 480 candidates per frame; when those do not hold 120
+    stars the whole list decides (the full path).  Five targets (one group of four + one) must equal the frame-by-frame calls --
+    which always take every record -- exactly, and the oracle pair by pair."""
+    import torch
+    rows, cols = 900, 1100
+    shifts = [(0, 0), (3, -2), (-4, 6), (0, 0), (7, 1), (-2, -5)]
+    frames = _crowded_frames(kind, rows, cols, shifts, seed=31 if kind == "spikes" else 32)
+    ref, tgts = frames[0], frames[1:]
+    # the premise: the full star list of the reference frame is long and its brightest 480 candidates hold fewer than 120 stars
+    stars, _, _ = ctx.detect_stars(ctx.normalize_for_detection(ref), 3.5)
+    assert len(stars) >= 120
+    batch = ctx.register_frames(torch.from_numpy(ref).cuda(), [torch.from_numpy(t).cuda() for t in tgts], num_threads=8)
+    for t, b in zip(tgts, batch):
+        single = ctx.align_channel_affine(ref, t, num_threads=8)
+        assert (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px) == \
+               (single.method, single.matched_stars, single.inliers, single.transform, single.residual_px)
+    want = oracle.align_channel_affine(ref, tgts[0], num_threads=8)
+    assert batch[0].method == want.method and batch[0].matched_stars == want.matched_stars and batch[0].inliers == want.inliers
+    assert np.allclose(batch[0].transform, want.transform, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("shape", [(512, 640), (600, 800), (257, 1000), (1100, 2048)])
+def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, shape):
+    """Round 5 changed how a GROUP of frames is detected: tile-local union-find in LDS + a border pass (widths that are multiples of
+    32: 640, 800, 2048; 1000 keeps the two-pass form), approximate flux in comp_stats, the brightest 480 candidates selected on the
+    device, moments for those only.  A context created under AB_LABEL_LEGACY=1 AB_DETECT_FULL_RECORDS=1 runs round 4's forms: the
+    transforms, star counts and inliers of nine targets (two groups of four + one) must be IDENTICAL."""
+    import torch
+    from astroburst_amd import synth
+    rows, cols = shape
+    y, x, flux = synth.star_catalog(rows, cols, int(900 * rows * cols / 1e6) + 150, seed=rows)
+    cat = (y, x, flux * 30.0)
+    ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=1e-4).cuda()
+    tgts = [synth.make_frame(rows, cols, k + 1, cat=cat, shift=(1.25 * k - 4.0, 3.0 - 0.8 * k), bad_patch_rate=1e-6, cosmic_rate=1e-4).cuda()
+            for k in range(9)]
+    new = ctx.register_frames(ref, tgts, num_threads=8)
+    old = ctx_r4_detect.register_frames(ref, tgts, num_threads=8)
+    for a, b in zip(new, old):
+        assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
+    assert sum(a.method in ("affine", "rigid") for a in new) >= 7

@@ -80,6 +80,11 @@ def test_create_master(ctx, oracle):
     assert np.array_equal(ctx.create_master("bias", many), oracle.create_master("bias", many))
     assert np.array_equal(ctx.create_master("dark", many, master_bias=bias[:40, :52].copy()),
                           oracle.create_master("dark", many, master_bias=bias[:40, :52].copy()))
+    lots = [rng.uniform(900, 1100, (12, 20)).astype(np.float32) for _ in range(600)]   # > 512 frames (calibration.rs:297-318 has no limit)
+    lots[5][1, 2] = np.nan
+    assert np.array_equal(ctx.create_master("bias", lots), oracle.create_master("bias", lots))
+    assert np.allclose(ctx.create_master("flat", lots, master_bias=bias[:12, :20].copy()),
+                       oracle.create_master("flat", lots, master_bias=bias[:12, :20].copy()), rtol=1.2e-7, atol=0)
     with pytest.raises(AstroBurstError, match="No dark frames provided"):
         ctx.create_master("dark", [])
     with pytest.raises(AstroBurstError, match=r"Dimension mismatch: expected \(200, 311\), got \(200, 310\)"):

@@ -203,3 +203,96 @@ def test_a_stale_segment_of_the_same_name_does_not_split_the_job(tmp_path):
         assert p.returncode == 0, o.decode(errors="replace")[-3000:]
     for r in (0, 1):
         assert float(np.load(os.path.join(tmp_path, f"rank{r}.npz"))["total"][0]) == 3.0
+
+
+def test_a_stale_segment_without_a_new_rank_0_times_out(tmp_path):
+    """ADVICE r4 (comm.hip:475): the retry on a dead job's segment used to re-enter the init call recursively with a fresh clock on
+    every pass, so a non-zero rank whose own rank 0 never starts span for ever.  The retry is a loop on ONE clock now: the rank
+    gives up after AB_COMM_TIMEOUT_MS with AB_ERR_COMM and leaves the stale segment alone."""
+    import signal
+    name = f"z{uuid.uuid4().hex[:12]}"
+    path = f"/dev/shm/abcomm_{name}"
+
+    def start(rank, timeout_ms):
+        return subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), name, "2", str(rank), "sum", str(tmp_path)],
+                                env=dict(os.environ, AB_COMM_TIMEOUT_MS=str(timeout_ms)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    a0 = start(0, 60000)
+    t0 = time.time()
+    while not os.path.exists(path) and time.time() - t0 < 120:
+        time.sleep(0.05)
+    assert os.path.exists(path), "job A's rank 0 never created its segment"
+    time.sleep(1.0)
+    a0.send_signal(signal.SIGKILL)
+    a0.wait()
+    try:
+        b1 = start(1, 3000)
+        try:
+            o, _ = b1.communicate(timeout=90.0)      # (a cold `import torch` + context creation come before the 3 s wait)
+        except subprocess.TimeoutExpired:
+            b1.kill()
+            pytest.fail("rank 1 still waits for a dead job's segment: the retry never times out")
+        text = o.decode(errors="replace")
+        assert b1.returncode != 0 and "dead job's segment" in text, text[-3000:]
+        assert os.path.exists(path)                  # not this rank's to remove
+    finally:
+        if os.path.exists(path):
+            os.unlink(path)
+
+
+@pytest.mark.parametrize("nranks", [3, 8])
+def test_row_bands_that_ingest_bands(tmp_path, ctx, oracle, nranks):
+    """VERDICT r4 missing 3 / SURVEY 8e: "GPU g owns rows [g R / G, (g + 1) R / G) of every frame (+ halo) ... each GPU ingests
+    N P / G pixels".  Every rank is GIVEN whole frames only for the targets it detects (i mod G) and the reference; of every target it
+    uploads just the rows ab_shard_source_rows names for its band (its rows + the halo of the exchanged transforms) and warps them
+    with ab_warp_image_rows_from_band.  The reassembled stack must equal the single-level oracle -- estimate on whole frames, warp
+    whole frames, stack -- bit for bit, the rejected count too, and a rank's resident target bytes stay near 1 / G of the frame set."""
+    import torch
+    res = spawn(nranks, "bands", tmp_path, timeout=600)
+    ref, tgts, truth = mw.band_frames()
+    rows, cols = ref.shape
+    single = ctx.register_frames(ref.cuda(), [t.cuda() for t in tgts], num_threads=8)
+    want_t = np.array([r.transform for r in single])
+    assert all(r.method in ("affine", "rigid") for r in single)
+    assert np.abs(want_t - np.array(truth)).max() < 0.5                 # (the estimates recover the generating transforms)
+    warped = [ref.numpy()] + [oracle.warp_image(t.numpy(), tr, rows, cols) for t, tr in zip(tgts, want_t)]
+    want, want_rej = oracle.stack_images(warped, 3.0, 3.0, 5)
+    frame_set_bytes = len(tgts) * rows * cols * 4
+    for r, got in enumerate(res):
+        assert np.array_equal(got["transforms"], want_t), r             # exchanged bit for bit
+        assert np.array_equal(got["full"], want, equal_nan=True), r
+        assert int(got["rej"][0]) == want_rej, r
+        s0, sn, row0, nr = (int(v) for v in got["src"])
+        assert s0 <= row0 and s0 + sn >= row0 + nr and sn <= nr + 2 * 24   # rows + a halo of at most ~9 px shift + 0.6 deg x 640 / 2 + 3
+        assert int(got["resident"][0]) == len(tgts) * sn * cols * 4 <= frame_set_bytes * (1.0 / nranks + 0.15)
+        assert nr == 0 or int(got["short_band_code"][0]) == 1, r           # AB_ERR_INVALID: a band lacking rows is refused
+
+
+def test_warp_source_rows_is_exact(ctx, oracle):
+    """ab_warp_source_rows names exactly the hull of the rows a band of warp_image reads: the band warped from those rows equals the
+    rows of the whole-frame warp, and with one row less at either end the call is refused (when that row is really needed)."""
+    import torch
+    from astroburst_amd import AstroBurstError
+    rng = np.random.default_rng(3)
+    rows, cols = 300, 421
+    img = rng.normal(100, 10, (rows, cols)).astype(np.float32)
+    dev = torch.from_numpy(img).cuda()
+    cases = [(1.0, 0.0, 0.0, 0.0, 1.0, 0.0), (1.0, 0.0, 3.25, 0.0, 1.0, -7.5), (0.9998, -0.02, 4.0, 0.02, 0.9998, -6.0),
+             (1.0, 0.0, 0.0, 0.0, 1.0, 500.0), (1.0, 0.0, 0.0, 0.0, 1.0, -500.0), (1.0, 0.0, 0.0, 0.3, 0.5, 20.0), (1.0, 0.0, 0.0, 0.0, -1.0, 299.0)]
+    for tr in cases:
+        whole = oracle.warp_image(img, tr, rows, cols)
+        for row0, nrows in ((0, 40), (130, 37), (299, 1), (260, 40)):
+            s0, sn = ctx.warp_source_rows(tr, rows, cols, cols, row0, nrows)
+            out = torch.full((nrows, cols), -1.0, device="cuda")
+            band = dev[s0:s0 + sn].contiguous() if sn else torch.empty((0, cols), device="cuda")
+            ctx.warp_image_rows_from_band(band, s0, rows, tr, rows, row0, out)
+            assert np.array_equal(out.cpu().numpy(), whole[row0:row0 + nrows]), (tr, row0)
+            if sn == 0:
+                assert not whole[row0:row0 + nrows].any()
+                continue
+            # the hull is tight: its first and its last row are read by some pixel (interior rows of the frame only: an edge row
+            # may be in the hull through the clamp without changing a value, so the check is on the refusal, not on pixels)
+            for cut0, cutn in ((s0 + 1, sn - 1), (s0, sn - 1)):
+                if cutn <= 0:
+                    continue
+                with pytest.raises(AstroBurstError, match="read source rows"):
+                    ctx.warp_image_rows_from_band(dev[cut0:cut0 + cutn].contiguous(), cut0, rows, tr, rows, row0, out)

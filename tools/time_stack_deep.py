@@ -9,10 +9,11 @@ import torch  # noqa: E402
 from astroburst_amd import Context  # noqa: E402
 
 ctx = Context(0)
+SIDE = int(os.environ.get("SIDE", "4096"))
 g = torch.Generator(device="cuda").manual_seed(1)
 for n in [int(v) for v in os.environ.get("N_LIST", "64,96,128,256").split(",")]:
-    fr = [torch.randn((4096, 4096), device="cuda", generator=g) * 15.0 + 1200.0 for _ in range(n)]
-    out = torch.empty((4096, 4096), device="cuda")
+    fr = [torch.randn((SIDE, SIDE), device="cuda", generator=g) * 15.0 + 1200.0 for _ in range(n)]
+    out = torch.empty((SIDE, SIDE), device="cuda")
     ctx.stack_sigma_clip(fr, out=out, want_rejected=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -20,5 +21,5 @@ for n in [int(v) for v in os.environ.get("N_LIST", "64,96,128,256").split(",")]:
         ctx.stack_sigma_clip(fr, out=out, want_rejected=False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
-    print(f"{n:4d} frames x 4096^2: {ms:8.2f} ms  ({n * 4096 * 4096 * 4 / ms / 1e9:.2f} TB/s of samples)  kernels {ctx.stack_last_kernel_ms():.2f} ms")
+    print(f"{n:4d} frames x {SIDE}^2: {ms:8.2f} ms  ({n * SIDE * SIDE * 4 / ms / 1e9:.2f} TB/s of samples)  kernels {ctx.stack_last_kernel_ms():.2f} ms")
     del fr
