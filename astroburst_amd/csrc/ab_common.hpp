@@ -134,9 +134,8 @@ struct ab_ctx {
     // detect.hip's round-4 forms, kept as cross-checks (read from AB_LABEL_LEGACY / AB_DETECT_FULL_RECORDS when the context is created,
     // inherited by its workers): two-pass labelling instead of the tile-local union-find; every component's record instead of the
     // device-side selection of the brightest
-    bool label_legacy = false, detect_full_records = false;
+    bool label_legacy = false, detect_full_records = false, detect_midjoin = false;
     uint64_t det_select_fallbacks = 0;  // detect.hip: frames whose device-side selection of the brightest components had to be redone in full
-    bool det_group_ws = false;  // detect.hip: the detection workspaces were last carved for a group of frames
     unsigned int *tile_fail[2] = {nullptr, nullptr};
     size_t tile_fail_cap[2] = {0, 0};
     // progress / cancel (infra/progress.rs:39-74): the callback is serialised by progress_mu (frame workers tick it too);
@@ -228,6 +227,7 @@ int ab_catch(ab_ctx *ctx, const char *fn);
 #define AB_CATCH_NOCTX catch (...) { return ab_catch(nullptr, __func__); }
 
 // Scratch arena: returns a device pointer valid until the next ab_scratch() call with a larger size.
+extern thread_local std::string *ab_tls_error_sink;  // see ab_set_error
 int ab_scratch(ab_ctx *ctx, size_t bytes, void **out);
 int ab_pinned(ab_ctx *ctx, size_t bytes, void **out);
 // persistent workspace `slot` of at least `bytes` (contents are undefined after a growth)

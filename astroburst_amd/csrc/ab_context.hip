@@ -9,12 +9,20 @@
 #include <new>
 #include <thread>
 
+// A helper thread that works on a context another thread is calling into (detect.hip's feeder) must not write that context's
+// error slot: it points this at a string of its own, and whoever waits for the helper reports the message.
+thread_local std::string *ab_tls_error_sink = nullptr;
+
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
+    if (ab_tls_error_sink) {
+        *ab_tls_error_sink = buf;
+        return code;
+    }
     if (ctx) {
         std::lock_guard<std::mutex> lk(ctx->err_mu);
         ctx->err = buf;
@@ -117,6 +125,7 @@ int ab_ctx_create(int device_id, ab_ctx **out) try {
     ctx->stack_exact = ex && ex[0] == '1';
     ctx->label_legacy = getenv("AB_LABEL_LEGACY") != nullptr;
     ctx->detect_full_records = getenv("AB_DETECT_FULL_RECORDS") != nullptr;
+    ctx->detect_midjoin = getenv("AB_DETECT_MIDJOIN") != nullptr;
     if (const char *e = getenv("AB_STACK_DEEP_FROM")) ctx->stack_deep_from = std::min(4096, std::max(64, atoi(e)));
     if (const char *e = getenv("AB_BATCH_DEEP_FROM")) ctx->batch_deep_from = std::min(2048, std::max(64, atoi(e)));
     if (const char *rw = getenv("AB_REGISTER_WORKERS")) ctx->register_workers = std::max(1, atoi(rw));
@@ -435,6 +444,7 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
         wc->parent = ctx;
         wc->label_legacy = ctx->label_legacy;  // (the parent's choices, not the environment's at the time the pool grows)
         wc->detect_full_records = ctx->detect_full_records;
+        wc->detect_midjoin = ctx->detect_midjoin;
         ctx->workers.push_back(wc);
     }
     if (drain_caller_stream) AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // whatever the caller queued on ctx (its frames, shared tables) is complete

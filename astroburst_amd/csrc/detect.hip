@@ -451,9 +451,17 @@ __device__ __forceinline__ void lds_union(int *lab, int a, int b) {
         a = old;
     }
 }
+// The lists are split into kRegions REGIONS (tile t appends to region t mod kRegions, each with its own counter 256 bytes from the
+// next and its own segment of the list): one reservation per tile on ONE counter was 8192 same-address atomics-with-return per
+// frame -- ~12 ns each, serialised in the L2: 100 of the kernel's 110 us (the first version measured 53 us per frame against 34
+// for the two passes it replaces).  The consumers walk region by region (blockIdx.x mod kRegions).
+constexpr int kRegions = 64, kRegionPitch = 64;  // counters: lcnt[r * kRegionPitch] = labelled, lcnt[(kRegions + r) * kRegionPitch] = border
 __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
-                                                int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist, unsigned int *nlab,
-                                                int *__restrict__ blist, unsigned int *nborder) {
+                                                int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist_all, size_t plist_stride,
+                                                int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt) {
+    const int region = (int)(blockIdx.x % kRegions);
+    int *__restrict__ plist = plist_all + (size_t)region * plist_stride, *__restrict__ blist = blist_all + (size_t)region * blist_stride;
+    unsigned int *nlab = lcnt + region * kRegionPitch, *nborder = lcnt + (kRegions + region) * kRegionPitch;
     __shared__ unsigned int tmask[kTileH][kTileW / 32];
     __shared__ int lab[kTileH * kTileW];
     __shared__ unsigned int n_found, n_edge, base_found, base_edge;
@@ -550,9 +558,9 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
 
 // cross-tile unions of the border pixels (the forward neighbours that lie in another tile), on the global forest
 __device__ __forceinline__ void label_border_body(int rows, int cols, int *parent, const unsigned int *__restrict__ mask, const int *__restrict__ blist,
-                                                  const unsigned int *__restrict__ nborder) {
+                                                  const unsigned int *__restrict__ nborder, unsigned int bid, unsigned int nblk) {
     const unsigned int n = *nborder;
-    for (unsigned int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
+    for (unsigned int k = bid * 256 + threadIdx.x; k < n; k += nblk * 256) {
         const int i = blist[k];
         const int r = i / cols, c = i - r * cols;
         const int tr = r / kTileH, tc = c / kTileW;
@@ -587,13 +595,14 @@ struct CompRec {  // what the host needs to finish one star (star_detection.rs:1
 constexpr int kRootsBlock = 256;
 __device__ __forceinline__ void roots_body(const int *__restrict__ parent, const int *__restrict__ plist,
                                                             const unsigned int *__restrict__ nlab, int *__restrict__ roots, int *__restrict__ cid,
-                                                            unsigned int *nroots, unsigned int cap) {
+                                                            unsigned int *nroots, unsigned int cap, CompStat *__restrict__ st = nullptr,
+                                                            unsigned int bid = blockIdx.x, unsigned int nblk = gridDim.x) {
     __shared__ unsigned int wave_cnt[kRootsBlock / 64], block_base;
     const unsigned int n = *nlab;
-    const unsigned int rounds = (n + gridDim.x * kRootsBlock - 1) / (gridDim.x * kRootsBlock);  // uniform trip count (barriers inside)
+    const unsigned int rounds = (n + nblk * kRootsBlock - 1) / (nblk * kRootsBlock);  // uniform trip count (barriers inside)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (unsigned int it = 0; it < rounds; ++it) {
-        const unsigned int k = (it * gridDim.x + blockIdx.x) * kRootsBlock + threadIdx.x;
+        const unsigned int k = (it * nblk + bid) * kRootsBlock + threadIdx.x;
         int i = -1;
         bool is = false;
         if (k < n) {
@@ -615,6 +624,7 @@ __device__ __forceinline__ void roots_body(const int *__restrict__ parent, const
             if (pos < cap) {
                 roots[pos] = i;
                 cid[i] = (int)pos;
+                if (st) st[pos] = CompStat{0, 0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff, 0.0};  // (the chain without a host join: no comp_init launch)
             }
         }
         __syncthreads();  // wave_cnt / block_base are rewritten next round
@@ -631,13 +641,13 @@ template <bool FLUX>
 __device__ __forceinline__ void comp_stats_body(int rows, int cols, int *parent, const int *__restrict__ cid, CompStat *st,
                                                          const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
                                                          const float *__restrict__ img = nullptr, int64_t ld = 0, const ab_pixel_xf xf = ab_pixel_xf(),
-                                                         double bg_median = 0.0) {
+                                                         double bg_median = 0.0, unsigned int bid = blockIdx.x, unsigned int nblk = gridDim.x) {
     const unsigned int n = *nlab;
     const int lane = threadIdx.x & 63;
     // wave-uniform trip count (the shuffles below need every lane); consecutive list entries are mostly row neighbours
     // of one component, so each RUN of equal roots inside a wave is folded by shuffles and only its first lane issues
     // the six atomics (per-pixel atomics on a component's record serialise: 46 us per frame)
-    for (unsigned int k0 = blockIdx.x * 256 + (threadIdx.x & ~63); k0 < n; k0 += gridDim.x * 256) {
+    for (unsigned int k0 = bid * 256 + (threadIdx.x & ~63); k0 < n; k0 += nblk * 256) {
         const unsigned int k = k0 + lane;
         const bool valid = k < n;
         int root = -1 - lane, i = 0;  // invalid lanes: pairwise distinct pseudo-roots, never equal to a real one
@@ -943,7 +953,12 @@ struct DetGroup {
     CompStat *st[kGroupMax];
     CompRec *rec[kGroupMax];
     unsigned int ncomp[kGroupMax];
-    int *blist[kGroupMax];            // border pixels of the tile-local labelling (label_tile_many_kernel); counters[f][3] = their number
+    unsigned int comp_cap;            // chained form (no host join before the component kernels): capacity of st[f]; ncomp is read on the device
+    int chained;
+    int *blist[kGroupMax];            // border pixels of the tile-local labelling (label_tile_many_kernel), kRegions segments like plist
+    unsigned int *lcnt[kGroupMax];    // its 2 x kRegions list counters, kRegionPitch words apart
+    size_t plist_stride, blist_stride;  // ints per region segment
+    int tiled;
     unsigned int *sel[kGroupMax];     // indices of the selected components (comp_select_many_kernel), kSelCap each
     unsigned int *selout[kGroupMax];  // PINNED HOST: {selected, candidates} of the frame
 };
@@ -962,110 +977,164 @@ __device__ __forceinline__ unsigned int sel_key(const CompStat &c) {  // 0 = can
     const bool ok = c.npix >= 3 && c.npix <= 5000 && c.first_interior != 0x7fffffff && c.flux > 0.0;
     return ok ? (unsigned int)((unsigned long long)__double_as_longlong(c.flux) >> 32) + 1u : 0u;
 }
-// one LDS atomic per DISTINCT bin of a wave (the faint crowd shares its exponent: ten thousand same-address atomics otherwise)
-__device__ __forceinline__ void hist_add_matched(unsigned int *hist, unsigned int bin, bool active) {
-    unsigned long long todo = __ballot(active);
-    while (todo) {  // wave-uniform
-        const int leader = __builtin_ctzll(todo);
-        const unsigned int b = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
-        const unsigned long long same = __ballot(active && bin == b) & todo;
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[b], (unsigned int)__builtin_popcountll(same));
-        todo &= ~same;
-    }
+// 256 threads (a 1024-thread workgroup waits for sixteen free wave slots on one CU while the batch's other kernels hold them: 100 - 170 us
+// per launch inside a batch for ~20 us of work) and TWO passes over the component table: pass A histograms a coarse, monotone digit
+// of every candidate's key (sel_digit: 2048 bins of 1/16 octave of flux between 2^-64 and 2^64, clamped outside) and finds the bin d0
+// that holds the kSelKeep-th brightest; pass B emits everything in a brighter bin straight away and copies the (key, index) pairs of
+// bin d0 -- a few hundred -- into LDS, where a radix select on the full key (11 / 11 / 10 bits) finds the cut.  A bin d0 with more
+// than kSelSub members (thousands of components within 4 % of the cut) is left out altogether: fewer than kSelKeep are selected
+// and the host's rule (candidates remain, fewer than max_keep stars) decides whether the frame is redone in full.
+constexpr int kSelThreads = 256, kSelSub = 2048;
+__device__ __forceinline__ unsigned int sel_digit(unsigned int k) {  // non-decreasing in k; k != 0
+    constexpr int kBase = (1023 - 64) << 20;  // the high word of 2^-64
+    const int d = ((int)k - kBase) >> 16;
+    return (unsigned int)(d < 0 ? 0 : (d > 2047 ? 2047 : d));
 }
-__global__ __launch_bounds__(1024) void comp_select_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
+__device__ __forceinline__ void sel_find_digit(const unsigned int *hist, int nb, unsigned int want, int tid, unsigned int *digit, unsigned int *above) {
+    // one wave walks the digits from the top: the digit that holds the `want`-th largest key and the count strictly above it
+    unsigned int run = 0, found = 0, ab = 0;
+    bool done = false;
+    for (int base = nb - 64; base >= 0 && !done; base -= 64) {
+        const unsigned int c = hist[base + 63 - tid];  // lane 0 = the highest digit of the chunk
+        unsigned int incl = c;                          // inclusive prefix over lanes 0 .. tid
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off, 64);
+            if (tid >= off) incl += o;
+        }
+        const unsigned long long hit = __ballot(run + incl >= want);
+        if (hit) {
+            const int l = __builtin_ctzll(hit);
+            ab = run + __shfl(incl, l, 64) - __shfl(c, l, 64);
+            found = (unsigned int)(base + 63 - l);
+            done = true;
+        } else {
+            run += __shfl(incl, 63, 64);
+        }
+    }
+    *digit = found;
+    *above = ab;
+}
+__global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.x, tid = threadIdx.x;
-    const unsigned int n = g.ncomp[f];
+    unsigned int n = g.ncomp[f];
+    if (g.chained) {
+        n = g.counters[f][0];
+        if (tid == 0) g.selout[f][2] = n;     // the host's only look at the component count
+        if (n > g.comp_cap) n = 0;            // table overflow: nothing is selected, the host redoes the frame in full
+    }
     const CompStat *__restrict__ st = g.st[f];
     unsigned int *__restrict__ sel = g.sel[f];
     __shared__ unsigned int hist[2048];
-    __shared__ unsigned int s_prefix, s_mask, s_want, s_ncand, s_ge, s_gt, s_count;
-    if (tid == 0) {
-        s_prefix = 0;
-        s_mask = 0;
-        s_want = kSelKeep;
-        s_ncand = s_ge = s_gt = s_count = 0;
-    }
-    unsigned int thr = 1;  // select every candidate unless there are more than kSelKeep
-    // ---- candidates ----
-    {
-        unsigned int mine = 0;
-        for (unsigned int i = tid; i < n; i += 1024) mine += sel_key(st[i]) ? 1u : 0u;
-        __syncthreads();
+    __shared__ unsigned int sub_key[kSelSub], sub_idx[kSelSub];
+    __shared__ unsigned int s_ncand, s_d0, s_above, s_count, s_nsub, s_prefix, s_want, s_ge;
+    for (unsigned int b = tid; b < 2048; b += kSelThreads) hist[b] = 0;
+    if (tid == 0) s_ncand = s_d0 = s_above = s_count = s_nsub = s_prefix = s_want = s_ge = 0;
+    __syncthreads();
+    const unsigned int trips = (n + kSelThreads - 1) / kSelThreads;  // block-uniform (the ballots below need whole waves)
+    // ---- pass A: level-0 histogram of the candidates ----
+    // (kSelIlp records in flight per thread: one thread's 40 dependent round trips to L2 were the kernel -- 150 us inside a batch)
+    constexpr unsigned int kSelIlp = 8;
+    unsigned int mine = 0;
+    for (unsigned int t0 = 0; t0 < trips; t0 += kSelIlp) {
+        unsigned int k[kSelIlp];
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
-        if ((tid & 63) == 0 && mine) atomicAdd(&s_ncand, mine);
-        __syncthreads();
+        for (unsigned int u = 0; u < kSelIlp; ++u) {
+            const unsigned int i = (t0 + u) * kSelThreads + tid;
+            k[u] = i < n ? sel_key(st[i]) : 0u;
+        }
+#pragma unroll
+        for (unsigned int u = 0; u < kSelIlp; ++u) {
+            if (t0 + u >= trips) break;  // block-uniform
+            mine += k[u] ? 1u : 0u;
+            if (k[u]) atomicAdd(&hist[sel_digit(k[u])], 1u);  // (bins of 1/16 octave: a wave's 64 keys rarely share one -- plain LDS atomics;
+                                                               // one ballot round per DISTINCT bin, hist_add_matched, was 150 us of this kernel)
+        }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((tid & 63) == 0 && mine) atomicAdd(&s_ncand, mine);
+    __syncthreads();
     const unsigned int ncand = s_ncand;
-    if (ncand > kSelKeep) {  // block-uniform
-        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-#pragma unroll
-        for (int lv = 0; lv < 3; ++lv) {
-            const unsigned int nb = 1u << bits[lv];
-            for (unsigned int b = tid; b < nb; b += 1024) hist[b] = 0;
-            __syncthreads();
-            const unsigned int prefix = s_prefix, mask = s_mask;
-            for (unsigned int i0 = 0; i0 < n; i0 += 1024) {  // block-uniform trip count: the ballots need whole waves
-                const unsigned int i = i0 + tid;
-                const unsigned int k = i < n ? sel_key(st[i]) : 0u;
-                hist_add_matched(hist, (k >> shifts[lv]) & (nb - 1), k && (k & mask) == prefix);
-            }
-            __syncthreads();
-            if (tid < 64) {  // one wave walks the digits from the top: the digit that holds the `want`-th largest key
-                unsigned int want = s_want, run = 0, found = 0;
-                bool done = false;
-                for (int base = (int)nb - 64; base >= 0 && !done; base -= 64) {
-                    const unsigned int c = hist[base + 63 - tid];  // lane 0 = the highest digit of the chunk
-                    unsigned int incl = c;                          // inclusive prefix over lanes 0 .. tid
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const unsigned int o = __shfl_up(incl, off, 64);
-                        if (tid >= off) incl += o;
-                    }
-                    const unsigned long long hit = __ballot(run + incl >= want);
-                    if (hit) {
-                        const int l = __builtin_ctzll(hit);
-                        const unsigned int before = run + __shfl(incl, l, 64) - __shfl(c, l, 64);
-                        found = (unsigned int)(base + 63 - l);
-                        want -= before;
-                        done = true;
-                    } else {
-                        run += __shfl(incl, 63, 64);
-                    }
-                }
-                if (tid == 0) {
-                    s_prefix = prefix | (found << shifts[lv]);
-                    s_mask = mask | ((nb - 1) << shifts[lv]);
-                    s_want = want;
-                }
-            }
-            __syncthreads();
+    const bool all = ncand <= kSelKeep;  // block-uniform: select every candidate
+    if (!all && tid < 64) {
+        unsigned int d0, above;
+        sel_find_digit(hist, 2048, kSelKeep, tid, &d0, &above);
+        if (tid == 0) {
+            s_d0 = d0;
+            s_above = above;
         }
-        thr = s_prefix;
-        unsigned int ge = 0, gt = 0;
-        for (unsigned int i = tid; i < n; i += 1024) {
-            const unsigned int k = sel_key(st[i]);
-            ge += k >= thr ? 1u : 0u;
-            gt += k > thr ? 1u : 0u;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            ge += __shfl_xor(ge, off, 64);
-            gt += __shfl_xor(gt, off, 64);
-        }
-        if ((tid & 63) == 0) {
-            if (ge) atomicAdd(&s_ge, ge);
-            if (gt) atomicAdd(&s_gt, gt);
-        }
-        __syncthreads();
-        if (s_ge > kSelCap) thr += 1;  // a crowd of equal keys at the cut: take what is strictly brighter (fewer than kSelKeep)
     }
-    for (unsigned int i = tid; i < n; i += 1024) {
-        const unsigned int k = sel_key(st[i]);
-        if (k >= thr) {
-            const unsigned int at = atomicAdd(&s_count, 1u);
-            if (at < kSelCap) sel[at] = i;
+    __syncthreads();
+    const unsigned int d0 = s_d0, above = s_above;
+    // ---- pass B: emit what is brighter than bin d0, collect bin d0 ----
+    for (unsigned int t0 = 0; t0 < trips; t0 += kSelIlp) {
+        unsigned int k[kSelIlp];
+#pragma unroll
+        for (unsigned int u = 0; u < kSelIlp; ++u) {
+            const unsigned int i = (t0 + u) * kSelThreads + tid;
+            k[u] = i < n ? sel_key(st[i]) : 0u;
+        }
+#pragma unroll
+        for (unsigned int u = 0; u < kSelIlp; ++u) {
+            const unsigned int i = (t0 + u) * kSelThreads + tid;
+            if (!k[u]) continue;
+            const unsigned int dg = sel_digit(k[u]);
+            if (all || dg > d0) {
+                const unsigned int at = atomicAdd(&s_count, 1u);
+                if (at < kSelCap) sel[at] = i;
+            } else if (dg == d0) {
+                const unsigned int at = atomicAdd(&s_nsub, 1u);
+                if (at < (unsigned int)kSelSub) {
+                    sub_key[at] = k[u];
+                    sub_idx[at] = i;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned int nsub = s_nsub;
+    if (!all && nsub <= (unsigned int)kSelSub) {  // block-uniform: resolve the remaining 21 bits inside bin d0, in LDS
+        const unsigned int want0 = kSelKeep - above;  // >= 1: the kSelKeep-th brightest lies in bin d0
+        const unsigned int strips = (nsub + kSelThreads - 1) / kSelThreads;
+        unsigned int prefix = 0, mask = 0, want = want0;
+        const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+        for (int lv = 0; lv < 3; ++lv) {  // radix select of the want0-th largest FULL key among bin d0's members
+            const unsigned int nb = 1u << bits[lv];
+            for (unsigned int b = tid; b < nb; b += kSelThreads) hist[b] = 0;
+            __syncthreads();
+            for (unsigned int t = 0; t < strips; ++t) {
+                const unsigned int j = t * kSelThreads + tid;
+                const unsigned int k = j < nsub ? sub_key[j] : 0u;
+                if (j < nsub && (k & mask) == prefix) atomicAdd(&hist[(k >> shifts[lv]) & (nb - 1)], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                unsigned int dg, ab;
+                sel_find_digit(hist, (int)nb, want, tid, &dg, &ab);
+                if (tid == 0) {
+                    s_prefix = prefix | (dg << shifts[lv]);
+                    s_want = want - ab;
+                }
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            want = s_want;
+            mask |= (nb - 1) << shifts[lv];
+        }
+        unsigned int thr = prefix;  // the key of the kSelKeep-th brightest candidate
+        unsigned int ge = 0;
+        for (unsigned int j = tid; j < nsub; j += kSelThreads) ge += sub_key[j] >= thr ? 1u : 0u;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ge += __shfl_xor(ge, off, 64);
+        if ((tid & 63) == 0 && ge) atomicAdd(&s_ge, ge);
+        __syncthreads();
+        if (above + s_ge > kSelCap) thr += 1;  // a crowd of equal keys at the cut: take what is strictly brighter (fewer than kSelKeep)
+        for (unsigned int j = tid; j < nsub; j += kSelThreads) {
+            if (sub_key[j] >= thr) {
+                const unsigned int at = atomicAdd(&s_count, 1u);
+                if (at < kSelCap) sel[at] = sub_idx[j];
+            }
         }
     }
     __syncthreads();
@@ -1073,9 +1142,10 @@ __global__ __launch_bounds__(1024) void comp_select_many_kernel(const DetGroup g
         const unsigned int m = min(s_count, kSelCap);
         g.counters[f][2] = m;
         g.selout[f][0] = m;
-        g.selout[f][1] = s_count > kSelCap ? 0xffffffffu : ncand;  // (cannot happen: ncand <= kSelKeep or the cut above; kept as a loud fallback)
+        g.selout[f][1] = s_count > kSelCap ? 0xffffffffu : ncand;  // (cannot happen: the cuts above keep it below kSelCap; kept as a loud fallback)
     }
 }
+
 __global__ __launch_bounds__(kInitBlock) void label_init_kernel(const float *__restrict__ img, int rows, int cols, int64_t ld, double threshold_arg,
                                                                 const ab_pixel_xf xf_arg, int *__restrict__ parent, unsigned int *__restrict__ mask,
                                                                 int *__restrict__ plist, unsigned int *nlab, int vec_ok, const FrameDev *__restrict__ fd) { AB_LATENCY_KERNEL_PRIO();
@@ -1095,11 +1165,13 @@ __global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g,
 }
 __global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    label_tile_body(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1, g.blist[f], g.counters[f] + 3);
+    label_tile_body(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f]);
 }
+// (grids of the region walkers: a multiple of kRegions blocks; block b works on region b mod kRegions as sub-block b / kRegions)
 __global__ __launch_bounds__(256) void label_border_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
-    const int f = blockIdx.y;
-    label_border_body(rows, cols, g.parent[f], g.mask[f], g.blist[f], g.counters[f] + 3);
+    const int f = blockIdx.y, r = blockIdx.x % kRegions;
+    label_border_body(rows, cols, g.parent[f], g.mask[f], g.blist[f] + (size_t)r * g.blist_stride, g.lcnt[f] + (kRegions + r) * kRegionPitch, blockIdx.x / kRegions,
+                      gridDim.x / kRegions);
 }
 __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
                                                             int *__restrict__ roots, int *__restrict__ cid, unsigned int *nroots, unsigned int cap) { AB_LATENCY_KERNEL_PRIO();
@@ -1107,7 +1179,13 @@ __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restric
 }
 __global__ __launch_bounds__(kRootsBlock) void roots_many_kernel(const DetGroup g, unsigned int cap) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    roots_body(g.parent[f], g.plist[f], g.counters[f] + 1, g.roots[f], g.cid[f], g.counters[f], cap);
+    if (g.tiled) {
+        const int r = blockIdx.x % kRegions;
+        roots_body(g.parent[f], g.plist[f] + (size_t)r * g.plist_stride, g.lcnt[f] + r * kRegionPitch, g.roots[f], g.cid[f], g.counters[f], cap,
+                   g.chained ? g.st[f] : nullptr, blockIdx.x / kRegions, gridDim.x / kRegions);
+        return;
+    }
+    roots_body(g.parent[f], g.plist[f], g.counters[f] + 1, g.roots[f], g.cid[f], g.counters[f], cap, g.chained ? g.st[f] : nullptr);
 }
 __global__ __launch_bounds__(256) void comp_init_kernel(CompStat *st, unsigned int n) { AB_LATENCY_KERNEL_PRIO(); comp_init_body(st, n); }
 __global__ __launch_bounds__(256) void comp_init_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
@@ -1120,7 +1198,18 @@ __global__ __launch_bounds__(256) void comp_stats_kernel(int rows, int cols, int
 }
 __global__ __launch_bounds__(256) void comp_stats_many_kernel(const DetGroup g, int rows, int cols, int64_t ld) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    if (g.ncomp[f] == 0) return;
+    if (g.chained) {
+        const unsigned int nc = g.counters[f][0];
+        if (nc == 0 || nc > g.comp_cap) return;  // (more components than the table holds: the host redoes the frame in full)
+    } else if (g.ncomp[f] == 0) {
+        return;
+    }
+    if (g.tiled) {
+        const int r = blockIdx.x % kRegions;
+        comp_stats_body<true>(rows, cols, g.parent[f], g.cid[f], g.st[f], g.plist[f] + (size_t)r * g.plist_stride, g.lcnt[f] + r * kRegionPitch, g.img[f], ld, g.xf[f],
+                              g.bg_median[f], blockIdx.x / kRegions, gridDim.x / kRegions);
+        return;
+    }
     comp_stats_body<true>(rows, cols, g.parent[f], g.cid[f], g.st[f], g.plist[f], g.counters[f] + 1, g.img[f], ld, g.xf[f], g.bg_median[f]);
 }
 __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restrict__ img, int cols, int64_t ld, const int *__restrict__ parent,
@@ -1657,16 +1746,29 @@ struct ab_bg_feed_impl {
     std::condition_variable cv;
     size_t enqueued = 0;  // chunks whose launches are in the streams
     int rc = AB_OK;
+    std::string err;             // the feeder's own error message (it never writes the caller's context: ab_tls_error_sink)
+    std::atomic<bool> stop{false};  // the batch was abandoned (a worker failed, a cancel): no further chunk is enqueued
     std::thread th;
+    void give_up() {  // (nobody should be waiting once the batch is abandoned; if somebody is, it gets an answer)
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (rc == AB_OK) rc = AB_ERR_CANCELLED;
+            err = "the batch was abandoned";
+        }
+        cv.notify_all();
+    }
     void run() {
+        ab_tls_error_sink = &err;
         (void)hipSetDevice(plan.ctx->device);
         for (size_t c = 0; c < plan.nchunks; ++c) {
+            if (stop.load(std::memory_order_acquire)) return give_up();
             int r = AB_OK;
             const size_t first = c * (size_t)plan.chunk, cnt = std::min<size_t>((size_t)plan.chunk, plan.n - first);
             for (size_t i = 0; i < cnt && r == AB_OK; ++i)
                 if (plan.landed[first + i] && hipEventSynchronize(plan.landed[first + i]) != hipSuccess)
                     r = ab_set_error(plan.ctx, AB_ERR_HIP, "waiting for an uploaded frame failed");
             ab_upload_trace("chunk landed", (long)c);
+            if (stop.load(std::memory_order_acquire)) return give_up();
             if (r == AB_OK) r = plan.enqueue(c);
             ab_upload_trace("chunk enqueued", (long)c);
             {
@@ -1777,6 +1879,7 @@ int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, 
 // joins the feeder (if any): call before the pipeline's streams are drained and before the planes go away
 void ab_bg_pipeline_end(ab_bg_pipeline *p) {
     if (p && p->feed) {
+        p->feed->stop.store(true, std::memory_order_release);  // (a finished feeder never looks; an abandoned batch stops at the next chunk)
         if (p->feed->th.joinable()) p->feed->th.join();
         delete p->feed;
         p->feed = nullptr;
@@ -1789,7 +1892,7 @@ int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *b
     if (p->feed) {  // the chunk's launches are in the streams only once its planes have landed
         std::unique_lock<std::mutex> g(p->feed->m);
         p->feed->cv.wait(g, [&] { return p->feed->enqueued > c || p->feed->rc != AB_OK; });
-        if (p->feed->enqueued <= c) return ab_set_error(ctx, p->feed->rc, "the background pipeline's feeder failed");
+        if (p->feed->enqueued <= c) return ab_set_error(ctx, p->feed->rc, "the background pipeline's feeder failed: %s", p->feed->err.c_str());
     }
     AB_HIP(ctx, hipEventSynchronize(p->events[c]));
     ab_upload_trace("tiles ready, plane", (long)i);
@@ -2066,10 +2169,13 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     bool tiled = !ctx->label_legacy && (cols % 32) == 0;
     for (int f = 0; f < G; ++f) tiled = tiled && ((uintptr_t)imgs[f] & 15) == 0;
     const int64_t tiles_x = (cols + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH, ntile = tiles_x * tiles_y;
-    const size_t border_cap = (size_t)ntile * (kTileW + 2 * kTileH);  // last row + first and last column of every tile
-    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)G * ((size_t)P + border_cap) * sizeof(int), (void **)&plist));
+    // (tiled: the lists come in kRegions segments, each sized for the tiles that append to it)
+    const size_t tiles_per_region = ((size_t)ntile + kRegions - 1) / kRegions;
+    const size_t plist_stride = tiles_per_region * (size_t)(kTileH * kTileW), blist_stride = tiles_per_region * (size_t)(kTileW + 2 * kTileH);
+    const size_t plist_ints = tiled ? (size_t)kRegions * plist_stride : (size_t)P, blist_ints = tiled ? (size_t)kRegions * blist_stride : 0;
+    const size_t lcnt_words = tiled ? (size_t)2 * kRegions * kRegionPitch : 0;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)G * (plist_ints + blist_ints + lcnt_words) * sizeof(int), (void **)&plist));
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_MASK, (size_t)G * mask_words * sizeof(unsigned int), (void **)&mask));
-    ctx->det_group_ws = true;  // (the single-frame path carves the same workspaces differently: nothing of it survives a call)
     DetGroup g;
     memset(&g, 0, sizeof g);
     g.n = G;
@@ -2082,16 +2188,50 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         g.xf[f] = xf[f];
         g.parent[f] = parent + (size_t)f * P;
         g.cid[f] = cid + (size_t)f * P;
-        g.plist[f] = plist + (size_t)f * P;
-        g.blist[f] = plist + (size_t)G * P + (size_t)f * border_cap;
+        g.plist[f] = plist + (size_t)f * plist_ints;
+        g.blist[f] = plist + (size_t)G * plist_ints + (size_t)f * blist_ints;
+        g.lcnt[f] = (unsigned int *)(plist + (size_t)G * (plist_ints + blist_ints)) + (size_t)f * lcnt_words;
         g.roots[f] = roots + (size_t)f * root_cap;
         g.mask[f] = mask + (size_t)f * mask_words;
         g.counters[f] = counters + 4 * f;
         vec_ok = vec_ok && ((uintptr_t)imgs[f] & 15) == 0;
     }
     const int cus = ctx->cu_count > 0 ? ctx->cu_count : 256;
-    const int gl = cus * 2;  // list kernels: grid-stride over the frame's labelled pixels (a fraction of a percent of the frame)
+    // list kernels: grid-stride over the frame's labelled pixels (a fraction of a percent of the frame); tiled: a multiple of kRegions
+    const int gl = tiled ? std::max(kRegions, (cus * 2 / kRegions) * kRegions) : cus * 2;
+    // The matcher's 120 (max_keep <= kSelKeep / 4): the brightest kSelKeep candidates are chosen on the device and only they are
+    // walked and sent (comp_select_many_kernel).  A caller that wants every star, or AB_DETECT_FULL_RECORDS=1, takes all records.
+    const bool select = !ctx->detect_full_records && 4 * max_keep <= (size_t)kSelKeep;
+    // With the selection the component kernels' grids no longer depend on the component count, so the whole detection is ONE chain
+    // with one host join at its end (labels -> roots (which also initialise the component table) -> statistics -> selection ->
+    // moments); the table holds comp_cap components per frame, a frame with more is redone in full.  AB_DETECT_MIDJOIN=1 keeps the
+    // join after the root numbering (round 4's shape: the host sizes the table and the grids).
+    const bool chained = select && !ctx->detect_midjoin;
+    const unsigned int comp_cap = (unsigned int)std::min<int64_t>(root_cap, (int64_t)1 << 18);
+    void *pin = nullptr;
+    unsigned int *selout = nullptr;
+    if (chained) {
+        void *cbuf = nullptr;
+        AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, (size_t)G * comp_cap * sizeof(CompStat) + (size_t)G * kSelCap * sizeof(unsigned int), &cbuf));
+        CompStat *dstat = (CompStat *)cbuf;
+        unsigned int *dsel = (unsigned int *)(dstat + (size_t)G * comp_cap);
+        AB_TRY(ab_pinned(ctx, (size_t)G * kSelCap * sizeof(CompRec) + (size_t)G * 4 * sizeof(unsigned int), &pin));
+        selout = (unsigned int *)((CompRec *)pin + (size_t)G * kSelCap);
+        for (int f = 0; f < G; ++f) {
+            g.rec[f] = (CompRec *)pin + (size_t)f * kSelCap;
+            g.st[f] = dstat + (size_t)f * comp_cap;
+            g.sel[f] = dsel + (size_t)f * kSelCap;
+            g.selout[f] = selout + 4 * f;
+            selout[4 * f] = selout[4 * f + 1] = selout[4 * f + 2] = 0;
+        }
+        g.comp_cap = comp_cap;
+        g.chained = 1;
+    }
     AB_HIP(ctx, hipMemsetAsync(counters, 0, (size_t)G * 4 * sizeof(unsigned int), ctx->stream));
+    g.tiled = tiled ? 1 : 0;
+    g.plist_stride = plist_stride;
+    g.blist_stride = blist_stride;
+    if (tiled) AB_HIP(ctx, hipMemsetAsync(g.lcnt[0], 0, (size_t)G * lcnt_words * sizeof(unsigned int), ctx->stream));
     if (tiled) {
         hipLaunchKernelGGL(label_tile_many_kernel, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
         hipLaunchKernelGGL(label_border_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
@@ -2100,9 +2240,38 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
                            (int)rows, (int)cols, cols, (int)vec_ok);
         hipLaunchKernelGGL(label_merge_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
     }
-    hipLaunchKernelGGL(roots_many_kernel, dim3(gl, G), dim3(kRootsBlock), 0, ctx->stream, g, root_cap);
+    hipLaunchKernelGGL(roots_many_kernel, dim3(gl, G), dim3(kRootsBlock), 0, ctx->stream, g, chained ? comp_cap : root_cap);
     AB_HIP(ctx, hipGetLastError());
-    void *pin = nullptr;
+    if (chained) {
+        hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols, cols);
+        hipLaunchKernelGGL(comp_select_many_kernel, dim3(G), dim3(kSelThreads), 0, ctx->stream, g);
+        hipLaunchKernelGGL(comp_moments_many_kernel, dim3((kSelCap + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
+        AB_HIP(ctx, hipGetLastError());
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        bool redo[kGroupMax] = {};
+        for (int f = 0; f < G; ++f) {
+            const unsigned int m = selout[4 * f], ncand = selout[4 * f + 1], ncomp = selout[4 * f + 2];
+            AB_CHECK(ctx, m <= kSelCap, "detect_stars: the selection of frame %d holds %u components", f, m);
+            AB_CHECK(ctx, ncomp <= root_cap, "detect_stars: %u components exceed the table capacity", ncomp);
+            if (ncomp > comp_cap) {  // more components than the chained table holds
+                redo[f] = true;
+                continue;
+            }
+            finish_stars(g.rec[f], m, bg[f][1], max_keep, &stars[f]);
+            redo[f] = stars[f].size() < max_keep && ncand > m;  // (see below)
+        }
+        for (int f = 0; f < G; ++f) {
+            if (!redo[f]) continue;
+            static const bool trace = getenv("AB_TRACE") != nullptr;
+            if (trace)
+                fprintf(stderr, "[ab_trace] detect_stars: frame %d of the group redone in full (%u components, %u candidates, %u selected, %zu stars of them)\n", f,
+                        selout[4 * f + 2], selout[4 * f + 1], selout[4 * f], stars[f].size());
+            double m0 = 0.0, s0 = 0.0;
+            AB_TRY(ab_detect_stars_device(ctx, imgs[f], rows, cols, cols, sigma_threshold, &stars[f], &m0, &s0, xf[f], max_keep, false, bg[f]));
+            ctx->det_select_fallbacks++;
+        }
+        return AB_OK;
+    }
     AB_TRY(ab_pinned(ctx, (size_t)G * 4 * sizeof(unsigned int), &pin));
     AB_HIP(ctx, hipMemcpyAsync(pin, counters, (size_t)G * 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2117,9 +2286,6 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     }
     off[G] = total;
     if (total == 0) return AB_OK;
-    // The matcher's 120 (max_keep <= kSelKeep / 4): the brightest kSelKeep candidates are chosen on the device and only they are
-    // walked and sent (comp_select_many_kernel).  A caller that wants every star, or AB_DETECT_FULL_RECORDS=1, takes all records.
-    const bool select = !ctx->detect_full_records && 4 * max_keep <= (size_t)kSelKeep;
     void *cbuf = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, total * sizeof(CompStat) + (size_t)G * kSelCap * sizeof(unsigned int), &cbuf));
     CompStat *dstat = (CompStat *)cbuf;
@@ -2127,7 +2293,7 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     // the component records (72 B each, written once, by one lane, never read on the device) go STRAIGHT into pinned host memory
     const size_t rec_count = select ? (size_t)G * kSelCap : total;
     AB_TRY(ab_pinned(ctx, rec_count * sizeof(CompRec) + (size_t)G * 4 * sizeof(unsigned int), &pin));
-    unsigned int *selout = (unsigned int *)((CompRec *)pin + rec_count);
+    selout = (unsigned int *)((CompRec *)pin + rec_count);
     for (int f = 0; f < G; ++f) {
         g.rec[f] = (CompRec *)pin + (select ? (size_t)f * kSelCap : off[f]);
         g.st[f] = dstat + off[f];
@@ -2144,7 +2310,7 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     }
 #endif
     if (select) {
-        hipLaunchKernelGGL(comp_select_many_kernel, dim3(G), dim3(1024), 0, ctx->stream, g);
+        hipLaunchKernelGGL(comp_select_many_kernel, dim3(G), dim3(kSelThreads), 0, ctx->stream, g);
         hipLaunchKernelGGL(comp_moments_many_kernel, dim3((kSelCap + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
     } else {
         hipLaunchKernelGGL(comp_moments_many_kernel, dim3((max_nc + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);

@@ -597,7 +597,21 @@ int masked_stretch_enqueue(ab_ctx *ctx, hipStream_t stream, const float *img, co
         hipLaunchKernelGGL(ms_pick_kernel, dim3(1), dim3(kPickBlock), 0, stream, hist, st, 2, it, iterations, cfg.target_background, cfg.convergence_threshold);
     };
     finish_median(-1);
+    // The reference leaves its loop at convergence (masked_stretch.rs:82-91); here an iteration that the decision has switched off
+    // still costs six launches that read the state and return.  The usual ten iterations are enqueued in one go (one join for the
+    // whole call); a configuration that asks for many more -- a convergence-bounded loop with a large ceiling is a natural use --
+    // is enqueued kIterChunk at a time with a look at `done` in between, so its cost is bounded by what the loop really runs
+    // (6 x iterations no-op launches, up to 6 000 000).  Beyond the first chunk the channels of the shared-mask form
+    // run one after the other.
+    constexpr int kIterChunk = 32;
     for (int it = 0; it < iterations; ++it) {
+        if (it > 0 && it % kIterChunk == 0) {
+            void *pin = nullptr;
+            AB_TRY(ab_pinned(ctx, sizeof(MsState), &pin));
+            AB_HIP(ctx, hipMemcpyAsync(pin, st, sizeof(MsState), hipMemcpyDeviceToHost, stream));
+            AB_HIP(ctx, hipStreamSynchronize(stream));
+            if (((const MsState *)pin)->done) break;
+        }
         hipLaunchKernelGGL(ms_blend_hist0_kernel, dim3(grid), dim3(kBlock), 0, stream, work, mask, n, st, protection, hist);
         finish_median(it + 1);
     }

@@ -255,6 +255,7 @@ int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_
 }
 
 // rows [row0, row0 + nrows) of warp_image(src, t, out_rows, out_cols) into the contiguous nrows x out_cols plane `out`
+constexpr long kWarpLdsKB = 0;  // (see ab_warp_rows_device)
 int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
                         int64_t out_cols, int64_t row0, int64_t nrows, float *out) {
     AB_HIP(ctx, hipSetDevice(ctx->device));
@@ -283,11 +284,20 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
 #endif
     bool tame = true;  // every product and sum of the coordinate arithmetic stays finite (x, y < 2^16)
     for (int i = 0; i < 6; ++i) tame = tame && std::isfinite(t[i]) && fabs(t[i]) <= 1e150;
+    // Occupancy cap (AB_WARP_LDS_KB, default below): the kernel is bound by the f64 pipe, which two to four waves per SIMD with two
+    // independent chains per lane keep busy; left alone its 28-VGPR waves take EVERY wave slot of the chip and the registration
+    // batch's latency-bound estimate kernels (dependent loads, a few VALU cycles between them) wait for slots instead of running in
+    // the f64 instructions' shadow.  Unused dynamic LDS per workgroup is the cap: 160 KB / n KB workgroups of 4 waves per CU.
+    static const unsigned warp_lds = [] {
+        const char *e = getenv("AB_WARP_LDS_KB");
+        const long kb = e ? atol(e) : kWarpLdsKB;
+        return (unsigned)(kb < 0 ? 0 : (kb > 64 ? 64 : kb)) * 1024u;
+    }();
     if (tame)
-        hipLaunchKernelGGL(warp_kernel<false>, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
+        hipLaunchKernelGGL(warp_kernel<false>, grid, block, warp_lds, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
                            t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
     else
-        hipLaunchKernelGGL(warp_kernel<true>, grid, block, 0, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
+        hipLaunchKernelGGL(warp_kernel<true>, grid, block, warp_lds, ctx->stream, src, (int)src_rows, (int)src_cols, t[0], t[1], t[2], t[3],
                            t[4], t[5], (int)out_rows, (int)out_cols, out, (int)row0);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;

@@ -776,9 +776,13 @@ __device__ __forceinline__ ClipResult clip_fast(float (&v)[NP], int n, float med
 // need more appends its pixel to one of kDeferSlots lists and writes nothing.  kGeneralPass re-runs the complete
 // algorithm for exactly those pixels (a few percent), densely packed into waves.  kPlain is the single-pass kernel
 // (partial frame sets, ragged strides, the exact engine).  All three produce bit-identical pixels.
-template <int NP, bool PARTIAL, bool EXACT, int STAGE, bool DIRECT, int MODE, int INPUT = kInNative>
+// NREAL (<= NP): a frame-count CLASS of a padded stack -- slots NREAL .. NP - 1 are +inf pads known at compile time: their loads are
+// not issued and the sorting network runs as SortNet<NP>::sort_fused_n<NREAL> (operations on pad wires vanish).  129 .. 256 frames
+// in classes of 32: 200 frames sort 224 wires' worth of the 256-wire network instead of all of it.
+template <int NP, bool PARTIAL, bool EXACT, int STAGE, bool DIRECT, int MODE, int INPUT = kInNative, int NREAL = NP>
 __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, const bool valid) {
     static_assert(INPUT == kInNative || DIRECT, "raw FITS planes are only read through the DIRECT gather");
+    static_assert(NREAL == NP || (DIRECT && INPUT == kInNative && NP > 64 && MODE == kPlain && NREAL < NP && NREAL % 8 == 0), "frame-count classes: the deep direct-gather kernels only");
     const int64_t total = args.rows * args.cols;
 
     int64_t y = 0, x = g;
@@ -852,6 +856,12 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         const uint32_t plane_bytes = ((uint32_t)total * kSampleBytes + 3u) & ~3u;
 #pragma unroll
         for (int f = 0; f < NP; ++f) {
+            if constexpr (NREAL < NP) {
+                if (f >= NREAL) {  // (compile time: the loop is unrolled) a pad of the frame-count class: no load
+                    v[f] = __builtin_inff();
+                    continue;
+                }
+            }
             const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)phi[f >> 6], f & 63) << 32) |
                                   (uint32_t)__builtin_amdgcn_readlane((int)plo[f >> 6], f & 63);
             // buffer descriptor in 4 SGPRs -> `buffer_load_dword v, voffset, s[rsrc], 0 offen`
@@ -979,6 +989,8 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         };
         SortNet<NP>::sort_fused(v, hook);
         n -= lost;
+    } else if constexpr (NREAL < NP) {
+        SortNet<NP>::template sort_fused_n<NREAL>(v, [](auto) {});
     } else if constexpr (NP >= 8 && NP <= 256) {
         SortNet<NP>::sort_fused(v);
     } else {
@@ -1078,7 +1090,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
         atomicAdd(&args.rejected[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kRejSlots - 1)], (unsigned long long)rej);
 }
 
-template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain, int INPUT = kInNative>
+template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain, int INPUT = kInNative, int NREAL = NP>
 __global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : AB_STACK_WAVES_PER_SIMD) void stack_sigma_clip_kernel(const StackArgs args) {
     if constexpr (MODE == kGeneralPass) {
         // ONE wave per workgroup, kGenWaves workgroups per list (launched with 64 threads).  With one 4-wave workgroup per list
@@ -1090,7 +1102,7 @@ __global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : AB_STACK_WAVES_PER_SI
         for (unsigned int base = sub * 64u; base < cnt; base += 64u * kGenWaves) {
             const unsigned int k = base + threadIdx.x;
             const bool valid = k < cnt;
-            stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE, INPUT>(args, (int64_t)list[valid ? k : cnt - 1], valid);
+            stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE, INPUT, NREAL>(args, (int64_t)list[valid ? k : cnt - 1], valid);
         }
         // the last of the list's workgroups to get here leaves the list empty for the next launch.  (No fence: each workgroup's
         // own read of the count has returned before its ticket is taken -- the loop bound depends on it -- and a device-scope
@@ -1106,7 +1118,7 @@ __global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : AB_STACK_WAVES_PER_SI
         int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
         const bool valid = g < total;
         if (!valid) g = total - 1;
-        stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE, INPUT>(args, g, valid);
+        stack_pixel<NP, PARTIAL, EXACT, STAGE, DIRECT, MODE, INPUT, NREAL>(args, g, valid);
     }
 }
 
@@ -1305,10 +1317,22 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
         if (np == 256) {  // 129 .. 256 contiguous frames: 256 samples per lane (VGPRs + AGPRs), single pass
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-            if (median_only)
-                hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 10, true>), grid, block, 0, ctx->stream, args);
-            else
-                hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 99, true>), grid, block, 0, ctx->stream, args);
+            // frame-count classes of 32 (AB_STACK_NO_CLASSES=1: every count pays for 256): the pads' loads and the network's
+            // operations on pad wires are gone at compile time
+            static const bool no_classes = getenv("AB_STACK_NO_CLASSES") != nullptr;
+            const int cls = no_classes ? 256 : (args.n_real + 31) / 32 * 32;
+#define AB_LAUNCH_256(NREAL)                                                                                                               \
+    do {                                                                                                                                   \
+        if (median_only)                                                                                                                   \
+            hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 10, true, kPlain, kInNative, NREAL>), grid, block, 0, ctx->stream, args); \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((stack_sigma_clip_kernel<256, false, false, 99, true, kPlain, kInNative, NREAL>), grid, block, 0, ctx->stream, args); \
+    } while (0)
+            if (cls <= 160) AB_LAUNCH_256(160);
+            else if (cls == 192) AB_LAUNCH_256(192);
+            else if (cls == 224) AB_LAUNCH_256(224);
+            else AB_LAUNCH_256(256);
+#undef AB_LAUNCH_256
             AB_HIP(ctx, hipGetLastError());
         } else if (np == 128) {  // reg128 (checked above): only the direct-gather kernels exist for 128 samples per lane
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);

@@ -879,7 +879,7 @@ int enqueue_resident(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int
 // One resident kernel at a time per device: a workgroup needs a whole CU (16 waves x 128 registers), so two of them launched
 // together would each hold part of the chip and wait for the rest until the barrier times out.  A caller that finds the lock
 // taken uses the chain.  The lock has two halves: a mutex for the threads of this process, and an advisory file lock
-// (flock on /dev/shm/astroburst_resident_<uid>_<device>.lock, non-blocking) for OTHER processes on the same GPU -- several ranks
+// (flock on /dev/shm/astroburst_resident_<uid>_<PCI bus id>.lock, non-blocking) for OTHER processes on the same GPU -- several ranks
 // may share one device (tests/multirank_worker.py does).  Where the file cannot be opened the process half alone decides; two
 // processes colliding then costs each a timed-out barrier (0.5 s), the abort flag, the chain's (exact) result, and after three in
 // a row the context stays on the chain (resident_takes): slow, never wrong.
@@ -889,9 +889,18 @@ struct ResidentLock {
     bool try_lock(int device) {
         if (!m.try_lock()) return false;
         if (fd == -2) {
-            char path[96];
-            snprintf(path, sizeof path, "/dev/shm/astroburst_resident_%u_%d.lock", (unsigned)getuid(), device);
-            fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC, 0600);
+            // keyed on the GPU's PCI address, not on this process's HIP ordinal: under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES two
+            // processes number the same GPU differently (no guard at all) and different GPUs alike (false serialisation) -- ADVICE r4.
+            // O_NOFOLLOW: /dev/shm is world-writable, the name is predictable; a planted symlink is refused, not followed.
+            char path[128], bus[32] = "";
+            if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) {
+                (void)hipGetLastError();
+                snprintf(bus, sizeof bus, "ordinal%d", device);
+            }
+            for (char *c = bus; *c; ++c)
+                if (*c == ':' || *c == '.' || *c == '/') *c = '_';
+            snprintf(path, sizeof path, "/dev/shm/astroburst_resident_%u_%s.lock", (unsigned)getuid(), bus);
+            fd = open(path, O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0600);
         }
         if (fd >= 0 && flock(fd, LOCK_EX | LOCK_NB) != 0) {
             m.unlock();

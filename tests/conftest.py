@@ -65,6 +65,28 @@ def ctx_deep():
     c.close()
 
 
+def _ctx_under(env):
+    import astroburst_amd as ab
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return ab.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="session")
+def ctx_midjoin():
+    """Same library, AB_DETECT_MIDJOIN=1: the grouped detection with a host join after the root numbering (the default is one chain)."""
+    c = _ctx_under({"AB_DETECT_MIDJOIN": "1"})
+    yield c
+    c.close()
+
+
 @pytest.fixture(scope="session")
 def ctx_r4_detect():
     """Same library with round 4's detection forms (AB_LABEL_LEGACY=1: two-pass labelling; AB_DETECT_FULL_RECORDS=1: every component's

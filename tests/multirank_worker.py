@@ -264,7 +264,12 @@ def scenario_bands(ab, ctx, comm, rank, nranks, out):
     and the reference; of every other target just the rows its band of the output reads (ab_shard_source_rows: its rows + the halo the
     exchanged transforms need).  The host slices are cut from the frames BEFORE they reach the device: a rank never holds more."""
     import torch
+
+    def say(what):
+        print(f"[bands rank {rank}] {what} at {time.time() % 1000:.1f}", file=sys.stderr, flush=True)
+    say("start")
     ref, tgts, _ = band_frames()
+    say("frames generated")
     rows, cols = ref.shape
     n = len(tgts)
     mine = [i for i in range(n) if i % nranks == rank]
@@ -273,6 +278,7 @@ def scenario_bands(ab, ctx, comm, rank, nranks, out):
     ref_dev = ref.cuda()
     regs = ctx.register_frames_sharded(comm, ref_dev, dev_targets, num_threads=8)
     transforms = [r.transform for r in regs]
+    say("registered")
     del dev_targets
     row0, nrows = ctx.shard_rows(rows, nranks, rank)
     s0, sn = ctx.shard_source_rows(transforms, rows, cols, rows, cols, nranks, rank)
@@ -288,11 +294,14 @@ def scenario_bands(ab, ctx, comm, rank, nranks, out):
         ctx.warp_image_rows_from_band(band_dev, s0, rows, transforms[i], rows, row0, o)
         warped.append(o)
     # (the frames are bands already: the band-local stack + the rejected count summed over the ranks)
+    say("warped")
     out_band, rej_local = ctx.stack_sigma_clip(warped, 3.0, 3.0, 5) if nrows > 0 else (torch.empty((0, cols), device="cuda"), 0)
+    say("stacked")
     t = torch.tensor([rej_local], dtype=torch.int64, device="cuda")
     comm.allreduce(t, "sum")
     full = torch.zeros((rows, cols), device="cuda")
     ctx.allgather_rows(comm, out_band, full)
+    say("gathered")
     # a band that is too short is refused loudly, naming the rows: target 0 without the last row its band of the output reads
     code = 0
     f0, fn = ctx.warp_source_rows(transforms[0], rows, cols, cols, row0, nrows)
@@ -316,6 +325,8 @@ def scenario_sum(ab, ctx, comm, rank, nranks, out):
 
 def main():
     name, nranks, rank, scenario, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    import torch
+    torch.set_num_threads(2)   # eight ranks generate their inputs on the host at once: eight full-width thread pools starve each other
     import astroburst_amd as ab
     ctx = ab.Context(0)
     ctx.use_torch_stream()

@@ -471,7 +471,7 @@ def test_registration_when_the_brightest_components_are_not_stars(ctx, oracle, k
 
 
 @pytest.mark.parametrize("shape", [(512, 640), (600, 800), (257, 1000), (1100, 2048)])
-def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, shape):
+def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midjoin, shape):
     """Round 5 changed how a GROUP of frames is detected: tile-local union-find in LDS + a border pass (widths that are multiples of
     32: 640, 800, 2048; 1000 keeps the two-pass form), approximate flux in comp_stats, the brightest 480 candidates selected on the
     device, moments for those only.  A context created under AB_LABEL_LEGACY=1 AB_DETECT_FULL_RECORDS=1 runs round 4's forms: the
@@ -486,6 +486,8 @@ def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, shape):
             for k in range(9)]
     new = ctx.register_frames(ref, tgts, num_threads=8)
     old = ctx_r4_detect.register_frames(ref, tgts, num_threads=8)
-    for a, b in zip(new, old):
+    mid = ctx_midjoin.register_frames(ref, tgts, num_threads=8)      # (the selection with a host join after the root numbering)
+    for a, b, c in zip(new, old, mid):
         assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
+        assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (c.method, c.matched_stars, c.inliers, c.transform, c.residual_px)
     assert sum(a.method in ("affine", "rigid") for a in new) >= 7

@@ -138,3 +138,28 @@ def test_full_size_properties(ctx):
     assert float(res.image.min()) >= 0.0 and float(res.image.max()) <= 1.0
     sky = res.image[res.image < 0.5]
     assert abs(float(np.median(sky)) - 0.25) < 0.01
+
+
+def test_a_large_iteration_ceiling_costs_what_the_loop_runs(ctx, oracle):
+    """the device-resident chain used to enqueue six launches for EVERY configured iteration (the reference breaks at
+    convergence, masked_stretch.rs:82-91): iterations = 200 000 meant 1.2 M no-op launches per channel.  Iterations are now enqueued
+    32 at a time with a look at the loop state in between: same result as the oracle, in a fraction of a second."""
+    import time
+    rng = np.random.default_rng(77)
+    img = star_field(rng, 333, 517, 60)
+    stars = [(rng.uniform(0, 517), rng.uniform(0, 333), rng.uniform(1.5, 8.0)) for _ in range(40)]
+    m_or = oracle.generate_star_mask(img, stars=stars, luminance_protect=True)
+    m_gp = ctx.generate_star_mask(img, stars=stars, luminance_protect=True)
+    want = oracle.masked_stretch(img, mask=m_or, iterations=200000)
+    assert want.iterations_run < 64
+    t0 = time.perf_counter()
+    got = ctx.masked_stretch(img, mask=m_gp, iterations=200000)
+    assert time.perf_counter() - t0 < 5.0
+    result_equal(got, want)
+    rgb = [img, (img * np.float32(0.8)).astype(np.float32), (img * np.float32(0.6)).astype(np.float32)]
+    t0 = time.perf_counter()
+    r, g, b, _ = ctx.masked_stretch_rgb_shared(*rgb, iterations=200000)
+    assert time.perf_counter() - t0 < 10.0
+    r10, g10, b10, _ = ctx.masked_stretch_rgb_shared(*rgb, iterations=want.iterations_run + 40)
+    for a, c in ((r, r10), (g, g10), (b, b10)):
+        assert a.iterations_run == c.iterations_run and a.final_background == c.final_background and np.array_equal(np.asarray(a.image), np.asarray(c.image))

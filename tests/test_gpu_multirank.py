@@ -39,7 +39,14 @@ def spawn(nranks, scenario, tmp_path, timeout=300, expect_exit=None):
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
-            pytest.fail(f"rank {r} of the {scenario!r} scenario hung for {timeout} s")
+            tails = []
+            for k, q in enumerate(procs):     # what every rank had said before it was killed (where it hangs)
+                try:
+                    oo, _ = q.communicate(timeout=10)
+                    tails.append(f"--- rank {k}: " + oo.decode(errors="replace")[-600:])
+                except Exception as e:      # noqa: BLE001
+                    tails.append(f"--- rank {k}: <{e!r}>")
+            pytest.fail(f"rank {r} of the {scenario!r} scenario hung for {timeout} s\n" + "\n".join(tails))
         outs.append(o.decode(errors="replace"))
     for r, p in enumerate(procs):
         want = 0 if expect_exit is None else expect_exit.get(r, 0)
@@ -247,7 +254,7 @@ def test_row_bands_that_ingest_bands(tmp_path, ctx, oracle, nranks):
     with ab_warp_image_rows_from_band.  The reassembled stack must equal the single-level oracle -- estimate on whole frames, warp
     whole frames, stack -- bit for bit, the rejected count too, and a rank's resident target bytes stay near 1 / G of the frame set."""
     import torch
-    res = spawn(nranks, "bands", tmp_path, timeout=600)
+    res = spawn(nranks, "bands", tmp_path, timeout=240)
     ref, tgts, truth = mw.band_frames()
     rows, cols = ref.shape
     single = ctx.register_frames(ref.cuda(), [t.cuda() for t in tgts], num_threads=8)

@@ -157,10 +157,12 @@ def deep_frames(n, shape, seed):
 
 
 @pytest.mark.parametrize("shape", [(23, 41), (24, 40)])               # scalar gather / 16-byte quad gather (4 | pixels)
-@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 256, 257, 512])
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 150, 160, 161, 192, 193, 200, 224, 225, 256, 257, 512])
 def test_deep_stacks_one_wave_per_pixel(ctx, oracle, n, shape):
     """more than 64 frames: 128 / 256 samples per lane in registers (contiguous planes, up to 256 frames) or
-    csrc/stack_wide.hip (bitonic sort across a wave; 257 .. 512 here) must equal the oracle bit for bit"""
+    csrc/stack_wide.hip (bitonic sort across a wave; 257 .. 512 here) must equal the oracle bit for bit.  129 .. 256 frames run in
+    frame-count classes of 32 (160 / 192 / 224 / 256: SortNet<256>::sort_fused_n, the pad wires' operations gone at compile time):
+    both sides of every class boundary are here."""
     fr = deep_frames(n, shape, n)
     for sl, sh, it in ((3.0, 3.0, 5), (2.0, 2.5, 3), (1.0, 1.0, 1), (3.0, 3.0, 0)):
         want, wrej = oracle.stack_images(fr, sl, sh, it)
@@ -217,7 +219,7 @@ def test_workgroup_per_pixel_stack_equals_the_oracle(ctx_deep, oracle, n):
     assert res.image.shape == (13, 21) and res.rejected_pixels == wrej and np.array_equal(res.image, want, equal_nan=True)
 
 
-@pytest.mark.parametrize("n", [65, 100, 128, 129, 200, 256, 300])
+@pytest.mark.parametrize("n", [65, 100, 128, 129, 160, 161, 192, 200, 224, 230, 256, 300])
 def test_deep_median_combine(ctx, oracle, n):
     """median_combine (calibration masters) of deep stacks: the register kernels up to 256 contiguous frames, a wave per pixel beyond"""
     fr = deep_frames(n, (21, 45), 1000 + n)

@@ -36,6 +36,7 @@ import numpy as np
 
 SIZES = (2, 4, 8, 16, 32, 64, 128, 256)
 FUSED_SIZES = (8, 16, 32, 64, 128, 256)
+PADDED_SIZES = (128, 256)   # sizes that also get sort_fused_n<NREAL>: the same programme with the wires >= NREAL known to be +inf pads
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -559,6 +560,43 @@ def render_fused(n, out, stats):
     out.append(line.rstrip())
     out.append("    }")
     out.append("    static __device__ __forceinline__ void sort_fused(float (&v)[%d]) { sort_fused(v, [](auto) {}); }" % n)
+    if n in PADDED_SIZES:
+        # The SAME programme on values that are either a float or the tag snpad::Inf.  A stack of fewer than %d frames pads the top
+        # wires with +inf; Batcher's network is standard (every exchange leaves the minimum on the lower wire), so a pad never
+        # leaves its wire and every operation that touches one collapses AT COMPILE TIME: min(x, inf) = x, max(x, inf) = inf,
+        # med3(x, y, inf) = max(x, y), an exchange with a pad is no instruction at all.  200 frames then run the part of the
+        # 256-wire network that 208 wires need.  Value for value the full programme with real +inf inputs (each snpad overload
+        # returns what the instruction would return), so everything the generator proved about it carries over.
+        out.append("    // the same programme with wires >= NREAL known to be +inf pads (snpad: operations on pads vanish at compile time)")
+        out.append("    template <int NREAL, typename Hook> static __device__ __forceinline__ void sort_fused_n(float (&v)[%d], Hook &&hook) {" % n)
+
+        def pn(s):
+            return f"snpad::in<{s[1:]}, NREAL>(v)" if s[0] == "i" else s
+
+        line = "        "
+        for dst, op, srcs in ops:
+            a = "" if op == "hook" else ", ".join(pn(s) for s in srcs)
+            if op == "hook":
+                tok = f"hook(std::integral_constant<int, {srcs[0]}>{{}}); "
+            elif op == "ce":
+                tok = f"const auto p_{dst[0]} = snpad::ce({a}); const auto {dst[0]} = p_{dst[0]}.lo; const auto {dst[1]} = p_{dst[0]}.hi; "
+            else:
+                tok = f"const auto {dst} = snpad::{op}({a}); "
+            if len(line) + len(tok) > 150:
+                out.append(line.rstrip())
+                line = "        "
+            line += tok
+        if line.strip():
+            out.append(line.rstrip())
+        line = "        "
+        for w, s in enumerate(outs):
+            tok = f"snpad::out<{w}>(v, {pn(s)}); "
+            if len(line) + len(tok) > 150:
+                out.append(line.rstrip())
+                line = "        "
+            line += tok
+        out.append(line.rstrip())
+        out.append("    }")
 
 
 def render(stats=None):
@@ -590,6 +628,38 @@ def render(stats=None):
     out.append("#ifndef AB_SN_CE")
     out.append("#define AB_SN_CE(lo, hi, x, y) { lo = AB_SN_MIN2(x, y); hi = AB_SN_MAX2(x, y); }")
     out.append("#endif")
+    out.append("// sort_fused_n<NREAL>: values are floats or the tag Inf (a wire >= NREAL: a +inf pad that never leaves its wire).  Every overload")
+    out.append("// returns what the instruction would return on a real +inf -- as a type where the answer is a pad, with fewer instructions where it is not.")
+    out.append("namespace snpad {")
+    out.append("struct Inf {};")
+    out.append("template <class T> constexpr bool pad = std::is_same<T, Inf>::value;")
+    out.append("template <class A, class B> struct Pair { A lo; B hi; };")
+    out.append("template <int I, int NREAL, int N> __device__ __forceinline__ auto in(const float (&v)[N]) { if constexpr (I < NREAL) return v[I]; else return Inf{}; }")
+    out.append("template <int I, int N, class T> __device__ __forceinline__ void out(float (&v)[N], T t) { if constexpr (!pad<T>) v[I] = t; }  // (a pad wire holds +inf already)")
+    out.append("template <class A, class B> __device__ __forceinline__ auto min2(A a, B b) {")
+    out.append("    if constexpr (pad<A>) return b; else if constexpr (pad<B>) return a; else return AB_SN_MIN2(a, b);")
+    out.append("}")
+    out.append("template <class A, class B> __device__ __forceinline__ auto max2(A a, B b) {")
+    out.append("    if constexpr (pad<A> || pad<B>) return Inf{}; else return AB_SN_MAX2(a, b);")
+    out.append("}")
+    out.append("template <class A, class B, class C> __device__ __forceinline__ auto min3(A a, B b, C c) {")
+    out.append("    if constexpr (pad<A>) return min2(b, c); else if constexpr (pad<B>) return min2(a, c); else if constexpr (pad<C>) return min2(a, b);")
+    out.append("    else return AB_SN_MIN3(a, b, c);")
+    out.append("}")
+    out.append("template <class A, class B, class C> __device__ __forceinline__ auto max3(A a, B b, C c) {")
+    out.append("    if constexpr (pad<A> || pad<B> || pad<C>) return Inf{}; else return AB_SN_MAX3(a, b, c);")
+    out.append("}")
+    out.append("template <class A, class B, class C> __device__ __forceinline__ auto med3(A a, B b, C c) {  // the median of {x, y, +inf} is max(x, y)")
+    out.append("    if constexpr (pad<A>) return max2(b, c); else if constexpr (pad<B>) return max2(a, c); else if constexpr (pad<C>) return max2(a, b);")
+    out.append("    else return AB_SN_MED3(a, b, c);")
+    out.append("}")
+    out.append("template <class A, class B> __device__ __forceinline__ auto ce(A x, B y) {")
+    out.append("    if constexpr (pad<A> && pad<B>) return Pair<Inf, Inf>{};")
+    out.append("    else if constexpr (pad<A>) return Pair<B, Inf>{y, Inf{}};")
+    out.append("    else if constexpr (pad<B>) return Pair<A, Inf>{x, Inf{}};")
+    out.append("    else { float lo, hi; AB_SN_CE(lo, hi, x, y); return Pair<float, float>{lo, hi}; }")
+    out.append("}")
+    out.append("}  // namespace snpad")
     out.append("template <int NP> struct SortNet;")
     out.extend(body)
     return "\n".join(out) + "\n"
