@@ -51,6 +51,7 @@ enum {
     AB_WS_SCOPE7,
     AB_WS_STACK_DEEP,         // plane tables + per-workgroup sample segments of a > 4096-frame stack (stack_deep.hip)
     AB_WS_BATCH_DEEP,         // the same for the batch stack (batch_pipeline.hip)
+    AB_WS_STACK_SHIFTED,      // the registered copies of stack_images(align = true)'s frames 1 .. n - 1 (stack_images.hip)
     AB_WS_SLOTS
 };
 

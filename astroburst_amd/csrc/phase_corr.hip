@@ -180,8 +180,12 @@ struct PeakPartial {
 };
 
 // inverse_2d's 1/(rows*cols) scaling + extract_real + find_peak + first moment, one pass
+// (blockIdx.y = pair of a batch: every pointer advances by its pair stride; a single correlation launches one row of workgroups)
 __global__ __launch_bounds__(kBlock) void scale_peak_kernel(const double2 *__restrict__ buf, int n, double norm,
-                                                            double *__restrict__ corr, PeakPartial *__restrict__ partials) {
+                                                            double *__restrict__ corr, PeakPartial *__restrict__ partials, int partials_per_pair = 0) {
+    buf += (size_t)blockIdx.y * n;
+    corr += (size_t)blockIdx.y * n;
+    partials += (size_t)blockIdx.y * partials_per_pair;
     double best = -DBL_MAX, sum = 0.0, count = 0.0;
     int best_idx = 0x7fffffff;
     const int stride = gridDim.x * kBlock;
@@ -227,7 +231,9 @@ struct PcFin {
     double sv[5];
 };
 // (a workgroup fetches the partials into LDS together; one thread then walks them in order: 256 dependent global loads took 60 us)
-__global__ __launch_bounds__(256) void peak_finish_kernel(const PeakPartial *__restrict__ pp, int pg, PcFin *fin) {
+__global__ __launch_bounds__(256) void peak_finish_kernel(const PeakPartial *__restrict__ pp, int pg, PcFin *fin, int partials_per_pair = 0) {
+    pp += (size_t)blockIdx.x * partials_per_pair;  // (one workgroup per pair)
+    fin += blockIdx.x;
     __shared__ PeakPartial sh[256];
     if ((int)threadIdx.x < pg) sh[threadIdx.x] = pp[threadIdx.x];
     __syncthreads();
@@ -247,7 +253,11 @@ __global__ __launch_bounds__(256) void peak_finish_kernel(const PeakPartial *__r
     fin->count = count;
     fin->mean = count >= 1.0 ? sum / count : 0.0;  // normalization.rs:128-161
 }
-__global__ __launch_bounds__(256) void var_finish_kernel(const double *__restrict__ vp, int pg, const double *__restrict__ corr, int fr, int fc, PcFin *fin) {
+__global__ __launch_bounds__(256) void var_finish_kernel(const double *__restrict__ vp, int pg, const double *__restrict__ corr, int fr, int fc, PcFin *fin,
+                                                         int partials_per_pair = 0) {
+    vp += (size_t)blockIdx.x * partials_per_pair;  // (one workgroup per pair)
+    corr += (size_t)blockIdx.x * fr * fc;
+    fin += blockIdx.x;
     __shared__ double sh[256];
     if ((int)threadIdx.x < pg) sh[threadIdx.x] = vp[threadIdx.x];
     __syncthreads();
@@ -265,7 +275,11 @@ __global__ __launch_bounds__(256) void var_finish_kernel(const double *__restric
     fin->sv[4] = corr[py * fc + (px == fc - 1 ? 0 : px + 1)];
 }
 
-__global__ __launch_bounds__(kBlock) void var_kernel(const double *__restrict__ corr, int n, const PcFin *__restrict__ fin, double *__restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void var_kernel(const double *__restrict__ corr, int n, const PcFin *__restrict__ fin, double *__restrict__ partials,
+                                                     int partials_per_pair = 0) {
+    corr += (size_t)blockIdx.y * n;
+    fin += blockIdx.y;
+    partials += (size_t)blockIdx.y * partials_per_pair;
     const double mean = fin->mean;
     double vs = 0.0;
     const int stride = gridDim.x * kBlock;
@@ -284,6 +298,156 @@ __global__ __launch_bounds__(kBlock) void var_kernel(const double *__restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) partials[blockIdx.x] = sh[0];
+}
+
+// ---- the same kernels with blockIdx.y = one PAIR of a batch (round 5: stack_images(align) correlates every frame with frame 0) ----
+// Each is the single-pair kernel's body on the pair's own source view / buffers: the arithmetic and its order are the single
+// pair's, so a batch returns bit for bit what n calls of ab_phase_correlate_device return.
+struct PcItem {  // the source view of pair b: a plane, a downsampled plane or a crop of one
+    const float *p;
+    int64_t ld;
+    int rows, cols;
+};
+__global__ __launch_bounds__(kBlock) void minmax_finite_many_kernel(const PcItem *__restrict__ items, MinMaxPartial *__restrict__ partials, int per_item) {
+    const PcItem it = items[blockIdx.y];
+    const float *img = it.p;
+    const int rows = it.rows, cols = it.cols;
+    const int64_t ld = it.ld;
+    float mn = __builtin_inff(), mx = -__builtin_inff();
+    unsigned long long cnt = 0;
+    auto take = [&](float v) {
+        if (__builtin_isfinite(v)) {
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+            cnt += 1;
+        }
+    };
+    const bool vec = (((uintptr_t)img) & 15) == 0 && (ld & 3) == 0;
+    for (int y = blockIdx.x; y < rows; y += gridDim.x) {
+        const float *row = img + (int64_t)y * ld;
+        int x = 0;
+        if (vec) {
+            const float4 *r4 = reinterpret_cast<const float4 *>(row);
+            const int c4 = cols >> 2;
+            int i = threadIdx.x;
+            for (; i + kBlock < c4; i += 2 * kBlock) {
+                const float4 a = r4[i], b = r4[i + kBlock];
+                take(a.x), take(a.y), take(a.z), take(a.w);
+                take(b.x), take(b.y), take(b.z), take(b.w);
+            }
+            if (i < c4) {
+                const float4 a = r4[i];
+                take(a.x), take(a.y), take(a.z), take(a.w);
+            }
+            x = c4 << 2;
+        }
+        for (int i = x + threadIdx.x; i < cols; i += kBlock) take(row[i]);
+    }
+    __shared__ float s_mn[kBlock / 64], s_mx[kBlock / 64];
+    __shared__ unsigned long long s_c[kBlock / 64];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, off, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        cnt += __shfl_xor(cnt, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_mn[threadIdx.x >> 6] = mn;
+        s_mx[threadIdx.x >> 6] = mx;
+        s_c[threadIdx.x >> 6] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / 64; ++i) {
+            mn = fminf(mn, s_mn[i]);
+            mx = fmaxf(mx, s_mx[i]);
+            cnt += s_c[i];
+        }
+        MinMaxPartial *o = partials + (size_t)blockIdx.y * per_item + blockIdx.x;
+        o->mn = mn;
+        o->mx = mx;
+        o->finite = cnt;
+    }
+}
+__global__ __launch_bounds__(kBlock) void area_downsample_many_kernel(const PcItem *__restrict__ items, int out_rows, int out_cols, double scale_y, double scale_x,
+                                                                      float *__restrict__ out_all) {
+    const PcItem it = items[blockIdx.y];
+    const float *src = it.p;
+    const int in_rows = it.rows, in_cols = it.cols;
+    const int64_t ld = it.ld;
+    float *out = out_all + (size_t)blockIdx.y * out_rows * out_cols;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= out_rows * out_cols) return;
+    const int oy = idx / out_cols, ox = idx - oy * out_cols;
+    auto clampi = [](long long v, int len) { return v < 0 ? 0 : (v >= len ? len - 1 : (int)v); };
+    const int y0 = clampi((long long)floor((double)oy * scale_y), in_rows);
+    const long long y1r = (long long)ceil((double)(oy + 1) * scale_y);
+    const int y1 = y1r <= 0 ? 0 : (y1r < in_rows ? (int)y1r : in_rows);
+    const int x0 = clampi((long long)floor((double)ox * scale_x), in_cols);
+    const long long x1r = (long long)ceil((double)(ox + 1) * scale_x);
+    const int x1 = x1r <= 0 ? 0 : (x1r < in_cols ? (int)x1r : in_cols);
+    double sum = 0.0;
+    unsigned count = 0;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const float v = src[y * ld + x];
+            if (__builtin_isfinite(v)) {
+                sum += (double)v;
+                count += 1;
+            }
+        }
+    out[idx] = count > 0 ? (float)(sum / (double)count) : 0.0f;
+}
+__global__ __launch_bounds__(kBlock) void window_pad_many_kernel(const PcItem *__restrict__ items, const double *__restrict__ win_y, const double *__restrict__ win_x,
+                                                                 int fft_rows, int fft_cols, double2 *__restrict__ out_all) {
+    const PcItem it = items[blockIdx.y];
+    double2 *out = out_all + (size_t)blockIdx.y * fft_rows * fft_cols;
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= fft_rows * fft_cols) return;
+    const int y = idx / fft_cols, x = idx - y * fft_cols;
+    double re = 0.0;
+    if (y < it.rows && x < it.cols) {
+        const double v = (double)it.p[y * it.ld + x];
+        re = __builtin_isfinite(v) ? v * win_y[y] * win_x[x] : 0.0;
+    }
+    out[idx] = make_double2(re, 0.0);
+}
+__global__ __launch_bounds__(kBlock) void fft_lines_many_kernel(double2 *data_all, int64_t batch_stride, int n, int log2n, int64_t elem_stride, int64_t line_stride,
+                                                                const double2 *__restrict__ tw, int inverse) {
+    __shared__ double2 s[512];
+    double2 *line = data_all + (int64_t)blockIdx.y * batch_stride + (int64_t)blockIdx.x * line_stride;
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const int r = log2n ? (int)(__brev((unsigned)i) >> (32 - log2n)) : 0;
+        s[r] = line[(int64_t)i * elem_stride];
+    }
+    __syncthreads();
+    for (int m = 2; m <= n; m <<= 1) {
+        const int half = m >> 1, step = n / m;
+        for (int t = threadIdx.x; t < n / 2; t += kBlock) {
+            const int k = (t / half) * m, j = t % half;
+            double2 w = tw[j * step];
+            if (inverse) w.y = -w.y;
+            const double2 x = s[k + j + half];
+            const double tr = w.x * x.x - w.y * x.y;
+            const double ti = w.x * x.y + w.y * x.x;
+            const double2 u = s[k + j];
+            s[k + j] = make_double2(u.x + tr, u.y + ti);
+            s[k + j + half] = make_double2(u.x - tr, u.y - ti);
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += kBlock) line[(int64_t)i * elem_stride] = s[i];
+}
+// complex.rs:27-44 with the reference's spectrum shared by every pair: fb <- A conj(B) / |A conj(B)|
+__global__ __launch_bounds__(kBlock) void cross_power_many_kernel(const double2 *__restrict__ fa, double2 *fb_all, int n, double eps) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double2 *fb = fb_all + (size_t)blockIdx.y * n;
+    const double2 a = fa[i], b = fb[i];
+    const double pr = a.x * b.x + a.y * b.y;
+    const double pi = a.y * b.x - a.x * b.y;
+    const double mag = sqrt(pr * pr + pi * pi);
+    fb[i] = mag > eps ? make_double2(pr / mag, pi / mag) : make_double2(0.0, 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -436,6 +600,25 @@ int constant_or_zero2(ab_ctx *ctx, const View &r, const View &t, const PcScratch
     return AB_OK;
 }
 
+// the host's part of correlate_single (:128-141): sigma, confidence, wrap-around, 3-point refinement -- from the PcFin the device leaves
+void finish_from_fin(const PcFin &fin, int fr, int fc, double *dx, double *dy, double *conf) {
+    const double mean = fin.mean, count = fin.count;
+    const double sigma = count >= 1.0 ? std::sqrt(fin.var_sum / (count > 1.0 ? count - 1.0 : 1.0)) : 0.0;
+    const int py = fin.best_idx / fc, px = fin.best_idx % fc;
+    const double *sv = fin.sv;
+    auto refine = [](double center, double prev, double next) {
+        const double denom = 2.0 * (2.0 * center - prev - next);
+        if (std::fabs(denom) < 1e-15) return 0.0;  // FftFloat::epsilon_val() for f64 is 1e-15 (math/fft.rs)
+        const double r = (prev - next) / denom;
+        return std::fmin(std::fmax(r, -0.5), 0.5);
+    };
+    *conf = std::fabs(sigma) < 1e-15 ? 0.0 : (sv[0] - mean) / sigma;                    // normalization.rs:163-168
+    const double raw_dy = py > fr / 2 ? (double)py - (double)fr : (double)py;           // subpixel.rs:77-83
+    const double raw_dx = px > fc / 2 ? (double)px - (double)fc : (double)px;
+    *dy = raw_dy + refine(sv[0], sv[1], sv[2]);
+    *dx = raw_dx + refine(sv[0], sv[3], sv[4]);
+}
+
 // phase_correlation.rs:105-141
 int correlate_single(ab_ctx *ctx, const View &a, const View &b, PcScratch s, int table_set, double *dx, double *dy, double *conf,
                      double *surface_host) {
@@ -464,21 +647,7 @@ int correlate_single(ab_ctx *ctx, const View &a, const View &b, PcScratch s, int
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PcFin fin;
     memcpy(&fin, pin, sizeof fin);
-    const double mean = fin.mean, count = fin.count;
-    const double sigma = count >= 1.0 ? std::sqrt(fin.var_sum / (count > 1.0 ? count - 1.0 : 1.0)) : 0.0;
-    const int py = fin.best_idx / fc, px = fin.best_idx % fc;
-    const double *sv = fin.sv;
-    auto refine = [](double center, double prev, double next) {
-        const double denom = 2.0 * (2.0 * center - prev - next);
-        if (std::fabs(denom) < 1e-15) return 0.0;  // FftFloat::epsilon_val() for f64 is 1e-15 (math/fft.rs)
-        const double r = (prev - next) / denom;
-        return std::fmin(std::fmax(r, -0.5), 0.5);
-    };
-    *conf = std::fabs(sigma) < 1e-15 ? 0.0 : (sv[0] - mean) / sigma;                    // normalization.rs:163-168
-    const double raw_dy = py > fr / 2 ? (double)py - (double)fr : (double)py;           // subpixel.rs:77-83
-    const double raw_dx = px > fc / 2 ? (double)px - (double)fc : (double)px;
-    *dy = raw_dy + refine(sv[0], sv[1], sv[2]);
-    *dx = raw_dx + refine(sv[0], sv[3], sv[4]);
+    finish_from_fin(fin, fr, fc, dx, dy, conf);
     return AB_OK;
 }
 
@@ -541,6 +710,210 @@ int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, i
     *dx = coarse_dx + rdx;
     *dy = coarse_dy + rdy;
     *confidence = rconf;
+    return AB_OK;
+}
+
+// ---- phase_correlate(reference, targets[i]) for every i in ONE batch per stage (round 5) ----------------------------
+// stack_images(align = true) registers every frame on frame 0 (combine.rs:123-138): the reference's min / max, its downsampled
+// plane, its window + coarse spectrum and its crop's spectrum used to be recomputed for every pair, and every pair brought three
+// host joins of its own.  Here a stage runs for all pairs at once (blockIdx.y = pair) and ends in one read-back: three joins per
+// batch instead of three per pair, the reference's work done once.  Same kernels' arithmetic in the same order: every (dx, dy,
+// confidence) equals ab_phase_correlate_device's bit for bit.
+namespace {
+
+constexpr size_t kPcBatch = 16;  // pairs per round (4 MiB of spectrum + 2 MiB of surface + 1 MiB of downsampled plane each)
+
+struct PcBatchScratch {
+    double2 *fa;       // the reference's spectrum (512 x 512)
+    double2 *fb;       // kPcBatch x 512 x 512
+    double *corr;      // kPcBatch x 512 x 512
+    float *ds;         // (1 + kPcBatch) x 512 x 512: the downsampled reference, then the targets
+    MinMaxPartial *mm;  // (1 + kPcBatch) x kMinMaxPartials
+    PeakPartial *peak;  // kPcBatch x kPartials
+    double *var;        // kPcBatch x kPartials
+    PcFin *fin;         // kPcBatch
+    PcItem *items;      // 1 + kPcBatch
+    unsigned int upload = 0;  // uploads so far: each takes its own 1 KiB slot of the pinned block (two may be pending between joins)
+};
+
+int pc_batch_carve(ab_ctx *ctx, PcBatchScratch *s) {
+    const size_t n = 512 * 512, B = kPcBatch;
+    const size_t bytes = n * sizeof(double2) + B * n * sizeof(double2) + B * n * sizeof(double) + (1 + B) * n * sizeof(float) +
+                         (1 + B) * kMinMaxPartials * sizeof(MinMaxPartial) + B * kPartials * sizeof(PeakPartial) + B * kPartials * sizeof(double) +
+                         B * sizeof(PcFin) + (1 + B) * sizeof(PcItem) + 1024;
+    void *p = nullptr;
+    AB_TRY(ab_scratch(ctx, bytes, &p));
+    char *c = (char *)p;
+    s->fa = (double2 *)c; c += n * sizeof(double2);
+    s->fb = (double2 *)c; c += B * n * sizeof(double2);
+    s->corr = (double *)c; c += B * n * sizeof(double);
+    s->ds = (float *)c; c += (1 + B) * n * sizeof(float);
+    s->mm = (MinMaxPartial *)c; c += (1 + B) * kMinMaxPartials * sizeof(MinMaxPartial);
+    s->peak = (PeakPartial *)c; c += B * kPartials * sizeof(PeakPartial);
+    s->var = (double *)c; c += B * kPartials * sizeof(double);
+    s->fin = (PcFin *)c; c += ((B * sizeof(PcFin) + 15) / 16) * 16;
+    s->items = (PcItem *)c;
+    return AB_OK;
+}
+
+// upload `cnt` views as the kernels' item table (through the context's pinned buffer: the host vector is a local)
+int pc_upload_items(ab_ctx *ctx, PcBatchScratch &s, const View *v, size_t cnt) {
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, 64 * 1024, &pin));  // (also holds the stage's read-back further up: see the offsets below)
+    PcItem *h = (PcItem *)((char *)pin + (size_t)(s.upload++ % 16u) * 1024);  // (a slot is reused only many joins later)
+    for (size_t i = 0; i < cnt; ++i) h[i] = PcItem{v[i].p, v[i].ld, v[i].rows, v[i].cols};
+    AB_HIP(ctx, hipMemcpyAsync(s.items, h, cnt * sizeof(PcItem), hipMemcpyHostToDevice, ctx->stream));
+    return AB_OK;
+}
+
+// correlate_single(a, b[i]) for i < nb: all views rows x cols (<= 512 x 512)
+int correlate_batch(ab_ctx *ctx, const View &a, const View *b, size_t nb, PcBatchScratch &s, int table_set, double *dx, double *dy, double *conf) {
+    const int rows = a.rows, cols = a.cols;
+    const int fr = next_pow2(rows), fc = next_pow2(cols), n = fr * fc;
+    PcScratch t{};
+    AB_TRY(pc_tables(ctx, &t, table_set, rows, cols, fr, fc));
+    const int g = (n + kBlock - 1) / kBlock;
+    std::vector<View> views(b, b + nb);
+    AB_TRY(pc_upload_items(ctx, s, views.data(), nb));
+    hipLaunchKernelGGL(window_pad_kernel, dim3(g), dim3(kBlock), 0, ctx->stream, a.p, rows, cols, a.ld, t.hann_y, t.hann_x, fr, fc, s.fa);
+    hipLaunchKernelGGL(window_pad_many_kernel, dim3(g, (unsigned)nb), dim3(kBlock), 0, ctx->stream, (const PcItem *)s.items, (const double *)t.hann_y, (const double *)t.hann_x, fr, fc,
+                       s.fb);
+    AB_TRY(fft2d(ctx, s.fa, fr, fc, t, 0));
+    auto fft2d_many = [&](int inverse) {
+        hipLaunchKernelGGL(fft_lines_many_kernel, dim3(fr, (unsigned)nb), dim3(kBlock), 0, ctx->stream, s.fb, (int64_t)n, fc, ilog2(fc), (int64_t)1, (int64_t)fc,
+                           (const double2 *)t.tw_c, inverse);  // rows
+        hipLaunchKernelGGL(fft_lines_many_kernel, dim3(fc, (unsigned)nb), dim3(kBlock), 0, ctx->stream, s.fb, (int64_t)n, fr, ilog2(fr), (int64_t)fc, (int64_t)1,
+                           (const double2 *)t.tw_r, inverse);  // columns
+    };
+    fft2d_many(0);
+    hipLaunchKernelGGL(cross_power_many_kernel, dim3(g, (unsigned)nb), dim3(kBlock), 0, ctx->stream, (const double2 *)s.fa, s.fb, n, kEpsilon);
+    fft2d_many(1);
+    const int pg = std::min(kPartials, g);
+    hipLaunchKernelGGL(scale_peak_kernel, dim3(pg, (unsigned)nb), dim3(kBlock), 0, ctx->stream, (const double2 *)s.fb, n, 1.0 / (double)((size_t)fr * fc), s.corr, s.peak, kPartials);
+    hipLaunchKernelGGL(peak_finish_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const PeakPartial *)s.peak, pg, s.fin, kPartials);
+    hipLaunchKernelGGL(var_kernel, dim3(pg, (unsigned)nb), dim3(kBlock), 0, ctx->stream, (const double *)s.corr, n, (const PcFin *)s.fin, s.var, kPartials);
+    hipLaunchKernelGGL(var_finish_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const double *)s.var, pg, (const double *)s.corr, fr, fc, s.fin, kPartials);
+    AB_HIP(ctx, hipGetLastError());
+    void *pin = nullptr;
+    AB_TRY(ab_pinned(ctx, 64 * 1024, &pin));
+    PcFin *hf = (PcFin *)((char *)pin + 32 * 1024);
+    AB_HIP(ctx, hipMemcpyAsync(hf, s.fin, nb * sizeof(PcFin), hipMemcpyDeviceToHost, ctx->stream));
+    AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < nb; ++i) finish_from_fin(hf[i], fr, fc, &dx[i], &dy[i], &conf[i]);
+    return AB_OK;
+}
+
+}  // namespace
+
+int ab_phase_correlate_many_device(ab_ctx *ctx, const float *ref, int64_t ref_ld, const float *const *tgts, const int64_t *tgt_ld, size_t n, int64_t rows,
+                                   int64_t cols, double *dx, double *dy, double *confidence) {
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    for (size_t i = 0; i < n; ++i) dx[i] = dy[i] = confidence[i] = 0.0;
+    if (n == 0) return AB_OK;
+    AB_CHECK(ctx, rows > 0 && cols > 0 && rows < (1 << 30) && cols < (1 << 30), "phase_correlate: bad dims");
+    static_assert(sizeof(PcItem) * (1 + kPcBatch) <= 1024 && sizeof(PcFin) * kPcBatch <= 16 * 1024, "the pinned block's slots");
+    PcBatchScratch s;
+    AB_TRY(pc_batch_carve(ctx, &s));
+    const View r{ref, (int)rows, (int)cols, ref_ld};
+    for (size_t base = 0; base < n; base += kPcBatch) {
+        const size_t nb = std::min(kPcBatch, n - base);
+        std::vector<View> t(nb);
+        for (size_t i = 0; i < nb; ++i) t[i] = View{tgts[base + i], (int)rows, (int)cols, tgt_ld[base + i]};
+        // ---- is_constant_or_zero (:143-160) of the reference and of every target: one launch, one read-back ----
+        std::vector<View> all(1 + nb);
+        all[0] = r;
+        for (size_t i = 0; i < nb; ++i) all[1 + i] = t[i];
+        AB_TRY(pc_upload_items(ctx, s, all.data(), all.size()));
+        const int mg = (int)std::min<int64_t>(kMinMaxPartials, rows);
+        hipLaunchKernelGGL(minmax_finite_many_kernel, dim3(mg, (unsigned)(1 + nb)), dim3(kBlock), 0, ctx->stream, (const PcItem *)s.items, s.mm, kMinMaxPartials);
+        AB_HIP(ctx, hipGetLastError());
+        std::vector<MinMaxPartial> hm((1 + nb) * (size_t)mg);
+        {
+            // (the partials of plane k sit kMinMaxPartials apart: mg of them are copied per plane)
+            void *pin = nullptr;
+            const size_t need = (1 + nb) * (size_t)kMinMaxPartials * sizeof(MinMaxPartial);
+            AB_TRY(ab_pinned(ctx, std::max<size_t>(need, 64 * 1024), &pin));
+            AB_HIP(ctx, hipMemcpyAsync(pin, s.mm, need, hipMemcpyDeviceToHost, ctx->stream));
+            AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (size_t k = 0; k < 1 + nb; ++k) memcpy(&hm[k * mg], (const MinMaxPartial *)pin + k * kMinMaxPartials, (size_t)mg * sizeof(MinMaxPartial));
+        }
+        auto degenerate = [&](size_t k) {
+            float mn = INFINITY, mx = -INFINITY;
+            unsigned long long cnt = 0;
+            for (int i = 0; i < mg; ++i) {
+                mn = std::fmin(mn, hm[k * mg + i].mn);
+                mx = std::fmax(mx, hm[k * mg + i].mx);
+                cnt += hm[k * mg + i].finite;
+            }
+            return cnt < 16 || std::fabs(mx - mn) < 1e-10f;
+        };
+        if (degenerate(0)) continue;  // :42-44: every pair of this round is (0, 0, 0)
+        std::vector<size_t> live;     // indices (within the round) of the pairs that are correlated
+        for (size_t i = 0; i < nb; ++i)
+            if (!degenerate(1 + i)) live.push_back(i);  // :45-48
+        if (live.empty()) continue;
+        std::vector<View> lv(live.size());
+        std::vector<double> ldx(live.size()), ldy(live.size()), lcf(live.size());
+        if (rows <= kCoarseMaxDim && cols <= kCoarseMaxDim) {  // :50-52
+            for (size_t k = 0; k < live.size(); ++k) lv[k] = t[live[k]];
+            AB_TRY(correlate_batch(ctx, r, lv.data(), lv.size(), s, 0, ldx.data(), ldy.data(), lcf.data()));
+            for (size_t k = 0; k < live.size(); ++k) {
+                dx[base + live[k]] = ldx[k];
+                dy[base + live[k]] = ldy[k];
+                confidence[base + live[k]] = lcf[k];
+            }
+            continue;
+        }
+        // ---- coarse: area_downsample to <= 512 x 512 (the reference once), correlate (:54-64) ----
+        const double scale_y = (double)rows / (double)kCoarseMaxDim, scale_x = (double)cols / (double)kCoarseMaxDim;
+        const int ds_rows = (int)std::min<int64_t>(kCoarseMaxDim, rows), ds_cols = (int)std::min<int64_t>(kCoarseMaxDim, cols);
+        const double dsy = (double)rows / (double)ds_rows, dsx = (double)cols / (double)ds_cols;
+        const size_t dn = (size_t)ds_rows * ds_cols;
+        std::vector<View> src(1 + live.size());
+        src[0] = r;
+        for (size_t k = 0; k < live.size(); ++k) src[1 + k] = t[live[k]];
+        AB_TRY(pc_upload_items(ctx, s, src.data(), src.size()));
+        hipLaunchKernelGGL(area_downsample_many_kernel, dim3((unsigned)((dn + kBlock - 1) / kBlock), (unsigned)src.size()), dim3(kBlock), 0, ctx->stream, (const PcItem *)s.items, ds_rows,
+                           ds_cols, dsy, dsx, s.ds);
+        AB_HIP(ctx, hipGetLastError());
+        for (size_t k = 0; k < live.size(); ++k) lv[k] = View{s.ds + (1 + k) * dn, ds_rows, ds_cols, ds_cols};
+        AB_TRY(correlate_batch(ctx, View{s.ds, ds_rows, ds_cols, ds_cols}, lv.data(), lv.size(), s, 0, ldx.data(), ldy.data(), lcf.data()));
+        // ---- refine on centred 512 x 512 crops (:66-88); a pair whose crops differ in size keeps the coarse answer (:74-80) ----
+        const int64_t half = kRefineCropSize / 2, ref_cy = rows / 2, ref_cx = cols / 2;
+        auto crop = [&](const View &v, int64_t cy, int64_t cx) {  // extract_crop, :91-103
+            const int64_t y0 = cy > half ? cy - half : 0, y1 = std::min(cy + half, rows), x0 = cx > half ? cx - half : 0, x1 = std::min(cx + half, cols);
+            return View{v.p + y0 * v.ld + x0, (int)(y1 - y0), (int)(x1 - x0), v.ld};
+        };
+        const View rc = crop(r, ref_cy, ref_cx);
+        std::vector<size_t> fine;  // positions in `live`
+        std::vector<View> fv;
+        std::vector<double> cdx(live.size()), cdy(live.size());
+        for (size_t k = 0; k < live.size(); ++k) {
+            cdx[k] = ldx[k] * scale_x;
+            cdy[k] = ldy[k] * scale_y;
+            const int64_t tgt_cy = std::min(std::max<int64_t>(f64_to_i64_sat(std::round((double)ref_cy + cdy[k])), 0), rows - 1);
+            const int64_t tgt_cx = std::min(std::max<int64_t>(f64_to_i64_sat(std::round((double)ref_cx + cdx[k])), 0), cols - 1);
+            const View tc = crop(t[live[k]], tgt_cy, tgt_cx);
+            if (tc.rows != rc.rows || tc.cols != rc.cols) {
+                dx[base + live[k]] = cdx[k];
+                dy[base + live[k]] = cdy[k];
+                confidence[base + live[k]] = lcf[k];
+            } else {
+                fine.push_back(k);
+                fv.push_back(tc);
+            }
+        }
+        if (!fine.empty()) {
+            std::vector<double> rdx(fine.size()), rdy(fine.size()), rcf(fine.size());
+            AB_TRY(correlate_batch(ctx, rc, fv.data(), fv.size(), s, 1, rdx.data(), rdy.data(), rcf.data()));
+            for (size_t j = 0; j < fine.size(); ++j) {
+                const size_t k = fine[j];
+                dx[base + live[k]] = cdx[k] + rdx[j];
+                dy[base + live[k]] = cdy[k] + rdy[j];
+                confidence[base + live[k]] = rcf[j];
+            }
+        }
+    }
     return AB_OK;
 }
 

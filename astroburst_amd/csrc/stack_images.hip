@@ -11,6 +11,8 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
                     uint64_t *out_rejected, bool median_only);
 int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, int64_t ref_cols, int64_t ref_ld, const float *tgt,
                               int64_t tgt_rows, int64_t tgt_cols, int64_t tgt_ld, double *dx, double *dy, double *confidence);
+int ab_phase_correlate_many_device(ab_ctx *ctx, const float *ref, int64_t ref_ld, const float *const *tgts, const int64_t *tgt_ld, size_t n, int64_t rows,
+                                   int64_t cols, double *dx, double *dy, double *confidence);
 int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, int64_t src_ld, double dy, double dx, float *out);
 
 namespace {
@@ -44,7 +46,7 @@ extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, co
     std::vector<StagedPlane> st(n);
     std::vector<const float *> dp(n);
     std::vector<int64_t> ld(n);
-    std::vector<void *> shifted(n, nullptr);
+    char *shifted_pool = nullptr;
     int rc = AB_OK;
     size_t staged = 0;
     for (; staged < n; ++staged) {
@@ -54,22 +56,27 @@ extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, co
         ld[staged] = st[staged].cols;
     }
     const size_t plane_bytes = (size_t)min_rows * (size_t)min_cols * sizeof(float);
+    // every frame against frame 0 as ONE batch per stage (AB_STACK_PAIRWISE=1: a phase_correlate call per pair, round 4's form)
+    std::vector<double> sdx(n, 0.0), sdy(n, 0.0), scf(n, 0.0);
+    static const bool pairwise = getenv("AB_STACK_PAIRWISE") != nullptr;
+    if (rc == AB_OK && !pairwise)
+        rc = ab_phase_correlate_many_device(ctx, dp[0], ld[0], dp.data() + 1, ld.data() + 1, n - 1, min_rows, min_cols, sdx.data() + 1, sdy.data() + 1, scf.data() + 1);
     for (size_t i = 1; rc == AB_OK && i < n; ++i) {
-        double dx = 0.0, dy = 0.0, conf = 0.0;
-        rc = ab_phase_correlate_device(ctx, dp[0], min_rows, min_cols, ld[0], dp[i], min_rows, min_cols, ld[i], &dx, &dy, &conf);
+        double dx = sdx[i], dy = sdy[i], conf = scf[i];
+        if (pairwise) rc = ab_phase_correlate_device(ctx, dp[0], min_rows, min_cols, ld[0], dp[i], min_rows, min_cols, ld[i], &dx, &dy, &conf);
         if (rc != AB_OK) break;
         if (offsets_dy_dx) {
             offsets_dy_dx[2 * i] = round_to_i32(dy);
             offsets_dy_dx[2 * i + 1] = round_to_i32(dx);
         }
         if (std::fabs(dy) < 1e-12 && std::fabs(dx) < 1e-12) continue;  // align.rs:37-39: clone -> read the frame in place
-        hipError_t e = hipMalloc(&shifted[i], plane_bytes);
-        if (e != hipSuccess) {
-            rc = ab_set_error(ctx, AB_ERR_HIP, "hipMalloc(%zu) for aligned frame %zu: %s", plane_bytes, i, hipGetErrorString(e));
-            break;
+        if (!shifted_pool) {  // one grow-only workspace for all the registered copies (a hipMalloc + hipFree pair per frame cost 0.2 - 0.5 ms each)
+            rc = ab_workspace(ctx, AB_WS_STACK_SHIFTED, (n - 1) * plane_bytes, (void **)&shifted_pool);
+            if (rc != AB_OK) break;
         }
-        rc = ab_shift_device(ctx, dp[i], min_rows, min_cols, ld[i], dy, dx, (float *)shifted[i]);
-        dp[i] = (const float *)shifted[i];
+        float *dst = (float *)(shifted_pool + (i - 1) * plane_bytes);
+        rc = ab_shift_device(ctx, dp[i], min_rows, min_cols, ld[i], dy, dx, dst);
+        dp[i] = dst;
         ld[i] = min_cols;
     }
     StagedOut so;
@@ -86,9 +93,6 @@ extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, co
         so_open = false;
     }
     if (so_open) ab_stage_out_abort(ctx, &so);
-    (void)hipStreamSynchronize(ctx->stream);
-    for (size_t i = 0; i < n; ++i)
-        if (shifted[i]) (void)hipFree(shifted[i]);
     for (size_t i = 0; i < staged; ++i) ab_stage_release(ctx, &st[i]);
     if (rc == AB_OK && out_rejected) *out_rejected = rejected;
     return rc;
