@@ -458,10 +458,7 @@ __device__ __forceinline__ void lds_union(int *lab, int a, int b) {
 constexpr int kRegions = 64, kRegionPitch = 64;  // counters: lcnt[r * kRegionPitch] = labelled, lcnt[(kRegions + r) * kRegionPitch] = border
 __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
                                                 int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist_all, size_t plist_stride,
-                                                int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt, int ntile) {
-    // A workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x is a multiple of kRegions: one region per
-    // workgroup; by default gridDim.x covers every tile and the loop runs once) and prefetches the next tile's pixels as soon as
-    // the current tile's have been thresholded.
+                                                int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt) {
     const int region = (int)(blockIdx.x % kRegions);
     int *__restrict__ plist = plist_all + (size_t)region * plist_stride, *__restrict__ blist = blist_all + (size_t)region * blist_stride;
     unsigned int *nlab = lcnt + region * kRegionPitch, *nborder = lcnt + (kRegions + region) * kRegionPitch;
@@ -470,98 +467,92 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
     __shared__ unsigned int n_found, n_edge, base_found, base_edge;
     const int tid = threadIdx.x, lane = tid & 63;
     const int tiles_x = (cols + kTileW - 1) / kTileW;
+    const int ty0 = (int)(blockIdx.x / tiles_x) * kTileH, tx0 = (int)(blockIdx.x % tiles_x) * kTileW;
     const int q = tid & 31, r0 = tid >> 5;  // this thread: columns 4 q .. 4 q + 3 of rows r0, r0 + 8, r0 + 16, r0 + 24
-    auto fetch = [&](int tile, float4 (&v)[4]) {
-        const int ty0 = (tile / tiles_x) * kTileH, tx0 = (tile % tiles_x) * kTileW;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
-            v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (tile < ntile && r < rows && c < cols) v[j] = *reinterpret_cast<const float4 *>(img + (int64_t)r * cols + c);  // (cols % 4 == 0: the quad is inside)
-        }
-    };
+    if (tid == 0) n_found = n_edge = 0;
+    unsigned int bits = 0;  // bit 4 j + k: pixel (r0 + 8 j, 4 q + k)
     float4 v[4];
-    fetch((int)blockIdx.x, v);
-    for (int tile = (int)blockIdx.x; tile < ntile; tile += (int)gridDim.x) {  // block-uniform
-        const int ty0 = (tile / tiles_x) * kTileH, tx0 = (tile % tiles_x) * kTileW;
-        if (tid == 0) n_found = n_edge = 0;
-        unsigned int bits = 0;  // bit 4 j + k: pixel (r0 + 8 j, 4 q + k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
-            const bool in = r < rows && c < cols;
-            const unsigned int b = (unsigned int)(in && above(ab_px(xf, v[j].x), threshold)) | ((unsigned int)(in && above(ab_px(xf, v[j].y), threshold)) << 1) |
-                                   ((unsigned int)(in && above(ab_px(xf, v[j].z), threshold)) << 2) | ((unsigned int)(in && above(ab_px(xf, v[j].w), threshold)) << 3);
-            bits |= b << (4 * j);
-            unsigned int w = b << (4 * (lane & 7));  // eight lanes make one mask word
-            w |= __shfl_xor(w, 1, 64);
-            w |= __shfl_xor(w, 2, 64);
-            w |= __shfl_xor(w, 4, 64);
-            if ((lane & 7) == 0) {
-                tmask[r0 + 8 * j][q >> 3] = w;
-                if (in) mask[((int64_t)r * cols + c) >> 5] = w;  // (cols % 32 == 0 and tx0 % 32 == 0: a whole word of this row)
-            }
+    for (int j = 0; j < 4; ++j) {
+        const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
+        v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (r < rows && c < cols) v[j] = *reinterpret_cast<const float4 *>(img + (int64_t)r * cols + c);  // (cols % 4 == 0: the quad is inside)
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
+        const bool in = r < rows && c < cols;
+        const unsigned int b = (unsigned int)(in && above(ab_px(xf, v[j].x), threshold)) | ((unsigned int)(in && above(ab_px(xf, v[j].y), threshold)) << 1) |
+                               ((unsigned int)(in && above(ab_px(xf, v[j].z), threshold)) << 2) | ((unsigned int)(in && above(ab_px(xf, v[j].w), threshold)) << 3);
+        bits |= b << (4 * j);
+        unsigned int w = b << (4 * (lane & 7));  // eight lanes make one mask word
+        w |= __shfl_xor(w, 1, 64);
+        w |= __shfl_xor(w, 2, 64);
+        w |= __shfl_xor(w, 4, 64);
+        if ((lane & 7) == 0) {
+            tmask[r0 + 8 * j][q >> 3] = w;
+            if (in) mask[((int64_t)r * cols + c) >> 5] = w;  // (cols % 32 == 0 and tx0 % 32 == 0: a whole word of this row)
         }
-        fetch(tile + (int)gridDim.x, v);  // the next tile's loads fly while this one is labelled
-        // labels: own local index where labelled
+    }
+    // labels: own local index where labelled
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((bits >> (4 * j + k)) & 1u) {
-                    const int li = (r0 + 8 * j) * kTileW + 4 * q + k;
-                    lab[li] = li;
-                }
-        __syncthreads();
-        auto lbl = [&](int r, int c) -> bool { return (tmask[r][c >> 5] >> (c & 31)) & 1u; };
-        // unions inside the tile, forward half of the 8-neighbourhood: E, SW, S, SE
-        unsigned int todo = bits;
-        while (todo) {
-            const int bpos = __builtin_ctz(todo);
-            todo &= todo - 1;
-            const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
-            if (c + 1 < kTileW && lbl(r, c + 1)) lds_union(lab, li, li + 1);
-            if (r + 1 < kTileH) {
-                const int d = li + kTileW;
-                if (c > 0 && lbl(r + 1, c - 1)) lds_union(lab, li, d - 1);
-                if (lbl(r + 1, c)) lds_union(lab, li, d);
-                if (c + 1 < kTileW && lbl(r + 1, c + 1)) lds_union(lab, li, d + 1);
+        for (int k = 0; k < 4; ++k)
+            if ((bits >> (4 * j + k)) & 1u) {
+                const int li = (r0 + 8 * j) * kTileW + 4 * q + k;
+                lab[li] = li;
             }
+    __syncthreads();
+    auto lbl = [&](int r, int c) -> bool { return (tmask[r][c >> 5] >> (c & 31)) & 1u; };
+    // unions inside the tile, forward half of the 8-neighbourhood: E, SW, S, SE
+    unsigned int todo = bits;
+    while (todo) {
+        const int bpos = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
+        if (c + 1 < kTileW && lbl(r, c + 1)) lds_union(lab, li, li + 1);
+        if (r + 1 < kTileH) {
+            const int d = li + kTileW;
+            if (c > 0 && lbl(r + 1, c - 1)) lds_union(lab, li, d - 1);
+            if (lbl(r + 1, c)) lds_union(lab, li, d);
+            if (c + 1 < kTileW && lbl(r + 1, c + 1)) lds_union(lab, li, d + 1);
         }
-        // list + border list positions (one LDS atomic per thread, one global atomic per workgroup and list, from two lanes at once)
-        const int cnt = __builtin_popcount(bits);
-        unsigned int edge_bits = 0;
+    }
+    __syncthreads();
+    // flatten -> global forest; list + border list positions (one LDS atomic per thread, one global atomic per workgroup)
+    const int cnt = __builtin_popcount(bits);
+    unsigned int edge_bits = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int r = r0 + 8 * j, c = 4 * q + k;
-                const bool on_edge = r == kTileH - 1 || c == 0 || c == kTileW - 1;
-                if (((bits >> (4 * j + k)) & 1u) && on_edge) edge_bits |= 1u << (4 * j + k);
-            }
-        const int ecnt = __builtin_popcount(edge_bits);
-        unsigned int at = 0, eat = 0;
-        if (cnt) at = atomicAdd(&n_found, (unsigned int)cnt);
-        if (ecnt) eat = atomicAdd(&n_edge, (unsigned int)ecnt);
-        __syncthreads();  // (unions done, counts complete)
-        if (tid == 0) base_found = n_found ? atomicAdd(nlab, n_found) : 0u;
-        if (tid == 64) base_edge = n_edge ? atomicAdd(nborder, n_edge) : 0u;
-        __syncthreads();
-        at += base_found;
-        eat += base_edge;
-        // flatten -> global forest
-        todo = bits;
-        while (todo) {
-            const int bpos = __builtin_ctz(todo);
-            todo &= todo - 1;
-            const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
-            const int root = lds_find(lab, li);
-            const int gi = (ty0 + r) * cols + tx0 + c, groot = (ty0 + (root >> 7)) * cols + tx0 + (root & (kTileW - 1));
-            parent[gi] = groot;
-            plist[at++] = gi;
-            if ((edge_bits >> bpos) & 1u) blist[eat++] = gi;
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + 8 * j, c = 4 * q + k;
+            const bool on_edge = r == kTileH - 1 || c == 0 || c == kTileW - 1;
+            if (((bits >> (4 * j + k)) & 1u) && on_edge) edge_bits |= 1u << (4 * j + k);
         }
-        __syncthreads();  // the next tile rewrites tmask / lab / the counters
+    const int ecnt = __builtin_popcount(edge_bits);
+    unsigned int at = 0, eat = 0;
+    if (cnt) at = atomicAdd(&n_found, (unsigned int)cnt);
+    if (ecnt) eat = atomicAdd(&n_edge, (unsigned int)ecnt);
+    __syncthreads();
+    if (tid == 0) {
+        base_found = n_found ? atomicAdd(nlab, n_found) : 0u;
+        base_edge = n_edge ? atomicAdd(nborder, n_edge) : 0u;
+    }
+    __syncthreads();
+    at += base_found;
+    eat += base_edge;
+    todo = bits;
+    while (todo) {
+        const int bpos = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
+        const int root = lds_find(lab, li);
+        const int gi = (ty0 + r) * cols + tx0 + c, groot = (ty0 + (root >> 7)) * cols + tx0 + (root & (kTileW - 1));
+        parent[gi] = groot;
+        plist[at++] = gi;
+        if ((edge_bits >> bpos) & 1u) blist[eat++] = gi;
     }
 }
 
@@ -1172,9 +1163,9 @@ __global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g,
     const int f = blockIdx.y;
     label_merge_body(rows, cols, g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1);
 }
-__global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const DetGroup g, int rows, int cols, int ntile) { AB_LATENCY_KERNEL_PRIO();
+__global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    label_tile_body(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f], ntile);
+    label_tile_body(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f]);
 }
 // (grids of the region walkers: a multiple of kRegions blocks; block b works on region b mod kRegions as sub-block b / kRegions)
 __global__ __launch_bounds__(256) void label_border_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
@@ -2242,13 +2233,10 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     g.blist_stride = blist_stride;
     if (tiled) AB_HIP(ctx, hipMemsetAsync(g.lcnt[0], 0, (size_t)G * lcnt_words * sizeof(unsigned int), ctx->stream));
     if (tiled) {
-        // workgroups per frame: a multiple of kRegions (one list region per workgroup); by default one per tile.  AB_LABEL_TILE_WG=n
-        // caps them, a workgroup then walks several tiles with the next tile's loads in flight: measured 128 / 142 us per group of
-        // four 4096^2 frames with 1024 / 2048 workgroups against 101 us with one tile each (profiles/r05_label_tile_variants.txt) --
-        // the stage does not change either way (11.2 ms), so the simpler shape is the default.
-        static const int tile_wg = getenv("AB_LABEL_TILE_WG") ? std::max(1, atoi(getenv("AB_LABEL_TILE_WG"))) : (1 << 30);
-        const unsigned int tgrid = (unsigned int)std::max<int64_t>(kRegions, std::min<int64_t>((ntile + kRegions - 1) / kRegions * kRegions, (int64_t)tile_wg / kRegions * kRegions));
-        hipLaunchKernelGGL(label_tile_many_kernel, dim3(tgrid, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols, (int)ntile);
+        // (one workgroup per tile.  Tried: fewer workgroups that walk several tiles with the next tile's loads in flight -- 128 / 142 us
+        // per group of four 4096^2 frames with 1024 / 2048 workgroups against 101 us, profiles/r05_label_tile_variants.txt; the loop
+        // alone, one trip per workgroup, cost 40 us: 36 VGPRs instead of 20 and the prefetch's predication.  The stage did not move.)
+        hipLaunchKernelGGL(label_tile_many_kernel, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
         hipLaunchKernelGGL(label_border_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
     } else {
         hipLaunchKernelGGL(label_init_many_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds)), (unsigned)G), dim3(kInitBlock), 0, ctx->stream, g,
