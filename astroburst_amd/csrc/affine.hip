@@ -459,14 +459,21 @@ __device__ __forceinline__ void tri_build_body(const double *__restrict__ xy, in
     }
 }
 
-// exclusive scan of the 4096 bucket counts (one 1024-thread block); sets the scatter cursors and re-zeroes the
-// histogram for the next table
+// exclusive scan of the 4096 bucket counts (one 256-thread block, 16 buckets per thread: a 1024-thread workgroup waits for sixteen
+// free wave slots on one CU -- inside a batch of 171-Mpixel frames this 3 us kernel took 270 - 400 us); sets the scatter cursors and
+// re-zeroes the histogram for the next table
+constexpr int kScanThreads = 256, kScanPer = kTriBins / kScanThreads;
 __device__ __forceinline__ void tri_bin_scan_body(unsigned int *__restrict__ hist, unsigned int *__restrict__ off /* kTriBins + 1 */,
                                                             unsigned int *__restrict__ cursor) {
-    __shared__ unsigned int wave_tot[16];
+    __shared__ unsigned int wave_tot[kScanThreads / 64];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const unsigned int h0 = hist[4 * t], h1 = hist[4 * t + 1], h2 = hist[4 * t + 2], h3 = hist[4 * t + 3];
-    const unsigned int s = h0 + h1 + h2 + h3;
+    unsigned int h[kScanPer], s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; j += 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(hist + kScanPer * t + j);
+        h[j] = q.x, h[j + 1] = q.y, h[j + 2] = q.z, h[j + 3] = q.w;
+        s += q.x + q.y + q.z + q.w;
+    }
     unsigned int inc = s;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -477,15 +484,15 @@ __device__ __forceinline__ void tri_bin_scan_body(unsigned int *__restrict__ his
     __syncthreads();
     unsigned int base = 0;
     for (int i = 0; i < wv; ++i) base += wave_tot[i];
-    const unsigned int e = base + inc - s;
-    const unsigned int c[4] = {e, e + h0, e + h0 + h1, e + h0 + h1 + h2};
+    unsigned int e = base + inc - s;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        off[4 * t + j] = c[j];
-        cursor[4 * t + j] = c[j];
-        hist[4 * t + j] = 0;
+    for (int j = 0; j < kScanPer; ++j) {
+        off[kScanPer * t + j] = e;
+        cursor[kScanPer * t + j] = e;
+        hist[kScanPer * t + j] = 0;
+        e += h[j];
     }
-    if (t == 1023) off[kTriBins] = e + s;
+    if (t == kScanThreads - 1) off[kTriBins] = e;
 }
 
 // Bucket scatter.  A block ranks its 1024 triangles inside their buckets with LDS atomics and reserves each touched
@@ -694,10 +701,10 @@ __global__ __launch_bounds__(kTriBlock) void tri_build_many_kernel(const TriGrou
     const int f = blockIdx.y;
     tri_build_body(stars[f].xy, g.limit[f], g.raw[f], g.count[f], g.bin_hist[f], g.votes[f], vote_words);
 }
-__global__ __launch_bounds__(1024) void tri_bin_scan_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ off, unsigned int *__restrict__ cursor) { AB_LATENCY_KERNEL_PRIO();
+__global__ __launch_bounds__(kScanThreads) void tri_bin_scan_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ off, unsigned int *__restrict__ cursor) { AB_LATENCY_KERNEL_PRIO();
     tri_bin_scan_body(hist, off, cursor);
 }
-__global__ __launch_bounds__(1024) void tri_bin_scan_many_kernel(const TriGroup g) { AB_LATENCY_KERNEL_PRIO();
+__global__ __launch_bounds__(kScanThreads) void tri_bin_scan_many_kernel(const TriGroup g) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     tri_bin_scan_body(g.bin_hist[f], g.bin_off[f], g.cursor[f]);
 }
@@ -786,7 +793,7 @@ int gpu_build_triangles(ab_ctx *ctx, const MatchWs &w, const std::vector<Pt> &st
                            clears ? w.votes : (unsigned int *)nullptr, vote_words);
     if (which && !clears) AB_HIP(ctx, hipMemsetAsync(w.votes, 0, (size_t)vote_words * sizeof(unsigned int), ctx->stream));
     // (the scan leaves bin_hist zeroed again)
-    hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
+    hipLaunchKernelGGL(tri_bin_scan_kernel, dim3(1), dim3(kScanThreads), 0, ctx->stream, w.bin_hist, w.bin_off, w.cursor);
     hipLaunchKernelGGL(tri_scatter_kernel, dim3((kMaxTris + kTriBlock - 1) / kTriBlock), dim3(kTriBlock), 0, ctx->stream, raw, w.counts + which, w.cursor, sorted);
     if (!which) {
         hipLaunchKernelGGL(tri_bucket_sort_kernel, dim3(kTriBins), dim3(256), 0, ctx->stream, sorted, w.bin_off);
@@ -880,7 +887,7 @@ int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *s
     // every table's builder clears that frame's vote matrices (its grid must have the threads: 1024-thread blocks over limit^3 >= 27)
     const int total = max_limit * max_limit * max_limit, blocks = std::max((total + kTriBlock - 1) / kTriBlock, (vote_words + kTriBlock - 1) / kTriBlock);
     hipLaunchKernelGGL(tri_build_many_kernel, dim3(blocks, G), dim3(kTriBlock), 0, ctx->stream, w.g, (const StarXY *)w.stars, vote_words);
-    hipLaunchKernelGGL(tri_bin_scan_many_kernel, dim3(1, G), dim3(1024), 0, ctx->stream, w.g);
+    hipLaunchKernelGGL(tri_bin_scan_many_kernel, dim3(1, G), dim3(kScanThreads), 0, ctx->stream, w.g);
     hipLaunchKernelGGL(tri_scatter_many_kernel, dim3((kMaxTris + kTriBlock - 1) / kTriBlock, G), dim3(kTriBlock), 0, ctx->stream, w.g);
     hipLaunchKernelGGL(tri_vote_many_kernel, dim3(kVoteBlocks, G), dim3(64), 0, ctx->stream, w.g, (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts,
                        copies, (const RefGroup *)ref_ws.groups);
@@ -899,8 +906,17 @@ int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::
     double m, s;
     // the normalised frame is never materialised: detection applies the transform on load.  xf: the frame's transform if the
     // caller has it already (a batch takes all its frames' percentiles in one go); otherwise detection derives it first
-    AB_TRY(ab_detect_stars_device(ctx, img, rows, cols, cols, kDetectionSigma, &stars, &m, &s, xf ? *xf : ab_pixel_xf(), kMaxStars,
-                                  /*normalize_first=*/xf == nullptr, xf ? bg : nullptr));  // top_n_stars (:272-277)
+    if (xf && bg) {
+        // transform and background known (a batch's reference frame, or a target taken frame by frame): the grouped detection with
+        // a group of one -- the brightest candidates are chosen on the device and only their boxes are walked (round 5; the full
+        // list of C3's reference frame, ~100 000 components, cost 3.8 ms of moments at the head of every call).  Same stars:
+        // tests/test_gpu_detect_affine.py holds the grouped form to the frame-by-frame one.
+        const double b2[1][2] = {{bg[0], bg[1]}};
+        AB_TRY(ab_detect_stars_group_device(ctx, &img, 1, rows, cols, kDetectionSigma, xf, b2, kMaxStars, &stars));
+    } else {
+        AB_TRY(ab_detect_stars_device(ctx, img, rows, cols, cols, kDetectionSigma, &stars, &m, &s, xf ? *xf : ab_pixel_xf(), kMaxStars,
+                                      /*normalize_first=*/xf == nullptr, xf ? bg : nullptr));  // top_n_stars (:272-277)
+    }
     out->clear();
     for (const auto &st : stars) {
         if (out->size() >= kMaxStars) break;  // top_n_stars (:272-277): detections are already sorted by flux
