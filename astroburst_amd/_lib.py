@@ -343,6 +343,7 @@ def lib() -> C.CDLL:
     L.ab_comm_allreduce.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int]
     L.ab_comm_allgather.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.ab_comm_broadcast.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
+    L.ab_ctx_trim.argtypes = [vp]
     L.ab_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
     L.ab_shard_frames.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ab_stack_sigma_clip_rows.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), C.c_int64, pp, u64p]

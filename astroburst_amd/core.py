@@ -324,6 +324,10 @@ class Context:
     def synchronize(self):
         self._check(self._L.ab_ctx_synchronize(self._h))
 
+    def trim(self):
+        """release the device memory the context has grown (workspaces, scratch, host-frame staging); it stays usable"""
+        self._check(self._L.ab_ctx_trim(self._h))
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cu, mem = C.c_int(), C.c_uint64()

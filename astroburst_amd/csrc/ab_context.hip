@@ -164,6 +164,31 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     delete ctx;
 }
 
+// Give back what the context has grown: the scratch arena, every workspace, the host-frame staging area (63 frames of 8192^2 are
+// 17 GB that used to stay pinned to the context until ab_ctx_destroy -- ADVICE r4), of this context and of its frame workers.  The
+// context stays usable; the next call that needs a buffer allocates it again (and re-initialises what it keeps in it: every user
+// compares the pointer it gets with the one it initialised).  Blocks until the context's streams are idle.
+int ab_ctx_trim(ab_ctx *ctx) try {
+    if (!ctx) return AB_ERR_INVALID;
+    AB_HIP(ctx, hipSetDevice(ctx->device));
+    for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->pct_stream, ctx->warp_stream, ctx->upload_stream})
+        if (st || st == ctx->stream) AB_HIP(ctx, hipStreamSynchronize(st));
+    for (ab_ctx *w : ctx->workers) AB_TRY(ab_ctx_trim(w));
+    if (ctx->scratch) AB_HIP(ctx, hipFree(ctx->scratch));
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    for (int i = 0; i < AB_WS_SLOTS; ++i) {
+        if (ctx->ws[i]) AB_HIP(ctx, hipFree(ctx->ws[i]));
+        ctx->ws[i] = nullptr;
+        ctx->ws_bytes[i] = 0;
+    }
+    ctx->pc_tab_ws = nullptr;  // (phase_corr.hip rebuilds its tables when the workspace pointer changes)
+    if (ctx->upload_buf) AB_HIP(ctx, hipFree(ctx->upload_buf));
+    ctx->upload_buf = nullptr;
+    ctx->upload_bytes = 0;
+    return AB_OK;
+} AB_CATCH(ctx)
+
 // (a copy per calling thread, taken under the lock ab_set_error writes under: a frame worker may be recording an error while the
 // caller reads the previous one; the pointer stays valid until this thread's next ab_last_error)
 const char *ab_last_error(const ab_ctx *ctx) {

@@ -96,6 +96,12 @@ impl Hip {
         Ok((unsafe { CStr::from_ptr(name.as_ptr()) }.to_string_lossy().into_owned(), cus, hbm))
     }
 
+    /// release the device memory the context has grown for its calls (workspaces, scratch, the staging area of host frames);
+    /// the context stays usable -- for a long-lived command thread after a large batch
+    pub fn trim(&self) -> Result<()> {
+        self.check(unsafe { sys::ab_ctx_trim(self.ctx) })
+    }
+
     pub fn synchronize(&self) -> Result<()> {
         self.check(unsafe { sys::ab_ctx_synchronize(self.ctx) })
     }

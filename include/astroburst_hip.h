@@ -88,6 +88,11 @@ AB_API int ab_ctx_request_cancel(ab_ctx *ctx);
 AB_API int ab_ctx_clear_cancel(ab_ctx *ctx);
 /* device properties the bench prints: name, CU count, HBM bytes */
 AB_API int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint64_t *hbm_bytes);
+/* Release the device memory the context has grown for its calls (scratch arena, workspaces, the staging area of host-resident
+ * frames -- as large as the largest frame set it was given), its frame workers' too.  The context stays usable: the next call
+ * allocates what it needs again.  Blocks until the context's streams are idle.  A long-lived host (one ab_ctx per command
+ * thread, infra/cache.rs keeps the planes) calls it after a large batch. */
+AB_API int ab_ctx_trim(ab_ctx *ctx);
 
 /* ---- a1/a2  core/stacking/combine.rs ------------------------------------------------------ */
 /* StackConfig, types/stacking.rs:3-20 (defaults 3.0, 3.0, 5, align=true) */

@@ -491,3 +491,43 @@ def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midj
         assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
         assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (c.method, c.matched_stars, c.inliers, c.transform, c.residual_px)
     assert sum(a.method in ("affine", "rigid") for a in new) >= 7
+
+
+def test_ctx_trim_releases_and_the_context_keeps_working(oracle):
+    """ab_ctx_trim (the host-frame staging area -- 63 x 8192^2 = 17 GB -- stayed pinned to the context until it was destroyed):
+    workspaces, scratch and staging of the context and its workers go back to the allocator; the next calls allocate again and
+    give the same answers (registration of host frames, a stack, a phase correlation: every user of a kept workspace must notice
+    that its buffer is new)."""
+    import torch
+    import astroburst_amd as ab
+    from astroburst_amd import synth
+    rows, cols = 512, 640
+    y, x, flux = synth.star_catalog(rows, cols, 400, seed=13)
+    cat = (y, x, flux * 30.0)
+    ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=0.0)
+    tgts = [synth.make_frame(rows, cols, k + 1, cat=cat, shift=s, bad_patch_rate=0.0, cosmic_rate=0.0).pin_memory()
+            for k, s in enumerate([(2.5, -1.0), (-3.0, 4.0), (0.5, 0.25), (6.0, 2.0), (-1.25, -2.5)])]
+    c = ab.Context(0)
+    try:
+        def run():
+            outs = [torch.empty((rows, cols), device="cuda") for _ in tgts]
+            res = c.align_pairs_affine(ref, tgts, outs, num_threads=8)
+            st = c.stack_images([ref.cuda()] + outs, align=True)
+            big = torch.cat([o for o in outs] * 3, dim=0)[:2100]                    # > 4 000 000 px: the statistics' histogram path
+            u8, stats, stf = c.auto_stretch_preview(big.contiguous())
+            c.synchronize()
+            return ([(r.method, r.transform, r.inliers) for r in res], [o.cpu().numpy() for o in outs], st.image.cpu().numpy(),
+                    (st.offsets, stats.median, stats.mad, stats.valid_count, stf.midtone, int(u8.sum().item())))
+        free0 = torch.cuda.mem_get_info()[0]
+        first = run()
+        used = free0 - torch.cuda.mem_get_info()[0]
+        c.trim()
+        after = free0 - torch.cuda.mem_get_info()[0]
+        assert used > 8 * rows * cols * 4 and after < used // 4, (used, after)     # the bulk went back
+        for rep in range(2):
+            again = run()
+            assert again[0] == first[0] and again[3] == first[3]
+            assert all(np.array_equal(a, b) for a, b in zip(again[1], first[1])) and np.array_equal(again[2], first[2], equal_nan=True)
+            c.trim()
+    finally:
+        c.close()
