@@ -124,6 +124,7 @@ int ab_ctx_create(int device_id, ab_ctx **out) try {
     const char *ex = getenv("AB_STACK_EXACT");
     ctx->stack_exact = ex && ex[0] == '1';
     ctx->label_legacy = getenv("AB_LABEL_LEGACY") != nullptr;
+    ctx->label_pixelwise = getenv("AB_LABEL_PIXELWISE") != nullptr;
     ctx->detect_full_records = getenv("AB_DETECT_FULL_RECORDS") != nullptr;
     ctx->detect_midjoin = getenv("AB_DETECT_MIDJOIN") != nullptr;
     if (const char *e = getenv("AB_STACK_DEEP_FROM")) ctx->stack_deep_from = std::min(4096, std::max(64, atoi(e)));
@@ -467,7 +468,8 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
         if (ab_ctx_create(ctx->device, &wc) != AB_OK) return ab_set_error(ctx, AB_ERR_HIP, "cannot create %s worker context", what);
         wc->register_workers = 1;
         wc->parent = ctx;
-        wc->label_legacy = ctx->label_legacy;  // (the parent's choices, not the environment's at the time the pool grows)
+        wc->label_legacy = ctx->label_legacy;
+        wc->label_pixelwise = ctx->label_pixelwise;  // (the parent's choices, not the environment's at the time the pool grows)
         wc->detect_full_records = ctx->detect_full_records;
         wc->detect_midjoin = ctx->detect_midjoin;
         ctx->workers.push_back(wc);

@@ -456,13 +456,58 @@ __device__ __forceinline__ void lds_union(int *lab, int a, int b) {
 // frame -- ~12 ns each, serialised in the L2: 100 of the kernel's 110 us (the first version measured 53 us per frame against 34
 // for the two passes it replaces).  The consumers walk region by region (blockIdx.x mod kRegions).
 constexpr int kRegions = 64, kRegionPitch = 64;  // counters: lcnt[r * kRegionPitch] = labelled, lcnt[(kRegions + r) * kRegionPitch] = border
+
+// One row of a tile's mask (128 bits) and the RUNS in it.  The unions go run by run (AB_LABEL_PIXELWISE=1 keeps the pixel-by-pixel
+// form): a horizontal run of labelled pixels is one node of the tile's forest, named by its first pixel, so the E neighbour needs no
+// union at all, and the SW / S / SE neighbours of all pixels of a run [s, e] are the runs of the next row that touch columns
+// [s - 1, e + 1] -- one union per touching run instead of up to three per pixel.  A 13 x 13 star is ~13 + 12 nodes and ~12 unions
+// where the pixel form makes ~500 with every find a chain of dependent LDS round trips (tools/label_bench.hip: 30 of the kernel's
+// 42 us per frame).  The forest has the same roots: a component's smallest raster index always starts a run.
+struct RowBits {
+    unsigned long long lo, hi;  // columns 0 .. 63, 64 .. 127
+};
+__device__ __forceinline__ unsigned long long ones64(int a, int b) {  // bits a .. b, 0 <= a <= b <= 63
+    return (b == 63 ? ~0ull : ((1ull << (b + 1)) - 1ull)) & ~((1ull << a) - 1ull);
+}
+__device__ __forceinline__ RowBits row_bits(const unsigned int (*tmask)[kTileW / 32], int r) {
+    const uint4 w = *reinterpret_cast<const uint4 *>(tmask[r]);
+    return {(unsigned long long)w.x | ((unsigned long long)w.y << 32), (unsigned long long)w.z | ((unsigned long long)w.w << 32)};
+}
+__device__ __forceinline__ RowBits row_range(const RowBits &m, int a, int b) {  // m restricted to columns a .. b (0 <= a <= b <= 127)
+    RowBits o = {0ull, 0ull};
+    if (a < 64) o.lo = m.lo & ones64(a, b < 63 ? b : 63);
+    if (b >= 64) o.hi = m.hi & ones64(a > 64 ? a - 64 : 0, b - 64);
+    return o;
+}
+__device__ __forceinline__ int run_start(const RowBits &m, int c) {  // first column of the run that holds column c
+    if (c >= 64) {
+        const unsigned long long z = ~m.hi & ((1ull << (c - 64)) - 1ull);
+        if (z) return 128 - __builtin_clzll(z);
+        const unsigned long long zl = ~m.lo;
+        return zl ? 64 - __builtin_clzll(zl) : 0;
+    }
+    const unsigned long long z = ~m.lo & ((1ull << c) - 1ull);
+    return z ? 64 - __builtin_clzll(z) : 0;
+}
+__device__ __forceinline__ int run_end(const RowBits &m, int c) {  // last column of the run that holds column c
+    if (c < 64) {
+        const unsigned long long z = ~m.lo >> c;  // (bit 0 is clear: column c is labelled)
+        if (z) return c + __builtin_ctzll(z) - 1;
+        const unsigned long long zh = ~m.hi;
+        return zh ? 63 + __builtin_ctzll(zh) : 127;
+    }
+    const unsigned long long z = ~m.hi >> (c - 64);
+    return z ? c + __builtin_ctzll(z) - 1 : 127;
+}
+
+template <bool RUNS>
 __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
                                                 int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist_all, size_t plist_stride,
                                                 int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt) {
     const int region = (int)(blockIdx.x % kRegions);
     int *__restrict__ plist = plist_all + (size_t)region * plist_stride, *__restrict__ blist = blist_all + (size_t)region * blist_stride;
     unsigned int *nlab = lcnt + region * kRegionPitch, *nborder = lcnt + (kRegions + region) * kRegionPitch;
-    __shared__ unsigned int tmask[kTileH][kTileW / 32];
+    __shared__ __attribute__((aligned(16))) unsigned int tmask[kTileH][kTileW / 32];
     __shared__ int lab[kTileH * kTileW];
     __shared__ unsigned int n_found, n_edge, base_found, base_edge;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -494,33 +539,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
             if (in) mask[((int64_t)r * cols + c) >> 5] = w;  // (cols % 32 == 0 and tx0 % 32 == 0: a whole word of this row)
         }
     }
-    // labels: own local index where labelled
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if ((bits >> (4 * j + k)) & 1u) {
-                const int li = (r0 + 8 * j) * kTileW + 4 * q + k;
-                lab[li] = li;
-            }
-    __syncthreads();
-    auto lbl = [&](int r, int c) -> bool { return (tmask[r][c >> 5] >> (c & 31)) & 1u; };
-    // unions inside the tile, forward half of the 8-neighbourhood: E, SW, S, SE
-    unsigned int todo = bits;
-    while (todo) {
-        const int bpos = __builtin_ctz(todo);
-        todo &= todo - 1;
-        const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
-        if (c + 1 < kTileW && lbl(r, c + 1)) lds_union(lab, li, li + 1);
-        if (r + 1 < kTileH) {
-            const int d = li + kTileW;
-            if (c > 0 && lbl(r + 1, c - 1)) lds_union(lab, li, d - 1);
-            if (lbl(r + 1, c)) lds_union(lab, li, d);
-            if (c + 1 < kTileW && lbl(r + 1, c + 1)) lds_union(lab, li, d + 1);
-        }
-    }
-    __syncthreads();
-    // flatten -> global forest; list + border list positions (one LDS atomic per thread, one global atomic per workgroup)
+    // flatten's bookkeeping can start now: list + border list positions (one LDS atomic per thread, one global atomic per workgroup)
     const int cnt = __builtin_popcount(bits);
     unsigned int edge_bits = 0;
 #pragma unroll
@@ -532,9 +551,80 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
             if (((bits >> (4 * j + k)) & 1u) && on_edge) edge_bits |= 1u << (4 * j + k);
         }
     const int ecnt = __builtin_popcount(edge_bits);
+    unsigned int starts = 0;  // RUNS: the pixels of this thread that start a run (the pixel to their left is not labelled)
+    if constexpr (RUNS) {
+        const unsigned int left = __shfl_up(bits, 1, 64);  // lane - 1 holds columns 4 q - 4 .. 4 q - 1 of the same rows when q > 0
+        const unsigned int prev = q > 0 ? ((left >> 3) & 0x1111u) : 0u;  // bit 4 j: pixel (r0 + 8 j, 4 q - 1)
+        starts = bits & ~(((bits << 1) & 0xeeeeu) | prev);
+        unsigned int todo = starts;
+        while (todo) {
+            const int bpos = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int li = (r0 + 8 * (bpos >> 2)) * kTileW + 4 * q + (bpos & 3);
+            lab[li] = li;
+        }
+    } else {
+        // labels: own local index where labelled
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((bits >> (4 * j + k)) & 1u) {
+                    const int li = (r0 + 8 * j) * kTileW + 4 * q + k;
+                    lab[li] = li;
+                }
+    }
+    __syncthreads();
     unsigned int at = 0, eat = 0;
     if (cnt) at = atomicAdd(&n_found, (unsigned int)cnt);
     if (ecnt) eat = atomicAdd(&n_edge, (unsigned int)ecnt);
+    if constexpr (RUNS) {
+        // unions: every run with the runs of the next row that touch [s - 1, e + 1]
+        unsigned int todo = starts;
+        while (todo) {
+            const int bpos = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int r = r0 + 8 * (bpos >> 2), s0 = 4 * q + (bpos & 3);
+            if (r + 1 >= kTileH) continue;
+            const RowBits m = row_bits(tmask, r), below = row_bits(tmask, r + 1);
+            const int e0 = run_end(m, s0);
+            RowBits nb = row_range(below, s0 > 0 ? s0 - 1 : 0, e0 + 1 < kTileW ? e0 + 1 : kTileW - 1);
+            while (nb.lo | nb.hi) {
+                const int p = nb.lo ? __builtin_ctzll(nb.lo) : 64 + __builtin_ctzll(nb.hi);
+                const int s1 = run_start(below, p), e1 = run_end(below, p);
+                lds_union(lab, r * kTileW + s0, (r + 1) * kTileW + s1);
+                // (that run is done: drop its columns p .. e1 from the set)
+                if (p < 64) nb.lo &= ~ones64(p, e1 < 63 ? e1 : 63);
+                if (e1 >= 64) nb.hi &= ~ones64(p > 64 ? p - 64 : 0, e1 - 64);
+            }
+        }
+        __syncthreads();
+        // every run's node -> its root, so that a pixel reads its root in one step
+        todo = starts;
+        while (todo) {
+            const int bpos = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int li = (r0 + 8 * (bpos >> 2)) * kTileW + 4 * q + (bpos & 3);
+            const int root = lds_find(lab, li);
+            if (root != li) __hip_atomic_store(&lab[li], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a node others walk through: it still points at an ancestor)
+        }
+    } else {
+        auto lbl = [&](int r, int c) -> bool { return (tmask[r][c >> 5] >> (c & 31)) & 1u; };
+        // unions inside the tile, forward half of the 8-neighbourhood: E, SW, S, SE
+        unsigned int todo = bits;
+        while (todo) {
+            const int bpos = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
+            if (c + 1 < kTileW && lbl(r, c + 1)) lds_union(lab, li, li + 1);
+            if (r + 1 < kTileH) {
+                const int d = li + kTileW;
+                if (c > 0 && lbl(r + 1, c - 1)) lds_union(lab, li, d - 1);
+                if (lbl(r + 1, c)) lds_union(lab, li, d);
+                if (c + 1 < kTileW && lbl(r + 1, c + 1)) lds_union(lab, li, d + 1);
+            }
+        }
+    }
     __syncthreads();
     if (tid == 0) {
         base_found = n_found ? atomicAdd(nlab, n_found) : 0u;
@@ -543,16 +633,39 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
     __syncthreads();
     at += base_found;
     eat += base_edge;
-    todo = bits;
-    while (todo) {
-        const int bpos = __builtin_ctz(todo);
-        todo &= todo - 1;
-        const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
-        const int root = lds_find(lab, li);
-        const int gi = (ty0 + r) * cols + tx0 + c, groot = (ty0 + (root >> 7)) * cols + tx0 + (root & (kTileW - 1));
-        parent[gi] = groot;
-        plist[at++] = gi;
-        if ((edge_bits >> bpos) & 1u) blist[eat++] = gi;
+    // flatten -> global forest
+    if constexpr (RUNS) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned int b = (bits >> (4 * j)) & 15u;
+            if (!b) continue;
+            const int r = r0 + 8 * j;
+            const RowBits m = row_bits(tmask, r);
+            int root[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) root[k] = ((b >> k) & 1u) ? lab[r * kTileW + run_start(m, 4 * q + k)] : 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((b >> k) & 1u) {
+                    const int rt = root[k];  // (every node points at its root since the barrier)
+                    const int gi = (ty0 + r) * cols + tx0 + 4 * q + k, groot = (ty0 + (rt >> 7)) * cols + tx0 + (rt & (kTileW - 1));
+                    parent[gi] = groot;
+                    plist[at++] = gi;
+                    if ((edge_bits >> (4 * j + k)) & 1u) blist[eat++] = gi;
+                }
+        }
+    } else {
+        unsigned int todo = bits;
+        while (todo) {
+            const int bpos = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int r = r0 + 8 * (bpos >> 2), c = 4 * q + (bpos & 3), li = r * kTileW + c;
+            const int root = lds_find(lab, li);
+            const int gi = (ty0 + r) * cols + tx0 + c, groot = (ty0 + (root >> 7)) * cols + tx0 + (root & (kTileW - 1));
+            parent[gi] = groot;
+            plist[at++] = gi;
+            if ((edge_bits >> bpos) & 1u) blist[eat++] = gi;
+        }
     }
 }
 
@@ -1163,9 +1276,10 @@ __global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g,
     const int f = blockIdx.y;
     label_merge_body(rows, cols, g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1);
 }
+template <bool RUNS>
 __global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    label_tile_body(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f]);
+    label_tile_body<RUNS>(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f]);
 }
 // (grids of the region walkers: a multiple of kRegions blocks; block b works on region b mod kRegions as sub-block b / kRegions)
 __global__ __launch_bounds__(256) void label_border_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
@@ -2236,7 +2350,10 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         // (one workgroup per tile.  Tried: fewer workgroups that walk several tiles with the next tile's loads in flight -- 128 / 142 us
         // per group of four 4096^2 frames with 1024 / 2048 workgroups against 101 us, profiles/r05_label_tile_variants.txt; the loop
         // alone, one trip per workgroup, cost 40 us: 36 VGPRs instead of 20 and the prefetch's predication.  The stage did not move.)
-        hipLaunchKernelGGL(label_tile_many_kernel, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
+        if (ctx->label_pixelwise)
+            hipLaunchKernelGGL(label_tile_many_kernel<false>, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
+        else
+            hipLaunchKernelGGL(label_tile_many_kernel<true>, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
         hipLaunchKernelGGL(label_border_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
     } else {
         hipLaunchKernelGGL(label_init_many_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds)), (unsigned)G), dim3(kInitBlock), 0, ctx->stream, g,

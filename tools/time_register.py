@@ -25,14 +25,19 @@ for k in range(N):
     raw.append(synth.make_frame(R, C, k, device=dev, truth=truth, border=16 if k % 10 == 9 else 0))
 warped = [torch.empty_like(raw[0]) for _ in range(1, N)]
 torch.cuda.synchronize()
+NOALIGN = os.environ.get("NOALIGN") == "1"     # estimates only (register_frames): no warps
+def call():
+    if NOALIGN:
+        return ctx.register_frames(raw[0], raw[1:], num_threads=8)
+    return ctx.align_pairs_affine(raw[0], raw[1:], warped, num_threads=8)
 for _ in range(2):
-    res = ctx.align_pairs_affine(raw[0], raw[1:], warped, num_threads=8)
+    res = call()
 torch.cuda.synchronize()
 ts = []
 for _ in range(int(os.environ.get('REPS', '8'))):
     t0 = time.perf_counter()
-    res = ctx.align_pairs_affine(raw[0], raw[1:], warped, num_threads=8)
+    res = call()
     torch.cuda.synchronize()
     ts.append((time.perf_counter() - t0) * 1e3)
 knobs = {k: v for k, v in os.environ.items() if k.startswith("AB_")}
-print(f"align_pairs_affine x63: min {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms  {knobs}  methods {sorted(set(r.method for r in res))}  all " + " ".join(f"{t:.2f}" for t in ts))
+print(f"{'register_frames' if NOALIGN else 'align_pairs_affine'} x63: min {min(ts):.2f} ms, median {sorted(ts)[len(ts) // 2]:.2f} ms  {knobs}  methods {sorted(set(r.method for r in res))}  all " + " ".join(f"{t:.2f}" for t in ts))
