@@ -135,7 +135,7 @@ struct ab_ctx {
     // detect.hip's round-4 forms, kept as cross-checks (read from AB_LABEL_LEGACY / AB_DETECT_FULL_RECORDS when the context is created,
     // inherited by its workers): two-pass labelling instead of the tile-local union-find; every component's record instead of the
     // device-side selection of the brightest
-    bool label_legacy = false, label_pixelwise = false, detect_full_records = false, detect_midjoin = false;
+    bool label_legacy = false, label_pixelwise = false, detect_no_recs = false, detect_full_records = false, detect_midjoin = false;
     uint64_t det_select_fallbacks = 0;  // detect.hip: frames whose device-side selection of the brightest components had to be redone in full
     unsigned int *tile_fail[2] = {nullptr, nullptr};
     size_t tile_fail_cap[2] = {0, 0};

@@ -125,6 +125,7 @@ int ab_ctx_create(int device_id, ab_ctx **out) try {
     ctx->stack_exact = ex && ex[0] == '1';
     ctx->label_legacy = getenv("AB_LABEL_LEGACY") != nullptr;
     ctx->label_pixelwise = getenv("AB_LABEL_PIXELWISE") != nullptr;
+    ctx->detect_no_recs = getenv("AB_DETECT_NO_RECS") != nullptr;
     ctx->detect_full_records = getenv("AB_DETECT_FULL_RECORDS") != nullptr;
     ctx->detect_midjoin = getenv("AB_DETECT_MIDJOIN") != nullptr;
     if (const char *e = getenv("AB_STACK_DEEP_FROM")) ctx->stack_deep_from = std::min(4096, std::max(64, atoi(e)));
@@ -469,7 +470,8 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
         wc->register_workers = 1;
         wc->parent = ctx;
         wc->label_legacy = ctx->label_legacy;
-        wc->label_pixelwise = ctx->label_pixelwise;  // (the parent's choices, not the environment's at the time the pool grows)
+        wc->label_pixelwise = ctx->label_pixelwise;
+        wc->detect_no_recs = ctx->detect_no_recs;  // (the parent's choices, not the environment's at the time the pool grows)
         wc->detect_full_records = ctx->detect_full_records;
         wc->detect_midjoin = ctx->detect_midjoin;
         ctx->workers.push_back(wc);

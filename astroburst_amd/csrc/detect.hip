@@ -416,6 +416,20 @@ __device__ __forceinline__ void label_merge_body(int rows, int cols, int *parent
     }
 }
 
+struct CompStat {  // filled by atomics (order-independent integers)
+    int npix, x0, x1, y0, y1, first_interior;
+    // group path only (comp_stats_body<true>): sum of max(v - background, 0) over the member pixels, added by f64 atomics in whatever
+    // order the waves arrive.  It only RANKS components (comp_select_kernel); every number a star is made of is recomputed by
+    // comp_moments' fixed butterfly.  (For normalised pixels the sum is exact in f64, hence the same in any order: DESIGN 4.3.)
+    double flux;
+};
+static_assert(sizeof(CompStat) == 32, "CompStat layout");
+
+struct CompRec {  // what the host needs to finish one star (star_detection.rs:147-213)
+    int first_interior, npix;
+    double sum_flux, sum_x, sum_y, peak, sum_r2, sum_xx, sum_yy, sum_xy;
+};
+
 // ---- threshold + TILE-LOCAL union-find in LDS (round 5) ----------------------------------------------------------
 // label_init + label_merge as above are two passes over global memory: the threshold pass writes parent = self, the merge pass then
 // walks the list and hooks roots with global atomics -- 170 000 labelled pixels of a 4096^2 frame, every union a chain of dependent
@@ -500,21 +514,41 @@ __device__ __forceinline__ int run_end(const RowBits &m, int c) {  // last colum
     return z ? c + __builtin_ctzll(z) - 1 : 127;
 }
 
-template <bool RUNS>
+// RECS (with RUNS; the registration batch's chained form): the tile also gathers what comp_stats would -- size, bounding box, first
+// interior pixel and approximate flux of every tile-local component, accumulated in LDS from one contribution per run piece -- and
+// emits ONE RECORD per tile-local component: st[pos] (CompStat), roots[pos] = its root pixel, cid[root] = pos, pos taken from the
+// record segment of the tile's record region.  No pixel list is written: roots_many / comp_stats_many (two walks over the frame's
+// ~170 000 labelled pixels, 7 global atomics per run of equal roots) are replaced by comp_merge_many over the ~10 000 records, of
+// which only those whose tile root was hooked under another tile's (a star on a tile border) have anything to do.  A tile with more
+// than kTileSlots components raises the frame's overflow flag: the host redoes that frame through the full path.
+constexpr int kTileSlots = 64;
+constexpr int kRecRegions = 16;  // record regions (tile t -> region t mod kRecRegions), counters at lcnt[(2 kRegions + r) * kRegionPitch]
+struct TileRecOut {
+    CompStat *st;
+    int *roots, *cid;
+    size_t stride;        // records per region segment (= tiles of a region x kTileSlots: a segment cannot overflow)
+    unsigned int *flags;  // [0] |= 1: some tile had more than kTileSlots components
+    double bg_median;
+};
+template <bool RUNS, bool RECS = false>
 __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
                                                 int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist_all, size_t plist_stride,
-                                                int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt) {
+                                                int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt, const TileRecOut ro = TileRecOut()) {
+    static_assert(RUNS || !RECS, "records need the run form");
     const int region = (int)(blockIdx.x % kRegions);
     int *__restrict__ plist = plist_all + (size_t)region * plist_stride, *__restrict__ blist = blist_all + (size_t)region * blist_stride;
     unsigned int *nlab = lcnt + region * kRegionPitch, *nborder = lcnt + (kRegions + region) * kRegionPitch;
     __shared__ __attribute__((aligned(16))) unsigned int tmask[kTileH][kTileW / 32];
     __shared__ int lab[kTileH * kTileW];
     __shared__ unsigned int n_found, n_edge, base_found, base_edge;
+    __shared__ int acc_i[RECS ? 7 : 1][RECS ? kTileSlots : 1];  // npix, x0, x1, y0, y1, first_interior, root (tile index)
+    __shared__ double acc_flux[RECS ? kTileSlots : 1];
+    __shared__ unsigned int n_slots, base_rec;
     const int tid = threadIdx.x, lane = tid & 63;
     const int tiles_x = (cols + kTileW - 1) / kTileW;
     const int ty0 = (int)(blockIdx.x / tiles_x) * kTileH, tx0 = (int)(blockIdx.x % tiles_x) * kTileW;
     const int q = tid & 31, r0 = tid >> 5;  // this thread: columns 4 q .. 4 q + 3 of rows r0, r0 + 8, r0 + 16, r0 + 24
-    if (tid == 0) n_found = n_edge = 0;
+    if (tid == 0) n_found = n_edge = n_slots = 0;
     unsigned int bits = 0;  // bit 4 j + k: pixel (r0 + 8 j, 4 q + k)
     float4 v[4];
 #pragma unroll
@@ -527,8 +561,9 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
     for (int j = 0; j < 4; ++j) {
         const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
         const bool in = r < rows && c < cols;
-        const unsigned int b = (unsigned int)(in && above(ab_px(xf, v[j].x), threshold)) | ((unsigned int)(in && above(ab_px(xf, v[j].y), threshold)) << 1) |
-                               ((unsigned int)(in && above(ab_px(xf, v[j].z), threshold)) << 2) | ((unsigned int)(in && above(ab_px(xf, v[j].w), threshold)) << 3);
+        v[j] = make_float4(ab_px(xf, v[j].x), ab_px(xf, v[j].y), ab_px(xf, v[j].z), ab_px(xf, v[j].w));  // (RECS adds these up further down)
+        const unsigned int b = (unsigned int)(in && above(v[j].x, threshold)) | ((unsigned int)(in && above(v[j].y, threshold)) << 1) |
+                               ((unsigned int)(in && above(v[j].z, threshold)) << 2) | ((unsigned int)(in && above(v[j].w, threshold)) << 3);
         bits |= b << (4 * j);
         unsigned int w = b << (4 * (lane & 7));  // eight lanes make one mask word
         w |= __shfl_xor(w, 1, 64);
@@ -576,7 +611,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
     }
     __syncthreads();
     unsigned int at = 0, eat = 0;
-    if (cnt) at = atomicAdd(&n_found, (unsigned int)cnt);
+    if (cnt && !RECS) at = atomicAdd(&n_found, (unsigned int)cnt);
     if (ecnt) eat = atomicAdd(&n_edge, (unsigned int)ecnt);
     if constexpr (RUNS) {
         // unions: every run with the runs of the next row that touch [s - 1, e + 1]
@@ -605,8 +640,34 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
             const int bpos = __builtin_ctz(todo);
             todo &= todo - 1;
             const int li = (r0 + 8 * (bpos >> 2)) * kTileW + 4 * q + (bpos & 3);
-            const int root = lds_find(lab, li);
-            if (root != li) __hip_atomic_store(&lab[li], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a node others walk through: it still points at an ancestor)
+            if constexpr (RECS) {
+                // ... and a root takes a slot of the tile's record table and marks itself with -1 - slot (walkers stop at a mark)
+                int x = li;
+                while (true) {
+                    const int pnt = __hip_atomic_load(&lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (pnt < 0 || pnt == x) break;
+                    x = pnt;
+                }
+                if (x == li) {  // (only a node's owner marks it, and this loop visits every run once)
+                    const unsigned int slot = atomicAdd(&n_slots, 1u);
+                    if (slot < (unsigned int)kTileSlots) {
+                        acc_i[0][slot] = 0;
+                        acc_i[1][slot] = 0x7fffffff;
+                        acc_i[2][slot] = -1;
+                        acc_i[3][slot] = 0x7fffffff;
+                        acc_i[4][slot] = -1;
+                        acc_i[5][slot] = 0x7fffffff;
+                        acc_i[6][slot] = li;
+                        acc_flux[slot] = 0.0;
+                    }
+                    __hip_atomic_store(&lab[li], -1 - (int)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    __hip_atomic_store(&lab[li], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
+                const int root = lds_find(lab, li);
+                if (root != li) __hip_atomic_store(&lab[li], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a node others walk through: it still points at an ancestor)
+            }
         }
     } else {
         auto lbl = [&](int r, int c) -> bool { return (tmask[r][c >> 5] >> (c & 31)) & 1u; };
@@ -626,6 +687,69 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
         }
     }
     __syncthreads();
+    if constexpr (RECS) {
+        const unsigned int rec_region = blockIdx.x % kRecRegions;
+        if (tid == 0) {
+            base_edge = n_edge ? atomicAdd(nborder, n_edge) : 0u;
+            const unsigned int ns = n_slots;
+            base_rec = ns ? atomicAdd(lcnt + (2 * kRegions + rec_region) * kRegionPitch, ns < (unsigned int)kTileSlots ? ns : (unsigned int)kTileSlots) : 0u;
+            if (ns > (unsigned int)kTileSlots) atomicOr(ro.flags, 1u);
+        }
+        // every run piece of this thread: its pixels' parents, and one contribution to its component's slot
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned int bb = (bits >> (4 * j)) & 15u;
+            if (!bb) continue;
+            const int r = r0 + 8 * j, gy = ty0 + r;
+            const RowBits m = row_bits(tmask, r);
+            const float f4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+            while (bb) {  // (at most two pieces in four pixels)
+                const int k0 = __builtin_ctz(bb), len = __builtin_ctz(~(bb >> k0));
+                const int c0 = 4 * q + k0, s0 = k0 ? c0 : run_start(m, c0);
+                const int node = r * kTileW + s0, pnt = lab[node];
+                const int rt = pnt >= 0 ? pnt : node;
+                const int slot = -1 - (pnt >= 0 ? lab[pnt] : pnt);  // (every root is marked since the barrier)
+                const int groot = (ty0 + (rt >> 7)) * cols + tx0 + (rt & (kTileW - 1));
+                double fl = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k >= k0 && k < k0 + len) {
+                        fl += fmax((double)f4[k] - ro.bg_median, 0.0);
+                        parent[gy * cols + tx0 + 4 * q + k] = groot;
+                    }
+                if (slot < kTileSlots) {
+                    const int x0 = tx0 + c0, x1 = x0 + len - 1;
+                    atomicAdd(&acc_i[0][slot], len);
+                    atomicMin(&acc_i[1][slot], x0);
+                    atomicMax(&acc_i[2][slot], x1);
+                    atomicMin(&acc_i[3][slot], gy);
+                    atomicMax(&acc_i[4][slot], gy);
+                    // BFS seeds are interior (star_detection.rs:107-110): the piece's first pixel off the frame's border columns, on an interior row
+                    const int cf = x0 > 1 ? x0 : 1, cl = x1 < cols - 2 ? x1 : cols - 2;
+                    if (gy >= 1 && gy < rows - 1 && cf <= cl) atomicMin(&acc_i[5][slot], gy * cols + cf);
+                    if (fl > 0.0) unsafeAtomicAdd(&acc_flux[slot], fl);
+                }
+                bb &= ~(((1u << len) - 1u) << k0);
+            }
+        }
+        __syncthreads();
+        eat += base_edge;
+        unsigned int todo = edge_bits;
+        while (todo) {
+            const int bpos = __builtin_ctz(todo);
+            todo &= todo - 1;
+            blist[eat++] = (ty0 + r0 + 8 * (bpos >> 2)) * cols + tx0 + 4 * q + (bpos & 3);
+        }
+        const unsigned int ns = n_slots < (unsigned int)kTileSlots ? n_slots : (unsigned int)kTileSlots;
+        if ((unsigned int)tid < ns) {
+            const size_t pos = (size_t)rec_region * ro.stride + base_rec + (unsigned int)tid;
+            const int rt = acc_i[6][tid], groot = (ty0 + (rt >> 7)) * cols + tx0 + (rt & (kTileW - 1));
+            ro.st[pos] = CompStat{acc_i[0][tid], acc_i[1][tid], acc_i[2][tid], acc_i[3][tid], acc_i[4][tid], acc_i[5][tid], acc_flux[tid]};
+            ro.roots[pos] = groot;
+            ro.cid[groot] = (int)pos;
+        }
+        return;
+    }
     if (tid == 0) {
         base_found = n_found ? atomicAdd(nlab, n_found) : 0u;
         base_edge = n_edge ? atomicAdd(nborder, n_edge) : 0u;
@@ -689,20 +813,6 @@ __device__ __forceinline__ void label_border_body(int rows, int cols, int *paren
 }
 
 // ---- per-component statistics and moments -------------------------------------------------------------
-struct CompStat {  // filled by atomics (order-independent integers)
-    int npix, x0, x1, y0, y1, first_interior;
-    // group path only (comp_stats_body<true>): sum of max(v - background, 0) over the member pixels, added by f64 atomics in whatever
-    // order the waves arrive.  It only RANKS components (comp_select_kernel); every number a star is made of is recomputed by
-    // comp_moments' fixed butterfly.  (For normalised pixels the sum is exact in f64, hence the same in any order: DESIGN 4.3.)
-    double flux;
-};
-static_assert(sizeof(CompStat) == 32, "CompStat layout");
-
-struct CompRec {  // what the host needs to finish one star (star_detection.rs:147-213)
-    int first_interior, npix;
-    double sum_flux, sum_x, sum_y, peak, sum_r2, sum_xx, sum_yy, sum_xy;
-};
-
 // number the component roots (parent[i] == i) among the labelled pixels; one atomic per 1024-thread block and round on the
 // tail (one per WAVE serialised on that single counter: ~2500 x 12 ns per frame)
 constexpr int kRootsBlock = 256;
@@ -747,6 +857,30 @@ __device__ __forceinline__ void roots_body(const int *__restrict__ parent, const
 __device__ __forceinline__ void comp_init_body(CompStat *st, unsigned int n) {
     const unsigned int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) st[i] = CompStat{0, 0x7fffffff, -1, 0x7fffffff, -1, 0x7fffffff, 0.0};
+}
+
+// RECS: fold the records of tile-local components whose root was hooked under another tile's (label_border) into their component's
+// record, and point their root pixel straight at the component's root -- a member pixel is then at most two steps from it
+// (pixel -> tile root -> root; comp_moments looks twice).  The folded record is left with npix = 0: not a component any more.
+__device__ __forceinline__ void comp_merge_body(int *parent, const int *__restrict__ roots, const int *__restrict__ cid, CompStat *st, unsigned int n, size_t seg_base,
+                                                unsigned int bid, unsigned int nblk) {
+    for (unsigned int j = bid * 256 + threadIdx.x; j < n; j += nblk * 256) {
+        const size_t pos = seg_base + j;
+        const int groot = roots[pos];
+        if (__hip_atomic_load(&parent[groot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groot) continue;
+        const int root = uf_find(parent, groot);
+        __hip_atomic_store(&parent[groot], root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const CompStat me = st[pos];
+        CompStat *t = &st[cid[root]];
+        atomicAdd(&t->npix, me.npix);
+        atomicMin(&t->x0, me.x0);
+        atomicMax(&t->x1, me.x1);
+        atomicMin(&t->y0, me.y0);
+        atomicMax(&t->y1, me.y1);
+        if (me.first_interior != 0x7fffffff) atomicMin(&t->first_interior, me.first_interior);
+        if (me.flux > 0.0) unsafeAtomicAdd(&t->flux, me.flux);
+        st[pos].npix = 0;
+    }
 }
 
 // flatten the forest and gather size / bounding box / first interior pixel of every component
@@ -861,7 +995,7 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
                                                            double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
                                                            const FrameDev *__restrict__ fd, const unsigned int *__restrict__ sel = nullptr,
-                                                           const unsigned int *__restrict__ nsel = nullptr) {
+                                                           const unsigned int *__restrict__ nsel = nullptr, bool two_hop = false) {
     const double bg_median = fd ? fd->bg_median : bg_median_arg;
     const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
     const unsigned int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kMomPerWave;
@@ -882,7 +1016,10 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
         const unsigned int m = mask[idx >> 5];
         const int p = parent[idx];  // (defined at labelled pixels only: the bit decides)
         const float px = img[rr * ld + cc];
-        const bool member = valid && ((m >> (idx & 31)) & 1u) && p == root;
+        const bool bit = (m >> (idx & 31)) & 1u;
+        // (records form: a pixel points at its TILE's root, which points at the component's root when that lies in another tile)
+        const int p2 = (two_hop && valid && bit && p != root) ? parent[p] : p;
+        const bool member = valid && bit && p2 == root;
         return member ? fmax((double)ab_px(xf, px) - bg_median, 0.0) : 0.0;
     };
     CompStat S[kMomPerWave];
@@ -1072,6 +1209,8 @@ struct DetGroup {
     unsigned int *lcnt[kGroupMax];    // its 2 x kRegions list counters, kRegionPitch words apart
     size_t plist_stride, blist_stride;  // ints per region segment
     int tiled;
+    int recs;                         // label_tile_body<true, true>: st / roots hold one record per TILE-LOCAL component, in kRecRegions segments of rec_stride
+    size_t rec_stride;
     unsigned int *sel[kGroupMax];     // indices of the selected components (comp_select_many_kernel), kSelCap each
     unsigned int *selout[kGroupMax];  // PINNED HOST: {selected, candidates} of the frame
 };
@@ -1131,7 +1270,7 @@ __device__ __forceinline__ void sel_find_digit(const unsigned int *hist, int nb,
 __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.x, tid = threadIdx.x;
     unsigned int n = g.ncomp[f];
-    if (g.chained) {
+    if (g.chained && !g.recs) {
         n = g.counters[f][0];
         if (tid == 0) g.selout[f][2] = n;     // the host's only look at the component count
         if (n > g.comp_cap) n = 0;            // table overflow: nothing is selected, the host redoes the frame in full
@@ -1141,10 +1280,43 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
     __shared__ unsigned int hist[2048];
     __shared__ unsigned int sub_key[kSelSub], sub_idx[kSelSub];
     __shared__ unsigned int s_ncand, s_d0, s_above, s_count, s_nsub, s_prefix, s_want, s_ge;
+    // the table as segments: one of n entries, or (records form) kRecRegions segments rec_stride apart, each filled to its own count
+    __shared__ unsigned int seg_n[kRecRegions], seg_t0[kRecRegions + 1];
+    const int nseg = g.recs ? kRecRegions : 1;
+    const unsigned int seg_stride = g.recs ? (unsigned int)g.rec_stride : 0u;
     for (unsigned int b = tid; b < 2048; b += kSelThreads) hist[b] = 0;
     if (tid == 0) s_ncand = s_d0 = s_above = s_count = s_nsub = s_prefix = s_want = s_ge = 0;
+    if (g.recs) {
+        const bool overflow = g.counters[f][3] != 0;  // a tile with more components than slots: nothing is selected, the host redoes the frame in full
+        if (tid < kRecRegions) {
+            const unsigned int cnt = g.lcnt[f][(2 * kRegions + tid) * kRegionPitch];
+            seg_n[tid] = overflow ? 0u : (cnt < seg_stride ? cnt : seg_stride);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned int t = 0, total = 0;
+            for (int sg = 0; sg < kRecRegions; ++sg) {
+                seg_t0[sg] = t;
+                t += (seg_n[sg] + kSelThreads - 1) / kSelThreads;
+                total += seg_n[sg];
+            }
+            seg_t0[kRecRegions] = t;
+            g.selout[f][2] = overflow ? g.comp_cap + 1u : total;  // (records, folded ones included: the host only compares it with the capacity)
+        }
+    } else if (tid == 0) {
+        seg_n[0] = n;
+        seg_t0[0] = 0;
+        seg_t0[1] = (n + kSelThreads - 1) / kSelThreads;
+    }
     __syncthreads();
-    const unsigned int trips = (n + kSelThreads - 1) / kSelThreads;  // block-uniform (the ballots below need whole waves)
+    const unsigned int trips = seg_t0[nseg];  // block-uniform (the ballots below need whole waves)
+    auto index_of = [&](unsigned int T, unsigned int &i) -> bool {  // entry `tid` of trip T
+        int sg = 0;
+        while (sg + 1 < nseg && T >= seg_t0[sg + 1]) ++sg;
+        const unsigned int j = (T - seg_t0[sg]) * kSelThreads + tid;
+        i = (unsigned int)sg * seg_stride + j;
+        return T < trips && j < seg_n[sg];
+    };
     // ---- pass A: level-0 histogram of the candidates ----
     // (kSelIlp records in flight per thread: one thread's 40 dependent round trips to L2 were the kernel -- 150 us inside a batch)
     constexpr unsigned int kSelIlp = 8;
@@ -1153,8 +1325,8 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
         unsigned int k[kSelIlp];
 #pragma unroll
         for (unsigned int u = 0; u < kSelIlp; ++u) {
-            const unsigned int i = (t0 + u) * kSelThreads + tid;
-            k[u] = i < n ? sel_key(st[i]) : 0u;
+            unsigned int i;
+            k[u] = index_of(t0 + u, i) ? sel_key(st[i]) : 0u;
         }
 #pragma unroll
         for (unsigned int u = 0; u < kSelIlp; ++u) {
@@ -1182,15 +1354,12 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
     const unsigned int d0 = s_d0, above = s_above;
     // ---- pass B: emit what is brighter than bin d0, collect bin d0 ----
     for (unsigned int t0 = 0; t0 < trips; t0 += kSelIlp) {
-        unsigned int k[kSelIlp];
+        unsigned int k[kSelIlp], idx[kSelIlp];
+#pragma unroll
+        for (unsigned int u = 0; u < kSelIlp; ++u) k[u] = index_of(t0 + u, idx[u]) ? sel_key(st[idx[u]]) : 0u;
 #pragma unroll
         for (unsigned int u = 0; u < kSelIlp; ++u) {
-            const unsigned int i = (t0 + u) * kSelThreads + tid;
-            k[u] = i < n ? sel_key(st[i]) : 0u;
-        }
-#pragma unroll
-        for (unsigned int u = 0; u < kSelIlp; ++u) {
-            const unsigned int i = (t0 + u) * kSelThreads + tid;
+            const unsigned int i = idx[u];
             if (!k[u]) continue;
             const unsigned int dg = sel_digit(k[u]);
             if (all || dg > d0) {
@@ -1276,10 +1445,20 @@ __global__ __launch_bounds__(256) void label_merge_many_kernel(const DetGroup g,
     const int f = blockIdx.y;
     label_merge_body(rows, cols, g.parent[f], g.mask[f], g.plist[f], g.counters[f] + 1);
 }
-template <bool RUNS>
+template <bool RUNS, bool RECS>
 __global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    label_tile_body<RUNS>(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f]);
+    TileRecOut ro;
+    if constexpr (RECS) ro = TileRecOut{g.st[f], g.roots[f], g.cid[f], g.rec_stride, g.counters[f] + 3, g.bg_median[f]};
+    label_tile_body<RUNS, RECS>(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f], ro);
+}
+// (grid: a multiple of kRecRegions blocks; block b works on record region b mod kRecRegions as sub-block b / kRecRegions)
+__global__ __launch_bounds__(256) void comp_merge_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
+    const int f = blockIdx.y, r = blockIdx.x % kRecRegions;
+    if (g.counters[f][3]) return;  // (a tile overflowed its slots: the host redoes the frame in full)
+    const unsigned int cnt = g.lcnt[f][(2 * kRegions + r) * kRegionPitch];
+    comp_merge_body(g.parent[f], g.roots[f], g.cid[f], g.st[f], cnt < g.rec_stride ? cnt : (unsigned int)g.rec_stride, (size_t)r * g.rec_stride, blockIdx.x / kRecRegions,
+                    gridDim.x / kRecRegions);
 }
 // (grids of the region walkers: a multiple of kRegions blocks; block b works on region b mod kRegions as sub-block b / kRegions)
 __global__ __launch_bounds__(256) void label_border_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
@@ -1335,7 +1514,7 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
 __global__ __launch_bounds__(256) void comp_moments_many_kernel(const DetGroup g, int cols, int64_t ld) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     comp_moments_body(g.img[f], cols, ld, g.parent[f], g.mask[f], g.roots[f], g.st[f], g.ncomp[f], g.bg_median[f], g.xf[f], g.rec[f], nullptr,
-                      g.sel[f], g.sel[f] ? g.counters[f] + 2 : nullptr);
+                      g.sel[f], g.sel[f] ? g.counters[f] + 2 : nullptr, g.recs != 0);
 }
 
 // ---- normalize_for_detection (affine.rs:24-53) ------------------------------------------------------
@@ -2287,7 +2466,7 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     const size_t tiles_per_region = ((size_t)ntile + kRegions - 1) / kRegions;
     const size_t plist_stride = tiles_per_region * (size_t)(kTileH * kTileW), blist_stride = tiles_per_region * (size_t)(kTileW + 2 * kTileH);
     const size_t plist_ints = tiled ? (size_t)kRegions * plist_stride : (size_t)P, blist_ints = tiled ? (size_t)kRegions * blist_stride : 0;
-    const size_t lcnt_words = tiled ? (size_t)2 * kRegions * kRegionPitch : 0;
+    const size_t lcnt_words = tiled ? (size_t)(2 * kRegions + kRecRegions) * kRegionPitch : 0;
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)G * (plist_ints + blist_ints + lcnt_words) * sizeof(int), (void **)&plist));
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_MASK, (size_t)G * mask_words * sizeof(unsigned int), (void **)&mask));
     DetGroup g;
@@ -2321,7 +2500,11 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     // moments); the table holds comp_cap components per frame, a frame with more is redone in full.  AB_DETECT_MIDJOIN=1 keeps the
     // join after the root numbering (round 4's shape: the host sizes the table and the grids).
     const bool chained = select && !ctx->detect_midjoin;
-    const unsigned int comp_cap = (unsigned int)std::min<int64_t>(root_cap, (int64_t)1 << 18);
+    // records form (label_tile_body<true, true>): the tiles gather their components' statistics themselves; roots_many and
+    // comp_stats_many give way to comp_merge_many.  AB_DETECT_NO_RECS=1 keeps the pixel-list chain (the GPU tests run both).
+    const size_t rec_stride = (((size_t)ntile + kRecRegions - 1) / kRecRegions) * (size_t)kTileSlots, rec_cap = (size_t)kRecRegions * rec_stride;
+    const bool recs = chained && tiled && !ctx->label_pixelwise && !ctx->detect_no_recs && rec_cap <= (size_t)root_cap;
+    const unsigned int comp_cap = recs ? (unsigned int)rec_cap : (unsigned int)std::min<int64_t>(root_cap, (int64_t)1 << 18);
     void *pin = nullptr;
     unsigned int *selout = nullptr;
     if (chained) {
@@ -2343,6 +2526,8 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     }
     AB_HIP(ctx, hipMemsetAsync(counters, 0, (size_t)G * 4 * sizeof(unsigned int), ctx->stream));
     g.tiled = tiled ? 1 : 0;
+    g.recs = recs ? 1 : 0;
+    g.rec_stride = rec_stride;
     g.plist_stride = plist_stride;
     g.blist_stride = blist_stride;
     if (tiled) AB_HIP(ctx, hipMemsetAsync(g.lcnt[0], 0, (size_t)G * lcnt_words * sizeof(unsigned int), ctx->stream));
@@ -2350,20 +2535,26 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         // (one workgroup per tile.  Tried: fewer workgroups that walk several tiles with the next tile's loads in flight -- 128 / 142 us
         // per group of four 4096^2 frames with 1024 / 2048 workgroups against 101 us, profiles/r05_label_tile_variants.txt; the loop
         // alone, one trip per workgroup, cost 40 us: 36 VGPRs instead of 20 and the prefetch's predication.  The stage did not move.)
-        if (ctx->label_pixelwise)
-            hipLaunchKernelGGL(label_tile_many_kernel<false>, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
+        if (recs)
+            hipLaunchKernelGGL((label_tile_many_kernel<true, true>), dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
+        else if (ctx->label_pixelwise)
+            hipLaunchKernelGGL((label_tile_many_kernel<false, false>), dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
         else
-            hipLaunchKernelGGL(label_tile_many_kernel<true>, dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
+            hipLaunchKernelGGL((label_tile_many_kernel<true, false>), dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
         hipLaunchKernelGGL(label_border_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
     } else {
         hipLaunchKernelGGL(label_init_many_kernel, dim3((unsigned)((P + kInitSub * kInitRounds - 1) / (kInitSub * kInitRounds)), (unsigned)G), dim3(kInitBlock), 0, ctx->stream, g,
                            (int)rows, (int)cols, cols, (int)vec_ok);
         hipLaunchKernelGGL(label_merge_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols);
     }
-    hipLaunchKernelGGL(roots_many_kernel, dim3(gl, G), dim3(kRootsBlock), 0, ctx->stream, g, chained ? comp_cap : root_cap);
+    if (recs) {
+        hipLaunchKernelGGL(comp_merge_many_kernel, dim3(4 * kRecRegions, G), dim3(256), 0, ctx->stream, g);
+    } else {
+        hipLaunchKernelGGL(roots_many_kernel, dim3(gl, G), dim3(kRootsBlock), 0, ctx->stream, g, chained ? comp_cap : root_cap);
+    }
     AB_HIP(ctx, hipGetLastError());
     if (chained) {
-        hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols, cols);
+        if (!recs) hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols, cols);
         hipLaunchKernelGGL(comp_select_many_kernel, dim3(G), dim3(kSelThreads), 0, ctx->stream, g);
         hipLaunchKernelGGL(comp_moments_many_kernel, dim3((kSelCap + 4 * kMomPerWave - 1) / (4 * kMomPerWave), G), dim3(256), 0, ctx->stream, g, (int)cols, cols);
         AB_HIP(ctx, hipGetLastError());

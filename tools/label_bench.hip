@@ -1,6 +1,6 @@
 // Developer tool: where label_tile_many_kernel's time goes (round 5).  Built against the library's own source:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iastroburst_amd/csrc -Iinclude tools/label_bench.hip -Lastroburst_amd -lastroburst_hip -o build/label_bench
-// Variants: 0 the real body (runs) | 7 the pixel-by-pixel unions | 1 loads only, 32 x 128 tile pattern | 2 loads only, 16 KB contiguous per workgroup | 3 loads + threshold +
+// Variants: 8 runs + component records | 0 runs, pixel list | 7 the pixel-by-pixel unions | 1 loads only, 32 x 128 tile pattern | 2 loads only, 16 KB contiguous per workgroup | 3 loads + threshold +
 // mask words, no labels | 4 loads only, 8 x 512 pattern | 5 loads only, 16 x 256 pattern | 6 as 3 with the labels' LDS allocated (occupancy)
 #include "../astroburst_amd/csrc/detect.hip"
 
@@ -10,10 +10,14 @@
 namespace {
 template <int V>
 __global__ __launch_bounds__(256) void bench_kernel(const float *const *imgs, int rows, int cols, double threshold, ab_pixel_xf xf, int **parent, unsigned int **mask,
-                                                    int **plist, size_t plist_stride, int **blist, size_t blist_stride, unsigned int **lcnt, float *sink) {
+                                                    int **plist, size_t plist_stride, int **blist, size_t blist_stride, unsigned int **lcnt, float *sink,
+                                                    CompStat **st = nullptr, int **roots = nullptr, int **cid = nullptr, size_t rec_stride = 0, unsigned int *flags = nullptr) {
     const int f = blockIdx.y;
     const float *img = imgs[f];
-    if constexpr (V == 0 || V == 7) {
+    if constexpr (V == 8) {
+        label_tile_body<true, true>(img, rows, cols, threshold, xf, parent[f], mask[f], plist[f], plist_stride, blist[f], blist_stride, lcnt[f],
+                                    TileRecOut{st[f], roots[f], cid[f], rec_stride, flags + 4 * f, 0.0125});
+    } else if constexpr (V == 0 || V == 7) {
         label_tile_body<V == 0>(img, rows, cols, threshold, xf, parent[f], mask[f], plist[f], plist_stride, blist[f], blist_stride, lcnt[f]);
     } else {
         const int tid = threadIdx.x, lane = tid & 63;
@@ -67,6 +71,10 @@ __global__ __launch_bounds__(256) void bench_kernel(const float *const *imgs, in
     }
 }
 
+CompStat **g_st;
+int **g_roots, **g_cid;
+size_t g_rec_stride;
+unsigned int *g_flags;
 template <int V>
 float run(const float *const *d_imgs, int G, int rows, int cols, double thr, ab_pixel_xf xf, int **parent, unsigned int **mask, int **plist, size_t ps, int **blist, size_t bs,
           unsigned int **lcnt, unsigned int *lcnt_flat, size_t lcnt_words, float *sink, int reps) {
@@ -77,7 +85,8 @@ float run(const float *const *d_imgs, int G, int rows, int cols, double thr, ab_
     for (int r = 0; r < reps + 2; ++r) {
         hipMemsetAsync(lcnt_flat, 0, lcnt_words * 4, 0);
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL(bench_kernel<V>, dim3(4096, G), dim3(256), 0, 0, d_imgs, rows, cols, thr, xf, parent, mask, plist, ps, blist, bs, lcnt, sink);
+        hipLaunchKernelGGL(bench_kernel<V>, dim3(4096, G), dim3(256), 0, 0, d_imgs, rows, cols, thr, xf, parent, mask, plist, ps, blist, bs, lcnt, sink, g_st, g_roots, g_cid,
+                           g_rec_stride, g_flags);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
@@ -113,7 +122,7 @@ int main(int argc, char **argv) {
     std::vector<const float *> imgs(G);
     std::vector<int *> parent(G), plist(G), blist(G);
     std::vector<unsigned int *> mask(G), lcnt(G);
-    const size_t ps = P / 16 / kRegions, bs = P / 64 / kRegions, lw = (size_t)2 * kRegions * kRegionPitch;
+    const size_t ps = P / 16 / kRegions, bs = P / 64 / kRegions, lw = (size_t)(2 * kRegions + kRecRegions) * kRegionPitch;
     unsigned int *lcnt_flat;
     hipMalloc(&lcnt_flat, G * lw * 4);
     for (int f = 0; f < G; ++f) {
@@ -144,6 +153,24 @@ int main(int argc, char **argv) {
     hipMemcpy(d_blist, blist.data(), G * 8, hipMemcpyHostToDevice);
     hipMemcpy(d_mask, mask.data(), G * 8, hipMemcpyHostToDevice);
     hipMemcpy(d_lcnt, lcnt.data(), G * 8, hipMemcpyHostToDevice);
+    {
+        g_rec_stride = (4096 / kRecRegions) * (size_t)kTileSlots;
+        std::vector<CompStat *> st(G);
+        std::vector<int *> ro(G), ci(G);
+        for (int f = 0; f < G; ++f) {
+            hipMalloc(&st[f], kRecRegions * g_rec_stride * sizeof(CompStat));
+            hipMalloc(&ro[f], kRecRegions * g_rec_stride * 4);
+            hipMalloc(&ci[f], P * 4);
+        }
+        hipMalloc(&g_st, G * 8);
+        hipMalloc(&g_roots, G * 8);
+        hipMalloc(&g_cid, G * 8);
+        hipMalloc(&g_flags, G * 16);
+        hipMemset(g_flags, 0, G * 16);
+        hipMemcpy(g_st, st.data(), G * 8, hipMemcpyHostToDevice);
+        hipMemcpy(g_roots, ro.data(), G * 8, hipMemcpyHostToDevice);
+        hipMemcpy(g_cid, ci.data(), G * 8, hipMemcpyHostToDevice);
+    }
     ab_pixel_xf xf;
     xf.on = 1;
     xf.lo = 150.0;
@@ -151,6 +178,7 @@ int main(int argc, char **argv) {
     const double thr = (200.0 + 5.0 * 6.0 - 150.0) / 4000.0;
 #define RUN(V) run<V>(d_imgs, G, rows, cols, thr, xf, d_parent, d_mask, d_plist, ps, d_blist, bs, d_lcnt, lcnt_flat, G * lw, sink, reps)
     for (int round = 0; round < 2; ++round) {
+        RUN(8);
         RUN(0);
         RUN(7);
         RUN(1);
@@ -181,6 +209,11 @@ int main(int argc, char **argv) {
             lab_px += pa[i] >= 0;
         }
         printf("pixelwise vs runs: %zu labelled pixels, %zu parents differ, masks %s, counters %s\n", lab_px, diff, ma == mb ? "equal" : "DIFFER", ca == cb ? "equal" : "DIFFER");
+    }
+    {
+        unsigned int fl[4];
+        hipMemcpy(fl, g_flags, 16, hipMemcpyDeviceToHost);
+        printf("records form: overflow flag of frame 0 = %u\n", fl[0]);
     }
     std::vector<unsigned int> c(G * lw);
     hipMemcpy(c.data(), lcnt_flat, G * lw * 4, hipMemcpyDeviceToHost);
