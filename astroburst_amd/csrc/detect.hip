@@ -530,6 +530,18 @@ struct TileRecOut {
     unsigned int *flags;  // [0] |= 1: some tile had more than kTileSlots components
     double bg_median;
 };
+#ifdef AB_LABEL_TIMING  // (tools/label_bench.hip: s_memtime of every wave at each phase boundary)
+__device__ long long *g_label_marks = nullptr;  // [tile][wave][8]
+#define LT_MARK(i)                                                                                                   \
+    do {                                                                                                             \
+        if (g_label_marks && (threadIdx.x & 63) == 0 && blockIdx.y == 0)                                             \
+            g_label_marks[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define LT_MARK(i) \
+    do {           \
+    } while (0)
+#endif
 template <bool RUNS, bool RECS = false>
 __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
                                                 int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist_all, size_t plist_stride,
@@ -549,6 +561,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
     const int ty0 = (int)(blockIdx.x / tiles_x) * kTileH, tx0 = (int)(blockIdx.x % tiles_x) * kTileW;
     const int q = tid & 31, r0 = tid >> 5;  // this thread: columns 4 q .. 4 q + 3 of rows r0, r0 + 8, r0 + 16, r0 + 24
     if (tid == 0) n_found = n_edge = n_slots = 0;
+    LT_MARK(0);
     unsigned int bits = 0;  // bit 4 j + k: pixel (r0 + 8 j, 4 q + k)
     float4 v[4];
 #pragma unroll
@@ -574,6 +587,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
             if (in) mask[((int64_t)r * cols + c) >> 5] = w;  // (cols % 32 == 0 and tx0 % 32 == 0: a whole word of this row)
         }
     }
+    LT_MARK(1);  // loads + threshold + mask
     // flatten's bookkeeping can start now: list + border list positions (one LDS atomic per thread, one global atomic per workgroup)
     const int cnt = __builtin_popcount(bits);
     unsigned int edge_bits = 0;
@@ -609,6 +623,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
                     lab[li] = li;
                 }
     }
+    LT_MARK(2);  // run starts
     __syncthreads();
     unsigned int at = 0, eat = 0;
     if (cnt && !RECS) at = atomicAdd(&n_found, (unsigned int)cnt);
@@ -633,6 +648,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
                 if (e1 >= 64) nb.hi &= ~ones64(p > 64 ? p - 64 : 0, e1 - 64);
             }
         }
+        LT_MARK(3);  // unions
         __syncthreads();
         // every run's node -> its root, so that a pixel reads its root in one step
         todo = starts;
@@ -686,6 +702,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
             }
         }
     }
+    LT_MARK(4);  // roots, slots
     __syncthreads();
     if constexpr (RECS) {
         const unsigned int rec_region = blockIdx.x % kRecRegions;
@@ -732,6 +749,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
                 bb &= ~(((1u << len) - 1u) << k0);
             }
         }
+        LT_MARK(5);  // contributions + parents
         __syncthreads();
         eat += base_edge;
         unsigned int todo = edge_bits;
@@ -748,6 +766,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
             ro.roots[pos] = groot;
             ro.cid[groot] = (int)pos;
         }
+        LT_MARK(6);  // border list + records
         return;
     }
     if (tid == 0) {
@@ -1279,13 +1298,13 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
     unsigned int *__restrict__ sel = g.sel[f];
     __shared__ unsigned int hist[2048];
     __shared__ unsigned int sub_key[kSelSub], sub_idx[kSelSub];
-    __shared__ unsigned int s_ncand, s_d0, s_above, s_count, s_nsub, s_prefix, s_want, s_ge;
+    __shared__ unsigned int s_ncand, s_d0, s_above, s_count, s_nsub, s_prefix, s_want, s_ge, s_take;
     // the table as segments: one of n entries, or (records form) kRecRegions segments rec_stride apart, each filled to its own count
     __shared__ unsigned int seg_n[kRecRegions], seg_t0[kRecRegions + 1];
     const int nseg = g.recs ? kRecRegions : 1;
     const unsigned int seg_stride = g.recs ? (unsigned int)g.rec_stride : 0u;
     for (unsigned int b = tid; b < 2048; b += kSelThreads) hist[b] = 0;
-    if (tid == 0) s_ncand = s_d0 = s_above = s_count = s_nsub = s_prefix = s_want = s_ge = 0;
+    if (tid == 0) s_ncand = s_d0 = s_above = s_count = s_nsub = s_prefix = s_want = s_ge = s_take = 0;
     if (g.recs) {
         const bool overflow = g.counters[f][3] != 0;  // a tile with more components than slots: nothing is selected, the host redoes the frame in full
         if (tid < kRecRegions) {
@@ -1310,32 +1329,42 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
     }
     __syncthreads();
     const unsigned int trips = seg_t0[nseg];  // block-uniform (the ballots below need whole waves)
-    auto index_of = [&](unsigned int T, unsigned int &i) -> bool {  // entry `tid` of trip T
-        int sg = 0;
-        while (sg + 1 < nseg && T >= seg_t0[sg + 1]) ++sg;
-        const unsigned int j = (T - seg_t0[sg]) * kSelThreads + tid;
-        i = (unsigned int)sg * seg_stride + j;
-        return T < trips && j < seg_n[sg];
+    // every entry of the table through consume(key, index), a batch of independent loads at a time (one thread's dependent round
+    // trips to L2 were the kernel -- 150 us inside a batch): eight consecutive trips of the one segment, or one trip of all
+    // kRecRegions segments at once (the records form: a segment holds two or three trips' worth)
+    constexpr unsigned int kSelIlp = 8;
+    auto scan = [&](auto &&consume) {
+        if (g.recs) {
+            unsigned int most = 0;
+#pragma unroll
+            for (int sg = 0; sg < kRecRegions; ++sg) most = max(most, seg_n[sg]);
+            for (unsigned int j = tid; j < most; j += kSelThreads) {  // (block-uniform trip count)
+                unsigned int k[kRecRegions];
+#pragma unroll
+                for (int sg = 0; sg < kRecRegions; ++sg) k[sg] = j < seg_n[sg] ? sel_key(st[(unsigned int)sg * seg_stride + j]) : 0u;
+#pragma unroll
+                for (int sg = 0; sg < kRecRegions; ++sg) consume(k[sg], (unsigned int)sg * seg_stride + j);
+            }
+            return;
+        }
+        for (unsigned int t0 = 0; t0 < trips; t0 += kSelIlp) {
+            unsigned int k[kSelIlp];
+#pragma unroll
+            for (unsigned int u = 0; u < kSelIlp; ++u) {
+                const unsigned int i = (t0 + u) * kSelThreads + tid;
+                k[u] = i < n ? sel_key(st[i]) : 0u;
+            }
+#pragma unroll
+            for (unsigned int u = 0; u < kSelIlp; ++u) consume(k[u], (t0 + u) * kSelThreads + tid);
+        }
     };
     // ---- pass A: level-0 histogram of the candidates ----
-    // (kSelIlp records in flight per thread: one thread's 40 dependent round trips to L2 were the kernel -- 150 us inside a batch)
-    constexpr unsigned int kSelIlp = 8;
     unsigned int mine = 0;
-    for (unsigned int t0 = 0; t0 < trips; t0 += kSelIlp) {
-        unsigned int k[kSelIlp];
-#pragma unroll
-        for (unsigned int u = 0; u < kSelIlp; ++u) {
-            unsigned int i;
-            k[u] = index_of(t0 + u, i) ? sel_key(st[i]) : 0u;
-        }
-#pragma unroll
-        for (unsigned int u = 0; u < kSelIlp; ++u) {
-            if (t0 + u >= trips) break;  // block-uniform
-            mine += k[u] ? 1u : 0u;
-            if (k[u]) atomicAdd(&hist[sel_digit(k[u])], 1u);  // (bins of 1/16 octave: a wave's 64 keys rarely share one -- plain LDS atomics;
-                                                               // one ballot round per DISTINCT bin, hist_add_matched, was 150 us of this kernel)
-        }
-    }
+    scan([&](unsigned int k, unsigned int) {
+        mine += k ? 1u : 0u;
+        if (k) atomicAdd(&hist[sel_digit(k)], 1u);  // (bins of 1/16 octave: a wave's 64 keys rarely share one -- plain LDS atomics;
+                                                    // one ballot round per DISTINCT bin, hist_add_matched, was 150 us of this kernel)
+    });
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
     if ((tid & 63) == 0 && mine) atomicAdd(&s_ncand, mine);
@@ -1348,35 +1377,32 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
         if (tid == 0) {
             s_d0 = d0;
             s_above = above;
+            // the whole bin of the cut fits beside what is brighter (the usual case: a bin is 4 % of flux wide): it is taken as it is --
+            // a few candidates more than kSelKeep, none of the brightest kSelKeep missing -- and the radix select inside it is skipped
+            s_take = above + hist[d0] <= kSelCap ? 1u : 0u;
         }
     }
     __syncthreads();
     const unsigned int d0 = s_d0, above = s_above;
+    const bool take_bin = s_take != 0;
     // ---- pass B: emit what is brighter than bin d0, collect bin d0 ----
-    for (unsigned int t0 = 0; t0 < trips; t0 += kSelIlp) {
-        unsigned int k[kSelIlp], idx[kSelIlp];
-#pragma unroll
-        for (unsigned int u = 0; u < kSelIlp; ++u) k[u] = index_of(t0 + u, idx[u]) ? sel_key(st[idx[u]]) : 0u;
-#pragma unroll
-        for (unsigned int u = 0; u < kSelIlp; ++u) {
-            const unsigned int i = idx[u];
-            if (!k[u]) continue;
-            const unsigned int dg = sel_digit(k[u]);
-            if (all || dg > d0) {
-                const unsigned int at = atomicAdd(&s_count, 1u);
-                if (at < kSelCap) sel[at] = i;
-            } else if (dg == d0) {
-                const unsigned int at = atomicAdd(&s_nsub, 1u);
-                if (at < (unsigned int)kSelSub) {
-                    sub_key[at] = k[u];
-                    sub_idx[at] = i;
-                }
+    scan([&](unsigned int k, unsigned int i) {
+        if (!k) return;
+        const unsigned int dg = sel_digit(k);
+        if (all || dg > d0 || (take_bin && dg == d0)) {
+            const unsigned int at = atomicAdd(&s_count, 1u);
+            if (at < kSelCap) sel[at] = i;
+        } else if (dg == d0) {
+            const unsigned int at = atomicAdd(&s_nsub, 1u);
+            if (at < (unsigned int)kSelSub) {
+                sub_key[at] = k;
+                sub_idx[at] = i;
             }
         }
-    }
+    });
     __syncthreads();
     const unsigned int nsub = s_nsub;
-    if (!all && nsub <= (unsigned int)kSelSub) {  // block-uniform: resolve the remaining 21 bits inside bin d0, in LDS
+    if (!all && !take_bin && nsub <= (unsigned int)kSelSub) {  // block-uniform: resolve the remaining 21 bits inside bin d0, in LDS
         const unsigned int want0 = kSelKeep - above;  // >= 1: the kSelKeep-th brightest lies in bin d0
         const unsigned int strips = (nsub + kSelThreads - 1) / kSelThreads;
         unsigned int prefix = 0, mask = 0, want = want0;

@@ -88,6 +88,23 @@ def ctx_midjoin():
 
 
 @pytest.fixture(scope="session")
+def ctx_pixel_list():
+    """Same library, AB_DETECT_NO_RECS=1: the chained detection over the tiles' PIXEL lists (roots + comp_stats) instead of one record
+    per tile-local component (label_tile_body<true, true> + comp_merge)."""
+    c = _ctx_under({"AB_DETECT_NO_RECS": "1"})
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def ctx_pixelwise():
+    """Same library, AB_LABEL_PIXELWISE=1: the tile-local unions pixel by pixel instead of run by run (and hence the pixel-list chain)."""
+    c = _ctx_under({"AB_LABEL_PIXELWISE": "1"})
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
 def ctx_r4_detect():
     """Same library with round 4's detection forms (AB_LABEL_LEGACY=1: two-pass labelling; AB_DETECT_FULL_RECORDS=1: every component's
     record crosses to the host): the cross-check of the tile-local union-find and of the device-side selection of the brightest."""

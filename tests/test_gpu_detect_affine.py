@@ -471,7 +471,7 @@ def test_registration_when_the_brightest_components_are_not_stars(ctx, oracle, k
 
 
 @pytest.mark.parametrize("shape", [(512, 640), (600, 800), (257, 1000), (1100, 2048)])
-def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midjoin, shape):
+def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midjoin, ctx_pixel_list, ctx_pixelwise, shape):
     """Round 5 changed how a GROUP of frames is detected: tile-local union-find in LDS + a border pass (widths that are multiples of
     32: 640, 800, 2048; 1000 keeps the two-pass form), approximate flux in comp_stats, the brightest 480 candidates selected on the
     device, moments for those only.  A context created under AB_LABEL_LEGACY=1 AB_DETECT_FULL_RECORDS=1 runs round 4's forms: the
@@ -487,10 +487,44 @@ def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midj
     new = ctx.register_frames(ref, tgts, num_threads=8)
     old = ctx_r4_detect.register_frames(ref, tgts, num_threads=8)
     mid = ctx_midjoin.register_frames(ref, tgts, num_threads=8)      # (the selection with a host join after the root numbering)
-    for a, b, c in zip(new, old, mid):
+    plist = ctx_pixel_list.register_frames(ref, tgts, num_threads=8)   # (the chain over pixel lists instead of tile-component records)
+    pixw = ctx_pixelwise.register_frames(ref, tgts, num_threads=8)     # (tile-local unions pixel by pixel instead of run by run)
+    for a, *others in zip(new, old, mid, plist, pixw):
+        for b in others:
+            assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
+    assert sum(a.method in ("affine", "rigid") for a in new) >= 7
+
+
+def test_crowded_tiles_and_stars_on_tile_corners(ctx, ctx_r4_detect, ctx_pixel_list):
+    """The records form of the tile labelling (one record per tile-local component, 64 slots per 32 x 128 tile): (i) stars centred on
+    tile CORNERS are four tile-local components whose records comp_merge folds into one; (ii) a patch of 3-pixel components on a
+    4-pixel lattice puts ~250 components into one tile -- more than its slots: the frame's overflow flag is raised and the host
+    redoes it through the full path.  Transforms, star counts and inliers must equal round 4's forms and the pixel-list chain."""
+    import torch
+    from astroburst_amd import synth
+    rows, cols = 512, 640
+    y, x, flux = synth.star_catalog(rows, cols, 420, seed=77)
+    ky, kx = np.meshgrid(32.0 * np.arange(2, 14, 3) - 0.5, 128.0 * np.arange(1, 5) - 0.5, indexing="ij")     # tile corners
+    y = torch.cat([y, torch.from_numpy(ky.ravel()).to(y.dtype)])
+    x = torch.cat([x, torch.from_numpy(kx.ravel()).to(x.dtype)])
+    flux = torch.cat([flux, torch.full((ky.size,), float(flux.max()) * 0.8, dtype=flux.dtype)])
+    cat = (y, x, flux * 30.0)
+    ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=0.0)
+    tgts = [synth.make_frame(rows, cols, k + 1, cat=cat, shift=(2.0 * k - 5.0, 1.5 * k - 3.0), bad_patch_rate=0.0, cosmic_rate=0.0) for k in range(6)]
+    for t in (tgts[1], tgts[4]):                                     # the crowded patch, in two frames of different groups
+        for yy in range(68, 92, 4):
+            for xx in range(260, 380, 4):
+                t[yy, xx] += 9000.0
+                t[yy, xx + 1] += 7000.0
+                t[yy + 1, xx] += 7000.0
+    ref, tgts = ref.cuda(), [t.cuda() for t in tgts]
+    new = ctx.register_frames(ref, tgts, num_threads=8)
+    old = ctx_r4_detect.register_frames(ref, tgts, num_threads=8)
+    plist = ctx_pixel_list.register_frames(ref, tgts, num_threads=8)
+    for a, b, c in zip(new, old, plist):
         assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
         assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (c.method, c.matched_stars, c.inliers, c.transform, c.residual_px)
-    assert sum(a.method in ("affine", "rigid") for a in new) >= 7
+    assert sum(a.method in ("affine", "rigid") for a in new) >= 5
 
 
 def test_ctx_trim_releases_and_the_context_keeps_working(oracle):

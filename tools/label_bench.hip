@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iastroburst_amd/csrc -Iinclude tools/label_bench.hip -Lastroburst_amd -lastroburst_hip -o build/label_bench
 // Variants: 8 runs + component records | 0 runs, pixel list | 7 the pixel-by-pixel unions | 1 loads only, 32 x 128 tile pattern | 2 loads only, 16 KB contiguous per workgroup | 3 loads + threshold +
 // mask words, no labels | 4 loads only, 8 x 512 pattern | 5 loads only, 16 x 256 pattern | 6 as 3 with the labels' LDS allocated (occupancy)
+#define AB_LABEL_TIMING 1
 #include "../astroburst_amd/csrc/detect.hip"
 
 #include <random>
@@ -214,6 +215,39 @@ int main(int argc, char **argv) {
         unsigned int fl[4];
         hipMemcpy(fl, g_flags, 16, hipMemcpyDeviceToHost);
         printf("records form: overflow flag of frame 0 = %u\n", fl[0]);
+    }
+    {  // phase marks of the records form, frame 0: per tile the slowest wave's time at each mark, and the tile's lifetime
+        long long *marks;
+        hipMalloc(&marks, 4096 * 4 * 8 * 8);
+        hipMemset(marks, 0, 4096 * 4 * 8 * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_label_marks), &marks, sizeof marks);
+        hipMemset(lcnt_flat, 0, G * lw * 4);
+        hipLaunchKernelGGL(bench_kernel<8>, dim3(4096, G), dim3(256), 0, 0, d_imgs, rows, cols, thr, xf, d_parent, d_mask, d_plist, ps, d_blist, bs, d_lcnt, sink, g_st, g_roots, g_cid,
+                           g_rec_stride, g_flags);
+        hipDeviceSynchronize();
+        std::vector<long long> m(4096 * 4 * 8);
+        hipMemcpy(m.data(), marks, m.size() * 8, hipMemcpyDeviceToHost);
+        long long *none = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_label_marks), &none, sizeof none);
+        double ph[7] = {0}, life = 0;
+        const char *names[7] = {"", "loads+threshold+mask", "run starts", "unions", "roots+slots", "contributions+parents", "border list+records"};
+        for (int t = 0; t < 4096; ++t) {
+            long long t0 = m[(t * 4) * 8], last[7];
+            for (int w = 1; w < 4; ++w) t0 = std::min(t0, m[(t * 4 + w) * 8]);
+            for (int i = 1; i < 7; ++i) {
+                last[i] = 0;
+                for (int w = 0; w < 4; ++w) last[i] = std::max(last[i], m[(t * 4 + w) * 8 + i]);
+            }
+            long long prev = t0;
+            for (int i = 1; i < 7; ++i) {
+                ph[i] += (double)(last[i] - prev);
+                prev = last[i];
+            }
+            life += (double)(last[6] - t0);
+        }
+        printf("records form, per tile (s_memtime ticks of 10 ns, slowest wave at each mark): lifetime %.0f;", life / 4096);
+        for (int i = 1; i < 7; ++i) printf("  %s %.0f", names[i], ph[i] / 4096);
+        printf("\n");
     }
     std::vector<unsigned int> c(G * lw);
     hipMemcpy(c.data(), lcnt_flat, G * lw * 4, hipMemcpyDeviceToHost);
