@@ -625,62 +625,92 @@ int vote_copies() {
     }();
     return c;
 }
+// one work item: slice `item % kVoteSlices` of the candidates of reference group `item / kVoteSlices`, by one wave, into the LDS matrix
+constexpr int kVoteLdsStride = kVoteDim + 1;  // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and
+                                              // with a stride of 64 (a multiple of the bank count) all of those atomics would land in one bank
+__device__ __forceinline__ void tri_vote_item(unsigned int item, int lane, unsigned int nr, const DTri *__restrict__ rt_sorted, const DTri *__restrict__ tt_sorted,
+                                              const unsigned int *__restrict__ bin_off, const RefGroup *__restrict__ groups, unsigned int *votes) {
+    const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
+    const bool have = r < nr;
+    const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
+    const RefGroup grp = groups[item / kVoteSlices];  // (uniform: scalar loads)
+    // a candidate can match SOME triangle of the group only inside the group's ratio windows (widened by the tolerance)
+    const double win_lo = grp.lmin - kTriangleTolerance * 1.0001, win_hi = grp.lmax + kTriangleTolerance * 1.0001;
+    const double mwin_lo = grp.mmin - kTriangleTolerance * 1.0001, mwin_hi = grp.mmax + kTriangleTolerance * 1.0001;
+    const int bmin = grp.bmin, bmax = grp.bmax;
+    unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
+    {
+        const unsigned int per = (q1 - q0 + kVoteSlices - 1) / kVoteSlices;
+        q0 = min(q0 + slice * per, q1);
+        q1 = min(q0 + per, q1);
+    }
+    // nothing else hides the table's load latency, so the next 64 candidates are fetched while the current ones are tested
+    DTri nxt = {0.0, 0.0, 0u, 0u};
+    if (q0 + lane < q1) nxt = tt_sorted[q0 + lane];
+    for (unsigned int base = q0; base < q1; base += 64) {
+        const unsigned int idx = base + lane;
+        const DTri t = nxt;
+        if (idx + 64 < q1) nxt = tt_sorted[idx + 64];
+        const bool keep = idx < q1 && t.lng >= win_lo && t.lng <= win_hi && t.mid >= mwin_lo && t.mid <= mwin_hi;
+        // the kept candidates stay in their lanes' registers and are broadcast one by one through the scalar unit
+        // (v_readlane): staging them in LDS cost two dependent LDS round trips per candidate with nothing to hide them
+        unsigned long long m = __ballot(keep);
+        while (m) {
+            const int q = (int)__builtin_ctzll(m);
+            m &= m - 1;
+            const double c_mid = lane_f64(t.mid, q), c_lng = lane_f64(t.lng, q);
+            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)t.verts, q);
+            if (!have || fabs(a.mid - c_mid) > kTriangleTolerance || fabs(a.lng - c_lng) > kTriangleTolerance) continue;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) atomicAdd(&votes[((a.verts >> (8 * p)) & 255u) * kVoteLdsStride + ((b >> (8 * p)) & 255u)], 1u);
+        }
+    }
+}
+
+// round 2 .. 5a: 1024 persistent one-wave blocks, each walking ~4 items and flushing its own LDS matrix (AB_VOTE_WAVES=1 keeps it)
 __device__ __forceinline__ void tri_vote_body(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p,
                                                       const DTri *__restrict__ tt_sorted, const unsigned int *__restrict__ bin_off,
                                                       unsigned int *__restrict__ votes_out /* copies x 64 x 64, zeroed */, int copies,
                                                       const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *tgt_count_to_clear = 0;  // tri_scatter_kernel was its last reader
-    // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and with a stride of 64
-    // (a multiple of the bank count) all of those atomics would land in one bank
-    constexpr int kLdsStride = kVoteDim + 1;
-    __shared__ unsigned int votes[kVoteDim * kLdsStride];
+    __shared__ unsigned int votes[kVoteDim * kVoteLdsStride];
     const int lane = threadIdx.x;
     const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * kVoteSlices;
     if (blockIdx.x >= items) return;
-    for (int i = lane; i < kVoteDim * kLdsStride; i += 64) votes[i] = 0;
+    for (int i = lane; i < kVoteDim * kVoteLdsStride; i += 64) votes[i] = 0;
     __syncthreads();
-    for (unsigned int item = blockIdx.x; item < items; item += gridDim.x) {
-        const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
-        const bool have = r < nr;
-        const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
-        const RefGroup grp = groups[item / kVoteSlices];  // (uniform: scalar loads)
-        // a candidate can match SOME triangle of the group only inside the group's ratio windows (widened by the tolerance)
-        const double win_lo = grp.lmin - kTriangleTolerance * 1.0001, win_hi = grp.lmax + kTriangleTolerance * 1.0001;
-        const double mwin_lo = grp.mmin - kTriangleTolerance * 1.0001, mwin_hi = grp.mmax + kTriangleTolerance * 1.0001;
-        const int bmin = grp.bmin, bmax = grp.bmax;
-        unsigned int q0 = bin_off[bmin > 0 ? bmin - 1 : 0], q1 = bin_off[(bmax < kTriBins - 1 ? bmax + 1 : kTriBins - 1) + 1];
-        {
-            const unsigned int per = (q1 - q0 + kVoteSlices - 1) / kVoteSlices;
-            q0 = min(q0 + slice * per, q1);
-            q1 = min(q0 + per, q1);
-        }
-        // one wave per SIMD: nothing else hides the table's load latency, so the next 64 candidates are fetched
-        // while the current ones are tested
-        DTri nxt = {0.0, 0.0, 0u, 0u};
-        if (q0 + lane < q1) nxt = tt_sorted[q0 + lane];
-        for (unsigned int base = q0; base < q1; base += 64) {
-            const unsigned int idx = base + lane;
-            const DTri t = nxt;
-            if (idx + 64 < q1) nxt = tt_sorted[idx + 64];
-            const bool keep = idx < q1 && t.lng >= win_lo && t.lng <= win_hi && t.mid >= mwin_lo && t.mid <= mwin_hi;
-            // the kept candidates stay in their lanes' registers and are broadcast one by one through the scalar unit
-            // (v_readlane): staging them in LDS cost two dependent LDS round trips per candidate with nothing to hide them
-            unsigned long long m = __ballot(keep);
-            while (m) {
-                const int q = (int)__builtin_ctzll(m);
-                m &= m - 1;
-                const double c_mid = lane_f64(t.mid, q), c_lng = lane_f64(t.lng, q);
-                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)t.verts, q);
-                if (!have || fabs(a.mid - c_mid) > kTriangleTolerance || fabs(a.lng - c_lng) > kTriangleTolerance) continue;
-#pragma unroll
-                for (int p = 0; p < 3; ++p) atomicAdd(&votes[((a.verts >> (8 * p)) & 255u) * kLdsStride + ((b >> (8 * p)) & 255u)], 1u);
-            }
-        }
-    }
+    for (unsigned int item = blockIdx.x; item < items; item += gridDim.x) tri_vote_item(item, lane, nr, rt_sorted, tt_sorted, bin_off, groups, votes);
     __syncthreads();
     unsigned int *mine = votes_out + (size_t)(blockIdx.x % (unsigned int)copies) * (kVoteDim * kVoteDim);
     for (int row = 0; row < kVoteDim; ++row) {  // lane = column
-        const unsigned int v = votes[row * kLdsStride + lane];
+        const unsigned int v = votes[row * kVoteLdsStride + lane];
+        if (v) atomicAdd(&mine[row * kVoteDim + lane], v);
+    }
+}
+
+// Round 5: ONE item per wave, kVoteWaves waves per block sharing the block's LDS matrix.  An item is a chain of three dependent
+// global round trips (the group's windows -> the bucket offsets -> the first candidates) in front of a few dozen pair tests; a
+// persistent wave walked four such chains one after the other with nothing beside it on its SIMD to hide them (90 us per group of
+// four frames, 55 of them whatever the frame count).  Now every chain of a frame is in flight at once, and a block's clear + flush
+// of the 64 x 64 matrix is shared by its waves (one-item one-wave blocks were tried in round 4: the flush per item made them slower).
+constexpr int kVoteWaves = 8;
+constexpr int kVoteItemsMax = ((kMaxTris + 63) / 64) * kVoteSlices;
+__device__ __forceinline__ void tri_vote_wide_body(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, const DTri *__restrict__ tt_sorted,
+                                                   const unsigned int *__restrict__ bin_off, unsigned int *__restrict__ votes_out, int copies,
+                                                   const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *tgt_count_to_clear = 0;  // tri_scatter_kernel was its last reader
+    __shared__ unsigned int votes[kVoteDim * kVoteLdsStride];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * kVoteSlices;
+    if (blockIdx.x * kVoteWaves >= items) return;  // (block-uniform)
+    for (int i = threadIdx.x; i < kVoteDim * kVoteLdsStride; i += kVoteWaves * 64) votes[i] = 0;
+    __syncthreads();
+    const unsigned int item = blockIdx.x * kVoteWaves + wv;  // consecutive items: slices of one reference group
+    if (item < items) tri_vote_item(item, lane, nr, rt_sorted, tt_sorted, bin_off, groups, votes);
+    __syncthreads();
+    unsigned int *mine = votes_out + (size_t)(blockIdx.x % (unsigned int)copies) * (kVoteDim * kVoteDim);
+    for (int row = wv; row < kVoteDim; row += kVoteWaves) {  // lane = column
+        const unsigned int v = votes[row * kVoteLdsStride + lane];
         if (v) atomicAdd(&mine[row * kVoteDim + lane], v);
     }
 }
@@ -725,6 +755,23 @@ __global__ __launch_bounds__(64) void tri_vote_many_kernel(const TriGroup g, con
                                                            const RefGroup *__restrict__ groups) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     tri_vote_body(rt_sorted, nr_p, g.sorted[f], g.bin_off[f], g.votes[f], copies, groups, g.count[f]);
+}
+__global__ __launch_bounds__(kVoteWaves * 64) void tri_vote_wide_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, const DTri *__restrict__ tt_sorted,
+                                                                        const unsigned int *__restrict__ bin_off, unsigned int *__restrict__ votes_out, int copies,
+                                                                        const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) { AB_LATENCY_KERNEL_PRIO();
+    tri_vote_wide_body(rt_sorted, nr_p, tt_sorted, bin_off, votes_out, copies, groups, tgt_count_to_clear);
+}
+__global__ __launch_bounds__(kVoteWaves * 64) void tri_vote_wide_many_kernel(const TriGroup g, const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, int copies,
+                                                                             const RefGroup *__restrict__ groups) { AB_LATENCY_KERNEL_PRIO();
+    const int f = blockIdx.y;
+    tri_vote_wide_body(rt_sorted, nr_p, g.sorted[f], g.bin_off[f], g.votes[f], copies, groups, g.count[f]);
+}
+bool vote_wide() {
+    static const bool on = [] {
+        const char *e = getenv("AB_VOTE_WAVES");
+        return !(e && atoi(e) == 1);
+    }();
+    return on;
 }
 
 // the `copies` partial vote matrices of every frame of a group added up, straight into pinned host memory (round 4: the group's
@@ -809,8 +856,12 @@ int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std:
     // (w.votes was cleared by this frame's tri_build_kernel or the memset beside it; the kernel resets the target table's counter
     // for the next frame)
     const int copies = vote_copies();
-    hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, copies,
-                       (const RefGroup *)w.groups, w.counts + 1);
+    if (vote_wide())
+        hipLaunchKernelGGL(tri_vote_wide_kernel, dim3((kVoteItemsMax + kVoteWaves - 1) / kVoteWaves), dim3(kVoteWaves * 64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted,
+                           w.bin_off, w.votes, copies, (const RefGroup *)w.groups, w.counts + 1);
+    else
+        hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, copies,
+                           (const RefGroup *)w.groups, w.counts + 1);
     AB_HIP(ctx, hipGetLastError());
     const size_t words = (size_t)copies * kVoteDim * kVoteDim;
     void *pin = nullptr;  // (read back into pinned memory: a copy into a std::vector is staged and synchronised by the runtime)
@@ -889,8 +940,12 @@ int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *s
     hipLaunchKernelGGL(tri_build_many_kernel, dim3(blocks, G), dim3(kTriBlock), 0, ctx->stream, w.g, (const StarXY *)w.stars, vote_words);
     hipLaunchKernelGGL(tri_bin_scan_many_kernel, dim3(1, G), dim3(kScanThreads), 0, ctx->stream, w.g);
     hipLaunchKernelGGL(tri_scatter_many_kernel, dim3((kMaxTris + kTriBlock - 1) / kTriBlock, G), dim3(kTriBlock), 0, ctx->stream, w.g);
-    hipLaunchKernelGGL(tri_vote_many_kernel, dim3(kVoteBlocks, G), dim3(64), 0, ctx->stream, w.g, (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts,
-                       copies, (const RefGroup *)ref_ws.groups);
+    if (vote_wide())
+        hipLaunchKernelGGL(tri_vote_wide_many_kernel, dim3((kVoteItemsMax + kVoteWaves - 1) / kVoteWaves, G), dim3(kVoteWaves * 64), 0, ctx->stream, w.g,
+                           (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts, copies, (const RefGroup *)ref_ws.groups);
+    else
+        hipLaunchKernelGGL(tri_vote_many_kernel, dim3(kVoteBlocks, G), dim3(64), 0, ctx->stream, w.g, (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts,
+                           copies, (const RefGroup *)ref_ws.groups);
     uint32_t *hv = (uint32_t *)((char *)pin + stars_bytes);
     hipLaunchKernelGGL(votes_reduce_many_kernel, dim3((kVoteDim * kVoteDim + 255) / 256, G), dim3(256), 0, ctx->stream, w.g, copies, hv);
     AB_HIP(ctx, hipGetLastError());
