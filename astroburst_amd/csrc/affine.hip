@@ -629,7 +629,8 @@ int vote_copies() {
 constexpr int kVoteLdsStride = kVoteDim + 1;  // LDS rows are 65 words apart: for one candidate every voting lane targets the SAME column, and
                                               // with a stride of 64 (a multiple of the bank count) all of those atomics would land in one bank
 __device__ __forceinline__ void tri_vote_item(unsigned int item, int lane, unsigned int nr, const DTri *__restrict__ rt_sorted, const DTri *__restrict__ tt_sorted,
-                                              const unsigned int *__restrict__ bin_off, const RefGroup *__restrict__ groups, unsigned int *votes) {
+                                              const unsigned int *__restrict__ bin_off, const RefGroup *__restrict__ groups, unsigned int *votes,
+                                              const unsigned int kVoteSlices = ::kVoteSlices) {
     const unsigned int first = (item / kVoteSlices) * 64, slice = item % kVoteSlices, r = first + lane;
     const bool have = r < nr;
     const DTri a = rt_sorted[have ? r : nr - 1];  // tail lanes replicate the last triangle (they never vote)
@@ -697,16 +698,16 @@ constexpr int kVoteWaves = 8;
 constexpr int kVoteItemsMax = ((kMaxTris + 63) / 64) * kVoteSlices;
 __device__ __forceinline__ void tri_vote_wide_body(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, const DTri *__restrict__ tt_sorted,
                                                    const unsigned int *__restrict__ bin_off, unsigned int *__restrict__ votes_out, int copies,
-                                                   const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) {
+                                                   const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear, unsigned int slices) {
     if (blockIdx.x == 0 && threadIdx.x == 0) *tgt_count_to_clear = 0;  // tri_scatter_kernel was its last reader
     __shared__ unsigned int votes[kVoteDim * kVoteLdsStride];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * kVoteSlices;
+    const unsigned int nr = *nr_p, items = ((nr + 63u) / 64u) * slices;
     if (blockIdx.x * kVoteWaves >= items) return;  // (block-uniform)
     for (int i = threadIdx.x; i < kVoteDim * kVoteLdsStride; i += kVoteWaves * 64) votes[i] = 0;
     __syncthreads();
     const unsigned int item = blockIdx.x * kVoteWaves + wv;  // consecutive items: slices of one reference group
-    if (item < items) tri_vote_item(item, lane, nr, rt_sorted, tt_sorted, bin_off, groups, votes);
+    if (item < items) tri_vote_item(item, lane, nr, rt_sorted, tt_sorted, bin_off, groups, votes, slices);
     __syncthreads();
     unsigned int *mine = votes_out + (size_t)(blockIdx.x % (unsigned int)copies) * (kVoteDim * kVoteDim);
     for (int row = wv; row < kVoteDim; row += kVoteWaves) {  // lane = column
@@ -758,13 +759,21 @@ __global__ __launch_bounds__(64) void tri_vote_many_kernel(const TriGroup g, con
 }
 __global__ __launch_bounds__(kVoteWaves * 64) void tri_vote_wide_kernel(const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, const DTri *__restrict__ tt_sorted,
                                                                         const unsigned int *__restrict__ bin_off, unsigned int *__restrict__ votes_out, int copies,
-                                                                        const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear) { AB_LATENCY_KERNEL_PRIO();
-    tri_vote_wide_body(rt_sorted, nr_p, tt_sorted, bin_off, votes_out, copies, groups, tgt_count_to_clear);
+                                                                        const RefGroup *__restrict__ groups, unsigned int *__restrict__ tgt_count_to_clear, unsigned int slices) { AB_LATENCY_KERNEL_PRIO();
+    tri_vote_wide_body(rt_sorted, nr_p, tt_sorted, bin_off, votes_out, copies, groups, tgt_count_to_clear, slices);
 }
 __global__ __launch_bounds__(kVoteWaves * 64) void tri_vote_wide_many_kernel(const TriGroup g, const DTri *__restrict__ rt_sorted, const unsigned int *__restrict__ nr_p, int copies,
-                                                                             const RefGroup *__restrict__ groups) { AB_LATENCY_KERNEL_PRIO();
+                                                                             const RefGroup *__restrict__ groups, unsigned int slices) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
-    tri_vote_wide_body(rt_sorted, nr_p, g.sorted[f], g.bin_off[f], g.votes[f], copies, groups, g.count[f]);
+    tri_vote_wide_body(rt_sorted, nr_p, g.sorted[f], g.bin_off[f], g.votes[f], copies, groups, g.count[f], slices);
+}
+unsigned int vote_wide_slices() {  // slices of a reference group's candidate range in the wide form (AB_VOTE_SLICES)
+    static const unsigned int v = [] {
+        const char *e = getenv("AB_VOTE_SLICES");
+        const int x = e ? atoi(e) : 8;  // (8 / 4 / 2 / 1 measured: 9.4 / 9.6 / 9.6 / 10.0 ms for the stage)
+        return (unsigned int)(x < 1 ? 1 : (x > 8 ? 8 : x));
+    }();
+    return v;
 }
 bool vote_wide() {
     static const bool on = [] {
@@ -858,7 +867,7 @@ int gpu_votes(ab_ctx *ctx, const MatchWs &w, const unsigned int *ref_count, std:
     const int copies = vote_copies();
     if (vote_wide())
         hipLaunchKernelGGL(tri_vote_wide_kernel, dim3((kVoteItemsMax + kVoteWaves - 1) / kVoteWaves), dim3(kVoteWaves * 64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted,
-                           w.bin_off, w.votes, copies, (const RefGroup *)w.groups, w.counts + 1);
+                           w.bin_off, w.votes, copies, (const RefGroup *)w.groups, w.counts + 1, vote_wide_slices());
     else
         hipLaunchKernelGGL(tri_vote_kernel, dim3(kVoteBlocks), dim3(64), 0, ctx->stream, w.ref_sorted, ref_count, w.tgt_sorted, w.bin_off, w.votes, copies,
                            (const RefGroup *)w.groups, w.counts + 1);
@@ -942,7 +951,7 @@ int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *s
     hipLaunchKernelGGL(tri_scatter_many_kernel, dim3((kMaxTris + kTriBlock - 1) / kTriBlock, G), dim3(kTriBlock), 0, ctx->stream, w.g);
     if (vote_wide())
         hipLaunchKernelGGL(tri_vote_wide_many_kernel, dim3((kVoteItemsMax + kVoteWaves - 1) / kVoteWaves, G), dim3(kVoteWaves * 64), 0, ctx->stream, w.g,
-                           (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts, copies, (const RefGroup *)ref_ws.groups);
+                           (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts, copies, (const RefGroup *)ref_ws.groups, vote_wide_slices());
     else
         hipLaunchKernelGGL(tri_vote_many_kernel, dim3(kVoteBlocks, G), dim3(64), 0, ctx->stream, w.g, (const DTri *)ref_ws.ref_sorted, (const unsigned int *)ref_ws.counts,
                            copies, (const RefGroup *)ref_ws.groups);
