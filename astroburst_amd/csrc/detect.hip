@@ -266,7 +266,7 @@ __global__ __launch_bounds__(ts::kThreads) void tile_background_stream_kernel(co
     r.x0 = (int)(blockIdx.x % (unsigned int)ntx) * step;
     r.y1 = min(r.y0 + step, rows);
     r.x1 = min(r.x0 + step, cols);
-    r.vec = ((ld | (int64_t)step | (int64_t)cols) & 3) == 0 && ((uintptr_t)img & 15) == 0;
+    r.vec = (step & 3) == 0 && ((r.x1 - r.x0) & 3) == 0;
     const ts::TileResult res = ts::tile_stats(sh, r, xf);
     if (threadIdx.x == 0) {
         if (res.declined) {
@@ -545,8 +545,11 @@ __device__ long long *g_label_marks = nullptr;  // [tile][wave][8]
 template <bool RUNS, bool RECS = false>
 __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
                                                 int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ plist_all, size_t plist_stride,
-                                                int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt, const TileRecOut ro = TileRecOut()) {
+                                                int *__restrict__ blist_all, size_t blist_stride, unsigned int *lcnt, const TileRecOut ro = TileRecOut(), int mpitch = 0) {
     static_assert(RUNS || !RECS, "records need the run form");
+    // mpitch: bits per row of the mask (a multiple of 32 >= cols; 0 = cols, which must then be one): with padded mask rows a tile's 32-
+    // column words never straddle rows, whatever the plane's width (round 5: any width takes this path; cols % 32 == 0 used to be required)
+    const int64_t mp = mpitch ? mpitch : cols;
     const int region = (int)(blockIdx.x % kRegions);
     int *__restrict__ plist = plist_all + (size_t)region * plist_stride, *__restrict__ blist = blist_all + (size_t)region * blist_stride;
     unsigned int *nlab = lcnt + region * kRegionPitch, *nborder = lcnt + (kRegions + region) * kRegionPitch;
@@ -568,15 +571,22 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
     for (int j = 0; j < 4; ++j) {
         const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
         v[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (r < rows && c < cols) v[j] = *reinterpret_cast<const float4 *>(img + (int64_t)r * cols + c);  // (cols % 4 == 0: the quad is inside)
+        if (r < rows && c + 3 < cols) {
+            v[j] = ts::load4u(img + (int64_t)r * cols + c);  // (any dword address)
+        } else if (r < rows && c < cols) {  // the ragged quad at the end of a row whose width is not a multiple of 4
+            const float *p = img + (int64_t)r * cols + c;
+            v[j].x = p[0];
+            if (c + 1 < cols) v[j].y = p[1];
+            if (c + 2 < cols) v[j].z = p[2];
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = ty0 + r0 + 8 * j, c = tx0 + 4 * q;
         const bool in = r < rows && c < cols;
         v[j] = make_float4(ab_px(xf, v[j].x), ab_px(xf, v[j].y), ab_px(xf, v[j].z), ab_px(xf, v[j].w));  // (RECS adds these up further down)
-        const unsigned int b = (unsigned int)(in && above(v[j].x, threshold)) | ((unsigned int)(in && above(v[j].y, threshold)) << 1) |
-                               ((unsigned int)(in && above(v[j].z, threshold)) << 2) | ((unsigned int)(in && above(v[j].w, threshold)) << 3);
+        const unsigned int b = (unsigned int)(in && above(v[j].x, threshold)) | ((unsigned int)(in && c + 1 < cols && above(v[j].y, threshold)) << 1) |
+                               ((unsigned int)(in && c + 2 < cols && above(v[j].z, threshold)) << 2) | ((unsigned int)(in && c + 3 < cols && above(v[j].w, threshold)) << 3);
         bits |= b << (4 * j);
         unsigned int w = b << (4 * (lane & 7));  // eight lanes make one mask word
         w |= __shfl_xor(w, 1, 64);
@@ -584,7 +594,7 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
         w |= __shfl_xor(w, 4, 64);
         if ((lane & 7) == 0) {
             tmask[r0 + 8 * j][q >> 3] = w;
-            if (in) mask[((int64_t)r * cols + c) >> 5] = w;  // (cols % 32 == 0 and tx0 % 32 == 0: a whole word of this row)
+            if (in) mask[((int64_t)r * mp + c) >> 5] = w;  // (mp % 32 == 0 and tx0 % 32 == 0: a whole word of this row)
         }
     }
     LT_MARK(1);  // loads + threshold + mask
@@ -814,19 +824,23 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
 
 // cross-tile unions of the border pixels (the forward neighbours that lie in another tile), on the global forest
 __device__ __forceinline__ void label_border_body(int rows, int cols, int *parent, const unsigned int *__restrict__ mask, const int *__restrict__ blist,
-                                                  const unsigned int *__restrict__ nborder, unsigned int bid, unsigned int nblk) {
+                                                  const unsigned int *__restrict__ nborder, unsigned int bid, unsigned int nblk, int mpitch) {
     const unsigned int n = *nborder;
+    auto lab_at = [&](int rr, int cc) -> bool {  // (mask rows are mpitch bits apart)
+        const int64_t j = (int64_t)rr * mpitch + cc;
+        return (mask[j >> 5] >> (j & 31)) & 1u;
+    };
     for (unsigned int k = bid * 256 + threadIdx.x; k < n; k += nblk * 256) {
         const int i = blist[k];
         const int r = i / cols, c = i - r * cols;
         const int tr = r / kTileH, tc = c / kTileW;
         auto other = [&](int rr, int cc) { return rr / kTileH != tr || cc / kTileW != tc; };
-        if (c + 1 < cols && other(r, c + 1) && labelled(mask, i + 1)) uf_union(parent, i, i + 1);
+        if (c + 1 < cols && other(r, c + 1) && lab_at(r, c + 1)) uf_union(parent, i, i + 1);
         if (r + 1 < rows) {
             const int d = i + cols;
-            if (c > 0 && other(r + 1, c - 1) && labelled(mask, d - 1)) uf_union(parent, i, d - 1);
-            if (other(r + 1, c) && labelled(mask, d)) uf_union(parent, i, d);
-            if (c + 1 < cols && other(r + 1, c + 1) && labelled(mask, d + 1)) uf_union(parent, i, d + 1);
+            if (c > 0 && other(r + 1, c - 1) && lab_at(r + 1, c - 1)) uf_union(parent, i, d - 1);
+            if (other(r + 1, c) && lab_at(r + 1, c)) uf_union(parent, i, d);
+            if (c + 1 < cols && other(r + 1, c + 1) && lab_at(r + 1, c + 1)) uf_union(parent, i, d + 1);
         }
     }
 }
@@ -1014,7 +1028,7 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
                                                            const unsigned int *__restrict__ mask, const int *__restrict__ roots, const CompStat *__restrict__ st, unsigned int ncomp,
                                                            double bg_median_arg, const ab_pixel_xf xf_arg, CompRec *__restrict__ rec,
                                                            const FrameDev *__restrict__ fd, const unsigned int *__restrict__ sel = nullptr,
-                                                           const unsigned int *__restrict__ nsel = nullptr, bool two_hop = false) {
+                                                           const unsigned int *__restrict__ nsel = nullptr, bool two_hop = false, int mpitch = 0) {
     const double bg_median = fd ? fd->bg_median : bg_median_arg;
     const ab_pixel_xf xf = fd ? fd->xf : xf_arg;
     const unsigned int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kMomPerWave;
@@ -1032,10 +1046,11 @@ __device__ __forceinline__ void comp_moments_body(const float *__restrict__ img,
     // three loads are independent: all are taken for every pixel of the box and the mask bit decides afterwards
     auto value = [&](const CompStat &s, int root, int r, int c, bool valid) -> double {
         const int rr = valid ? r : s.y0, cc = valid ? c : s.x0, idx = rr * cols + cc;  // invalid lanes re-read the box's corner
-        const unsigned int m = mask[idx >> 5];
+        const int64_t midx = mpitch ? (int64_t)rr * mpitch + cc : (int64_t)idx;  // (the tiled labelling pads the mask's rows)
+        const unsigned int m = mask[midx >> 5];
         const int p = parent[idx];  // (defined at labelled pixels only: the bit decides)
         const float px = img[rr * ld + cc];
-        const bool bit = (m >> (idx & 31)) & 1u;
+        const bool bit = (m >> (midx & 31)) & 1u;
         // (records form: a pixel points at its TILE's root, which points at the component's root when that lies in another tile)
         const int p2 = (two_hop && valid && bit && p != root) ? parent[p] : p;
         const bool member = valid && bit && p2 == root;
@@ -1228,6 +1243,7 @@ struct DetGroup {
     unsigned int *lcnt[kGroupMax];    // its 2 x kRegions list counters, kRegionPitch words apart
     size_t plist_stride, blist_stride;  // ints per region segment
     int tiled;
+    int mask_pitch;                   // tiled: bits per row of mask[f] (cols rounded up to 32)
     int recs;                         // label_tile_body<true, true>: st / roots hold one record per TILE-LOCAL component, in kRecRegions segments of rec_stride
     size_t rec_stride;
     unsigned int *sel[kGroupMax];     // indices of the selected components (comp_select_many_kernel), kSelCap each
@@ -1476,7 +1492,8 @@ __global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const Det
     const int f = blockIdx.y;
     TileRecOut ro;
     if constexpr (RECS) ro = TileRecOut{g.st[f], g.roots[f], g.cid[f], g.rec_stride, g.counters[f] + 3, g.bg_median[f]};
-    label_tile_body<RUNS, RECS>(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f], ro);
+    label_tile_body<RUNS, RECS>(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f], ro,
+                                g.mask_pitch);
 }
 // (grid: a multiple of kRecRegions blocks; block b works on record region b mod kRecRegions as sub-block b / kRecRegions)
 __global__ __launch_bounds__(256) void comp_merge_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
@@ -1490,7 +1507,7 @@ __global__ __launch_bounds__(256) void comp_merge_many_kernel(const DetGroup g) 
 __global__ __launch_bounds__(256) void label_border_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y, r = blockIdx.x % kRegions;
     label_border_body(rows, cols, g.parent[f], g.mask[f], g.blist[f] + (size_t)r * g.blist_stride, g.lcnt[f] + (kRegions + r) * kRegionPitch, blockIdx.x / kRegions,
-                      gridDim.x / kRegions);
+                      gridDim.x / kRegions, g.mask_pitch);
 }
 __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
                                                             int *__restrict__ roots, int *__restrict__ cid, unsigned int *nroots, unsigned int cap) { AB_LATENCY_KERNEL_PRIO();
@@ -1540,7 +1557,7 @@ __global__ __launch_bounds__(256) void comp_moments_kernel(const float *__restri
 __global__ __launch_bounds__(256) void comp_moments_many_kernel(const DetGroup g, int cols, int64_t ld) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y;
     comp_moments_body(g.img[f], cols, ld, g.parent[f], g.mask[f], g.roots[f], g.st[f], g.ncomp[f], g.bg_median[f], g.xf[f], g.rec[f], nullptr,
-                      g.sel[f], g.sel[f] ? g.counters[f] + 2 : nullptr, g.recs != 0);
+                      g.sel[f], g.sel[f] ? g.counters[f] + 2 : nullptr, g.recs != 0, g.tiled ? g.mask_pitch : 0);
 }
 
 // ---- normalize_for_detection (affine.rs:24-53) ------------------------------------------------------
@@ -2479,14 +2496,14 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     const unsigned int root_cap = (unsigned int)(P / 4 + 1);
     int *parent = nullptr, *cid = nullptr, *roots = nullptr, *plist = nullptr;
     unsigned int *mask = nullptr;
-    const size_t mask_words = (size_t)P / 32 + 2, roots_words = (size_t)root_cap + 4;
+    const int mask_pitch = (int)((cols + 31) / 32 * 32);  // (the tiled labelling's; the two-pass form indexes the mask by pixel number)
+    const size_t mask_words = (size_t)rows * (size_t)(mask_pitch / 32) + 2, roots_words = (size_t)root_cap + 4;
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_PARENT, (size_t)G * P * sizeof(int), (void **)&parent));
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_CID, (size_t)G * P * sizeof(int), (void **)&cid));
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_ROOTS, (size_t)G * roots_words * sizeof(int), (void **)&roots));
-    // tile-local labelling (label_tile_many_kernel) where the planes allow it: contiguous (always, here), 16-byte aligned, width a
-    // multiple of 32; AB_LABEL_LEGACY=1 keeps the two-pass form (the GPU tests run both)
-    bool tiled = !ctx->label_legacy && (cols % 32) == 0;
-    for (int f = 0; f < G; ++f) tiled = tiled && ((uintptr_t)imgs[f] & 15) == 0;
+    // tile-local labelling (label_tile_many_kernel): contiguous planes (always, here) of any width -- the mask's rows are padded to
+    // whole words, a row's ragged last quad is loaded float by float; AB_LABEL_LEGACY=1 keeps the two-pass form (the GPU tests run both)
+    const bool tiled = !ctx->label_legacy;  // (any width, any dword alignment: round 5)
     const int64_t tiles_x = (cols + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH, ntile = tiles_x * tiles_y;
     // (tiled: the lists come in kRegions segments, each sized for the tiles that append to it)
     const size_t tiles_per_region = ((size_t)ntile + kRegions - 1) / kRegions;
@@ -2552,6 +2569,7 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     }
     AB_HIP(ctx, hipMemsetAsync(counters, 0, (size_t)G * 4 * sizeof(unsigned int), ctx->stream));
     g.tiled = tiled ? 1 : 0;
+    g.mask_pitch = mask_pitch;
     g.recs = recs ? 1 : 0;
     g.rec_stride = rec_stride;
     g.plist_stride = plist_stride;

@@ -860,8 +860,16 @@ struct TileRect {
     const float *img;
     int64_t ld;
     int y0, y1, x0, x1;
-    bool vec;  // x0, x1, ld multiples of 4 and img 16-byte aligned: rows as float4
+    bool vec;  // the tile's width is a multiple of 4: rows as four-float loads (dword-aligned is enough: global_load_dwordx4 takes any
+               // dword address; round 5 -- rows of an odd-width plane start at every alignment, and 16-byte alignment used to be required)
 };
+struct __attribute__((packed, aligned(4))) F4u {  // four floats at a dword-aligned address
+    float x, y, z, w;
+};
+__device__ __forceinline__ float4 load4u(const float *p) {
+    const F4u t = *reinterpret_cast<const F4u *>(p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 // f(raw value) for every pixel of the tile (NaN where a lane has no pixel)
 template <class F>
 __device__ __forceinline__ void stream_tile(const TileRect &r, F f) {
@@ -877,7 +885,7 @@ __device__ __forceinline__ void stream_tile(const TileRect &r, F f) {
         float4 A[U], B[U];
         auto load = [&](float4(&X)[U]) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) X[u] = *reinterpret_cast<const float4 *>(p + u * step);
+            for (int u = 0; u < U; ++u) X[u] = load4u(p + u * step);
             p += U * step;
         };
         auto eat = [&](const float4(&X)[U]) {
@@ -908,7 +916,7 @@ __device__ __forceinline__ void stream_tile(const TileRect &r, F f) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = r0 + kWaves * u;
-                raw[u] = (col_ok && row < r.y1) ? *reinterpret_cast<const float4 *>(p + (int64_t)row * r.ld)
+                raw[u] = (col_ok && row < r.y1) ? load4u(p + (int64_t)row * r.ld)
                                                 : make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             }
 #pragma unroll

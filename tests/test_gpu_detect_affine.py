@@ -470,10 +470,11 @@ def test_registration_when_the_brightest_components_are_not_stars(ctx, oracle, k
     assert np.allclose(batch[0].transform, want.transform, rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("shape", [(512, 640), (600, 800), (257, 1000), (1100, 2048)])
+@pytest.mark.parametrize("shape", [(512, 640), (600, 800), (257, 1000), (1100, 2048), (300, 1003), (515, 777)])
 def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midjoin, ctx_pixel_list, ctx_pixelwise, shape):
-    """Round 5 changed how a GROUP of frames is detected: tile-local union-find in LDS + a border pass (widths that are multiples of
-    32: 640, 800, 2048; 1000 keeps the two-pass form), approximate flux in comp_stats, the brightest 480 candidates selected on the
+    """Round 5 changed how a GROUP of frames is detected: tile-local union-find in LDS + a border pass (any width: the mask's rows are
+    padded to whole words and a row's ragged last quad is loaded float by float -- 1000, 1003 and 777 are not multiples of 32, the
+    last two not of 4 either, so their rows start at every dword alignment), approximate flux in comp_stats, the brightest 480 candidates selected on the
     device, moments for those only.  A context created under AB_LABEL_LEGACY=1 AB_DETECT_FULL_RECORDS=1 runs round 4's forms: the
     transforms, star counts and inliers of nine targets (two groups of four + one) must be IDENTICAL."""
     import torch
