@@ -1900,7 +1900,10 @@ static int launch_tile_kernels(ab_ctx *ctx, hipStream_t stream, int which, const
     }
     unsigned int *fail = nullptr;
     AB_TRY(tile_fail_buffer(ctx, which, (size_t)ntiles * (size_t)nplanes, &fail));
-    hipLaunchKernelGGL(tile_background_stream_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(ts::kThreads), 0, stream, img, (int)rows, (int)cols, ld,
+    // AB_TILE_PAD_KB (developer knob): unused dynamic LDS per tile workgroup.  Four of them take 156 of a CU's 160 KB, so no kernel that
+    // needs LDS (the tile labelling, the votes, the selection) runs beside a tile launch; any padding leaves three and 43 KB free.
+    static const unsigned int tile_pad = getenv("AB_TILE_PAD_KB") ? (unsigned int)std::min(std::max(atoi(getenv("AB_TILE_PAD_KB")), 0), 100) * 1024u : 0u;
+    hipLaunchKernelGGL(tile_background_stream_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(ts::kThreads), tile_pad, stream, img, (int)rows, (int)cols, ld,
                        step, ntx, xf, out, fd, many_planes, many_xf, fail);
     const unsigned int blocks = (unsigned int)std::min<int64_t>((int64_t)ntiles * nplanes, 256);
     hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(blocks), dim3(tb::kThreads), 0, stream, img, (int)rows, (int)cols, ld, step, ntx, xf, out, fd,
