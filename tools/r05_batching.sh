@@ -1,12 +1,12 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_detect_affine.py -m gpu -x -q --timeout=600 --timeout-method=thread -p no:cacheprovider 2>&1 | tail -2
-out=gpurun_out/r05an_pct.txt; : > $out
-for rep in 1 2 3; do
-  for cfg in "AB_NOOP=1" "AB_PCT_TWO_KERNELS=1"; do
-    env $cfg REPS=10 timeout 200 python tools/time_register.py 2>&1 | grep -v "^/opt" >> $out
-    env $cfg NOALIGN=1 REPS=10 timeout 200 python tools/time_register.py 2>&1 | grep -v "^/opt" >> $out
-  done
-done
-cut -c1-140 $out
-AB_UPLOAD_TRACE=1 REPS=1 timeout 100 python tools/time_register.py 2>&1 | grep "percentiles joined" | tail -2
+timeout 600 python bench.py > gpurun_out/r05p_bench.json 2> gpurun_out/r05p_bench.err; echo "bench rc=$?"
+timeout 1800 bash tools/profile_bench.sh r05final 5 > gpurun_out/r05p_profile.log 2>&1; echo "profile rc=$?"
+timeout 600 python bench.py > gpurun_out/r05p_bench_after.json 2> gpurun_out/r05p_bench2.err
+python - <<'PY'
+import json
+for f in ("gpurun_out/r05p_bench.json","gpurun_out/r05p_bench_after.json"):
+    d=json.loads(open(f).read().strip().split("\n")[-1]); r=d["roofline"]
+    print(f, d["ms_per_step"], d["config"]["stage_ms"], {k:r[k] for k in ("frac","frac_in_step","frac_sustained","profile_avg_ms","avg_kernel_ms","traffic")})
+PY
+grep "stack_sigma_clip" gpurun_out/prof_r05final/r05final_kernel_stats.txt | cut -c1-60,88-140
