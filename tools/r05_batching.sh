@@ -1,9 +1,9 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_stack.py tests/test_gpu_extras.py -m gpu -x -q --timeout=900 --timeout-method=thread -p no:cacheprovider > gpurun_out/r05ar_tests.txt 2>&1; tail -5 gpurun_out/r05ar_tests.txt | cut -c1-300
-out=gpurun_out/r05ar_quad.txt; : > $out
-for cfg in "AB_NOOP=1" "AB_STACK_PAIR=1"; do
-  echo "## $cfg" >> $out
-  env $cfg N_LIST=257,320,400,512 timeout 600 python tools/time_stack_deep.py 2>&1 | grep -v "^/opt" >> $out
+out=gpurun_out/r05as_group.txt; : > $out
+for rep in 1 2; do
+  for cfg in "AB_NOOP=1" "AB_REGISTER_GROUP=5" "AB_REGISTER_GROUP=6" "AB_REGISTER_GROUP=6 AB_TILE_CHUNK=6" "AB_REGISTER_GROUP=3 AB_REGISTER_WORKERS=21" "AB_REGISTER_GROUP=8 AB_TILE_CHUNK=8"; do
+    env $cfg REPS=10 timeout 200 python tools/time_register.py 2>&1 | grep -v "^/opt" >> $out
+  done
 done
-cat $out
+cut -c1-150 $out
