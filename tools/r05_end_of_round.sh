@@ -2,26 +2,25 @@
 # developer job: the round's end figures -- bench + rocprofv3 summaries, the other configurations, the multi-rank code paths
 mkdir -p gpurun_out
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-timeout 600 python bench.py > gpurun_out/r05n_bench.json 2> gpurun_out/r05n_bench.err; echo "bench rc=$?" > gpurun_out/r05n_rc.txt
-timeout 1800 bash tools/profile_bench.sh r05final 5 > gpurun_out/r05n_profile.log 2>&1; echo "profile rc=$?" >> gpurun_out/r05n_rc.txt
+timeout 600 python bench.py > gpurun_out/r05z_bench.json 2> gpurun_out/r05z_bench.err; echo "bench rc=$?" > gpurun_out/r05z_rc.txt
 for c in C1 C3 C5; do
-  timeout 900 python bench.py --config $c > gpurun_out/r05n_bench_$c.json 2> gpurun_out/r05n_bench_$c.err; echo "$c rc=$?" >> gpurun_out/r05n_rc.txt
+  timeout 900 python bench.py --config $c > gpurun_out/r05z_bench_$c.json 2> gpurun_out/r05z_bench_$c.err; echo "$c rc=$?" >> gpurun_out/r05z_rc.txt
 done
-timeout 600 python bench.py --force-sharded --no-cpu-baseline > gpurun_out/r05n_bench_sharded.json 2> gpurun_out/r05n_sharded.err; echo "sharded rc=$?" >> gpurun_out/r05n_rc.txt
-timeout 600 python bench.py --force-sharded --mode rowband --no-cpu-baseline > gpurun_out/r05n_bench_rowband.json 2> gpurun_out/r05n_rowband.err; echo "rowband rc=$?" >> gpurun_out/r05n_rc.txt
+timeout 600 python bench.py --force-sharded --no-cpu-baseline > gpurun_out/r05z_bench_sharded.json 2> gpurun_out/r05z_sharded.err; echo "sharded rc=$?" >> gpurun_out/r05z_rc.txt
+timeout 600 python bench.py --force-sharded --mode rowband --no-cpu-baseline > gpurun_out/r05z_bench_rowband.json 2> gpurun_out/r05z_rowband.err; echo "rowband rc=$?" >> gpurun_out/r05z_rc.txt
 for m in frames rowband; do
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 8 --host-staged --mode $m --steps 3 --warmup 1 --no-cpu-baseline \
-     > gpurun_out/r05n_bench_hoststaged_8ranks_$m.json 2> gpurun_out/r05n_hoststaged_$m.err; echo "hoststaged $m rc=$?" >> gpurun_out/r05n_rc.txt
+     > gpurun_out/r05z_bench_hoststaged_8ranks_$m.json 2> gpurun_out/r05z_hoststaged_$m.err; echo "hoststaged $m rc=$?" >> gpurun_out/r05z_rc.txt
 done
-timeout 600 python bench.py --host-planes --no-cpu-baseline > gpurun_out/r05n_bench_host_planes.json 2> gpurun_out/r05n_host_planes.err; echo "host planes rc=$?" >> gpurun_out/r05n_rc.txt
-cat gpurun_out/r05n_rc.txt
+timeout 600 python bench.py --host-planes --no-cpu-baseline > gpurun_out/r05z_bench_host_planes.json 2> gpurun_out/r05z_host_planes.err; echo "host planes rc=$?" >> gpurun_out/r05z_rc.txt
+cat gpurun_out/r05z_rc.txt
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r05n_bench*.json")):
+for f in sorted(glob.glob("gpurun_out/r05z_bench*.json")):
     try:
         d = json.loads(open(f).read().strip().split("\n")[-1])
         print(f, d["ms_per_step"], d.get("roofline", {}).get("frac"), d["config"].get("stage_ms"), d["config"].get("rowband_ingest", ""))
     except Exception as e:
         print(f, "ERR", e)
 PY
-tail -3 gpurun_out/r05n_hoststaged_rowband.err
+tail -3 gpurun_out/r05z_hoststaged_rowband.err
