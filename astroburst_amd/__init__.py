@@ -4,7 +4,7 @@ The product is astroburst_amd/libastroburst_hip.so (hand-written HIP behind the 
 include/astroburst_hip.h).  `core` mirrors the reference's `core::*` Rust functions over that
 ABI for tests and benchmarks; `synth` makes deterministic synthetic frame stacks.
 """
-from ._lib import AstroBurstError, LIB_PATH, build, declared_symbols  # noqa: F401
+from ._lib import AstroBurstError, LIB_PATH, build, declared_symbols, is_dev_build, version  # noqa: F401
 from .core import Comm, Context, ImageStats, StackResult, StfParams  # noqa: F401
 
 __version__ = "0.2.0"

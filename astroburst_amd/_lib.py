@@ -192,6 +192,16 @@ def declared_symbols() -> list[str]:
 _lib = None
 
 
+def version() -> str:
+    return lib().ab_version().decode()
+
+
+def is_dev_build() -> bool:
+    """True when the loaded library was built with -DAB_DEV_ABLATION (`make -C astroburst_amd/csrc dev`, selected through AB_LIB_PATH):
+    only then are the developer switches of ab_dev_env() (superseded forms, sweep knobs, fault injection) live."""
+    return lib().ab_version().decode().endswith("+dev")
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
@@ -344,6 +354,7 @@ def lib() -> C.CDLL:
     L.ab_comm_allgather.argtypes = [vp, vp, vp, vp, C.c_size_t]
     L.ab_comm_broadcast.argtypes = [vp, vp, vp, C.c_size_t, C.c_int]
     L.ab_ctx_trim.argtypes = [vp]
+    L.ab_ctx_fallback_counts.argtypes = [vp, C.POINTER(C.c_uint64), C.c_size_t, C.c_int]
     L.ab_shard_rows.argtypes = [C.c_int64, C.c_int, C.c_int, i64p, i64p]
     L.ab_shard_frames.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ab_stack_sigma_clip_rows.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), C.c_int64, pp, u64p]

@@ -328,6 +328,16 @@ class Context:
         """release the device memory the context has grown (workspaces, scratch, host-frame staging); it stays usable"""
         self._check(self._L.ab_ctx_trim(self._h))
 
+    FALLBACK_KINDS = ("frames_redone", "tile_slots", "component_table", "selection_short", "selection_cut", "tiles_declined",
+                      "stats_chain", "stack_general_pixels")   # ab_fallback_kind, include/astroburst_hip.h
+
+    def fallback_counts(self, reset: bool = False) -> dict:
+        """How often a fast path handed over to its exact fallback (same results, more time) since the context was created or last
+        reset -- frame workers included (ab_ctx_fallback_counts)."""
+        out = (C.c_uint64 * len(self.FALLBACK_KINDS))()
+        self._check(self._L.ab_ctx_fallback_counts(self._h, out, len(self.FALLBACK_KINDS), 1 if reset else 0))
+        return dict(zip(self.FALLBACK_KINDS, (int(v) for v in out)))
+
     def device_info(self):
         name = C.create_string_buffer(256)
         cu, mem = C.c_int(), C.c_uint64()

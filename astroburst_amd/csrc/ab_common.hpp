@@ -136,7 +136,7 @@ struct ab_ctx {
     // inherited by its workers): two-pass labelling instead of the tile-local union-find; every component's record instead of the
     // device-side selection of the brightest
     bool label_legacy = false, label_pixelwise = false, detect_no_recs = false, detect_full_records = false, detect_midjoin = false;
-    uint64_t det_select_fallbacks = 0;  // detect.hip: frames whose device-side selection of the brightest components had to be redone in full
+    std::atomic<uint64_t> fallbacks[AB_FB_COUNT] = {};  // ab_ctx_fallback_counts: kept in the ROOT context (a worker's events are added to its parent's)
     unsigned int *tile_fail[2] = {nullptr, nullptr};
     size_t tile_fail_cap[2] = {0, 0};
     // progress / cancel (infra/progress.rs:39-74): the callback is serialised by progress_mu (frame workers tick it too);
@@ -163,13 +163,36 @@ int ab_progress(ab_ctx *ctx, const char *stage, uint64_t current, uint64_t total
 
 int ab_set_error(ab_ctx *ctx, int code, const char *fmt, ...);
 
+// ---- environment -------------------------------------------------------------------------------------------------------------------
+// The RELEASE library reads eight environment variables -- AB_TRACE, AB_STACK_EXACT, AB_STATS_CHAIN, AB_REGISTER_WORKERS,
+// AB_STACK_DEEP_FROM, AB_BATCH_DEEP_FROM, AB_COMM_TIMEOUT_MS, AB_COMM_HOST_SLOT_MB: the list in include/astroburst_hip.h
+// ("Environment") and INTEGRATION.md -- through ab_env().  Every other switch (superseded forms kept as cross-checks, sweep knobs,
+// fault injection, stage cuts) goes through ab_dev_env(), which answers "unset" unless the library was built with -DAB_DEV_ABLATION
+// (`make dev` -> libastroburst_hip_dev.so): a drop-in for a desktop application must not change its numerics path with variables
+// nobody documented.  tests/test_abi_cpu.py scans the release library's strings for any other AB_* name.
+static inline const char *ab_env(const char *name) { return getenv(name); }
+#ifdef AB_DEV_ABLATION
+static inline const char *ab_dev_env(const char *name) { return getenv(name); }
+#define AB_DEV_NAME(s) s
+#else
+static inline const char *ab_dev_env(const char *) { return nullptr; }
+#define AB_DEV_NAME(s) nullptr  // (a developer variable's NAME handed to a helper: not even the string reaches the release library)
+#endif
+
+// one more event of a fallback kind (include/astroburst_hip.h: ab_fallback_kind), counted in the root context
+static inline void ab_count_fallback(ab_ctx *ctx, int kind, uint64_t n = 1) {
+    if (!ctx || kind < 0 || kind >= AB_FB_COUNT || n == 0) return;
+    while (ctx->parent) ctx = ctx->parent;
+    ctx->fallbacks[kind].fetch_add(n, std::memory_order_relaxed);
+}
+
 // AB_UPLOAD_TRACE=1 (developer knob): a timeline of a host-fed registration call on stderr, milliseconds since the call began
 inline std::chrono::steady_clock::time_point &ab_trace_t0() {
     static std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     return t;
 }
 inline bool ab_upload_trace_on() {
-    static const bool on = getenv("AB_UPLOAD_TRACE") != nullptr;
+    static const bool on = ab_dev_env("AB_UPLOAD_TRACE") != nullptr;
     return on;
 }
 inline void ab_upload_trace(const char *what, long a, long b = -1) {
@@ -185,10 +208,10 @@ inline void ab_upload_trace(const char *what, long a, long b = -1) {
 // a stream that holds long-running or long-waiting packets (the tile kernels, the upload's copy barriers) no longer stands in
 // front of a quarter of the worker streams' kernels.
 inline hipError_t ab_stream_create_masked(ab_ctx *ctx, hipStream_t *out, const char *env, const char *prio_env = nullptr, int prio_default = 0) {
-    const char *v = env ? getenv(env) : nullptr;
+    const char *v = env ? ab_dev_env(env) : nullptr;
     const uint32_t pat = v ? (uint32_t)strtoul(v, nullptr, 16) : 0u;
     if (pat == 0u || pat == 0xffffffffu) {
-        const char *pv = prio_env ? getenv(prio_env) : nullptr;
+        const char *pv = prio_env ? ab_dev_env(prio_env) : nullptr;
         int prio = pv ? atoi(pv) : prio_default;
         if (prio == 0) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
         int least = 0, greatest = 0;  // (numerically: greatest priority <= least priority)
@@ -360,7 +383,7 @@ static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b
 struct ab_trace {
     bool on;
     std::chrono::steady_clock::time_point t0;
-    explicit ab_trace(const char *what) : on(getenv("AB_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {
+    explicit ab_trace(const char *what) : on(ab_env("AB_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {
         if (on) fprintf(stderr, "[ab_trace] %s:", what);
     }
     void mark(const char *stage) {

@@ -92,7 +92,12 @@ int ab_ctx_clear_cancel(ab_ctx *ctx) try {
     return AB_OK;
 } AB_CATCH(ctx)
 
-const char *ab_version(void) { return "astroburst_hip 0.2.0 (gfx950)"; }
+// "+dev": built with -DAB_DEV_ABLATION (`make dev`): the developer switches of ab_dev_env() are live
+#ifdef AB_DEV_ABLATION
+const char *ab_version(void) { return "astroburst_hip 0.3.0 (gfx950) +dev"; }
+#else
+const char *ab_version(void) { return "astroburst_hip 0.3.0 (gfx950)"; }
+#endif
 
 int ab_ctx_create(int device_id, ab_ctx **out) try {
     if (!out) return AB_ERR_INVALID;
@@ -121,16 +126,16 @@ int ab_ctx_create(int device_id, ab_ctx **out) try {
         return AB_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    const char *ex = getenv("AB_STACK_EXACT");
+    const char *ex = ab_env("AB_STACK_EXACT");
     ctx->stack_exact = ex && ex[0] == '1';
-    ctx->label_legacy = getenv("AB_LABEL_LEGACY") != nullptr;
-    ctx->label_pixelwise = getenv("AB_LABEL_PIXELWISE") != nullptr;
-    ctx->detect_no_recs = getenv("AB_DETECT_NO_RECS") != nullptr;
-    ctx->detect_full_records = getenv("AB_DETECT_FULL_RECORDS") != nullptr;
-    ctx->detect_midjoin = getenv("AB_DETECT_MIDJOIN") != nullptr;
-    if (const char *e = getenv("AB_STACK_DEEP_FROM")) ctx->stack_deep_from = std::min(4096, std::max(64, atoi(e)));
-    if (const char *e = getenv("AB_BATCH_DEEP_FROM")) ctx->batch_deep_from = std::min(2048, std::max(64, atoi(e)));
-    if (const char *rw = getenv("AB_REGISTER_WORKERS")) ctx->register_workers = std::max(1, atoi(rw));
+    ctx->label_legacy = ab_dev_env("AB_LABEL_LEGACY") != nullptr;
+    ctx->label_pixelwise = ab_dev_env("AB_LABEL_PIXELWISE") != nullptr;
+    ctx->detect_no_recs = ab_dev_env("AB_DETECT_NO_RECS") != nullptr;
+    ctx->detect_full_records = ab_dev_env("AB_DETECT_FULL_RECORDS") != nullptr;
+    ctx->detect_midjoin = ab_dev_env("AB_DETECT_MIDJOIN") != nullptr;
+    if (const char *e = ab_env("AB_STACK_DEEP_FROM")) ctx->stack_deep_from = std::min(4096, std::max(64, atoi(e)));
+    if (const char *e = ab_env("AB_BATCH_DEEP_FROM")) ctx->batch_deep_from = std::min(2048, std::max(64, atoi(e)));
+    if (const char *rw = ab_env("AB_REGISTER_WORKERS")) ctx->register_workers = std::max(1, atoi(rw));
     *out = ctx;
     return AB_OK;
 } AB_CATCH_NOCTX
@@ -175,19 +180,55 @@ int ab_ctx_trim(ab_ctx *ctx) try {
     AB_HIP(ctx, hipSetDevice(ctx->device));
     for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->pct_stream, ctx->warp_stream, ctx->upload_stream})
         if (st || st == ctx->stream) AB_HIP(ctx, hipStreamSynchronize(st));
-    for (ab_ctx *w : ctx->workers) AB_TRY(ab_ctx_trim(w));
-    if (ctx->scratch) AB_HIP(ctx, hipFree(ctx->scratch));
-    ctx->scratch = nullptr;
-    ctx->scratch_bytes = 0;
-    for (int i = 0; i < AB_WS_SLOTS; ++i) {
-        if (ctx->ws[i]) AB_HIP(ctx, hipFree(ctx->ws[i]));
-        ctx->ws[i] = nullptr;
-        ctx->ws_bytes[i] = 0;
+    // Every buffer is forgotten BEFORE its release is checked and every slot is visited whatever an earlier release returned
+    // (an early return left dangling pointers and untrimmed slots); the first failure is what the call reports, with
+    // its message in THIS context (a worker's own error text lives in the worker).
+    int first_rc = AB_OK;
+    std::string first_msg;
+    auto note = [&](hipError_t e, const char *what) {
+        if (e == hipSuccess || first_rc != AB_OK) return;
+        first_rc = AB_ERR_HIP;
+        first_msg = std::string(what) + " failed: " + hipGetErrorString(e);
+    };
+    auto drop = [&](void *&p, size_t &bytes, bool host, const char *what) {
+        void *q = p;
+        p = nullptr;
+        bytes = 0;
+        if (q) note(host ? hipHostFree(q) : hipFree(q), what);
+    };
+    for (ab_ctx *w : ctx->workers) {
+        const int rc = ab_ctx_trim(w);
+        if (rc != AB_OK && first_rc == AB_OK) {
+            first_rc = rc;
+            first_msg = std::string("worker context: ") + ab_last_error(w);
+        }
     }
+    drop(ctx->scratch, ctx->scratch_bytes, false, "hipFree(scratch)");
+    for (int i = 0; i < AB_WS_SLOTS; ++i) drop(ctx->ws[i], ctx->ws_bytes[i], false, "hipFree(workspace)");
     ctx->pc_tab_ws = nullptr;  // (phase_corr.hip rebuilds its tables when the workspace pointer changes)
-    if (ctx->upload_buf) AB_HIP(ctx, hipFree(ctx->upload_buf));
-    ctx->upload_buf = nullptr;
-    ctx->upload_bytes = 0;
+    ctx->stats_bar = nullptr;  // (stats.hip clears the resident kernel's barrier flags when its workspace is new)
+    drop(ctx->upload_buf, ctx->upload_bytes, false, "hipFree(upload_buf)");
+    // the pinned read-back buffers (they grow with the frame-group size: G * kSelCap selection records) and the declined-tile lists
+    drop(ctx->pinned, ctx->pinned_bytes, true, "hipHostFree(pinned)");
+    drop(ctx->aux_pinned, ctx->aux_pinned_bytes, true, "hipHostFree(aux_pinned)");
+    for (int i = 0; i < 2; ++i) {
+        void *p = ctx->tile_fail[i];
+        size_t cap = 0;
+        ctx->tile_fail[i] = nullptr;
+        ctx->tile_fail_cap[i] = 0;
+        drop(p, cap, false, "hipFree(tile_fail)");
+    }
+    if (first_rc != AB_OK) return ab_set_error(ctx, first_rc, "ab_ctx_trim: %s", first_msg.c_str());
+    return AB_OK;
+} AB_CATCH(ctx)
+
+int ab_ctx_fallback_counts(ab_ctx *ctx, uint64_t *out, size_t cap, int reset) try {
+    if (!ctx || (!out && cap)) return AB_ERR_INVALID;
+    while (ctx->parent) ctx = ctx->parent;
+    for (size_t k = 0; k < (size_t)AB_FB_COUNT; ++k) {
+        const uint64_t v = reset ? ctx->fallbacks[k].exchange(0, std::memory_order_relaxed) : ctx->fallbacks[k].load(std::memory_order_relaxed);
+        if (k < cap) out[k] = v;
+    }
     return AB_OK;
 } AB_CATCH(ctx)
 

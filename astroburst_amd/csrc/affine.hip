@@ -619,7 +619,7 @@ constexpr int kVoteBlocks = 1024;
 constexpr int kVoteCopiesMax = 16;
 int vote_copies() {
     static const int c = [] {
-        const char *e = getenv("AB_VOTE_COPIES");
+        const char *e = ab_dev_env("AB_VOTE_COPIES");
         const int v = e ? atoi(e) : 4;
         return v < 1 ? 1 : (v > kVoteCopiesMax ? kVoteCopiesMax : v);
     }();
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(kVoteWaves * 64) void tri_vote_wide_many_kernel(con
 }
 unsigned int vote_wide_slices() {  // slices of a reference group's candidate range in the wide form (AB_VOTE_SLICES)
     static const unsigned int v = [] {
-        const char *e = getenv("AB_VOTE_SLICES");
+        const char *e = ab_dev_env("AB_VOTE_SLICES");
         const int x = e ? atoi(e) : 8;  // (8 / 4 / 2 / 1 measured: 9.4 / 9.6 / 9.6 / 10.0 ms for the stage)
         return (unsigned int)(x < 1 ? 1 : (x > 8 ? 8 : x));
     }();
@@ -777,7 +777,7 @@ unsigned int vote_wide_slices() {  // slices of a reference group's candidate ra
 }
 bool vote_wide() {
     static const bool on = [] {
-        const char *e = getenv("AB_VOTE_WAVES");
+        const char *e = ab_dev_env("AB_VOTE_WAVES");
         return !(e && atoi(e) == 1);
     }();
     return on;
@@ -1159,11 +1159,11 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     // before the first tile launch.  Device-resident frames keep the percentiles of all frames up front (two launches + a join):
     // measured on the bench stack, same box, 12.99 ms for the stage against 13.34 fed (sixteen more launches in the tile stream's
     // way).  AB_PIPE_FED=1 feeds them too (the GPU tests hold the two orders to the same transforms).
-    static const bool force_fed = getenv("AB_PIPE_FED") != nullptr;
+    static const bool force_fed = ab_dev_env("AB_PIPE_FED") != nullptr;
     const bool fed = have_xf && (landed != nullptr || force_fed);
     if (fed) {
-        static const int chunk = getenv("AB_TILE_CHUNK") ? std::max(atoi(getenv("AB_TILE_CHUNK")), 1) : 8;
-        static const int fed_chunk = getenv("AB_FEED_CHUNK") ? std::max(atoi(getenv("AB_FEED_CHUNK")), 1) : 4;  // frames per launch while frames are still arriving
+        static const int chunk = ab_dev_env("AB_TILE_CHUNK") ? std::max(atoi(ab_dev_env("AB_TILE_CHUNK")), 1) : 8;
+        static const int fed_chunk = ab_dev_env("AB_FEED_CHUNK") ? std::max(atoi(ab_dev_env("AB_FEED_CHUNK")), 1) : 4;  // frames per launch while frames are still arriving
         std::vector<const float *> order;  // reference first
         std::vector<hipEvent_t> ev;
         order.push_back(ref);
@@ -1187,7 +1187,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         ab_upload_trace("percentiles joined, planes", (long)(n + 1));
         // ... and their background tiles: the tile kernel runs on its own stream, a few frames per launch, the reference first,
         // while the workers already label the frames whose tiles are done (register_one blocks on its frame's chunk)
-        static const int chunk = getenv("AB_TILE_CHUNK") ? atoi(getenv("AB_TILE_CHUNK")) : 8;  // frames per launch (0: every frame's tiles in its own chain); measured 0 / 2 / 4 / 8 / 16 -> 17.6 / 17.5 / 17.2 / 17.0 / 17.4 ms for the stage
+        static const int chunk = ab_dev_env("AB_TILE_CHUNK") ? atoi(ab_dev_env("AB_TILE_CHUNK")) : 8;  // frames per launch (0: every frame's tiles in its own chain); measured 0 / 2 / 4 / 8 / 16 -> 17.6 / 17.5 / 17.2 / 17.0 / 17.4 ms for the stage
         if (chunk > 0) {
             std::vector<const float *> order;  // reference first
             std::vector<ab_pixel_xf> oxf;
@@ -1233,7 +1233,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     // Round 4: the targets go through detection and matching in GROUPS of kGroup (AB_REGISTER_GROUP, default 4; 1 = frame by frame as
     // in rounds 2 / 3): the stage was bound by the number of launches the four hardware queues serialise, not by their work.
     static const int kGroup = [] {
-        const char *e = getenv("AB_REGISTER_GROUP");
+        const char *e = ab_dev_env("AB_REGISTER_GROUP");
         const int v = e ? atoi(e) : 4;
         return v < 1 ? 1 : (v > kTriGroupMax ? kTriGroupMax : v);
     }();
@@ -1262,9 +1262,12 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     const size_t n_jobs = grouped ? n_groups : n;
     const std::function<int(ab_ctx *, size_t)> job = grouped ? std::function<int(ab_ctx *, size_t)>(one_group) : std::function<int(ab_ctx *, size_t)>(one);
     const bool inline_run = std::min<size_t>(n_jobs, (size_t)std::max(ctx->register_workers, 1)) <= 1;
-    static const bool own_warp_stream = getenv("AB_NO_WARP_STREAM") == nullptr;
+    static const bool own_warp_stream = ab_dev_env("AB_NO_WARP_STREAM") == nullptr;
     if (!inline_run && aligned && own_warp_stream) {
-        if (!ctx->warp_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->warp_stream, "AB_WARP_CU_MASK", "AB_WARP_PRIO", 0));
+        if (!ctx->warp_stream) {
+        const hipError_t stream_rc = ab_stream_create_masked(ctx, &ctx->warp_stream, AB_DEV_NAME("AB_WARP_CU_MASK"), AB_DEV_NAME("AB_WARP_PRIO"), 0);  // (outside AB_HIP: its message would carry the developer variables' names)
+        AB_HIP(ctx, stream_rc);
+    }
         warp_stream = ctx->warp_stream;
     }
     if (inline_run) {  // the reference first, on ctx
@@ -1381,7 +1384,10 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
     }
     // (a queue of its own pool: 63 copies are enqueued up front, each a barrier packet that waits for its DMA -- on a queue shared
     // with worker streams they held a quarter of the groups back until the LAST frame had landed: measured, 8 ms after the last byte)
-    if (!ctx->upload_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->upload_stream, nullptr, "AB_UPLOAD_PRIO", 1));
+    if (!ctx->upload_stream) {
+        const hipError_t stream_rc = ab_stream_create_masked(ctx, &ctx->upload_stream, nullptr, AB_DEV_NAME("AB_UPLOAD_PRIO"), 1);  // (outside AB_HIP: its message would carry the developer variables' names)
+        AB_HIP(ctx, stream_rc);
+    }
     while (ctx->upload_events.size() < slots) {
         hipEvent_t e;
         AB_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1402,7 +1408,7 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
         ++slot;
     }
     // AB_UPLOAD_TRACE=1 (developer knob): how long the copies took under the registration's load, and what was left after the last
-    static const bool up_trace = getenv("AB_UPLOAD_TRACE") != nullptr;
+    static const bool up_trace = ab_dev_env("AB_UPLOAD_TRACE") != nullptr;
     hipEvent_t tr0 = nullptr, tr1 = nullptr;
     const auto t_call = std::chrono::steady_clock::now();
     ab_trace_t0() = t_call;

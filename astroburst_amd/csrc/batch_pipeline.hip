@@ -97,7 +97,7 @@ bool retain_thresholds(BatchArgs *a) {
     auto usable = [](float v) { return std::isfinite(v) && std::fabs(v) >= 1e-30f && std::fabs(v) <= 1e30f; };
     a->retain_fast = 0;
     a->mid_lo = a->mid_hi = 0.0;
-    if (!usable(nsl) || !usable(sh) || getenv("AB_BATCH_DIVIDE")) return false;
+    if (!usable(nsl) || !usable(sh) || ab_dev_env("AB_BATCH_DIVIDE")) return false;
     a->mid_hi = ((double)std::nextafterf(sh, -INFINITY) + (double)sh) * 0.5;
     a->mid_lo = ((double)nsl + (double)std::nextafterf(nsl, INFINITY)) * 0.5;
     a->retain_fast = 1;
@@ -836,9 +836,9 @@ int launch_scms_np(ab_ctx *ctx, const BatchArgs &a, int64_t nchunks, uint32_t **
     AB_TRY(ab_workspace(ctx, AB_WS_BATCH_REJ, ((size_t)waves + 2) * kMaxFrames * sizeof(unsigned long long), &rej));
     BatchArgs b = a;
     retain_thresholds(&b);
-    b.guess_step = getenv("AB_BATCH_GUESS") ? atoi(getenv("AB_BATCH_GUESS")) : 1;
+    b.guess_step = ab_dev_env("AB_BATCH_GUESS") ? atoi(ab_dev_env("AB_BATCH_GUESS")) : 1;
 #ifdef AB_DEV_ABLATION  // (stage cuts for tools/time_batch.py: only in a -DAB_DEV_ABLATION build)
-    b.stage = getenv("AB_BATCH_STAGE") ? atoi(getenv("AB_BATCH_STAGE")) : 0;
+    b.stage = ab_dev_env("AB_BATCH_STAGE") ? atoi(ab_dev_env("AB_BATCH_STAGE")) : 0;
 #else
     b.stage = 0;
 #endif

@@ -174,7 +174,7 @@ uint64_t own_pidns() {
 // that share /dev/shm see each other's pids as nonexistent, so across namespaces the answer is "cannot tell" = alive, and a dead
 // job's segment is then caught by the join time-out instead (AB_COMM_HOST_PIDCHECK=0 forces that behaviour everywhere).
 bool owner_is_dead(const HostShm *h) {
-    static const bool check = [] { const char *e = getenv("AB_COMM_HOST_PIDCHECK"); return !(e && *e == '0'); }();
+    static const bool check = [] { const char *e = ab_dev_env("AB_COMM_HOST_PIDCHECK"); return !(e && *e == '0'); }();
     if (!check) return false;
     if (h->owner_pid <= 0) return true;
     const uint64_t ns = own_pidns();
@@ -185,7 +185,7 @@ bool owner_is_dead(const HostShm *h) {
 }
 
 int64_t default_timeout_ms() {
-    const char *e = getenv("AB_COMM_TIMEOUT_MS");
+    const char *e = ab_env("AB_COMM_TIMEOUT_MS");
     const long long v = e ? atoll(e) : 300000;
     return v > 0 ? (int64_t)v : 300000;
 }
@@ -440,7 +440,7 @@ int ab_comm_init_rank_host(ab_ctx *ctx, const char *name, int nranks, int rank, 
     AB_CHECK(ctx, strlen(name) < 200 && !strchr(name, '/'), "communicator name must be a short string without '/'");
     *out = nullptr;
     AB_HIP(ctx, hipSetDevice(ctx->device));
-    const char *se = getenv("AB_COMM_HOST_SLOT_MB");
+    const char *se = ab_env("AB_COMM_HOST_SLOT_MB");
     const long long slot_mb = se ? atoll(se) : 4;
     const size_t slot = (size_t)(slot_mb >= 1 && slot_mb <= 1024 ? slot_mb : 4) << 20;
     const size_t bytes = kShmHeader + (size_t)nranks * slot;

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(co
             o.median = r.median;
             o.sigma = r.sigma;
             o.valid = r.valid;
-            o.pad = 0;
+            o.pad = fail ? 1 : 0;  // (1: a tile the streaming kernel declined -- the host counts them, AB_FB_TILES_DECLINED)
             out[tile] = o;
         }
         __syncthreads();  // (the next tile reuses the shared block)
@@ -1250,6 +1250,22 @@ struct DetGroup {
     unsigned int *selout[kGroupMax];  // PINNED HOST: {selected, candidates} of the frame
 };
 
+// The selection cuts on CompStat::flux -- an f64 sum whose order of additions varies from run to run -- while finish_stars ranks by the
+// moments kernel's exact sum: a candidate just below the cut may hold a larger exact flux than a selected one.  The two
+// sums differ by a few ulp(f64); a key step (the high word of the f64) is 2^-20 of the flux.  So: when the list was cut
+// (candidates > selected) and the faintest star that was KEPT lies within two key steps of the cut, what was left out might have
+// been ranked before it and the frame is redone through the full path.  A kept star clear of the cut by two steps is brighter,
+// exactly, than everything left out.  (Registration frames: the 120th star is ~4x brighter than the 480th candidate.)
+static inline bool selection_cut_too_close(const std::vector<ab_detected_star> &stars, size_t max_keep, unsigned int selected, unsigned int candidates,
+                                           unsigned int cut_key) {
+    if (candidates <= selected || cut_key == 0 || stars.empty() || stars.size() < max_keep) return false;  // (fewer than max_keep: redone anyway)
+    unsigned long long bits;
+    const double fl = stars.back().flux;
+    memcpy(&bits, &fl, sizeof bits);
+    const unsigned long long key = (bits >> 32) + 1ull;
+    return key < (unsigned long long)cut_key + 2ull;
+}
+
 // ---- the brightest few hundred, chosen on the device ----------------------------------------------------------
 // The matcher takes the first 120 stars of the flux-ordered, 3 px-deduplicated list (affine.rs:272-277 after star_detection.rs:
 // 215-248); a 4096^2 frame has ~10 000 components.  finish_stars already orders only the brightest 4 x 120 candidates first because
@@ -1418,6 +1434,9 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
     });
     __syncthreads();
     const unsigned int nsub = s_nsub;
+    // the smallest key the selection admits (selout[3]): whatever was left out has an APPROXIMATE key below it.  0: nothing was left out
+    constexpr unsigned int kDigitBase = (unsigned int)((1023 - 64) << 20);
+    unsigned int cut_key = all ? 0u : (take_bin ? (d0 ? kDigitBase + (d0 << 16) : 1u) : kDigitBase + ((d0 + 1u) << 16));
     if (!all && !take_bin && nsub <= (unsigned int)kSelSub) {  // block-uniform: resolve the remaining 21 bits inside bin d0, in LDS
         const unsigned int want0 = kSelKeep - above;  // >= 1: the kSelKeep-th brightest lies in bin d0
         const unsigned int strips = (nsub + kSelThreads - 1) / kSelThreads;
@@ -1454,6 +1473,7 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
         if ((tid & 63) == 0 && ge) atomicAdd(&s_ge, ge);
         __syncthreads();
         if (above + s_ge > kSelCap) thr += 1;  // a crowd of equal keys at the cut: take what is strictly brighter (fewer than kSelKeep)
+        cut_key = thr;
         for (unsigned int j = tid; j < nsub; j += kSelThreads) {
             if (sub_key[j] >= thr) {
                 const unsigned int at = atomicAdd(&s_count, 1u);
@@ -1466,6 +1486,7 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
         const unsigned int m = min(s_count, kSelCap);
         g.counters[f][2] = m;
         g.selout[f][0] = m;
+        g.selout[f][3] = cut_key;
         g.selout[f][1] = s_count > kSelCap ? 0xffffffffu : ncand;  // (cannot happen: the cuts above keep it below kSelCap; kept as a loud fallback)
     }
 }
@@ -1892,7 +1913,7 @@ static int tile_fail_buffer(ab_ctx *ctx, int which, size_t tiles, unsigned int *
 static int launch_tile_kernels(ab_ctx *ctx, hipStream_t stream, int which, const float *img, int64_t rows, int64_t cols, int64_t ld, int step, int ntx,
                                int ntiles, int nplanes, const ab_pixel_xf &xf, TileOut *out, const FrameDev *fd, const float *const *many_planes,
                                const ab_pixel_xf *many_xf) {
-    static const bool resident = getenv("AB_TILE_RESIDENT") != nullptr;
+    static const bool resident = ab_dev_env("AB_TILE_RESIDENT") != nullptr;
     if (resident) {
         hipLaunchKernelGGL(tile_background_bucket_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(tb::kThreads), 0, stream, img, (int)rows, (int)cols,
                            ld, step, ntx, xf, out, fd, many_planes, many_xf, (unsigned int *)nullptr, 0);
@@ -1902,7 +1923,7 @@ static int launch_tile_kernels(ab_ctx *ctx, hipStream_t stream, int which, const
     AB_TRY(tile_fail_buffer(ctx, which, (size_t)ntiles * (size_t)nplanes, &fail));
     // AB_TILE_PAD_KB (developer knob): unused dynamic LDS per tile workgroup.  Four of them take 156 of a CU's 160 KB, so no kernel that
     // needs LDS (the tile labelling, the votes, the selection) runs beside a tile launch; any padding leaves three and 43 KB free.
-    static const unsigned int tile_pad = getenv("AB_TILE_PAD_KB") ? (unsigned int)std::min(std::max(atoi(getenv("AB_TILE_PAD_KB")), 0), 100) * 1024u : 0u;
+    static const unsigned int tile_pad = ab_dev_env("AB_TILE_PAD_KB") ? (unsigned int)std::min(std::max(atoi(ab_dev_env("AB_TILE_PAD_KB")), 0), 100) * 1024u : 0u;
     hipLaunchKernelGGL(tile_background_stream_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(ts::kThreads), tile_pad, stream, img, (int)rows, (int)cols, ld,
                        step, ntx, xf, out, fd, many_planes, many_xf, fail);
     const unsigned int blocks = (unsigned int)std::min<int64_t>((int64_t)ntiles * nplanes, 256);
@@ -1924,7 +1945,7 @@ static int tile_stats_host(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     // through the runtime's staging pages for a pageable destination, just the stream sync
     void *pin = nullptr;
     AB_TRY(ab_pinned(ctx, (size_t)ntiles * sizeof(TileOut), &pin));
-    static const bool legacy = getenv("AB_TILE_LEGACY") != nullptr;
+    static const bool legacy = ab_dev_env("AB_TILE_LEGACY") != nullptr;
     if (legacy)
         hipLaunchKernelGGL(tile_background_kernel, dim3(ntiles), dim3(absel::kBlock), 0, ctx->stream, img, (int)rows, (int)cols, ld, step,
                            ntx, xf, (TileOut *)pin);
@@ -1938,8 +1959,11 @@ static int tile_stats_host(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
 }
 
 // (median, sigma) of estimate_background's tiles (star_detection.rs:70-83)
-static void background_from_tiles(const TileOut *t, int ntiles, double *out_median, double *out_sigma) {
+static void background_from_tiles(const TileOut *t, int ntiles, double *out_median, double *out_sigma, ab_ctx *count_in = nullptr) {
     std::vector<double> med, sig;
+    uint64_t declined = 0;
+    for (int i = 0; i < ntiles; ++i) declined += t[i].pad != 0;
+    ab_count_fallback(count_in, AB_FB_TILES_DECLINED, declined);
     for (int i = 0; i < ntiles; ++i)
         if (t[i].valid) {
             med.push_back(t[i].median);
@@ -1967,17 +1991,20 @@ static void background_from_tiles(const TileOut *t, int ntiles, double *out_medi
 int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, const ab_pixel_xf *xf, int chunk,
                          ab_bg_pipeline *p) {
     *p = ab_bg_pipeline();
-    static const bool legacy = getenv("AB_TILE_LEGACY") != nullptr;
+    static const bool legacy = ab_dev_env("AB_TILE_LEGACY") != nullptr;
     if (legacy || n == 0 || rows < 3 || cols < 3 || chunk < 1) return AB_OK;
     AB_HIP(ctx, hipSetDevice(ctx->device));
     const int64_t m = std::min(rows, cols);
     const int64_t tile_size = std::min<int64_t>(std::max<int64_t>(m / 8, 32), 256);  // detect_stars' choice (:100)
     const int step = (int)std::max<int64_t>(tile_size, 16);
     const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
-    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK", "AB_TILE_PRIO", 0));
+    if (!ctx->aux_stream) {
+        const hipError_t stream_rc = ab_stream_create_masked(ctx, &ctx->aux_stream, AB_DEV_NAME("AB_TILE_CU_MASK"), AB_DEV_NAME("AB_TILE_PRIO"), 0);  // (outside AB_HIP: its message would carry the developer variables' names)
+        AB_HIP(ctx, stream_rc);
+    }
     // the first launch holds the reference and the first group's targets only (AB_TILE_FIRST, default 5; 0 = `chunk` like the rest):
     // nothing else can run until a group's tiles are done, and eight frames' tiles are ~300 us of an otherwise idle chip
-    static const int first_env = getenv("AB_TILE_FIRST") ? atoi(getenv("AB_TILE_FIRST")) : 5;
+    static const int first_env = ab_dev_env("AB_TILE_FIRST") ? atoi(ab_dev_env("AB_TILE_FIRST")) : 5;
     const size_t first = (first_env > 0 && first_env < chunk && (size_t)first_env < n) ? (size_t)first_env : 0;
     const size_t nchunks = first ? 1 + (n - first + (size_t)chunk - 1) / (size_t)chunk : (n + (size_t)chunk - 1) / (size_t)chunk;
     while (ctx->aux_events.size() < nchunks) {
@@ -2126,7 +2153,7 @@ struct ab_bg_feed_impl {
 int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, int chunk, const hipEvent_t *landed,
                              ab_bg_pipeline *p) {
     *p = ab_bg_pipeline();
-    static const bool legacy = getenv("AB_TILE_LEGACY") != nullptr;
+    static const bool legacy = ab_dev_env("AB_TILE_LEGACY") != nullptr;
     if (legacy || n == 0 || rows < 3 || cols < 3 || chunk < 1) return AB_OK;
     if (chunk > kManyPlanes) chunk = kManyPlanes;
     AB_HIP(ctx, hipSetDevice(ctx->device));
@@ -2145,7 +2172,10 @@ int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, 
     f.len = rows * cols;
     f.sstep = std::max<int64_t>(f.len / 100000, 1);  // affine.rs:28-30
     f.ns = (f.len + f.sstep - 1) / f.sstep;
-    if (!ctx->aux_stream) AB_HIP(ctx, ab_stream_create_masked(ctx, &ctx->aux_stream, "AB_TILE_CU_MASK", "AB_TILE_PRIO", 0));
+    if (!ctx->aux_stream) {
+        const hipError_t stream_rc = ab_stream_create_masked(ctx, &ctx->aux_stream, AB_DEV_NAME("AB_TILE_CU_MASK"), AB_DEV_NAME("AB_TILE_PRIO"), 0);  // (outside AB_HIP: its message would carry the developer variables' names)
+        AB_HIP(ctx, stream_rc);
+    }
     if (!ctx->pct_stream) AB_HIP(ctx, hipStreamCreateWithFlags(&ctx->pct_stream, hipStreamNonBlocking));
     f.nchunks = (n + (size_t)chunk - 1) / (size_t)chunk;
     while (ctx->aux_events.size() < f.nchunks) {
@@ -2235,7 +2265,7 @@ int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *b
     }
     AB_HIP(ctx, hipEventSynchronize(p->events[c]));
     ab_upload_trace("tiles ready, plane", (long)i);
-    background_from_tiles((const TileOut *)p->tiles + i * (size_t)p->ntiles, p->ntiles, &bg[0], &bg[1]);
+    background_from_tiles((const TileOut *)p->tiles + i * (size_t)p->ntiles, p->ntiles, &bg[0], &bg[1], ctx);
     return AB_OK;
 }
 
@@ -2244,6 +2274,9 @@ int ab_estimate_background_device(ab_ctx *ctx, const float *img, int64_t rows, i
     std::vector<TileOut> h;
     AB_TRY(tile_stats_host(ctx, img, rows, cols, ld, tile_size, xf, &h, nullptr));
     std::vector<double> med, sig;
+    uint64_t declined = 0;
+    for (const auto &t : h) declined += t.pad != 0;
+    ab_count_fallback(ctx, AB_FB_TILES_DECLINED, declined);
     for (const auto &t : h)
         if (t.valid) {
             med.push_back(t.median);
@@ -2382,12 +2415,12 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
     // enqueued back to back, every parameter travelling through FrameDev; the host joins at the component count.
     const int step = (int)std::max<int64_t>(tile_size, 16);
     const int nty = (int)((rows + step - 1) / step), ntx = (int)((cols + step - 1) / step), ntiles = nty * ntx;
-    static const bool legacy_tiles = getenv("AB_TILE_LEGACY") != nullptr;
+    static const bool legacy_tiles = ab_dev_env("AB_TILE_LEGACY") != nullptr;
     // OFF by default (AB_DETECT_CHAIN=1 turns it on): measured on the bench, same box, three runs each -- registration stage 18.4 /
     // 18.6 / 18.7 ms with the two host joins against 21.0 / 21.9 / 22.2 ms chained, although one frame alone gets faster (0.39 ->
     // 0.37 ms).  Sixteen streams share four in-order hardware queues; a stream that enqueues nine packets in one go holds its
     // queue until they have all run, and the three streams behind it wait -- the host joins were what interleaved them.
-    static const bool want_chain = getenv("AB_DETECT_CHAIN") != nullptr;
+    static const bool want_chain = ab_dev_env("AB_DETECT_CHAIN") != nullptr;
     const bool chained = normalize_first && !bg_known && ld == cols && ntiles <= kBgTiles && !legacy_tiles && want_chain;
     double bg_median = 0.0, bg_sigma = 1.0, threshold = 0.0;
     FrameDev *fd = nullptr;
@@ -2565,7 +2598,7 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
             g.st[f] = dstat + (size_t)f * comp_cap;
             g.sel[f] = dsel + (size_t)f * kSelCap;
             g.selout[f] = selout + 4 * f;
-            selout[4 * f] = selout[4 * f + 1] = selout[4 * f + 2] = 0;
+            selout[4 * f] = selout[4 * f + 1] = selout[4 * f + 2] = selout[4 * f + 3] = 0;
         }
         g.comp_cap = comp_cap;
         g.chained = 1;
@@ -2607,26 +2640,40 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         AB_HIP(ctx, hipGetLastError());
         AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
         bool redo[kGroupMax] = {};
+        // (what the trace prints is copied out BEFORE any frame is redone: the full path may regrow -- and free -- the pinned buffer
+        // selout lives in: ADVICE r5)
+        unsigned int sel_m[kGroupMax] = {}, sel_ncand[kGroupMax] = {}, sel_ncomp[kGroupMax] = {};
+        size_t sel_stars[kGroupMax] = {};
         for (int f = 0; f < G; ++f) {
-            const unsigned int m = selout[4 * f], ncand = selout[4 * f + 1], ncomp = selout[4 * f + 2];
+            const unsigned int m = selout[4 * f], ncand = selout[4 * f + 1], ncomp = selout[4 * f + 2], cut_key = selout[4 * f + 3];
+            sel_m[f] = m;
+            sel_ncand[f] = ncand;
+            sel_ncomp[f] = ncomp;
             AB_CHECK(ctx, m <= kSelCap, "detect_stars: the selection of frame %d holds %u components", f, m);
             AB_CHECK(ctx, ncomp <= root_cap, "detect_stars: %u components exceed the table capacity", ncomp);
-            if (ncomp > comp_cap) {  // more components than the chained table holds
+            if (ncomp > comp_cap) {  // more components than the chained table holds (or a tile with more components than record slots)
                 redo[f] = true;
+                ab_count_fallback(ctx, recs && ncomp == comp_cap + 1u ? AB_FB_TILE_SLOTS : AB_FB_COMPONENT_TABLE);
                 continue;
             }
             finish_stars(g.rec[f], m, bg[f][1], max_keep, &stars[f]);
+            sel_stars[f] = stars[f].size();
             redo[f] = stars[f].size() < max_keep && ncand > m;  // (see below)
+            if (redo[f]) ab_count_fallback(ctx, AB_FB_SELECTION_SHORT);
+            if (!redo[f] && selection_cut_too_close(stars[f], max_keep, m, ncand, cut_key)) {
+                redo[f] = true;
+                ab_count_fallback(ctx, AB_FB_SELECTION_CUT);
+            }
         }
         for (int f = 0; f < G; ++f) {
             if (!redo[f]) continue;
-            static const bool trace = getenv("AB_TRACE") != nullptr;
+            static const bool trace = ab_env("AB_TRACE") != nullptr;
             if (trace)
                 fprintf(stderr, "[ab_trace] detect_stars: frame %d of the group redone in full (%u components, %u candidates, %u selected, %zu stars of them)\n", f,
-                        selout[4 * f + 2], selout[4 * f + 1], selout[4 * f], stars[f].size());
+                        sel_ncomp[f], sel_ncand[f], sel_m[f], sel_stars[f]);
             double m0 = 0.0, s0 = 0.0;
             AB_TRY(ab_detect_stars_device(ctx, imgs[f], rows, cols, cols, sigma_threshold, &stars[f], &m0, &s0, xf[f], max_keep, false, bg[f]));
-            ctx->det_select_fallbacks++;
+            ab_count_fallback(ctx, AB_FB_FRAMES_REDONE);
         }
         return AB_OK;
     }
@@ -2657,13 +2704,13 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         g.st[f] = dstat + off[f];
         g.sel[f] = select ? dsel + (size_t)f * kSelCap : nullptr;
         g.selout[f] = selout + 4 * f;
-        selout[4 * f] = selout[4 * f + 1] = 0;
+        selout[4 * f] = selout[4 * f + 1] = selout[4 * f + 3] = 0;
     }
     hipLaunchKernelGGL(comp_init_many_kernel, dim3((max_nc + 255) / 256, G), dim3(256), 0, ctx->stream, g);
     hipLaunchKernelGGL(comp_stats_many_kernel, dim3(gl, G), dim3(256), 0, ctx->stream, g, (int)rows, (int)cols, cols);
 #ifdef AB_DEV_ABLATION
-    if (getenv("AB_ABLATE_MOMENTS")) {
-        const int v = atoi(getenv("AB_ABLATE_MOMENTS"));
+    if (ab_dev_env("AB_ABLATE_MOMENTS")) {
+        const int v = atoi(ab_dev_env("AB_ABLATE_MOMENTS"));
         AB_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_mom_ablate), &v, sizeof v));
     }
 #endif
@@ -2681,18 +2728,23 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
             finish_stars((const CompRec *)pin + off[f], g.ncomp[f], bg[f][1], max_keep, &stars[f]);
             continue;
         }
-        const unsigned int m = selout[4 * f], ncand = selout[4 * f + 1];
+        const unsigned int m = selout[4 * f], ncand = selout[4 * f + 1], cut_key = selout[4 * f + 3];
         AB_CHECK(ctx, m <= kSelCap, "detect_stars: the selection of frame %d holds %u components", f, m);
         finish_stars(g.rec[f], m, bg[f][1], max_keep, &stars[f]);
         // the brightest kSelKeep did not yield max_keep survivors and fainter candidates exist (a crowded field whose dedup eats
         // hundreds, or a crowd of equal fluxes at the cut): the whole list decides
         redo[f] = stars[f].size() < max_keep && ncand > m;
+        if (redo[f]) ab_count_fallback(ctx, AB_FB_SELECTION_SHORT);
+        if (!redo[f] && selection_cut_too_close(stars[f], max_keep, m, ncand, cut_key)) {
+            redo[f] = true;
+            ab_count_fallback(ctx, AB_FB_SELECTION_CUT);
+        }
     }
     for (int f = 0; f < G; ++f) {  // (after every frame's records have been read: the full path re-carves the workspaces and the pinned buffer)
         if (!redo[f]) continue;
         double m0 = 0.0, s0 = 0.0;
         AB_TRY(ab_detect_stars_device(ctx, imgs[f], rows, cols, cols, sigma_threshold, &stars[f], &m0, &s0, xf[f], max_keep, false, bg[f]));
-        ctx->det_select_fallbacks++;
+        ab_count_fallback(ctx, AB_FB_FRAMES_REDONE);
     }
     return AB_OK;
 }

@@ -267,7 +267,7 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
              "image of %lld x %lld needs a tiled launch (not in this build)", (long long)out_rows, (long long)out_cols);
     const dim3 grid((unsigned)((out_cols + 511) / 512), (unsigned)nrows), block(256);
 #ifdef AB_DEV_ABLATION  // developer timing experiments, compiled only into a -DAB_DEV_ABLATION build (profiles/r04_warp_ablation.txt)
-    static const int ablate = getenv("AB_ABLATE_WARP") ? atoi(getenv("AB_ABLATE_WARP")) : 0;  // developer timing experiments
+    static const int ablate = ab_dev_env("AB_ABLATE_WARP") ? atoi(ab_dev_env("AB_ABLATE_WARP")) : 0;  // developer timing experiments
     if (ablate == 1) return AB_OK;  // what the registration stage takes without the warps
     if (ablate == 3) {              // ... and without the sixteen conversions and the address arithmetic
         const dim3 g2((unsigned)((out_cols + 511) / 512), (unsigned)nrows);
@@ -289,7 +289,7 @@ int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t
     // batch's latency-bound estimate kernels (dependent loads, a few VALU cycles between them) wait for slots instead of running in
     // the f64 instructions' shadow.  Unused dynamic LDS per workgroup is the cap: 160 KB / n KB workgroups of 4 waves per CU.
     static const unsigned warp_lds = [] {
-        const char *e = getenv("AB_WARP_LDS_KB");
+        const char *e = ab_dev_env("AB_WARP_LDS_KB");
         const long kb = e ? atol(e) : kWarpLdsKB;
         return (unsigned)(kb < 0 ? 0 : (kb > 64 ? 64 : kb)) * 1024u;
     }();

@@ -58,7 +58,7 @@ extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, co
     const size_t plane_bytes = (size_t)min_rows * (size_t)min_cols * sizeof(float);
     // every frame against frame 0 as ONE batch per stage (AB_STACK_PAIRWISE=1: a phase_correlate call per pair, round 4's form)
     std::vector<double> sdx(n, 0.0), sdy(n, 0.0), scf(n, 0.0);
-    static const bool pairwise = getenv("AB_STACK_PAIRWISE") != nullptr;
+    static const bool pairwise = ab_dev_env("AB_STACK_PAIRWISE") != nullptr;
     if (rc == AB_OK && !pairwise)
         rc = ab_phase_correlate_many_device(ctx, dp[0], ld[0], dp.data() + 1, ld.data() + 1, n - 1, min_rows, min_cols, sdx.data() + 1, sdy.data() + 1, scf.data() + 1);
     for (size_t i = 1; rc == AB_OK && i < n; ++i) {
@@ -94,6 +94,17 @@ extern "C" int ab_stack_images(ab_ctx *ctx, const ab_plane *planes, size_t n, co
     }
     if (so_open) ab_stage_out_abort(ctx, &so);
     for (size_t i = 0; i < staged; ++i) ab_stage_release(ctx, &st[i]);
+    // The registered copies are (n - 1) planes -- 17 GB for 63 frames of 8192^2 -- in a grow-only workspace: a pool that large goes
+    // back at the end of the call (a long-lived context would otherwise hold it beside every later call's buffers: ADVICE r5);
+    // up to 1 GiB (C1: 31 MB) stays for the next call, which is what the workspace is for.
+    if (shifted_pool && ctx->ws_bytes[AB_WS_STACK_SHIFTED] > ((size_t)1 << 30)) {
+        (void)hipStreamSynchronize(ctx->stream);
+        void *p = ctx->ws[AB_WS_STACK_SHIFTED];
+        ctx->ws[AB_WS_STACK_SHIFTED] = nullptr;
+        ctx->ws_bytes[AB_WS_STACK_SHIFTED] = 0;
+        const hipError_t e = hipFree(p);
+        if (e != hipSuccess && rc == AB_OK) rc = ab_set_error(ctx, AB_ERR_HIP, "hipFree(registered copies) failed: %s", hipGetErrorString(e));
+    }
     if (rc == AB_OK && out_rejected) *out_rejected = rejected;
     return rc;
 } AB_CATCH(ctx)

@@ -1213,7 +1213,7 @@ static int setup_defer(ab_ctx *ctx, StackArgs *args, int64_t total) {
     args->defer_list = (int *)(ws + (size_t)2 * kDeferSlots * sizeof(unsigned int));
     args->defer_cap = cap;
     // the general pass leaves every counter at zero again, so only a fresh workspace needs clearing
-    args->keep_counts = getenv("AB_TRACE") ? 1 : 0;
+    args->keep_counts = ab_env("AB_TRACE") ? 1 : 0;
     if (ws != before || args->keep_counts) AB_HIP(ctx, hipMemsetAsync(args->defer_count, 0, 2 * kDeferSlots * sizeof(unsigned int), ctx->stream));
     return AB_OK;
 }
@@ -1245,7 +1245,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         // to the wave-per-pixel kernel (AB_STACK_NO_PAIR=1 keeps that one); everything else: one wave per pixel (stack_wide.hip)
         // 513 .. 4096: the wave-per-pixel kernel with 16 / 32 / 64 registers per lane; beyond: one workgroup per pixel, samples
         // in global scratch (stack_deep.hip; a context created under AB_STACK_DEEP_FROM=k sends every stack of more than k >= 64 frames there: the tests do)
-        static const bool no_pair = getenv("AB_STACK_NO_PAIR") != nullptr;
+        static const bool no_pair = ab_dev_env("AB_STACK_NO_PAIR") != nullptr;
         if (n > (size_t)ctx->stack_deep_from)
             AB_TRY(ab_stack_deep_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
         else if (n > 256 && n <= 512 && contig_all && !partial && !no_pair)
@@ -1308,7 +1308,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         // (the fast pass of the two-pass mode only looks at sorted positions NP-4 .. NP-1 for the high end: on a padded stack
         // those are pads and every pixel would be deferred, so padded stacks take the single-pass kernel)
         if (!padded && !median_only && !ctx->stack_exact && (int)n == np && np >= 8 && contiguous && total < (int64_t(1) << 30) &&
-            !getenv("AB_STACK_SINGLE_PASS")) {
+            !ab_dev_env("AB_STACK_SINGLE_PASS")) {
             AB_TRY(setup_defer(ctx, &args, total));
         }
         for (hipEvent_t &e : ctx->stack_ev)
@@ -1319,7 +1319,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
             // frame-count classes of 32 (AB_STACK_NO_CLASSES=1: every count pays for 256): the pads' loads and the network's
             // operations on pad wires are gone at compile time
-            static const bool no_classes = getenv("AB_STACK_NO_CLASSES") != nullptr;
+            static const bool no_classes = ab_dev_env("AB_STACK_NO_CLASSES") != nullptr;
             const int cls = no_classes ? 256 : (args.n_real + 31) / 32 * 32;
 #define AB_LAUNCH_256(NREAL)                                                                                                               \
     do {                                                                                                                                   \
@@ -1354,7 +1354,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         AB_HIP(ctx, hipEventRecord(ctx->stack_ev[1], ctx->stream));
         ctx->stack_ev_valid = true;
     }
-    if (getenv("AB_TRACE") && n > 1) {  // developer aid: how many pixels the fast pass handed to the general pass
+    if (ab_env("AB_TRACE") && n > 1) {  // developer aid: how many pixels the fast pass handed to the general pass
         std::vector<unsigned int> cnt(kDeferSlots, 0);
         void *ws = ctx->ws[AB_WS_STACK_DEFER];
         if (ws) {
@@ -1362,6 +1362,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
             unsigned long long tot = 0, mx = 0;
             for (unsigned int c : cnt) tot += c, mx = c > mx ? c : mx;
+            ab_count_fallback(ctx, AB_FB_STACK_GENERAL_PIXELS, tot);
             fprintf(stderr, "[ab_trace] stack: %llu of %lld pixels deferred (%.2f %%), fullest list %llu\n", tot, (long long)total,
                     100.0 * (double)tot / (double)total, mx);
         }

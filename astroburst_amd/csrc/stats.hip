@@ -843,7 +843,7 @@ int enqueue_exact_path(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n,
 // The resident kernel (stats_resident.hpp) takes the histogram path of one unsharded, 16-byte aligned plane that one
 // workgroup per CU can hold; AB_STATS_CHAIN=1 keeps the chain (the GPU tests run both).
 bool resident_takes(ab_ctx *ctx, const float *data, int64_t n, const uint8_t *u8) {
-    const char *e = getenv("AB_STATS_CHAIN");
+    const char *e = ab_env("AB_STATS_CHAIN");
     if (e && *e && *e != '0') return false;
     if (ctx->stats_aborts >= 3) return false;  // (fewer CUs than it reports, e.g. a CU mask: every launch would wait out its barrier first)
     const int64_t cus = ctx->cu_count;
@@ -866,7 +866,7 @@ int enqueue_resident(ab_ctx *ctx, const float *data, int64_t n, const Ws &w, int
     // LAST workgroup behaves at its k-th barrier as if it had timed out AFTER publishing its arrival -- its peers pass that barrier
     // and run to the end without it (what a real time-out at the final barrier does)
     int abort_at = 0;
-    if (const char *e = getenv("AB_STATS_FORCE_ABORT"); e && *e) {
+    if (const char *e = ab_dev_env("AB_STATS_FORCE_ABORT"); e && *e) {
         if (*e == '1') AB_HIP(ctx, hipMemsetAsync(w.res.bar + kBarAbort, 1, 1, ctx->stream));
         if (*e == 'b') abort_at = atoi(e + 1);
     }
@@ -987,8 +987,9 @@ static int fetch_result(ab_ctx *ctx, const ab_image_stats *result_dev, ab_image_
         *aborted = done != ctx->stats_expect;
         if (*aborted) ctx->stats_bar = nullptr;
         ctx->stats_aborts = *aborted ? ctx->stats_aborts + 1 : 0;
+        if (*aborted) ab_count_fallback(ctx, AB_FB_STATS_CHAIN);  // (the caller repeats the launch as the chain)
     }
-    if (aborted && getenv("AB_STATS_TIMING")) {  // workgroup 0's phase stamps (s_memtime: shader clock cycles)
+    if (aborted && ab_dev_env("AB_STATS_TIMING")) {  // workgroup 0's phase stamps (s_memtime: shader clock cycles)
         Ws w;
         AB_TRY(carve(ctx, &w));
         unsigned long long st[24];

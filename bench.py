@@ -448,6 +448,16 @@ def main():
 
     roofline["back_to_back_ms"] = None if iso_ms is None else round(iso_ms, 4)
     roofline["frac_sustained"] = None if iso_ms is None else round(algo_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if iso_ms is not None:
+        # Round 6: the headline `frac` / `achieved` are THIS run's sustained figure -- the stack launch repeated back
+        # to back, the slowest of the three views (a VALU-saturated kernel clocks down when nothing idles the chip in between) and the
+        # one a reader reproduces with HIP events alone; the in-step figure and the committed profile's stand beside it.
+        roofline["achieved"] = round(algo_bytes / (iso_ms * 1e-3) / 1e9, 1)
+        roofline["frac"] = roofline["frac_sustained"]
+        roofline["avg_kernel_ms"] = round(iso_ms, 4)
+        roofline["in_step_kernel_ms"] = round(stack_avg_ms, 4)
+        roofline["frac_basis"] = ("this run: HIP events on the library's stream around the stack launch (fast + general pass) repeated back to back; "
+                                  "frac_in_step = the same events inside the timed steps, frac_profile = rocprofv3 average of the committed profile")
     # measured streaming ceiling of this GPU (float4 copy), for context
     a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev)
     b = torch.empty_like(a)
@@ -583,6 +593,7 @@ def main():
                        "output_mpix_per_s": round((1 if rowband else world) * P / 1e6 / (elapsed / args.steps), 1),
                        "rejected_pixels": rejected, "median": st.median,
                        "measured_copy_GBs": round(copy_gbs, 1), "stage_ms": stage_ms, "registration": reg_info,
+                       "fallbacks": ctx.fallback_counts(), "library": ab.version() if hasattr(ab, "version") else None,
                        **({"host_resident_mpix_s": host_info["host_resident_mpix_s"], "host_planes": host_info} if host_info else {})},
             "roofline": roofline,
             "roofline_step": {"bound": "hbm", "achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS * world, "unit": "GB/s",

@@ -102,6 +102,16 @@ impl Hip {
         self.check(unsafe { sys::ab_ctx_trim(self.ctx) })
     }
 
+    /// how often a fast path handed over to its exact fallback (same results, more time) since the context was created or last
+    /// reset, indexed by the `sys::AB_FB_*` constants (frames redone in full, crowded tiles, short / close selections, declined
+    /// background tiles, aborted resident statistics) -- for the host's log: a session whose registration suddenly takes twice as
+    /// long shows up here, not in the pixels
+    pub fn fallback_counts(&self, reset: bool) -> Result<[u64; sys::AB_FB_COUNT as usize]> {
+        let mut out = [0u64; sys::AB_FB_COUNT as usize];
+        self.check(unsafe { sys::ab_ctx_fallback_counts(self.ctx, out.as_mut_ptr(), out.len(), reset as i32) })?;
+        Ok(out)
+    }
+
     pub fn synchronize(&self) -> Result<()> {
         self.check(unsafe { sys::ab_ctx_synchronize(self.ctx) })
     }
@@ -345,11 +355,16 @@ pub fn warp_image_rows_from_band(hip: &Hip, src_band: &impl PlaneSrc, src_row0: 
     })
 }
 /// source rows (first, count) that output rows [row0, row0 + nrows) of warp_image read (affine.rs:663-690, sampling.rs:48-80)
-pub fn warp_source_rows(t: &AffineTransform, src_rows: usize, src_cols: usize, out_cols: usize, row0: usize, nrows: usize) -> (usize, usize) {
+/// (context-free: a non-zero status -- negative dimensions, a band outside the output -- has no message to fetch, so it is named here;
+/// it must not become "(0, 0): no source rows needed")
+pub fn warp_source_rows(t: &AffineTransform, src_rows: usize, src_cols: usize, out_cols: usize, row0: usize, nrows: usize) -> Result<(usize, usize)> {
     let m = [t.a, t.b, t.tx, t.c, t.d, t.ty];
     let (mut s0, mut sn) = (0i64, 0i64);
-    unsafe { sys::ab_warp_source_rows(m.as_ptr(), src_rows as i64, src_cols as i64, out_cols as i64, row0 as i64, nrows as i64, &mut s0, &mut sn) };
-    (s0 as usize, sn as usize)
+    let rc = unsafe { sys::ab_warp_source_rows(m.as_ptr(), src_rows as i64, src_cols as i64, out_cols as i64, row0 as i64, nrows as i64, &mut s0, &mut sn) };
+    if rc != 0 {
+        bail!("warp_source_rows: invalid arguments (status {rc}: src {src_rows}x{src_cols}, out cols {out_cols}, rows {row0}+{nrows})");
+    }
+    Ok((s0 as usize, sn as usize))
 }
 
 // ---- a8  core/alignment/phase_correlation.rs --------------------------------------------------------------------------------------
@@ -1204,25 +1219,35 @@ impl Drop for Comm {
     }
 }
 /// rows [row0, row0 + nrows) of a `rows`-row image that belong to `rank`
-pub fn shard_rows(rows: usize, nranks: i32, rank: i32) -> (usize, usize) {
+pub fn shard_rows(rows: usize, nranks: i32, rank: i32) -> Result<(usize, usize)> {
     let (mut r0, mut n) = (0i64, 0i64);
-    unsafe { sys::ab_shard_rows(rows as i64, nranks, rank, &mut r0, &mut n) };
-    (r0 as usize, n as usize)
+    let rc = unsafe { sys::ab_shard_rows(rows as i64, nranks, rank, &mut r0, &mut n) };
+    if rc != 0 {
+        bail!("shard_rows: invalid arguments (status {rc}: {rows} rows, rank {rank} of {nranks})");
+    }
+    Ok((r0 as usize, n as usize))
 }
 /// what `rank` must hold of every target frame to warp its band with `transforms`: its rows + the halo (first row, count)
-pub fn shard_source_rows(transforms: &[AffineTransform], src_rows: usize, src_cols: usize, out_rows: usize, out_cols: usize, nranks: i32, rank: i32) -> (usize, usize) {
+pub fn shard_source_rows(transforms: &[AffineTransform], src_rows: usize, src_cols: usize, out_rows: usize, out_cols: usize, nranks: i32, rank: i32) -> Result<(usize, usize)> {
     let flat: Vec<f64> = transforms.iter().flat_map(|t| [t.a, t.b, t.tx, t.c, t.d, t.ty]).collect();
     let (mut s0, mut sn) = (0i64, 0i64);
-    unsafe {
+    let rc = unsafe {
         sys::ab_shard_source_rows(flat.as_ptr(), transforms.len(), src_rows as i64, src_cols as i64, out_rows as i64, out_cols as i64, nranks, rank, &mut s0, &mut sn)
     };
-    (s0 as usize, sn as usize)
+    if rc != 0 {
+        // (AB_ERR_INVALID from ab_shard_rows or the dimension checks: an empty band would only fail later, in ab_warp_image_rows_from_band)
+        bail!("shard_source_rows: invalid arguments (status {rc}: src {src_rows}x{src_cols}, out {out_rows}x{out_cols}, rank {rank} of {nranks})");
+    }
+    Ok((s0 as usize, sn as usize))
 }
 /// frames [f0, f0 + nf) of an n-frame stack that belong to `rank`
-pub fn shard_frames(n_frames: usize, nranks: i32, rank: i32) -> (usize, usize) {
+pub fn shard_frames(n_frames: usize, nranks: i32, rank: i32) -> Result<(usize, usize)> {
     let (mut f0, mut nf) = (0usize, 0usize);
-    unsafe { sys::ab_shard_frames(n_frames, nranks, rank, &mut f0, &mut nf) };
-    (f0, nf)
+    let rc = unsafe { sys::ab_shard_frames(n_frames, nranks, rank, &mut f0, &mut nf) };
+    if rc != 0 {
+        bail!("shard_frames: invalid arguments (status {rc}: {n_frames} frames, rank {rank} of {nranks})");
+    }
+    Ok((f0, nf))
 }
 
 /// One context + one RCCL rank per GPU, each driven by its own thread (what `handleStackAll`'s concurrent commands already

@@ -20,6 +20,23 @@
  *    arena; it is not shared between threads -- create one per calling thread (the Tauri
  *    commands run concurrently on tokio blocking threads, cmd/common.rs:345-352).
  *  - device-plane calls are asynchronous on the context's stream unless they return scalars.
+ *
+ * Environment
+ *  The library reads these eight variables and no others (each when a context / communicator is created, AB_TRACE per call).
+ *  None changes a result: every engine they select is held to the same oracle by the tests.
+ *    AB_TRACE=1              stage stamps, deferred-pixel and redone-frame notes on stderr (also fills AB_FB_STACK_GENERAL_PIXELS)
+ *    AB_STACK_EXACT=1        ab_stack_*: the direct two-pass clipping engine instead of the running-sum one (bit-exact cross-check
+ *                            of the default engine's 1e-5 contract; ~1.3x slower)
+ *    AB_STATS_CHAIN=1        ab_compute_image_stats*: the histogram chain instead of the register-resident kernel (identical results;
+ *                            what a resident launch falls back to by itself when its grid barrier times out)
+ *    AB_REGISTER_WORKERS=n   host threads (= frame groups in flight) of ab_register_frames / ab_align_pairs_affine (default 12)
+ *    AB_STACK_DEEP_FROM=n    stacks of more than n frames (64 <= n <= 4096, default 4096) take the workgroup-per-pixel kernel
+ *    AB_BATCH_DEEP_FROM=n    the same for ab_sigma_clipped_mean_stack (64 <= n <= 2048, default 2048)
+ *    AB_COMM_TIMEOUT_MS=n    how long a rank waits on a collective (either transport) before AB_ERR_COMM (default 300000)
+ *    AB_COMM_HOST_SLOT_MB=n  host-staged communicator: size of a rank's shared-memory slot, 1 .. 1024 (default 4)
+ *  Superseded kernel forms, sweep knobs, stage cuts and fault injection exist only in the developer build
+ *  (`make -C astroburst_amd/csrc dev` -> libastroburst_hip_dev.so, ab_version() ends in "+dev"); the release library does not
+ *  contain their names (tests/test_abi_cpu.py checks both lists against the sources and the built library).
  */
 #ifndef ASTROBURST_HIP_H
 #define ASTROBURST_HIP_H
@@ -88,11 +105,29 @@ AB_API int ab_ctx_request_cancel(ab_ctx *ctx);
 AB_API int ab_ctx_clear_cancel(ab_ctx *ctx);
 /* device properties the bench prints: name, CU count, HBM bytes */
 AB_API int ab_device_info(ab_ctx *ctx, char *name, size_t name_cap, int *cu_count, uint64_t *hbm_bytes);
-/* Release the device memory the context has grown for its calls (scratch arena, workspaces, the staging area of host-resident
- * frames -- as large as the largest frame set it was given), its frame workers' too.  The context stays usable: the next call
- * allocates what it needs again.  Blocks until the context's streams are idle.  A long-lived host (one ab_ctx per command
- * thread, infra/cache.rs keeps the planes) calls it after a large batch. */
+/* Release what the context has grown for its calls: the scratch arena, every workspace, the HBM staging area of host-resident
+ * frames (as large as the largest frame set it was given), the pinned read-back buffers and the declined-tile lists -- its frame
+ * workers' too.  The context stays usable: the next call allocates what it needs again.  Blocks until the context's streams are
+ * idle.  Every buffer is released whatever an earlier release returned; the first failure is the return code, its text in
+ * ab_last_error(ctx).  A long-lived host (one ab_ctx per command thread, infra/cache.rs keeps the planes) calls it after a large
+ * batch.  (ab_stack_images(align) gives its registered copies back by itself when they exceed 1 GiB.) */
 AB_API int ab_ctx_trim(ab_ctx *ctx);
+/* Every fast path of the library has an exact fallback that gives the SAME result (a frame redone through the full component list,
+ * a background tile settled by the resident kernel, a statistics launch repeated as the histogram chain).  They are silent in the
+ * results and not in the run time, so the context counts them (its frame workers' too): out[k] = events of kind k since the
+ * context was created (or since the last call with reset != 0), for k < min(cap, AB_FB_COUNT).  Thread-safe. */
+typedef enum {
+    AB_FB_FRAMES_REDONE = 0,  /* detect_stars of a registration frame redone through the full path (any of the four reasons below) */
+    AB_FB_TILE_SLOTS,         /* ... a 32 x 128 labelling tile held more components than its record slots */
+    AB_FB_COMPONENT_TABLE,    /* ... more components than the chained table holds */
+    AB_FB_SELECTION_SHORT,    /* ... the brightest 480 components did not yield the matcher's 120 stars and fainter ones exist */
+    AB_FB_SELECTION_CUT,      /* ... the faintest kept star lay within two key steps of the selection's cut */
+    AB_FB_TILES_DECLINED,     /* background tiles the streaming kernel declined (settled by the resident tile kernel) */
+    AB_FB_STATS_CHAIN,        /* compute_image_stats launches whose resident kernel aborted and were repeated as the chain */
+    AB_FB_STACK_GENERAL_PIXELS, /* pixels the stack's fast pass handed to its general pass (counted only under AB_TRACE=1) */
+    AB_FB_COUNT
+} ab_fallback_kind;
+AB_API int ab_ctx_fallback_counts(ab_ctx *ctx, uint64_t *out, size_t cap, int reset);
 
 /* ---- a1/a2  core/stacking/combine.rs ------------------------------------------------------ */
 /* StackConfig, types/stacking.rs:3-20 (defaults 3.0, 3.0, 5, align=true) */

@@ -65,8 +65,26 @@ def ctx_deep():
     c.close()
 
 
-def _ctx_under(env):
+DEV_ONLY = ("needs the developer library: `make -C astroburst_amd/csrc dev` and AB_LIB_PATH=astroburst_amd/libastroburst_hip_dev.so "
+            "(the release library compiles the superseded forms' switches, the sweep knobs and the fault injection out: ab_dev_env)")
+
+
+def require_dev_build():
+    """Skip unless the loaded library is the -DAB_DEV_ABLATION build: the switches a test is about to set do nothing in the release."""
     import astroburst_amd as ab
+    if not ab.is_dev_build():
+        pytest.skip(DEV_ONLY)
+
+
+@pytest.fixture(scope="session")
+def dev_build():
+    require_dev_build()
+
+
+def _ctx_under(env):
+    """A context created under developer switches (dev build only)."""
+    import astroburst_amd as ab
+    require_dev_build()
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -109,6 +127,7 @@ def ctx_r4_detect():
     """Same library with round 4's detection forms (AB_LABEL_LEGACY=1: two-pass labelling; AB_DETECT_FULL_RECORDS=1: every component's
     record crosses to the host): the cross-check of the tile-local union-find and of the device-side selection of the brightest."""
     import astroburst_amd as ab
+    require_dev_build()
     old = {k: os.environ.get(k) for k in ("AB_LABEL_LEGACY", "AB_DETECT_FULL_RECORDS")}
     os.environ.update(AB_LABEL_LEGACY="1", AB_DETECT_FULL_RECORDS="1")
     try:

@@ -234,3 +234,38 @@ def test_no_dpp_reads_a_register_inside_its_write_hazard_window(tmp_path):
     with open(stripped, "w") as f:
         f.write("\n".join(l for l in open(lst).read().split("\n") if "s_nop" not in l))
     assert chk.check_listing(stripped)[1], "the checker does not see a hazard when the fences are gone"
+
+
+def test_the_release_library_reads_the_documented_environment_variables_only():
+    """`ship one code path`.  (i) no raw getenv in csrc/ outside the two helpers of ab_common.hpp; (ii) the names
+    given to ab_env() -- the release library's -- are exactly the eight the header's "Environment" section and INTEGRATION.md list;
+    (iii) none of the developer names (ab_dev_env / AB_DEV_NAME: superseded forms, sweep knobs, stage cuts, fault injection) is
+    present in the built release library, not even as a string."""
+    import glob
+    import re
+    from astroburst_amd import _lib
+    rel, dev = set(), set()
+    for path in glob.glob(os.path.join(_lib.CSRC, "*.h*")):
+        if path.endswith("sortnet_gen.hpp"):
+            continue
+        text = open(path).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        raw = re.findall(r"\bgetenv\s*\(", code)
+        assert len(raw) == (2 if path.endswith("ab_common.hpp") else 0), f"{path}: raw getenv"
+        rel |= set(re.findall(r'\bab_env\("([A-Z0-9_]+)"\)', code))
+        dev |= set(re.findall(r'\bab_dev_env\("([A-Z0-9_]+)"\)', code)) | set(re.findall(r'AB_DEV_NAME\("([A-Z0-9_]+)"\)', code))
+    header = open(_lib.HEADER_PATH).read()
+    section = header[header.index(" * Environment"):header.index("#ifndef ASTROBURST_HIP_H")]
+    documented = set(re.findall(r"^ \*    (AB_[A-Z0-9_]+)=", section, flags=re.M))
+    assert len(documented) == 8 and rel == documented, (sorted(rel), sorted(documented))
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name in documented:
+        assert name in integration, f"{name} is not in INTEGRATION.md"
+    assert len(dev) >= 25 and not (dev & rel)
+    if not os.path.exists(_lib.LIB_PATH) or _lib.LIB_PATH.endswith("_dev.so"):
+        return
+    blob = open(_lib.LIB_PATH, "rb").read()
+    present = sorted(n for n in dev if n.encode() in blob)
+    assert not present, f"developer switches reached the release library: {present}"
+    for n in documented:
+        assert n.encode() in blob, n

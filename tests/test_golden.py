@@ -118,6 +118,105 @@ def test_oracle_detect_resample_frozen(oracle):
     assert same([oracle.bicubic_sample(r["src"], 37, 41, y, x) for y, x in r["bicubic_pts"]], r["bicubic"])
 
 
+# ---- round 6: a6 / a12 / a13 / a18 / f2 -- the rows whose only pins were restatements by the oracle's own author ---------------------
+METHODS = ("affine", "rigid", "phase_correlation", "identity")
+
+
+def affine_row(a):
+    return list(a.transform), [a.matched_stars, a.inliers, METHODS.index(a.method)], a.residual_px
+
+
+def check_affine(api, exact):
+    g = load("affine")
+    rows, cols = (int(v) for v in g["stars_dims"])
+    for nt in (1, 8):
+        t, c, r = affine_row(api.affine_from_stars(g["stars_ref_xy"], g["stars_tgt_xy"], rows, cols, num_threads=nt))
+        assert c == list(g[f"stars_t{nt}_counts"]), nt
+        if exact:
+            assert same(t, g[f"stars_t{nt}_transform"]) and r == g[f"stars_t{nt}_residual"][0], nt
+        else:   # (the library's host geometry is C++ with the oracle's operation order; libm / contraction free: held to 1e-9 like the parity tests)
+            assert np.allclose(t, g[f"stars_t{nt}_transform"], rtol=0, atol=1e-9) and abs(r - g[f"stars_t{nt}_residual"][0]) < 1e-9, nt
+    t, c, r = affine_row(api.align_channel_affine(g["pair_ref"], g["pair_tgt"], num_threads=8))
+    assert c == list(g["pair_counts"]) and c[2] == 0 and c[1] >= 20            # an affine fit on dozens of inliers
+    assert abs(g["pair_transform"][2] - (-1.75)) < 0.5 and abs(g["pair_transform"][5] - 2.5) < 0.5   # (the frozen answer IS the generating shift)
+    if exact:
+        assert same(t, g["pair_transform"]) and r == g["pair_residual"][0]
+    else:
+        assert np.allclose(t, g["pair_transform"], rtol=0, atol=1e-8) and abs(r - g["pair_residual"][0]) < 1e-8
+    return g, t
+
+
+def test_oracle_affine_frozen(oracle):
+    g, t = check_affine(oracle, exact=True)
+    w = oracle.warp_image(g["pair_tgt"], tuple(t), 256, 320)
+    assert int(w.view(np.uint32).astype(np.uint64).sum()) == int(g["pair_warped_checksum"][0])
+
+
+def check_background(api, mode_of):
+    g = load("background")
+    for tag in ("sub_g4_d2", "div_g6_d1"):
+        grid, deg, kappa, it, mode = g[f"{tag}_cfg"]
+        b = api.extract_background(g["img"], grid_size=int(grid), poly_degree=int(deg), sigma_clip=float(kappa), iterations=int(it), mode=mode_of(int(mode)))
+        assert b.sample_count == int(g[f"{tag}_scalars"][0]), tag
+        n = len(np.asarray(b.coeffs))
+        assert same(np.asarray(b.coeffs, np.float64), g[f"{tag}_coeffs"][:n]) and not g[f"{tag}_coeffs"][n:].any(), tag
+        assert same(b.model, g[f"{tag}_model"]) and same(b.corrected, g[f"{tag}_corrected"]), tag
+        assert abs(b.rms_residual - g[f"{tag}_scalars"][1]) <= 1e-12 * g[f"{tag}_scalars"][1], tag
+
+
+def test_oracle_background_frozen(oracle):
+    check_background(oracle, lambda m: m)
+
+
+def check_masked(api):
+    g = load("masked")
+    mk = api.generate_star_mask(g["img"], stars=[tuple(s) for s in g["stars_xyf"]], luminance_protect=True, luminance_ceiling=0.85)
+    assert same(mk.mask, g["mask"]) and [float(mk.stars_masked), mk.coverage_fraction] == list(g["mask_scalars"])
+    assert 0 < mk.stars_masked < len(g["stars_xyf"])                 # some of the list is outside the plane / the FWHM range
+    for tag, cfg in (("default", dict()), ("hard", dict(iterations=25, target_background=0.4, protection_amount=0.3, convergence_threshold=1e-7))):
+        ms = api.masked_stretch(g["img"], mask=mk, **cfg)
+        img = ms.image.cpu().numpy() if hasattr(ms.image, "cpu") else ms.image
+        assert same(img, g[f"{tag}_image"]), tag
+        assert [float(ms.iterations_run), ms.final_background, float(ms.converged), float(ms.stars_masked), ms.mask_coverage] == list(g[f"{tag}_scalars"]), tag
+
+
+def test_oracle_masked_frozen(oracle):
+    check_masked(oracle)
+
+
+def check_spcc(api, oracle_mod, rtol):
+    g = load("spcc")
+    stars = [oracle_mod.DetectedStar(x=r[0], y=r[1], flux=r[2], fwhm=r[3], eccentricity=r[4], peak=r[5], snr=r[6], npix=int(r[7])) for r in g["stars"]]
+    for white in ("average_spiral", "g2v"):
+        res = api.spcc_calibrate_rgb(g["r"], g["g"], g["b"], 1.2, detection=(stars, float(g["lum_max"][0])), min_snr=15.0, max_stars=150,
+                                     saturation_limit=0.95, white_reference=white)
+        assert [res.stars_matched, res.stars_total] == list(g[f"{white}_counts"]) and res.stars_matched >= 20, white
+        got = [res.r_factor, res.g_factor, res.b_factor, res.avg_color_index]
+        assert np.allclose(got, g[f"{white}_factors"], rtol=rtol, atol=0), white
+    assert g["average_spiral_factors"][0] < 1.0 < g["average_spiral_factors"][2]   # the field was rendered with gains (1.4, 1.0, 0.7)
+
+
+def test_oracle_spcc_frozen(oracle):
+    check_spcc(oracle, oracle, 0.0)
+
+
+def batch_frames(g, n):
+    return [np.ascontiguousarray(g[f"adv{n}_in"][f].reshape(12, 32)) for f in range(n)]
+
+
+def test_oracle_batch_frozen(oracle):
+    g = load("batch")
+    for n in (5, 16, 33):
+        for (sl, sh, it) in ((2.5, 3.0, 5), (1.0, 1.0, 2)):
+            img, rej = oracle.sigma_clipped_mean_stack(batch_frames(g, n), sl, sh, it)
+            assert same(img, g[f"adv{n}_{sl}_{sh}_{it}_out"]) and same(np.asarray(rej, np.int64), g[f"adv{n}_{sl}_{sh}_{it}_rej"]), (n, sl, sh, it)
+    lights = [np.ascontiguousarray(f) for f in g["lights"]]
+    for normalize in (True, False):
+        img, rej, mean, std = oracle.run_batch_channel(lights, g["bias"], None, g["flat"], normalize=normalize)
+        k = f"channel_norm{int(normalize)}"
+        assert same(img, g[f"{k}_out"]) and same(np.asarray(rej, np.int64), g[f"{k}_rej"]) and same([mean, std], g[f"{k}_stats"]), k
+
+
 def test_generator_reproduces_the_committed_fixtures():
     """tools/gen_golden.py --check: the committed files are what the committed generator + oracle produce"""
     import subprocess
@@ -183,3 +282,41 @@ def test_hip_detect_resample_frozen(ctx):
     r = load("resample")
     assert same(ctx.shift_image_subpixel(r["src"], 1.25, -2.5), r["shift"])
     assert same(ctx.warp_image(r["src"], tuple(r["transform"]), 37, 41), r["warp"])
+
+
+@pytest.mark.gpu
+def test_hip_affine_frozen(ctx):
+    g, t = check_affine(ctx, exact=False)
+    w = ctx.warp_image(g["pair_tgt"], tuple(g["pair_transform"]), 256, 320)      # (the FROZEN transform: the warp is bit-exact given its input)
+    assert int(np.asarray(w).view(np.uint32).astype(np.uint64).sum()) == int(g["pair_warped_checksum"][0])
+
+
+@pytest.mark.gpu
+def test_hip_background_frozen(ctx):
+    check_background(ctx, lambda m: ("subtract", "divide")[m])
+
+
+@pytest.mark.gpu
+def test_hip_masked_frozen(ctx):
+    check_masked(ctx)
+
+
+@pytest.mark.gpu
+def test_hip_spcc_frozen(ctx, oracle):
+    check_spcc(ctx, oracle, 0.0)          # (aperture sums in the oracle's raster order, the colour maths the same host f64 ops: bit for bit)
+
+
+@pytest.mark.gpu
+def test_hip_batch_frozen(ctx):
+    from astroburst_amd.core import BatchStackConfig
+    g = load("batch")
+    for n in (5, 16, 33):
+        for (sl, sh, it) in ((2.5, 3.0, 5), (1.0, 1.0, 2)):
+            img, rej = ctx.sigma_clipped_mean_stack(batch_frames(g, n), BatchStackConfig(sl, sh, it))
+            assert same(img, g[f"adv{n}_{sl}_{sh}_{it}_out"]) and same(np.asarray(rej, np.int64), g[f"adv{n}_{sl}_{sh}_{it}_rej"]), (n, sl, sh, it)
+    lights = [np.ascontiguousarray(f) for f in g["lights"]]
+    for normalize in (True, False):
+        img, rej, mean, std = ctx.run_batch_channel(lights, g["bias"], None, g["flat"], BatchStackConfig(normalize_before_stack=normalize))
+        k = f"channel_norm{int(normalize)}"
+        assert same(img, g[f"{k}_out"]) and same(np.asarray(rej, np.int64), g[f"{k}_rej"]), k
+        assert abs(mean - g[f"{k}_stats"][0]) <= 1e-12 * abs(g[f"{k}_stats"][0]) and abs(std - g[f"{k}_stats"][1]) <= 1e-10 * abs(g[f"{k}_stats"][1]), k

@@ -333,7 +333,7 @@ def test_host_frames_cancel_errors_and_degenerate_sets(ctx, oracle):
         ctx.align_pairs_affine(ref.cuda(), [np.zeros((rows, cols + 1), np.float32)], [torch.empty((rows, cols + 1), device="cuda")], num_threads=8)
 
 
-def test_fed_pipeline_equals_upfront_percentiles(tmp_path):
+def test_fed_pipeline_equals_upfront_percentiles(tmp_path, dev_build):
     """Round 4: frames arriving from the host go through a pipeline whose percentiles run chunk by chunk on the device
     (ab_bg_pipeline_begin_fed); AB_PIPE_FED=1 sends device-resident frames the same way.  The default order (all frames'
     percentiles up front, a host join, then the tiles) and the fed one give the same transforms, bit for bit."""
@@ -370,7 +370,7 @@ def test_fed_pipeline_equals_upfront_percentiles(tmp_path):
     assert out[0].count("affine") == 6
 
 
-def test_chained_detection_gives_the_same_transform(tmp_path):
+def test_chained_detection_gives_the_same_transform(tmp_path, dev_build):
     """AB_DETECT_CHAIN=1 (read once per process): percentiles -> tiles -> background -> threshold -> labels enqueued back to back
     with the parameters travelling through device memory.  Same registration result as the default path, bit for bit.  (The two
     child processes load the SAME frames from disk: rendering them again would not do, the star renderer accumulates with
@@ -470,14 +470,20 @@ def test_registration_when_the_brightest_components_are_not_stars(ctx, oracle, k
     assert np.allclose(batch[0].transform, want.transform, rtol=0, atol=1e-8)
 
 
-@pytest.mark.parametrize("shape", [(512, 640), (600, 800), (257, 1000), (1100, 2048), (300, 1003), (515, 777)])
-def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midjoin, ctx_pixel_list, ctx_pixelwise, shape):
-    """Round 5 changed how a GROUP of frames is detected: tile-local union-find in LDS + a border pass (any width: the mask's rows are
-    padded to whole words and a row's ragged last quad is loaded float by float -- 1000, 1003 and 777 are not multiples of 32, the
-    last two not of 4 either, so their rows start at every dword alignment), approximate flux in comp_stats, the brightest 480 candidates selected on the
-    device, moments for those only.  A context created under AB_LABEL_LEGACY=1 AB_DETECT_FULL_RECORDS=1 runs round 4's forms: the
-    transforms, star counts and inliers of nine targets (two groups of four + one) must be IDENTICAL."""
-    import torch
+def _same_registration(a, b):
+    return (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
+
+
+def _holds_to_the_oracle(oracle, ref, tgts, got, atol=1e-8):
+    """every target's grouped result against oracle.align_channel_affine of the pair (detection -> matching -> RANSAC -> fit)"""
+    ref_h = ref.cpu().numpy()
+    for t, g in zip(tgts, got):
+        want = oracle.align_channel_affine(ref_h, t.cpu().numpy(), num_threads=8)
+        assert g.method == want.method and g.matched_stars == want.matched_stars and g.inliers == want.inliers, (g, want)
+        assert np.allclose(g.transform, want.transform, rtol=0, atol=atol)
+
+
+def _grouped_case(shape):
     from astroburst_amd import synth
     rows, cols = shape
     y, x, flux = synth.star_catalog(rows, cols, int(900 * rows * cols / 1e6) + 150, seed=rows)
@@ -485,6 +491,31 @@ def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midj
     ref = synth.make_frame(rows, cols, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=1e-4).cuda()
     tgts = [synth.make_frame(rows, cols, k + 1, cat=cat, shift=(1.25 * k - 4.0, 3.0 - 0.8 * k), bad_patch_rate=1e-6, cosmic_rate=1e-4).cuda()
             for k in range(9)]
+    return ref, tgts
+
+
+@pytest.mark.parametrize("shape", [(512, 640), (600, 800), (257, 1000), (1100, 2048), (300, 1003), (515, 777)])
+def test_grouped_registration_equals_the_oracle(ctx, oracle, shape):
+    """How a GROUP of frames is detected (tile-local union-find in LDS + a border pass, at any width: the mask's rows are padded to
+    whole words and a row's ragged last quad is loaded float by float -- 1000, 1003 and 777 are not multiples of 32, the last two
+    not of 4 either, so their rows start at every dword alignment; one record per tile-local component; the brightest 480 candidates
+    selected on the device; moments for those only) against the ORACLE's pairwise align_channel_affine: nine targets = two groups of
+    four + one, every transform, star count and inlier count.  (Round 5 held this path to its own superseded forms only.)"""
+    ref, tgts = _grouped_case(shape)
+    before = ctx.fallback_counts()
+    new = ctx.register_frames(ref, tgts, num_threads=8)
+    _holds_to_the_oracle(oracle, ref, tgts, new)
+    assert sum(a.method in ("affine", "rigid") for a in new) >= 7
+    after = ctx.fallback_counts()
+    assert after["frames_redone"] == before["frames_redone"], "an ordinary star field must not need the full path"
+
+
+@pytest.mark.parametrize("shape", [(512, 640), (257, 1000), (515, 777)])
+def test_grouped_registration_equals_the_superseded_forms(ctx, ctx_r4_detect, ctx_midjoin, ctx_pixel_list, ctx_pixelwise, shape):
+    """DEVELOPER build only (the release library compiles these switches out): round 4's forms (AB_LABEL_LEGACY=1
+    AB_DETECT_FULL_RECORDS=1), the mid-join chain, the pixel-list chain and the pixel-by-pixel tile unions give IDENTICAL transforms,
+    star counts and inliers.  A self-comparison, kept as a bisecting aid: the evidence is the oracle test above."""
+    ref, tgts = _grouped_case(shape)
     new = ctx.register_frames(ref, tgts, num_threads=8)
     old = ctx_r4_detect.register_frames(ref, tgts, num_threads=8)
     mid = ctx_midjoin.register_frames(ref, tgts, num_threads=8)      # (the selection with a host join after the root numbering)
@@ -492,15 +523,15 @@ def test_grouped_registration_equals_round_4s_forms(ctx, ctx_r4_detect, ctx_midj
     pixw = ctx_pixelwise.register_frames(ref, tgts, num_threads=8)     # (tile-local unions pixel by pixel instead of run by run)
     for a, *others in zip(new, old, mid, plist, pixw):
         for b in others:
-            assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
-    assert sum(a.method in ("affine", "rigid") for a in new) >= 7
+            assert _same_registration(a, b)
 
 
-def test_crowded_tiles_and_stars_on_tile_corners(ctx, ctx_r4_detect, ctx_pixel_list):
+def test_crowded_tiles_and_stars_on_tile_corners(ctx, oracle):
     """The records form of the tile labelling (one record per tile-local component, 64 slots per 32 x 128 tile): (i) stars centred on
     tile CORNERS are four tile-local components whose records comp_merge folds into one; (ii) a patch of 3-pixel components on a
     4-pixel lattice puts ~250 components into one tile -- more than its slots: the frame's overflow flag is raised and the host
-    redoes it through the full path.  Transforms, star counts and inliers must equal round 4's forms and the pixel-list chain."""
+    redoes it through the full path (the context COUNTS that: ab_ctx_fallback_counts).  Transforms, star counts and inliers must equal
+    the oracle's; on a developer build also round 4's forms and the pixel-list chain."""
     import torch
     from astroburst_amd import synth
     rows, cols = 512, 640
@@ -519,13 +550,22 @@ def test_crowded_tiles_and_stars_on_tile_corners(ctx, ctx_r4_detect, ctx_pixel_l
                 t[yy, xx + 1] += 7000.0
                 t[yy + 1, xx] += 7000.0
     ref, tgts = ref.cuda(), [t.cuda() for t in tgts]
+    before = ctx.fallback_counts()
     new = ctx.register_frames(ref, tgts, num_threads=8)
-    old = ctx_r4_detect.register_frames(ref, tgts, num_threads=8)
-    plist = ctx_pixel_list.register_frames(ref, tgts, num_threads=8)
-    for a, b, c in zip(new, old, plist):
-        assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (b.method, b.matched_stars, b.inliers, b.transform, b.residual_px)
-        assert (a.method, a.matched_stars, a.inliers, a.transform, a.residual_px) == (c.method, c.matched_stars, c.inliers, c.transform, c.residual_px)
+    after = ctx.fallback_counts()
+    _holds_to_the_oracle(oracle, ref, tgts, new)
     assert sum(a.method in ("affine", "rigid") for a in new) >= 5
+    assert after["tile_slots"] - before["tile_slots"] == 2 and after["frames_redone"] - before["frames_redone"] == 2, (before, after)
+    import astroburst_amd as ab
+    if ab.is_dev_build():
+        from conftest import _ctx_under
+        for env in ({"AB_LABEL_LEGACY": "1", "AB_DETECT_FULL_RECORDS": "1"}, {"AB_DETECT_NO_RECS": "1"}):
+            c = _ctx_under(env)
+            try:
+                for a, b in zip(new, c.register_frames(ref, tgts, num_threads=8)):
+                    assert _same_registration(a, b), env
+            finally:
+                c.close()
 
 
 def test_ctx_trim_releases_and_the_context_keeps_working(oracle):

@@ -222,7 +222,7 @@ def test_bench_copy_probe_copies(ctx, n):
     assert torch.equal(b[:n], a) and bool((b[n:] == -1.0).all())
 
 
-def test_stats_resident_abort_falls_back_to_the_chain(ctx, oracle):
+def test_stats_resident_abort_falls_back_to_the_chain(ctx, oracle, dev_build):
     """A grid barrier of the one-kernel engine that cannot complete raises an abort flag; the host then runs the chain.  The test
     hook raises the flag before the launch: statistics and stretched bytes must still be the oracle's."""
     import torch
@@ -247,7 +247,7 @@ def test_stats_resident_abort_falls_back_to_the_chain(ctx, oracle):
 
 
 @pytest.mark.parametrize("barrier", [1, 2, 3, 4, 5, 6, 7])
-def test_stats_resident_timeout_after_arrival_at_any_barrier(ctx, oracle, barrier):
+def test_stats_resident_timeout_after_arrival_at_any_barrier(ctx, oracle, barrier, dev_build):
     """A workgroup that times out at a barrier AFTER publishing its arrival there lets its peers pass.  At the LAST barrier of a
     launch they then run to the end without it, and with the completion marker written by workgroup 0 alone (round 3) the host took
     a preview with an unwritten tile for complete.  The hook makes the last workgroup do exactly that at its `barrier`-th barrier

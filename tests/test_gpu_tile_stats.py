@@ -111,7 +111,7 @@ def test_normalised_frame_tiles(ctx, oracle):
     check(ctx, oracle, frame, 128)
 
 
-def test_round1_kernel_behind_ab_tile_legacy():
+def test_round1_kernel_behind_ab_tile_legacy(dev_build):
     """AB_TILE_LEGACY=1 (read once per process) selects round 1's radix-select tile kernel: same per-tile answers.
     Run in a child process so that both kernels are exercised by one `pytest -m gpu`."""
     import os

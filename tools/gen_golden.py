@@ -176,6 +176,130 @@ def build():
     d["bicubic"] = np.asarray([o.bicubic_sample(src, 37, 41, yy, xx) for yy, xx in pts])
     d["bilinear"] = np.asarray([o.bilinear_sample(src, 37, 41, yy, xx) for yy, xx in pts])
     out["resample"] = d
+
+    # ==== round 6: rows whose only pins were same-author restatements get FROZEN arrays too, so that an edit
+    # which moves oracle/*.c and the kernels together no longer goes unseen ===================================================
+
+    # ---- a6  core/alignment/affine.rs:129-212 (+ :400-642 the fits / RANSAC) ---------------------------------------------------
+    d = {}
+    import math
+    r6 = np.random.default_rng(606)
+    ref_xy = np.column_stack([r6.uniform(20, 1180, 90), r6.uniform(20, 980, 90)])
+    ang = math.radians(-0.8)
+    ca, sa = math.cos(ang), math.sin(ang)
+    tgt_xy = np.column_stack([ca * ref_xy[:, 0] - sa * ref_xy[:, 1] - 21.0, sa * ref_xy[:, 0] + ca * ref_xy[:, 1] + 6.5]) + r6.normal(0, 0.1, ref_xy.shape)
+    tgt_xy = tgt_xy[r6.permutation(90)][:70]                         # 20 stars missing in the target, order shuffled
+    d["stars_ref_xy"], d["stars_tgt_xy"] = ref_xy, tgt_xy
+    d["stars_dims"] = np.asarray([1000, 1200], np.int64)
+    for nt in (1, 8):
+        a = o.affine_from_stars(ref_xy, tgt_xy, 1000, 1200, num_threads=nt)
+        d[f"stars_t{nt}_transform"] = np.asarray(a.transform)
+        d[f"stars_t{nt}_counts"] = np.asarray([a.matched_stars, a.inliers, o.AFFINE_METHODS.index(a.method)], np.int64)
+        d[f"stars_t{nt}_residual"] = np.asarray([a.residual_px])
+    y, x, flux = synth.star_catalog(256, 320, 160, seed=66)
+    cat = (y, x, flux * 30.0)
+    pair_ref = synth.make_frame(256, 320, 0, cat=cat, bad_patch_rate=0.0, cosmic_rate=0.0).numpy()
+    pair_tgt = synth.make_frame(256, 320, 1, cat=cat, shift=(2.5, -1.75), bad_patch_rate=0.0, cosmic_rate=0.0).numpy()
+    d["pair_ref"], d["pair_tgt"] = pair_ref, pair_tgt
+    a = o.align_channel_affine(pair_ref, pair_tgt, num_threads=8)
+    d["pair_transform"] = np.asarray(a.transform)
+    d["pair_counts"] = np.asarray([a.matched_stars, a.inliers, o.AFFINE_METHODS.index(a.method)], np.int64)
+    d["pair_residual"] = np.asarray([a.residual_px])
+    d["pair_warped_checksum"] = np.asarray([int(o.warp_image(pair_tgt, a.transform, 256, 320).view(np.uint32).astype(np.uint64).sum())], np.uint64)
+    out["affine"] = d
+
+    # ---- a12  core/imaging/background.rs:118-290 ---------------------------------------------------------------------------------
+    d = {}
+    yy, xx = np.mgrid[0:96, 0:128]
+    ny, nx = yy / 96 - 0.5, xx / 128 - 0.5
+    sky = 300.0 + 80.0 * ny - 40.0 * nx + 60.0 * ny * nx + 35.0 * nx * nx + r6.normal(0, 3.0, (96, 128))
+    for _ in range(12):
+        cy, cx, amp, sg = r6.uniform(0, 96), r6.uniform(0, 128), r6.uniform(200, 20000), r6.uniform(1.0, 3.0)
+        sky += amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sg * sg))
+    sky = sky.astype(np.float32)
+    sky[5, 7:30] = np.nan
+    sky[48, 40] = np.inf
+    sky[30, 64] = -np.inf
+    d["img"] = sky
+    for tag, kw in (("sub_g4_d2", dict(grid_size=4, poly_degree=2, sigma_clip=2.5, iterations=3, mode=0)),
+                    ("div_g6_d1", dict(grid_size=6, poly_degree=1, sigma_clip=3.0, iterations=2, mode=1))):
+        b = o.extract_background(sky, **kw)
+        d[f"{tag}_cfg"] = np.asarray([kw["grid_size"], kw["poly_degree"], kw["sigma_clip"], kw["iterations"], kw["mode"]], np.float64)
+        d[f"{tag}_coeffs"] = np.asarray(b.coeffs, np.float64)
+        d[f"{tag}_model"], d[f"{tag}_corrected"] = b.model, b.corrected
+        d[f"{tag}_scalars"] = np.asarray([float(b.sample_count), b.rms_residual])
+    out["background"] = d
+
+    # ---- a13  core/imaging/star_mask.rs:38-138, masked_stretch.rs:60-118 -----------------------------------------------------
+    d = {}
+    field = r6.normal(0.02, 0.002, (120, 160))
+    sig = 3.5 / 2.3548
+    yy, xx = np.mgrid[0:120, 0:160]
+    for _ in range(25):
+        cy, cx, amp = r6.uniform(8, 112), r6.uniform(8, 152), r6.uniform(0.05, 0.9)
+        field += amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sig * sig))
+    field = field.clip(1e-5, None).astype(np.float32)
+    field[0, 0], field[1, 1], field[2, 2] = np.nan, -1.0, np.inf
+    mstars = np.asarray([(r6.uniform(0, 160), r6.uniform(0, 120), r6.uniform(1.5, 8.0)) for _ in range(20)]
+                        + [(-30.0, -30.0, 5.0), (400.0, 100.0, 5.0), (60.0, 60.0, 31.0), (100.0, 50.0, 1.0)])   # outside / FWHM out of range
+    d["img"], d["stars_xyf"] = field, mstars
+    mk = o.generate_star_mask(field, stars=[tuple(s) for s in mstars], luminance_protect=True, luminance_ceiling=0.85)
+    d["mask"] = mk.mask
+    d["mask_scalars"] = np.asarray([float(mk.stars_masked), mk.coverage_fraction])
+    for tag, cfg in (("default", dict()), ("hard", dict(iterations=25, target_background=0.4, protection_amount=0.3, convergence_threshold=1e-7))):
+        ms = o.masked_stretch(field, mask=mk, **cfg)
+        d[f"{tag}_image"] = ms.image
+        d[f"{tag}_scalars"] = np.asarray([float(ms.iterations_run), ms.final_background, float(ms.converged), float(ms.stars_masked), ms.mask_coverage])
+    out["masked"] = d
+
+    # ---- a18  core/astrometry/spcc.rs:328-435 (after the detection: apertures, cross-match on the synthetic catalogue, factors) ---
+    d = {}
+    planes = [np.full((160, 200), 0.02, np.float64) for _ in range(3)]
+    sig = 3.2 / 2.3548
+    for _ in range(45):
+        cy, cx, amp = r6.uniform(15, 145), r6.uniform(15, 185), r6.uniform(0.05, 0.6)
+        col = r6.uniform(0.7, 1.3, 3)
+        y0, x0 = int(cy) - 12, int(cx) - 12
+        yy, xx = np.mgrid[y0:y0 + 25, x0:x0 + 25]
+        psf = amp * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sig * sig))
+        for c, gain in enumerate((1.4, 1.0, 0.7)):
+            planes[c][y0:y0 + 25, x0:x0 + 25] += psf * col[c] * gain
+    rgb = [(p + r6.normal(0, 0.0008, p.shape)).astype(np.float32) for p in planes]
+    lum = (np.float32(0.2126) * rgb[0] + np.float32(0.7152) * rgb[1]) + np.float32(0.0722) * rgb[2]
+    sp_stars, _, _ = o.detect_stars(lum, 5.0)
+    lum_max = o.compute_image_stats(lum).max
+    d["r"], d["g"], d["b"] = rgb
+    d["stars"] = np.asarray([[s.x, s.y, s.flux, s.fwhm, s.eccentricity, s.peak, s.snr, float(s.npix)] for s in sp_stars])
+    d["lum_max"] = np.asarray([lum_max])
+    for white in ("average_spiral", "g2v"):
+        res = o.spcc_calibrate_rgb(*rgb, 1.2, detection=(sp_stars, lum_max), min_snr=15.0, max_stars=150, saturation_limit=0.95, white_reference=white)
+        d[f"{white}_factors"] = np.asarray([res.r_factor, res.g_factor, res.b_factor, res.avg_color_index])
+        d[f"{white}_counts"] = np.asarray([res.stars_matched, res.stars_total], np.int64)
+    out["spcc"] = d
+
+    # ---- f2  core/imaging/calibration_pipeline.rs:317-378 (median / MAD every iteration, strict <, per-frame rejection counts) -----
+    d = {}
+    for n in (5, 16, 33):
+        px = adversarial_pixels(r6, n, 384)
+        d[f"adv{n}_in"] = px
+        frames = [np.ascontiguousarray(px[f].reshape(12, 32)) for f in range(n)]
+        for (sl, sh, it) in ((2.5, 3.0, 5), (1.0, 1.0, 2)):
+            img, rej = o.sigma_clipped_mean_stack(frames, sl, sh, it)
+            d[f"adv{n}_{sl}_{sh}_{it}_out"] = img
+            d[f"adv{n}_{sl}_{sh}_{it}_rej"] = np.asarray(rej, np.int64)
+    lights = [r6.normal(400 + 3 * k, 12, (24, 40)).astype(np.float32) for k in range(9)]
+    lights[2][r6.random((24, 40)) < 0.05] += 500.0
+    lights[1][5, 5] = np.nan
+    bias = r6.normal(100, 2, (24, 40)).astype(np.float32)
+    flat = r6.normal(1.0, 0.05, (24, 40)).astype(np.float32)
+    flat[3, 3] = 0.0
+    d["lights"], d["bias"], d["flat"] = np.stack(lights), bias, flat
+    for normalize in (True, False):
+        img, rej, mean, std = o.run_batch_channel(lights, bias, None, flat, normalize=normalize)
+        d[f"channel_norm{int(normalize)}_out"] = img
+        d[f"channel_norm{int(normalize)}_rej"] = np.asarray(rej, np.int64)
+        d[f"channel_norm{int(normalize)}_stats"] = np.asarray([mean, std])
+    out["batch"] = d
     return out
 
 
