@@ -360,8 +360,10 @@ def lib() -> C.CDLL:
     L.ab_stack_sigma_clip_rows.argtypes = [vp, pp, C.c_size_t, C.POINTER(StackConfig), C.c_int64, pp, u64p]
     L.ab_stack_sigma_clip_rowband.argtypes = [vp, vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, u64p]
     L.ab_stack_sigma_clip_sharded.argtypes = [vp, vp, pp, C.c_size_t, C.POINTER(StackConfig), pp, u64p]
+    L.ab_stack_sharded_last_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ab_allgather_rows.argtypes = [vp, vp, pp, pp]
     L.ab_register_frames_sharded.argtypes = [vp, vp, pp, pp, C.c_size_t, C.c_int, C.POINTER(AffineAlignResultC)]
+    L.ab_align_pairs_affine_rowband.argtypes = [vp, vp, pp, pp, C.POINTER(C.c_int64), C.c_size_t, C.c_int, C.c_int64, C.POINTER(AffineAlignResultC), pp]
     L.ab_compute_image_stats_sharded.argtypes = [vp, vp, pp, C.c_int64, C.POINTER(ImageStatsC)]
     L.ab_warp_image_rows.argtypes = [vp, pp, C.POINTER(C.c_double), C.c_int64, C.c_int64, pp]
     L.ab_warp_image_rows_from_band.argtypes = [vp, pp, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.c_int64, C.c_int64, pp]

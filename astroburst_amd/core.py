@@ -329,7 +329,7 @@ class Context:
         self._check(self._L.ab_ctx_trim(self._h))
 
     FALLBACK_KINDS = ("frames_redone", "tile_slots", "component_table", "selection_short", "selection_cut", "tiles_declined",
-                      "stats_chain", "stack_general_pixels")   # ab_fallback_kind, include/astroburst_hip.h
+                      "stats_chain", "stack_general_pixels", "label_tiles_dense")   # ab_fallback_kind, include/astroburst_hip.h
 
     def fallback_counts(self, reset: bool = False) -> dict:
         """How often a fast path handed over to its exact fallback (same results, more time) since the context was created or last
@@ -527,6 +527,13 @@ class Context:
                                                         C.byref(po), C.byref(rej) if want_rejected else None))
         return out, (int(rej.value) if want_rejected else None)
 
+    def stack_sharded_last_ms(self):
+        """(span of the partial stacks on the context's stream, time inside the all-reduces + divisions on the comm stream) of the last
+        stack_sigma_clip_sharded; blocks until that call's work is done"""
+        a, b = C.c_float(0.0), C.c_float(0.0)
+        self._check(self._L.ab_stack_sharded_last_ms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
     def allgather_rows(self, comm, band, full):
         keep = []
         pb = Plane(C.c_void_p(band.data_ptr() if band.numel() else 0), band.shape[0], band.shape[1], 1)
@@ -543,6 +550,26 @@ class Context:
         self._check(self._L.ab_register_frames_sharded(self._h, comm._h if comm else None, C.byref(pr), planes, len(targets), num_threads, res))
         return [AffineAlignResult(tuple(r.transform), int(r.matched_stars), int(r.inliers), r.residual_px, AFFINE_METHODS[r.method])
                 for r in res[:len(targets)]]
+
+    def align_pairs_affine_rowband(self, comm, reference, targets, out_bands, row0: int, target_row0=None, num_threads: int = 8):
+        """the row-band scheme's registration as one call: this rank's rows [row0, row0 + band rows) of every registered frame;
+        targets[i] = rows [target_row0[i], ...) of target i (whole for i mod size == rank); own frames are warped as they are fitted"""
+        keep = []
+        pr = self._plane(reference, keep)
+        n = len(targets)
+        planes = (Plane * max(n, 1))()
+        for i, t in enumerate(targets):
+            if t.numel() == 0:
+                planes[i] = Plane(C.c_void_p(0), 0, reference.shape[1], 1)
+            else:
+                planes[i] = self._plane(t, keep)
+        outs = (Plane * max(n, 1))()
+        for i, o in enumerate(out_bands):
+            outs[i] = Plane(C.c_void_p(o.data_ptr() if o.numel() else 0), o.shape[0], o.shape[1], 1)
+        t0 = (C.c_int64 * max(n, 1))(*[int(v) for v in (target_row0 if target_row0 is not None else [0] * n)]) if n else None
+        res = (_lib.AffineAlignResultC * max(n, 1))()
+        self._check(self._L.ab_align_pairs_affine_rowband(self._h, comm._h if comm else None, C.byref(pr), planes, t0, n, num_threads, row0, res, outs))
+        return [AffineAlignResult(tuple(r.transform), int(r.matched_stars), int(r.inliers), r.residual_px, AFFINE_METHODS[r.method]) for r in res[:n]]
 
     def compute_image_stats_sharded(self, comm, band, total_rows: int) -> ImageStats:
         keep = []

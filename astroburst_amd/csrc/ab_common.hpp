@@ -52,6 +52,7 @@ enum {
     AB_WS_STACK_DEEP,         // plane tables + per-workgroup sample segments of a > 4096-frame stack (stack_deep.hip)
     AB_WS_BATCH_DEEP,         // the same for the batch stack (batch_pipeline.hip)
     AB_WS_STACK_SHIFTED,      // the registered copies of stack_images(align = true)'s frames 1 .. n - 1 (stack_images.hip)
+    AB_WS_DETECT_CAND,        // the candidate lists the tile pass of a registration batch leaves for the labelling pass (detect.hip: TileCand)
     AB_WS_SLOTS
 };
 
@@ -115,6 +116,13 @@ struct ab_ctx {
     hipEvent_t stack_ev[2] = {nullptr, nullptr};
     bool stack_ev_valid = false;
     hipEvent_t switch_ev = nullptr;  // orders the stream being left before the one switched to (ab_ctx_set_stream)
+    // the frame-sharded stack in row chunks (sharded.hip): chunk k's all-reduces + division run on comm_stream while chunk k + 1 is
+    // stacked on the context's stream; shard_ev[2 k] = chunk k stacked, [2 k + 1] = chunk k reduced; shard_tm = timing events
+    // {first partial starts, last partial done} on the context's stream and {begin, end} per chunk on comm_stream
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> shard_ev, shard_tm;
+    int shard_chunks_timed = 0;
+    bool stack_keep_counters = false;  // ab_stack_device: do not clear the rejection counters / restart the stack events (chunks 2 .. K of one stack)
     // the background-tile pipeline of a registration batch (detect.hip: ab_bg_pipeline_*): its own stream, one event per chunk
     // of frames, its own pinned result buffer (the context's general one may be reallocated by the reference's detection)
     hipStream_t aux_stream = nullptr;
@@ -317,8 +325,10 @@ int ab_stats_enqueue(ab_ctx *ctx, ab_comm *comm, const float *data, int64_t n, i
 // apply_stf -> u8 with the transform (StfTx) read from device memory
 int ab_stf_u8_device_tx(ab_ctx *ctx, const float *in, int64_t n, const void *tx_dev, uint8_t *out);
 // detect_stars of G frames of one size in lockstep (one launch per step for all of them); bg[f] = {median, sigma} of frame f's background
+struct ab_frame_cand;
 int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, int64_t rows, int64_t cols, double sigma_threshold, const ab_pixel_xf *xf,
-                                 const double (*bg)[2], size_t max_keep, std::vector<ab_detected_star> *stars /* [G] */);
+                                 const double (*bg)[2], size_t max_keep, std::vector<ab_detected_star> *stars /* [G] */,
+                                 const struct ab_frame_cand *cand = nullptr /* [G], nullable: the frames' candidate lists (ab_bg_pipeline_cand) */);
 int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, int64_t ld, double sigma_threshold,
                            std::vector<ab_detected_star> *stars, double *bg_median_out, double *bg_sigma_out,
                            ab_pixel_xf xf = ab_pixel_xf(), size_t max_keep = (size_t)-1 /* only the brightest max_keep stars are wanted */,
@@ -336,14 +346,37 @@ struct ab_bg_pipeline {
     size_t n = 0;
     const ab_pixel_xf *xf_host = nullptr;  // fed pipeline: plane i's transform, valid once ab_bg_pipeline_get(i) has returned
     struct ab_bg_feed_impl *feed = nullptr;  // the feeder thread of a pipeline whose planes are still landing (detect.hip)
+    // the candidate lists of plane i's tiles (DEVICE; valid once ab_bg_pipeline_get(i) has returned): entries at cand_ent + (i * ntiles
+    // + tile) * cand_cap (uint2 {position in the tile, raw bits}), counts / cuts at [i * ntiles + tile].  nullptr: the pipeline left none
+    // (tiles smaller than 256 px).  detect.hip: label_bgtile_body
+    void *cand_ent = nullptr;
+    unsigned int *cand_cnt = nullptr;
+    float *cand_cut = nullptr;
+    int cand_step = 0;  // the background tile's edge (256)
 };
+// plane i's lists, as ab_detect_stars_group_device takes them
+struct ab_frame_cand {
+    const void *ent = nullptr;
+    const unsigned int *cnt = nullptr;
+    const float *cut = nullptr;
+};
+static inline ab_frame_cand ab_bg_pipeline_cand(const ab_bg_pipeline *p, size_t i) {
+    ab_frame_cand c;
+    if (p && p->on && p->cand_ent) {
+        c.ent = (const char *)p->cand_ent + i * (size_t)p->ntiles * (size_t)2048 * 8u;  // (kCandCap entries of 8 bytes: detect.hip)
+        c.cnt = p->cand_cnt + i * (size_t)p->ntiles;
+        c.cut = p->cand_cut + i * (size_t)p->ntiles;
+    }
+    return c;
+}
 void ab_bg_pipeline_end(ab_bg_pipeline *p);  // joins the feeder, if any (before the streams are drained / the planes released)
 // the pipeline fed chunk by chunk: the percentiles run per chunk on the device (no host join before the first tile launch); with
 // `landed` events (nullable; a null entry = the plane is complete already) a feeder thread enqueues a chunk when its planes have landed
+// want_cand: whole 256-px tiles also leave their candidate lists (ab_bg_pipeline_cand) for the labelling pass of a registration batch
 int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, int chunk, const hipEvent_t *landed,
-                             ab_bg_pipeline *p);
+                             ab_bg_pipeline *p, bool want_cand = false);
 int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, const ab_pixel_xf *xf, int chunk,
-                         ab_bg_pipeline *p);
+                         ab_bg_pipeline *p, bool want_cand = false);
 int ab_bg_pipeline_get(ab_ctx *ctx, const ab_bg_pipeline *p, size_t i, double *bg /* [2] */);
 // the percentile normalisation's parameters (xf->on = 0 where the reference returns image.clone())
 int ab_normalize_params_device(ab_ctx *ctx, const float *img, int64_t len, ab_pixel_xf *xf);
@@ -355,6 +388,10 @@ int ab_phase_correlate_device(ab_ctx *ctx, const float *ref, int64_t ref_rows, i
 int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
                                    ab_affine_align_result *out);
 int ab_shift_device(ab_ctx *ctx, const float *src, int64_t rows, int64_t cols, int64_t src_ld, double dy, double dx, float *out);
+// affine.hip: align_channel_affine of n device-resident targets against one reference, optionally with the registered copies (whole
+// frames, or rows [band_row0, band_row0 + band_rows) of them when band_rows >= 0) written as each frame is fitted
+int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const *targets, size_t n, int64_t rows, int64_t cols, int num_threads,
+                              ab_affine_align_result *out, float *const *aligned, const hipEvent_t *landed, int64_t band_row0, int64_t band_rows);
 int ab_warp_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,
                    int64_t out_cols, float *out);
 int ab_warp_rows_device(ab_ctx *ctx, const float *src, int64_t src_rows, int64_t src_cols, const double t[6], int64_t out_rows,

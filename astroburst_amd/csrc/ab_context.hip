@@ -156,6 +156,9 @@ void ab_ctx_destroy(ab_ctx *ctx) {
     for (hipEvent_t e : ctx->stack_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->switch_ev) (void)hipEventDestroy(ctx->switch_ev);
+    for (hipEvent_t e : ctx->shard_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->shard_tm) (void)hipEventDestroy(e);
+    if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
     for (hipEvent_t e : ctx->aux_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pct_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->upload_events) (void)hipEventDestroy(e);
@@ -178,7 +181,7 @@ void ab_ctx_destroy(ab_ctx *ctx) {
 int ab_ctx_trim(ab_ctx *ctx) try {
     if (!ctx) return AB_ERR_INVALID;
     AB_HIP(ctx, hipSetDevice(ctx->device));
-    for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->pct_stream, ctx->warp_stream, ctx->upload_stream})
+    for (hipStream_t st : {ctx->stream, ctx->aux_stream, ctx->pct_stream, ctx->warp_stream, ctx->upload_stream, ctx->comm_stream})
         if (st || st == ctx->stream) AB_HIP(ctx, hipStreamSynchronize(st));
     // Every buffer is forgotten BEFORE its release is checked and every slot is visited whatever an earlier release returned
     // (an early return left dangling pointers and untrimmed slots); the first failure is what the call reports, with

@@ -965,7 +965,7 @@ int gpu_match_group(ab_ctx *ctx, const MatchWs &ref_ws, const std::vector<Pt> *s
 
 // normalize_for_detection + detect_stars(3.5 sigma) + top_n_stars of one frame (:134-160)
 int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::vector<Pt> *out, const ab_pixel_xf *xf = nullptr,
-                const double *bg = nullptr) {
+                const double *bg = nullptr, const ab_frame_cand *cand = nullptr /* the frame's candidate lists, if its tiles left any */) {
     std::vector<ab_detected_star> stars;
     double m, s;
     // the normalised frame is never materialised: detection applies the transform on load.  xf: the frame's transform if the
@@ -976,7 +976,7 @@ int frame_stars(ab_ctx *ctx, const float *img, int64_t rows, int64_t cols, std::
         // list of C3's reference frame, ~100 000 components, cost 3.8 ms of moments at the head of every call).  Same stars:
         // tests/test_gpu_detect_affine.py holds the grouped form to the frame-by-frame one.
         const double b2[1][2] = {{bg[0], bg[1]}};
-        AB_TRY(ab_detect_stars_group_device(ctx, &img, 1, rows, cols, kDetectionSigma, xf, b2, kMaxStars, &stars));
+        AB_TRY(ab_detect_stars_group_device(ctx, &img, 1, rows, cols, kDetectionSigma, xf, b2, kMaxStars, &stars, cand));
     } else {
         AB_TRY(ab_detect_stars_device(ctx, img, rows, cols, cols, kDetectionSigma, &stars, &m, &s, xf ? *xf : ab_pixel_xf(), kMaxStars,
                                       /*normalize_first=*/xf == nullptr, xf ? bg : nullptr));  // top_n_stars (:272-277)
@@ -1063,7 +1063,8 @@ static int register_one(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const f
 // the host geometry frame by frame in between.  out / xf are indexed by frame, bg by position in the group.
 static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const float *ref, const float *const *targets, const size_t *frames, int G,
                           int64_t rows, int64_t cols, int num_threads, ab_affine_align_result *out, const ab_pixel_xf *xfs, const double (*bg)[2],
-                          const std::function<int(size_t)> &frame_done /* called with a frame's index as soon as out[frame] is final */) {
+                          const std::function<int(size_t)> &frame_done /* called with a frame's index as soon as out[frame] is final */,
+                          const ab_frame_cand *cands = nullptr /* [G], by position in the group */) {
     const float *imgs[kTriGroupMax];
     ab_pixel_xf xf[kTriGroupMax];
     for (int k = 0; k < G; ++k) {
@@ -1072,7 +1073,7 @@ static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const
     }
     std::vector<ab_detected_star> det[kTriGroupMax];
     ab_upload_trace("group starts detection, first frame", (long)frames[0]);
-    AB_TRY(ab_detect_stars_group_device(wc, imgs, G, rows, cols, kDetectionSigma, xf, bg, kMaxStars, det));
+    AB_TRY(ab_detect_stars_group_device(wc, imgs, G, rows, cols, kDetectionSigma, xf, bg, kMaxStars, det, cands));
     ab_upload_trace("group detected, first frame", (long)frames[0]);
     std::vector<Pt> ts[kTriGroupMax];
     for (int k = 0; k < G; ++k)
@@ -1095,6 +1096,8 @@ static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const
             std::vector<uint32_t> votes[kTriGroupMax];
             AB_TRY(gpu_match_group(wc, ref_ws, live, G, votes));
             ab_upload_trace("group votes back, first frame", (long)frames[0]);
+            // (Round 6, measured and not kept: fitting the group's frames side by side on helper threads -- 0.6 -> 0.16 ms of host
+            // arithmetic per group -- moved the step by 0.04 ms, inside the noise: the chains are not what the call waits for.)
             for (int k = 0; k < G; ++k) {
                 if (live[k].empty()) continue;
                 const auto matches = matches_from_votes(rs, ts[k], votes[k].data(), kVoteDim);
@@ -1130,9 +1133,16 @@ static int register_group(ab_ctx *wc, const MatchWs &ref_ws, RefTable &rt, const
 // ctx->register_workers host threads, each driving its own HIP stream and workspaces (child contexts cached in
 // ctx): one frame's host geometry overlaps the other frames' GPU passes.  Results do not depend on the worker
 // count (each out[i] equals a stand-alone align_channel_affine(reference, targets[i])).
+// band_rows >= 0 (round 6, the row-band scheme): aligned[f] holds rows [band_row0, band_row0 + band_rows) of warp_image(target f, transform)
+// only -- a rank warps ITS rows of a frame the moment the frame is fitted, overlapped with the other frames' estimates like the full warps.
 int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const *targets, size_t n, int64_t rows, int64_t cols, int num_threads,
                               ab_affine_align_result *out, float *const *aligned /* nullable: warp_image(target, transform) per target */,
-                              const hipEvent_t *landed /* nullable: per target, the event after which its pixels are in HBM (an upload in flight) */) {
+                              const hipEvent_t *landed /* nullable: per target, the event after which its pixels are in HBM (an upload in flight) */,
+                              int64_t band_row0, int64_t band_rows) {
+    auto warp_out = [&](ab_ctx *wc, size_t f) -> int {
+        if (band_rows >= 0) return ab_warp_rows_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, band_row0, band_rows, aligned[f]);
+        return ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]);
+    };
     AB_HIP(ctx, hipSetDevice(ctx->device));
     if (ab_upload_trace_on() && !landed) ab_trace_t0() = std::chrono::steady_clock::now();  // (a host-fed call has set it)
     MatchWs w;
@@ -1160,6 +1170,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     // measured on the bench stack, same box, 12.99 ms for the stage against 13.34 fed (sixteen more launches in the tile stream's
     // way).  AB_PIPE_FED=1 feeds them too (the GPU tests hold the two orders to the same transforms).
     static const bool force_fed = ab_dev_env("AB_PIPE_FED") != nullptr;
+    static const bool want_cand = ab_dev_env("AB_NO_CAND_LISTS") == nullptr;  // (developer A/B: the labelling reads the frames as in round 5)
     const bool fed = have_xf && (landed != nullptr || force_fed);
     if (fed) {
         static const int chunk = ab_dev_env("AB_TILE_CHUNK") ? std::max(atoi(ab_dev_env("AB_TILE_CHUNK")), 1) : 8;
@@ -1174,7 +1185,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         }
         xfs.resize(n + 1);
         AB_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's frames are complete before any other stream reads them
-        AB_TRY(ab_bg_pipeline_begin_fed(ctx, order.data(), n + 1, rows, cols, landed ? fed_chunk : chunk, landed ? ev.data() : nullptr, &pipe));
+        AB_TRY(ab_bg_pipeline_begin_fed(ctx, order.data(), n + 1, rows, cols, landed ? fed_chunk : chunk, landed ? ev.data() : nullptr, &pipe, want_cand));
         if (!pipe.on && landed)  // (planes too small for tiles, AB_TILE_LEGACY: the frames are waited for and the batch takes the path below)
             for (size_t i = 0; i < n; ++i)
                 if (landed[i]) AB_HIP(ctx, hipEventSynchronize(landed[i]));
@@ -1197,7 +1208,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
                 order.push_back(targets[i]);
                 oxf.push_back(xfs[i]);
             }
-            AB_TRY(ab_bg_pipeline_begin(ctx, order.data(), n + 1, rows, cols, oxf.data(), chunk, &pipe));
+            AB_TRY(ab_bg_pipeline_begin(ctx, order.data(), n + 1, rows, cols, oxf.data(), chunk, &pipe, want_cand));
             ab_upload_trace("tile launches enqueued, planes", (long)(n + 1));
         }
     }
@@ -1205,7 +1216,8 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         double bg[2];
         if (pipe.on) AB_TRY(ab_bg_pipeline_get(ctx, &pipe, 0, bg));
         if (pipe.xf_host) xfs[n] = pipe.xf_host[0];
-        AB_TRY(frame_stars(ctx, ref, rows, cols, &rt.stars, have_xf ? &xfs[n] : nullptr, pipe.on ? bg : nullptr));
+        const ab_frame_cand ref_cand = ab_bg_pipeline_cand(&pipe, 0);
+        AB_TRY(frame_stars(ctx, ref, rows, cols, &rt.stars, have_xf ? &xfs[n] : nullptr, pipe.on ? bg : nullptr, &ref_cand));
         if (rt.stars.size() < kMinMatchesRigid) return AB_OK;
         // reference table: built, bucketed by ratio_mid and ordered by ratio_long inside the buckets on the GPU
         AB_TRY(gpu_build_triangles(ctx, w, rt.stars, 0));
@@ -1224,7 +1236,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
             // next frame does not queue up behind it on the worker's own stream
             hipStream_t keep = wc->stream;
             if (warp_stream) wc->stream = warp_stream;
-            const int rc = ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]);
+            const int rc = warp_out(wc, f);
             wc->stream = keep;
             if (rc != AB_OK) return rc;
         }
@@ -1242,30 +1254,36 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     auto one_group = [&](ab_ctx *wc, size_t gi) -> int {
         size_t frames[kTriGroupMax];
         double bgs[kTriGroupMax][2];
+        ab_frame_cand cands[kTriGroupMax];
         const size_t f0 = gi * (size_t)kGroup;
         const int G = (int)std::min<size_t>((size_t)kGroup, n - f0);
         for (int k = 0; k < G; ++k) {
             frames[k] = f0 + (size_t)k;
             AB_TRY(ab_bg_pipeline_get(wc, &pipe, frames[k] + 1, bgs[k]));
+            cands[k] = ab_bg_pipeline_cand(&pipe, frames[k] + 1);  // (complete: the plane's chunk has run)
             if (pipe.xf_host) xfs[frames[k]] = pipe.xf_host[frames[k] + 1];  // (each worker writes its own frames' entries)
         }
         const std::function<int(size_t)> warp_frame = [&](size_t f) -> int {
             if (!aligned) return AB_OK;  // pair.rs:59-61
             hipStream_t keep = wc->stream;
             if (warp_stream) wc->stream = warp_stream;
-            const int rc = ab_warp_device(wc, targets[f], rows, cols, out[f].transform, rows, cols, aligned[f]);
+            const int rc = warp_out(wc, f);
             wc->stream = keep;
             return rc;
         };
-        return register_group(wc, w, rt, ref, targets, frames, G, rows, cols, num_threads, out, xfs.data(), bgs, warp_frame);
+        return register_group(wc, w, rt, ref, targets, frames, G, rows, cols, num_threads, out, xfs.data(), bgs, warp_frame, cands);
     };
     const size_t n_jobs = grouped ? n_groups : n;
     const std::function<int(ab_ctx *, size_t)> job = grouped ? std::function<int(ab_ctx *, size_t)>(one_group) : std::function<int(ab_ctx *, size_t)>(one);
     const bool inline_run = std::min<size_t>(n_jobs, (size_t)std::max(ctx->register_workers, 1)) <= 1;
     static const bool own_warp_stream = ab_dev_env("AB_NO_WARP_STREAM") == nullptr;
+    // The warps run at LOW stream priority (round 6): they need nothing but a fitted transform and 4.35 ms of f64 issue slots, while
+    // every estimate kernel is on some group's chain to its fit.  Same box, interleaved, three runs each: 10.61 / 10.72 / 10.79 ms
+    // per step with the warp stream at normal priority, 10.40 / 10.49 / 10.37 at low (profiles/r06_priority_ab.txt); a HIGH-priority
+    // tile stream made it worse (10.82 / 10.78 / 10.92), both together no better than low warps alone.
     if (!inline_run && aligned && own_warp_stream) {
         if (!ctx->warp_stream) {
-        const hipError_t stream_rc = ab_stream_create_masked(ctx, &ctx->warp_stream, AB_DEV_NAME("AB_WARP_CU_MASK"), AB_DEV_NAME("AB_WARP_PRIO"), 0);  // (outside AB_HIP: its message would carry the developer variables' names)
+        const hipError_t stream_rc = ab_stream_create_masked(ctx, &ctx->warp_stream, AB_DEV_NAME("AB_WARP_CU_MASK"), AB_DEV_NAME("AB_WARP_PRIO"), 1);  // (outside AB_HIP: its message would carry the developer variables' names)
         AB_HIP(ctx, stream_rc);
     }
         warp_stream = ctx->warp_stream;
@@ -1296,7 +1314,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
 
 int ab_align_channel_affine_device(ab_ctx *ctx, const float *ref, const float *tgt, int64_t rows, int64_t cols, int num_threads,
                                    ab_affine_align_result *out) {
-    return ab_register_frames_device(ctx, ref, &tgt, 1, rows, cols, num_threads, out, nullptr, nullptr);
+    return ab_register_frames_device(ctx, ref, &tgt, 1, rows, cols, num_threads, out, nullptr, nullptr, 0, -1);
 }
 
 extern "C" {
@@ -1338,7 +1356,7 @@ int ab_register_frames(ab_ctx *ctx, const ab_plane *reference, const ab_plane *t
         if (rc != AB_OK) break;
         ptrs[staged] = st[staged].dptr;
     }
-    if (rc == AB_OK) rc = ab_register_frames_device(ctx, r.dptr, ptrs.data(), n, r.rows, r.cols, num_threads, out, nullptr, nullptr);
+    if (rc == AB_OK) rc = ab_register_frames_device(ctx, r.dptr, ptrs.data(), n, r.rows, r.cols, num_threads, out, nullptr, nullptr, 0, -1);
     for (size_t i = 0; i < staged && i < n; ++i) ab_stage_release(ctx, &st[i]);
     ab_stage_release(ctx, &r);
     return rc;
@@ -1362,7 +1380,7 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
         if (!targets[i].on_device) ++n_host;
     }
     if (n_host == 0 && reference->on_device)
-        return ab_register_frames_device(ctx, reference->data, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data(), nullptr);
+        return ab_register_frames_device(ctx, reference->data, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data(), nullptr, 0, -1);
     // Frames held by the HOST (as the application holds them: Array2<f32> in the image cache, calibration.rs:306-315): every host
     // frame is copied into an HBM staging area on the context's upload stream, an event behind each, all enqueued before anything
     // else; the registration's pipeline waits for a frame's event, not for the batch, so the link is busy from the first byte to the
@@ -1430,7 +1448,7 @@ int ab_align_pairs_affine(ab_ctx *ctx, const ab_plane *reference, const ab_plane
     if (up_trace) AB_HIP(ctx, hipEventRecord(tr1, ctx->upload_stream));
     const double enq_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
     const int rc = ab_register_frames_device(ctx, ref_dev, ptrs.data(), n, reference->rows, reference->cols, num_threads, out, outs.data(),
-                                             n_host ? landed.data() : nullptr);
+                                             n_host ? landed.data() : nullptr, 0, -1);
     ab_upload_trace("registration returned", (long)n);
     if (up_trace) {
         const double call_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();

@@ -51,6 +51,15 @@ struct FrameDev {
     unsigned int pad;
 };
 
+// the candidate lists a tile launch leaves for the labelling pass (tile_stream.hpp: CandSink), planes x tiles of the LAUNCH:
+// ent[(plane * tiles + tile) * kCandCap ..], cnt / cut[plane * tiles + tile].  ent == nullptr: no lists.
+constexpr int kCandCap = 2048;  // entries per 256 x 256 tile (~1000 on a sky tile at 2.5 sigma: the Gaussian tail + the stars' pixels)
+struct TileCand {
+    uint2 *ent = nullptr;
+    unsigned int *cnt = nullptr;
+    float *cut = nullptr;
+};
+
 // ---- per-tile sigma-clipped statistics ---------------------------------------------------------
 struct TileOut {
     double median, sigma;
@@ -175,6 +184,9 @@ __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(co
     const unsigned int nwork = fail ? fail[0] : 1u;
 #pragma unroll 1
     for (unsigned int wi = fail ? blockIdx.x : 0u; wi < nwork; wi += gridDim.x) {
+#ifdef AB_TILE_LOOP_SYNC
+        __syncthreads();
+#endif
         const float *__restrict__ img = img_arg;
         TileOut *__restrict__ out = out_arg;
         unsigned int tile = blockIdx.x, plane = blockIdx.y, per_plane = gridDim.x;
@@ -244,7 +256,8 @@ __global__ __launch_bounds__(tb::kThreads) void tile_background_bucket_kernel(co
 __global__ __launch_bounds__(ts::kThreads) void tile_background_stream_kernel(const float *__restrict__ img_arg, int rows, int cols, int64_t ld, int step,
                                                                               int ntx, const ab_pixel_xf xf_arg, TileOut *__restrict__ out,
                                                                               const FrameDev *__restrict__ fd, const float *const *__restrict__ many_planes,
-                                                                              const ab_pixel_xf *__restrict__ many_xf, unsigned int *__restrict__ fail) {
+                                                                              const ab_pixel_xf *__restrict__ many_xf, unsigned int *__restrict__ fail,
+                                                                              const TileCand cand) {
     __shared__ ts::Shared sh;
 #ifdef AB_TILE_VGPR_FLOOR
     // developer experiment: a register floor caps the tile workgroups per CU (four of them take 156 of the 160 KB of LDS, and no
@@ -267,7 +280,15 @@ __global__ __launch_bounds__(ts::kThreads) void tile_background_stream_kernel(co
     r.y1 = min(r.y0 + step, rows);
     r.x1 = min(r.x0 + step, cols);
     r.vec = (step & 3) == 0 && ((r.x1 - r.x0) & 3) == 0;
-    const ts::TileResult res = ts::tile_stats(sh, r, xf);
+    ts::CandSink cs;
+    if (cand.ent) {  // (the registration batch: whole tiles also leave their candidate lists for the labelling pass)
+        const size_t tl = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        cs.ent = cand.ent + tl * (size_t)kCandCap;
+        cs.cnt = cand.cnt + tl;
+        cs.cut = cand.cut + tl;
+        cs.cap = (unsigned int)kCandCap;
+    }
+    const ts::TileResult res = ts::tile_stats(sh, r, xf, cs);
     if (threadIdx.x == 0) {
         if (res.declined) {
             const unsigned int at = atomicAdd(&fail[0], 1u);
@@ -822,9 +843,327 @@ __device__ __forceinline__ void label_tile_body(const float *__restrict__ img, i
     }
 }
 
+// ---- round 6: a frame labelled from its background tiles' CANDIDATE LISTS --------------------------------------
+// label_tile_body above streams the whole frame from HBM to find the ~1 % of its pixels above the threshold (loads + threshold + mask
+// words: 11.7 of its 24 us per 4096^2 frame) and pays the fixed cost of its LDS phases 4096 times per frame.  The tile pass of the
+// background estimate has had every pixel in hand already: whole 256 x 256 tiles leave {position, raw value} of everything above a
+// conservative cut (tile_stream.hpp: CandSink).  Here ONE workgroup labels one BACKGROUND tile from that list -- the frame is not read
+// at all -- with the same outputs as label_tile_body<true, true>: mask words, parent = global index of the tile-local root, the border
+// list, one record per tile-local component.  The forest is the same forest (a component's root is its smallest raster index; here
+// a tile-local root is the tile's smallest, and label_border joins tiles on the global forest as before), so everything downstream
+// (label_border with the tile's dimensions, comp_merge, the selection, comp_moments) is unchanged and the stars are identical.
+//   sparse tile: count <= kCandCap, cut not NaN, and xf(cut) <= threshold (xf non-decreasing: what is not on the list cannot be above)
+//   dense tile:  anything else (a partial tile, a tile the stream kernel declined, a tile brighter than the frame's threshold, an
+//                overflowed list): the tile's pixels are read from the frame and tested one by one -- same code after the test.
+// Nodes of the tile's forest are RUNS of labelled pixels numbered in raster order (row prefix + popcount of the run-start bits), so the
+// union-find needs kBgRunCap labels, not 65 536; more runs or more than kBgSlots components raise the frame's overflow flag (the host
+// redoes the frame through the full path, like a crowded 32 x 128 tile before).
+// LDS is what this kernel waits for inside a registration batch: the background-tile workgroups of the tile pipeline hold 39 KB each, four
+// per CU (157 of 160 KB), so a labelling workgroup only finds room where a tile workgroup has just retired.  The first version (whole
+// 256 x 256 tiles, 62 KB: run descriptors, 4096 labels, 512 slots) waited ten times longer than it ran; at 36 KB the step fell by 0.43
+// ms (profiles/r06_lds_ab.txt).  Hence: a workgroup labels a SUB-TILE of kBgRows rows x 256 columns of its background tile (it reads
+// the tile's whole list, 8 entries per thread, and keeps its rows'), there are no run descriptors (a run's owner knows its row and
+// first column where they are needed; a root leaves its pixel index in its slot), and the caps are per sub-tile.
+#ifndef AB_BG_ROWS
+#define AB_BG_ROWS 128
+#endif
+#ifndef AB_BG_RUNCAP
+#define AB_BG_RUNCAP (12 * AB_BG_ROWS)
+#endif
+#ifndef AB_BG_SLOTS
+#define AB_BG_SLOTS (2 * AB_BG_ROWS)
+#endif
+constexpr int kBgT = 256, kBgRows = AB_BG_ROWS, kBgSub = kBgT / kBgRows, kBgThreads = 256, kBgRunCap = AB_BG_RUNCAP, kBgSlots = AB_BG_SLOTS;
+static_assert(kBgRows == 256 || kBgRows == 128 || kBgRows == 64 || kBgRows == 32, "sub-tiles: whole rows of the 256-px background tile");
+struct BgShared {
+    unsigned int tmask[kBgRows][8];     // one bit per pixel of the sub-tile: above the threshold
+    unsigned char wpre[kBgRows][8];     // runs of row r that start in the words before word w
+    unsigned int row_base[kBgRows + 4]; // runs in the rows above r; [kBgRows] = the sub-tile's runs
+    int lab[kBgRunCap];                 // the forest over run ids; after the flattening: root id, or -1 - slot at a root
+    int acc_i[7][kBgSlots];             // npix, x0, x1, y0, y1, first_interior, the root's global pixel index
+    double acc_flux[kBgSlots];
+    unsigned int wave_tot[kBgThreads / 64];
+    unsigned int n_edge, base_edge, n_slots, base_rec;
+};
+static_assert(sizeof(BgShared) <= 40 * 1024, "a labelling workgroup must fit where ONE tile workgroup (39.3 KB) has retired");
+__device__ __forceinline__ unsigned int bg_start_word(const unsigned int (*tm)[8], int r, int w) {
+    const unsigned int m = tm[r][w], prev = w ? tm[r][w - 1] >> 31 : 0u;
+    return m & ~((m << 1) | prev);
+}
+// runs of row r that start at or before column c
+__device__ __forceinline__ unsigned int bg_rank_incl(const BgShared &sh, int r, int c) {
+    const int w = c >> 5;
+    return (unsigned int)sh.wpre[r][w] + (unsigned int)__builtin_popcount(bg_start_word(sh.tmask, r, w) & (0xffffffffu >> (31 - (c & 31))));
+}
+struct FrameCandDev {
+    const uint2 *ent;
+    const unsigned int *cnt;
+    const float *cut;
+};
+// grid.x = background tiles x kBgSub: workgroup b labels rows [sub * kBgRows, (sub + 1) * kBgRows) of background tile b / kBgSub, sub = b % kBgSub
+__device__ __forceinline__ void label_bgtile_body(BgShared &sh, const float *__restrict__ img, int rows, int cols, double threshold, const ab_pixel_xf xf,
+                                                  int *__restrict__ parent, unsigned int *__restrict__ mask, int *__restrict__ blist_all, size_t blist_stride,
+                                                  unsigned int *lcnt, const TileRecOut ro, int mpitch, const FrameCandDev cand) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (cols + kBgT - 1) / kBgT;
+    const unsigned int bgtile = blockIdx.x / kBgSub;
+    const int sub = (int)(blockIdx.x % kBgSub);
+    const int ty0 = (int)(bgtile / tiles_x) * kBgT + sub * kBgRows, tx0 = (int)(bgtile % tiles_x) * kBgT;
+    const int region = (int)(blockIdx.x % kRegions), rec_region = (int)(blockIdx.x % kRecRegions);
+    int *__restrict__ blist = blist_all + (size_t)region * blist_stride;
+    unsigned int *nborder = lcnt + (kRegions + region) * kRegionPitch;
+    const int64_t mp = mpitch;
+    if (ty0 >= rows) return;  // (the last background tile's lower sub-tiles may lie below the frame; block-uniform)
+    // ---- which form ----
+    const unsigned int n = cand.ent ? cand.cnt[bgtile] : 0xffffffffu;
+    const float cut = cand.ent ? cand.cut[bgtile] : __builtin_nanf("");
+    const bool sparse = cand.ent && n <= (unsigned int)kCandCap && cut == cut && !((double)ab_px(xf, cut) > threshold);  // (block-uniform)
+    if (tid == 0) {
+        sh.n_edge = sh.n_slots = 0;
+        if (!sparse && sub == 0) atomicAdd(ro.flags, 2u);  // (bit 0 is the overflow flag; the host reports flags >> 1 = background tiles read from the frame)
+    }
+    constexpr int kPerThread = kCandCap / kBgThreads;  // 8 list entries per thread
+    uint2 ent[kPerThread];
+    unsigned int pass = 0;     // sparse: bit j = entry j of this thread lies in this sub-tile and is above the threshold
+    unsigned int ecnt = 0;     // this thread's labelled pixels on the sub-tile's last row, first or last column
+    auto on_edge = [](int r, int c) { return r == kBgRows - 1 || c == 0 || c == kBgT - 1; };
+    auto quad = [&](int gy, int gx) -> float4 {  // four pixels of the frame at (gy, gx ..), zeros past the row's end
+        float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float *p = img + (int64_t)gy * cols + gx;
+        if (gx + 3 < cols) {
+            v = ts::load4u(p);
+        } else {
+            v.x = p[0];
+            if (gx + 1 < cols) v.y = p[1];
+            if (gx + 2 < cols) v.z = p[2];
+        }
+        return v;
+    };
+    if (sparse) {
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const unsigned int k = (unsigned int)(tid + kBgThreads * j);
+            ent[j] = k < n ? cand.ent[(size_t)bgtile * kCandCap + k] : make_uint2(0xffffffffu, 0u);  // (row 0xffffff: in no sub-tile)
+        }
+        if (tid < kBgRows) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sh.tmask[tid][w] = 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int rt = (int)(ent[j].x >> 8), c = (int)(ent[j].x & 255u), r = rt - sub * kBgRows;
+            const float nv = ab_px(xf, __uint_as_float(ent[j].y));
+            if (r >= 0 && r < kBgRows && above(nv, threshold)) {
+                atomicOr(&sh.tmask[r][c >> 5], 1u << (c & 31));
+                pass |= 1u << j;
+                ecnt += on_edge(r, c) ? 1u : 0u;
+            }
+        }
+    } else {
+        // thread: columns 4 lane .. 4 lane + 3 of rows wv, wv + 4, ... (a wave reads whole rows); eight lanes make one mask word
+#pragma unroll 4
+        for (int j = 0; j < kBgRows / 4; ++j) {
+            const int r = wv + 4 * j, gy = ty0 + r, gx = tx0 + 4 * lane;
+            unsigned int nib = 0;
+            if (gy < rows && gx < cols) {
+                const float4 v = quad(gy, gx);
+                nib = (unsigned int)above(ab_px(xf, v.x), threshold) | ((unsigned int)(gx + 1 < cols && above(ab_px(xf, v.y), threshold)) << 1) |
+                      ((unsigned int)(gx + 2 < cols && above(ab_px(xf, v.z), threshold)) << 2) | ((unsigned int)(gx + 3 < cols && above(ab_px(xf, v.w), threshold)) << 3);
+            }
+            unsigned int ebits = r == kBgRows - 1 ? 15u : 0u;
+            if (lane == 0) ebits |= 1u;
+            if (lane == 63) ebits |= 8u;
+            ecnt += (unsigned int)__builtin_popcount(nib & ebits);
+            unsigned int w = nib << (4 * (lane & 7));
+            w |= __shfl_xor(w, 1, 64);
+            w |= __shfl_xor(w, 2, 64);
+            w |= __shfl_xor(w, 4, 64);
+            if ((lane & 7) == 0) sh.tmask[r][lane >> 3] = w;
+        }
+    }
+    __syncthreads();
+    const unsigned int eat0 = ecnt ? atomicAdd(&sh.n_edge, ecnt) : 0u;
+    // ---- row tid (tid < kBgRows): its runs are counted ----
+    unsigned int nruns = 0;
+    if (tid < kBgRows) {
+        const int r = tid;
+        unsigned int m[8];
+        *reinterpret_cast<uint4 *>(&m[0]) = *reinterpret_cast<const uint4 *>(&sh.tmask[r][0]);
+        *reinterpret_cast<uint4 *>(&m[4]) = *reinterpret_cast<const uint4 *>(&sh.tmask[r][4]);
+        unsigned char pre[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const unsigned int st = m[w] & ~((m[w] << 1) | (w ? m[w - 1] >> 31 : 0u));
+            pre[w] = (unsigned char)nruns;
+            nruns += (unsigned int)__builtin_popcount(st);
+        }
+        *reinterpret_cast<uint2 *>(&sh.wpre[r][0]) = make_uint2((unsigned int)pre[0] | ((unsigned int)pre[1] << 8) | ((unsigned int)pre[2] << 16) | ((unsigned int)pre[3] << 24),
+                                                                 (unsigned int)pre[4] | ((unsigned int)pre[5] << 8) | ((unsigned int)pre[6] << 16) | ((unsigned int)pre[7] << 24));
+    }
+    // exclusive scan of the rows' run counts over the workgroup
+    unsigned int incl = nruns;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) sh.wave_tot[wv] = incl;
+    __syncthreads();
+    unsigned int before = 0;
+#pragma unroll
+    for (int i = 0; i < kBgThreads / 64; ++i) before += i < wv ? sh.wave_tot[i] : 0u;
+    const unsigned int my_base = before + incl - nruns;
+    if (tid < kBgRows) sh.row_base[tid] = my_base;
+    const unsigned int total_runs = sh.wave_tot[0] + sh.wave_tot[1] + sh.wave_tot[2] + sh.wave_tot[3];
+    const bool too_many = total_runs > (unsigned int)kBgRunCap;  // (block-uniform) more runs than the forest holds: the host redoes the frame in full
+    if (tid < kBgRows) {
+        // the sub-tile's mask words (row tid).  An overflowed sub-tile writes ZEROS and nothing else: its neighbours' border pixels must not
+        // be united with pixels whose parents were never written (the frame's results are discarded, its kernels still run)
+        const int gy = ty0 + tid;
+        if (gy < rows) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                if (tx0 + 32 * w < mpitch) mask[((int64_t)gy * mp + tx0 + 32 * w) >> 5] = too_many ? 0u : sh.tmask[tid][w];
+        }
+    }
+    if (too_many) {
+        if (tid == 0) atomicOr(ro.flags, 1u);
+        return;
+    }
+    if (tid == 0) {
+        sh.row_base[kBgRows] = total_runs;
+        sh.base_edge = sh.n_edge ? atomicAdd(nborder, sh.n_edge) : 0u;
+    }
+    // for every run [s0, e0] of row r, in raster order: f(id, s0, e0)
+    auto for_runs_of_row = [&](int r, unsigned int id0, auto &&f) {
+        unsigned int id = id0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            unsigned int st = bg_start_word(sh.tmask, r, w);
+            const unsigned int mw = sh.tmask[r][w];
+            while (st) {
+                const int b = __builtin_ctz(st);
+                st &= st - 1;
+                const int s0 = 32 * w + b;
+                const unsigned int z = b == 31 ? 0u : ((~mw) >> (b + 1));  // zeros after column s0 inside the word
+                int e0;
+                if (z) {
+                    e0 = s0 + __builtin_ctz(z);
+                } else {
+                    int w2 = w + 1;
+                    while (w2 < 8 && sh.tmask[r][w2] == 0xffffffffu) ++w2;
+                    e0 = w2 == 8 ? kBgT - 1 : 32 * w2 + __builtin_ctz(~sh.tmask[r][w2]) - 1;
+                }
+                f(id, s0, e0);
+                ++id;
+            }
+        }
+    };
+    // the runs of row tid: a node of their own
+    if (tid < kBgRows)
+        for (unsigned int id = my_base; id < my_base + nruns; ++id) sh.lab[id] = (int)id;
+    __syncthreads();
+    // ---- unions: every run of row tid with the runs of the next row that touch [s - 1, e + 1] ----
+    if (tid + 1 < kBgRows && nruns) {
+        const int r = tid;
+        const unsigned int nb = sh.row_base[r + 1];
+        for_runs_of_row(r, my_base, [&](unsigned int id, int s0, int e0) {
+            const int lo = s0 > 0 ? s0 - 1 : 0, hi = e0 < kBgT - 1 ? e0 + 1 : kBgT - 1;
+            const unsigned int lo_set = (sh.tmask[r + 1][lo >> 5] >> (lo & 31)) & 1u;
+            const unsigned int first = bg_rank_incl(sh, r + 1, lo) - lo_set, last = bg_rank_incl(sh, r + 1, hi);
+            for (unsigned int k = first; k < last; ++k) lds_union(sh.lab, (int)id, (int)(nb + k));
+        });
+    }
+    __syncthreads();
+    // ---- every run's node -> its root; a root takes a record slot, leaves its pixel's global index there and marks itself with
+    // -1 - slot (walkers stop at a mark) ----
+    if (tid < kBgRows && nruns) {
+        for_runs_of_row(tid, my_base, [&](unsigned int id, int s0, int) {
+            int x = (int)id;
+            while (true) {
+                const int pnt = __hip_atomic_load(&sh.lab[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (pnt < 0 || pnt == x) break;
+                x = pnt;
+            }
+            if (x == (int)id) {  // (only a node's owner marks it)
+                const unsigned int slot = atomicAdd(&sh.n_slots, 1u);
+                if (slot < (unsigned int)kBgSlots) {
+                    sh.acc_i[0][slot] = 0;
+                    sh.acc_i[1][slot] = 0x7fffffff;
+                    sh.acc_i[2][slot] = -1;
+                    sh.acc_i[3][slot] = 0x7fffffff;
+                    sh.acc_i[4][slot] = -1;
+                    sh.acc_i[5][slot] = 0x7fffffff;
+                    sh.acc_i[6][slot] = (ty0 + tid) * cols + tx0 + s0;
+                    sh.acc_flux[slot] = 0.0;
+                }
+                __hip_atomic_store(&sh.lab[id], -1 - (int)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                __hip_atomic_store(&sh.lab[id], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        });
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int ns = sh.n_slots;
+        sh.base_rec = ns ? atomicAdd(lcnt + (2 * kRegions + rec_region) * kRegionPitch, ns < (unsigned int)kBgSlots ? ns : (unsigned int)kBgSlots) : 0u;
+        if (ns > (unsigned int)kBgSlots) atomicOr(ro.flags, 1u);
+    }
+    // ---- every labelled pixel: its parent, one contribution to its component's slot, the border list ----
+    unsigned int eat = sh.base_edge + eat0;
+    auto contribute = [&](int r, int c, float nv) {
+        const unsigned int id = sh.row_base[r] + bg_rank_incl(sh, r, c) - 1u;
+        const int pnt = sh.lab[id];
+        const int slot = -1 - (pnt >= 0 ? sh.lab[pnt] : pnt);  // (every root is marked since the barrier)
+        const int gy = ty0 + r, gx = tx0 + c, gi = gy * cols + gx;
+        if (slot < kBgSlots) {
+            parent[gi] = sh.acc_i[6][slot];
+            atomicAdd(&sh.acc_i[0][slot], 1);
+            atomicMin(&sh.acc_i[1][slot], gx);
+            atomicMax(&sh.acc_i[2][slot], gx);
+            atomicMin(&sh.acc_i[3][slot], gy);
+            atomicMax(&sh.acc_i[4][slot], gy);
+            // BFS seeds are interior (star_detection.rs:107-110)
+            if (gy >= 1 && gy < rows - 1 && gx >= 1 && gx <= cols - 2) atomicMin(&sh.acc_i[5][slot], gi);
+            const double fl = fmax((double)nv - ro.bg_median, 0.0);
+            if (fl > 0.0) unsafeAtomicAdd(&sh.acc_flux[slot], fl);
+        } else {
+            parent[gi] = gi;  // (more components than slots: the frame is redone in full; the forest the other kernels walk stays valid)
+        }
+        if (on_edge(r, c)) blist[eat++] = gi;
+    };
+    if (sparse) {
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j)
+            if ((pass >> j) & 1u) contribute((int)(ent[j].x >> 8) - sub * kBgRows, (int)(ent[j].x & 255u), ab_px(xf, __uint_as_float(ent[j].y)));
+    } else {
+        for (int j = 0; j < kBgRows / 4; ++j) {
+            const int r = wv + 4 * j, gy = ty0 + r, gx = tx0 + 4 * lane;
+            const unsigned int nib = (sh.tmask[r][lane >> 3] >> (4 * (lane & 7))) & 15u;
+            if (!nib) continue;
+            const float4 v = quad(gy, gx);  // (labelled: inside the frame)
+            const float f4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((nib >> k) & 1u) contribute(r, 4 * lane + k, ab_px(xf, f4[k]));
+        }
+    }
+    __syncthreads();
+    const unsigned int ns = sh.n_slots < (unsigned int)kBgSlots ? sh.n_slots : (unsigned int)kBgSlots;
+    for (unsigned int sl = (unsigned int)tid; sl < ns; sl += kBgThreads) {
+        const size_t pos = (size_t)rec_region * ro.stride + sh.base_rec + sl;
+        const int groot = sh.acc_i[6][sl];
+        ro.st[pos] = CompStat{sh.acc_i[0][sl], sh.acc_i[1][sl], sh.acc_i[2][sl], sh.acc_i[3][sl], sh.acc_i[4][sl], sh.acc_i[5][sl], sh.acc_flux[sl]};
+        ro.roots[pos] = groot;
+        ro.cid[groot] = (int)pos;
+    }
+}
+
 // cross-tile unions of the border pixels (the forward neighbours that lie in another tile), on the global forest
 __device__ __forceinline__ void label_border_body(int rows, int cols, int *parent, const unsigned int *__restrict__ mask, const int *__restrict__ blist,
-                                                  const unsigned int *__restrict__ nborder, unsigned int bid, unsigned int nblk, int mpitch) {
+                                                  const unsigned int *__restrict__ nborder, unsigned int bid, unsigned int nblk, int mpitch,
+                                                  int tile_h = kTileH, int tile_w = kTileW) {
     const unsigned int n = *nborder;
     auto lab_at = [&](int rr, int cc) -> bool {  // (mask rows are mpitch bits apart)
         const int64_t j = (int64_t)rr * mpitch + cc;
@@ -833,8 +1172,8 @@ __device__ __forceinline__ void label_border_body(int rows, int cols, int *paren
     for (unsigned int k = bid * 256 + threadIdx.x; k < n; k += nblk * 256) {
         const int i = blist[k];
         const int r = i / cols, c = i - r * cols;
-        const int tr = r / kTileH, tc = c / kTileW;
-        auto other = [&](int rr, int cc) { return rr / kTileH != tr || cc / kTileW != tc; };
+        const int tr = r / tile_h, tc = c / tile_w;
+        auto other = [&](int rr, int cc) { return rr / tile_h != tr || cc / tile_w != tc; };
         if (c + 1 < cols && other(r, c + 1) && lab_at(r, c + 1)) uf_union(parent, i, i + 1);
         if (r + 1 < rows) {
             const int d = i + cols;
@@ -1248,6 +1587,12 @@ struct DetGroup {
     size_t rec_stride;
     unsigned int *sel[kGroupMax];     // indices of the selected components (comp_select_many_kernel), kSelCap each
     unsigned int *selout[kGroupMax];  // PINNED HOST: {selected, candidates} of the frame
+    // round 6: the frames' candidate lists (label_bgtile_many_kernel; ent == nullptr: that frame's tiles are read from the frame) and
+    // the labelling tile's dimensions (label_border_many_kernel: 32 x 128, or 256 x 256 with the background tiles)
+    const uint2 *cand_ent[kGroupMax];
+    const unsigned int *cand_cnt[kGroupMax];
+    const float *cand_cut[kGroupMax];
+    int tile_h, tile_w;
 };
 
 // The selection cuts on CompStat::flux -- an f64 sum whose order of additions varies from run to run -- while finish_stars ranks by the
@@ -1338,7 +1683,9 @@ __global__ __launch_bounds__(kSelThreads) void comp_select_many_kernel(const Det
     for (unsigned int b = tid; b < 2048; b += kSelThreads) hist[b] = 0;
     if (tid == 0) s_ncand = s_d0 = s_above = s_count = s_nsub = s_prefix = s_want = s_ge = s_take = 0;
     if (g.recs) {
-        const bool overflow = g.counters[f][3] != 0;  // a tile with more components than slots: nothing is selected, the host redoes the frame in full
+        const unsigned int flagw = g.counters[f][3];   // bit 0: a tile with more components than slots (nothing is selected, the host redoes the frame in
+        const bool overflow = (flagw & 1u) != 0;       // full); the rest: 2 x the tiles label_bgtile read from the frame for want of a usable candidate list
+        if (tid == 0 && g.chained) g.selout[f][4] = flagw >> 1;
         if (tid < kRecRegions) {
             const unsigned int cnt = g.lcnt[f][(2 * kRegions + tid) * kRegionPitch];
             seg_n[tid] = overflow ? 0u : (cnt < seg_stride ? cnt : seg_stride);
@@ -1516,10 +1863,17 @@ __global__ __launch_bounds__(kTileThreads) void label_tile_many_kernel(const Det
     label_tile_body<RUNS, RECS>(g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.plist[f], g.plist_stride, g.blist[f], g.blist_stride, g.lcnt[f], ro,
                                 g.mask_pitch);
 }
+__global__ __launch_bounds__(kBgThreads) void label_bgtile_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
+    __shared__ BgShared sh;
+    const int f = blockIdx.y;
+    const TileRecOut ro = TileRecOut{g.st[f], g.roots[f], g.cid[f], g.rec_stride, g.counters[f] + 3, g.bg_median[f]};
+    label_bgtile_body(sh, g.img[f], rows, cols, g.threshold[f], g.xf[f], g.parent[f], g.mask[f], g.blist[f], g.blist_stride, g.lcnt[f], ro, g.mask_pitch,
+                      FrameCandDev{g.cand_ent[f], g.cand_cnt[f], g.cand_cut[f]});
+}
 // (grid: a multiple of kRecRegions blocks; block b works on record region b mod kRecRegions as sub-block b / kRecRegions)
 __global__ __launch_bounds__(256) void comp_merge_many_kernel(const DetGroup g) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y, r = blockIdx.x % kRecRegions;
-    if (g.counters[f][3]) return;  // (a tile overflowed its slots: the host redoes the frame in full)
+    if (g.counters[f][3] & 1u) return;  // (a tile overflowed its slots: the host redoes the frame in full)
     const unsigned int cnt = g.lcnt[f][(2 * kRegions + r) * kRegionPitch];
     comp_merge_body(g.parent[f], g.roots[f], g.cid[f], g.st[f], cnt < g.rec_stride ? cnt : (unsigned int)g.rec_stride, (size_t)r * g.rec_stride, blockIdx.x / kRecRegions,
                     gridDim.x / kRecRegions);
@@ -1528,7 +1882,7 @@ __global__ __launch_bounds__(256) void comp_merge_many_kernel(const DetGroup g) 
 __global__ __launch_bounds__(256) void label_border_many_kernel(const DetGroup g, int rows, int cols) { AB_LATENCY_KERNEL_PRIO();
     const int f = blockIdx.y, r = blockIdx.x % kRegions;
     label_border_body(rows, cols, g.parent[f], g.mask[f], g.blist[f] + (size_t)r * g.blist_stride, g.lcnt[f] + (kRegions + r) * kRegionPitch, blockIdx.x / kRegions,
-                      gridDim.x / kRegions, g.mask_pitch);
+                      gridDim.x / kRegions, g.mask_pitch, g.tile_h, g.tile_w);
 }
 __global__ __launch_bounds__(kRootsBlock) void roots_kernel(const int *__restrict__ parent, const int *__restrict__ plist, const unsigned int *__restrict__ nlab,
                                                             int *__restrict__ roots, int *__restrict__ cid, unsigned int *nroots, unsigned int cap) { AB_LATENCY_KERNEL_PRIO();
@@ -1900,7 +2254,11 @@ static int tile_fail_buffer(ab_ctx *ctx, int which, size_t tiles, unsigned int *
         }
         const size_t cap = tiles + 2 + (tiles >> 1);
         AB_HIP(ctx, hipMalloc((void **)&ctx->tile_fail[which], cap * sizeof(unsigned int)));
-        AB_HIP(ctx, hipMemset(ctx->tile_fail[which], 0, 2 * sizeof(unsigned int)));  // (synchronous, once: the kernels keep it zeroed)
+        // once: the kernels keep it zeroed.  hipMemset on device memory is NOT ordered with the context's non-blocking streams and may
+        // return before it has run (round 6: a fresh worker context's first tile launch could append its declined tiles to a list
+        // that the fill then wiped -- a stale tile statistic in 1 of ~10 first calls, tests/test_gpu_subframe.py): fill, then wait
+        AB_HIP(ctx, hipMemset(ctx->tile_fail[which], 0, 2 * sizeof(unsigned int)));
+        AB_HIP(ctx, hipDeviceSynchronize());
         ctx->tile_fail_cap[which] = cap;
     }
     *out = ctx->tile_fail[which];
@@ -1912,7 +2270,7 @@ static int tile_fail_buffer(ab_ctx *ctx, int which, size_t tiles, unsigned int *
 // resident kernel alone (round 2 / 3's arrangement).  which: 0 = the context's stream, 1 = its auxiliary stream.
 static int launch_tile_kernels(ab_ctx *ctx, hipStream_t stream, int which, const float *img, int64_t rows, int64_t cols, int64_t ld, int step, int ntx,
                                int ntiles, int nplanes, const ab_pixel_xf &xf, TileOut *out, const FrameDev *fd, const float *const *many_planes,
-                               const ab_pixel_xf *many_xf) {
+                               const ab_pixel_xf *many_xf, const TileCand cand = TileCand()) {
     static const bool resident = ab_dev_env("AB_TILE_RESIDENT") != nullptr;
     if (resident) {
         hipLaunchKernelGGL(tile_background_bucket_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(tb::kThreads), 0, stream, img, (int)rows, (int)cols,
@@ -1925,8 +2283,14 @@ static int launch_tile_kernels(ab_ctx *ctx, hipStream_t stream, int which, const
     // needs LDS (the tile labelling, the votes, the selection) runs beside a tile launch; any padding leaves three and 43 KB free.
     static const unsigned int tile_pad = ab_dev_env("AB_TILE_PAD_KB") ? (unsigned int)std::min(std::max(atoi(ab_dev_env("AB_TILE_PAD_KB")), 0), 100) * 1024u : 0u;
     hipLaunchKernelGGL(tile_background_stream_kernel, dim3((unsigned)ntiles, (unsigned)nplanes), dim3(ts::kThreads), tile_pad, stream, img, (int)rows, (int)cols, ld,
-                       step, ntx, xf, out, fd, many_planes, many_xf, fail);
-    const unsigned int blocks = (unsigned int)std::min<int64_t>((int64_t)ntiles * nplanes, 256);
+                       step, ntx, xf, out, fd, many_planes, many_xf, fail, cand);
+    // (the fallback's workgroups need 55 KB of LDS each before they can even look at the -- almost always empty -- list, and inside a batch
+    // that room has to be waited for: 256 of them delayed the next tile launch by 16 - 80 us; 64 find it sooner and still work a long list
+    // off side by side)
+#ifndef AB_TILE_FALLBACK_BLOCKS
+#define AB_TILE_FALLBACK_BLOCKS 64
+#endif
+    const unsigned int blocks = (unsigned int)std::min<int64_t>((int64_t)ntiles * nplanes, AB_TILE_FALLBACK_BLOCKS);
     hipLaunchKernelGGL(tile_background_bucket_kernel, dim3(blocks), dim3(tb::kThreads), 0, stream, img, (int)rows, (int)cols, ld, step, ntx, xf, out, fd,
                        many_planes, many_xf, fail, ntiles);
     return AB_OK;
@@ -1981,6 +2345,30 @@ static void background_from_tiles(const TileOut *t, int ntiles, double *out_medi
     *out_sigma = std::fmax(sig[sig.size() / 2], 1e-10);
 }
 
+// The candidate lists of a pipeline's planes (TileCand; only for 256-px tiles -- frames of 2048 px and more on the short side -- whose
+// tiles the labelling pass can take one for one): n x ntiles x kCandCap entries + counts + cuts in a workspace of the pipeline's context
+static_assert(kCandCap == 2048, "ab_common.hpp: ab_bg_pipeline_cand assumes 2048 entries per tile");
+static int pipeline_cand_lists(ab_ctx *ctx, size_t n, int ntiles, int step, TileCand *out) {
+    *out = TileCand();
+    if (step != 256 || n == 0) return AB_OK;
+    const size_t tiles = n * (size_t)ntiles, ent_bytes = tiles * (size_t)kCandCap * sizeof(uint2);
+    char *base = nullptr;
+    AB_TRY(ab_workspace(ctx, AB_WS_DETECT_CAND, ent_bytes + tiles * (sizeof(unsigned int) + sizeof(float)) + 64, (void **)&base));
+    out->ent = (uint2 *)base;
+    out->cnt = (unsigned int *)(base + ent_bytes);
+    out->cut = (float *)(out->cnt + tiles);
+    return AB_OK;
+}
+static inline TileCand cand_at(const TileCand &c, size_t plane, int ntiles) {
+    TileCand o;
+    if (c.ent) {
+        o.ent = c.ent + plane * (size_t)ntiles * (size_t)kCandCap;
+        o.cnt = c.cnt + plane * (size_t)ntiles;
+        o.cut = c.cut + plane * (size_t)ntiles;
+    }
+    return o;
+}
+
 // estimate_background of the n contiguous planes of a registration batch, each with its own load transform, as a PIPELINE: the
 // tile kernel runs on the context's auxiliary stream, `chunk` planes per launch (grid: tiles x planes), an event after every
 // launch, results in a pinned buffer of its own; ab_bg_pipeline_get blocks on a plane's event and reduces its tiles.  Inside a
@@ -1989,7 +2377,7 @@ static void background_from_tiles(const TileOut *t, int ntiles, double *out_medi
 // synchronisation was slower than the per-frame form -- 5.9 ms during which nothing else runs: 19.0 against 18.0 ms for the
 // stage; the pipeline measures 17.1.)
 int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, const ab_pixel_xf *xf, int chunk,
-                         ab_bg_pipeline *p) {
+                         ab_bg_pipeline *p, bool want_cand) {
     *p = ab_bg_pipeline();
     static const bool legacy = ab_dev_env("AB_TILE_LEGACY") != nullptr;
     if (legacy || n == 0 || rows < 3 || cols < 3 || chunk < 1) return AB_OK;
@@ -2031,6 +2419,8 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_DEV, ptr_bytes + xf_bytes + 64, (void **)&dv));
     const float **dplanes = (const float **)dv;
     ab_pixel_xf *dxf = (ab_pixel_xf *)(dv + ((ptr_bytes + 15) & ~(size_t)15));
+    TileCand cand;
+    if (want_cand) AB_TRY(pipeline_cand_lists(ctx, n, ntiles, step, &cand));
     char *stage = (char *)ctx->aux_pinned + tiles_bytes;
     memcpy(stage, planes, ptr_bytes);
     memcpy(stage + ((ptr_bytes + 15) & ~(size_t)15), xf, xf_bytes);
@@ -2038,12 +2428,13 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     auto enqueue = [&]() -> int {
         AB_HIP(ctx, hipMemcpyAsync(dplanes, stage, ptr_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
         AB_HIP(ctx, hipMemcpyAsync(dxf, stage + ((ptr_bytes + 15) & ~(size_t)15), xf_bytes, hipMemcpyHostToDevice, ctx->aux_stream));
+        if (cand.ent) AB_HIP(ctx, hipMemsetAsync(cand.cut, 0xff, n * (size_t)ntiles * sizeof(float), ctx->aux_stream));  // NaN: "no list" until a tile says otherwise
         for (size_t c = 0; c < nchunks; ++c) {
             const size_t begin = first ? (c == 0 ? 0 : first + (c - 1) * (size_t)chunk) : c * (size_t)chunk;
             const size_t cnt = (first && c == 0) ? first : std::min<size_t>((size_t)chunk, n - begin);
             AB_TRY(launch_tile_kernels(ctx, ctx->aux_stream, 1, nullptr, rows, cols, cols, step, ntx, ntiles, (int)cnt, ab_pixel_xf(),
                                        (TileOut *)ctx->aux_pinned + begin * (size_t)ntiles, nullptr, (const float *const *)(dplanes + begin),
-                                       (const ab_pixel_xf *)(dxf + begin)));
+                                       (const ab_pixel_xf *)(dxf + begin), cand_at(cand, begin, ntiles)));
             AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
         }
         AB_HIP(ctx, hipGetLastError());
@@ -2061,6 +2452,10 @@ int ab_bg_pipeline_begin(ab_ctx *ctx, const float *const *planes, size_t n, int6
     p->chunk = chunk;
     p->first = (int)first;
     p->n = n;
+    p->cand_ent = cand.ent;
+    p->cand_cnt = cand.cnt;
+    p->cand_cut = cand.cut;
+    p->cand_step = cand.ent ? step : 0;
     return AB_OK;
 }
 
@@ -2084,6 +2479,7 @@ struct FedPlan {  // everything a chunk's launches need, by value (the feeder ou
     const float **dplanes = nullptr;
     ab_pixel_xf *dxf = nullptr, *hxf = nullptr;
     PercentileOut *hpo = nullptr;
+    TileCand cand;  // the candidate lists of all n planes (pipeline_cand_lists; their cuts are preset to NaN)
     int enqueue(size_t c) const {
         const size_t first = c * (size_t)chunk, cnt = std::min<size_t>((size_t)chunk, n - first);
         PlaneList pl;
@@ -2100,7 +2496,7 @@ struct FedPlan {  // everything a chunk's launches need, by value (the feeder ou
         AB_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->pct_events[c], 0));
         AB_TRY(launch_tile_kernels(ctx, ctx->aux_stream, 1, nullptr, rows, cols, cols, step, ntx, ntiles, (int)cnt, ab_pixel_xf(),
                                    (TileOut *)ctx->aux_pinned + first * (size_t)ntiles, nullptr, (const float *const *)(dplanes + first),
-                                   (const ab_pixel_xf *)(dxf + first)));
+                                   (const ab_pixel_xf *)(dxf + first), cand_at(cand, first, ntiles)));
         AB_HIP(ctx, hipEventRecord(ctx->aux_events[c], ctx->aux_stream));
         AB_HIP(ctx, hipGetLastError());
         return AB_OK;
@@ -2151,7 +2547,7 @@ struct ab_bg_feed_impl {
 };
 
 int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, int64_t rows, int64_t cols, int chunk, const hipEvent_t *landed,
-                             ab_bg_pipeline *p) {
+                             ab_bg_pipeline *p, bool want_cand) {
     *p = ab_bg_pipeline();
     static const bool legacy = ab_dev_env("AB_TILE_LEGACY") != nullptr;
     if (legacy || n == 0 || rows < 3 || cols < 3 || chunk < 1) return AB_OK;
@@ -2217,12 +2613,18 @@ int ab_bg_pipeline_begin_fed(ab_ctx *ctx, const float *const *planes, size_t n, 
     f.planes.assign(planes, planes + n);
     if (landed) f.landed.assign(landed, landed + n);
     AB_HIP(ctx, hipMemcpyAsync(f.dplanes, stage, n * sizeof(const float *), hipMemcpyHostToDevice, ctx->aux_stream));
+    if (want_cand) AB_TRY(pipeline_cand_lists(ctx, n, f.ntiles, f.step, &f.cand));
+    if (f.cand.ent) AB_HIP(ctx, hipMemsetAsync(f.cand.cut, 0xff, n * (size_t)f.ntiles * sizeof(float), ctx->aux_stream));  // NaN: "no list"
     p->tiles = ctx->aux_pinned;
     p->events = ctx->aux_events.data();
     p->ntiles = f.ntiles;
     p->chunk = chunk;
     p->n = n;
     p->xf_host = f.hxf;
+    p->cand_ent = f.cand.ent;
+    p->cand_cnt = f.cand.cnt;
+    p->cand_cut = f.cand.cut;
+    p->cand_step = f.cand.ent ? f.step : 0;
     if (landed) {
         ab_bg_feed_impl *feed = new ab_bg_feed_impl();
         feed->plan = std::move(f);
@@ -2522,7 +2924,7 @@ int ab_detect_stars_device(ab_ctx *ctx, const float *img, int64_t rows, int64_t 
 // step of the chain is ONE launch for all of them (blockIdx.y = frame), the counters and the component records come back in one
 // copy each.  Results equal G calls of ab_detect_stars_device.
 int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, int64_t rows, int64_t cols, double sigma_threshold, const ab_pixel_xf *xf,
-                                 const double (*bg)[2], size_t max_keep, std::vector<ab_detected_star> *stars /* [G] */) {
+                                 const double (*bg)[2], size_t max_keep, std::vector<ab_detected_star> *stars /* [G] */, const ab_frame_cand *cand) {
     for (int f = 0; f < G; ++f) stars[f].clear();
     if (rows < 3 || cols < 3 || G <= 0) return AB_OK;  // :89-98
     AB_CHECK(ctx, G <= kGroupMax, "detect_stars: groups of at most %d frames", kGroupMax);
@@ -2540,10 +2942,17 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     // tile-local labelling (label_tile_many_kernel): contiguous planes (always, here) of any width -- the mask's rows are padded to
     // whole words, a row's ragged last quad is loaded float by float; AB_LABEL_LEGACY=1 keeps the two-pass form (the GPU tests run both)
     const bool tiled = !ctx->label_legacy;  // (any width, any dword alignment: round 5)
-    const int64_t tiles_x = (cols + kTileW - 1) / kTileW, tiles_y = (rows + kTileH - 1) / kTileH, ntile = tiles_x * tiles_y;
+    // Round 6: with the tile pass's candidate lists (a registration batch's frames: ab_bg_pipeline_cand) the labelling tile IS the 256 x 256
+    // background tile and the frame is not read at all (label_bgtile_many_kernel); a frame without lists keeps the 32 x 128 tiles.  The
+    // records form only (the chained detection with the device-side selection: decided below with the same conditions).
+    const bool bg_tiles = tiled && cand && cand[0].ent && !ctx->label_pixelwise && !ctx->detect_no_recs && !ctx->detect_full_records && !ctx->detect_midjoin &&
+                          4 * max_keep <= (size_t)kSelKeep;
+    const int tile_h = bg_tiles ? kBgRows : kTileH, tile_w = bg_tiles ? kBgT : kTileW, tile_slots = bg_tiles ? kBgSlots : kTileSlots;
+    // (background tiles: one workgroup per sub-tile of kBgRows rows, kBgSub of them per 256 x 256 tile -- the last tile row's may lie below the frame)
+    const int64_t tiles_x = (cols + tile_w - 1) / tile_w, tiles_y = bg_tiles ? ((rows + kBgT - 1) / kBgT) * kBgSub : (rows + tile_h - 1) / tile_h, ntile = tiles_x * tiles_y;
     // (tiled: the lists come in kRegions segments, each sized for the tiles that append to it)
     const size_t tiles_per_region = ((size_t)ntile + kRegions - 1) / kRegions;
-    const size_t plist_stride = tiles_per_region * (size_t)(kTileH * kTileW), blist_stride = tiles_per_region * (size_t)(kTileW + 2 * kTileH);
+    const size_t plist_stride = bg_tiles ? 0 : tiles_per_region * (size_t)(kTileH * kTileW), blist_stride = tiles_per_region * (size_t)(tile_w + 2 * tile_h);
     const size_t plist_ints = tiled ? (size_t)kRegions * plist_stride : (size_t)P, blist_ints = tiled ? (size_t)kRegions * blist_stride : 0;
     const size_t lcnt_words = tiled ? (size_t)(2 * kRegions + kRecRegions) * kRegionPitch : 0;
     AB_TRY(ab_workspace(ctx, AB_WS_DETECT_LIST, (size_t)G * (plist_ints + blist_ints + lcnt_words) * sizeof(int), (void **)&plist));
@@ -2581,8 +2990,9 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
     const bool chained = select && !ctx->detect_midjoin;
     // records form (label_tile_body<true, true>): the tiles gather their components' statistics themselves; roots_many and
     // comp_stats_many give way to comp_merge_many.  AB_DETECT_NO_RECS=1 keeps the pixel-list chain (the GPU tests run both).
-    const size_t rec_stride = (((size_t)ntile + kRecRegions - 1) / kRecRegions) * (size_t)kTileSlots, rec_cap = (size_t)kRecRegions * rec_stride;
+    const size_t rec_stride = (((size_t)ntile + kRecRegions - 1) / kRecRegions) * (size_t)tile_slots, rec_cap = (size_t)kRecRegions * rec_stride;
     const bool recs = chained && tiled && !ctx->label_pixelwise && !ctx->detect_no_recs && rec_cap <= (size_t)root_cap;
+    AB_CHECK(ctx, !bg_tiles || recs, "detect_stars: the background-tile labelling needs the records form (%zu records for %u roots)", rec_cap, root_cap);
     const unsigned int comp_cap = recs ? (unsigned int)rec_cap : (unsigned int)std::min<int64_t>(root_cap, (int64_t)1 << 18);
     void *pin = nullptr;
     unsigned int *selout = nullptr;
@@ -2591,20 +3001,28 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         AB_TRY(ab_workspace(ctx, AB_WS_DETECT_COMPS, (size_t)G * comp_cap * sizeof(CompStat) + (size_t)G * kSelCap * sizeof(unsigned int), &cbuf));
         CompStat *dstat = (CompStat *)cbuf;
         unsigned int *dsel = (unsigned int *)(dstat + (size_t)G * comp_cap);
-        AB_TRY(ab_pinned(ctx, (size_t)G * kSelCap * sizeof(CompRec) + (size_t)G * 4 * sizeof(unsigned int), &pin));
-        selout = (unsigned int *)((CompRec *)pin + (size_t)G * kSelCap);
+        AB_TRY(ab_pinned(ctx, (size_t)G * kSelCap * sizeof(CompRec) + (size_t)G * 8 * sizeof(unsigned int), &pin));
+        selout = (unsigned int *)((CompRec *)pin + (size_t)G * kSelCap);  // 8 words per frame: selected, candidates, components, cut key, dense tiles
         for (int f = 0; f < G; ++f) {
             g.rec[f] = (CompRec *)pin + (size_t)f * kSelCap;
             g.st[f] = dstat + (size_t)f * comp_cap;
             g.sel[f] = dsel + (size_t)f * kSelCap;
-            g.selout[f] = selout + 4 * f;
-            selout[4 * f] = selout[4 * f + 1] = selout[4 * f + 2] = selout[4 * f + 3] = 0;
+            g.selout[f] = selout + 8 * f;
+            for (int k = 0; k < 8; ++k) selout[8 * f + k] = 0;
         }
         g.comp_cap = comp_cap;
         g.chained = 1;
     }
     AB_HIP(ctx, hipMemsetAsync(counters, 0, (size_t)G * 4 * sizeof(unsigned int), ctx->stream));
     g.tiled = tiled ? 1 : 0;
+    g.tile_h = tile_h;
+    g.tile_w = tile_w;
+    for (int f = 0; f < G; ++f) {
+        const bool has = bg_tiles && cand[f].ent;
+        g.cand_ent[f] = has ? (const uint2 *)cand[f].ent : nullptr;
+        g.cand_cnt[f] = has ? cand[f].cnt : nullptr;
+        g.cand_cut[f] = has ? cand[f].cut : nullptr;
+    }
     g.mask_pitch = mask_pitch;
     g.recs = recs ? 1 : 0;
     g.rec_stride = rec_stride;
@@ -2615,7 +3033,9 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         // (one workgroup per tile.  Tried: fewer workgroups that walk several tiles with the next tile's loads in flight -- 128 / 142 us
         // per group of four 4096^2 frames with 1024 / 2048 workgroups against 101 us, profiles/r05_label_tile_variants.txt; the loop
         // alone, one trip per workgroup, cost 40 us: 36 VGPRs instead of 20 and the prefetch's predication.  The stage did not move.)
-        if (recs)
+        if (bg_tiles)
+            hipLaunchKernelGGL(label_bgtile_many_kernel, dim3((unsigned)ntile, (unsigned)G), dim3(kBgThreads), 0, ctx->stream, g, (int)rows, (int)cols);
+        else if (recs)
             hipLaunchKernelGGL((label_tile_many_kernel<true, true>), dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
         else if (ctx->label_pixelwise)
             hipLaunchKernelGGL((label_tile_many_kernel<false, false>), dim3((unsigned)ntile, (unsigned)G), dim3(kTileThreads), 0, ctx->stream, g, (int)rows, (int)cols);
@@ -2645,7 +3065,8 @@ int ab_detect_stars_group_device(ab_ctx *ctx, const float *const *imgs, int G, i
         unsigned int sel_m[kGroupMax] = {}, sel_ncand[kGroupMax] = {}, sel_ncomp[kGroupMax] = {};
         size_t sel_stars[kGroupMax] = {};
         for (int f = 0; f < G; ++f) {
-            const unsigned int m = selout[4 * f], ncand = selout[4 * f + 1], ncomp = selout[4 * f + 2], cut_key = selout[4 * f + 3];
+            const unsigned int m = selout[8 * f], ncand = selout[8 * f + 1], ncomp = selout[8 * f + 2], cut_key = selout[8 * f + 3];
+            if (bg_tiles) ab_count_fallback(ctx, AB_FB_LABEL_TILES_DENSE, selout[8 * f + 4]);
             sel_m[f] = m;
             sel_ncand[f] = ncand;
             sel_ncomp[f] = ncomp;

@@ -1229,7 +1229,8 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     const int64_t total = rows * cols;
     const bool partial = out_sum_dev != nullptr;
 
-    AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kRejSlots * sizeof(unsigned long long), ctx->stream));
+    const bool first_chunk = !ctx->stack_keep_counters;  // (sharded.hip stacks in row chunks: the later ones add to the first one's counts and events)
+    if (first_chunk) AB_HIP(ctx, hipMemsetAsync(ctx->counters, 0, kRejSlots * sizeof(unsigned long long), ctx->stream));
     // 65 .. 128 contiguous frames, plain full-image stack: still one lane per pixel, 128 samples in registers (one wave per
     // SIMD).  Everything else beyond 64 frames -- ragged strides, partial sums, the median combine, the exact engine, more
     // than 128 frames -- takes one wave per pixel (stack_wide.hip).
@@ -1240,7 +1241,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
         ctx->stack_ev_valid = false;
-        AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
+        if (first_chunk) AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
         // 257 .. 512 contiguous frames, plain full-image stack or median combine: two lanes per pixel (stack_pair.hip), bit-identical
         // to the wave-per-pixel kernel (AB_STACK_NO_PAIR=1 keeps that one); everything else: one wave per pixel (stack_wide.hip)
         // 513 .. 4096: the wave-per-pixel kernel with 16 / 32 / 64 registers per lane; beyond: one workgroup per pixel, samples
@@ -1314,7 +1315,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
         ctx->stack_ev_valid = false;
-        AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
+        if (first_chunk) AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
         if (np == 256) {  // 129 .. 256 contiguous frames: 256 samples per lane (VGPRs + AGPRs), single pass
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
             // frame-count classes of 32 (AB_STACK_NO_CLASSES=1: every count pays for 256): the pads' loads and the network's

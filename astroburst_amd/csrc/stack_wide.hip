@@ -55,10 +55,39 @@ __device__ __forceinline__ double ranked_sum(const float (&x)[K], int a, int b, 
     return s;
 }
 
+// The same sums as a TREE (round 6, the default engine of the > 512-frame stacks): every lane adds its own K sorted elements inside
+// [a, b] in f64, then six butterfly steps.  The serial ascending chain above is what made a 1024-frame pixel cost ~32 000
+// instructions (2 x 1024 dependent f64 adds per iteration); the tree is ~100.  It is the <= 64-frame fast engine's contract, not
+// the oracle's order: f64 sums of <= 4096 f32 values in another order differ in their last bits, the f32 result almost never
+// (tests: 1e-5 relative, at most 1e-4 of the pixels may differ at all, measured none); AB_STACK_EXACT=1 keeps the chain.
+template <int K, int MODE>
+__device__ __forceinline__ double ranked_sum_tree(const float (&x)[K], int a, int b, double mean, int lane) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int e = lane * K + k;
+        const double v = (double)x[k];
+        const double t = MODE == 0 ? v : (v - mean) * (v - mean);
+        s += (e >= a && e <= b) ? t : 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    return s;
+}
+template <int K, int MODE, bool TREE>
+__device__ __forceinline__ double ranked_sum_any(const float (&x)[K], int a, int b, double mean, int lane) {
+    if constexpr (TREE) return ranked_sum_tree<K, MODE>(x, a, b, mean, lane);
+    return ranked_sum<K, MODE>(x, a, b, mean);
+}
+
 // sigma_clip_combine of one pixel whose samples sit in x[] (non-finite ones already replaced by +inf, `fin` of this lane's are
 // finite); returns the rejected-sample count and writes the outputs from lane 0
-template <int K>
-__device__ __forceinline__ uint32_t wide_pixel(const WideArgs &a, int64_t g, float (&x)[K], int fin, int lane) {
+// `row` (nullable): 64 K floats of LDS that belong to this wave alone (the staged pixel's row, already consumed).  With it the MAD
+// needs no second sort: among SORTED samples the deviations left and right of the median are two sorted runs, and the m-th smallest
+// of their merge is min over p = 0 .. m of max(med - x[p], x[p + m] - med) (x[>= n] = +inf) -- stack_sigma_clip.hip's med_mad_at,
+// evaluated here by the whole wave at once: the sorted samples go to the row, every lane reads its elements' partners p + m back.
+template <int K, bool TREE = false>
+__device__ __forceinline__ uint32_t wide_pixel(const WideArgs &a, int64_t g, float (&x)[K], int fin, int lane, float *row = nullptr) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) fin += __shfl_xor(fin, off, 64);
     const int n = __builtin_amdgcn_readfirstlane(fin);  // finite samples: sorted ranks [0, n); uniform by construction
@@ -77,11 +106,32 @@ __device__ __forceinline__ uint32_t wide_pixel(const WideArgs &a, int64_t g, flo
             value = med;
         } else {
             // MAD (combine.rs:42-46): the n/2-th smallest |v - med| -- sort the deviations the same way
-            float d[K];
+            float mad;
+            if (row) {
+                const int m = n >> 1;
 #pragma unroll
-            for (int k = 0; k < K; ++k) d[k] = (lane * K + k) < n ? fabsf(x[k] - med) : __builtin_inff();
-            wave_sort<K>(d, lane);
-            const float mad = elem<K>(d, n >> 1);
+                for (int k = 0; k < K; ++k) row[lane * K + k] = x[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float best = __builtin_inff();
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const int p = lane * K + k, q = p + m;
+                    const float xq = q < 64 * K ? row[q < 64 * K ? q : 0] : __builtin_inff();
+                    const float term = fmaxf(med - x[k], xq - med);
+                    best = p <= m ? fminf(best, term) : best;
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) best = fminf(best, __shfl_xor(best, off, 64));
+                mad = best;
+            } else {
+                float d[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) d[k] = (lane * K + k) < n ? fabsf(x[k] - med) : __builtin_inff();
+                wave_sort<K>(d, lane);
+                mad = elem<K>(d, n >> 1);
+            }
             float sigma = (float)fmax((double)mad * kMadToSigma, 1e-10);
             float center = med, last_center = __builtin_nanf("");
             int lo_r = 0, hi_r = n - 1;  // survivors = sorted ranks lo_r..hi_r (`v - center` is monotone in v)
@@ -89,8 +139,8 @@ __device__ __forceinline__ uint32_t wide_pixel(const WideArgs &a, int64_t g, flo
                 if (len < 2) break;  // combine.rs:33-35
                 if (it > 0) {        // mean / sample variance of the survivors, f64, ascending (combine.rs:50-60)
                     const double nn = (double)len;
-                    const double mean = ranked_sum<K, 0>(x, lo_r, hi_r, 0.0) / nn;
-                    const double q = ranked_sum<K, 1>(x, lo_r, hi_r, mean);
+                    const double mean = ranked_sum_any<K, 0, TREE>(x, lo_r, hi_r, 0.0, lane) / nn;
+                    const double q = ranked_sum_any<K, 1, TREE>(x, lo_r, hi_r, mean, lane);
                     const double variance = q / fmax(nn - 1.0, 1.0);
                     center = (float)mean;
                     sigma = (float)fmax(sqrt(variance), 1e-10);
@@ -123,7 +173,7 @@ __device__ __forceinline__ uint32_t wide_pixel(const WideArgs &a, int64_t g, flo
             if (len == 0) {  // combine.rs:85-88
                 value = __builtin_isfinite(last_center) ? last_center : 0.0f;
             } else {
-                S = ranked_sum<K, 0>(x, lo_r, hi_r, 0.0);  // combine.rs:90-91
+                S = ranked_sum_any<K, 0, TREE>(x, lo_r, hi_r, 0.0, lane);  // combine.rs:90-91
                 value = (float)(S / (double)len);
             }
         }
@@ -206,6 +256,64 @@ __global__ __launch_bounds__(256) void stack_wide_quad_kernel(const WideArgs a) 
     if (lane == 0 && rej_total) atomicAdd(&a.rejected[wave_id & (kRejSlots - 1)], rej_total);
 }
 
+// 513 .. 4096 contiguous frames (round 6): a pixel's 4 bytes are all a wave of stack_wide_kernel uses of every
+// 64-byte line it touches -- 16 x the algorithmic traffic, and that, not the ~3000 instructions per pixel, made 1024 x 2048^2 take
+// 242 ms (0.07 TB/s of samples).  Here a workgroup stages G = 16 / 8 / 4 ADJACENT pixels of all n frames through LDS (K = 16 / 32 / 64:
+// 64 KB) with 16-byte loads -- every byte fetched is used -- and its four waves then combine the pixels one after the other with
+// the same wide_pixel (bit-identical results).  Needs contiguous 16-byte aligned planes and a pixel count that is a multiple of 16.
+constexpr int kTileWaves = 8;  // 512 threads: two workgroups of 64 KB per CU are then four waves per SIMD
+template <int K, bool TREE>
+__global__ __launch_bounds__(64 * kTileWaves) void stack_wide_tile_kernel(const WideArgs a) {
+    constexpr int G = 256 / K, NPAD = 64 * K;  // pixels per group (G x NPAD floats = 64 KB), frames padded to the wave's 64 K slots
+    static_assert(G >= 4 && G % 4 == 0 && G * NPAD * 4 == 65536, "32 / 16 / 8 / 4 adjacent pixels in 64 KB");
+    extern __shared__ __attribute__((aligned(16))) float tile[];  // [G][NPAD]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int64_t groups = (a.rows * a.cols) / G;
+    for (int i = t; i < G * (NPAD - a.n); i += 64 * kTileWaves) {  // the slots past the last frame: +inf, once
+        const int row = i / (NPAD - a.n), col = a.n + i % (NPAD - a.n);
+        tile[row * NPAD + col] = __builtin_inff();
+    }
+    unsigned long long rej_total = 0;
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int64_t base = grp * G;
+        constexpr int QPF = G / 4;  // 16-byte quads per frame and group
+        for (int i0 = 0; i0 < a.n * QPF; i0 += 64 * kTileWaves * 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * kTileWaves * u + t;
+                if (i < a.n * QPF) v[u] = *reinterpret_cast<const float4 *>(a.p[i / QPF] + base + 4 * (i % QPF));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * kTileWaves * u + t;
+                if (i < a.n * QPF) {
+                    const int f = i / QPF, q = i % QPF;
+                    tile[(4 * q + 0) * NPAD + f] = v[u].x;
+                    tile[(4 * q + 1) * NPAD + f] = v[u].y;
+                    tile[(4 * q + 2) * NPAD + f] = v[u].z;
+                    tile[(4 * q + 3) * NPAD + f] = v[u].w;
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = wv; j < G; j += kTileWaves) {
+            float x[K];
+            int fin = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float sv = tile[j * NPAD + lane + 64 * k];
+                const bool ok = __builtin_isfinite(sv);  // (the +inf of an absent frame is not finite either)
+                x[k] = ok ? sv : __builtin_inff();
+                fin += ok ? 1 : 0;
+            }
+            rej_total += wide_pixel<K, TREE>(a, base + j, x, fin, lane, tile + j * NPAD);
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && rej_total) atomicAdd(&a.rejected[(blockIdx.x * (unsigned int)kTileWaves + (unsigned int)wv) & (kRejSlots - 1)], rej_total);
+}
+
 }  // namespace
 
 // dplanes / ld are HOST arrays of n entries (64 < n <= 512); counters already cleared by the caller
@@ -241,7 +349,27 @@ int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t
     for (size_t i = 0; i < n && quad; ++i) quad = ((uintptr_t)dplanes[i] & 15) == 0;
     // 513 .. 4096 frames (K = 16, 32, 64 registers per lane and array): the same wave-per-pixel definition, one pixel at a time
     // (four pixels' worth of 16-byte loads would not fit the register file beside two sort arrays)
-    if (n > 2048) {
+    // (the LDS-staged form: contiguous 16-byte aligned planes, whole groups of 16 pixels; two workgroups of 64 KB per CU)
+    const int64_t gpx = n > 2048 ? 4 : (n > 1024 ? 8 : (n > 512 ? 16 : 32));  // pixels per group of stack_wide_tile_kernel<64 / 32 / 16 / 8>
+    const bool tiled = quad && total % gpx == 0 && n > 256;  // (257 .. 512 frames reach this file only where stack_pair.hip does not take them)
+    const int tgrid = (int)std::max<int64_t>(1, std::min<int64_t>(total / 4, (int64_t)(ctx->cu_count > 0 ? ctx->cu_count : 256) * 2));
+    // the tree sums: the default engine here; the partial sums of the sharded estimator and AB_STACK_EXACT=1 keep the ascending chain
+    const bool tree = !ctx->stack_exact && !out_sum_dev;
+#define AB_WIDE_TILE(KK, TT)                                                                                                                   \
+    do {                                                                                                                                       \
+        AB_HIP(ctx, hipFuncSetAttribute((const void *)stack_wide_tile_kernel<KK, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));  \
+        hipLaunchKernelGGL((stack_wide_tile_kernel<KK, TT>), dim3(tgrid), dim3(64 * kTileWaves), 65536, ctx->stream, a);                                 \
+    } while (0)
+    if (tiled && n > 2048) {
+        if (tree) AB_WIDE_TILE(64, true); else AB_WIDE_TILE(64, false);
+    } else if (tiled && n > 1024) {
+        if (tree) AB_WIDE_TILE(32, true); else AB_WIDE_TILE(32, false);
+    } else if (tiled && n > 512) {
+        if (tree) AB_WIDE_TILE(16, true); else AB_WIDE_TILE(16, false);
+    } else if (tiled) {
+        if (tree) AB_WIDE_TILE(8, true); else AB_WIDE_TILE(8, false);
+#undef AB_WIDE_TILE
+    } else if (n > 2048) {
         hipLaunchKernelGGL(stack_wide_kernel<64>, dim3(grid), dim3(256), 0, ctx->stream, a);
     } else if (n > 1024) {
         hipLaunchKernelGGL(stack_wide_kernel<32>, dim3(grid), dim3(256), 0, ctx->stream, a);

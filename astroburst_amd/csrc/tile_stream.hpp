@@ -89,6 +89,7 @@ struct alignas(16) Shared {
     int zone_tab[kMaxZones];              // table index of bucket zone_lo[z] - 1
     int nzones;
     int decline;
+    unsigned int ncand;  // pass 2: entries appended to the tile's candidate list (CandSink)
 #ifdef AB_TILE_TIMING
     long long t_phase[16];  // 0 sample 1 pass1 2 scan 3 plan 4 zones+lut 5 pass2 6 rest of rounds; rounds: 8 v:find+gather 9 v:select 10 d:geo 11 d:first 12 d:gather 13 d:select 14 d:proof 15 edges
     long long t_mark;
@@ -870,11 +871,51 @@ __device__ __forceinline__ float4 load4u(const float *p) {
     const F4u t = *reinterpret_cast<const F4u *>(p);
     return make_float4(t.x, t.y, t.z, t.w);
 }
+__device__ __forceinline__ bool whole_tile(const TileRect &r) { return r.vec && r.y1 - r.y0 == 256 && r.x1 - r.x0 == 256; }
+// A WHOLE tile in BATCHES of 16 pixels: f(v[16], position of v[0], ...) -- the same loads in the same order as stream_tile's first
+// branch; pixel i of a batch sits at position base + (i / 4) * (kWaves * 256) + (i % 4) of the tile (256 * row + column).  Pass 2 wants
+// the batch: per pixel it is three DEPENDENT LDS round trips (zone table -> atomic with return -> list store), and written pixel by
+// pixel the compiler must keep them in order across pixels too (the byte-typed table may alias anything): 512 round trips per thread,
+// 58 000 of a tile's cycles.  Sixteen reads, then sixteen atomics, then sixteen stores are three round trips per batch.
+template <class F>
+__device__ __forceinline__ void stream_whole_tile_batches(const TileRect &r, F f) {
+    constexpr int U = 4, kRounds = 64 / (2 * U);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const float *p = r.img + (int64_t)(r.y0 + wv) * r.ld + r.x0 + 4 * lane;
+    const int64_t step = (int64_t)kWaves * r.ld;
+    float4 A[U], B[U];
+    auto load = [&](float4(&X)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) X[u] = load4u(p + u * step);
+        p += U * step;
+    };
+    unsigned int at = (unsigned int)(wv * 256 + 4 * lane);  // position of the batch's first pixel
+    auto eat = [&](const float4(&X)[U]) {
+        float v[4 * U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[4 * u + 0] = X[u].x;
+            v[4 * u + 1] = X[u].y;
+            v[4 * u + 2] = X[u].z;
+            v[4 * u + 3] = X[u].w;
+        }
+        f(v, at);
+        at += (unsigned int)(U * kWaves * 256);
+    };
+    load(A);
+#pragma unroll 1
+    for (int it = 0; it < kRounds; ++it) {
+        load(B);
+        eat(A);
+        if (it + 1 < kRounds) load(A);
+        eat(B);
+    }
+}
 // f(raw value) for every pixel of the tile (NaN where a lane has no pixel)
 template <class F>
 __device__ __forceinline__ void stream_tile(const TileRect &r, F f) {
     const int t = threadIdx.x;
-    if (r.vec && r.y1 - r.y0 == 256 && r.x1 - r.x0 == 256) {
+    if (whole_tile(r)) {
         // A whole tile: wave w reads rows w, w + 4, ... -- 64 rows of 256 px, one float4 per lane.  Four rows are processed while
         // the next four are in flight (two register sets, taking turns): a wave that waits for every batch it has just asked for
         // exposes the memory latency eight times per pass.
@@ -1013,10 +1054,36 @@ __device__ __forceinline__ bool zoom_from_sample(Shared &sh, const TileRect &r, 
     return sig > 0.0f && __builtin_isfinite(g->scale) && __builtin_isfinite(g->off) && g->scale > 0.0f;
 }
 
+// ---- the tile's CANDIDATE LIST (round 6) ------------------------------------------------------------------------
+// The registration's labelling pass used to stream every frame from HBM a second time to find the ~1 % of its pixels above the
+// detection threshold T = median of tile medians + 3.5 x median of tile sigmas (star_detection.rs:70-84, :103) -- a number nobody
+// knows before the last tile of the frame is done.  Pass 2 has every pixel in hand, so a WHOLE tile now also appends
+// {position in the tile, raw value} of every pixel in bucket >= cb to a list in global memory, cb = the sample's median + kCandSigmas
+// sample sigmas (buckets are uniform in the raw value, so "bucket >= cb" is "raw >= cut", cut = the smallest float of bucket cb,
+// exactly).  The labelling kernel (detect.hip: label_bgtile_body) then checks xf(cut) <= T per tile -- xf is non-decreasing, so
+// every pixel NOT on the list has xf(raw) <= xf(cut) <= T: the list is a superset of the thresholded set and what it labels is
+// bit-identical -- and labels the tile from the list alone (1 - 2 % of the pixels, 8 bytes each).  A tile whose list is missing
+// (cut = NaN: not a whole tile, declined before pass 2, no usable geometry), overflowed (count > cap) or cut too high (a tile
+// brighter than the frame's threshold) is read from the frame, as before.
+struct CandSink {
+    uint2 *ent = nullptr;         // this tile's segment of `cap` entries {position = 256 * row + column, raw bits}
+    unsigned int *cnt = nullptr;  // this tile's count (may exceed cap: the list is then not usable)
+    float *cut = nullptr;         // this tile's cut (NaN: no list)
+    unsigned int cap = 0;
+};
+#ifndef TS_CAND_SIGMAS
+#define TS_CAND_SIGMAS 2.5f
+#endif
+constexpr float kCandSigmas = TS_CAND_SIGMAS;  // 3.5 is the matcher's threshold; 2.5 leaves a tile one sigma of offset against the frame's median
+
 // the whole tile; wave 0's threads return the result (the other waves: `declined` only)
-__device__ __forceinline__ TileResult tile_stats(Shared &sh, const TileRect &r, const ab_pixel_xf &xf) {
+__device__ __forceinline__ TileResult tile_stats(Shared &sh, const TileRect &r, const ab_pixel_xf &xf, const CandSink cs = CandSink()) {
     const int t = threadIdx.x;
     TileResult res = {0.0, 1.0, 0, 0};
+    if (cs.cut && t == 0) {
+        *cs.cut = __builtin_nanf("");  // (until pass 2 has run: every early return leaves "no list")
+        *cs.cnt = 0u;
+    }
 #ifdef AB_TILE_TIMING
     if (t == 0) {
         for (int i = 0; i < 16; ++i) sh.t_phase[i] = 0;
@@ -1026,6 +1093,7 @@ __device__ __forceinline__ TileResult tile_stats(Shared &sh, const TileRect &r, 
     if (t == 0) {
         sh.decline = D_NONE;
         sh.nzones = 0;
+        sh.ncand = 0u;
     }
 #pragma unroll
     for (int i = 0; i < kPer; i += 4) *reinterpret_cast<uint4 *>(&sh.prefix[t * kPer + i]) = make_uint4(0u, 0u, 0u, 0u);
@@ -1063,13 +1131,54 @@ __device__ __forceinline__ TileResult tile_stats(Shared &sh, const TileRect &r, 
     __syncthreads();
     TS_MARK(sh, 4);
     // ---- pass 2: the hot pixels, by zone (no branches: what is not hot lands in the thread's scratch words) ----
-    stream_tile(r, [&](float v) {
-        unsigned int z = sh.lut[g.bucket(v)];
-        z = g.is_cand(v) ? z : 0u;
-        const unsigned int at = atomicAdd(&sh.zcur[z ? z - 1u : (unsigned int)(kMaxZones + t)], 1u);
-        sh.list[(z && at < (unsigned int)kHotCap) ? at : (unsigned int)(kHotCap + t)] = v;
-    });
+    // the candidate list's cut: bucket cb (the sample's median sits in bucket 2048, a sample sigma is kPerSigma buckets) and the
+    // smallest float in it; without an exact cut there is no list
+    const int cb = (kBuckets - 2) / 2 + 1 + (int)(kCandSigmas * kPerSigma);
+    float cut_raw = 0.0f;
+    const bool emit = cs.ent != nullptr && cb > 1 && cb < kTop && whole_tile(r) && g.first_raw(cb, &cut_raw);  // (block-uniform)
+    if (whole_tile(r)) {
+        // sixteen pixels at a time, phase by phase (see stream_whole_tile_batches); `emit` is block-uniform
+        stream_whole_tile_batches(r, [&](const float(&v)[16], unsigned int pos0) {
+            int b[16];
+            unsigned int z[16], at[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) b[i] = g.bucket(v[i]);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = sh.lut[b[i]];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = g.is_cand(v[i]) ? z[i] : 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) at[i] = atomicAdd(&sh.zcur[z[i] ? z[i] - 1u : (unsigned int)(kMaxZones + t)], 1u);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sh.list[(z[i] && at[i] < (unsigned int)kHotCap) ? at[i] : (unsigned int)(kHotCap + t)] = v[i];
+            if (emit) {
+                unsigned int hit = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hit |= (b[i] >= cb && v[i] <= g.r_max) ? 1u << i : 0u;  // (NaN fails the second test)
+                while (hit) {  // rare: 1 - 2 % of the pixels
+                    const int i = __builtin_ctz(hit);
+                    hit &= hit - 1u;
+                    const unsigned int ca = atomicAdd(&sh.ncand, 1u);
+                    float vi = v[0];
+#pragma unroll
+                    for (int k = 1; k < 16; ++k) vi = i == k ? v[k] : vi;  // (no runtime index into the register array)
+                    if (ca < cs.cap) cs.ent[ca] = make_uint2(pos0 + (unsigned int)((i >> 2) * (kWaves * 256) + (i & 3)), __float_as_uint(vi));
+                }
+            }
+        });
+    } else {
+        stream_tile(r, [&](float v) {
+            unsigned int z = sh.lut[g.bucket(v)];
+            z = g.is_cand(v) ? z : 0u;
+            const unsigned int at = atomicAdd(&sh.zcur[z ? z - 1u : (unsigned int)(kMaxZones + t)], 1u);
+            sh.list[(z && at < (unsigned int)kHotCap) ? at : (unsigned int)(kHotCap + t)] = v;
+        });
+    }
     __syncthreads();
+    if (emit && t == 0) {
+        *cs.cnt = sh.ncand;
+        *cs.cut = cut_raw;
+    }
     // the list as normalised keys, in place (the only place the normalisation is evaluated for more than a handful of values)
     {
         const unsigned int n = sh.zone_at[sh.nzones];

@@ -1302,6 +1302,12 @@ pub fn stack_sharded(hip: &Hip, comm: &Comm, local_planes: &[DevicePlane], confi
     hip.check(unsafe { sys::ab_stack_sigma_clip_sharded(hip.ctx, comm.0, planes.as_ptr(), planes.len(), &stack_cfg(config), &mut out.ab_mut(), &mut rejected) })?;
     Ok(rejected)
 }
+/// (partial stacks' span on the context's stream, time inside the all-reduces + divisions on the comm stream) of the last `stack_sharded`, ms
+pub fn stack_sharded_last_ms(hip: &Hip) -> Result<(f32, f32)> {
+    let (mut stack_ms, mut comm_ms) = (0f32, 0f32);
+    hip.check(unsafe { sys::ab_stack_sharded_last_ms(hip.ctx, &mut stack_ms, &mut comm_ms) })?;
+    Ok((stack_ms, comm_ms))
+}
 pub fn allgather_rows(hip: &Hip, comm: &Comm, band: &DevicePlane, full: &mut DevicePlane) -> Result<()> {
     hip.check(unsafe { sys::ab_allgather_rows(hip.ctx, comm.0, &band.ab(), &mut full.ab_mut()) })
 }
@@ -1310,6 +1316,24 @@ pub fn register_frames_sharded(hip: &Hip, comm: &Comm, reference: &DevicePlane, 
     let planes: Vec<_> = targets.iter().map(|t| t.ab()).collect();
     let mut out: Vec<sys::ab_affine_align_result> = vec![unsafe { std::mem::zeroed() }; targets.len()];
     hip.check(unsafe { sys::ab_register_frames_sharded(hip.ctx, comm.0, &reference.ab(), planes.as_ptr(), planes.len(), num_threads(), out.as_mut_ptr()) })?;
+    Ok(out.iter().map(align_from_sys).collect())
+}
+/// the row-band scheme's registration as one call: this rank's rows `[row0, row0 + bands[i].rows)` of every registered frame.  `targets[i]` holds
+/// rows `[target_row0[i], ..)` of target i -- whole for the targets this rank estimates (i mod size == rank); own frames are warped as they are
+/// fitted, the estimates are exchanged, the other frames are warped from their bands
+pub fn align_pairs_affine_rowband(hip: &Hip, comm: &Comm, reference: &DevicePlane, targets: &[DevicePlane], target_row0: &[usize], row0: usize,
+                                  bands: &mut [DevicePlane]) -> Result<Vec<AffineAlignResult>> {
+    if targets.len() != target_row0.len() || targets.len() != bands.len() {
+        bail!("align_pairs_affine_rowband: {} targets, {} first rows, {} bands", targets.len(), target_row0.len(), bands.len());
+    }
+    let planes: Vec<_> = targets.iter().map(|t| t.ab()).collect();
+    let first: Vec<i64> = target_row0.iter().map(|&r| r as i64).collect();
+    let mut outs: Vec<_> = bands.iter_mut().map(|b| b.ab_mut()).collect();
+    let mut out: Vec<sys::ab_affine_align_result> = vec![unsafe { std::mem::zeroed() }; targets.len()];
+    hip.check(unsafe {
+        sys::ab_align_pairs_affine_rowband(hip.ctx, comm.0, &reference.ab(), planes.as_ptr(), first.as_ptr(), planes.len(), num_threads(), row0 as i64,
+                                           out.as_mut_ptr(), outs.as_mut_ptr())
+    })?;
     Ok(out.iter().map(align_from_sys).collect())
 }
 /// compute_image_stats of an image of which this rank holds a row band (histograms all-reduced in stream)

@@ -125,6 +125,8 @@ typedef enum {
     AB_FB_TILES_DECLINED,     /* background tiles the streaming kernel declined (settled by the resident tile kernel) */
     AB_FB_STATS_CHAIN,        /* compute_image_stats launches whose resident kernel aborted and were repeated as the chain */
     AB_FB_STACK_GENERAL_PIXELS, /* pixels the stack's fast pass handed to its general pass (counted only under AB_TRACE=1) */
+    AB_FB_LABEL_TILES_DENSE,  /* 256 x 256 labelling tiles of registration frames read from the frame: no usable candidate list from the tile pass
+                                 (a partial tile, a tile brighter than the frame's threshold, an overflowed list, a tile the streaming kernel declined) */
     AB_FB_COUNT
 } ab_fallback_kind;
 AB_API int ab_ctx_fallback_counts(ab_ctx *ctx, uint64_t *out, size_t cap, int reset);
@@ -705,12 +707,24 @@ AB_API int ab_stack_sigma_clip_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plan
  * reference's estimator (a median over all frames is not decomposable); checker: orc_stack_partial_noalign. */
 AB_API int ab_stack_sigma_clip_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *local_planes, size_t n_local,
                                        const ab_stack_config *cfg, ab_plane_mut *out, uint64_t *out_rejected_total);
+/* the last ab_stack_sigma_clip_sharded of this context: the span of its partial stacks on the context's stream, and the time inside
+ * its all-reduces + divisions (they run chunk by chunk on a second stream while the next chunk is stacked: with overlap the two add
+ * up to more than the call took).  Blocks until that call's work is done.  bench.py: stage_ms.comm_* */
+AB_API int ab_stack_sharded_last_ms(ab_ctx *ctx, float *stack_ms, float *comm_ms);
 /* every rank's band -> the full image on every rank (one broadcast per rank inside one RCCL group) */
 AB_API int ab_allgather_rows(ab_ctx *ctx, ab_comm *comm, const ab_plane *band, ab_plane_mut *full);
 /* align_channel_affine(reference, targets[i]) for i < n, target i estimated on rank i mod size, all n results on every
  * rank (exchanged bit for bit as integer words); targets a rank does not own are not read there */
 AB_API int ab_register_frames_sharded(ab_ctx *ctx, ab_comm *comm, const ab_plane *reference, const ab_plane *targets, size_t n,
                                       int num_threads, ab_affine_align_result *out);
+/* The row-band scheme's registration as ONE call (pair.rs:41-77 per target): this rank's rows [row0, row0 + out_bands[i].rows)
+ * of warp_image(target i, its transform) for every i.  targets[i] holds rows [target_row0[i], + targets[i].rows) of target i
+ * (target_row0 NULL = whole frames): whole for the targets this rank estimates (i mod size == rank), of the others at least the rows
+ * its band reads (ab_shard_source_rows).  Own frames are warped as they are fitted, overlapped with the remaining estimates; then the
+ * estimates are exchanged and the other frames warped from their bands.  out[i] / the pixels equal ab_register_frames_sharded +
+ * ab_warp_image_rows(_from_band) bit for bit. */
+AB_API int ab_align_pairs_affine_rowband(ab_ctx *ctx, ab_comm *comm, const ab_plane *reference, const ab_plane *targets, const int64_t *target_row0,
+                                         size_t n, int num_threads, int64_t row0, ab_affine_align_result *out, ab_plane_mut *out_bands);
 /* compute_image_stats (stats.rs:15-210) of an image whose rows are spread over the ranks: `band` = this rank's rows,
  * total_rows = the whole image's.  min / max, counts and the 65 536-bin histograms are all-reduced between the passes
  * (integers: every bin equals the single-GPU bin); every rank receives the whole image's statistics. */

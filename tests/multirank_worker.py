@@ -279,7 +279,16 @@ def scenario_bands(ab, ctx, comm, rank, nranks, out):
     regs = ctx.register_frames_sharded(comm, ref_dev, dev_targets, num_threads=8)
     transforms = [r.transform for r in regs]
     say("registered")
-    del dev_targets
+    # round 6: the same through ab_align_pairs_affine_rowband (own frames whole and warped as they are fitted, the others from
+    # their rows + halo after the exchange) -- checked further down against the step-by-step route, pixel for pixel
+    row0_, nrows_ = ctx.shard_rows(rows, nranks, rank)
+    s0_, sn_ = ctx.shard_source_rows(transforms, rows, cols, rows, cols, nranks, rank)
+    one_call_in = [dev_targets[i] if i in mine else tgts[i][s0_:s0_ + sn_].contiguous().cuda() for i in range(n)]
+    one_call_out = [torch.empty((nrows_, cols), device="cuda") for _ in range(n)]
+    regs1 = ctx.align_pairs_affine_rowband(comm, ref_dev, one_call_in, one_call_out, row0_, target_row0=[0 if i in mine else s0_ for i in range(n)], num_threads=8)
+    assert [(r.method, r.transform, r.inliers) for r in regs1] == [(r.method, r.transform, r.inliers) for r in regs], "the one-call registration differs"
+    say("registered in one call")
+    del dev_targets, one_call_in
     row0, nrows = ctx.shard_rows(rows, nranks, rank)
     s0, sn = ctx.shard_source_rows(transforms, rows, cols, rows, cols, nranks, rank)
     resident = 0
@@ -292,6 +301,7 @@ def scenario_bands(ab, ctx, comm, rank, nranks, out):
         resident += band_dev.numel() * 4
         o = torch.empty((nrows, cols), device="cuda")
         ctx.warp_image_rows_from_band(band_dev, s0, rows, transforms[i], rows, row0, o)
+        assert torch.equal(torch.nan_to_num(o, nan=-1.0), torch.nan_to_num(one_call_out[i], nan=-1.0)), f"frame {i}: the one-call band differs"
         warped.append(o)
     # (the frames are bands already: the band-local stack + the rejected count summed over the ranks)
     say("warped")

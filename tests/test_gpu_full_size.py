@@ -155,7 +155,9 @@ def test_c4_per_gpu_leg_64x4096_partial_allreduce_finalize(tctx, oracle):
         out = torch.empty((r, c), device="cuda")
         before = comm.collectives_issued
         _, rej = ctx.stack_sigma_clip_sharded(comm, frames, out, want_rejected=True)
-        assert comm.collectives_issued - before == 3                    # sum, count, rejected
+        assert comm.collectives_issued - before == 2 * 4 + 1            # (sum, count) of each of the four row chunks + rejected
+        stack_ms, comm_ms = ctx.stack_sharded_last_ms()                # the library's own spans: partial stacks | collectives + divisions
+        assert 0.5 < stack_ms < 10.0 and 0.0 < comm_ms < 10.0, (stack_ms, comm_ms)
         for row0 in (0, 1998, 4088):
             crop = [f[row0:row0 + 8].cpu().numpy() for f in frames]
             s, cnt, _ = oracle.stack_partial(crop, 3.0, 3.0, 5)

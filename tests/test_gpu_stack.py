@@ -172,10 +172,13 @@ def test_deep_stacks_one_wave_per_pixel(ctx, oracle, n, shape):
 
 
 @pytest.mark.parametrize("n", [513, 700, 1024, 1025, 2048, 2100, 4096])
-def test_more_than_512_frames_wave_per_pixel(ctx, oracle, n):
+def test_more_than_512_frames_wave_per_pixel(engine, oracle, n):
     """VERDICT r4 missing 2: the reference stacks whatever `paths` holds (calibration.rs:297-318 -> combine.rs:94-193).  513 .. 4096
-    frames: stack_wide.hip with 16 / 32 / 64 registers per lane.  64 x 96 frames, dirty (NaN / inf / ties / constant / empty /
-    single-sample pixels) and clean, bit for bit against the oracle: kappa-sigma, rejection count, median combine."""
+    frames: stack_wide.hip with 16 / 32 / 64 registers per lane, sixteen / eight / four adjacent pixels staged through LDS (round 6).
+    64 x 96 frames, dirty (NaN / inf / ties / constant / empty / single-sample pixels) and clean: kappa-sigma, rejection count, median
+    combine.  Round 6: the default engine sums the survivors as a tree (the <= 64-frame fast engine's contract: 1e-5 relative, at most
+    1e-4 of the pixels may differ at all); the exact engine (AB_STACK_EXACT=1: the oracle's ascending chain) is held bit for bit."""
+    ctx, exact = engine
     shape = (64, 96) if n <= 1024 else (16, 24)
     fr = deep_frames(n, shape, 9000 + n)
     rng = np.random.default_rng(n)
@@ -186,9 +189,17 @@ def test_more_than_512_frames_wave_per_pixel(ctx, oracle, n):
         for sl, sh, it in ((3.0, 3.0, 5), (1.0, 1.0, 2)):
             want, wrej = oracle.stack_images(frames, sl, sh, it)
             got, rej = ctx.stack_sigma_clip(frames, sl, sh, it)
-            assert rej == wrej, (name, sl, sh, it)
-            assert np.array_equal(got, want, equal_nan=True), (name, sl, sh, it)
+            assert_stack_parity(got, want, rej, wrej, exact)
         assert np.array_equal(ctx.median_combine(frames), oracle.median_combine(frames), equal_nan=True), name
+
+
+def test_more_than_512_frames_unaligned_pixel_counts(ctx, oracle):
+    """a pixel count that is not a multiple of 16 keeps the wave-per-pixel kernel without the LDS staging (and its ascending sums)"""
+    n, shape = 600, (7, 9)
+    fr = deep_frames(n, shape, 77)
+    want, wrej = oracle.stack_images(fr, 3.0, 3.0, 5)
+    got, rej = ctx.stack_sigma_clip(fr, 3.0, 3.0, 5)
+    assert rej == wrej and np.array_equal(got, want, equal_nan=True)
 
 
 def test_more_than_4096_frames_workgroup_per_pixel(ctx, oracle):
