@@ -5,6 +5,6 @@ include/astroburst_hip.h).  `core` mirrors the reference's `core::*` Rust functi
 ABI for tests and benchmarks; `synth` makes deterministic synthetic frame stacks.
 """
 from ._lib import AstroBurstError, LIB_PATH, build, declared_symbols, is_dev_build, version  # noqa: F401
-from .core import Comm, Context, ImageStats, StackResult, StfParams  # noqa: F401
+from .core import Comm, Context, ImageStats, PlaneList, StackResult, StfParams  # noqa: F401
 
 __version__ = "0.2.0"

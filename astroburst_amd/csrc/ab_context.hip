@@ -513,6 +513,9 @@ int ab_parallel_frames(ab_ctx *ctx, size_t n, const char *what, const std::funct
         if (ab_ctx_create(ctx->device, &wc) != AB_OK) return ab_set_error(ctx, AB_ERR_HIP, "cannot create %s worker context", what);
         wc->register_workers = 1;
         wc->parent = ctx;
+        // (Round 6, measured and not kept: HIGH-priority worker streams, so that no worker shares an in-order hardware queue with the tile
+        // pipeline's stream -- the group whose worker does sits behind all tile launches, profiles/r06_register_timeline.txt -- made the
+        // step 0.9 ms SLOWER, 10.5 against 9.6 ms: profiles/r06_priority_ab.txt.)
         wc->label_legacy = ctx->label_legacy;
         wc->label_pixelwise = ctx->label_pixelwise;
         wc->detect_no_recs = ctx->detect_no_recs;  // (the parent's choices, not the environment's at the time the pool grows)

@@ -1173,7 +1173,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
     static const bool want_cand = ab_dev_env("AB_NO_CAND_LISTS") == nullptr;  // (developer A/B: the labelling reads the frames as in round 5)
     const bool fed = have_xf && (landed != nullptr || force_fed);
     if (fed) {
-        static const int chunk = ab_dev_env("AB_TILE_CHUNK") ? std::max(atoi(ab_dev_env("AB_TILE_CHUNK")), 1) : 8;
+        static const int chunk = ab_dev_env("AB_TILE_CHUNK") ? std::max(atoi(ab_dev_env("AB_TILE_CHUNK")), 1) : 16;
         static const int fed_chunk = ab_dev_env("AB_FEED_CHUNK") ? std::max(atoi(ab_dev_env("AB_FEED_CHUNK")), 1) : 4;  // frames per launch while frames are still arriving
         std::vector<const float *> order;  // reference first
         std::vector<hipEvent_t> ev;
@@ -1198,7 +1198,7 @@ int ab_register_frames_device(ab_ctx *ctx, const float *ref, const float *const 
         ab_upload_trace("percentiles joined, planes", (long)(n + 1));
         // ... and their background tiles: the tile kernel runs on its own stream, a few frames per launch, the reference first,
         // while the workers already label the frames whose tiles are done (register_one blocks on its frame's chunk)
-        static const int chunk = ab_dev_env("AB_TILE_CHUNK") ? atoi(ab_dev_env("AB_TILE_CHUNK")) : 8;  // frames per launch (0: every frame's tiles in its own chain); measured 0 / 2 / 4 / 8 / 16 -> 17.6 / 17.5 / 17.2 / 17.0 / 17.4 ms for the stage
+        static const int chunk = ab_dev_env("AB_TILE_CHUNK") ? atoi(ab_dev_env("AB_TILE_CHUNK")) : 16;  // (round 6: 16 frames per launch, 9.73 / 9.74 / 9.68 ms per step against 9.82 / 9.80 / 9.90 with 8: profiles/r06_priority_ab.txt)  // frames per launch (0: every frame's tiles in its own chain); measured 0 / 2 / 4 / 8 / 16 -> 17.6 / 17.5 / 17.2 / 17.0 / 17.4 ms for the stage
         if (chunk > 0) {
             std::vector<const float *> order;  // reference first
             std::vector<ab_pixel_xf> oxf;

@@ -241,6 +241,12 @@ def main():
     u8 = torch.empty((nrows, Cc), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
+    # the frames' ab_plane descriptors are marshalled ONCE, as a Rust / C host holds them: rebuilt per call they are 2 us of Python per
+    # plane -- 0.4 ms per step with the GPU idle (round 6; the C ABI takes `const ab_plane *` either way)
+    if not rowband and register and not args.known_transforms and not sharded:
+        targets_pl, warped_out_pl, warped_pl = ctx.planes(raw[1:]), ctx.planes(warped[1:]), ctx.planes(warped)
+    else:
+        targets_pl, warped_out_pl, warped_pl = raw[1:], warped[1:], warped
     stack_ms, warp_ms, tail_ms, est_ms, kern_ms = [], [], [], [], []
     nsteps = args.steps + args.warmup
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(nsteps)]
@@ -264,14 +270,14 @@ def main():
         else:
             if register and not args.known_transforms:
                 # align_pair(frame 0, frame k, Affine) x 63 (pair.rs:41-77): estimate + warp, frame-parallel workers
-                estimated[0] = ctx.align_pairs_affine(raw[0], raw[1:], warped[1:], num_threads=8)
+                estimated[0] = ctx.align_pairs_affine(raw[0], targets_pl, warped_out_pl, num_threads=8)
             e[0].record()
             if register and args.known_transforms:
                 for k in range(1, N):
                     ctx.warp_image(raw[k], transforms[k], R, Cc, out=warped[k])
             e[1].record()
             if not sharded:
-                ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
+                ctx.stack_sigma_clip(warped_pl, 3.0, 3.0, 5, out=stacked, want_rejected=False)
             else:  # per-GPU partial -> RCCL all-reduce(sum f64, count u32) over xGMI -> divide, all inside the library
                 ctx.stack_sigma_clip_sharded(comm, warped, stacked, 3.0, 3.0, 5, want_rejected=False)
             e[2].record()
@@ -403,10 +409,10 @@ def main():
     iso_ms = None
     if world == 1 and not sharded:
         i0, i1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
+        ctx.stack_sigma_clip(warped_pl, 3.0, 3.0, 5, out=stacked, want_rejected=False)
         i0.record()
         for _ in range(5):
-            ctx.stack_sigma_clip(warped, 3.0, 3.0, 5, out=stacked, want_rejected=False)
+            ctx.stack_sigma_clip(warped_pl, 3.0, 3.0, 5, out=stacked, want_rejected=False)
         i1.record()
         torch.cuda.synchronize()
         iso_ms = i0.elapsed_time(i1) / 5
