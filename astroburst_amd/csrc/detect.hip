@@ -289,7 +289,7 @@ __global__ __launch_bounds__(ts::kThreads) void tile_background_stream_kernel(co
         cs.cap = (unsigned int)kCandCap;
     }
     const ts::TileResult res = ts::tile_stats(sh, r, xf, cs);
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x == 64 * ts::rounds_wave()) {
         if (res.declined) {
             const unsigned int at = atomicAdd(&fail[0], 1u);
             fail[2 + at] = blockIdx.y * gridDim.x + blockIdx.x;

@@ -1076,7 +1076,19 @@ struct CandSink {
 #endif
 constexpr float kCandSigmas = TS_CAND_SIGMAS;  // 3.5 is the matcher's threshold; 2.5 leaves a tile one sigma of offset against the frame's median
 
-// the whole tile; wave 0's threads return the result (the other waves: `declined` only)
+// Which of the workgroup's four waves plans the zones and runs the rounds (alone: the other three leave): tile b's wave b mod 4, not
+// always wave 0 -- a workgroup's wave i tends to land on SIMD i, and the four tiles of a CU ran their single-wave rounds (half of a
+// tile's lifetime) on ONE SIMD.  Round 6, interleaved A/B of the bench step: 9.54 / 9.50 / 9.52 / 9.47 ms rotated against 9.68 / 9.54 /
+// 9.62 / 9.52 with wave 0 (-DTS_ROUNDS_WAVE0 keeps wave 0).
+__device__ __forceinline__ int rounds_wave() {
+#ifdef TS_ROUNDS_WAVE0
+    return 0;
+#else
+    return (int)(blockIdx.x & 3u);
+#endif
+}
+
+// the whole tile; the threads of wave rounds_wave() return the result (the other waves: `declined` only)
 __device__ __forceinline__ TileResult tile_stats(Shared &sh, const TileRect &r, const ab_pixel_xf &xf, const CandSink cs = CandSink()) {
     const int t = threadIdx.x;
     TileResult res = {0.0, 1.0, 0, 0};
@@ -1117,7 +1129,8 @@ __device__ __forceinline__ TileResult tile_stats(Shared &sh, const TileRect &r, 
     res.valid = 1;
     // ---- plan, zones (wave 0), their tables (everybody) ----
     unsigned int first_guess[3] = {kNone, kNone, kNone};
-    if (t < 64) {
+    const int rw = rounds_wave();
+    if ((t >> 6) == rw) {
         const int nz = plan_zones(sh, g, cnt, mad_guess, first_guess);
         TS_MARK(sh, 3);
         if (!build_zones(sh, g, nz)) sh.decline = sh.nzones == 0 ? D_ZONES : D_HOT_OVERFLOW;
@@ -1189,7 +1202,7 @@ __device__ __forceinline__ TileResult tile_stats(Shared &sh, const TileRect &r, 
 #ifdef AB_TILE_TIMING
     if (t == 0) sh.t_phase[7] = sh.zone_at[sh.nzones] * 1000 + sh.nzones;  // (hot pixels, zones: printed by tools/tile_stream_bench)
 #endif
-    if (t >= 64) return res;  // (declined / valid of these waves are not read)
+    if ((t >> 6) != rw) return res;  // (declined / valid of these waves are not read)
     // ---- the rounds (wave 0) ----
     Rounds rounds = {sh, g, ZReg()};
     if (!rounds.run(cnt, first_guess, &res.median, &res.sigma)) res.declined = sh.decline ? sh.decline : 1;

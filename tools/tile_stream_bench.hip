@@ -50,7 +50,7 @@ __global__ __launch_bounds__(ts::kThreads) void k_stream(const float *img, int c
     r.x1 = r.x0 + 256;
     r.vec = true;
     const ts::TileResult res = ts::tile_stats(sh, r, xf);
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x == 64 * ts::rounds_wave()) {
         out[3 * blockIdx.x] = res.median;
         out[3 * blockIdx.x + 1] = res.sigma;
         out[3 * blockIdx.x + 2] = res.valid;
