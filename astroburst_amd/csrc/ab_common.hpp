@@ -32,6 +32,7 @@ enum {
     AB_WS_STACK_WIDE,         // plane pointer / stride tables of a > 64-frame stack
     AB_WS_BATCH_WIDE,         // tables of a > 64-frame batch stack
     AB_WS_STACK_INF,          // one plane of +inf: stands in for the frames a stack is short of a power of two
+    AB_WS_STACK_PAIR_LISTS,   // the pixels a two-lane fast pass hands to the oracle-arithmetic kernel (stack_pair.hip, stack_duo.hip)
     AB_WS_BATCH_PAD,          // one plane of FLT_MAX: the same for the batch stack (where +inf is a sample like any other)
     AB_WS_STATS,              // state block, 65 536-bin histograms and partials of the statistics chain (stats.hip)
     AB_WS_SHARD,              // (sum f64, count u32) partial planes of the frame-sharded stack (sharded.hip)

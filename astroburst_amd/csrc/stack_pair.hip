@@ -27,109 +27,24 @@
 // workgroups kept in step by a barrier every 128 exchanges so that the 60 KB of straight-line sort is fetched once per
 // workgroup (70.7 ms: the instruction cache was not the limit).  What would help is two waves per SIMD: four lanes per pixel
 // with 128 samples each.
-#include "ab_common.hpp"
+#include "stack_pair.hpp"
 
 #include <algorithm>
 #include <cmath>
 
-#include "sort_ops.hpp"
-#define AB_CE(a, b)                       \
-    {                                     \
-        T lo_ = ab_v_min(v[a], v[b]);     \
-        T hi_ = ab_v_max(v[a], v[b]);     \
-        v[a] = lo_;                       \
-        v[b] = hi_;                       \
-    }
-#define AB_SORT4(a, b, c, d)                                                                          \
-    {                                                                                                 \
-        const T x0_ = v[a], x1_ = v[b], x2_ = v[c], x3_ = v[d];                                       \
-        const T s0_ = ab_v_min3(x0_, x1_, x2_), s1_ = ab_v_med3(x0_, x1_, x2_), s2_ = ab_v_max3(x0_, x1_, x2_); \
-        v[a] = ab_v_min(s0_, x3_);                                                                    \
-        v[b] = ab_v_med3(s0_, s1_, x3_);                                                              \
-        v[c] = ab_v_med3(s1_, s2_, x3_);                                                              \
-        v[d] = ab_v_max(s2_, x3_);                                                                    \
-    }
-#include "sortnet_gen.hpp"
+using namespace abpair;
 
 namespace {
-
-constexpr double kMadToSigma = 1.4826;  // types/constants.rs:7
-constexpr int kRejSlots = AB_REJ_SLOTS;
-constexpr int H = 256;  // samples per lane
-
-struct PairArgs {
-    const float *const *p;  // n plane pointers (device array), n in (256, 512]
-    int n;
-    int64_t total;  // pixels
-    float sigma_low, sigma_high;
-    uint32_t max_iter;
-    float *out;
-    unsigned long long *rejected;
-    int median_only;  // median_combine_row_major (calibration.rs:84-125): [len/2] of the finite samples
-};
-
-// the partner lane's value (lanes 2k <-> 2k+1): DPP quad_perm [1,0,3,2]
-__device__ __forceinline__ float swapf(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));
-}
-__device__ __forceinline__ int swapi(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); }
-__device__ __forceinline__ double swapd(double x) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
-    const unsigned int lo = (unsigned int)swapi((int)(unsigned int)u), hi = (unsigned int)swapi((int)(unsigned int)(u >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
-
-// The network's min / max are inline assembly, and the compiler's hazard recogniser does not see a VALU write inside an asm
-// statement: a DPP read of such a register within two wait states returns the OLD value.  Every sample therefore passes through
-// one of these (volatile, `s_nop 1` inside, the sample an in/out operand) between the network that wrote it and the first DPP
-// that reads it.
-__device__ __forceinline__ void dpp_fence(float (&v)[256]) {
-#pragma unroll
-    for (int i = 0; i < 256; i += 8)
-        asm volatile("s_nop 1" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]),
-                     "+v"(v[i + 7]));
-}
-
-// Compiler fence (no instructions): the sample vector looks rewritten, so LLVM does not hoist 256 f32->f64 conversions out of
-// the clipping loop (stack_sigma_clip.hip: launder)
-__device__ __forceinline__ void launder(float (&v)[H]) {
-#pragma unroll
-    for (int i = 0; i < H; i += 8)
-        asm volatile("" : "+v"(v[i]), "+v"(v[i + 1]), "+v"(v[i + 2]), "+v"(v[i + 3]), "+v"(v[i + 4]), "+v"(v[i + 5]), "+v"(v[i + 6]),
-                     "+v"(v[i + 7]));
-}
-__device__ __forceinline__ void opaque(int &a, int &b) { asm volatile("" : "+v"(a), "+v"(b)); }
-
-// in-lane bitonic merge of a bitonic sequence of 256 (ascending result): eight half-cleaner stages.  (One function per stage: as
-// two nested `#pragma unroll` loops the body exceeds the pragma's size limit, the outer loop stays a loop, and the samples live
-// in scratch memory.)
-template <int D>
-__device__ __forceinline__ void half_cleaner(float (&v)[H]) {
-    using T = float;
-#pragma unroll
-    for (int i = 0; i < H; ++i)
-        if ((i & D) == 0) AB_CE(i, i + D)
-}
-__device__ __forceinline__ void bitonic_merge_256(float (&v)[H]) {
-    half_cleaner<128>(v);
-    half_cleaner<64>(v);
-    half_cleaner<32>(v);
-    half_cleaner<16>(v);
-    half_cleaner<8>(v);
-    half_cleaner<4>(v);
-    half_cleaner<2>(v);
-    half_cleaner<1>(v);
-}
 
 // One f64 accumulation over the global rank interval [a, b] (ranks 0 .. 511 over the pair), ascending: the even lane's part
 // first, then the odd lane continues from the even lane's sum.  la / lb: this lane's part of the interval in local indices
 // (la = lb = -1: none).  MODE 0: sum of v; MODE 1: sum of (v - mean)^2.  Both lanes return the pair's total.
-template <int MODE>
+template <int H, int MODE>
 __device__ __forceinline__ double pair_sum(float (&v)[H], int la, int lb, bool odd, double mean) {
     double S = 0.0;
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
-        launder(v);  // (or the 256 conversions, the same in both phases, are hoisted out of this loop: 512 registers, all spilled)
+        launder<H>(v);  // (or the H conversions, the same in both phases, are hoisted out of this loop: 512 registers, all spilled)
         // phase 0: even lanes add their samples, odd lanes add zeros; phase 1: the odd lane continues the even lane's sum
         if (phase == 1) {
             const double from_even = swapd(S);  // (evaluated by ALL lanes: a DPP read of a lane that is switched off returns nothing)
@@ -156,6 +71,7 @@ __device__ __forceinline__ double pair_sum(float (&v)[H], int la, int lb, bool o
 
 // ranks through LDS: `buf` holds one half (256 ranks) of each of the wave's 32 pixels, rank-major (conflict-free: a wave's
 // accesses to one rank are 32 consecutive words)
+template <int H>
 __device__ __forceinline__ void put_half(float *buf, const float (&v)[H], bool writer, int pix) {
     if (writer) {
 #pragma unroll
@@ -163,23 +79,20 @@ __device__ __forceinline__ void put_half(float *buf, const float (&v)[H], bool w
     }
 }
 
-template <bool MEDIAN_ONLY>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void stack_pair_kernel(const PairArgs a) {
-    __shared__ float buf[H * 32];
+// one wave's 32 pixels (g: this pair's pixel; valid: it exists).  Returns the pixel's rejected-sample count in the even lane.
+template <int H, bool MEDIAN_ONLY>
+__device__ __forceinline__ uint32_t pair_pixel(const PairArgs &a, float *buf, int64_t g, bool valid) {
     const int lane = threadIdx.x;
     const bool odd = lane & 1;
     const int pix = lane >> 1;
-    int64_t g = (int64_t)blockIdx.x * 32 + pix;
-    const bool valid = g < a.total;
-    if (!valid) g = a.total - 1;
 
     // ---- gather (combine.rs:170-175 / calibration.rs:95-104): only finite samples take part; the rest are +inf pads ----
-    // lane-parity halves: two exec-masked load streams of 256 instructions, 32 lanes x 4 B = one 128-byte line each
+    // lane-parity halves: two exec-masked load streams of H instructions, 32 lanes x 4 B = one 128-byte line each
     // Every load instruction has a wave-uniform plane (scalar base + one shared 32-bit byte offset, no vector address work): BOTH
-    // lanes of a pair fetch their pixel from frame f and from frame f + 256 (the two lanes read the same word: one 128-byte
+    // lanes of a pair fetch their pixel from frame f and from frame f + H (the two lanes read the same word: one 128-byte
     // line per instruction either way) and each keeps its half's sample.
     float v[H];
-    const int have = odd ? a.n - H : H;  // frames of this half (n > 256: the even half is full)
+    const int have = odd ? a.n - H : H;  // frames of this half (n > H: the even half is full)
     const uint32_t boff = (uint32_t)g * 4u;
 #pragma unroll
     for (int f = 0; f < H; ++f) {
@@ -202,38 +115,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
     const int n = n_lane + swapi(n_lane);  // the pixel's finite samples: sorted ranks [0, n)
 
-    // ---- sort: 256 per lane, cross step, in-lane bitonic merge ----
-    SortNet<H>::sort_fused(v);  // the rewrite over min3 / med3 / max3 (tools/gen_sortnet.py): 5493 instructions, not 7486
-    dpp_fence(v);
-#pragma unroll
-    for (int i = 0; i < H / 2; ++i) {
-        const float t1 = swapf(v[H - 1 - i]), t2 = swapf(v[i]);
-        const float lo1 = ab_v_min(v[i], t1), hi1 = ab_v_max(v[i], t1);
-        const float lo2 = ab_v_min(v[H - 1 - i], t2), hi2 = ab_v_max(v[H - 1 - i], t2);
-        v[i] = odd ? hi1 : lo1;
-        v[H - 1 - i] = odd ? hi2 : lo2;
-    }
+    // ---- sort: H per lane, cross step, in-lane bitonic merge ----
+    SortNet<H>::sort_fused(v);  // the rewrite over min3 / med3 / max3 (tools/gen_sortnet.py): 5493 instructions for 256, not 7486
+    dpp_fence<H>(v);
+    cross_step<H>(v, odd);
     if constexpr (MEDIAN_ONLY) {
-        // calibration.rs:106-124: 0 for no finite sample, else sorted[len / 2].  All 512 finite: rank 256 = the smallest of the odd
+        // calibration.rs:106-124: 0 for no finite sample, else sorted[len / 2].  All 2H finite: rank H = the smallest of the odd
         // lane's half, no merge needed
         if (__all(n == 2 * H)) {
             float m = v[0];
 #pragma unroll
             for (int i = 1; i < H; ++i) m = ab_v_min(m, v[i]);
             if (valid && odd) a.out[g] = m;
-            return;
+            return 0;
         }
     }
-    bitonic_merge_256(v);
-    dpp_fence(v);
+    bitonic_merge<H>(v);
+    dpp_fence<H>(v);
 
     // ---- median (combine.rs:38-40) and MAD (combine.rs:42-46) ----
     const int M = n >> 1;
     float med, mad;
     if (__all(n == 2 * H)) {
         const float o0 = swapf(v[0]);
-        med = odd ? v[0] : o0;  // rank 256
-        // term(p) = max(med - V[p], V[p + 256] - med), p = 0 .. 255: V[p] is the even lane's v[p], V[p + 256] the odd lane's
+        med = odd ? v[0] : o0;  // rank H
+        // term(p) = max(med - V[p], V[p + H] - med), p = 0 .. H - 1: V[p] is the even lane's v[p], V[p + H] the odd lane's
         float best = __builtin_inff();
 #pragma unroll
         for (int p = 0; p < H; ++p) {
@@ -243,15 +149,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         mad = best;
     } else {
         // per-pixel offsets: the ranks travel through LDS, the odd lane's half first.  The even lane evaluates
-        //   med = V[M];  best = med - V[0];  for p = 1 .. M with p + M < 512: best = min(best, max(med - V[p], V[p + M] - med))
-        // (ranks >= n are +inf pads and drop out by themselves; p <= 255 because a term needs p + M <= n - 1 <= 511)
+        //   med = V[M];  best = med - V[0];  for p = 1 .. M with p + M < 2H: best = min(best, max(med - V[p], V[p + M] - med))
+        // (ranks >= n are +inf pads and drop out by themselves; p <= H - 1 because a term needs p + M <= n - 1 <= 2H - 1)
         float medv = 0.0f, best = __builtin_inff();
-        put_half(buf, v, odd, pix);
+        __syncthreads();  // (LIST mode: the previous pixels' reads of buf are done)
+        put_half<H>(buf, v, odd, pix);
         __syncthreads();
         if (M >= H && M < 2 * H) medv = buf[(M - H) * 32 + pix];
         if (__any(M < H)) {  // (wave-uniform) some pixel's median and near partners lie in the EVEN half
             __syncthreads();
-            put_half(buf, v, !odd, pix);
+            put_half<H>(buf, v, !odd, pix);
             __syncthreads();
             if (M < H) medv = buf[M * 32 + pix];
             if constexpr (!MEDIAN_ONLY) {
@@ -266,7 +173,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
             }
             __syncthreads();
-            put_half(buf, v, odd, pix);
+            put_half<H>(buf, v, odd, pix);
             __syncthreads();
         }
         if constexpr (!MEDIAN_ONLY) {
@@ -288,7 +195,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     if constexpr (MEDIAN_ONLY) {
         if (valid && !odd) a.out[g] = (n == 0) ? 0.0f : med;
-        return;
+        return 0;
     }
 
     // ---- clipping iterations (combine.rs:31-83), the oracle's arithmetic: two-pass mean / variance over the rank interval ----
@@ -301,15 +208,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     bool active = n >= 2;
     for (uint32_t it = 0; it < a.max_iter; ++it) {
         if (!__any(active)) break;
-        launder(v);
+        launder<H>(v);
         int la = max(ra - base, 0), lb = min(rb - base, H - 1);  // this lane's part of the interval
         if (ra > rb || la > lb) la = lb = -1;                    // none: (unsigned)(i + 1) <= 0 holds for no i >= 0
         if (it > 0) {
-            const double S = pair_sum<0>(v, la, lb, odd, 0.0);
+            const double S = pair_sum<H, 0>(v, la, lb, odd, 0.0);
             const double nn = (double)len;
             const double mean = S / nn;
             opaque(la, lb);
-            const double Q = pair_sum<1>(v, la, lb, odd, mean);
+            const double Q = pair_sum<H, 1>(v, la, lb, odd, mean);
             const double variance = Q / fmax(nn - 1.0, 1.0);
             center = (float)mean;
             sigma = (float)fmax(sqrt(variance), 1e-10);
@@ -346,11 +253,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 
     // ---- result (combine.rs:20-26,85-91) ----
-    launder(v);
+    launder<H>(v);
     int la = max(ra - base, 0), lb = min(rb - base, H - 1);
     if (ra > rb || la > lb) la = lb = -1;
     opaque(la, lb);
-    const double S = pair_sum<0>(v, la, lb, odd, 0.0);  // an empty interval sums to 0
+    const double S = pair_sum<H, 0>(v, la, lb, odd, 0.0);  // an empty interval sums to 0
     float value;
     if (n == 0)
         value = 0.0f;
@@ -361,30 +268,65 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     else
         value = (float)(S / (double)len);
     if (valid && !odd) a.out[g] = value;
+    return (valid && !odd) ? rej : 0u;
+}
 
+// H = 256: one wave per SIMD (the samples fill the register file); H = 128 (the list pass of a 129 .. 256-frame stack): two
+template <int H, bool MEDIAN_ONLY>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(H == 128 ? 2 : 1, H == 128 ? 2 : 1))) void stack_pair_kernel(const PairArgs a) {
+    __shared__ float buf[H * 32];
+    const int pix = threadIdx.x >> 1;
+    int r = 0;
+    if (a.walk_lists) {
+        // LIST mode: the pixels stack_duo.hip's fast pass handed over, kListWaves one-wave workgroups per list
+        const unsigned int slot = blockIdx.x / kListWaves, sub = blockIdx.x % kListWaves;
+        const unsigned int cnt = a.list_count[slot];
+        const int *list = a.list + (size_t)slot * a.list_cap;
+#pragma unroll 1
+        for (unsigned int base = sub * 32u; base < cnt; base += 32u * kListWaves) {
+            const unsigned int k = base + (unsigned int)pix;
+            const bool valid = k < cnt;
+            r += (int)pair_pixel<H, MEDIAN_ONLY>(a, buf, (int64_t)list[valid ? k : cnt - 1], valid);
+        }
+        // the last of the list's workgroups to get here leaves the list empty for the next launch (stack_sigma_clip.hip: no fence)
+        if (threadIdx.x == 0) {
+            if (atomicAdd(&a.list_ticket[slot], 1u) == kListWaves - 1) {
+                a.list_ticket[slot] = 0;
+                a.list_count[slot] = 0;
+            }
+        }
+    } else {
+        int64_t g = (int64_t)blockIdx.x * 32 + pix;
+        const bool valid = g < a.total;
+        if (!valid) g = a.total - 1;
+        r = (int)pair_pixel<H, MEDIAN_ONLY>(a, buf, g, valid);
+    }
     // rejection count: one atomic per wave, spread over kRejSlots counters (summed by the host)
-    int r = (valid && !odd) ? (int)rej : 0;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) r += __shfl_xor(r, off, 64);
-    if (lane == 0 && r != 0) atomicAdd(&a.rejected[blockIdx.x & (kRejSlots - 1)], (unsigned long long)r);
+    if (threadIdx.x == 0 && r != 0) atomicAdd(&a.rejected[blockIdx.x & (kRejSlots - 1)], (unsigned long long)r);
 }
 
 }  // namespace
 
-// dplanes: HOST array of n device pointers (256 < n <= 512), contiguous planes of rows x cols; counters already cleared by the caller
+// dplanes: HOST array of n device pointers (128 < n <= 512), contiguous planes of rows x cols; counters already cleared by the caller.
+// 257 .. 512 frames under the exact engine and every median combine: the oracle-arithmetic kernel over all pixels.  The default
+// engine (129 .. 512 frames): stack_duo.hip's fast pass, then this file's kernel over the pixels it handed over.
 int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg,
                          float *out_dev, bool median_only) {
-    AB_CHECK(ctx, n > 256 && n <= 512, "the two-lane stack takes 257 .. 512 frames (got %zu)", n);
+    AB_CHECK(ctx, n > 128 && n <= 512, "the two-lane stack takes 129 .. 512 frames (got %zu)", n);
+    const int H = n > 256 ? 256 : 128;
+    const bool fast = !median_only && !ctx->stack_exact;
+    AB_CHECK(ctx, fast || H == 256, "internal: the oracle-arithmetic two-lane kernel over all pixels exists for 257 .. 512 frames");
     void *ws = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, 512 * (sizeof(float *) + sizeof(int64_t)), &ws));
-    // the table is tiny; a blocking copy keeps the host array's lifetime out of the picture
+    AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, 2 * 512 * sizeof(float *), &ws));
+    // the tables are tiny; a blocking copy keeps the host array's lifetime out of the picture
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    // frames the stack is short of 512: ONE plane of +inf stands in for all of them (a non-finite sample is exactly what the
+    // frames the stack is short of: ONE plane of +inf stands in for all of them (a non-finite sample is exactly what the
     // algorithm ignores, combine.rs:170-175; the pad reads stay in L2) -- every load of the kernel is unconditional
-    const float *table[512];
     const int64_t total = rows * cols;
     const float *inf_plane = nullptr;
-    if (n < 512) {
+    {
         float *ip = nullptr;
         const void *before = ctx->ws[AB_WS_STACK_INF];
         const size_t had = ctx->ws_bytes[AB_WS_STACK_INF];
@@ -393,11 +335,18 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
             AB_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ip, 0x7f800000, ctx->ws_bytes[AB_WS_STACK_INF] / sizeof(float), ctx->stream));
         inf_plane = ip;
     }
-    for (size_t i = 0; i < 512; ++i) table[i] = i < n ? dplanes[i] : inf_plane;
+    // frame-count classes of the fast pass: R frames per lane, a multiple of H / 8 (the pads' loads and network operations vanish)
+    const int cw = H / 8;
+    const int R = fast ? (int)(((n + 1) / 2 + (size_t)cw - 1) / (size_t)cw) * cw : H;
+    const float *table[2 * 512];  // [0, 2R): the fast pass's table; [512, 512 + 2H): the oracle-arithmetic kernel's
+    for (int i = 0; i < 512; ++i) table[i] = (size_t)i < n ? dplanes[i] : inf_plane;
+    for (int i = 0; i < 512; ++i) table[512 + i] = table[i];
     AB_HIP(ctx, hipMemcpy(ws, table, sizeof table, hipMemcpyHostToDevice));
     PairArgs a;
-    a.p = (const float *const *)ws;
+    memset(&a, 0, sizeof a);
+    a.p = (const float *const *)ws + 512;
     a.n = (int)n;
+    a.half = H;
     a.total = total;
     a.sigma_low = cfg->sigma_low;
     a.sigma_high = cfg->sigma_high;
@@ -406,10 +355,46 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
     a.rejected = ctx->counters;
     a.median_only = median_only ? 1 : 0;
     const dim3 grid((unsigned)((a.total + 31) / 32)), block(64);
-    if (median_only)
-        hipLaunchKernelGGL(stack_pair_kernel<true>, grid, block, 0, ctx->stream, a);
+    if (!fast) {
+        if (median_only)
+            hipLaunchKernelGGL((stack_pair_kernel<256, true>), grid, block, 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((stack_pair_kernel<256, false>), grid, block, 0, ctx->stream, a);
+        AB_HIP(ctx, hipGetLastError());
+        return AB_OK;
+    }
+    // the lists: slot = wave index & (kListSlots - 1) (rotated), so a slot holds at most ceil(waves / kListSlots) waves' worth of pixels
+    const int64_t waves = (total + 31) / 32;
+    const unsigned int cap = (unsigned int)(((waves + kListSlots - 1) / kListSlots) * 32);
+    char *lw = nullptr;
+    const void *before = ctx->ws[AB_WS_STACK_PAIR_LISTS];
+    AB_TRY(ab_workspace(ctx, AB_WS_STACK_PAIR_LISTS, (size_t)2 * kListSlots * sizeof(unsigned int) + (size_t)kListSlots * cap * sizeof(int), (void **)&lw));
+    a.list_count = (unsigned int *)lw;
+    a.list_ticket = a.list_count + kListSlots;
+    a.list = (int *)(lw + (size_t)2 * kListSlots * sizeof(unsigned int));
+    a.list_cap = cap;
+    // the list pass leaves every counter at zero again, so only a fresh workspace needs clearing
+    if (lw != before) AB_HIP(ctx, hipMemsetAsync(a.list_count, 0, 2 * kListSlots * sizeof(unsigned int), ctx->stream));
+    PairArgs f = a;
+    f.p = (const float *const *)ws;
+    f.half = R;
+    AB_TRY(ab_stack_duo_launch(ctx, H, R, f));
+    if (ab_env("AB_TRACE")) {  // developer aid: how many pixels the fast pass handed over
+        std::vector<unsigned int> cnt(kListSlots, 0);
+        AB_HIP(ctx, hipMemcpyAsync(cnt.data(), a.list_count, kListSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long tot = 0, mx = 0;
+        for (unsigned int c : cnt) tot += c, mx = c > mx ? c : mx;
+        ab_count_fallback(ctx, AB_FB_STACK_GENERAL_PIXELS, tot);
+        fprintf(stderr, "[ab_trace] two-lane stack: %llu of %lld pixels handed to the list pass (%.2f %%), fullest list %llu of %u\n", tot, (long long)total,
+                100.0 * (double)tot / (double)total, mx, cap);
+    }
+    a.walk_lists = 1;
+    const dim3 lgrid(kListSlots * kListWaves);
+    if (H == 128)
+        hipLaunchKernelGGL((stack_pair_kernel<128, false>), lgrid, block, 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(stack_pair_kernel<false>, grid, block, 0, ctx->stream, a);
+        hipLaunchKernelGGL((stack_pair_kernel<256, false>), lgrid, block, 0, ctx->stream, a);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }

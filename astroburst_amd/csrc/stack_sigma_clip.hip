@@ -1237,7 +1237,11 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     bool contig_all = total < (int64_t(1) << 30);
     for (size_t i = 0; i < n && contig_all; ++i) contig_all = ld[i] == cols;
     const bool reg128 = n > 64 && n <= 256 && contig_all && !partial && !ctx->stack_exact;  // (and 129 .. 256; median_combine too)
-    if (n > 64 && !reg128) {  // deeper than one lane's registers
+    // Round 6: 129 .. 256 frames of a plain stack take two lanes per pixel, 128 samples each, two waves per SIMD (stack_duo.hip);
+    // AB_STACK_NO_DUO=1 (developer build) keeps round 5's one-lane 256-sample kernel, and the median combine still uses it
+    static const bool no_duo = ab_dev_env("AB_STACK_NO_DUO") != nullptr;
+    const bool duo = reg128 && n > 128 && !median_only && !no_duo;
+    if (n > 64 && (!reg128 || duo)) {  // deeper than one lane's registers
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
         ctx->stack_ev_valid = false;
@@ -1249,7 +1253,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         static const bool no_pair = ab_dev_env("AB_STACK_NO_PAIR") != nullptr;
         if (n > (size_t)ctx->stack_deep_from)
             AB_TRY(ab_stack_deep_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
-        else if (n > 256 && n <= 512 && contig_all && !partial && !no_pair)
+        else if (duo || (n > 256 && n <= 512 && contig_all && !partial && !no_pair))
             AB_TRY(ab_stack_pair_device(ctx, dplanes, n, rows, cols, cfg, out_dev, median_only));
         else
             AB_TRY(ab_stack_wide_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));

@@ -167,8 +167,38 @@ def test_deep_stacks_one_wave_per_pixel(ctx, oracle, n, shape):
     for sl, sh, it in ((3.0, 3.0, 5), (2.0, 2.5, 3), (1.0, 1.0, 1), (3.0, 3.0, 0)):
         want, wrej = oracle.stack_images(fr, sl, sh, it)
         got, rej = ctx.stack_sigma_clip(fr, sl, sh, it)
-        assert rej == wrej, (sl, sh, it)
-        assert np.array_equal(got, want, equal_nan=True), (sl, sh, it)
+        # (round 6: 129 .. 512 frames take the two-lane fast pass under the default engine's contract; these dirty frames leave few
+        # pixels with every sample finite, so nearly all of them go through the oracle-arithmetic list pass)
+        assert_stack_parity(got, want, rej, wrej, n <= 128)
+
+
+def clean_frames(n, shape, seed, every=11, rate=0.02):
+    rng = np.random.default_rng(seed)
+    fr = [rng.normal(500.0, 12.0, shape).astype(np.float32) for _ in range(n)]
+    for k in range(0, n, every):
+        fr[k][rng.random(shape) < rate] += 300.0                      # outliers to clip, still finite
+    return fr
+
+
+@pytest.mark.parametrize("n", [129, 130, 131, 135, 136, 137, 138, 144, 145, 159, 160, 161, 162, 176, 191, 192, 193, 207, 223, 224, 225, 255, 256,
+                               257, 258, 263, 264, 265, 266, 300, 319, 320, 321, 322, 383, 384, 385, 447, 448, 449, 511, 512])
+def test_two_lane_fast_pass(engine, oracle, n):
+    """Round 6: 129 .. 512 frames with every sample finite -- csrc/stack_duo.hip's fast pass (two lanes per
+    pixel, 128 or 256 samples each, frame-count classes of 32 / 64, the median / MAD instance chosen by n / 2, eight samples per
+    end, running moments) + stack_pair.hip's list pass for what it hands over.  Both sides of every class boundary, odd and even
+    counts, the counts whose odd lane holds at most eight samples (the high walk goes on into the even lane), a pixel count that
+    leaves the last wave partly filled; settings that clip nothing, a little, and more than eight samples per end (the list pass)."""
+    ctx, exact = engine
+    shape = (30, 50) if n % 2 else (31, 37)
+    fr = clean_frames(n, shape, 5000 + n)
+    fr[0][0, 0] = np.nan                                               # one pixel with a non-finite sample: handed over
+    fr[3][5:9, 7] += 1e4                                               # a streak
+    for k in range(0, n, 2):
+        fr[k][11, 3:9] -= 200.0                                        # half of the samples low: the low walk gives up
+    for sl, sh, it in ((3.0, 3.0, 5), (2.0, 2.5, 3), (1.0, 1.0, 2), (3.0, 3.0, 0), (3.0, 3.0, 1), (0.5, 0.5, 8), (4.0, 1.5, 4)):
+        want, wrej = oracle.stack_images(fr, sl, sh, it)
+        got, rej = ctx.stack_sigma_clip(fr, sl, sh, it)
+        assert_stack_parity(got, want, rej, wrej, exact)
 
 
 @pytest.mark.parametrize("n", [513, 700, 1024, 1025, 2048, 2100, 4096])
@@ -238,11 +268,12 @@ def test_deep_median_combine(ctx, oracle, n):
 
 
 @pytest.mark.parametrize("n", [257, 300, 384, 511, 512])
-def test_two_lanes_per_pixel_stack(ctx, oracle, n):
+def test_two_lanes_per_pixel_stack(engine, oracle, n):
     """257 .. 512 contiguous frames: csrc/stack_pair.hip (two lanes per pixel: 256 samples each, cross step + in-lane bitonic
     merge, ranks through DPP or LDS, the oracle's ascending f64 sums continued from the even lane into the odd one).  Bit for bit
     the oracle on dirty frames (NaN / inf / ties / constant / empty / single-sample pixels: the LDS paths) and on clean ones (all
     samples finite: the DPP paths), sigma-clip and median combine; 1500 pixels = 47 waves, the last one partly filled."""
+    ctx, exact = engine
     fr = deep_frames(n, (30, 50), 7000 + n)
     rng = np.random.default_rng(n)
     clean = [rng.normal(500.0, 12.0, (30, 50)).astype(np.float32) for _ in range(n)]
@@ -252,8 +283,8 @@ def test_two_lanes_per_pixel_stack(ctx, oracle, n):
         for sl, sh, it in ((3.0, 3.0, 5), (2.0, 2.5, 3), (1.0, 1.0, 1), (3.0, 3.0, 0), (0.5, 0.5, 8)):
             want, wrej = oracle.stack_images(frames, sl, sh, it)
             got, rej = ctx.stack_sigma_clip(frames, sl, sh, it)
-            assert rej == wrej, (name, sl, sh, it)
-            assert np.array_equal(got, want, equal_nan=True), (name, sl, sh, it)
+            # (the default engine: stack_duo.hip's fast pass under the fast contract, this file's kernel for the pixels it hands over)
+            assert_stack_parity(got, want, rej, wrej, exact)
         assert np.array_equal(ctx.median_combine(frames), oracle.median_combine(frames), equal_nan=True), name
 
 
@@ -272,8 +303,7 @@ def test_two_lanes_per_pixel_at_scale(ctx, oracle):
     for n in (512, 320):
         want, wrej = oracle.stack_images(fr[:n], 3.0, 3.0, 5)
         got, rej = ctx.stack_sigma_clip(dev[:n], 3.0, 3.0, 5)
-        assert rej == wrej
-        assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)
+        assert_stack_parity(got.cpu().numpy(), want, rej, wrej, False)
         assert np.array_equal(ctx.median_combine(dev[:n]).cpu().numpy(), oracle.median_combine(fr[:n]), equal_nan=True)
 
 
@@ -291,8 +321,7 @@ def test_deep_stack_at_scale(ctx, oracle, n):
     fr = [d.cpu().numpy() for d in dev]
     want, wrej = oracle.stack_images(fr, 3.0, 3.0, 5)
     got, rej = ctx.stack_sigma_clip(dev, 3.0, 3.0, 5)
-    assert rej == wrej
-    assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)
+    assert_stack_parity(got.cpu().numpy(), want, rej, wrej, n <= 128)
     assert np.array_equal(ctx.median_combine(dev).cpu().numpy(), oracle.median_combine(fr), equal_nan=True)
 
 

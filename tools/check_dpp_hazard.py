@@ -97,9 +97,9 @@ def check_listing(path):
     return ndpp, viol
 
 
-def compile_listing(src, tmp):
+def compile_listing(src, tmp, extra=()):
     out = os.path.join(tmp, os.path.basename(src) + ".o")
-    subprocess.run([HIPCC, *FLAGS, "--save-temps", "-c", src, "-o", out], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.run([HIPCC, *FLAGS, *extra, "--save-temps", "-c", src, "-o", out], cwd=tmp, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     stem = os.path.splitext(os.path.basename(src))[0]
     return os.path.join(tmp, f"{stem}-hip-amdgcn-amd-amdhsa-gfx950.s")
 
