@@ -368,10 +368,12 @@ int ab_stack_duo_launch(ab_ctx *ctx, int H, int R, const PairArgs &args) {
     AB_DUO_CASE(128, 80)
     AB_DUO_CASE(128, 96)
     AB_DUO_CASE(128, 128)
+#ifdef AB_DEV_ABLATION  // (257 .. 512 frames take four lanes per pixel, stack_quad.hip; AB_STACK_NO_QUAD=1 on a developer build: 36 ms against 15 for 512 frames)
     AB_DUO_CASE(256, 160)
     AB_DUO_CASE(256, 192)
     AB_DUO_CASE(256, 224)
     AB_DUO_CASE(256, 256)
+#endif
 #endif
     AB_DUO_CASE(128, 112)
 #undef AB_DUO_CASE

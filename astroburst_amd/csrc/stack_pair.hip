@@ -336,8 +336,12 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
         inf_plane = ip;
     }
     // frame-count classes of the fast pass: R frames per lane, a multiple of H / 8 (the pads' loads and network operations vanish)
-    const int cw = H / 8;
-    const int R = fast ? (int)(((n + 1) / 2 + (size_t)cw - 1) / (size_t)cw) * cw : H;
+    // (257 .. 512 frames: FOUR lanes per pixel with 128 samples each, stack_quad.hip; AB_STACK_NO_QUAD=1 on a developer build keeps two)
+    static const bool no_quad = ab_dev_env("AB_STACK_NO_QUAD") != nullptr;
+    const bool quad = fast && H == 256 && !no_quad;
+    const int cw = quad ? 16 : H / 8;
+    const size_t lanes = quad ? 4 : 2;
+    const int R = fast ? (int)(((n + lanes - 1) / lanes + (size_t)cw - 1) / (size_t)cw) * cw : H;
     const float *table[2 * 512];  // [0, 2R): the fast pass's table; [512, 512 + 2H): the oracle-arithmetic kernel's
     for (int i = 0; i < 512; ++i) table[i] = (size_t)i < n ? dplanes[i] : inf_plane;
     for (int i = 0; i < 512; ++i) table[512 + i] = table[i];
@@ -378,7 +382,10 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
     PairArgs f = a;
     f.p = (const float *const *)ws;
     f.half = R;
-    AB_TRY(ab_stack_duo_launch(ctx, H, R, f));
+    if (quad)
+        AB_TRY(ab_stack_quad_launch(ctx, R, f));
+    else
+        AB_TRY(ab_stack_duo_launch(ctx, H, R, f));
     if (ab_env("AB_TRACE")) {  // developer aid: how many pixels the fast pass handed over
         std::vector<unsigned int> cnt(kListSlots, 0);
         AB_HIP(ctx, hipMemcpyAsync(cnt.data(), a.list_count, kListSlots * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));

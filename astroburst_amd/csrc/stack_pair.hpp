@@ -107,15 +107,17 @@ __device__ __forceinline__ void bitonic_merge(float (&v)[H]) {
 
 // One cross step -- v[i] against the partner's v[H - 1 - i] -- leaves the H smallest of the pair's 2H sorted samples in the even
 // lane and the H largest in the odd lane, each a bitonic sequence.
+// (An exchange keeps v_med3(x, partner, -inf) = the minimum in the even lane, v_med3(x, partner, +inf) = the maximum in the odd
+// lane: one instruction by a per-lane constant instead of min, max and a select.)
 template <int H>
 __device__ __forceinline__ void cross_step(float (&v)[H], bool odd) {
+    const float sel = odd ? __builtin_inff() : -__builtin_inff();
 #pragma unroll
     for (int i = 0; i < H / 2; ++i) {
         const float t1 = swapf(v[H - 1 - i]), t2 = swapf(v[i]);
-        const float lo1 = ab_v_min(v[i], t1), hi1 = ab_v_max(v[i], t1);
-        const float lo2 = ab_v_min(v[H - 1 - i], t2), hi2 = ab_v_max(v[H - 1 - i], t2);
-        v[i] = odd ? hi1 : lo1;
-        v[H - 1 - i] = odd ? hi2 : lo2;
+        const float a = ab_v_med3(v[i], t1, sel), b = ab_v_med3(v[H - 1 - i], t2, sel);
+        v[i] = a;
+        v[H - 1 - i] = b;
     }
 }
 
@@ -124,3 +126,6 @@ __device__ __forceinline__ void cross_step(float (&v)[H], bool odd) {
 // stack_duo.hip: the fast pass of a 129 .. 512-frame stack (H = 128 or 256 samples per lane, the class R of frames per lane);
 // the arguments' table holds 2 R pointers
 int ab_stack_duo_launch(ab_ctx *ctx, int H, int R, const abpair::PairArgs &args);
+// stack_quad.hip: the fast pass of a 257 .. 512-frame stack, four lanes per pixel with 128 samples each (class R of frames per lane); the
+// table holds 4 R pointers
+int ab_stack_quad_launch(ab_ctx *ctx, int R, const abpair::PairArgs &args);

@@ -1091,7 +1091,7 @@ __device__ __forceinline__ void stack_pixel(const StackArgs &args, int64_t g, co
 }
 
 template <int NP, bool PARTIAL, bool EXACT, int STAGE = 99, bool DIRECT = false, int MODE = kPlain, int INPUT = kInNative, int NREAL = NP>
-__global__ __launch_bounds__(256, (EXACT || NP > 64) ? 1 : AB_STACK_WAVES_PER_SIMD) void stack_sigma_clip_kernel(const StackArgs args) {
+__global__ __launch_bounds__(256, (EXACT || NP > 128) ? 1 : (NP > 64 ? 2 : AB_STACK_WAVES_PER_SIMD)) void stack_sigma_clip_kernel(const StackArgs args) {
     if constexpr (MODE == kGeneralPass) {
         // ONE wave per workgroup, kGenWaves workgroups per list (launched with 64 threads).  With one 4-wave workgroup per list
         // (round 2) a list of ~65 pixels kept one wave busy and three wave slots empty until it finished: 2048 workgroups went

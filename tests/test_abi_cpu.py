@@ -234,10 +234,12 @@ def test_no_dpp_reads_a_register_inside_its_write_hazard_window(tmp_path):
     with open(stripped, "w") as f:
         f.write("\n".join(l for l in open(lst).read().split("\n") if "s_nop" not in l))
     assert chk.check_listing(stripped)[1], "the checker does not see a hazard when the fences are gone"
-    # round 6: the fast two-lane kernel (csrc/stack_duo.hip) has the same network + DPP structure; one frame-count class is compiled
-    lst = chk.compile_listing(os.path.join(chk.CSRC, "stack_duo.hip"), str(tmp_path), extra=("-DAB_DUO_ONE_CLASS",))
-    ndpp, viol = chk.check_listing(lst)
-    assert ndpp > 500 and not viol, (ndpp, viol[:5])
+    # round 6: the fast two- and four-lane kernels (csrc/stack_duo.hip, stack_quad.hip) have the same network + DPP structure; one
+    # frame-count class of each is compiled
+    for name, flag in (("stack_duo.hip", "-DAB_DUO_ONE_CLASS"), ("stack_quad.hip", "-DAB_QUAD_ONE_CLASS")):
+        lst = chk.compile_listing(os.path.join(chk.CSRC, name), str(tmp_path), extra=(flag,))
+        ndpp, viol = chk.check_listing(lst)
+        assert ndpp > 500 and not viol, (name, ndpp, viol[:5])
 
 
 def test_the_release_library_reads_the_documented_environment_variables_only():

@@ -181,13 +181,14 @@ def clean_frames(n, shape, seed, every=11, rate=0.02):
 
 
 @pytest.mark.parametrize("n", [129, 130, 131, 135, 136, 137, 138, 144, 145, 159, 160, 161, 162, 176, 191, 192, 193, 207, 223, 224, 225, 255, 256,
-                               257, 258, 263, 264, 265, 266, 300, 319, 320, 321, 322, 383, 384, 385, 447, 448, 449, 511, 512])
+                               257, 258, 263, 264, 265, 266, 300, 319, 320, 321, 322, 383, 384, 385, 386, 391, 392, 393, 447, 448, 449, 511, 512])
 def test_two_lane_fast_pass(engine, oracle, n):
-    """Round 6: 129 .. 512 frames with every sample finite -- csrc/stack_duo.hip's fast pass (two lanes per
-    pixel, 128 or 256 samples each, frame-count classes of 32 / 64, the median / MAD instance chosen by n / 2, eight samples per
-    end, running moments) + stack_pair.hip's list pass for what it hands over.  Both sides of every class boundary, odd and even
-    counts, the counts whose odd lane holds at most eight samples (the high walk goes on into the even lane), a pixel count that
-    leaves the last wave partly filled; settings that clip nothing, a little, and more than eight samples per end (the list pass)."""
+    """Round 6: 129 .. 512 frames with every sample finite -- the fast passes csrc/stack_duo.hip (129 .. 256: two
+    lanes per pixel, 128 samples each) and csrc/stack_quad.hip (257 .. 512: four lanes per pixel), frame-count classes of 32 / 64,
+    the median / MAD instance chosen by n / 2, eight samples per end, running moments -- + stack_pair.hip's list pass for what they
+    hand over.  Both sides of every class boundary, odd and even counts, the counts whose top lane holds at most eight samples (the
+    high walk goes on into the lane below), a pixel count that leaves the last wave partly filled; settings that clip nothing, a
+    little, and more than eight samples per end (the list pass)."""
     ctx, exact = engine
     shape = (30, 50) if n % 2 else (31, 37)
     fr = clean_frames(n, shape, 5000 + n)

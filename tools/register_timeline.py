@@ -66,6 +66,20 @@ def main(path):
             by[key][1] += 1
         for k, (t, c) in sorted(by.items(), key=lambda kv: -kv[1][0])[:18]:
             print(f"  {k:48s} {c:5d} launches {t / 1e6:8.3f} ms  avg {t / c / 1e3:7.1f} us")
+        # when the warps start (a warp needs its frame's fitted transform: the call ends ~ first warp + the warps' durations)
+        ws = sorted((s - t0, e - s) for n, s, e in b if "warp_kernel" in n)
+        if ws:
+            pick = [0, 7, 15, 31, 47, len(ws) - 1]
+            print("  warp k starts at (ms): " + "  ".join(f"{k + 1}:{ws[k][0] / 1e6:.2f}" for k in pick if k < len(ws)) +
+                  f"   durations (us) first 16: {sum(d for _, d in ws[:16]) / 16e3:.0f}  last 16: {sum(d for _, d in ws[-16:]) / 16e3:.0f}")
+        fam = collections.defaultdict(lambda: [1 << 62, 0])
+        for n, s, e in b:
+            k = short(n)
+            fam[k][0] = min(fam[k][0], s - t0)
+            fam[k][1] = max(fam[k][1], e - t0)
+        print("  first start .. last end (ms): " + ", ".join(f"{k} {v[0] / 1e6:.2f}..{v[1] / 1e6:.2f}" for k, v in sorted(fam.items(), key=lambda kv: kv[1][0])
+                                                              if k in ("subsample_many_kernel", "percentiles_many_reg_kernel", "tile_background_stream_kernel", "label_bgtile_many_kernel",
+                                                                       "comp_select_many_kernel", "tri_vote_wide_many_kernel", "votes_reduce_many_kernel", "warp_kernel")))
         # the tail: what runs in the last 1.5 ms
         tail = [(n, s, e) for n, s, e in b if e > t1 - 1_500_000]
         print("  last 1.5 ms: " + ", ".join(f"{k}x{c}" for k, c in collections.Counter(short(n) for n, _, _ in tail).most_common(8)))
