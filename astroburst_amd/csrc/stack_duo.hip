@@ -108,6 +108,37 @@ __device__ __forceinline__ void med_mad_dispatch(const float (&v)[H], bool odd, 
     }
 }
 
+// the median alone (median_combine_row_major, calibration.rs:106-124: sorted[len / 2]): rank M
+template <int H, int LO, int HI>
+__device__ __forceinline__ float median_dispatch(const float (&v)[H], bool odd, int M /* launch-uniform */) {
+    if constexpr (LO == HI) {
+        if constexpr (LO < H) {
+            const float o = swapf(v[LO]);
+            return odd ? o : v[LO];
+        } else {
+            const float o = swapf(v[0]);
+            return odd ? v[0] : o;
+        }
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        return M <= MID ? median_dispatch<H, LO, MID>(v, odd, M) : median_dispatch<H, MID + 1, HI>(v, odd, M);
+    }
+}
+
+// hand the pixel to the list pass: one atomic per wave, kListSlots counters (stack_sigma_clip.hip)
+__device__ __forceinline__ void hand_over(const PairArgs &a, bool d, int lane, int64_t g) {
+    const unsigned long long m = __ballot(d);
+    if (m) {
+        const int leader = (int)__builtin_ctzll(m);
+        const unsigned int w = blockIdx.x;
+        const unsigned int slot = (w + (w / kListSlots) * 977u) & (kListSlots - 1);
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&a.list_count[slot], (unsigned int)__builtin_popcountll(m));
+        base = __shfl(base, leader, 64);
+        if (d) a.list[(size_t)slot * a.list_cap + base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)g;
+    }
+}
+
 // One clipping pass over the two ends of the pair's rank interval (combine.rs:65-82).  [la, lb]: this lane's part of it in its own
 // register indices.  The low end is the even lane's registers 0 .. 7; the high end the odd lane's last real registers (chunks ct and
 // ct - 1, ct launch-uniform) and, when the odd lane holds at most eight samples, the even lane's top registers as well.  A sorted end
@@ -180,7 +211,7 @@ __device__ __forceinline__ void clip_walk(const float (&v)[H], bool odd, bool go
     ch_own = ch;
 }
 
-template <int H, int R>
+template <int H, int R, bool MEDIAN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(H == 128 ? 2 : 1, H == 128 ? 2 : 1))) void stack_duo_fast_kernel(const PairArgs a) {
     static_assert(R <= H && 2 * R > H && R % 8 == 0, "frame-count class");
     const int lane = threadIdx.x;
@@ -234,8 +265,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(H == 128 ? 2
 
     // ---- median / MAD: n / 2 is one number per launch ----
     constexpr int kClassWidth = H / 8;  // frames per lane between two classes
+    constexpr int kMLo = R - kClassWidth > H / 2 ? R - kClassWidth : H / 2;
+    if constexpr (MEDIAN) {  // median_combine_row_major (calibration.rs:84-125): the pixels with a non-finite sample go to the list pass
+        const float m = median_dispatch<H, kMLo, R>(v, odd, a.n >> 1);
+        const bool writer = valid && !odd;
+        if (writer && !defer) a.out[g] = m;
+        hand_over(a, writer && defer, lane, g);
+        return;
+    }
     float med, mad;
-    med_mad_dispatch<H, (R - kClassWidth > H / 2 ? R - kClassWidth : H / 2), R>(v, odd, (a.n & 1) != 0, a.n >> 1, med, mad);
+    med_mad_dispatch<H, kMLo, R>(v, odd, (a.n & 1) != 0, a.n >> 1, med, mad);
 
     // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
     const int t_top = a.n - 1 - H;  // the odd lane's highest real register
@@ -332,20 +371,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(H == 128 ? 2
     const bool writer = valid && !odd;
     if (writer && !defer) a.out[g] = value;
 
-    // hand the pixel to the list pass: one atomic per wave, kListSlots counters (stack_sigma_clip.hip)
-    {
-        const bool d = writer && defer;
-        const unsigned long long m = __ballot(d);
-        if (m) {
-            const int leader = (int)__builtin_ctzll(m);
-            const unsigned int w = blockIdx.x;
-            const unsigned int slot = (w + (w / kListSlots) * 977u) & (kListSlots - 1);
-            unsigned int base = 0;
-            if (lane == leader) base = atomicAdd(&a.list_count[slot], (unsigned int)__builtin_popcountll(m));
-            base = __shfl(base, leader, 64);
-            if (d) a.list[(size_t)slot * a.list_cap + base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)g;
-        }
-    }
+    hand_over(a, writer && defer, lane, g);
 
     // rejection count: one atomic per wave, spread over kRejSlots counters (summed by the host)
     int r = (writer && !defer) ? (int)rej : 0;
@@ -358,11 +384,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(H == 128 ? 2
 
 int ab_stack_duo_launch(ab_ctx *ctx, int H, int R, const PairArgs &args) {
     const dim3 grid((unsigned)((args.total + 31) / 32)), block(64);
-#define AB_DUO_CASE(HV, RV)                                                                    \
-    if (H == HV && R == RV) {                                                                  \
-        hipLaunchKernelGGL((stack_duo_fast_kernel<HV, RV>), grid, block, 0, ctx->stream, args); \
-        AB_HIP(ctx, hipGetLastError());                                                        \
-        return AB_OK;                                                                          \
+#define AB_DUO_CASE(HV, RV)                                                                              \
+    if (H == HV && R == RV) {                                                                            \
+        if (args.median_only)                                                                            \
+            hipLaunchKernelGGL((stack_duo_fast_kernel<HV, RV, true>), grid, block, 0, ctx->stream, args); \
+        else                                                                                             \
+            hipLaunchKernelGGL((stack_duo_fast_kernel<HV, RV>), grid, block, 0, ctx->stream, args);       \
+        AB_HIP(ctx, hipGetLastError());                                                                  \
+        return AB_OK;                                                                                    \
     }
 #ifndef AB_DUO_ONE_CLASS  // (tests/test_abi_cpu.py walks the listing of ONE instance: the others are the same code at other constants)
     AB_DUO_CASE(128, 80)

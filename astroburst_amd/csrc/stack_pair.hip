@@ -316,8 +316,7 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
                          float *out_dev, bool median_only) {
     AB_CHECK(ctx, n > 128 && n <= 512, "the two-lane stack takes 129 .. 512 frames (got %zu)", n);
     const int H = n > 256 ? 256 : 128;
-    const bool fast = !median_only && !ctx->stack_exact;
-    AB_CHECK(ctx, fast || H == 256, "internal: the oracle-arithmetic two-lane kernel over all pixels exists for 257 .. 512 frames");
+    const bool fast = !ctx->stack_exact;  // (the median combine too: a pixel with every sample finite needs the sort and one register)
     void *ws = nullptr;
     AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, 2 * 512 * sizeof(float *), &ws));
     // the tables are tiny; a blocking copy keeps the host array's lifetime out of the picture
@@ -359,8 +358,12 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
     a.rejected = ctx->counters;
     a.median_only = median_only ? 1 : 0;
     const dim3 grid((unsigned)((a.total + 31) / 32)), block(64);
-    if (!fast) {
-        if (median_only)
+    if (!fast) {  // the exact engine (AB_STACK_EXACT=1) and the median combine: every pixel through the oracle's arithmetic
+        if (H == 128 && median_only)
+            hipLaunchKernelGGL((stack_pair_kernel<128, true>), grid, block, 0, ctx->stream, a);
+        else if (H == 128)
+            hipLaunchKernelGGL((stack_pair_kernel<128, false>), grid, block, 0, ctx->stream, a);
+        else if (median_only)
             hipLaunchKernelGGL((stack_pair_kernel<256, true>), grid, block, 0, ctx->stream, a);
         else
             hipLaunchKernelGGL((stack_pair_kernel<256, false>), grid, block, 0, ctx->stream, a);
@@ -398,8 +401,12 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
     }
     a.walk_lists = 1;
     const dim3 lgrid(kListSlots * kListWaves);
-    if (H == 128)
+    if (H == 128 && median_only)
+        hipLaunchKernelGGL((stack_pair_kernel<128, true>), lgrid, block, 0, ctx->stream, a);
+    else if (H == 128)
         hipLaunchKernelGGL((stack_pair_kernel<128, false>), lgrid, block, 0, ctx->stream, a);
+    else if (median_only)
+        hipLaunchKernelGGL((stack_pair_kernel<256, true>), lgrid, block, 0, ctx->stream, a);
     else
         hipLaunchKernelGGL((stack_pair_kernel<256, false>), lgrid, block, 0, ctx->stream, a);
     AB_HIP(ctx, hipGetLastError());

@@ -138,6 +138,31 @@ __device__ __forceinline__ void med_mad_dispatch(const float (&v)[HQ], int q, bo
     }
 }
 
+// the median alone (median_combine_row_major, calibration.rs:106-124: sorted[len / 2]): rank M = lane M >> 7, register M & 127
+template <int LO, int HI>
+__device__ __forceinline__ float median_dispatch(const float (&v)[HQ], int M /* launch-uniform */) {
+    if constexpr (LO == HI) {
+        return dppf<(LO >> 7) * 0x55>(v[LO & 127]);
+    } else {
+        constexpr int MID = (LO + HI) / 2;
+        return M <= MID ? median_dispatch<LO, MID>(v, M) : median_dispatch<MID + 1, HI>(v, M);
+    }
+}
+
+// hand the pixel to the list pass: one atomic per wave, kListSlots counters (stack_sigma_clip.hip)
+__device__ __forceinline__ void hand_over(const PairArgs &a, bool d, int lane, int64_t g) {
+    const unsigned long long m = __ballot(d);
+    if (m) {
+        const int leader = (int)__builtin_ctzll(m);
+        const unsigned int w = blockIdx.x;
+        const unsigned int slot = (w + (w / kListSlots) * 977u) & (kListSlots - 1);
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&a.list_count[slot], (unsigned int)__builtin_popcountll(m));
+        base = __shfl(base, leader, 64);
+        if (d) a.list[(size_t)slot * a.list_cap + base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)g;
+    }
+}
+
 // One clipping pass over the two ends of the quad's rank interval (combine.rs:65-82; stack_duo.hip: clip_walk).  [la, lb]: this
 // lane's part of it in its own register indices.  The low end is lane 0's registers 0 .. 7; the high end lane qt's last real
 // registers (chunks ct and ct - 1; qt, ct launch-uniform) and, when that lane holds at most eight samples, lane qt - 1's top.
@@ -210,7 +235,7 @@ __device__ __forceinline__ void clip_walk(const float (&v)[HQ], int q, bool go, 
     ch_own = ch;
 }
 
-template <int R>
+template <int R, bool MEDIAN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void stack_quad_fast_kernel(const PairArgs a) {
     static_assert(R <= HQ && 4 * R > 2 * HQ && R % 8 == 0, "frame-count class");
     const int lane = threadIdx.x;
@@ -266,8 +291,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     dpp_fence<HQ>(v);
 
     // ---- median / MAD: n / 2 is one number per launch ----
+    constexpr int kMLo = 2 * R - 32 > 128 ? 2 * R - 32 : 128;
+    if constexpr (MEDIAN) {  // median_combine_row_major (calibration.rs:84-125): the pixels with a non-finite sample go to the list pass
+        const float m = median_dispatch<kMLo, 2 * R>(v, a.n >> 1);
+        const bool writer = valid && q == 0;
+        if (writer && !defer) a.out[g] = m;
+        hand_over(a, writer && defer, lane, g);
+        return;
+    }
     float med, mad;
-    med_mad_dispatch<(2 * R - 32 > 128 ? 2 * R - 32 : 128), 2 * R>(v, q, (a.n & 1) != 0, a.n >> 1, med, mad);
+    med_mad_dispatch<kMLo, 2 * R>(v, q, (a.n & 1) != 0, a.n >> 1, med, mad);
 
     // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
     const int qt = (a.n - 1) >> 7, t_top = (a.n - 1) & 127;  // rank n - 1: lane qt, register t_top
@@ -350,20 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool writer = valid && q == 0;
     if (writer && !defer) a.out[g] = value;
 
-    // hand the pixel to the list pass: one atomic per wave, kListSlots counters (stack_sigma_clip.hip)
-    {
-        const bool d = writer && defer;
-        const unsigned long long m = __ballot(d);
-        if (m) {
-            const int leader = (int)__builtin_ctzll(m);
-            const unsigned int w = blockIdx.x;
-            const unsigned int slot = (w + (w / kListSlots) * 977u) & (kListSlots - 1);
-            unsigned int base = 0;
-            if (lane == leader) base = atomicAdd(&a.list_count[slot], (unsigned int)__builtin_popcountll(m));
-            base = __shfl(base, leader, 64);
-            if (d) a.list[(size_t)slot * a.list_cap + base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int)g;
-        }
-    }
+    hand_over(a, writer && defer, lane, g);
 
     // rejection count: one atomic per wave, spread over kRejSlots counters (summed by the host)
     int r = (writer && !defer) ? (int)rej : 0;
@@ -377,11 +397,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // the fast pass of a 257 .. 512-frame stack; the arguments' table holds 4 R pointers
 int ab_stack_quad_launch(ab_ctx *ctx, int R, const PairArgs &args) {
     const dim3 grid((unsigned)((args.total + 15) / 16)), block(64);
-#define AB_QUAD_CASE(RV)                                                                    \
-    if (R == RV) {                                                                          \
-        hipLaunchKernelGGL((stack_quad_fast_kernel<RV>), grid, block, 0, ctx->stream, args); \
-        AB_HIP(ctx, hipGetLastError());                                                     \
-        return AB_OK;                                                                       \
+#define AB_QUAD_CASE(RV)                                                                              \
+    if (R == RV) {                                                                                    \
+        if (args.median_only)                                                                         \
+            hipLaunchKernelGGL((stack_quad_fast_kernel<RV, true>), grid, block, 0, ctx->stream, args); \
+        else                                                                                          \
+            hipLaunchKernelGGL((stack_quad_fast_kernel<RV>), grid, block, 0, ctx->stream, args);       \
+        AB_HIP(ctx, hipGetLastError());                                                               \
+        return AB_OK;                                                                                 \
     }
 #ifndef AB_QUAD_ONE_CLASS  // (tests/test_abi_cpu.py walks the listing of ONE instance)
     AB_QUAD_CASE(80)

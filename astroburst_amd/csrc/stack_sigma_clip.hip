@@ -1237,10 +1237,11 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
     bool contig_all = total < (int64_t(1) << 30);
     for (size_t i = 0; i < n && contig_all; ++i) contig_all = ld[i] == cols;
     const bool reg128 = n > 64 && n <= 256 && contig_all && !partial && !ctx->stack_exact;  // (and 129 .. 256; median_combine too)
-    // Round 6: 129 .. 256 frames of a plain stack take two lanes per pixel, 128 samples each, two waves per SIMD (stack_duo.hip);
-    // AB_STACK_NO_DUO=1 (developer build) keeps round 5's one-lane 256-sample kernel, and the median combine still uses it
+    // Round 6: 129 .. 256 contiguous frames take two lanes per pixel, 128 samples each, two waves per SIMD -- stack_duo.hip's fast pass
+    // for the default engine's stack and the median combine, stack_pair.hip's oracle-arithmetic kernel for AB_STACK_EXACT=1 (15.5 ms
+    // for 256 x 4096^2 where the wave-per-pixel kernel took 151).  AB_STACK_NO_DUO=1 (developer build) keeps round 5's routes.
     static const bool no_duo = ab_dev_env("AB_STACK_NO_DUO") != nullptr;
-    const bool duo = reg128 && n > 128 && !median_only && !no_duo;
+    const bool duo = n > 128 && n <= 256 && contig_all && !partial && !no_duo;
     if (n > 64 && (!reg128 || duo)) {  // deeper than one lane's registers
         for (hipEvent_t &e : ctx->stack_ev)
             if (!e) AB_HIP(ctx, hipEventCreate(&e));
@@ -1321,6 +1322,11 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         ctx->stack_ev_valid = false;
         if (first_chunk) AB_HIP(ctx, hipEventRecord(ctx->stack_ev[0], ctx->stream));
         if (np == 256) {  // 129 .. 256 contiguous frames: 256 samples per lane (VGPRs + AGPRs), single pass
+#ifndef AB_DEV_ABLATION
+            // (round 6: these frame counts take two lanes per pixel -- `duo` above; round 5's one-lane kernels are built into the
+            // developer library only, for the A/B under AB_STACK_NO_DUO=1)
+            return ab_set_error(ctx, AB_ERR_INVALID, "internal: %d frames reached the one-lane 256-sample route", args.n_real);
+#else
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
             // frame-count classes of 32 (AB_STACK_NO_CLASSES=1: every count pays for 256): the pads' loads and the network's
             // operations on pad wires are gone at compile time
@@ -1339,6 +1345,7 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
             else AB_LAUNCH_256(256);
 #undef AB_LAUNCH_256
             AB_HIP(ctx, hipGetLastError());
+#endif
         } else if (np == 128) {  // reg128 (checked above): only the direct-gather kernels exist for 128 samples per lane
             const dim3 grid((unsigned)((total + 255) / 256)), block(256);
             if (median_only) {

@@ -200,6 +200,8 @@ def test_two_lane_fast_pass(engine, oracle, n):
         want, wrej = oracle.stack_images(fr, sl, sh, it)
         got, rej = ctx.stack_sigma_clip(fr, sl, sh, it)
         assert_stack_parity(got, want, rej, wrej, exact)
+    # the median combine takes the same fast pass (an order statistic: bit for bit on either engine)
+    assert np.array_equal(ctx.median_combine(fr), oracle.median_combine(fr), equal_nan=True)
 
 
 @pytest.mark.parametrize("n", [513, 700, 1024, 1025, 2048, 2100, 4096])

@@ -14,12 +14,14 @@ g = torch.Generator(device="cuda").manual_seed(1)
 for n in [int(v) for v in os.environ.get("N_LIST", "64,96,128,256").split(",")]:
     fr = [torch.randn((SIDE, SIDE), device="cuda", generator=g) * 15.0 + 1200.0 for _ in range(n)]
     out = torch.empty((SIDE, SIDE), device="cuda")
-    ctx.stack_sigma_clip(fr, out=out, want_rejected=False)
+    median = os.environ.get("MODE", "") == "median"  # median_combine (calibration masters) instead of the kappa-sigma stack
+    run = (lambda: ctx.median_combine(fr, out=out)) if median else (lambda: ctx.stack_sigma_clip(fr, out=out, want_rejected=False))
+    run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
-        ctx.stack_sigma_clip(fr, out=out, want_rejected=False)
+        run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
-    print(f"{n:4d} frames x {SIDE}^2: {ms:8.2f} ms  ({n * SIDE * SIDE * 4 / ms / 1e9:.2f} TB/s of samples)  kernels {ctx.stack_last_kernel_ms():.2f} ms")
+    print(f"{n:4d} frames x {SIDE}^2{' median' if median else ''}: {ms:8.2f} ms  ({n * SIDE * SIDE * 4 / ms / 1e9:.2f} TB/s of samples)  kernels {ctx.stack_last_kernel_ms():.2f} ms")
     del fr
