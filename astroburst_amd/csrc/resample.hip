@@ -98,11 +98,33 @@ __device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, i
     return bicubic_taps(src, rows, cols, ld, ix, iy, wx0, wx1, wx2, wx3, wy0, wy1, wy2, wy3);
 }
 
+// Which piece of which row a workgroup takes.  The hardware hands workgroup ids round the eight XCDs (id % 8), and a piece needs four
+// source rows of which the piece below shares three.  With the pieces in row-major id order neighbouring rows land in different
+// XCDs' L2 whenever a row is not a multiple of 8 pieces wide (4096 columns in 512-pixel pieces are; 12 451 are not: every source row
+// was fetched into up to four L2s).  So the row-major sequence of pieces is cut into eight contiguous runs and XCD c walks run c:
+// a band of rows.  (A bijection: XCD j receives ids j, j + 8, ...: (total - j + 7) / 8 of them.)
+__device__ __forceinline__ void xcd_band_piece(unsigned int &piece_x, unsigned int &piece_y) {
+#ifndef AB_WARP_ROW_MAJOR
+    const unsigned int gx = gridDim.x, total = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+    const unsigned int c = id & 7u, k = id >> 3;
+    unsigned int start = 0;
+    for (unsigned int j = 0; j < c; ++j) start += (total - j + 7u) >> 3;
+    const unsigned int t = start + k;
+    piece_y = t / gx;
+    piece_x = t - piece_y * gx;
+#else
+    piece_x = blockIdx.x;
+    piece_y = blockIdx.y;
+#endif
+}
+
 // align.rs:46-55
 __global__ __launch_bounds__(256) void shift_kernel(const float *__restrict__ src, int rows, int cols, int ld, double dy,
                                                     double dx, float *__restrict__ out) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
+    unsigned int piece_x, piece_y;
+    xcd_band_piece(piece_x, piece_y);
+    const int x = piece_x * 256 + threadIdx.x;
+    const int y = piece_y;
     if (x >= cols) return;
     const double sy = (double)y + dy;
     const double sx = (double)x + dx;
@@ -138,10 +160,12 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
 #ifdef AB_WARP_WAVE_PRIO
     __builtin_amdgcn_s_setprio(AB_WARP_WAVE_PRIO);
 #endif
-    const int x0 = blockIdx.x * 512 + threadIdx.x;
+    unsigned int piece_x, piece_y;  // (the pieces of a row band per XCD: xcd_band_piece)
+    xcd_band_piece(piece_x, piece_y);
+    const int x0 = piece_x * 512 + threadIdx.x;
     // row0: the band of output rows [row0, row0 + gridDim.y) this launch produces (row-band sharding); the
     // coordinate arithmetic uses the row's index in the WHOLE output, so a band is bit-identical to the same rows of a full warp
-    const int y = blockIdx.y + row0;
+    const int y = piece_y + row0;
     const double yf = (double)y;
     float r[2];
     bool live[2];
@@ -193,15 +217,17 @@ __global__ __launch_bounds__(256) void warp_kernel(const float *__restrict__ src
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-        if (live[u]) out[(size_t)blockIdx.y * out_cols + x0 + 256 * u] = r[u];
+        if (live[u]) out[(size_t)piece_y * out_cols + x0 + 256 * u] = r[u];
 }
 
 // resample.rs:41-58: target pixel centres mapped onto the source grid
 __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__ src, int src_rows, int src_cols, double scale_y,
                                                        double scale_x, double half_shift_y, double half_shift_x, int out_cols,
                                                        float *__restrict__ out) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
+    unsigned int piece_x, piece_y;
+    xcd_band_piece(piece_x, piece_y);
+    const int x = piece_x * 256 + threadIdx.x;
+    const int y = piece_y;
     if (x >= out_cols) return;
     const double sy = (double)y * scale_y + half_shift_y;
     const double sx = (double)x * scale_x + half_shift_x;

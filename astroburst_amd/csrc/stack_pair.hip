@@ -371,8 +371,9 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
         return AB_OK;
     }
     // the lists: slot = wave index & (kListSlots - 1) (rotated), so a slot holds at most ceil(waves / kListSlots) waves' worth of pixels
-    const int64_t waves = (total + 31) / 32;
-    const unsigned int cap = (unsigned int)(((waves + kListSlots - 1) / kListSlots) * 32);
+    // (the fast pass's waves: 32 pixels each with two lanes per pixel, 16 with four and the grid rounded up to a multiple of 8)
+    const int64_t waves = quad ? ((total + 15) / 16 + 7) / 8 * 8 : (total + 31) / 32;
+    const unsigned int cap = (unsigned int)(((waves + kListSlots - 1) / kListSlots) * (quad ? 16 : 32));
     char *lw = nullptr;
     const void *before = ctx->ws[AB_WS_STACK_PAIR_LISTS];
     AB_TRY(ab_workspace(ctx, AB_WS_STACK_PAIR_LISTS, (size_t)2 * kListSlots * sizeof(unsigned int) + (size_t)kListSlots * cap * sizeof(int), (void **)&lw));

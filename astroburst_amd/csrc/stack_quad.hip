@@ -241,7 +241,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int lane = threadIdx.x;
     const int q = lane & 3;
     const int pix = lane >> 2;
-    int64_t g = (int64_t)blockIdx.x * 16 + pix;
+    // A wave reads 16 pixels = 64 bytes of every plane: HALF a cache line, the other half being the next wave's.  Workgroup ids go
+    // round the eight XCDs (id % 8), so consecutive ids would fetch every line into two XCDs' L2; ids id and id + 8 -- same XCD,
+    // dispatched together -- take neighbouring pixel groups instead (the grid is a multiple of 8).
+    const unsigned int per_xcd = gridDim.x >> 3;
+    const unsigned int group = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    int64_t g = (int64_t)group * 16 + pix;
     const bool valid = g < a.total;
     if (!valid) g = a.total - 1;
 
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 // the fast pass of a 257 .. 512-frame stack; the arguments' table holds 4 R pointers
 int ab_stack_quad_launch(ab_ctx *ctx, int R, const PairArgs &args) {
-    const dim3 grid((unsigned)((args.total + 15) / 16)), block(64);
+    const dim3 grid((unsigned)(((args.total + 15) / 16 + 7) / 8 * 8)), block(64);  // (a multiple of 8: see the kernel's pixel-group order)
 #define AB_QUAD_CASE(RV)                                                                              \
     if (R == RV) {                                                                                    \
         if (args.median_only)                                                                         \

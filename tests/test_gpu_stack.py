@@ -204,6 +204,18 @@ def test_two_lane_fast_pass(engine, oracle, n):
     assert np.array_equal(ctx.median_combine(fr), oracle.median_combine(fr), equal_nan=True)
 
 
+@pytest.mark.parametrize("n", [150, 256, 300, 512])
+@pytest.mark.parametrize("sl,sh,it", [(0.0, 0.0, 5), (-1.0, 3.0, 5), (3.0, float("inf"), 5), (float("nan"), 3.0, 2), (3.0, -2.0, 3), (1e-3, 1e30, 40)])
+def test_two_lane_fast_pass_odd_settings(engine, oracle, n, sl, sh, it):
+    """the parameter sweep of the <= 64-frame kernels (zero, negative, infinite, NaN kappas, many iterations) on the multi-lane passes:
+    whatever their eight-samples-per-end walks cannot decide must reach the oracle-arithmetic kernel"""
+    ctx, exact = engine
+    fr = clean_frames(n, (9, 40), 8000 + n, every=7, rate=0.05)
+    want, wrej = oracle.stack_images(fr, sl, sh, it)
+    got, rej = ctx.stack_sigma_clip(fr, sl, sh, it)
+    assert_stack_parity(got, want, rej, wrej, exact)
+
+
 @pytest.mark.parametrize("n", [513, 700, 1024, 1025, 2048, 2100, 4096])
 def test_more_than_512_frames_wave_per_pixel(engine, oracle, n):
     """VERDICT r4 missing 2: the reference stacks whatever `paths` holds (calibration.rs:297-318 -> combine.rs:94-193).  513 .. 4096
