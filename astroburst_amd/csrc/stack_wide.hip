@@ -261,9 +261,14 @@ __global__ __launch_bounds__(256) void stack_wide_quad_kernel(const WideArgs a) 
 // 242 ms (0.07 TB/s of samples).  Here a workgroup stages G = 16 / 8 / 4 ADJACENT pixels of all n frames through LDS (K = 16 / 32 / 64:
 // 64 KB) with 16-byte loads -- every byte fetched is used -- and its four waves then combine the pixels one after the other with
 // the same wide_pixel (bit-identical results).  Needs contiguous 16-byte aligned planes and a pixel count that is a multiple of 16.
-constexpr int kTileWaves = 8;  // 512 threads: two workgroups of 64 KB per CU are then four waves per SIMD
+// 512 threads: two workgroups of 64 KB per CU are then four waves per SIMD.  K = 64 (2049 .. 4096 frames, four pixels per group):
+// FOUR waves, one per pixel -- with eight, a thread may hold 256 registers and the two 64-register sort arrays spilled 279 of them
+// (2100 x 1024^2: 590 ms, twenty times the per-pixel time of 2048 frames).
+template <int K>
+constexpr int tile_waves() { return K == 64 ? 4 : 8; }
 template <int K, bool TREE>
-__global__ __launch_bounds__(64 * kTileWaves) void stack_wide_tile_kernel(const WideArgs a) {
+__global__ __launch_bounds__(64 * tile_waves<K>()) void stack_wide_tile_kernel(const WideArgs a) {
+    constexpr int kTileWaves = tile_waves<K>();
     constexpr int G = 256 / K, NPAD = 64 * K;  // pixels per group (G x NPAD floats = 64 KB), frames padded to the wave's 64 K slots
     static_assert(G >= 4 && G % 4 == 0 && G * NPAD * 4 == 65536, "32 / 16 / 8 / 4 adjacent pixels in 64 KB");
     extern __shared__ __attribute__((aligned(16))) float tile[];  // [G][NPAD]
@@ -274,7 +279,11 @@ __global__ __launch_bounds__(64 * kTileWaves) void stack_wide_tile_kernel(const 
         tile[row * NPAD + col] = __builtin_inff();
     }
     unsigned long long rej_total = 0;
-    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    // A group is 64 / 32 / 16 bytes of every plane: a half, a quarter, an eighth of a cache line, the rest being the next groups'.
+    // Workgroup ids go round the eight XCDs (id % 8): in id order the groups that share a line would pull it into as many L2s.
+    // Ids id, id + 8, ... -- one XCD -- take neighbouring groups instead (any grid that is a multiple of 8; else id order).
+    const unsigned int first = (gridDim.x & 7u) == 0 ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    for (int64_t grp = first; grp < groups; grp += gridDim.x) {
         const int64_t base = grp * G;
         constexpr int QPF = G / 4;  // 16-byte quads per frame and group
         for (int i0 = 0; i0 < a.n * QPF; i0 += 64 * kTileWaves * 4) {
@@ -358,7 +367,7 @@ int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t
 #define AB_WIDE_TILE(KK, TT)                                                                                                                   \
     do {                                                                                                                                       \
         AB_HIP(ctx, hipFuncSetAttribute((const void *)stack_wide_tile_kernel<KK, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));  \
-        hipLaunchKernelGGL((stack_wide_tile_kernel<KK, TT>), dim3(tgrid), dim3(64 * kTileWaves), 65536, ctx->stream, a);                                 \
+        hipLaunchKernelGGL((stack_wide_tile_kernel<KK, TT>), dim3(tgrid), dim3(64 * tile_waves<KK>()), 65536, ctx->stream, a);                                 \
     } while (0)
     if (tiled && n > 2048) {
         if (tree) AB_WIDE_TILE(64, true); else AB_WIDE_TILE(64, false);
