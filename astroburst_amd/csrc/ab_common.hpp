@@ -414,6 +414,10 @@ int ab_stack_deep_device(ab_ctx *ctx, const float *const *dplanes, const int64_t
                          const ab_stack_config *cfg, float *out_dev, double *out_sum_dev, uint32_t *out_cnt_dev, bool median_only);
 int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg,
                          float *out_dev, bool median_only);
+// stack_wide.hip: the pixels a 513 .. 1024-frame fast pass (stack_quad.hip, eight lanes per pixel) handed over -- 2048 lists of `cap`
+// pixel indices each -- one wave per pixel, the oracle's arithmetic; leaves the lists empty.  table_dev: DEVICE array of >= n plane pointers
+int ab_stack_wide_list_device(ab_ctx *ctx, const float *const *table_dev, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg, float *out_dev,
+                              bool median_only, unsigned int *list_count, const int *list, unsigned int cap);
 
 static inline int ab_div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -309,16 +309,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(H == 128 ? 2
 
 }  // namespace
 
-// dplanes: HOST array of n device pointers (128 < n <= 512), contiguous planes of rows x cols; counters already cleared by the caller.
-// 257 .. 512 frames under the exact engine and every median combine: the oracle-arithmetic kernel over all pixels.  The default
-// engine (129 .. 512 frames): stack_duo.hip's fast pass, then this file's kernel over the pixels it handed over.
+// dplanes: HOST array of n device pointers (128 < n <= 1024), contiguous planes of rows x cols; counters already cleared by the caller.
+// The default engine (and its median combine): a fast multi-lane pass -- two lanes per pixel for 129 .. 256 frames (stack_duo.hip), four
+// for 257 .. 512, eight for 513 .. 1024 (stack_quad.hip) -- then the oracle's arithmetic over the pixels it handed over (this file's
+// kernel in list mode up to 512 frames, stack_wide.hip's wave-per-pixel kernel beyond).  AB_STACK_EXACT=1 (129 .. 512 frames): this
+// file's kernel over all pixels.
 int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg,
                          float *out_dev, bool median_only) {
-    AB_CHECK(ctx, n > 128 && n <= 512, "the two-lane stack takes 129 .. 512 frames (got %zu)", n);
-    const int H = n > 256 ? 256 : 128;
+    AB_CHECK(ctx, n > 128 && n <= 1024, "the multi-lane stack takes 129 .. 1024 frames (got %zu)", n);
+    const int H = n > 256 ? 256 : 128;  // samples per lane of THIS file's kernel (129 .. 512 frames)
     const bool fast = !ctx->stack_exact;  // (the median combine too: a pixel with every sample finite needs the sort and one register)
+    AB_CHECK(ctx, fast || n <= 512, "internal: the exact engine of %zu frames is the wave-per-pixel kernel's", n);
+    constexpr size_t kTab = 1024;  // [0, kTab): the fast pass's table (frames, then the +inf plane); [kTab, kTab + 512): this file's kernel's
     void *ws = nullptr;
-    AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, 2 * 512 * sizeof(float *), &ws));
+    AB_TRY(ab_workspace(ctx, AB_WS_STACK_WIDE, (kTab + 512) * sizeof(float *), &ws));
     // the tables are tiny; a blocking copy keeps the host array's lifetime out of the picture
     AB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // frames the stack is short of: ONE plane of +inf stands in for all of them (a non-finite sample is exactly what the
@@ -334,20 +338,20 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
             AB_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ip, 0x7f800000, ctx->ws_bytes[AB_WS_STACK_INF] / sizeof(float), ctx->stream));
         inf_plane = ip;
     }
-    // frame-count classes of the fast pass: R frames per lane, a multiple of H / 8 (the pads' loads and network operations vanish)
-    // (257 .. 512 frames: FOUR lanes per pixel with 128 samples each, stack_quad.hip; AB_STACK_NO_QUAD=1 on a developer build keeps two)
+    // frame-count classes of the fast pass: R frames per lane, a multiple of 16 (H / 8 with two lanes): the pads' loads and network
+    // operations vanish.  (AB_STACK_NO_QUAD=1 on a developer build: 257 .. 512 frames on two lanes with 256 samples each.)
     static const bool no_quad = ab_dev_env("AB_STACK_NO_QUAD") != nullptr;
-    const bool quad = fast && H == 256 && !no_quad;
+    const bool quad = fast && n > 256 && (n > 512 || !no_quad);
+    const size_t lanes = n > 512 ? 8 : (quad ? 4 : 2);
     const int cw = quad ? 16 : H / 8;
-    const size_t lanes = quad ? 4 : 2;
     const int R = fast ? (int)(((n + lanes - 1) / lanes + (size_t)cw - 1) / (size_t)cw) * cw : H;
-    const float *table[2 * 512];  // [0, 2R): the fast pass's table; [512, 512 + 2H): the oracle-arithmetic kernel's
-    for (int i = 0; i < 512; ++i) table[i] = (size_t)i < n ? dplanes[i] : inf_plane;
-    for (int i = 0; i < 512; ++i) table[512 + i] = table[i];
-    AB_HIP(ctx, hipMemcpy(ws, table, sizeof table, hipMemcpyHostToDevice));
+    std::vector<const float *> table(kTab + 512);
+    for (size_t i = 0; i < kTab; ++i) table[i] = i < n ? dplanes[i] : inf_plane;
+    for (size_t i = 0; i < 512; ++i) table[kTab + i] = table[i];
+    AB_HIP(ctx, hipMemcpy(ws, table.data(), table.size() * sizeof(float *), hipMemcpyHostToDevice));
     PairArgs a;
     memset(&a, 0, sizeof a);
-    a.p = (const float *const *)ws + 512;
+    a.p = (const float *const *)ws + kTab;
     a.n = (int)n;
     a.half = H;
     a.total = total;
@@ -372,8 +376,9 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
     }
     // the lists: slot = wave index & (kListSlots - 1) (rotated), so a slot holds at most ceil(waves / kListSlots) waves' worth of pixels
     // (the fast pass's waves: 32 pixels each with two lanes per pixel, 16 with four and the grid rounded up to a multiple of 8)
-    const int64_t waves = quad ? ((total + 15) / 16 + 7) / 8 * 8 : (total + 31) / 32;
-    const unsigned int cap = (unsigned int)(((waves + kListSlots - 1) / kListSlots) * (quad ? 16 : 32));
+    const int64_t px_wave = 64 / (int64_t)lanes;
+    const int64_t waves = quad ? ((total + px_wave - 1) / px_wave + 7) / 8 * 8 : (total + 31) / 32;
+    const unsigned int cap = (unsigned int)(((waves + kListSlots - 1) / kListSlots) * px_wave);
     char *lw = nullptr;
     const void *before = ctx->ws[AB_WS_STACK_PAIR_LISTS];
     AB_TRY(ab_workspace(ctx, AB_WS_STACK_PAIR_LISTS, (size_t)2 * kListSlots * sizeof(unsigned int) + (size_t)kListSlots * cap * sizeof(int), (void **)&lw));
@@ -387,7 +392,7 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
     f.p = (const float *const *)ws;
     f.half = R;
     if (quad)
-        AB_TRY(ab_stack_quad_launch(ctx, R, f));
+        AB_TRY(ab_stack_quad_launch(ctx, (int)lanes, R, f));
     else
         AB_TRY(ab_stack_duo_launch(ctx, H, R, f));
     if (ab_env("AB_TRACE")) {  // developer aid: how many pixels the fast pass handed over
@@ -400,6 +405,8 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
         fprintf(stderr, "[ab_trace] two-lane stack: %llu of %lld pixels handed to the list pass (%.2f %%), fullest list %llu of %u\n", tot, (long long)total,
                 100.0 * (double)tot / (double)total, mx, cap);
     }
+    if (n > 512)  // the wave-per-pixel kernel walks the lists
+        return ab_stack_wide_list_device(ctx, (const float *const *)ws, n, rows, cols, cfg, out_dev, median_only, a.list_count, a.list, cap);
     a.walk_lists = 1;
     const dim3 lgrid(kListSlots * kListWaves);
     if (H == 128 && median_only)

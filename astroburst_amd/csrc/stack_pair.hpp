@@ -126,6 +126,6 @@ __device__ __forceinline__ void cross_step(float (&v)[H], bool odd) {
 // stack_duo.hip: the fast pass of a 129 .. 512-frame stack (H = 128 or 256 samples per lane, the class R of frames per lane);
 // the arguments' table holds 2 R pointers
 int ab_stack_duo_launch(ab_ctx *ctx, int H, int R, const abpair::PairArgs &args);
-// stack_quad.hip: the fast pass of a 257 .. 512-frame stack, four lanes per pixel with 128 samples each (class R of frames per lane); the
-// table holds 4 R pointers
-int ab_stack_quad_launch(ab_ctx *ctx, int R, const abpair::PairArgs &args);
+// stack_quad.hip: the fast pass of a 257 .. 512-frame (L = 4 lanes per pixel) or 513 .. 1024-frame (L = 8) stack, 128 samples per lane
+// (class R of frames per lane); the table holds L R pointers
+int ab_stack_quad_launch(ab_ctx *ctx, int L, int R, const abpair::PairArgs &args);

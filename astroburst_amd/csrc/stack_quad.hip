@@ -16,6 +16,12 @@
 //   * clipping, running moments, the list of pixels handed to stack_pair.hip's oracle-arithmetic kernel: as in stack_duo.hip, the
 //     low end in lane 0's first registers, the high end in the lane that holds rank n - 1.
 // Same contract as the <= 64-frame fast engine: 1e-5 relative, at most 1e-4 of the pixels may differ from the oracle at all.
+//
+// 513 .. 1024 frames: the same kernel with EIGHT lanes per pixel (L = 8; lanes 8k .. 8k + 7, pixel k of the wave's 8): a third
+// merge level (cross step against lane 7 - q's reversed registers = DPP row_half_mirror, half-cleaner stages between lanes q ^ 2
+// and q ^ 1, the in-lane merge), sums over three DPP steps, a window's far end `row_shl` 2 .. 5 lanes on, the median's lane through
+// ds_bpermute.  The wave-per-pixel kernel (stack_wide.hip: a bitonic sort through 64-lane shuffles) took 43.7 ms for 513 x 2048^2
+// where 512 frames take 5: its pixels now are only the ones this pass hands over.
 #include "stack_pair.hpp"
 
 #include <algorithm>
@@ -38,15 +44,22 @@ __device__ __forceinline__ int dppi(int x) {
 constexpr int kSwap1 = 0xB1;  // quad_perm [1,0,3,2]: lane q ^ 1
 constexpr int kSwap2 = 0x4E;  // quad_perm [2,3,0,1]: lane q ^ 2
 constexpr int kRev = 0x1B;    // quad_perm [3,2,1,0]: lane q ^ 3
-constexpr int kUp1 = 0xF9;    // quad_perm [1,2,3,3]: lane q + 1
-constexpr int kUp2 = 0xFE;    // quad_perm [2,3,3,3]: lane q + 2
-__device__ __forceinline__ int quad_sum(int x) {
+constexpr int kHalfMirror = 0x141;  // row_half_mirror: lane 7 - i of every 8
+// sums / ors / minima over the L = 4 or 8 lanes of a pixel: after the steps inside a quad every lane of it holds the quad's value,
+// and the half mirror pairs a lane with one of the other quad
+template <int L>
+__device__ __forceinline__ int grp_sum(int x) {
     x += dppi<kSwap1>(x);
-    return x + dppi<kSwap2>(x);
+    x += dppi<kSwap2>(x);
+    if constexpr (L == 8) x += dppi<kHalfMirror>(x);
+    return x;
 }
-__device__ __forceinline__ int quad_or(int x) {
+template <int L>
+__device__ __forceinline__ int grp_or(int x) {
     x |= dppi<kSwap1>(x);
-    return x | dppi<kSwap2>(x);
+    x |= dppi<kSwap2>(x);
+    if constexpr (L == 8) x |= dppi<kHalfMirror>(x);
+    return x;
 }
 template <int CTRL>
 __device__ __forceinline__ double dppd(double x) {
@@ -54,10 +67,29 @@ __device__ __forceinline__ double dppd(double x) {
     const unsigned int lo = (unsigned int)dppi<CTRL>((int)(unsigned int)u), hi = (unsigned int)dppi<CTRL>((int)(unsigned int)(u >> 32));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-// (both steps add the same two numbers in every lane of a pair, then of the quad: the four lanes end with the same bits)
-__device__ __forceinline__ double quad_sum(double x) {
+// (every step adds the same two numbers in both lanes of a pair: all lanes of the group end with the same bits)
+template <int L>
+__device__ __forceinline__ double grp_sum(double x) {
     x += dppd<kSwap1>(x);
-    return x + dppd<kSwap2>(x);
+    x += dppd<kSwap2>(x);
+    if constexpr (L == 8) x += dppd<kHalfMirror>(x);
+    return x;
+}
+template <int L>
+__device__ __forceinline__ float grp_min(float x) {
+    x = fminf(x, dppf<kSwap1>(x));
+    x = fminf(x, dppf<kSwap2>(x));
+    if constexpr (L == 8) x = fminf(x, dppf<kHalfMirror>(x));
+    return x;
+}
+// lane k's register for every lane of the group
+template <int L, int KLANE>
+__device__ __forceinline__ float grp_bcast(float x, int lane) {
+    if constexpr (L == 4) {
+        return dppf<KLANE * 0x55>(x);  // quad_perm [k,k,k,k]
+    } else {
+        return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane & ~7) | KLANE) << 2, __builtin_bit_cast(int, x)));
+    }
 }
 
 __device__ __forceinline__ double sqrt_for_sigma(double v) {  // stack_sigma_clip.hip
@@ -90,62 +122,60 @@ __device__ __forceinline__ void cross_same(float (&v)[HQ], float sel) {
     }
 }
 
-// median (combine.rs:38-40) and MAD (combine.rs:42-46) of a quad that holds n finite samples, n / 2 = M: rank r in lane r >> 7,
-// register r & 127.  MAD = min over p = 0 .. n - 1 - M of max(med - V[p], V[p + M] - med) (stack_duo.hip).  The window p belongs to the
-// lane that holds V[p] (lane 0: every p = i; lane 1: p = 128 + i <= M - 1); its high end is register (i + M) & 127 of lane q + 1 or q + 2.
-template <int M>
-__device__ __forceinline__ void med_mad_at(const float (&v)[HQ], int q, bool n_is_odd, float &med_out, float &mad_out) {
-    static_assert(M >= 128 && M <= 256, "a quad holds 257 .. 512 samples");
+// median (combine.rs:38-40) and MAD (combine.rs:42-46) of a group of L lanes that holds n finite samples, n / 2 = M: rank r in lane
+// r >> 7, register r & 127.  MAD = min over p = 0 .. n - 1 - M of max(med - V[p], V[p + M] - med) (stack_duo.hip).  The window p
+// belongs to the lane that holds V[p] (lanes below M >> 7: every register; lane M >> 7: registers below M & 127); its high end is
+// register (i + M) & 127 of the lane (M >> 7) or (M >> 7) + 1 places on: DPP row_shl.
+template <int L, int M>
+__device__ __forceinline__ void med_mad_at(const float (&v)[HQ], int q, int lane, bool n_is_odd, float &med_out, float &mad_out) {
+    static_assert(M >= 32 * L && M <= 64 * L, "a group of L lanes holds 64 L + 1 .. 128 L samples");
     constexpr int Mq = M >> 7, Mr = M & 127;
-    const float med = dppf<Mq * 0x55>(v[Mr]);  // (quad_perm [k,k,k,k]: lane k's register for everybody)
+    const float med = grp_bcast<L, Mq>(v[Mr], lane);
     const float inf = __builtin_inff();
-    float best_a = inf /* windows of lanes 0 and 1 */, best_b = inf /* windows of lane 0 only */;
+    float best_lo = inf /* windows from registers below Mr */, best_hi = inf /* from the others */;
 #pragma unroll
     for (int i = 0; i < HQ; ++i) {
         const int s2 = (i + Mr) & 127;
-        const bool two = Mq + ((i + Mr) >> 7) == 2;
-        const float hi_end = two ? dppf<kUp2>(v[s2]) : dppf<kUp1>(v[s2]);
+        const float hi_end = ((i + Mr) >> 7) ? dppf<0x100 + Mq + 1>(v[s2]) : dppf<0x100 + Mq>(v[s2]);  // row_shl: lane q + Mq (+ 1)
         const float t = ab_v_max(med - v[i], hi_end - med);
-        if (i <= M - 129)
-            best_a = ab_v_min(best_a, t);
+        if (i < Mr)
+            best_lo = ab_v_min(best_lo, t);
         else
-            best_b = ab_v_min(best_b, t);
+            best_hi = ab_v_min(best_hi, t);
     }
-    float x = q == 0 ? ab_v_min(best_a, best_b) : (q == 1 ? best_a : inf);
+    float x = q < Mq ? ab_v_min(best_lo, best_hi) : (q == Mq ? best_lo : inf);
     if (n_is_odd) {  // (launch-uniform) n = 2M + 1: the window [M, 2M], whose larger deviation is V[2M] - med
         constexpr int T = 2 * M;
-        if constexpr (T < 4 * HQ) {
-            const float e = dppf<(T >> 7) * 0x55>(v[T & 127]) - med;
+        if constexpr (T < L * HQ) {
+            const float e = grp_bcast<L, (T >> 7)>(v[T & 127], lane) - med;
             x = q == 0 ? fminf(x, e) : x;
         }
     }
     x = x + 0.0f;  // (a compiler-visible VALU write: the DPP reads below are then the hazard recogniser's business)
-    x = fminf(x, dppf<kSwap1>(x));
-    x = fminf(x, dppf<kSwap2>(x));
     med_out = med;
-    mad_out = x;
+    mad_out = grp_min<L>(x);
 }
-template <int LO, int HI>
-__device__ __forceinline__ void med_mad_dispatch(const float (&v)[HQ], int q, bool n_is_odd, int M /* launch-uniform */, float &med, float &mad) {
+template <int L, int LO, int HI>
+__device__ __forceinline__ void med_mad_dispatch(const float (&v)[HQ], int q, int lane, bool n_is_odd, int M /* launch-uniform */, float &med, float &mad) {
     if constexpr (LO == HI) {
-        med_mad_at<LO>(v, q, n_is_odd, med, mad);
+        med_mad_at<L, LO>(v, q, lane, n_is_odd, med, mad);
     } else {
         constexpr int MID = (LO + HI) / 2;
         if (M <= MID)
-            med_mad_dispatch<LO, MID>(v, q, n_is_odd, M, med, mad);
+            med_mad_dispatch<L, LO, MID>(v, q, lane, n_is_odd, M, med, mad);
         else
-            med_mad_dispatch<MID + 1, HI>(v, q, n_is_odd, M, med, mad);
+            med_mad_dispatch<L, MID + 1, HI>(v, q, lane, n_is_odd, M, med, mad);
     }
 }
 
 // the median alone (median_combine_row_major, calibration.rs:106-124: sorted[len / 2]): rank M = lane M >> 7, register M & 127
-template <int LO, int HI>
-__device__ __forceinline__ float median_dispatch(const float (&v)[HQ], int M /* launch-uniform */) {
+template <int L, int LO, int HI>
+__device__ __forceinline__ float median_dispatch(const float (&v)[HQ], int lane, int M /* launch-uniform */) {
     if constexpr (LO == HI) {
-        return dppf<(LO >> 7) * 0x55>(v[LO & 127]);
+        return grp_bcast<L, (LO >> 7)>(v[LO & 127], lane);
     } else {
         constexpr int MID = (LO + HI) / 2;
-        return M <= MID ? median_dispatch<LO, MID>(v, M) : median_dispatch<MID + 1, HI>(v, M);
+        return M <= MID ? median_dispatch<L, LO, MID>(v, lane, M) : median_dispatch<L, MID + 1, HI>(v, lane, M);
     }
 }
 
@@ -166,7 +196,7 @@ __device__ __forceinline__ void hand_over(const PairArgs &a, bool d, int lane, i
 // One clipping pass over the two ends of the quad's rank interval (combine.rs:65-82; stack_duo.hip: clip_walk).  [la, lb]: this
 // lane's part of it in its own register indices.  The low end is lane 0's registers 0 .. 7; the high end lane qt's last real
 // registers (chunks ct and ct - 1; qt, ct launch-uniform) and, when that lane holds at most eight samples, lane qt - 1's top.
-template <bool UPDATE>
+template <int L, bool UPDATE>
 __device__ __forceinline__ void clip_walk(const float (&v)[HQ], int q, bool go, int la, int lb, int qt, int ct, float center, float lo, float hi, float c0,
                                           double c0d, int &cl_own, int &ch_own, bool &decided, double &e_rem, double &q_rem) {
     constexpr int NC = HQ / 4;
@@ -216,7 +246,7 @@ __device__ __forceinline__ void clip_walk(const float (&v)[HQ], int q, bool go, 
         fold(r, 4 * c);
     };
     // (whether some pixel of the wave still looks for its first surviving sample at the high end: the quad's lanes share the flag)
-    auto open_hi = [&]() { return __any(go && quad_or(found_hi ? 1 : 0) == 0); };
+    auto open_hi = [&]() { return __any(go && grp_or<L>(found_hi ? 1 : 0) == 0); };
 #pragma unroll
     for (int c = NC - 1; c >= 0; --c) {
         if (c != ct && c != ct - 1) continue;  // (uniform)
@@ -230,23 +260,24 @@ __device__ __forceinline__ void clip_walk(const float (&v)[HQ], int q, bool go, 
         }
     }
     const int f_lo = (q == 0 && found_lo) ? 1 : 0, f_hi = found_hi ? 1 : 0;
-    decided = (quad_or(f_lo) & quad_or(f_hi)) != 0;
+    decided = (grp_or<L>(f_lo) & grp_or<L>(f_hi)) != 0;
     cl_own = cl;
     ch_own = ch;
 }
 
-template <int R, bool MEDIAN = false>
+template <int L, int R, bool MEDIAN = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void stack_quad_fast_kernel(const PairArgs a) {
-    static_assert(R <= HQ && 4 * R > 2 * HQ && R % 8 == 0, "frame-count class");
+    static_assert((L == 4 || L == 8) && R <= HQ && R > HQ / 2 && R % 8 == 0, "frame-count class");
+    constexpr int PX = 64 / L;  // pixels per wave
     const int lane = threadIdx.x;
-    const int q = lane & 3;
-    const int pix = lane >> 2;
-    // A wave reads 16 pixels = 64 bytes of every plane: HALF a cache line, the other half being the next wave's.  Workgroup ids go
-    // round the eight XCDs (id % 8), so consecutive ids would fetch every line into two XCDs' L2; ids id and id + 8 -- same XCD,
-    // dispatched together -- take neighbouring pixel groups instead (the grid is a multiple of 8).
+    const int q = lane & (L - 1);
+    const int pix = lane / L;
+    // A wave reads 16 (8) pixels = 64 (32) bytes of every plane: a HALF (quarter) of a cache line, the rest being the next waves'.
+    // Workgroup ids go round the eight XCDs (id % 8), so consecutive ids would fetch every line into several XCDs' L2; ids id, id + 8,
+    // ... -- same XCD, dispatched together -- take neighbouring pixel groups instead (the grid is a multiple of 8).
     const unsigned int per_xcd = gridDim.x >> 3;
     const unsigned int group = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-    int64_t g = (int64_t)group * 16 + pix;
+    int64_t g = (int64_t)group * PX + pix;
     const bool valid = g < a.total;
     if (!valid) g = a.total - 1;
 
@@ -276,9 +307,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         full = cnt == have ? 1 : 0;
     }
-    bool defer = quad_sum(full) != 4;
+    bool defer = grp_sum<L>(full) != L;
 
-    // ---- sort: R per lane, two merge levels ----
+    // ---- sort: R per lane, then log2 L merge levels ----
     const float inf = __builtin_inff();
     const float sel1 = (q & 1) ? inf : -inf, sel2 = (q & 2) ? inf : -inf;
     if constexpr (R < HQ)
@@ -286,26 +317,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     else
         SortNet<HQ>::sort_fused(v);
     dpp_fence<HQ>(v);
-    cross_rev<kSwap1>(v, sel1);
+    cross_rev<kSwap1>(v, sel1);  // lanes (0, 1), (2, 3), ...: runs of 256
     bitonic_merge<HQ>(v);
     dpp_fence<HQ>(v);
-    cross_rev<kRev>(v, sel2);
+    cross_rev<kRev>(v, sel2);  // quads: runs of 512
     dpp_fence<HQ>(v);
     cross_same<kSwap1>(v, sel1);
     bitonic_merge<HQ>(v);
     dpp_fence<HQ>(v);
+    if constexpr (L == 8) {  // the two quads: one run of 1024
+        const float sel4 = (q & 4) ? inf : -inf;
+        cross_rev<kHalfMirror>(v, sel4);
+        dpp_fence<HQ>(v);
+        cross_same<kSwap2>(v, sel2);
+        dpp_fence<HQ>(v);
+        cross_same<kSwap1>(v, sel1);
+        bitonic_merge<HQ>(v);
+        dpp_fence<HQ>(v);
+    }
 
     // ---- median / MAD: n / 2 is one number per launch ----
-    constexpr int kMLo = 2 * R - 32 > 128 ? 2 * R - 32 : 128;
+    constexpr int kMHi = L * R / 2, kMLo = kMHi - 8 * L > 32 * L ? kMHi - 8 * L : 32 * L;  // n / 2 over the class's frame counts
     if constexpr (MEDIAN) {  // median_combine_row_major (calibration.rs:84-125): the pixels with a non-finite sample go to the list pass
-        const float m = median_dispatch<kMLo, 2 * R>(v, a.n >> 1);
+        const float m = median_dispatch<L, kMLo, kMHi>(v, lane, a.n >> 1);
         const bool writer = valid && q == 0;
         if (writer && !defer) a.out[g] = m;
         hand_over(a, writer && defer, lane, g);
         return;
     }
     float med, mad;
-    med_mad_dispatch<kMLo, 2 * R>(v, q, (a.n & 1) != 0, a.n >> 1, med, mad);
+    med_mad_dispatch<L, kMLo, kMHi>(v, q, lane, (a.n & 1) != 0, a.n >> 1, med, mad);
 
     // ---- iteration 0: clip about the median with the MAD sigma (combine.rs:37-48,63-82) ----
     const int qt = (a.n - 1) >> 7, t_top = (a.n - 1) & 127;  // rank n - 1: lane qt, register t_top
@@ -319,7 +360,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double c0d = (double)med;
     double e_rem = 0.0, q_rem = 0.0;
     auto apply = [&](bool go, int cl_own, int ch_own, bool decided) {
-        const int cl = quad_sum(cl_own), ch = quad_sum(ch_own);
+        const int cl = grp_sum<L>(cl_own), ch = grp_sum<L>(ch_own);
         if (go && !decided) defer = true;
         const bool take = go && decided;
         const int removed = (cl + ch > len) ? len : (cl + ch);
@@ -337,7 +378,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (go) last_center = med;
         int cl_own, ch_own;
         bool decided;
-        clip_walk<false>(v, q, go, la, lb, qt, ct, med, -a.sigma_low * sigma, a.sigma_high * sigma, c0, c0d, cl_own, ch_own, decided, e_rem, q_rem);
+        clip_walk<L, false>(v, q, go, la, lb, qt, ct, med, -a.sigma_low * sigma, a.sigma_high * sigma, c0, c0d, cl_own, ch_own, decided, e_rem, q_rem);
         apply(go, cl_own, ch_own, decided);
     }
 
@@ -354,15 +395,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             E1 += e;
             Q1 = __builtin_fma(e, e, Q1);
         }
-        E = quad_sum(E1);
-        Q = quad_sum(Q1);
+        E = grp_sum<L>(E1);
+        Q = grp_sum<L>(Q1);
     }
 
     // ---- iterations >= 1: mean / sigma from the running sums (combine.rs:50-82; stack_sigma_clip.hip: clip_fast_tail) ----
     for (uint32_t it = 1; it < a.max_iter; ++it) {
         if (!__any(active)) break;
         launder<HQ>(v);  // stop LICM from hoisting the f32->f64 conversions out of this loop
-        const double er = quad_sum(e_rem), qr = quad_sum(q_rem);
+        const double er = grp_sum<L>(e_rem), qr = grp_sum<L>(q_rem);
         const double nn = (double)len;
         const double sum = __builtin_fma(nn, c0d, E - er);
         const double mean = sum / (double)(len > 0 ? len : 1);
@@ -376,12 +417,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (go) last_center = center;
         int cl_own, ch_own;
         bool decided;
-        clip_walk<true>(v, q, go, la, lb, qt, ct, center, -a.sigma_low * sigma, a.sigma_high * sigma, c0, c0d, cl_own, ch_own, decided, e_rem, q_rem);
+        clip_walk<L, true>(v, q, go, la, lb, qt, ct, center, -a.sigma_low * sigma, a.sigma_high * sigma, c0, c0d, cl_own, ch_own, decided, e_rem, q_rem);
         apply(go, cl_own, ch_own, decided);
     }
 
     // ---- result (combine.rs:85-91) ----
-    const double er = quad_sum(e_rem);
+    const double er = grp_sum<L>(e_rem);
     const double S = __builtin_fma((double)len, c0d, E - er);
     const float mean_f = (float)(S / (double)(len > 0 ? len : 1));
     const float value = len > 0 ? mean_f : (__builtin_isfinite(last_center) ? last_center : 0.0f);
@@ -399,24 +440,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 
 }  // namespace
 
-// the fast pass of a 257 .. 512-frame stack; the arguments' table holds 4 R pointers
-int ab_stack_quad_launch(ab_ctx *ctx, int R, const PairArgs &args) {
-    const dim3 grid((unsigned)(((args.total + 15) / 16 + 7) / 8 * 8)), block(64);  // (a multiple of 8: see the kernel's pixel-group order)
-#define AB_QUAD_CASE(RV)                                                                              \
-    if (R == RV) {                                                                                    \
-        if (args.median_only)                                                                         \
-            hipLaunchKernelGGL((stack_quad_fast_kernel<RV, true>), grid, block, 0, ctx->stream, args); \
-        else                                                                                          \
-            hipLaunchKernelGGL((stack_quad_fast_kernel<RV>), grid, block, 0, ctx->stream, args);       \
-        AB_HIP(ctx, hipGetLastError());                                                               \
-        return AB_OK;                                                                                 \
+// the fast pass of a 257 .. 512-frame (L = 4 lanes per pixel) or 513 .. 1024-frame (L = 8) stack; the arguments' table holds L R pointers
+int ab_stack_quad_launch(ab_ctx *ctx, int L, int R, const PairArgs &args) {
+    const int64_t px = 64 / L;
+    const dim3 grid((unsigned)(((args.total + px - 1) / px + 7) / 8 * 8)), block(64);  // (a multiple of 8: see the kernel's pixel-group order)
+#define AB_QUAD_CASE(LV, RV)                                                                              \
+    if (L == LV && R == RV) {                                                                             \
+        if (args.median_only)                                                                             \
+            hipLaunchKernelGGL((stack_quad_fast_kernel<LV, RV, true>), grid, block, 0, ctx->stream, args); \
+        else                                                                                              \
+            hipLaunchKernelGGL((stack_quad_fast_kernel<LV, RV>), grid, block, 0, ctx->stream, args);       \
+        AB_HIP(ctx, hipGetLastError());                                                                   \
+        return AB_OK;                                                                                     \
     }
-#ifndef AB_QUAD_ONE_CLASS  // (tests/test_abi_cpu.py walks the listing of ONE instance)
-    AB_QUAD_CASE(80)
-    AB_QUAD_CASE(96)
-    AB_QUAD_CASE(128)
+#ifndef AB_QUAD_ONE_CLASS  // (tests/test_abi_cpu.py walks the listing of ONE instance of each lane count)
+    AB_QUAD_CASE(4, 80)
+    AB_QUAD_CASE(4, 96)
+    AB_QUAD_CASE(4, 128)
+    AB_QUAD_CASE(8, 80)
+    AB_QUAD_CASE(8, 96)
+    AB_QUAD_CASE(8, 128)
 #endif
-    AB_QUAD_CASE(112)
+    AB_QUAD_CASE(4, 112)
+    AB_QUAD_CASE(8, 112)
 #undef AB_QUAD_CASE
-    return ab_set_error(ctx, AB_ERR_INVALID, "internal: no four-lane kernel for class %d", R);
+    return ab_set_error(ctx, AB_ERR_INVALID, "internal: no %d-lane kernel for class %d", L, R);
 }

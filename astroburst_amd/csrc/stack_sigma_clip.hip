@@ -1252,9 +1252,11 @@ int ab_stack_device(ab_ctx *ctx, const float *const *dplanes, const int64_t *ld,
         // 513 .. 4096: the wave-per-pixel kernel with 16 / 32 / 64 registers per lane; beyond: one workgroup per pixel, samples
         // in global scratch (stack_deep.hip; a context created under AB_STACK_DEEP_FROM=k sends every stack of more than k >= 64 frames there: the tests do)
         static const bool no_pair = ab_dev_env("AB_STACK_NO_PAIR") != nullptr;
+        static const bool no_octo = ab_dev_env("AB_STACK_NO_OCTO") != nullptr;  // (developer A/B: 513 .. 1024 frames one wave per pixel as before)
         if (n > (size_t)ctx->stack_deep_from)
             AB_TRY(ab_stack_deep_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));
-        else if (duo || (n > 256 && n <= 512 && contig_all && !partial && !no_pair))
+        else if (duo || (n > 256 && n <= 512 && contig_all && !partial && !no_pair) ||
+                 (n > 512 && n <= 1024 && contig_all && !partial && !ctx->stack_exact && !no_octo))  // (eight lanes per pixel: stack_quad.hip)
             AB_TRY(ab_stack_pair_device(ctx, dplanes, n, rows, cols, cfg, out_dev, median_only));
         else
             AB_TRY(ab_stack_wide_device(ctx, dplanes, ld, n, rows, cols, cfg, out_dev, out_sum_dev, out_cnt_dev, median_only));

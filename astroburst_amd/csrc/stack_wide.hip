@@ -323,6 +323,39 @@ __global__ __launch_bounds__(64 * tile_waves<K>()) void stack_wide_tile_kernel(c
     if (lane == 0 && rej_total) atomicAdd(&a.rejected[(blockIdx.x * (unsigned int)kTileWaves + (unsigned int)wv) & (kRejSlots - 1)], rej_total);
 }
 
+// The pixels a multi-lane fast pass (stack_quad.hip, 513 .. 1024 frames) handed over: `slots` lists of up to `cap` pixel indices, one
+// workgroup per list, a wave per pixel, the same wide_pixel (the oracle's ascending sums).  Leaves its list empty.
+template <int K>
+__global__ __launch_bounds__(256) void stack_wide_list_kernel(const WideArgs a, unsigned int *__restrict__ list_count, const int *__restrict__ list,
+                                                              unsigned int cap) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned int cnt = list_count[blockIdx.x];
+    const int *mine = list + (size_t)blockIdx.x * cap;
+    unsigned long long rej_total = 0;
+    for (unsigned int i = (unsigned int)wv; i < cnt; i += 4) {  // wave-uniform pixel
+        const int64_t g = (int64_t)mine[i];
+        float x[K];
+        int fin = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int f = lane + 64 * k;
+            float s = __builtin_inff();
+            if (f < a.n) {
+                const float v = a.p[f][g];
+                if (__builtin_isfinite(v)) {
+                    s = v;
+                    ++fin;
+                }
+            }
+            x[k] = s;
+        }
+        rej_total += wide_pixel<K>(a, g, x, fin, lane);
+    }
+    if (lane == 0 && rej_total) atomicAdd(&a.rejected[(blockIdx.x * 4u + (unsigned int)wv) & (kRejSlots - 1)], rej_total);
+    __syncthreads();  // (every wave has read the count)
+    if (threadIdx.x == 0) list_count[blockIdx.x] = 0;
+}
+
 }  // namespace
 
 // dplanes / ld are HOST arrays of n entries (64 < n <= 512); counters already cleared by the caller
@@ -398,6 +431,31 @@ int ab_stack_wide_device(ab_ctx *ctx, const float *const *dplanes, const int64_t
     } else {
         hipLaunchKernelGGL(stack_wide_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, a);
     }
+    AB_HIP(ctx, hipGetLastError());
+    return AB_OK;
+}
+
+
+// table_dev: DEVICE array of at least n plane pointers (contiguous planes of rows x cols); 2048 lists (stack_pair.hpp: kListSlots)
+int ab_stack_wide_list_device(ab_ctx *ctx, const float *const *table_dev, size_t n, int64_t rows, int64_t cols, const ab_stack_config *cfg, float *out_dev,
+                              bool median_only, unsigned int *list_count, const int *list, unsigned int cap) {
+    AB_CHECK(ctx, n > 512 && n <= 1024, "internal: the list pass of the wave-per-pixel kernel takes 513 .. 1024 frames (got %zu)", n);
+    WideArgs a;
+    a.p = table_dev;
+    a.ld = nullptr;
+    a.n = (int)n;
+    a.contiguous = 1;
+    a.rows = rows;
+    a.cols = cols;
+    a.sigma_low = cfg->sigma_low;
+    a.sigma_high = cfg->sigma_high;
+    a.max_iter = cfg->max_iterations;
+    a.out = out_dev;
+    a.out_sum = nullptr;
+    a.out_cnt = nullptr;
+    a.rejected = ctx->counters;
+    a.median_only = median_only ? 1 : 0;
+    hipLaunchKernelGGL(stack_wide_list_kernel<16>, dim3(2048), dim3(256), 0, ctx->stream, a, list_count, list, cap);
     AB_HIP(ctx, hipGetLastError());
     return AB_OK;
 }

@@ -181,10 +181,11 @@ def clean_frames(n, shape, seed, every=11, rate=0.02):
 
 
 @pytest.mark.parametrize("n", [129, 130, 131, 135, 136, 137, 138, 144, 145, 159, 160, 161, 162, 176, 191, 192, 193, 207, 223, 224, 225, 255, 256,
-                               257, 258, 263, 264, 265, 266, 300, 319, 320, 321, 322, 383, 384, 385, 386, 391, 392, 393, 447, 448, 449, 511, 512])
+                               257, 258, 263, 264, 265, 266, 300, 319, 320, 321, 322, 383, 384, 385, 386, 391, 392, 393, 447, 448, 449, 511, 512,
+                               513, 514, 520, 521, 639, 640, 641, 648, 649, 767, 768, 769, 776, 777, 895, 896, 897, 904, 905, 1000, 1023, 1024])
 def test_two_lane_fast_pass(engine, oracle, n):
     """Round 6: 129 .. 512 frames with every sample finite -- the fast passes csrc/stack_duo.hip (129 .. 256: two
-    lanes per pixel, 128 samples each) and csrc/stack_quad.hip (257 .. 512: four lanes per pixel), frame-count classes of 32 / 64,
+    lanes per pixel, 128 samples each) and csrc/stack_quad.hip (257 .. 512: four lanes per pixel; 513 .. 1024: eight), frame-count classes of 32 / 64,
     the median / MAD instance chosen by n / 2, eight samples per end, running moments -- + stack_pair.hip's list pass for what they
     hand over.  Both sides of every class boundary, odd and even counts, the counts whose top lane holds at most eight samples (the
     high walk goes on into the lane below), a pixel count that leaves the last wave partly filled; settings that clip nothing, a
@@ -204,7 +205,7 @@ def test_two_lane_fast_pass(engine, oracle, n):
     assert np.array_equal(ctx.median_combine(fr), oracle.median_combine(fr), equal_nan=True)
 
 
-@pytest.mark.parametrize("n", [150, 256, 300, 512])
+@pytest.mark.parametrize("n", [150, 256, 300, 512, 700, 1024])
 @pytest.mark.parametrize("sl,sh,it", [(0.0, 0.0, 5), (-1.0, 3.0, 5), (3.0, float("inf"), 5), (float("nan"), 3.0, 2), (3.0, -2.0, 3), (1e-3, 1e30, 40)])
 def test_two_lane_fast_pass_odd_settings(engine, oracle, n, sl, sh, it):
     """the parameter sweep of the <= 64-frame kernels (zero, negative, infinite, NaN kappas, many iterations) on the multi-lane passes:
