@@ -99,22 +99,27 @@ __device__ __forceinline__ float bicubic_sample(const float *__restrict__ src, i
 }
 
 // Which piece of which row a workgroup takes.  The hardware hands workgroup ids round the eight XCDs (id % 8), and a piece needs four
-// source rows of which the piece below shares three.  With the pieces in row-major id order neighbouring rows land in different
-// XCDs' L2 whenever a row is not a multiple of 8 pieces wide (4096 columns in 512-pixel pieces are; 12 451 are not: every source row
-// was fetched into up to four L2s).  So the row-major sequence of pieces is cut into eight contiguous runs and XCD c walks run c:
-// a band of rows.  (A bijection: XCD j receives ids j, j + 8, ...: (total - j + 7) / 8 of them.)
+// source rows of which the piece below shares three.  When a row is a multiple of 8 pieces wide (4096 columns in 512-pixel pieces)
+// the row-major ids are XCD-coherent by themselves -- every XCD walks down one column strip -- and nothing is done.  Otherwise
+// (12 451 columns = 25 pieces) the piece below lands in another XCD's L2 and every source row is fetched into up to four of them:
+// the row-major sequence of pieces is then cut into eight contiguous runs and XCD c walks run c, a band of rows (a bijection: XCD j
+// receives ids j, j + 8, ...: (total - j + 7) / 8 of them).  Measured, interleaved on one box (profiles/r06_warp_xcd_bands.txt): C3
+// 22.8 / 23.4 / 23.5 ms per step against 23.6 / 23.8 / 23.6 in id order.  Applied to the 8-pieces-wide bench step as well it cost 0.1 ms
+// (the index arithmetic is ~5 % of this kernel's workgroup, and eight XCDs reading rows 512 apart meet in the same memory channels);
+// column-major runs -- the 8-wide order generalised -- gained nothing on C3.
 __device__ __forceinline__ void xcd_band_piece(unsigned int &piece_x, unsigned int &piece_y) {
-#ifndef AB_WARP_ROW_MAJOR
-    const unsigned int gx = gridDim.x, total = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
-    const unsigned int c = id & 7u, k = id >> 3;
-    unsigned int start = 0;
-    for (unsigned int j = 0; j < c; ++j) start += (total - j + 7u) >> 3;
-    const unsigned int t = start + k;
-    piece_y = t / gx;
-    piece_x = t - piece_y * gx;
-#else
     piece_x = blockIdx.x;
     piece_y = blockIdx.y;
+#ifndef AB_WARP_ROW_MAJOR
+    if ((gridDim.x & 7u) != 0) {  // (uniform)
+        const unsigned int gx = gridDim.x, total = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+        const unsigned int c = id & 7u, k = id >> 3;
+        unsigned int start = 0;
+        for (unsigned int j = 0; j < c; ++j) start += (total - j + 7u) >> 3;
+        const unsigned int t = start + k;
+        piece_y = t / gx;
+        piece_x = t - piece_y * gx;
+    }
 #endif
 }
 
