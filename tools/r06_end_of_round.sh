@@ -3,7 +3,7 @@
 # configurations, the multi-rank code paths
 mkdir -p gpurun_out
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r06z_tests.log 2>&1; echo "tests rc=$?" > gpurun_out/r06z_rc.txt; tail -3 gpurun_out/r06z_tests.log
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r06z_tests.log 2>&1; echo "tests rc=$?" > gpurun_out/r06z_rc.txt; tail -3 gpurun_out/r06z_tests.log
 bash tools/profile_bench.sh r06final 7 > gpurun_out/r06final_profile.log 2>&1; tail -3 gpurun_out/r06final_profile.log
 timeout 600 python bench.py > gpurun_out/r06z_bench.json 2> gpurun_out/r06z_bench.err; echo "bench rc=$?" >> gpurun_out/r06z_rc.txt
 for c in C1 C3 C5; do
