@@ -242,6 +242,31 @@ def test_no_dpp_reads_a_register_inside_its_write_hazard_window(tmp_path):
         assert ndpp > 500 and not viol, (name, ndpp, viol[:5])
 
 
+def test_the_deepest_sort_network_stays_in_registers(tmp_path):
+    """Round 6: wave_sort.hpp's bitonic network over 64 registers per lane (2049 .. 4096 frames) is ~20 000 instructions fully unrolled --
+    above the default size limit of `#pragma unroll`.  Left to that limit it stays a loop, indexes its registers at run time, and the two
+    sort arrays of stack_wide.hip's kernels live in scratch memory (2100 x 1024^2: 590 ms instead of 89).  The Makefile raises the limit
+    for that file; this test compiles it with the Makefile's flags and reads the kernels' metadata: no scratch, no spills."""
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, "astroburst_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    flags = re.search(r"^FLAGS_stack_wide\s*:=\s*(.+)$", mk, flags=re.M).group(1).split()
+    assert "-pragma-unroll-threshold=1000000" in flags, flags
+    base = re.search(r"^CXXFLAGS\s*\?=\s*(.+)$", mk, flags=re.M).group(1).split()
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", *base, "-w", *flags, "--save-temps", "-c", os.path.join(csrc, "stack_wide.hip"), "-o",
+                    os.path.join(tmp_path, "stack_wide.o")], cwd=tmp_path, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lst = open(os.path.join(tmp_path, "stack_wide-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+    seen = 0
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.vgpr_spill_count:\s+(\d+)", lst, re.S):
+        if "stack_wide" not in m.group(1):
+            continue
+        seen += 1
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", m.group(2)).group(1))
+        assert scratch == 0 and int(m.group(3)) == 0, (m.group(1), scratch, m.group(3))
+    assert seen >= 10, seen
+
+
 def test_the_release_library_reads_the_documented_environment_variables_only():
     """`ship one code path`.  (i) no raw getenv in csrc/ outside the two helpers of ab_common.hpp; (ii) the names
     given to ab_env() -- the release library's -- are exactly the eight the header's "Environment" section and INTEGRATION.md list;
