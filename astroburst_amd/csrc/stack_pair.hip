@@ -386,8 +386,10 @@ int ab_stack_pair_device(ab_ctx *ctx, const float *const *dplanes, size_t n, int
     a.list_ticket = a.list_count + kListSlots;
     a.list = (int *)(lw + (size_t)2 * kListSlots * sizeof(unsigned int));
     a.list_cap = cap;
-    // the list pass leaves every counter at zero again, so only a fresh workspace needs clearing
-    if (lw != before) AB_HIP(ctx, hipMemsetAsync(a.list_count, 0, 2 * kListSlots * sizeof(unsigned int), ctx->stream));
+    // (the list pass leaves every counter at zero again, but a call that failed between the two passes would not have: 16 KB, in
+    // stream order, in front of a kernel of milliseconds)
+    (void)before;
+    AB_HIP(ctx, hipMemsetAsync(a.list_count, 0, 2 * kListSlots * sizeof(unsigned int), ctx->stream));
     PairArgs f = a;
     f.p = (const float *const *)ws;
     f.half = R;
